@@ -1,0 +1,62 @@
+"""Seeded synthetic inputs shared by tests/golden/make_golden.py and the tests.
+
+np.random.RandomState is numpy's frozen legacy generator, so these streams are reproducible
+across numpy versions; every fixture also stores a SHA-1 of the inputs it was generated from
+and the tests compare it before trusting the fixture.
+
+Shapes follow SURVEY.md section 8(d).
+"""
+import numpy as np
+
+
+def gmm_unit(n, d, n_comp, seed, dtype, sigma=0.35, nonneg=False):
+    """n unit-norm d-vectors from an n_comp-component isotropic Gaussian mixture (so that
+    nearest neighbours are meaningful); nonneg=True mimics post-ReLU CNN features."""
+    rs = np.random.RandomState(seed)
+    centers = rs.randn(n_comp, d)
+    comp = rs.randint(0, n_comp, size=n)
+    x = centers[comp] + sigma * rs.randn(n, d)
+    if nonneg:
+        np.maximum(x, 0.0, out=x)
+    x /= np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-12)
+    return x.astype(dtype)
+
+
+def perturbed_queries(X, nq, seed, eps=0.05):
+    rs = np.random.RandomState(seed)
+    idx = rs.choice(X.shape[0], nq, replace=False)
+    q = X[idx].astype(np.float64) + eps * rs.randn(nq, X.shape[1]) / np.sqrt(X.shape[1])
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q.astype(X.dtype), idx
+
+
+def c1_inputs():
+    rs = np.random.RandomState(1234)
+    X = rs.randn(100000, 128).astype(np.float32)
+    Q = rs.randn(100, 128).astype(np.float32)
+    return X, Q
+
+
+def c2_inputs():
+    X = gmm_unit(50000, 128, 256, 2, np.float64)
+    Q, _ = perturbed_queries(X, 64, 22)
+    return X, Q
+
+
+def c3_inputs():
+    X = gmm_unit(20000, 320, 128, 3, np.float32, nonneg=True)
+    Q, _ = perturbed_queries(X, 32, 33)
+    return X, Q
+
+
+def c3b_inputs():
+    X = gmm_unit(8000, 288, 64, 5, np.float32, nonneg=True)
+    Q, _ = perturbed_queries(X, 16, 55)
+    return X, Q
+
+
+def tiny_inputs():
+    rs = np.random.RandomState(7)
+    X = rs.randn(4000, 8)  # float64 -> float64 coarse centroids
+    Q = rs.randn(12, 8)
+    return X, Q
