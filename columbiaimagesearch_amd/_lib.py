@@ -1,0 +1,139 @@
+"""ctypes binding of libcis_hip.so (the C ABI declared in include/cis_hip.h).
+
+There is no CPU fallback: if the library is missing, or no MI355X is visible when a compute entry
+point is called, the failure is raised to the caller.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_uint16, c_uint32, c_void_p
+
+import numpy as np
+
+CIS_F32, CIS_F64 = 4, 8
+CIS_OK, CIS_EINVAL, CIS_EHIP, CIS_ENOMEM, CIS_EUNSUPPORTED, CIS_ENODEVICE = 0, -1, -2, -3, -4, -5
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcis_hip.so")
+
+
+class cis_hit(ctypes.Structure):
+    _fields_ = [("dist", c_double), ("visit_rank", c_uint32), ("pos", c_uint32), ("id", c_int64),
+                ("cell", c_int32), ("reserved", c_int32)]
+
+
+HIT_DTYPE = np.dtype([("dist", "<f8"), ("visit_rank", "<u4"), ("pos", "<u4"), ("id", "<i8"),
+                      ("cell", "<i4"), ("reserved", "<i4")])
+assert HIT_DTYPE.itemsize == ctypes.sizeof(cis_hit) == 32
+
+
+class HipError(RuntimeError):
+    """A HIP runtime call inside libcis_hip.so failed (or no gfx950 device is visible)."""
+
+
+_PROTOS = {
+    # name: (restype, argtypes)
+    "cis_version": (c_int, []),
+    "cis_last_error": (c_char_p, []),
+    "cis_device_count": (c_int, []),
+    "cis_set_device": (c_int, [c_int]),
+    "cis_model_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "cis_model_destroy": (None, [c_void_p]),
+    "cis_apply_pca": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "cis_encode": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "cis_encode_dev": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    "cis_predict_coarse": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "cis_project": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "cis_predict_fine": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "cis_subquantizer_distances": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "cis_reconstruct": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "cis_index_create": (c_int, [POINTER(c_void_p), c_void_p]),
+    "cis_index_destroy": (None, [c_void_p]),
+    "cis_index_set_shard": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "cis_index_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(c_int64)]),
+    "cis_index_size": (c_int64, [c_void_p]),
+    "cis_index_get_cell": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, POINTER(c_int64)]),
+    "cis_index_get_codes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "cis_index_search": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p]),
+    "cis_index_search_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cis_index_search_partial_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p,
+                                             c_void_p]),
+    "cis_merge_hits_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
+    "cis_index_last_stats": (c_int, [c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names declared in include/cis_hip.h (kept in sync by tests/test_abi.py)."""
+    return sorted(_PROTOS)
+
+
+def lib():
+    """Load libcis_hip.so once.  Raises ImportError with build instructions if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C columbiaimagesearch_amd/csrc`). columbiaimagesearch_amd has no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().cis_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Translate a C return code into the exception kinds the reference raises."""
+    if rc == CIS_OK:
+        return
+    msg = last_error()
+    if rc == CIS_EINVAL:
+        raise ValueError(msg)
+    if rc == CIS_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == CIS_ENOMEM:
+        raise MemoryError(msg)
+    raise HipError(msg)
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_void_p)
+
+
+def dtype_code(a):
+    if a.dtype == np.float32:
+        return CIS_F32
+    if a.dtype == np.float64:
+        return CIS_F64
+    raise ValueError("only float32 / float64 vectors are supported, got %s" % a.dtype)
+
+
+def as_float_matrix(x, cols=None):
+    """C-contiguous float32/float64 2-D view of x (other dtypes are promoted to float64, as numpy
+    would when the reference subtracts float64 parameters from them)."""
+    a = np.asarray(x)
+    if a.dtype != np.float32 and a.dtype != np.float64:
+        a = a.astype(np.float64)
+    if a.ndim == 1:
+        a = a[None, :]
+    if a.ndim != 2:
+        raise ValueError("expected a vector or a matrix of vectors, got shape %r" % (a.shape,))
+    if cols is not None and a.shape[1] != cols:
+        raise ValueError("expected vectors of dimension %d, got %d" % (cols, a.shape[1]))
+    return np.ascontiguousarray(a)

@@ -1,0 +1,755 @@
+// LOPQ model on MI355X: PCA projection, coarse assignment, local rotation, fine encoding.
+//
+// Replaces the arithmetic of lopq/lopq/model.py (predict :543-561/:980-1003, apply_PCA :961-978,
+// predict_coarse :563-573, project :604-641, predict_fine :575-602, reconstruct :643-671) and
+// lopq/lopq/utils.py:33-53 (predict_cluster) for whole batches.
+//
+// Exactness rules (SURVEY.md section 7 "hard parts"):
+//  * every squared distance that feeds an argmin is computed as the reference does: (x - c)
+//    rounded, squared rounded, summed in numpy's pairwise order (common.h), in float32 when both
+//    operands are float32 and float64 otherwise; argmin takes the first minimum.  Compiled with
+//    -ffp-contract=off so nothing is fused behind our back;
+//  * the rotation R[c].(r - mu[c]) and the PCA product are float64 dot products whose summation
+//    order inside BLAS is unspecified in the reference; here they are k-ascending fma chains.
+#include <stdarg.h>
+
+#include <mutex>
+
+#include "lopq_model.h"
+
+// ================================================================================================
+// library plumbing
+// ================================================================================================
+static thread_local std::string g_err;
+static int g_device = 0;
+static bool g_inited = false;
+static std::mutex g_init_mu;
+
+void cis_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+extern "C" const char* cis_last_error(void) { return g_err.c_str(); }
+extern "C" int cis_version(void) { return 100; }
+
+extern "C" int cis_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int cis_set_device(int device) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    g_device = device;
+    g_inited = false;
+    return CIS_OK;
+}
+
+int cis_current_device() { return g_device; }
+
+int cis_lazy_init() {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        cis_set_error("no HIP device visible: libcis_hip.so needs an MI355X (gfx950); there is no CPU fallback");
+        return CIS_ENODEVICE;
+    }
+    if (g_device < 0 || g_device >= n) {
+        cis_set_error("device %d out of range (%d visible)", g_device, n);
+        return CIS_EINVAL;
+    }
+    CIS_CHECK_HIP(hipSetDevice(g_device));
+    if (!g_inited) {
+        hipDeviceProp_t p;
+        CIS_CHECK_HIP(hipGetDeviceProperties(&p, g_device));
+        if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+            cis_set_error("device %d is %s; this library is built for gfx950 only", g_device, p.gcnArchName);
+            return CIS_ENODEVICE;
+        }
+        g_inited = true;
+    }
+    return CIS_OK;
+}
+
+static void pw_rec(int lo, int n, PwProg* P, bool* ok) {
+    if (n <= 128) {
+        if (P->n_leaves >= CIS_PW_MAX_LEAVES) {
+            *ok = false;
+            return;
+        }
+        P->leaf_start[P->n_leaves] = (int16_t)lo;
+        P->leaf_len[P->n_leaves] = (int16_t)n;
+        P->ops[P->n_ops++] = (int8_t)P->n_leaves;
+        P->n_leaves++;
+        return;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    pw_rec(lo, n2, P, ok);
+    if (!*ok) return;
+    pw_rec(lo + n2, n - n2, P, ok);
+    if (!*ok) return;
+    P->ops[P->n_ops++] = -1;
+}
+
+int cis_build_pwprog(int n, PwProg* out) {
+    memset(out, 0, sizeof(*out));
+    out->n = n;
+    bool ok = true;
+    pw_rec(0, n, out, &ok);
+    if (!ok || n > 32000) {
+        cis_set_error("vector length %d needs more than %d summation leaves", n, CIS_PW_MAX_LEAVES);
+        return CIS_EUNSUPPORTED;
+    }
+    return CIS_OK;
+}
+
+// ================================================================================================
+// kernels
+// ================================================================================================
+template <typename TI>
+__global__ void k_to_f64(const TI* __restrict__ in, double* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (double)in[i];
+}
+
+// Y[n][D] = (X - mu) . P, float64, 64x64 tile per 256-thread block, 4x4 outputs per thread.
+template <typename TX>
+__global__ __launch_bounds__(256) void k_pca_gemm(const TX* __restrict__ X, const double* __restrict__ mu,
+                                                  const double* __restrict__ P, double* __restrict__ Y,
+                                                  int64_t n, int D_in, int D) {
+    __shared__ double sA[16][64 + 1];  // [k][row]
+    __shared__ double sB[16][64];      // [k][col]
+    const int tid = threadIdx.x;
+    const int tr = tid / 16, tc = tid % 16;  // thread micro-tile origin: rows tr*4.., cols tc*4..
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int col0 = blockIdx.y * 64;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int k0 = 0; k0 < D_in; k0 += 16) {
+        // stage A: 64 rows x 16 k  (1024 elements, 4 per thread)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            const int r = idx / 16, k = idx % 16;
+            double v = 0.0;
+            if (row0 + r < n && k0 + k < D_in) v = (double)X[(row0 + r) * D_in + k0 + k] - mu[k0 + k];
+            sA[k][r] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            const int k = idx / 64, c = idx % 64;
+            double v = 0.0;
+            if (k0 + k < D_in && col0 + c < D) v = P[(int64_t)(k0 + k) * D + col0 + c];
+            sB[k][c] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = sA[k][tr * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = sB[k][tc * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t r = row0 + tr * 4 + i;
+        if (r >= n) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = col0 + tc * 4 + j;
+            if (c < D) Y[r * D + c] = acc[i][j];
+        }
+    }
+}
+
+// Row L2 renormalisation (numpy: sqrt(add.reduce(y*y, axis=1)), then y / norm) and float32 cast.
+// One 64-lane wave per row would break the summation order, so each thread owns a row.
+__global__ void k_pca_finish(const double* __restrict__ Y, float* __restrict__ out, int64_t n, int D,
+                             int renorm, PwProg prog) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const double* y = Y + r * D;
+    double nrm = 1.0;
+    if (renorm) {
+        auto sq = [&](int i) -> double { const double v = y[i]; return v * v; };
+        nrm = sqrt(pw_sum<double>(prog, sq));
+    }
+    for (int i = 0; i < D; ++i) out[r * D + i] = (float)(renorm ? (y[i] / nrm) : y[i]);
+}
+
+// out[r][c] = sum_i (X[r][xoff+i] - C[c][i])^2 in numpy's order; 16 rows x 16 centroids / block.
+template <typename T>
+__global__ __launch_bounds__(256) void k_sqdist_rows(const T* __restrict__ X, int64_t ldx, int xoff,
+                                                     const T* __restrict__ C, int64_t n, int ncent, int d,
+                                                     T* __restrict__ out, PwProg prog) {
+    const int c = blockIdx.y * 16 + (threadIdx.x % 16);
+    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x / 16);
+    if (r >= n || c >= ncent) return;
+    const T* x = X + r * ldx + xoff;
+    const T* cc = C + (int64_t)c * d;
+    auto elem = [&](int i) -> T { const T df = x[i] - cc[i]; return df * df; };
+    out[r * ncent + c] = pw_sum<T>(prog, elem);
+}
+
+// First-minimum argmin over each row (numpy argmin tie rule).
+template <typename T, typename TO>
+__global__ void k_argmin_rows(const T* __restrict__ dist, int64_t n, int ncent, TO* __restrict__ out,
+                              int ostride, int ooff) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const T* d = dist + r * ncent;
+    T best = d[0];
+    int bi = 0;
+    for (int c = 1; c < ncent; ++c) {
+        const T v = d[c];
+        if (v < best) { best = v; bi = c; }
+    }
+    out[r * ostride + ooff] = (TO)bi;
+}
+
+// ---- grouping rows by coarse cluster so that a tile of 64 vectors shares one rotation ----------
+struct ProjTile { int split, cluster, start, count; };
+
+__global__ void k_group_hist(const uint16_t* __restrict__ coarse, int64_t n, int V, int* __restrict__ counts) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    atomicAdd(&counts[coarse[r * 2 + 0]], 1);
+    atomicAdd(&counts[V + coarse[r * 2 + 1]], 1);
+}
+
+// single block: exclusive scans over the 2V (split, cluster) bins; emits the tile descriptors.
+__global__ void k_group_scan(const int* __restrict__ counts, int V, int* __restrict__ offsets,
+                             int* __restrict__ cursor, ProjTile* __restrict__ tiles, int* __restrict__ n_tiles,
+                             int tile_rows) {
+    if (threadIdx.x != 0) return;
+    int nt = 0;
+    for (int s = 0; s < 2; ++s) {
+        int off = 0;
+        for (int c = 0; c < V; ++c) {
+            const int cnt = counts[s * V + c];
+            offsets[s * V + c] = off;
+            cursor[s * V + c] = 0;
+            for (int t = 0; t < cnt; t += tile_rows) {
+                ProjTile pt;
+                pt.split = s; pt.cluster = c; pt.start = off + t;
+                pt.count = (cnt - t < tile_rows) ? (cnt - t) : tile_rows;
+                tiles[nt++] = pt;
+            }
+            off += cnt;
+        }
+    }
+    *n_tiles = nt;
+}
+
+__global__ void k_group_scatter(const uint16_t* __restrict__ coarse, int64_t n, int V,
+                                const int* __restrict__ offsets, int* __restrict__ cursor,
+                                int* __restrict__ perm /* [2][n] */) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    for (int s = 0; s < 2; ++s) {
+        const int c = coarse[r * 2 + s];
+        const int p = offsets[s * V + c] + atomicAdd(&cursor[s * V + c], 1);
+        perm[(int64_t)s * n + p] = (int)r;
+    }
+}
+
+// out[row][s*h + i] = sum_k R[s][c][i][k] * ((double)(x[row][s*h+k] - C[s][c][k]) - mu[s][c][k])
+// for a tile of <= 64 rows of one (split, cluster); grid.y tiles the h outputs by 64.
+template <typename CT>
+__global__ __launch_bounds__(256) void k_project_tiles(const CT* __restrict__ X, const CT* __restrict__ Cs,
+                                                       const double* __restrict__ Rt, const double* __restrict__ mus,
+                                                       const ProjTile* __restrict__ tiles, const int* __restrict__ n_tiles,
+                                                       const int* __restrict__ perm, int64_t n, int V, int h, int D,
+                                                       double* __restrict__ out) {
+    if ((int)blockIdx.x >= *n_tiles) return;
+    const ProjTile pt = tiles[blockIdx.x];
+    __shared__ double sA[16][64 + 1];  // [k][vec]
+    __shared__ double sB[16][64];      // [k][i]
+    __shared__ int srow[64];
+    const int tid = threadIdx.x;
+    const int tr = tid / 16, tc = tid % 16;
+    const int i0 = blockIdx.y * 64;
+    if (tid < 64) srow[tid] = (tid < pt.count) ? perm[(int64_t)pt.split * n + pt.start + tid] : -1;
+    __syncthreads();
+    const CT* Cc = Cs + ((int64_t)pt.split * V + pt.cluster) * h;
+    const double* mu = mus + ((int64_t)pt.split * V + pt.cluster) * h;
+    const double* R = Rt + ((int64_t)pt.split * V + pt.cluster) * h * h;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int k0 = 0; k0 < h; k0 += 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            const int v = idx / 16, k = idx % 16;
+            double val = 0.0;
+            const int row = srow[v];
+            if (row >= 0 && k0 + k < h) {
+                const CT res = X[(int64_t)row * D + pt.split * h + k0 + k] - Cc[k0 + k];  // rounds in CT
+                val = (double)res - mu[k0 + k];
+            }
+            sA[k][v] = val;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            const int k = idx / 64, i = idx % 64;
+            double val = 0.0;
+            if (k0 + k < h && i0 + i < h) val = R[(int64_t)(k0 + k) * h + i0 + i];
+            sB[k][i] = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = sA[k][tr * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = sB[k][tc * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = srow[tr * 4 + i];
+        if (row < 0) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = i0 + tc * 4 + j;
+            if (col < h) out[(int64_t)row * D + pt.split * h + col] = acc[i][j];
+        }
+    }
+}
+
+// reconstruct: x[s*h + k] = (sum_i R[c][i][k] * sx[i] + mu[c][k]) + C[c][k]   (model.py:662-669)
+__global__ void k_reconstruct(const uint16_t* __restrict__ coarse, const uint8_t* __restrict__ fine,
+                              const double* __restrict__ Rs, const double* __restrict__ mus,
+                              const double* __restrict__ Cs64, const double* __restrict__ subs, int64_t n, int V,
+                              int M, int K, int h, int w, double* __restrict__ out) {
+    const int64_t item = blockIdx.x;
+    const int s = blockIdx.y;
+    const int nf = M / 2;
+    const int c = coarse[item * 2 + s];
+    const double* R = Rs + ((int64_t)s * V + c) * h * h;
+    for (int k = threadIdx.x; k < h; k += blockDim.x) {
+        double acc = 0.0;
+        for (int i = 0; i < h; ++i) {
+            const int j = i / w;
+            const int f = fine[item * M + s * nf + j];
+            const double sx = subs[((int64_t)(s * nf + j) * K + f) * w + (i % w)];
+            acc = fma(R[(int64_t)i * h + k], sx, acc);
+        }
+        const double r = acc + mus[((int64_t)s * V + c) * h + k];
+        out[item * (2 * h) + s * h + k] = r + Cs64[((int64_t)s * V + c) * h + k];
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+template <typename T>
+static int upload(T** dst, const T* src, size_t count) {
+    CIS_CHECK_HIP(hipMalloc((void**)dst, count * sizeof(T)));
+    CIS_CHECK_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return CIS_OK;
+}
+
+extern "C" void cis_model_destroy(cis_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    void* ptrs[] = {m->d_Cs32, m->d_Cs64, m->d_Rs, m->d_Rt, m->d_mus, m->d_subs, m->d_P, m->d_pmu};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    DevBuf* bufs[] = {&m->ws_xp, &m->ws_x64, &m->ws_y64, &m->ws_dist, &m->ws_proj, &m->ws_group,
+                      &m->ws_in, &m->ws_out0, &m->ws_out1};
+    for (DevBuf* b : bufs) b->release();
+    delete m;
+}
+
+extern "C" int cis_model_create(cis_model** out, int D_in, int D, int V, int M, int K, int coarse_dtype,
+                                const void* Cs, const double* Rs, const double* mus, const double* subs,
+                                const double* pca_P, const double* pca_mu, int renorm) {
+    CIS_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    CIS_REQUIRE(Cs && Rs && mus && subs, "model parameters must not be NULL (fit the model first)");
+    CIS_REQUIRE(D > 0 && D % 2 == 0, "D=%d must be a positive even number", D);
+    CIS_REQUIRE(M >= 2 && M % 2 == 0 && D % M == 0, "M=%d must be even and divide D=%d", M, D);
+    CIS_REQUIRE(V >= 1 && K >= 1, "V and K must be positive");
+    CIS_REQUIRE(coarse_dtype == CIS_F32 || coarse_dtype == CIS_F64, "coarse_dtype must be 4 or 8");
+    CIS_REQUIRE((pca_P == nullptr) == (pca_mu == nullptr), "pca_P and pca_mu must both be given or both NULL");
+    CIS_REQUIRE(pca_P != nullptr || D_in == D, "without PCA D_in (%d) must equal D (%d)", D_in, D);
+    if (K > 256 || V > 4096) {
+        cis_set_error("K=%d > 256 or V=%d > 4096 is not supported by this build", K, V);
+        return CIS_EUNSUPPORTED;
+    }
+    CIS_TRY(cis_lazy_init());
+    cis_model* m = new cis_model();
+    m->device = cis_current_device();
+    m->D_in = D_in; m->D = D; m->V = V; m->M = M; m->K = K;
+    m->h = D / 2; m->w = D / M; m->nf = M / 2;
+    m->coarse_f32 = (coarse_dtype == CIS_F32);
+    m->has_pca = (pca_P != nullptr);
+    m->renorm = renorm != 0;
+    int rc = CIS_OK;
+    auto fail = [&](int r) { cis_model_destroy(m); return r; };
+    if ((rc = cis_build_pwprog(m->h, &m->prog_h)) != CIS_OK) return fail(rc);
+    if ((rc = cis_build_pwprog(m->w, &m->prog_w)) != CIS_OK) return fail(rc);
+    if ((rc = cis_build_pwprog(m->D, &m->prog_D)) != CIS_OK) return fail(rc);
+    const size_t nC = (size_t)2 * V * m->h;
+    std::vector<double> c64(nC);
+    if (m->coarse_f32) {
+        const float* c = (const float*)Cs;
+        for (size_t i = 0; i < nC; ++i) c64[i] = (double)c[i];
+        if ((rc = upload(&m->d_Cs32, c, nC)) != CIS_OK) return fail(rc);
+    } else {
+        memcpy(c64.data(), Cs, nC * sizeof(double));
+    }
+    if ((rc = upload(&m->d_Cs64, c64.data(), nC)) != CIS_OK) return fail(rc);
+    const size_t nR = (size_t)2 * V * m->h * m->h;
+    if ((rc = upload(&m->d_Rs, Rs, nR)) != CIS_OK) return fail(rc);
+    {
+        std::vector<double> rt(nR);
+        const size_t hh = (size_t)m->h * m->h;
+        for (size_t c = 0; c < (size_t)2 * V; ++c)
+            for (int i = 0; i < m->h; ++i)
+                for (int k = 0; k < m->h; ++k) rt[c * hh + (size_t)k * m->h + i] = Rs[c * hh + (size_t)i * m->h + k];
+        if ((rc = upload(&m->d_Rt, rt.data(), nR)) != CIS_OK) return fail(rc);
+    }
+    if ((rc = upload(&m->d_mus, mus, nC)) != CIS_OK) return fail(rc);
+    if ((rc = upload(&m->d_subs, subs, (size_t)M * K * m->w)) != CIS_OK) return fail(rc);
+    if (m->has_pca) {
+        if ((rc = upload(&m->d_P, pca_P, (size_t)D_in * D)) != CIS_OK) return fail(rc);
+        if ((rc = upload(&m->d_pmu, pca_mu, (size_t)D_in)) != CIS_OK) return fail(rc);
+    }
+    *out = m;
+    return CIS_OK;
+}
+
+static inline int grid1(int64_t n, int bs) { return (int)ceil_div(n, bs); }
+
+int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, float* d_out, hipStream_t st) {
+    CIS_REQUIRE(m->has_pca, "model has no PCA parameters");
+    if (n == 0) return CIS_OK;
+    CIS_TRY(m->ws_y64.reserve((size_t)n * m->D * sizeof(double)));
+    double* Y = m->ws_y64.as<double>();
+    dim3 g((unsigned)ceil_div(n, 64), (unsigned)ceil_div(m->D, 64));
+    if (x_dtype == CIS_F32)
+        hipLaunchKernelGGL(k_pca_gemm<float>, g, dim3(256), 0, st, (const float*)dX, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);
+    else
+        hipLaunchKernelGGL(k_pca_gemm<double>, g, dim3(256), 0, st, (const double*)dX, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);
+    hipLaunchKernelGGL(k_pca_finish, dim3(grid1(n, 64)), dim3(64), 0, st, Y, d_out, n, m->D, m->renorm ? 1 : 0, m->prog_D);
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
+}
+
+int cis_dev_coarse_type(cis_model* m, const void* d_xp, int xp_dtype, int64_t n, const void** xc, int* ct,
+                        hipStream_t st) {
+    if (xp_dtype == CIS_F32 && m->coarse_f32) {
+        *xc = d_xp;
+        *ct = CIS_F32;
+        return CIS_OK;
+    }
+    *ct = CIS_F64;
+    if (xp_dtype == CIS_F64) {
+        *xc = d_xp;
+        return CIS_OK;
+    }
+    CIS_TRY(m->ws_x64.reserve((size_t)n * m->D * sizeof(double)));
+    if (n > 0)
+        hipLaunchKernelGGL(k_to_f64<float>, dim3(2048), dim3(256), 0, st, (const float*)d_xp, m->ws_x64.as<double>(),
+                           n * m->D);
+    *xc = m->ws_x64.p;
+    return CIS_OK;
+}
+
+int cis_launch_sqdist(cis_model* m, const void* xc, int ct, int64_t n, int split, void* out, hipStream_t st) {
+    if (n == 0) return CIS_OK;
+    dim3 g((unsigned)ceil_div(n, 16), (unsigned)ceil_div(m->V, 16));
+    if (ct == CIS_F32)
+        hipLaunchKernelGGL(k_sqdist_rows<float>, g, dim3(256), 0, st, (const float*)xc, (int64_t)m->D, split * m->h,
+                           m->d_Cs32 + (size_t)split * m->V * m->h, n, m->V, m->h, (float*)out, m->prog_h);
+    else
+        hipLaunchKernelGGL(k_sqdist_rows<double>, g, dim3(256), 0, st, (const double*)xc, (int64_t)m->D, split * m->h,
+                           m->d_Cs64 + (size_t)split * m->V * m->h, n, m->V, m->h, (double*)out, m->prog_h);
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
+}
+
+// coarse ids of n LOPQ-space vectors (already in compute type ct) -> d_coarse [n][2]
+static int dev_predict_coarse(cis_model* m, const void* xc, int ct, int64_t n, uint16_t* d_coarse, hipStream_t st) {
+    if (n == 0) return CIS_OK;
+    CIS_TRY(m->ws_dist.reserve((size_t)n * (m->V > m->K ? m->V : m->K) * sizeof(double)));
+    dim3 g((unsigned)ceil_div(n, 16), (unsigned)ceil_div(m->V, 16));
+    for (int s = 0; s < 2; ++s) {
+        if (ct == CIS_F32) {
+            float* dist = m->ws_dist.as<float>();
+            hipLaunchKernelGGL(k_sqdist_rows<float>, g, dim3(256), 0, st, (const float*)xc, (int64_t)m->D, s * m->h,
+                               m->d_Cs32 + (size_t)s * m->V * m->h, n, m->V, m->h, dist, m->prog_h);
+            hipLaunchKernelGGL((k_argmin_rows<float, uint16_t>), dim3(grid1(n, 256)), dim3(256), 0, st, dist, n, m->V,
+                               d_coarse, 2, s);
+        } else {
+            double* dist = m->ws_dist.as<double>();
+            hipLaunchKernelGGL(k_sqdist_rows<double>, g, dim3(256), 0, st, (const double*)xc, (int64_t)m->D, s * m->h,
+                               m->d_Cs64 + (size_t)s * m->V * m->h, n, m->V, m->h, dist, m->prog_h);
+            hipLaunchKernelGGL((k_argmin_rows<double, uint16_t>), dim3(grid1(n, 256)), dim3(256), 0, st, dist, n, m->V,
+                               d_coarse, 2, s);
+        }
+    }
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
+}
+
+// local projection of n vectors given their coarse ids -> d_proj [n][D] float64
+static int dev_project(cis_model* m, const void* xc, int ct, int64_t n, const uint16_t* d_coarse, double* d_proj,
+                       hipStream_t st) {
+    if (n == 0) return CIS_OK;
+    CIS_REQUIRE(n < (int64_t)1 << 30, "batch too large for one projection pass");
+    const int V = m->V;
+    const int64_t max_tiles = 2 * (ceil_div(n, 64) + V);
+    // layout of ws_group: counts[2V] offsets[2V] cursor[2V] n_tiles[1] pad | perm[2n] | tiles[max_tiles]
+    const size_t ints = (size_t)6 * V + 4 + (size_t)2 * n;
+    CIS_TRY(m->ws_group.reserve(ints * sizeof(int) + (size_t)max_tiles * sizeof(ProjTile) + 64));
+    int* counts = m->ws_group.as<int>();
+    int* offsets = counts + 2 * V;
+    int* cursor = offsets + 2 * V;
+    int* n_tiles = cursor + 2 * V;
+    int* perm = n_tiles + 4;
+    ProjTile* tiles = reinterpret_cast<ProjTile*>(perm + 2 * n);
+    CIS_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)2 * V * sizeof(int), st));
+    hipLaunchKernelGGL(k_group_hist, dim3(grid1(n, 256)), dim3(256), 0, st, d_coarse, n, V, counts);
+    hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(64), 0, st, counts, V, offsets, cursor, tiles, n_tiles, 64);
+    hipLaunchKernelGGL(k_group_scatter, dim3(grid1(n, 256)), dim3(256), 0, st, d_coarse, n, V, offsets, cursor, perm);
+    dim3 g((unsigned)max_tiles, (unsigned)ceil_div(m->h, 64));
+    if (ct == CIS_F32)
+        hipLaunchKernelGGL(k_project_tiles<float>, g, dim3(256), 0, st, (const float*)xc, m->d_Cs32, m->d_Rt, m->d_mus,
+                           tiles, n_tiles, perm, n, V, m->h, m->D, d_proj);
+    else
+        hipLaunchKernelGGL(k_project_tiles<double>, g, dim3(256), 0, st, (const double*)xc, m->d_Cs64, m->d_Rt, m->d_mus,
+                           tiles, n_tiles, perm, n, V, m->h, m->D, d_proj);
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
+}
+
+static int dev_fine_from_proj(cis_model* m, const double* d_proj, int64_t n, uint8_t* d_fine, hipStream_t st) {
+    if (n == 0) return CIS_OK;
+    CIS_TRY(m->ws_dist.reserve((size_t)n * (m->V > m->K ? m->V : m->K) * sizeof(double)));
+    double* dist = m->ws_dist.as<double>();
+    dim3 g((unsigned)ceil_div(n, 16), (unsigned)ceil_div(m->K, 16));
+    for (int j = 0; j < m->M; ++j) {
+        hipLaunchKernelGGL(k_sqdist_rows<double>, g, dim3(256), 0, st, d_proj, (int64_t)m->D, j * m->w,
+                           m->d_subs + (size_t)j * m->K * m->w, n, m->K, m->w, dist, m->prog_w);
+        hipLaunchKernelGGL((k_argmin_rows<double, uint8_t>), dim3(grid1(n, 256)), dim3(256), 0, st, dist, n, m->K,
+                           d_fine, m->M, j);
+    }
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
+}
+
+static const int64_t ENCODE_CHUNK = 1 << 16;
+
+extern "C" int cis_encode_dev(cis_model* m, const void* dX, int x_dtype, int64_t n, uint16_t* d_coarse,
+                              uint8_t* d_fine, void* stream) {
+    CIS_REQUIRE(m != nullptr, "model is NULL");
+    CIS_REQUIRE(x_dtype == CIS_F32 || x_dtype == CIS_F64, "x_dtype must be 4 or 8");
+    CIS_REQUIRE(n >= 0, "n must be >= 0");
+    CIS_CHECK_HIP(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    for (int64_t a = 0; a < n; a += ENCODE_CHUNK) {
+        const int64_t cn = (n - a < ENCODE_CHUNK) ? (n - a) : ENCODE_CHUNK;
+        const char* xin = (const char*)dX + (size_t)a * m->D_in * x_dtype;
+        const void* xp = xin;
+        int xp_dtype = x_dtype;
+        if (m->has_pca) {
+            CIS_TRY(m->ws_xp.reserve((size_t)cn * m->D * sizeof(float)));
+            CIS_TRY(cis_dev_apply_pca(m, xin, x_dtype, cn, m->ws_xp.as<float>(), st));
+            xp = m->ws_xp.p;
+            xp_dtype = CIS_F32;
+        }
+        const void* xc;
+        int ct;
+        CIS_TRY(cis_dev_coarse_type(m, xp, xp_dtype, cn, &xc, &ct, st));
+        CIS_TRY(dev_predict_coarse(m, xc, ct, cn, d_coarse + a * 2, st));
+        CIS_TRY(m->ws_proj.reserve((size_t)cn * m->D * sizeof(double)));
+        CIS_TRY(dev_project(m, xc, ct, cn, d_coarse + a * 2, m->ws_proj.as<double>(), st));
+        CIS_TRY(dev_fine_from_proj(m, m->ws_proj.as<double>(), cn, d_fine + a * m->M, st));
+    }
+    return CIS_OK;
+}
+
+// ---- host-pointer wrappers ---------------------------------------------------------------------
+struct HostIO {
+    cis_model* m;
+    hipStream_t st = nullptr;
+    int in(const void* src, size_t bytes, void** dptr) {
+        CIS_TRY(m->ws_in.reserve(bytes ? bytes : 1));
+        if (bytes) CIS_CHECK_HIP(hipMemcpyAsync(m->ws_in.p, src, bytes, hipMemcpyHostToDevice, st));
+        *dptr = m->ws_in.p;
+        return CIS_OK;
+    }
+};
+
+#define CIS_ENTER(m)                                   \
+    CIS_REQUIRE((m) != nullptr, "model is NULL");      \
+    CIS_CHECK_HIP(hipSetDevice((m)->device));
+
+extern "C" int cis_encode(cis_model* m, const void* X, int x_dtype, int64_t n, uint16_t* coarse, uint8_t* fine) {
+    CIS_ENTER(m);
+    CIS_REQUIRE(x_dtype == CIS_F32 || x_dtype == CIS_F64, "x_dtype must be 4 or 8");
+    CIS_REQUIRE(n >= 0 && (n == 0 || (X && coarse && fine)), "NULL buffer");
+    if (n == 0) return CIS_OK;
+    HostIO io{m};
+    void* dX;
+    CIS_TRY(io.in(X, (size_t)n * m->D_in * x_dtype, &dX));
+    CIS_TRY(m->ws_out0.reserve((size_t)n * 2 * sizeof(uint16_t)));
+    CIS_TRY(m->ws_out1.reserve((size_t)n * m->M));
+    CIS_TRY(cis_encode_dev(m, dX, x_dtype, n, m->ws_out0.as<uint16_t>(), m->ws_out1.as<uint8_t>(), nullptr));
+    CIS_CHECK_HIP(hipMemcpy(coarse, m->ws_out0.p, (size_t)n * 2 * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    CIS_CHECK_HIP(hipMemcpy(fine, m->ws_out1.p, (size_t)n * m->M, hipMemcpyDeviceToHost));
+    return CIS_OK;
+}
+
+extern "C" int cis_apply_pca(cis_model* m, const void* X, int x_dtype, int64_t n, float* out) {
+    CIS_ENTER(m);
+    CIS_REQUIRE(x_dtype == CIS_F32 || x_dtype == CIS_F64, "x_dtype must be 4 or 8");
+    CIS_REQUIRE(m->has_pca, "model has no PCA parameters");
+    if (n == 0) return CIS_OK;
+    HostIO io{m};
+    void* dX;
+    CIS_TRY(io.in(X, (size_t)n * m->D_in * x_dtype, &dX));
+    CIS_TRY(m->ws_xp.reserve((size_t)n * m->D * sizeof(float)));
+    CIS_TRY(cis_dev_apply_pca(m, dX, x_dtype, n, m->ws_xp.as<float>(), nullptr));
+    CIS_CHECK_HIP(hipMemcpy(out, m->ws_xp.p, (size_t)n * m->D * sizeof(float), hipMemcpyDeviceToHost));
+    return CIS_OK;
+}
+
+extern "C" int cis_predict_coarse(cis_model* m, const void* X, int x_dtype, int64_t n, uint16_t* coarse) {
+    CIS_ENTER(m);
+    CIS_REQUIRE(x_dtype == CIS_F32 || x_dtype == CIS_F64, "x_dtype must be 4 or 8");
+    if (n == 0) return CIS_OK;
+    HostIO io{m};
+    void* dX;
+    CIS_TRY(io.in(X, (size_t)n * m->D * x_dtype, &dX));
+    const void* xc; int ct;
+    CIS_TRY(cis_dev_coarse_type(m, dX, x_dtype, n, &xc, &ct, nullptr));
+    CIS_TRY(m->ws_out0.reserve((size_t)n * 2 * sizeof(uint16_t)));
+    CIS_TRY(dev_predict_coarse(m, xc, ct, n, m->ws_out0.as<uint16_t>(), nullptr));
+    CIS_CHECK_HIP(hipMemcpy(coarse, m->ws_out0.p, (size_t)n * 2 * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    return CIS_OK;
+}
+
+static int check_coarse_host(cis_model* m, const uint16_t* coarse, int64_t n) {
+    for (int64_t i = 0; i < 2 * n; ++i)
+        CIS_REQUIRE(coarse[i] < m->V, "coarse code %d out of range (V=%d)", (int)coarse[i], m->V);
+    return CIS_OK;
+}
+
+extern "C" int cis_project(cis_model* m, const void* X, int x_dtype, int64_t n, const uint16_t* coarse, double* out) {
+    CIS_ENTER(m);
+    CIS_REQUIRE(x_dtype == CIS_F32 || x_dtype == CIS_F64, "x_dtype must be 4 or 8");
+    if (n == 0) return CIS_OK;
+    CIS_TRY(check_coarse_host(m, coarse, n));
+    HostIO io{m};
+    void* dX;
+    CIS_TRY(io.in(X, (size_t)n * m->D * x_dtype, &dX));
+    const void* xc; int ct;
+    CIS_TRY(cis_dev_coarse_type(m, dX, x_dtype, n, &xc, &ct, nullptr));
+    CIS_TRY(m->ws_out0.reserve((size_t)n * 2 * sizeof(uint16_t)));
+    CIS_CHECK_HIP(hipMemcpyAsync(m->ws_out0.p, coarse, (size_t)n * 2 * sizeof(uint16_t), hipMemcpyHostToDevice, nullptr));
+    CIS_TRY(m->ws_proj.reserve((size_t)n * m->D * sizeof(double)));
+    CIS_TRY(dev_project(m, xc, ct, n, m->ws_out0.as<uint16_t>(), m->ws_proj.as<double>(), nullptr));
+    CIS_CHECK_HIP(hipMemcpy(out, m->ws_proj.p, (size_t)n * m->D * sizeof(double), hipMemcpyDeviceToHost));
+    return CIS_OK;
+}
+
+extern "C" int cis_predict_fine(cis_model* m, const void* X, int x_dtype, int64_t n, const uint16_t* coarse,
+                                uint8_t* fine) {
+    CIS_ENTER(m);
+    CIS_REQUIRE(x_dtype == CIS_F32 || x_dtype == CIS_F64, "x_dtype must be 4 or 8");
+    if (n == 0) return CIS_OK;
+    CIS_TRY(check_coarse_host(m, coarse, n));
+    HostIO io{m};
+    void* dX;
+    CIS_TRY(io.in(X, (size_t)n * m->D * x_dtype, &dX));
+    const void* xc; int ct;
+    CIS_TRY(cis_dev_coarse_type(m, dX, x_dtype, n, &xc, &ct, nullptr));
+    CIS_TRY(m->ws_out0.reserve((size_t)n * 2 * sizeof(uint16_t)));
+    CIS_CHECK_HIP(hipMemcpyAsync(m->ws_out0.p, coarse, (size_t)n * 2 * sizeof(uint16_t), hipMemcpyHostToDevice, nullptr));
+    CIS_TRY(m->ws_proj.reserve((size_t)n * m->D * sizeof(double)));
+    CIS_TRY(dev_project(m, xc, ct, n, m->ws_out0.as<uint16_t>(), m->ws_proj.as<double>(), nullptr));
+    CIS_TRY(m->ws_out1.reserve((size_t)n * m->M));
+    CIS_TRY(dev_fine_from_proj(m, m->ws_proj.as<double>(), n, m->ws_out1.as<uint8_t>(), nullptr));
+    CIS_CHECK_HIP(hipMemcpy(fine, m->ws_out1.p, (size_t)n * m->M, hipMemcpyDeviceToHost));
+    return CIS_OK;
+}
+
+extern "C" int cis_subquantizer_distances(cis_model* m, const void* X, int x_dtype, int64_t n,
+                                          const uint16_t* coarse, double* tables) {
+    CIS_ENTER(m);
+    CIS_REQUIRE(x_dtype == CIS_F32 || x_dtype == CIS_F64, "x_dtype must be 4 or 8");
+    if (n == 0) return CIS_OK;
+    CIS_TRY(check_coarse_host(m, coarse, n));
+    HostIO io{m};
+    void* dX;
+    CIS_TRY(io.in(X, (size_t)n * m->D * x_dtype, &dX));
+    const void* xc; int ct;
+    CIS_TRY(cis_dev_coarse_type(m, dX, x_dtype, n, &xc, &ct, nullptr));
+    CIS_TRY(m->ws_out0.reserve((size_t)n * 2 * sizeof(uint16_t)));
+    CIS_CHECK_HIP(hipMemcpyAsync(m->ws_out0.p, coarse, (size_t)n * 2 * sizeof(uint16_t), hipMemcpyHostToDevice, nullptr));
+    CIS_TRY(m->ws_proj.reserve((size_t)n * m->D * sizeof(double)));
+    CIS_TRY(dev_project(m, xc, ct, n, m->ws_out0.as<uint16_t>(), m->ws_proj.as<double>(), nullptr));
+    // tables[r][j][k] = squared distance of projected sub-vector j to sub-centroid k
+    CIS_TRY(m->ws_dist.reserve((size_t)n * (m->V > m->K ? m->V : m->K) * sizeof(double)));
+    double* dist = m->ws_dist.as<double>();
+    dim3 g((unsigned)ceil_div(n, 16), (unsigned)ceil_div(m->K, 16));
+    for (int j = 0; j < m->M; ++j) {
+        hipLaunchKernelGGL(k_sqdist_rows<double>, g, dim3(256), 0, nullptr, m->ws_proj.as<double>(), (int64_t)m->D,
+                           j * m->w, m->d_subs + (size_t)j * m->K * m->w, n, m->K, m->w, dist, m->prog_w);
+        CIS_CHECK_HIP(hipMemcpy2D(tables + (size_t)j * m->K, (size_t)m->M * m->K * sizeof(double), dist,
+                                  (size_t)m->K * sizeof(double), (size_t)m->K * sizeof(double), (size_t)n,
+                                  hipMemcpyDeviceToHost));
+    }
+    return CIS_OK;
+}
+
+extern "C" int cis_reconstruct(cis_model* m, const uint16_t* coarse, const uint8_t* fine, int64_t n, double* out) {
+    CIS_ENTER(m);
+    if (n == 0) return CIS_OK;
+    CIS_TRY(check_coarse_host(m, coarse, n));
+    for (int64_t i = 0; i < n * m->M; ++i)
+        CIS_REQUIRE(fine[i] < m->K, "fine code %d out of range (K=%d)", (int)fine[i], m->K);
+    CIS_TRY(m->ws_out0.reserve((size_t)n * 2 * sizeof(uint16_t)));
+    CIS_TRY(m->ws_out1.reserve((size_t)n * m->M));
+    CIS_TRY(m->ws_proj.reserve((size_t)n * m->D * sizeof(double)));
+    CIS_CHECK_HIP(hipMemcpy(m->ws_out0.p, coarse, (size_t)n * 2 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    CIS_CHECK_HIP(hipMemcpy(m->ws_out1.p, fine, (size_t)n * m->M, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_reconstruct, dim3((unsigned)n, 2), dim3(128), 0, nullptr, m->ws_out0.as<uint16_t>(),
+                       m->ws_out1.as<uint8_t>(), m->d_Rs, m->d_mus, m->d_Cs64, m->d_subs, n, m->V, m->M, m->K, m->h,
+                       m->w, m->ws_proj.as<double>());
+    CIS_CHECK_HIP(hipGetLastError());
+    CIS_CHECK_HIP(hipMemcpy(out, m->ws_proj.p, (size_t)n * m->D * sizeof(double), hipMemcpyDeviceToHost));
+    return CIS_OK;
+}

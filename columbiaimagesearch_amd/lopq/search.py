@@ -1,0 +1,336 @@
+"""LOPQSearcherHIP: the reference's searcher surface over the MI355X index.
+
+Mirror of lopq/lopq/search.py:85-382 of the reference (LOPQSearcherBase / LOPQSearcher): same method
+names, arguments and return types -- ``search`` returns ``(list[Result], visited)`` with
+``Result(id, code[, dist])`` -- selected in cufacesearch by ``lopq_searcher = "LOPQSearcherHIP"``
+next to "LOPQSearcher" / "LOPQSearcherLMDB" (cufacesearch/searcher/searcher_lopqhbase.py:198-222).
+Additions: ``search_batch`` and ``add_codes_array`` (whole arrays in, arrays out), which is where
+the GPU earns its keep; the per-query ``search`` is the batch of one.
+
+Item ids may be any hashable (the reference uses ``sha1[_bbox]`` strings,
+cufacesearch/indexer/hbase_indexer_minimal.py:816): integers travel to the device as they are,
+everything else is mapped to an integer slot here.
+"""
+from collections import namedtuple
+from itertools import count
+
+import numpy as np
+
+from .. import _lib
+from .model import LOPQCode, LOPQModel, LOPQModelPCA, _code_dtype
+
+_SLOT_BASE = 1 << 62  # device ids >= this are slots of non-integer caller ids
+
+
+def _is_int(x):
+    return isinstance(x, (int, np.integer)) and not isinstance(x, (bool, np.bool_))
+
+
+class LOPQSearcherBase(object):
+    """Hooks shared by every searcher (reference: lopq/lopq/search.py:85-308)."""
+
+    def __init__(self):
+        self.nb_indexed = 0
+        self.verbose = 0
+
+    def get_nb_indexed(self):
+        return self.nb_indexed
+
+    def add_codes_from_dict(self, codes_dict):
+        """reference: lopq/lopq/search.py:275-283 -- {id: [coarse, fine]}"""
+        ids = list(codes_dict.keys())
+        self.add_codes([codes_dict[k] for k in ids], ids)
+
+    def add_data(self, data, ids=None, num_procs=1):
+        """reference: lopq/lopq/search.py:94-108 (num_procs is meaningless on the GPU)"""
+        coarse, fine = self.model.predict_batch(data)
+        self.add_codes_array(coarse, fine, ids)
+
+    def _add_codes_from_one_file(self, one_file, samples_count):
+        """reference: lopq/lopq/search.py:227-243 -- 'id<TAB>[[c0, c1], [f0, ...]]' lines"""
+        import ast
+        ids, codes = [], []
+        with open(one_file, "rt") as inf:
+            for line in inf:
+                if line.strip():
+                    one_id, one_code = line.rstrip("\n").split("\t")
+                    parsed = ast.literal_eval(one_code)
+                    ids.append(one_id)
+                    codes.append((tuple(parsed[0]), tuple(parsed[1])))
+        self.add_codes(codes, ids)
+        return samples_count + len(ids)
+
+    def add_codes_from_local(self, local_path):
+        """reference: lopq/lopq/search.py:245-263 -- one file, or a directory of Spark part-* files"""
+        import os
+        from glob import glob
+        files = [local_path] if os.path.isfile(local_path) else sorted(glob(local_path + "/part-*"))
+        n = 0
+        for f in files:
+            n = self._add_codes_from_one_file(f, n)
+        return n
+
+    def add_codes(self, codes, ids=None):
+        raise NotImplementedError()
+
+    def get_cell(self, cell):
+        raise NotImplementedError()
+
+
+class LOPQSearcherHIP(LOPQSearcherBase):
+    def __init__(self, model, shard=None):
+        """:param model: LOPQModel / LOPQModelPCA (this package's classes)
+        :param shard: None, or (rank, world[, owner]) for a cell-sharded index (one per GPU)"""
+        super(LOPQSearcherHIP, self).__init__()
+        self.model = model
+        self._ix = None
+        self._shard = shard
+        self._slot_of = {}  # non-integer id -> slot
+        self._id_of = []    # slot -> id
+        self._M = model.M
+        self._open()
+
+    # -- handle ----------------------------------------------------------------------------------
+    def _open(self):
+        out = _lib.c_void_p()
+        L = _lib.lib()
+        _lib.check(L.cis_index_create(_lib.ctypes.byref(out), self.model._handle()))
+        self._ix = out.value
+        if self._shard is not None:
+            rank, world = self._shard[0], self._shard[1]
+            owner = None
+            if len(self._shard) > 2 and self._shard[2] is not None:
+                owner = np.ascontiguousarray(self._shard[2], dtype=np.int32)
+            _lib.check(L.cis_index_set_shard(self._ix, int(rank), int(world), _lib.ptr(owner)))
+
+    def close(self):
+        if self._ix:
+            _lib.lib().cis_index_destroy(self._ix)
+            self._ix = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- ids -------------------------------------------------------------------------------------
+    def _device_ids(self, ids, n):
+        if ids is None:
+            return np.arange(n, dtype=np.int64)  # reference: ids = count() per call, search.py:336-337
+        if isinstance(ids, np.ndarray) and ids.dtype.kind in "iu":
+            out = np.ascontiguousarray(ids, dtype=np.int64)
+        else:
+            out = np.empty(n, dtype=np.int64)
+            k = -1
+            for k, item_id in zip(range(n), ids):
+                if _is_int(item_id):
+                    out[k] = int(item_id)
+                else:
+                    slot = self._slot_of.get(item_id)
+                    if slot is None:
+                        slot = len(self._id_of)
+                        self._slot_of[item_id] = slot
+                        self._id_of.append(item_id)
+                    out[k] = _SLOT_BASE + slot
+            if k + 1 != n:
+                out = out[:k + 1]
+        if out.shape[0] and ((out < 0).any()):
+            raise ValueError("integer ids must be >= 0")
+        return out
+
+    def _caller_id(self, dev_id):
+        dev_id = int(dev_id)
+        return self._id_of[dev_id - _SLOT_BASE] if dev_id >= _SLOT_BASE else dev_id
+
+    # -- insert ----------------------------------------------------------------------------------
+    def add_codes_array(self, coarse, fine, ids=None, dedup=True):
+        """Insert n codes given as arrays (coarse [n,2], fine [n,M]).  Same semantics as add_codes:
+        an id already present in the same cell is skipped (reference: lopq/lopq/search.py:349-364)."""
+        coarse = np.ascontiguousarray(np.asarray(coarse).reshape(-1, 2), dtype=np.uint16)
+        n = coarse.shape[0]
+        fine = np.ascontiguousarray(np.asarray(fine).reshape(n, self._M), dtype=np.uint8)
+        dev_ids = self._device_ids(ids, n)
+        m = min(n, dev_ids.shape[0])  # zip() semantics when ids is shorter
+        added = _lib.c_int64(0)
+        _lib.check(_lib.lib().cis_index_add(self._ix, _lib.ptr(dev_ids), _lib.ptr(coarse), _lib.ptr(fine), m,
+                                            1 if dedup else 0, _lib.ctypes.byref(added)))
+        self.nb_indexed = int(_lib.lib().cis_index_size(self._ix))
+        return int(added.value)
+
+    def add_codes(self, codes, ids=None):
+        """reference: lopq/lopq/search.py:325-369.  codes: iterable of (coarse, fine) tuples.  Items
+        that cannot be pushed are reported and skipped, like the reference does (:365-367)."""
+        V, K, M = self.model.V, self.model.subquantizer_clusters, self._M
+        good_c, good_f, good_ids = [], [], []
+        id_iter = count() if ids is None else iter(ids)
+        for item_id, code in zip(id_iter, codes):
+            try:
+                c = (int(code[0][0]), int(code[0][1]))
+                f = [int(v) for v in code[1]]
+                if not (0 <= c[0] < V and 0 <= c[1] < V) or len(f) != M or min(f) < 0 or max(f) >= K:
+                    raise ValueError("code out of range for this model")
+                if _is_int(item_id) and int(item_id) < 0:
+                    raise ValueError("negative id")
+            except Exception as inst:
+                print("Could not push code {}. ({}: {})".format(code, type(inst), inst))
+                continue
+            good_c.append(c)
+            good_f.append(f)
+            good_ids.append(item_id)
+        if good_c:
+            self.add_codes_array(np.array(good_c, dtype=np.uint16), np.array(good_f, dtype=np.uint8), good_ids)
+
+    def get_cell(self, cell):
+        """reference: lopq/lopq/search.py:372-382 -> [(id, LOPQCode), ...] in insertion order"""
+        c0, c1 = int(cell[0]), int(cell[1])
+        L = _lib.lib()
+        n = _lib.c_int64(0)
+        _lib.check(L.cis_index_get_cell(self._ix, c0, c1, 0, None, None, _lib.ctypes.byref(n)))
+        cap = int(n.value)
+        if cap == 0:
+            return []
+        ids = np.empty(cap, dtype=np.int64)
+        fine = np.empty((cap, self._M), dtype=np.uint8)
+        _lib.check(L.cis_index_get_cell(self._ix, c0, c1, cap, _lib.ptr(ids), _lib.ptr(fine), _lib.ctypes.byref(n)))
+        ct = _code_dtype(self.model.V)
+        coarse = (ct(c0), ct(c1))
+        return [(self._caller_id(i), LOPQCode(coarse, tuple(f))) for i, f in zip(ids, fine)]
+
+    # -- search ----------------------------------------------------------------------------------
+    def search_batch(self, X, quota=10, limit=None, with_codes=False):
+        """Search many queries in one call.
+
+        :returns: dict with ``ids`` [nq,L] int64 device ids (-1 padded; map with ``caller_ids``),
+            ``dists`` [nq,L] float64 squared ADC distances (NaN padded), ``n_found`` [nq],
+            ``visited`` [nq] and, if with_codes, ``cells`` / ``pos`` locating every result.
+        """
+        X = _lib.as_float_matrix(X, self.model.input_dim)
+        nq = X.shape[0]
+        L = int(quota) if limit is None else int(limit)
+        L = max(L, 0)
+        ids = -np.ones((nq, L), dtype=np.int64)
+        dists = np.full((nq, L), np.nan)
+        n_found = np.zeros(nq, dtype=np.int32)
+        visited = np.zeros(nq, dtype=np.int32)
+        cells = -np.ones((nq, L), dtype=np.int32) if with_codes else None
+        pos = np.zeros((nq, L), dtype=np.uint32) if with_codes else None
+        _lib.check(_lib.lib().cis_index_search(self._ix, _lib.ptr(X), _lib.dtype_code(X), nq, int(quota),
+                                               -1 if limit is None else int(limit), _lib.ptr(ids), _lib.ptr(dists),
+                                               _lib.ptr(n_found), _lib.ptr(visited), _lib.ptr(cells), _lib.ptr(pos)))
+        out = {"ids": ids, "dists": dists, "n_found": n_found, "visited": visited}
+        if with_codes:
+            out["cells"], out["pos"] = cells, pos
+        return out
+
+    def caller_ids(self, dev_ids):
+        """Map device ids of search_batch back to the ids given to add_codes."""
+        return [self._caller_id(i) for i in dev_ids if i >= 0]
+
+    def _codes_of(self, cells, pos):
+        n = cells.shape[0]
+        fine = np.empty((n, self._M), dtype=np.uint8)
+        if n:
+            c = np.ascontiguousarray(cells, dtype=np.int32)
+            p = np.ascontiguousarray(pos, dtype=np.uint32)
+            _lib.check(_lib.lib().cis_index_get_codes(self._ix, _lib.ptr(c), _lib.ptr(p), n, _lib.ptr(fine)))
+        V = self.model.V
+        ct = _code_dtype(V)
+        return [LOPQCode((ct(int(cl) // V), ct(int(cl) % V)), tuple(f)) for cl, f in zip(cells, fine)]
+
+    def search(self, x, quota=10, limit=None, with_dists=False):
+        """reference: lopq/lopq/search.py:179-224 -> (list[Result(id, code[, dist])], visited).
+        PCA is applied when the model has PCA parameters (the reference tests the exact class,
+        :198, which a subclass would silently fail; SURVEY.md section 8b gotcha i)."""
+        r = self.search_batch(np.asarray(x)[None, :], quota=quota, limit=limit, with_codes=True)
+        n = int(r["n_found"][0])
+        ids = [self._caller_id(i) for i in r["ids"][0, :n]]
+        codes = self._codes_of(r["cells"][0, :n], r["pos"][0, :n])
+        if with_dists:
+            Result = namedtuple("Result", ["id", "code", "dist"])
+            results = [Result(i, c, d) for i, c, d in zip(ids, codes, r["dists"][0, :n])]
+        else:
+            Result = namedtuple("Result", ["id", "code"])
+            results = [Result(i, c) for i, c in zip(ids, codes)]
+        return results, int(r["visited"][0])
+
+
+    # -- device-resident entry points (torch tensors are only the memory/stream plumbing) ---------
+    def _dev_args(self, q, quota, limit):
+        import torch
+        if not (q.is_cuda and q.is_contiguous() and q.dim() == 2 and q.shape[1] == self.model.input_dim):
+            raise ValueError("q must be a contiguous [nq, %d] tensor on the GPU" % self.model.input_dim)
+        if q.dtype not in (torch.float32, torch.float64):
+            raise ValueError("q must be float32 or float64")
+        L = int(quota) if limit is None else int(limit)
+        code = _lib.CIS_F32 if q.dtype == torch.float32 else _lib.CIS_F64
+        return max(L, 0), code, torch.cuda.current_stream(q.device).cuda_stream
+
+    def search_batch_dev(self, q, quota=10, limit=None, out=None, with_codes=False):
+        """search_batch on tensors already in HBM; returns torch tensors, does not synchronise
+        (apart from the small plan read-back inside the library)."""
+        import torch
+        L, code, stream = self._dev_args(q, quota, limit)
+        nq = q.shape[0]
+        if out is None:
+            out = {"ids": torch.empty((nq, L), dtype=torch.int64, device=q.device),
+                   "dists": torch.empty((nq, L), dtype=torch.float64, device=q.device),
+                   "n_found": torch.empty(nq, dtype=torch.int32, device=q.device),
+                   "visited": torch.empty(nq, dtype=torch.int32, device=q.device)}
+            if with_codes:
+                out["cells"] = torch.empty((nq, L), dtype=torch.int32, device=q.device)
+                out["pos"] = torch.empty((nq, L), dtype=torch.int32, device=q.device)
+        cells = out["cells"].data_ptr() if "cells" in out else None
+        pos = out["pos"].data_ptr() if "pos" in out else None
+        _lib.check(_lib.lib().cis_index_search_dev(self._ix, q.data_ptr(), code, nq, int(quota),
+                                                   -1 if limit is None else int(limit), out["ids"].data_ptr(),
+                                                   out["dists"].data_ptr(), out["n_found"].data_ptr(),
+                                                   out["visited"].data_ptr(), cells, pos, stream))
+        return out
+
+    def search_partial_dev(self, q, quota=10, limit=None):
+        """This shard's ranked hits: (hits uint8 [nq, L, 32] viewable as cis_hit, visited [nq])."""
+        import torch
+        L, code, stream = self._dev_args(q, quota, limit)
+        nq = q.shape[0]
+        hits = torch.empty((nq, L, _lib.HIT_DTYPE.itemsize), dtype=torch.uint8, device=q.device)
+        visited = torch.empty(nq, dtype=torch.int32, device=q.device)
+        _lib.check(_lib.lib().cis_index_search_partial_dev(self._ix, q.data_ptr(), code, nq, int(quota),
+                                                           -1 if limit is None else int(limit), hits.data_ptr(),
+                                                           visited.data_ptr(), stream))
+        return hits, visited
+
+    def last_stats(self):
+        """Counters of the last search: candidates scanned, work items, tables, scan launches."""
+        st = np.zeros(4, dtype=np.int64)
+        _lib.check(_lib.lib().cis_index_last_stats(self._ix, _lib.ptr(st)))
+        return {"candidates": int(st[0]), "items": int(st[1]), "tables": int(st[2]), "scan_launches": int(st[3])}
+
+
+def merge_hits_dev(parts, with_codes=False):
+    """Merge per-shard hit lists parts [world, nq, L, 32] (uint8, on the GPU) into the final ranking
+    by (dist, visit_rank, pos).  Returns dict of torch tensors like search_batch_dev."""
+    import torch
+    world, nq, L = int(parts.shape[0]), int(parts.shape[1]), int(parts.shape[2])
+    if not (parts.is_cuda and parts.is_contiguous() and parts.dtype == torch.uint8 and parts.shape[3] == 32):
+        raise ValueError("parts must be a contiguous uint8 [world, nq, L, 32] tensor on the GPU")
+    dev = parts.device
+    out = {"ids": torch.empty((nq, L), dtype=torch.int64, device=dev),
+           "dists": torch.empty((nq, L), dtype=torch.float64, device=dev),
+           "n_found": torch.zeros(nq, dtype=torch.int32, device=dev)}
+    if with_codes:
+        out["cells"] = torch.empty((nq, L), dtype=torch.int32, device=dev)
+        out["pos"] = torch.empty((nq, L), dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().cis_merge_hits_dev(parts.data_ptr(), world, nq, L, out["ids"].data_ptr(),
+                                             out["dists"].data_ptr(), out["n_found"].data_ptr(),
+                                             out["cells"].data_ptr() if with_codes else None,
+                                             out["pos"].data_ptr() if with_codes else None,
+                                             torch.cuda.current_stream(dev).cuda_stream))
+    return out
+
+
+# the reference's other class names resolve to the HIP searcher so that config strings and pickles
+# written for them keep loading
+LOPQSearcher = LOPQSearcherHIP
+
+__all__ = ["LOPQSearcherBase", "LOPQSearcherHIP", "LOPQSearcher", "LOPQModel", "LOPQModelPCA", "LOPQCode"]

@@ -1,0 +1,142 @@
+"""Host-side LOPQ training (numpy + scikit-learn), vectorised.
+
+Restates the training recipe of the reference (lopq/lopq/model.py:19-437) without its per-sample
+Python loops: covariance accumulators become matrix products.  k-means results depend on the
+scikit-learn version, so training is judged by distortion/recall, not bit parity (SURVEY.md
+section 8c caveat ii, section 8f row 3).  Not on the encode/search hot path.
+"""
+import logging
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+
+def eigenvalue_allocation(num_buckets, eigenvalues):
+    """Greedy balancing of eigenvalue log-products over buckets (OPQ section 3.2.4).
+    reference: lopq/lopq/model.py:19-71.  Returns the permutation of dimensions."""
+    eigenvalues = np.asarray(eigenvalues, dtype=np.float64)
+    D = eigenvalues.shape[0]
+    per_bucket = D // num_buckets
+    nz = np.abs(eigenvalues[np.nonzero(eigenvalues)])
+    scaled = eigenvalues / (nz.min() if nz.size else 1.0)  # keeps every |eigenvalue| >= 1
+    with np.errstate(divide="ignore"):
+        logs = np.log2(np.abs(scaled))
+    load = np.zeros(num_buckets)
+    fill = np.zeros(num_buckets, dtype=np.int64)
+    perm = np.zeros((num_buckets, per_bucket), dtype=np.int64)
+    for dim in np.argsort(scaled)[::-1]:
+        open_buckets = np.nonzero(fill < per_bucket)[0]
+        b = open_buckets[np.argmin(load[open_buckets])]
+        load[b] += logs[dim]
+        perm[b, fill[b]] = dim
+        fill[b] += 1
+    return perm.reshape(D)
+
+
+def assign_clusters(data, C, chunk=8192):
+    """argmin_c ||x - c||^2 with the reference's direct (x - c)^2 form (lopq/lopq/utils.py:47)."""
+    out = np.empty(data.shape[0], dtype=np.int64)
+    for a in range(0, data.shape[0], chunk):
+        d = data[a:a + chunk, None, :] - C[None, :, :]
+        out[a:a + chunk] = np.einsum("nvd,nvd->nv", d, d).argmin(axis=1)
+    return out
+
+
+def local_rotations(data, C, num_buckets):
+    """Per-cluster residual mean and PCA rotation with balanced variance.
+    reference: lopq/lopq/model.py:74-206.  Returns (R [V,d,d], mu [V,d], assignments, residuals)."""
+    V, d = C.shape
+    assign = assign_clusters(data, C)
+    residuals = np.asarray(data - C[assign], dtype=np.float64)
+    R = np.zeros((V, d, d))
+    mu = np.zeros((V, d))
+    for c in range(V):
+        r = residuals[assign == c]
+        n = r.shape[0]
+        if n > 0:
+            mu[c] = r.sum(axis=0) / n
+        if n < d:
+            logger.warning("Fewer points (%d) than dimensions (%d) in rotation computation for cluster %d", n, d, c)
+            eigvals, vecs = np.ones(d), np.eye(d)
+        else:
+            A = r.T.dot(r)
+            cov = (A + A.T) / (2.0 * (n - 1)) - np.outer(mu[c], mu[c])
+            eigvals, vecs = np.linalg.eigh(cov)
+        R[c] = vecs[:, eigenvalue_allocation(num_buckets, eigvals)].T
+    return R, mu, assign, residuals
+
+
+def project_to_local(residuals, assign, R, mu):
+    """R[a] . (res - mu[a]) for every training residual.  reference: lopq/lopq/model.py:209-234."""
+    out = np.zeros(residuals.shape)
+    for c in np.unique(assign):
+        sel = np.nonzero(assign == c)[0]
+        out[sel] = (residuals[sel] - mu[c]).dot(R[c].T)
+    return out
+
+
+def _kmeans(data, k, iters, n_init, random_state):
+    from sklearn.cluster import MiniBatchKMeans
+    km = MiniBatchKMeans(n_clusters=k, init="k-means++", max_iter=iters, n_init=n_init, batch_size=10000,
+                         verbose=False, random_state=random_state)
+    km.fit(data)
+    return km.cluster_centers_
+
+
+def train_pca(data, pca_dims=256, pca_subsample=None):
+    """PCA basis with variance balanced over the two halves.  reference: lopq/lopq/model.py:242-287."""
+    if pca_subsample:
+        data = data[:min(pca_subsample, data.shape[0])]
+    n, D = data.shape
+    pca_dims = min(pca_dims, D)
+    X = np.asarray(data, dtype=np.float64)
+    mu = X.mean(axis=0)
+    A = X.T.dot(X) / (n - 1) - np.outer(mu, mu)
+    E, P = np.linalg.eigh(A)
+    E, P = E[-pca_dims:], P[:, -pca_dims:]
+    P = P[:, eigenvalue_allocation(2, E)]
+    return {"mu": mu, "P": P, "E": E, "A": A, "c": n}, pca_dims
+
+
+def apply_pca_host(x, P, mu, renorm, dtype=np.float32):
+    """Training-time apply_PCA on the host (reference: lopq/lopq/model.py:961-978)."""
+    y = np.dot(x - mu, P)
+    if renorm:
+        y = y / np.linalg.norm(y, axis=-1, keepdims=True)
+    return y.astype(dtype)
+
+
+def train(data, V=8, M=4, subquantizer_clusters=256, parameters=None, kmeans_coarse_iters=10,
+          kmeans_local_iters=20, n_init=10, subquantizer_sample_ratio=1.0, random_state=None, verbose=False):
+    """Fit whatever is missing from `parameters`.  reference: lopq/lopq/model.py:339-437."""
+    Cs = Rs = mus = subs = None
+    if parameters is not None:
+        Cs, Rs, mus, subs = parameters
+    if Rs is None or mus is None:
+        Rs = mus = None
+    halves = np.split(data, 2, axis=1)
+    if Cs is None:
+        Cs = tuple(_kmeans(h, V, kmeans_coarse_iters, n_init, random_state) for h in halves)
+    fitted = None
+    if Rs is None:
+        fitted = [local_rotations(h, C, M // 2) for h, C in zip(halves, Cs)]
+        Rs = tuple(f[0] for f in fitted)
+        mus = tuple(f[1] for f in fitted)
+    if subs is not None:
+        return tuple(Cs), tuple(Rs), tuple(mus), subs
+    N = data.shape[0]
+    n_sub = int(np.floor(min(subquantizer_sample_ratio, 1.0) * N))
+    sample = np.random.RandomState(random_state).choice(N, n_sub, False)
+    subs = []
+    for s, (h, C) in enumerate(zip(halves, Cs)):
+        if fitted is not None:
+            assign, residuals = fitted[s][2][sample], fitted[s][3][sample]
+        else:
+            hs = h[sample]
+            assign = assign_clusters(hs, C)
+            residuals = np.asarray(hs - C[assign], dtype=np.float64)
+        projected = project_to_local(residuals, assign, Rs[s], mus[s])
+        subs.append([_kmeans(p, subquantizer_clusters, kmeans_local_iters, n_init, random_state)
+                     for p in np.split(projected, M // 2, axis=1)])
+    return tuple(Cs), tuple(Rs), tuple(mus), tuple(subs)

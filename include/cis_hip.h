@@ -1,0 +1,161 @@
+/*
+ * cis_hip.h -- C ABI of libcis_hip.so: the MI355X (gfx950) implementation of the
+ * embed-then-index hot path of ColumbiaImageSearch.
+ *
+ * The reference has no FFI: its boundary is three duck-typed Python surfaces
+ * (lopq.model.LOPQModel[PCA], lopq.search.LOPQSearcherBase subclasses, cufacesearch
+ * GenericFeaturizer).  The Python mirrors of those surfaces in columbiaimagesearch_amd/ bind
+ * exactly the entry points below through ctypes; INTEGRATION.md shows the binding a reference
+ * maintainer would add.  Each entry point cites the reference code it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; `*_dev` entry points take DEVICE pointers and a hipStream_t
+ *    (passed as void*; NULL = the null stream) and never synchronise; the others take HOST
+ *    pointers, copy, run and synchronise before returning;
+ *  - every function returns 0 on success or a negative CIS_E* code; the message of the last
+ *    failure on the calling thread is cis_last_error().  Nothing aborts or throws across the ABI
+ *    (the reference's callers log per-item errors and keep going: lopq/lopq/search.py:365-367);
+ *  - the library never keeps caller pointers after a call returns; handles own device memory;
+ *  - HIP is initialised lazily on first use, so a process may fork before touching the library
+ *    (gunicorn / multiprocessing callers); handles must not be shared across processes;
+ *  - dtype arguments: CIS_F32 = 4, CIS_F64 = 8 (bytes per element).
+ */
+#ifndef CIS_HIP_H
+#define CIS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CIS_F32 4
+#define CIS_F64 8
+
+#define CIS_OK 0
+#define CIS_EINVAL -1   /* bad argument (Python wrapper raises ValueError)            */
+#define CIS_EHIP -2     /* a HIP runtime call failed                                   */
+#define CIS_ENOMEM -3   /* device or host allocation failed                            */
+#define CIS_EUNSUPPORTED -4 /* valid in the reference but not built yet (NotImplementedError) */
+#define CIS_ENODEVICE -5 /* no gfx950 device visible                                   */
+
+typedef struct cis_model cis_model;
+typedef struct cis_index cis_index;
+typedef struct cis_cnn cis_cnn;
+
+/* One ranked candidate of a (possibly partial, per-shard) result list.  Ordering key is
+ * (dist, visit_rank, pos): the reference ranks with a stable sort over the retrieval order,
+ * i.e. multisequence cell order then insertion order inside the cell (lopq/lopq/search.py:128-133,
+ * :210).  32 bytes; this is also what travels in the RCCL all-gather of the sharded search. */
+typedef struct cis_hit {
+    double dist;         /* squared ADC distance, float64 (search.py:173)                 */
+    uint32_t visit_rank; /* 0-based position of the candidate's cell in multisequence order */
+    uint32_t pos;        /* 0-based insertion position inside that cell                   */
+    int64_t id;          /* caller's item id (-1: empty slot)                             */
+    int32_t cell;        /* c0 * V + c1 of the candidate's coarse cell                    */
+    int32_t reserved;
+} cis_hit;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int cis_version(void);
+const char* cis_last_error(void);
+/* Number of visible HIP devices (0 when none); never fails. */
+int cis_device_count(void);
+/* Select the device used by handles created afterwards by this process (default 0). */
+int cis_set_device(int device);
+
+/* ---- LOPQ model: replaces lopq.model.LOPQModel / LOPQModelPCA arithmetic --------------------
+ * Parameter layout = the reference's parameter tuple (lopq/lopq/model.py:461-473, :841), each
+ * pair concatenated split-major and C-contiguous:
+ *   Cs   [2][V][h]      coarse centroids, dtype coarse_dtype (float32 when LOPQ was trained on
+ *                       float32 data, e.g. after apply_PCA; float64 otherwise)
+ *   Rs   [2][V][h][h]   local rotations, applied as R[c] . r   (model.py:638)
+ *   mus  [2][V][h]      mean residuals
+ *   subs [M][K][w]      sub-quantizer centroids, fine split j of coarse split s at s*M/2 + j
+ *   pca_P [D_in][D], pca_mu [D_in]  or NULL/NULL for a plain LOPQModel (then D_in == D)
+ * with h = D/2, w = D/M.  K <= 256 and V <= 4096 in this build. */
+int cis_model_create(cis_model** out, int D_in, int D, int V, int M, int K, int coarse_dtype,
+                     const void* Cs, const double* Rs, const double* mus, const double* subs,
+                     const double* pca_P, const double* pca_mu, int renorm);
+void cis_model_destroy(cis_model* m);
+
+/* LOPQModelPCA.apply_PCA (model.py:961-978): out[n][D] float32.  x_dtype = dtype of X. */
+int cis_apply_pca(cis_model* m, const void* X, int x_dtype, int64_t n, float* out);
+
+/* LOPQModel.predict over n vectors (model.py:543-561, :980-1003; the loop of
+ * compute_codes_notparallel, lopq/lopq/utils.py:203-218).  X is [n][D_in] of x_dtype (PCA is
+ * applied first when the model has one).  coarse [n][2], fine [n][M]. */
+int cis_encode(cis_model* m, const void* X, int x_dtype, int64_t n, uint16_t* coarse, uint8_t* fine);
+int cis_encode_dev(cis_model* m, const void* dX, int x_dtype, int64_t n, uint16_t* d_coarse,
+                   uint8_t* d_fine, void* stream);
+
+/* The pieces of predict, exposed because the reference exposes them.  They take vectors that
+ * are ALREADY in LOPQ space (i.e. after apply_PCA), [n][D] of x_dtype:
+ *   predict_coarse (model.py:563-573), project (model.py:604-641) -> out [n][D] float64,
+ *   predict_fine (model.py:575-602),
+ *   get_subquantizer_distances (model.py:673-704) -> tables [n][M][K] float64,
+ *   reconstruct (model.py:643-671) -> out [n][D] float64. */
+int cis_predict_coarse(cis_model* m, const void* X, int x_dtype, int64_t n, uint16_t* coarse);
+int cis_project(cis_model* m, const void* X, int x_dtype, int64_t n, const uint16_t* coarse, double* out);
+int cis_predict_fine(cis_model* m, const void* X, int x_dtype, int64_t n, const uint16_t* coarse, uint8_t* fine);
+int cis_subquantizer_distances(cis_model* m, const void* X, int x_dtype, int64_t n,
+                               const uint16_t* coarse, double* tables);
+int cis_reconstruct(cis_model* m, const uint16_t* coarse, const uint8_t* fine, int64_t n, double* out);
+
+/* ---- LOPQ index: replaces lopq.search.LOPQSearcher (search.py:310-382) ---------------------- */
+/* The index keeps a borrowed pointer to `m`: destroy the index first. */
+int cis_index_create(cis_index** out, cis_model* m);
+void cis_index_destroy(cis_index* ix);
+
+/* Cell-sharded operation (one process per GPU): this handle stores only the cells with
+ * owner[cell] == rank but counts every cell, so that all ranks derive the same global
+ * multisequence order and quota cut-off without communicating (search.py:128-133).
+ * owner = NULL selects cell_id % world.  Must be called on an empty index. */
+int cis_index_set_shard(cis_index* ix, int rank, int world, const int32_t* owner /* [V*V] or NULL */);
+
+/* add_codes (search.py:325-369): append items in order; with dedup != 0 an id already present in
+ * the SAME cell is skipped (first occurrence wins).  *n_added = items counted (all shards). */
+int cis_index_add(cis_index* ix, const int64_t* ids, const uint16_t* coarse, const uint8_t* fine,
+                  int64_t n, int dedup, int64_t* n_added);
+/* get_nb_indexed (search.py:91-92): items over all shards. */
+int64_t cis_index_size(cis_index* ix);
+/* get_cell (search.py:372-382): items of one cell in insertion order.  Returns the cell's size in
+ * *n; copies at most cap items.  In sharded mode non-owned cells report their size but copy 0. */
+int cis_index_get_cell(cis_index* ix, int c0, int c1, int64_t cap, int64_t* ids, uint8_t* fine, int64_t* n);
+
+/* LOPQSearcherBase.search over nq queries (search.py:179-224): Q [nq][D_in] of q_dtype.
+ * limit < 0 means "limit = quota" (search.py:213-214).  Outputs, with L = effective limit:
+ *   ids [nq][L] (-1 padded), dists [nq][L] (NaN padded), n_found [nq], visited [nq], and
+ *   optionally (may be NULL) cells [nq][L] (c0*V+c1, -1 padded) and pos [nq][L]: where each
+ *   result lives, so that its code can be fetched with cis_index_get_codes (Result.code,
+ *   search.py:217-222). */
+int cis_index_search(cis_index* ix, const void* Q, int q_dtype, int nq, int64_t quota, int limit,
+                     int64_t* ids, double* dists, int32_t* n_found, int32_t* visited,
+                     int32_t* cells, uint32_t* pos);
+int cis_index_search_dev(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota, int limit,
+                         int64_t* d_ids, double* d_dists, int32_t* d_n_found, int32_t* d_visited,
+                         int32_t* d_cells, uint32_t* d_pos, void* stream);
+/* Fine codes of n stored items addressed by (cell, pos) as returned by a search.  fine [n][M].
+ * Items of cells owned by another shard yield CIS_EINVAL. */
+int cis_index_get_codes(cis_index* ix, const int32_t* cells, const uint32_t* pos, int64_t n, uint8_t* fine);
+
+/* Sharded search, step 1: this shard's ranked candidates.  d_hits [nq][L] (unused slots have
+ * id = -1, dist = +inf), d_visited [nq] (identical on every rank). */
+int cis_index_search_partial_dev(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota,
+                                 int limit, cis_hit* d_hits, int32_t* d_visited, void* stream);
+/* Sharded search, step 2 (after the all-gather): merge `world` partial lists
+ * d_parts [world][nq][L] into the final ranking. */
+int cis_merge_hits_dev(const cis_hit* d_parts, int world, int nq, int limit, int64_t* d_ids,
+                       double* d_dists, int32_t* d_n_found, int32_t* d_cells /* or NULL */,
+                       uint32_t* d_pos /* or NULL */, void* stream);
+
+/* Counters of the last search on this handle (for bench.py's roofline):
+ *   stats[0] candidates scanned (sum over queries of retrieved items on this shard)
+ *   stats[1] (query, cell) work items   stats[2] ADC tables built   stats[3] scan kernel launches */
+int cis_index_last_stats(cis_index* ix, int64_t stats[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIS_HIP_H */

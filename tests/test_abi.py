@@ -1,0 +1,66 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol that
+include/cis_hip.h declares, the ctypes table matches the header, and compute entry points fail
+loudly (never fall back to a CPU path) when no MI355X is visible."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO, has_gpu, load_golden
+
+HEADER = os.path.join(REPO, "include", "cis_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cis_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_ctypes_table_agree():
+    from columbiaimagesearch_amd import _lib
+    assert declared_symbols() == _lib.exported_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    from columbiaimagesearch_amd import _lib
+    L = _lib.lib()
+    for name in declared_symbols():
+        assert hasattr(L, name), name
+    assert L.cis_version() >= 100
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r"\bT (cis_[a-z0-9_]+)", out))
+    assert set(declared_symbols()) <= exported
+
+
+def test_hit_struct_layout():
+    from columbiaimagesearch_amd import _lib
+    assert ctypes.sizeof(_lib.cis_hit) == 32
+    assert _lib.HIT_DTYPE.fields["id"][1] == 16 and _lib.HIT_DTYPE.fields["cell"][1] == 24
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_no_gpu_means_loud_failure_not_fallback():
+    from columbiaimagesearch_amd import _lib
+    from test_lopq_hip_parity import hip_model
+    z, X, Q = load_golden("tiny")
+    m = hip_model(z)
+    with pytest.raises(_lib.HipError):
+        m.predict(X[0])
+    assert "no CPU fallback" in _lib.last_error() or "HIP" in _lib.last_error()
+
+
+def test_argument_errors_are_python_exceptions():
+    from columbiaimagesearch_amd import _lib
+    from columbiaimagesearch_amd.lopq import LOPQModel
+    with pytest.raises(ValueError):
+        LOPQModel(V=4, M=4).predict(np.zeros(8))  # no parameters yet
+    L = _lib.lib()
+    out = ctypes.c_void_p()
+    rc = L.cis_model_create(ctypes.byref(out), 8, 8, 4, 3, 16, 8, None, None, None, None, None, None, 0)
+    assert rc == _lib.CIS_EINVAL and out.value is None
+    with pytest.raises(ValueError):
+        _lib.check(rc)
