@@ -37,7 +37,7 @@ _PROTOS = {
     "cis_device_count": (c_int, []),
     "cis_set_device": (c_int, [c_int]),
     "cis_model_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "cis_model_destroy": (None, [c_void_p]),
     "cis_apply_pca": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "cis_encode": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
@@ -73,6 +73,29 @@ def exported_symbols():
     return sorted(_PROTOS)
 
 
+def _load_hip_runtime():
+    """Make ONE HIP runtime global in this process before libcis_hip.so binds to it.
+
+    libcis_hip.so is linked without a libamdhip64 dependency.  PyTorch-ROCm ships its own copy of the
+    runtime; two runtimes in one process cannot share device pointers or streams, so when torch is
+    installed its copy is the one we bind to (torch tensors are this package's device-memory and
+    stream plumbing).  Without torch the system ROCm runtime is used.
+    """
+    cands = []
+    try:
+        import torch  # noqa: F401  (loads torch/lib/libamdhip64.so)
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except ImportError:
+        pass
+    cands += ["libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    for c in cands:
+        try:
+            return ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            continue
+    raise ImportError("no HIP runtime (libamdhip64.so) found: install ROCm or PyTorch-ROCm")
+
+
 def lib():
     """Load libcis_hip.so once.  Raises ImportError with build instructions if it is absent."""
     global _lib
@@ -81,6 +104,7 @@ def lib():
             raise ImportError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C columbiaimagesearch_amd/csrc`). columbiaimagesearch_amd has no CPU fallback." % LIB_PATH)
+        _load_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(L, name)

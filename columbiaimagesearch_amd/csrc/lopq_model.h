@@ -7,6 +7,7 @@ struct cis_model {
     int h = 0, w = 0, nf = 0;  // D/2, D/M, M/2
     bool coarse_f32 = false;   // coarse centroids were given as float32
     bool has_pca = false, renorm = false;
+    bool pca_mu_f32 = false;   // the caller's pca_mu was float32: x - mu rounds in float32 for float32 x
     int device = 0;
 
     float* d_Cs32 = nullptr;   // [2][V][h]   (only when coarse_f32)

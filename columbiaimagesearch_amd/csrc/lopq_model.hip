@@ -120,7 +120,7 @@ __global__ void k_to_f64(const TI* __restrict__ in, double* __restrict__ out, in
 }
 
 // Y[n][D] = (X - mu) . P, float64, 64x64 tile per 256-thread block, 4x4 outputs per thread.
-template <typename TX>
+template <typename TX, bool SUBF32>
 __global__ __launch_bounds__(256) void k_pca_gemm(const TX* __restrict__ X, const double* __restrict__ mu,
                                                   const double* __restrict__ P, double* __restrict__ Y,
                                                   int64_t n, int D_in, int D) {
@@ -142,7 +142,14 @@ __global__ __launch_bounds__(256) void k_pca_gemm(const TX* __restrict__ X, cons
             const int idx = tid + e * 256;
             const int r = idx / 16, k = idx % 16;
             double v = 0.0;
-            if (row0 + r < n && k0 + k < D_in) v = (double)X[(row0 + r) * D_in + k0 + k] - mu[k0 + k];
+            if (row0 + r < n && k0 + k < D_in) {
+                if constexpr (SUBF32) {
+                    const float df = (float)X[(row0 + r) * D_in + k0 + k] - (float)mu[k0 + k];  // float32 - float32
+                    v = (double)df;
+                } else {
+                    v = (double)X[(row0 + r) * D_in + k0 + k] - mu[k0 + k];
+                }
+            }
             sA[k][r] = v;
         }
 #pragma unroll
@@ -392,7 +399,7 @@ extern "C" void cis_model_destroy(cis_model* m) {
 
 extern "C" int cis_model_create(cis_model** out, int D_in, int D, int V, int M, int K, int coarse_dtype,
                                 const void* Cs, const double* Rs, const double* mus, const double* subs,
-                                const double* pca_P, const double* pca_mu, int renorm) {
+                                const double* pca_P, const double* pca_mu, int pca_mu_dtype, int renorm) {
     CIS_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
     CIS_REQUIRE(Cs && Rs && mus && subs, "model parameters must not be NULL (fit the model first)");
@@ -414,6 +421,7 @@ extern "C" int cis_model_create(cis_model** out, int D_in, int D, int V, int M, 
     m->coarse_f32 = (coarse_dtype == CIS_F32);
     m->has_pca = (pca_P != nullptr);
     m->renorm = renorm != 0;
+    m->pca_mu_f32 = m->has_pca && pca_mu_dtype == CIS_F32;
     int rc = CIS_OK;
     auto fail = [&](int r) { cis_model_destroy(m); return r; };
     if ((rc = cis_build_pwprog(m->h, &m->prog_h)) != CIS_OK) return fail(rc);
@@ -457,10 +465,12 @@ int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, floa
     CIS_TRY(m->ws_y64.reserve((size_t)n * m->D * sizeof(double)));
     double* Y = m->ws_y64.as<double>();
     dim3 g((unsigned)ceil_div(n, 64), (unsigned)ceil_div(m->D, 64));
-    if (x_dtype == CIS_F32)
-        hipLaunchKernelGGL(k_pca_gemm<float>, g, dim3(256), 0, st, (const float*)dX, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);
+    if (x_dtype == CIS_F32 && m->pca_mu_f32)
+        hipLaunchKernelGGL((k_pca_gemm<float, true>), g, dim3(256), 0, st, (const float*)dX, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);
+    else if (x_dtype == CIS_F32)
+        hipLaunchKernelGGL((k_pca_gemm<float, false>), g, dim3(256), 0, st, (const float*)dX, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);
     else
-        hipLaunchKernelGGL(k_pca_gemm<double>, g, dim3(256), 0, st, (const double*)dX, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);
+        hipLaunchKernelGGL((k_pca_gemm<double, false>), g, dim3(256), 0, st, (const double*)dX, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);
     hipLaunchKernelGGL(k_pca_finish, dim3(grid1(n, 64)), dim3(64), 0, st, Y, d_out, n, m->D, m->renorm ? 1 : 0, m->prog_D);
     CIS_CHECK_HIP(hipGetLastError());
     return CIS_OK;

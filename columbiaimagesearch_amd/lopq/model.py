@@ -95,7 +95,9 @@ class LOPQModel(object):
         M, K, w = subs.shape
         if Rs.shape != (2, V, hdim, hdim) or mus.shape != (2, V, hdim) or w * M != D:
             raise ValueError("inconsistent LOPQ parameter shapes")
+        mu_f32 = False
         if P is not None:
+            mu_f32 = np.asarray(pmu).dtype == np.float32  # x - pca_mu rounds in float32 for float32 x
             P = np.ascontiguousarray(P, dtype=np.float64)
             pmu = np.ascontiguousarray(pmu, dtype=np.float64)
             if P.shape[1] != D or pmu.shape != (P.shape[0],):
@@ -107,7 +109,8 @@ class LOPQModel(object):
         L = _lib.lib()
         _lib.check(L.cis_model_create(_lib.ctypes.byref(out), D_in, D, V, M, K,
                                       _lib.CIS_F32 if coarse_f32 else _lib.CIS_F64, _lib.ptr(Cs), _lib.ptr(Rs),
-                                      _lib.ptr(mus), _lib.ptr(subs), _lib.ptr(P), _lib.ptr(pmu), 1 if renorm else 0))
+                                      _lib.ptr(mus), _lib.ptr(subs), _lib.ptr(P), _lib.ptr(pmu),
+                                      _lib.CIS_F32 if mu_f32 else _lib.CIS_F64, 1 if renorm else 0))
         self.__dict__["_hip"] = _Handle(out.value, key)
         self.__dict__["_dims"] = (D_in, D)
         return out.value

@@ -74,10 +74,14 @@ int cis_set_device(int device);
  *   mus  [2][V][h]      mean residuals
  *   subs [M][K][w]      sub-quantizer centroids, fine split j of coarse split s at s*M/2 + j
  *   pca_P [D_in][D], pca_mu [D_in]  or NULL/NULL for a plain LOPQModel (then D_in == D)
- * with h = D/2, w = D/M.  K <= 256 and V <= 4096 in this build. */
+ * with h = D/2, w = D/M.  K <= 256 and V <= 4096 in this build.
+ * pca_mu_dtype: dtype the caller's pca_mu array had.  train_pca takes np.mean of the training
+ * data (model.py:260), so a model trained on float32 features holds a float32 mean and
+ * apply_PCA's `x - pca_mu` (model.py:965) then rounds in float32 for float32 inputs; the values
+ * are passed here widened to double either way. */
 int cis_model_create(cis_model** out, int D_in, int D, int V, int M, int K, int coarse_dtype,
                      const void* Cs, const double* Rs, const double* mus, const double* subs,
-                     const double* pca_P, const double* pca_mu, int renorm);
+                     const double* pca_P, const double* pca_mu, int pca_mu_dtype, int renorm);
 void cis_model_destroy(cis_model* m);
 
 /* LOPQModelPCA.apply_PCA (model.py:961-978): out[n][D] float32.  x_dtype = dtype of X. */

@@ -60,7 +60,7 @@ def test_argument_errors_are_python_exceptions():
         LOPQModel(V=4, M=4).predict(np.zeros(8))  # no parameters yet
     L = _lib.lib()
     out = ctypes.c_void_p()
-    rc = L.cis_model_create(ctypes.byref(out), 8, 8, 4, 3, 16, 8, None, None, None, None, None, None, 0)
+    rc = L.cis_model_create(ctypes.byref(out), 8, 8, 4, 3, 16, 8, None, None, None, None, None, None, 8, 0)
     assert rc == _lib.CIS_EINVAL and out.value is None
     with pytest.raises(ValueError):
         _lib.check(rc)
