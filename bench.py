@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""Headline benchmark: LOPQ queries/sec at recall@10 on a 10M-vector index (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the search hot path over one batch of 8192 synthetic queries that are
+already resident in HBM: PCA -> coarse ranking -> multisequence plan -> ADC tables -> ADC scan +
+top-k -> merge (-> RCCL all-gather + merge when the index is sharded by coarse cell over N GPUs).
+Workload = BASELINE config C4 (10M x 128-d, LOPQModelPCA V=16, M=8, renorm) with the reference
+API's operating point quota=10000, limit=100 (cufacesearch/searcher/searcher_lopqhbase.py:833-838).
+The LOPQ model is the one the reference itself fitted on this generator (tests/golden/c2.npz).
+
+N > 1 is strong scaling: the same 10M index is sharded by coarse cell, every rank sees the whole
+query batch, scans its own cells and the per-shard top-`limit` lists are all-gathered over RCCL.
+
+Extra objects in the JSON line: "roofline" for the ADC scan kernel (algorithmic bytes =
+candidates x M, time from HIP events recorded on the launch stream inside the library) and
+"cpu_baseline" = the oracle (numpy restatement of the reference, reference-shaped per-candidate
+loop, 1 core) timed on this host on a bounded sample of the same queries, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+NQ = 8192          # queries per step
+QUOTA, LIMIT = 10000, 100
+N_CHUNKS = 80      # the database is generated in 80 equal chunks with per-chunk seeds
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def load_model():
+    from columbiaimagesearch_amd.lopq import LOPQModelPCA
+    z = np.load(os.path.join(REPO, "tests", "golden", "c2.npz"))
+    nf = int(z["num_fine_splits"])
+    subs = tuple([z["subs"][s, j] for j in range(nf)] for s in range(2))
+    params = ((z["Cs"][0], z["Cs"][1]), (z["Rs"][0], z["Rs"][1]), (z["mus"][0], z["mus"][1]), subs,
+              z["pca_P"], z["pca_mu"])
+    return LOPQModelPCA(renorm=bool(z["renorm"]), parameters=params), z
+
+
+def mixture_centers():
+    # same mixture as tests/golden_inputs.c2_inputs (the data the model was trained on)
+    return np.random.RandomState(2).randn(256, 128)
+
+
+def gen_chunk(centers_dev, chunk, n, device):
+    """n unit-norm float64 128-d vectors of chunk `chunk` (identical on every rank)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(1000 + chunk)
+    comp = torch.randint(0, centers_dev.shape[0], (n,), generator=g, device=device)
+    x = centers_dev[comp] + 0.35 * torch.randn((n, centers_dev.shape[1]), generator=g, device=device, dtype=torch.float64)
+    return x / x.norm(dim=1, keepdim=True)
+
+
+def make_queries(x0, batch, nq, device):
+    """Perturbed database points of chunk 0 (so that a true neighbour exists)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(77000 + batch)
+    idx = torch.randint(0, x0.shape[0], (nq,), generator=g, device=device)
+    q = x0[idx] + 0.05 * torch.randn((nq, x0.shape[1]), generator=g, device=device, dtype=torch.float64) / np.sqrt(x0.shape[1])
+    return (q / q.norm(dim=1, keepdim=True)).contiguous()
+
+
+def exact_nn(queries, centers_dev, n_total, chunk_n, device):
+    """True nearest neighbour ids (exact L2 on the unit sphere = max dot), streamed over chunks."""
+    best = torch.full((queries.shape[0],), -2.0, device=device, dtype=torch.float32)
+    arg = torch.zeros(queries.shape[0], dtype=torch.int64, device=device)
+    qf = queries.float()
+    for c in range(n_total // chunk_n):
+        x = gen_chunk(centers_dev, c, chunk_n, device).float()
+        s = qf @ x.t()
+        v, i = s.max(dim=1)
+        upd = v > best
+        best = torch.where(upd, v, best)
+        arg = torch.where(upd, i + c * chunk_n, arg)
+    return arg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("CIS_BENCH_N", 10_000_000)))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    from columbiaimagesearch_amd import _lib
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    from columbiaimagesearch_amd.lopq.search import merge_hits_dev
+    _lib.check(_lib.lib().cis_set_device(local_rank))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+
+    model, z = load_model()
+    N = args.n - args.n % (N_CHUNKS * world)
+    chunk_n = N // N_CHUNKS
+    centers = torch.as_tensor(mixture_centers(), device=device)
+
+    # ---- build: data-parallel encode on the GPUs, codes all-gathered, index sharded by cell -----
+    t_build = time.time()
+    my_chunks = [c for c in range(N_CHUNKS) if c * world // N_CHUNKS == rank]
+    coarse_l, fine_l = [], []
+    for c in my_chunks:
+        x = gen_chunk(centers, c, chunk_n, device)
+        co, fi = model.predict_batch_dev(x)
+        coarse_l.append(co)
+        fine_l.append(fi)
+    coarse = torch.cat(coarse_l)
+    fine = torch.cat(fine_l)
+    torch.cuda.synchronize()
+    encode_s = time.time() - t_build
+    if world > 1:
+        call = torch.empty((world,) + tuple(coarse.shape), dtype=coarse.dtype, device=device)
+        fall = torch.empty((world,) + tuple(fine.shape), dtype=fine.dtype, device=device)
+        dist.all_gather_into_tensor(call, coarse)
+        dist.all_gather_into_tensor(fall, fine)
+        coarse, fine = call.reshape(-1, 2), fall.reshape(-1, fine.shape[1])
+    coarse_h = coarse.cpu().numpy().view(np.uint16)
+    fine_h = fine.cpu().numpy()
+    V = model.V
+    cell = coarse_h[:, 0].astype(np.int64) * V + coarse_h[:, 1]
+    counts = np.bincount(cell, minlength=V * V)
+    shard = None
+    if world > 1:
+        # greedy balance of cell populations over ranks (identical on every rank)
+        owner = np.zeros(V * V, dtype=np.int32)
+        load = np.zeros(world, dtype=np.int64)
+        for cid in np.argsort(-counts, kind="stable"):
+            r = int(np.argmin(load))
+            owner[cid] = r
+            load[r] += counts[cid]
+        shard = (rank, world, owner)
+    searcher = LOPQSearcherHIP(model, shard=shard)
+    searcher.add_codes_array(coarse_h, fine_h, ids=np.arange(N, dtype=np.int64), dedup=False)
+    build_s = time.time() - t_build
+
+    # ---- queries (resident in HBM before the timed region) --------------------------------------
+    x0 = gen_chunk(centers, 0, chunk_n, device)
+    n_batches = args.warmup + args.steps
+    qbatches = [make_queries(x0, b, NQ, device) for b in range(min(n_batches, 8))]
+
+    def step(q):
+        if world == 1:
+            return searcher.search_batch_dev(q, quota=QUOTA, limit=LIMIT)
+        hits, visited = searcher.search_partial_dev(q, quota=QUOTA, limit=LIMIT)
+        parts = torch.empty((world,) + tuple(hits.shape), dtype=torch.uint8, device=device)
+        dist.all_gather_into_tensor(parts, hits)
+        out = merge_hits_dev(parts)
+        out["visited"] = visited
+        return out
+
+    for b in range(args.warmup):
+        step(qbatches[b % len(qbatches)])
+    searcher.set_profiling(True)
+    searcher.read_profile()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cand = 0
+    out = None
+    for b in range(args.steps):
+        out = step(qbatches[(args.warmup + b) % len(qbatches)])
+        cand += searcher.last_stats()["candidates"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    prof = searcher.read_profile()
+    searcher.set_profiling(False)
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        ct = torch.tensor([cand], device=device, dtype=torch.int64)
+        dist.all_reduce(ct)
+        cand_all = int(ct.item())
+    else:
+        cand_all = cand
+
+    # ---- recall@10 (lopq/lopq/eval.py:92-143 semantics), untimed, rank 0 -----------------------
+    recall10 = None
+    qr = qbatches[0][:1024].contiguous()
+    res = step(qr) if world > 1 else searcher.search_batch_dev(qr, quota=QUOTA, limit=LIMIT)
+    if rank == 0:
+        nn = exact_nn(qr, centers, N, chunk_n, device)
+        recall10 = float((res["ids"][:, :10] == nn[:, None]).any(dim=1).float().mean().item())
+
+    # ---- CPU baseline + parity spot check: oracle on a bounded sample (rank 0, N=1) ------------
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import lopq_oracle as O
+        om = O.OracleModel.from_npz(z)
+        oix = O.OracleCSRIndex(om, coarse_h, fine_h)
+        qh = qr.cpu().numpy()
+        gi, gd = res["ids"].cpu().numpy(), res["dists"].cpu().numpy()
+        n_loop, t_loop, ok, max_rel = 0, 0.0, True, 0.0
+        while t_loop < 12.0 and n_loop < 256:
+            tq = time.perf_counter()
+            ids, dd, _ = oix.search_loop(qh[n_loop], quota=QUOTA, limit=LIMIT)
+            t_loop += time.perf_counter() - tq
+            ok = ok and bool((gi[n_loop, :len(ids)] == ids).all())
+            max_rel = max(max_rel, float(np.max(np.abs(gd[n_loop, :len(ids)] - dd) / np.maximum(dd, 1e-300))))
+            n_loop += 1
+        n_vec, t_vec = 0, 0.0
+        while t_vec < 5.0 and n_vec < 1024:
+            tq = time.perf_counter()
+            ids, dd, _ = oix.search(qh[n_vec], quota=QUOTA, limit=LIMIT)
+            t_vec += time.perf_counter() - tq
+            ok = ok and bool((gi[n_vec, :len(ids)] == ids).all())
+            n_vec += 1
+        cpu = {"value": n_loop / t_loop, "unit": "queries/s", "cores": 1, "kind": "port",
+               "sample": "%d queries of the timed workload (quota=%d, limit=%d, 10M index) through the oracle's "
+                         "reference-shaped per-candidate loop (search.py:166-175); vectorised numpy restatement: "
+                         "%.1f queries/s on %d queries" % (n_loop, QUOTA, LIMIT, n_vec / t_vec, n_vec)}
+        parity = {"queries_checked": max(n_loop, n_vec), "ids_bit_exact": ok, "max_rel_dist_err": max_rel}
+
+    if rank == 0:
+        M = model.M
+        launches = max(prof["scan_launches"], 1)
+        scan_s = prof["scan_ms"] / 1e3
+        algo_bytes = cand * M  # this rank's scan kernel
+        achieved = algo_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "scan_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "queries/sec @ recall@10 on 10M LOPQ index",
+            "value": NQ * args.steps / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "recall_at_10": recall10,
+            "config": {"workload": "C4: %d x 128-d float64 unit vectors (256-component mixture), LOPQModelPCA V=16 M=8 "
+                                   "renorm, %d queries/step, quota=%d limit=%d" % (N, NQ, QUOTA, LIMIT),
+                       "index_vectors": N, "queries_per_step": NQ, "quota": QUOTA, "limit": LIMIT,
+                       "sharding": "by coarse cell over %d GPU(s)%s" % (world, ", RCCL all-gather merge" if world > 1 else ""),
+                       "candidates_per_query": cand_all / float(NQ * args.steps)},
+            "roofline": {"bound": "hbm", "kernel": "k_adc_scan", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes / launches,
+                         "avg_launch_ms": prof["scan_ms"] / launches, "launches": launches},
+            "stage_ms_per_step": {k: prof[k] / args.steps for k in ("front_ms", "tables_ms", "scan_ms", "merge_ms")},
+            "cpu_baseline": cpu,
+            "parity": parity,
+            "build": {"encode_s": encode_s, "total_s": build_s, "encode_vectors_per_s": len(my_chunks) * chunk_n / encode_s},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -540,6 +540,12 @@ struct cis_index {
     DevBuf w_xp, w_cd, w_order, w_sorted, w_plan, w_off, w_items, w_tabs, w_T, w_hits, w_hitn, w_part, w_q,
         w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos;
     int64_t stats[4] = {0, 0, 0, 0};
+    // optional stage timing (hipEvents on the launch stream)
+    bool profiling = false;
+    struct ProfRec { hipEvent_t ev[5]; bool has_scan; };
+    std::vector<ProfRec> prof;
+    double prof_ms[4] = {0, 0, 0, 0};
+    int64_t prof_launches = 0;
 
     bool owns(int64_t cell) const {
         if (world <= 1) return true;
@@ -729,6 +735,31 @@ extern "C" int cis_index_get_codes(cis_index* ix, const int32_t* cells, const ui
     return CIS_OK;
 }
 
+extern "C" int cis_index_set_profiling(cis_index* ix, int enable) {
+    CIS_REQUIRE(ix != nullptr, "index is NULL");
+    ix->profiling = enable != 0;
+    return CIS_OK;
+}
+
+extern "C" int cis_index_read_profile(cis_index* ix, double ms[4], int64_t* launches) {
+    CIS_REQUIRE(ix != nullptr && ms != nullptr, "NULL argument");
+    for (auto& r : ix->prof) {
+        CIS_CHECK_HIP(hipEventSynchronize(r.ev[4]));
+        for (int i = 0; i < 4; ++i) {
+            float t = 0.f;
+            CIS_CHECK_HIP(hipEventElapsedTime(&t, r.ev[i], r.ev[i + 1]));
+            ix->prof_ms[i] += t;
+        }
+        if (r.has_scan) ix->prof_launches += 1;
+        for (int i = 0; i < 5; ++i) (void)hipEventDestroy(r.ev[i]);
+    }
+    ix->prof.clear();
+    for (int i = 0; i < 4; ++i) { ms[i] = ix->prof_ms[i]; ix->prof_ms[i] = 0; }
+    if (launches) *launches = ix->prof_launches;
+    ix->prof_launches = 0;
+    return CIS_OK;
+}
+
 extern "C" int cis_index_last_stats(cis_index* ix, int64_t stats[4]) {
     CIS_REQUIRE(ix != nullptr && stats != nullptr, "NULL argument");
     for (int i = 0; i < 4; ++i) stats[i] = ix->stats[i];
@@ -764,6 +795,15 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                         int32_t* d_visited, hipStream_t st) {
     cis_model* m = ix->m;
     const int V = m->V, D = m->D, K = m->K, M = m->M, h = m->h, nf = m->nf;
+    cis_index::ProfRec pr;
+    pr.has_scan = false;
+    auto mark = [&](int i) -> int {
+        if (!ix->profiling) return CIS_OK;
+        CIS_CHECK_HIP(hipEventCreate(&pr.ev[i]));
+        CIS_CHECK_HIP(hipEventRecord(pr.ev[i], st));
+        return CIS_OK;
+    };
+    CIS_TRY(mark(0));
     // 1. LOPQ-space queries
     const void* xp = dQ;
     int xp_dtype = q_dtype;
@@ -814,6 +854,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     ix->stats[2] += n_tabs;
     CIS_REQUIRE(n_items < ((int64_t)1 << 31) && n_tabs < ((int64_t)1 << 31), "query batch too large");
     // 3. emit items + table list
+    CIS_TRY(mark(1));  // the plan read-back above is part of the front end
     CIS_TRY(ix->w_items.reserve((size_t)(n_items + 1) * sizeof(WorkItem)));
     CIS_TRY(ix->w_tabs.reserve((size_t)(n_tabs + 1) * sizeof(TabDesc)));
     CIS_TRY(ix->w_T.reserve((size_t)(n_tabs + 1) * nf * K * sizeof(double)));
@@ -839,7 +880,9 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                                m->d_Cs64, m->d_Rt, m->d_mus, m->d_subs, tabs, V, h, m->w, nf, K, D, T, m->prog_w);
     }
     // 4. ADC scan + block top-k
+    CIS_TRY(mark(2));
     if (n_items > 0) {
+        pr.has_scan = true;
         const uint8_t* codes = ix->d_codes.as<uint8_t>();
         const int64_t* ids = ix->d_ids.as<int64_t>();
         cis_hit* hits = ix->w_hits.as<cis_hit>();
@@ -850,6 +893,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         ix->stats[3] += 1;
     }
     // 5. per-query merge
+    CIS_TRY(mark(3));
     {
         const cis_hit* hits = ix->w_hits.as<cis_hit>();
         const int* hitn = ix->w_hitn.as<int>();
@@ -862,6 +906,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     }
     hipLaunchKernelGGL(k_copy_visited, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, plan, nq, d_visited);
     CIS_CHECK_HIP(hipGetLastError());
+    CIS_TRY(mark(4));
+    if (ix->profiling) ix->prof.push_back(pr);
     return CIS_OK;
 }
 

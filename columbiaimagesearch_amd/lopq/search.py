@@ -307,6 +307,19 @@ class LOPQSearcherHIP(LOPQSearcherBase):
         return {"candidates": int(st[0]), "items": int(st[1]), "tables": int(st[2]), "scan_launches": int(st[3])}
 
 
+    def set_profiling(self, enable=True):
+        """Record HIP events around the search stages on the launch stream (see read_profile)."""
+        _lib.check(_lib.lib().cis_index_set_profiling(self._ix, 1 if enable else 0))
+
+    def read_profile(self):
+        """Accumulated stage times in ms since the last read (waits for the recorded events)."""
+        ms = np.zeros(4, dtype=np.float64)
+        n = _lib.c_int64(0)
+        _lib.check(_lib.lib().cis_index_read_profile(self._ix, _lib.ptr(ms), _lib.ctypes.byref(n)))
+        return {"front_ms": float(ms[0]), "tables_ms": float(ms[1]), "scan_ms": float(ms[2]),
+                "merge_ms": float(ms[3]), "scan_launches": int(n.value)}
+
+
 def merge_hits_dev(parts, with_codes=False):
     """Merge per-shard hit lists parts [world, nq, L, 32] (uint8, on the GPU) into the final ranking
     by (dist, visit_rank, pos).  Returns dict of torch tensors like search_batch_dev."""

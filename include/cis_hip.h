@@ -159,6 +159,15 @@ int cis_merge_hits_dev(const cis_hit* d_parts, int world, int nq, int limit, int
  *   stats[1] (query, cell) work items   stats[2] ADC tables built   stats[3] scan kernel launches */
 int cis_index_last_stats(cis_index* ix, int64_t stats[4]);
 
+/* Stage timing with HIP events recorded on the stream the kernels are launched on (bench.py's
+ * roofline).  While enabled every search records events around its stages; read_profile waits for
+ * them, returns the accumulated milliseconds since the previous read and clears the accumulators:
+ *   ms[0] front end (PCA, coarse distances, rank, multisequence plan)   ms[1] ADC tables
+ *   ms[2] ADC scan + block top-k                                         ms[3] per-query merge
+ *   *launches = number of scan kernel launches accumulated. */
+int cis_index_set_profiling(cis_index* ix, int enable);
+int cis_index_read_profile(cis_index* ix, double ms[4], int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -432,6 +432,41 @@ class OracleCSRIndex(object):
         return self.ids[pos[order]], dists[order], visited
 
 
+    def search_loop(self, x, quota=10, limit=None):
+        """Same result as search(), computed with the reference's per-candidate Python loop
+        (compute_distances, lopq/lopq/search.py:166-175): the "reference-equivalent CPU" that
+        bench.py times.  Only the visited cells are materialised as (id, code) tuples."""
+        m = self.model
+        if m.has_pca:
+            x = apply_pca(m, x)
+        V = m.V
+        retrieved, visited = [], 0
+        for _, (c0, c1) in multisequence(m, x):
+            cid = int(c0) * V + int(c1)
+            a, b = self.offsets[cid], self.offsets[cid + 1]
+            coarse = (int(c0), int(c1))
+            retrieved += [(self.ids[p], (coarse, tuple(self.fine[p]))) for p in range(a, b)]
+            visited += 1
+            if len(retrieved) >= quota:
+                break
+        memo = [{}, {}]
+        scored = []
+        for item in retrieved:
+            coarse, fine = item[1]
+            tabs = []
+            for s in (0, 1):
+                c = coarse[s]
+                if c not in memo[s]:
+                    memo[s][c] = subquantizer_distances(m, x, coarse, coarse_split=s)
+                tabs += memo[s][c]
+            scored.append((sum([tabs[i][fc] for i, fc in enumerate(fine)]), item))
+        scored = sorted(scored, key=lambda d: d[0])
+        if limit is None:
+            limit = quota
+        scored = scored[:limit]
+        return (np.array([it[0] for _, it in scored], dtype=np.int64), np.array([d for d, _ in scored]), visited)
+
+
 def recall_at(true_nn, result_ids, ks=(1, 10, 100)):
     """Fraction of queries whose true nearest neighbour is in the top-k returned ids.
     Semantics of get_recall, lopq/lopq/eval.py:92-143."""
