@@ -64,6 +64,7 @@ _PROTOS = {
                                    c_void_p]),
     "cis_index_last_stats": (c_int, [c_void_p, c_void_p]),
     "cis_index_set_profiling": (c_int, [c_void_p, c_int]),
+    "cis_index_set_scan_mode": (c_int, [c_void_p, c_int]),
     "cis_index_read_profile": (c_int, [c_void_p, c_void_p, POINTER(c_int64)]),
 }
 

@@ -205,6 +205,36 @@ __global__ void k_plan_scan(const PlanOut* __restrict__ plan, int nq, int64_t* _
     }
 }
 
+// ---- work items sorted by coarse cell (counting sort; order inside a cell is irrelevant) ----------
+__global__ void k_item_hist(const WorkItem* __restrict__ items, int64_t n, int* __restrict__ cell_cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&cell_cnt[items[i].cell], 1);
+}
+
+__global__ void k_cell_scan(int* __restrict__ cell_cnt /* in: counts, out: exclusive offsets */, int ncells) {
+    __shared__ int part[256];
+    const int tid = threadIdx.x;
+    const int per = (ncells + 255) / 256;
+    const int a = tid * per, b = (a + per < ncells) ? a + per : ncells;
+    int s = 0;
+    for (int c = a; c < b; ++c) s += cell_cnt[c];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int k = 0; k < 256; ++k) { const int x = part[k]; part[k] = run; run += x; }
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int c = a; c < b; ++c) { const int x = cell_cnt[c]; cell_cnt[c] = run; run += x; }
+}
+
+__global__ void k_item_scatter(const WorkItem* __restrict__ items, int64_t n, int* __restrict__ cell_off,
+                               int* __restrict__ order) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[atomicAdd(&cell_off[items[i].cell], 1)] = (int)i;
+}
+
 // ================================================================================================
 // kernel: ADC tables  (lopq/lopq/model.py:673-704 for one (query, split, coarse id))
 // ================================================================================================
@@ -325,8 +355,9 @@ static __device__ __forceinline__ double adc_generic(const uint8_t* __restrict__
 template <int M /* 0 = generic */, int CAP, int U>
 __global__ __launch_bounds__(256) void k_adc_scan(const WorkItem* __restrict__ items, const double* __restrict__ T,
                                                   const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids,
-                                                  int Mrt, int K, int limit, cis_hit* __restrict__ item_hits,
-                                                  int* __restrict__ item_n) {
+                                                  int Mrt, int K, int limit, int S, const int* __restrict__ item_flag,
+                                                  cis_hit* __restrict__ item_hits, int* __restrict__ item_n) {
+    if (item_flag && !item_flag[blockIdx.x]) return;  // only redo what the fast kernel gave up on
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* ka = reinterpret_cast<uint64_t*>(smem);  // [CAP] dist bits
     uint64_t* kb = ka + CAP;                           // [CAP] position inside the chunk
@@ -365,6 +396,7 @@ __global__ __launch_bounds__(256) void k_adc_scan(const WorkItem* __restrict__ i
         }
         __syncthreads();
         const int cnt = s_cnt;
+        __syncthreads();  // everybody has read the count before the next iteration's appends change it
         if (cnt > CAP - 256 * U && base + 256 * U < len) {
             for (int e = cnt + tid; e < CAP; e += 256) { ka[e] = ~0ull; kb[e] = ~0ull; }
             __syncthreads();
@@ -383,7 +415,7 @@ __global__ __launch_bounds__(256) void k_adc_scan(const WorkItem* __restrict__ i
         block_bitonic<CAP, 256, false>(ka, kb, nullptr);
         cnt = limit;
     }
-    cis_hit* out = item_hits + (int64_t)blockIdx.x * limit;
+    cis_hit* out = item_hits + (int64_t)blockIdx.x * S;
     for (int e = tid; e < cnt; e += 256) {
         cis_hit hh;
         hh.dist = __longlong_as_double((long long)ka[e]);
@@ -394,6 +426,515 @@ __global__ __launch_bounds__(256) void k_adc_scan(const WorkItem* __restrict__ i
         out[e] = hh;
     }
     if (tid == 0) item_n[blockIdx.x] = cnt;
+}
+
+
+// ================================================================================================
+// kernel: ADC scan v2 -- float32 prefilter in LDS, barrier-free wave-private top-k on exact keys
+// ================================================================================================
+// Why a second kernel: v1 above is exact by construction (float64 tables and sums) but is bound by
+// LDS bank conflicts (32 lanes gathering from one 256-entry table collide ~3.5-way), by float64
+// adds and by workgroup barriers every iteration (rocprof: 59 % of wave cycles waiting).  v2 returns
+// bit-identical results with a different division of labour:
+//
+//  * the two half tables sit in LDS as float32 in ENTRY-major order tab[k][j] (j fastest).  Bank =
+//    (k*M + j) mod 32, so sub-quantizer j owns the 32/M banks {j, j+M, ...}.  Lane l walks the
+//    sub-quantizers in a rotated order (step t -> table rot(l, t)), so at every step the 32 lanes of
+//    an LDS lane group are spread evenly over all M tables: 32/M lanes into 32/M banks instead of
+//    32 lanes into 32 banks;
+//  * each candidate gets a float32 sum d32 (any order).  |d32 - d64| <= eps*d64 with
+//    eps = 2*M*2^-24 (entries are >= 0: one rounding per converted entry, M-1 per add).  The hot
+//    loop only REJECTS candidates with d32 > bound*(1+3eps), where `bound` is an exact float64
+//    distance that at least `limit` already-seen candidates do not exceed; a rejected candidate is
+//    therefore strictly worse than `limit` others and cannot be in the exact top-`limit`;
+//  * everything that is not rejected is appended (position only) to a wave-private LDS region -- no
+//    workgroup barrier in the loop.  When a region fills up its wave re-scores the new entries
+//    EXACTLY (float64 table entries from global memory, summed left to right as search.py:173),
+//    selects its own limit-th and ceil(limit/4)-th smallest exact keys (dist, pos) with register
+//    bitonic sorts, publishes them, and keeps only entries that are within its own top-`limit` and
+//    not above the block bound  min( max_w wt[w], min_w wl[w] )  built from the published values
+//    (each is a distance that >= `limit` seen candidates do not exceed).  Exact ties -- thousands of
+//    identical codes are common in real indexes -- are resolved on (dist, pos), never on float32;
+//  * at the end every wave holds <= `limit` exact hits; they are written as cis_hit and the
+//    per-query merge ranks them by (dist, visit_rank, pos).
+template <int NR>
+__device__ __forceinline__ void wave_bitonic_sort(uint32_t (&k)[NR]) {
+    const int lane = threadIdx.x & 63;
+    constexpr int N = NR * 64;  // element e = lane*NR + r
+#pragma unroll
+    for (int kk = 2; kk <= N; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            if (j < NR) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    if ((r & j) == 0) {
+                        const bool asc = (((lane * NR + r) & kk) == 0);
+                        const uint32_t a = k[r], b = k[r | j];
+                        const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+                        k[r] = asc ? lo : hi;
+                        k[r | j] = asc ? hi : lo;
+                    }
+                }
+            } else {
+                const int lj = j / NR;
+                const bool lower = ((lane & lj) == 0);
+                const bool asc = (((lane * NR) & kk) == 0);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const uint32_t o = (uint32_t)__shfl_xor((int)k[r], lj);
+                    const uint32_t mn = k[r] < o ? k[r] : o, mx = k[r] < o ? o : k[r];
+                    k[r] = (lower == asc) ? mn : mx;
+                }
+            }
+        }
+    }
+}
+
+template <int NR>
+__device__ __forceinline__ uint32_t wave_kth(const uint32_t (&k)[NR], int i) {  // i-th smallest after the sort
+    uint32_t v = k[0];
+#pragma unroll
+    for (int r = 1; r < NR; ++r)
+        if ((i % NR) == r) v = k[r];
+    return (uint32_t)__shfl((int)v, i / NR);
+}
+
+struct ScanShared {
+    uint64_t wt[4];  // per wave: exact dist bits that >= ceil(limit/4) of its candidates do not exceed
+    uint64_t wl[4];  // per wave: exact dist bits that >= limit of its candidates do not exceed
+    float wtf[4];    // the same two, rounded UP to float32, for the hot loop
+    float wlf[4];
+    int wcnt[4];     // survivors per wave at the end
+};
+
+static __device__ __forceinline__ float lds_ld(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+static __device__ __forceinline__ uint64_t lds_ld(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+static __device__ __forceinline__ void lds_st(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+static __device__ __forceinline__ void lds_st(uint64_t* p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+static __device__ __forceinline__ float block_bound_f32(const ScanShared* sh) {
+    const float t = fmaxf(fmaxf(lds_ld(&sh->wtf[0]), lds_ld(&sh->wtf[1])), fmaxf(lds_ld(&sh->wtf[2]), lds_ld(&sh->wtf[3])));
+    const float l = fminf(fminf(lds_ld(&sh->wlf[0]), lds_ld(&sh->wlf[1])), fminf(lds_ld(&sh->wlf[2]), lds_ld(&sh->wlf[3])));
+    return fminf(t, l);
+}
+static __device__ __forceinline__ uint64_t block_bound_u64(const ScanShared* sh) {
+    uint64_t t = lds_ld(&sh->wt[0]);
+    uint64_t l = lds_ld(&sh->wl[0]);
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        const uint64_t a = lds_ld(&sh->wt[i]), b = lds_ld(&sh->wl[i]);
+        t = a > t ? a : t;
+        l = b < l ? b : l;
+    }
+    return t < l ? t : l;
+}
+
+// exact float64 distance of one candidate: table entries from global memory, summed left to right
+static __device__ __forceinline__ double adc64_global(const uint8_t* __restrict__ codes, int64_t p, int M, int K,
+                                                      const double* __restrict__ t0, const double* __restrict__ t1) {
+    const uint8_t* c = codes + p * M;
+    const int nf = M / 2;
+    double d = t0[c[0]];
+    for (int j = 1; j < nf; ++j) d = d + t0[j * K + c[j]];
+    for (int j = 0; j < nf; ++j) d = d + t1[j * K + c[nf + j]];
+    return d;
+}
+
+// exact float64 distance from the code words (little-endian bytes = fine codes 0..M-1)
+template <int M>
+static __device__ __forceinline__ double adc64_words(const uint32_t (&cw)[(M + 3) / 4], int K, const double* __restrict__ t0,
+                                                     const double* __restrict__ t1) {
+    constexpr int nf = M / 2;
+    double f[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const uint32_t c = (cw[j >> 2] >> (8 * (j & 3))) & 255u;
+        f[j] = (j < nf) ? t0[j * K + c] : t1[(j - nf) * K + c];
+    }
+    double d = f[0];
+#pragma unroll
+    for (int j = 1; j < M; ++j) d = d + f[j];
+    return d;
+}
+
+// hi word -> the largest float64 bit pattern with that hi word (a distance no smaller than any
+// distance whose bits start with `vhi`); infinities stay infinite
+static __device__ __forceinline__ uint64_t hi_to_bound(uint32_t vhi) {
+    return vhi >= 0x7ff00000u ? 0x7ff0000000000000ull : (((uint64_t)vhi << 32) | 0xffffffffull);
+}
+
+// Exact re-score of the new entries [nexact, cnt), own top-L cut on exact (dist, pos) keys, publication
+// of this wave's bounds, filtering against the block bound.  Returns the new entry count (<= L).
+// Region entries are always in increasing candidate position (appends are, and the compaction is
+// stable), so among exactly equal distances "first in the region" == "smallest pos".
+// Wave-synchronous: no s_barrier inside.
+template <int M, int NR>
+__device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt, int nexact, int L, int Lw,
+                                            ScanShared* sh, int w, const uint8_t* __restrict__ codes, int64_t start,
+                                            int K, const double* __restrict__ t0, const double* __restrict__ t1) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t INF64 = 0x7ff0000000000000ull;
+    // new entries: M <= 8 stashed the code itself in the key slot at append time; M = 16 re-reads it
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int e = nexact + lane + 64 * i;
+        if (e < cnt) {
+            uint32_t cw[(M + 3) / 4];
+            if constexpr (M <= 8) {
+                const uint64_t c = rk[e];
+                cw[0] = (uint32_t)c;
+                if constexpr (M == 8) cw[1] = (uint32_t)(c >> 32);
+            } else {
+                const uint4 c = *reinterpret_cast<const uint4*>(codes + (start + rp[e]) * 16);
+                cw[0] = c.x; cw[1] = c.y; cw[2] = c.z; cw[3] = c.w;
+            }
+            rk[e] = (uint64_t)__double_as_longlong(adc64_words<M>(cw, K, t0, t1));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t hi[NR], lo[NR], pp[NR], shi[NR];
+    bool keep[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int e = r * 64 + lane;
+        keep[r] = e < cnt;
+        const uint64_t k = keep[r] ? rk[e] : ~0ull;
+        hi[r] = (uint32_t)(k >> 32);
+        lo[r] = (uint32_t)k;
+        pp[r] = keep[r] ? rp[e] : 0xffffffffu;
+        shi[r] = hi[r];
+    }
+    wave_bitonic_sort<NR>(shi);
+    const uint64_t boundW = (cnt >= Lw) ? hi_to_bound(wave_kth<NR>(shi, Lw - 1)) : INF64;
+    uint64_t boundL = INF64;
+    if (cnt >= L) {  // cut to this wave's own exact top-L
+        const uint32_t vhi = wave_kth<NR>(shi, L - 1);
+        boundL = hi_to_bound(vhi);
+        int c_less = 0, g = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            c_less += __popcll(__ballot(keep[r] && hi[r] < vhi));
+            g += __popcll(__ballot(keep[r] && hi[r] == vhi));
+        }
+        int need = L - c_less;  // members of the group {hi == vhi} to keep, 1 <= need <= g
+        if (need >= g) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) keep[r] = keep[r] && hi[r] <= vhi;
+        } else {
+            // low word of the first group member in region order; are all members equal to it?
+            uint32_t lo_first = 0;
+            bool found = false, uniform = true;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const bool in_g = keep[r] && hi[r] == vhi;
+                const unsigned long long m = __ballot(in_g);
+                if (!found && m) {
+                    lo_first = (uint32_t)__shfl((int)lo[r], __ffsll((long long)m) - 1);
+                    found = true;
+                }
+                if (found) uniform = uniform && (__ballot(in_g && lo[r] != lo_first) == 0ull);
+            }
+            uint32_t vlo = lo_first;
+            if (!uniform) {
+                uint32_t t2[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) t2[r] = (keep[r] && hi[r] == vhi) ? lo[r] : 0xffffffffu;
+                wave_bitonic_sort<NR>(t2);
+                vlo = wave_kth<NR>(t2, need - 1);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) need -= __popcll(__ballot(keep[r] && hi[r] == vhi && lo[r] < vlo));
+            }
+            // exact ties (hi, lo) == (vhi, vlo): the first `need` in region order have the smallest positions
+            int seen = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const bool tie = keep[r] && hi[r] == vhi && lo[r] == vlo;
+                const unsigned long long m = __ballot(tie);
+                const int rank = seen + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                keep[r] = keep[r] && (hi[r] < vhi || (hi[r] == vhi && (lo[r] < vlo || (tie && rank < need))));
+                seen += __popcll(m);
+            }
+        }
+    }
+    if (lane == 0) {
+        if (boundW < lds_ld(&sh->wt[w])) { lds_st(&sh->wt[w], boundW); lds_st(&sh->wtf[w], __double2float_ru(__longlong_as_double((long long)boundW))); }
+        if (boundL < lds_ld(&sh->wl[w])) { lds_st(&sh->wl[w], boundL); lds_st(&sh->wlf[w], __double2float_ru(__longlong_as_double((long long)boundL))); }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const uint64_t bound = block_bound_u64(sh);
+    int ncnt = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const uint64_t k = ((uint64_t)hi[r] << 32) | lo[r];
+        const bool kp = keep[r] && (k <= bound);
+        const unsigned long long m = __ballot(kp);
+        const int idx = ncnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (kp) { rk[idx] = k; rp[idx] = pp[r]; }
+        ncnt += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return ncnt;
+}
+
+// Drop entries above the (final) block bound; entries already carry exact keys.  Stable.
+template <int NR>
+__device__ __forceinline__ int wave_filter(uint64_t* rk, uint32_t* rp, int cnt, const ScanShared* sh) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t bound = block_bound_u64(sh);
+    uint64_t k[NR];
+    uint32_t pp[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int e = r * 64 + lane;
+        k[r] = e < cnt ? rk[e] : ~0ull;
+        pp[r] = e < cnt ? rp[e] : 0u;
+    }
+    int ncnt = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const bool kp = (r * 64 + lane < cnt) && (k[r] <= bound);
+        const unsigned long long m = __ballot(kp);
+        const int idx = ncnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (kp) { rk[idx] = k[r]; rp[idx] = pp[r]; }
+        ncnt += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return ncnt;
+}
+
+template <int M>
+struct RotConsts {
+    uint32_t sh[4];   // bit offset of the byte used at sub-step tq inside the selected dword
+    uint32_t cj[M];   // (table index << 2) for step t
+    uint32_t hsel;    // which dword this lane starts with
+};
+
+template <int M>
+__device__ __forceinline__ RotConsts<M> make_rot(int lane) {
+    RotConsts<M> rc;
+    const int r = lane & (M - 1);
+    const int h = r >> 2, q = r & 3;
+    rc.hsel = (uint32_t)h;
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq) rc.sh[tq] = 8u * (uint32_t)((q + tq) & 3);
+#pragma unroll
+    for (int t = 0; t < M; ++t) {
+        const int th = t >> 2, tq = t & 3;
+        const int j = ((h ^ th) << 2) | ((q + tq) & 3);
+        rc.cj[t] = (uint32_t)j << 2;
+    }
+    return rc;
+}
+
+// one candidate's code as 32-bit words (little-endian bytes = fine codes 0..M-1)
+template <int M>
+struct CodeWords { uint32_t w[(M + 3) / 4]; };
+
+template <int M>
+__device__ __forceinline__ CodeWords<M> load_code(const uint8_t* __restrict__ codes, int64_t p) {
+    CodeWords<M> c;
+    if constexpr (M == 4) {
+        c.w[0] = *reinterpret_cast<const uint32_t*>(codes + p * 4);
+    } else if constexpr (M == 8) {
+        const uint2 v = *reinterpret_cast<const uint2*>(codes + p * 8);
+        c.w[0] = v.x; c.w[1] = v.y;
+    } else {
+        const uint4 v = *reinterpret_cast<const uint4*>(codes + p * 16);
+        c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
+    }
+    return c;
+}
+
+// float32 ADC sum of one candidate with the lane-rotated table order (see header comment)
+template <int M>
+__device__ __forceinline__ float adc32(const CodeWords<M>& c, const char* __restrict__ tab, const RotConsts<M>& rc) {
+    constexpr int SH = (M == 4) ? 4 : (M == 8 ? 5 : 6);  // log2(M * 4 bytes)
+    uint32_t D[(M + 3) / 4];
+    if constexpr (M == 4) {
+        D[0] = c.w[0];
+    } else if constexpr (M == 8) {
+        D[0] = rc.hsel ? c.w[1] : c.w[0];
+        D[1] = rc.hsel ? c.w[0] : c.w[1];
+    } else {
+        const bool b0 = rc.hsel & 1, b1 = rc.hsel & 2;
+        const uint32_t x01 = b0 ? c.w[1] : c.w[0], y01 = b0 ? c.w[0] : c.w[1];
+        const uint32_t x23 = b0 ? c.w[3] : c.w[2], y23 = b0 ? c.w[2] : c.w[3];
+        D[0] = b1 ? x23 : x01;
+        D[1] = b1 ? y23 : y01;
+        D[2] = b1 ? x01 : x23;
+        D[3] = b1 ? y01 : y23;
+    }
+    float f[M];
+#pragma unroll
+    for (int t = 0; t < M; ++t) {
+        const uint32_t k = __builtin_amdgcn_ubfe(D[t >> 2], rc.sh[t & 3], 8);
+        const uint32_t addr = (k << SH) | rc.cj[t];
+        f[t] = *reinterpret_cast<const float*>(tab + addr);
+    }
+    float acc;
+    if constexpr (M == 4) {
+        acc = (f[0] + f[1]) + (f[2] + f[3]);
+    } else if constexpr (M == 8) {
+        acc = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+    } else {
+        acc = (((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]))) +
+              (((f[8] + f[9]) + (f[10] + f[11])) + ((f[12] + f[13]) + (f[14] + f[15])));
+    }
+    return acc;
+}
+
+template <int M, int NR, int U>
+__device__ __forceinline__ void scan2_item(const WorkItem& it, int item_idx, const double* __restrict__ T,
+                                           const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids, int K, int L,
+                                           int S, float margin, cis_hit* __restrict__ item_hits, int* __restrict__ item_n,
+                                           char* smem) {
+    constexpr int R = NR * 64;
+    char* tab = smem;                                                       // [K][M] float32
+    uint64_t* rk_all = reinterpret_cast<uint64_t*>(smem + (size_t)K * M * 4);  // [4][R] exact keys
+    uint32_t* rp_all = reinterpret_cast<uint32_t*>(rk_all + 4 * R);            // [4][R] positions
+    ScanShared* sh = reinterpret_cast<ScanShared*>(rp_all + 4 * R);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nf = M / 2;
+    const double* t0 = T + (int64_t)it.tab0 * nf * K;
+    const double* t1 = T + (int64_t)it.tab1 * nf * K;
+    const float INF = __int_as_float(0x7f800000);
+    {
+        float* tf = reinterpret_cast<float*>(tab);
+        for (int e = tid; e < nf * K; e += 256) {
+            const int j = e / K, k = e - j * K;
+            tf[k * M + j] = (float)t0[e];
+            tf[k * M + nf + j] = (float)t1[e];
+        }
+        if (tid < 4) {
+            sh->wt[tid] = 0x7ff0000000000000ull; sh->wl[tid] = 0x7ff0000000000000ull;
+            sh->wtf[tid] = INF; sh->wlf[tid] = INF; sh->wcnt[tid] = 0;
+        }
+    }
+    __syncthreads();
+    uint64_t* rk = rk_all + w * R;
+    uint32_t* rp = rp_all + w * R;
+    const RotConsts<M> rc = make_rot<M>(lane);
+    const int Lw = (L + 3) / 4;
+    const int len = it.len;
+    const int nit = (len + 64 * U - 1) / (64 * U);
+    int cnt = 0, nexact = 0;
+    CodeWords<M> nxt[U];
+    if (w < nit) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = w * 64 * U + u * 64 + lane;
+            nxt[u] = load_code<M>(codes, it.start + (p < len ? p : len - 1));
+        }
+    }
+    for (int iter = w; iter < nit; iter += 4) {
+        const int base = iter * 64 * U;
+        CodeWords<M> cur[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        if (iter + 4 < nit) {  // software prefetch: the next iteration's codes are in flight while this one computes
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = (iter + 4) * 64 * U + u * 64 + lane;
+                nxt[u] = load_code<M>(codes, it.start + (p < len ? p : len - 1));  // tail lanes re-read the last code; masked below
+            }
+        }
+        float d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = adc32<M>(cur[u], tab, rc);
+        float thrm = block_bound_f32(sh) * margin;
+#ifdef CIS_PROBE_HOTLOOP
+        thrm = (margin > 100.f) ? thrm : -1.0f;  // probe: nothing passes, only the float32 scan runs
+#endif
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = base + u * 64 + lane;
+            bool pass = (p < len) && (d[u] <= thrm);
+            unsigned long long m = __ballot(pass);
+            int n = __popcll(m);
+            if (cnt + n > R) {  // cannot happen right after a compaction: cnt <= L <= R - 64
+                cnt = wave_compact<M, NR>(rk, rp, cnt, nexact, L, Lw, sh, w, codes, it.start, K, t0, t1);
+                nexact = cnt;
+                thrm = block_bound_f32(sh) * margin;
+                pass = pass && (d[u] <= thrm);
+                m = __ballot(pass);
+                n = __popcll(m);
+            }
+            const int idx = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if (pass) {
+                rp[idx] = (uint32_t)p;
+                if constexpr (M == 4) rk[idx] = cur[u].w[0];  // stash the code; re-scored exactly at the next compaction
+                if constexpr (M == 8) rk[idx] = ((uint64_t)cur[u].w[1] << 32) | cur[u].w[0];
+            }
+            cnt += n;
+        }
+    }
+    // publish this wave's final bounds, then filter once more with everybody's final bounds
+    cnt = wave_compact<M, NR>(rk, rp, cnt, nexact, L, Lw, sh, w, codes, it.start, K, t0, t1);
+    __syncthreads();
+    cnt = wave_filter<NR>(rk, rp, cnt, sh);
+    if (lane == 0) sh->wcnt[w] = cnt;
+    __syncthreads();
+    const int c0 = sh->wcnt[0], c1 = sh->wcnt[1], c2 = sh->wcnt[2], c3 = sh->wcnt[3];
+    const int off = (w > 0 ? c0 : 0) + (w > 1 ? c1 : 0) + (w > 2 ? c2 : 0);
+    cis_hit* out = item_hits + (int64_t)item_idx * S + off;  // S >= 4 * L >= c0 + c1 + c2 + c3
+    for (int e = lane; e < cnt; e += 64) {
+        const uint32_t p = rp[e];
+        cis_hit hh;
+        hh.dist = __longlong_as_double((long long)rk[e]);
+        hh.visit_rank = (uint32_t)it.rank;
+        hh.pos = (uint32_t)it.pos0 + p;
+        hh.id = ids[it.start + p];
+        hh.cell = it.cell;
+        hh.reserved = 0;
+        out[e] = hh;
+    }
+    if (tid == 0) item_n[item_idx] = c0 + c1 + c2 + c3;
+}
+
+// Persistent launch: (blocks per CU) x 256 workgroups pull work items from eight queues, one per XCD.
+// The work items arrive sorted by coarse cell (`order`); queue x owns the x-th eighth of that list, so
+// the workgroups resident on one XCD (workgroup b runs on XCD b % 8 -- observed dispatch rule, used
+// for speed only) stream the same few cells through that XCD's private L2.  A workgroup whose own
+// queue is empty steals from the others, which removes the tail caused by unequal cell sizes.
+template <int M, int NR, int U>
+__global__ __launch_bounds__(256) void k_adc_scan2(const WorkItem* __restrict__ items, int n_items,
+                                                   const double* __restrict__ T, const uint8_t* __restrict__ codes,
+                                                   const int64_t* __restrict__ ids, int K, int L, int S, float margin,
+                                                   const int* __restrict__ order, int* __restrict__ queue_ctr /* [8], zeroed */,
+                                                   cis_hit* __restrict__ item_hits, int* __restrict__ item_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int R = NR * 64;
+    int* s_next = reinterpret_cast<int*>(smem + (size_t)K * M * 4 + (size_t)4 * R * 12 + sizeof(ScanShared));
+    const int q8 = n_items >> 3, r8 = n_items & 7;
+    const int home = blockIdx.x & 7;
+    for (int a = 0; a < 8; ++a) {
+        const int x = (home + a) & 7;
+        const int start = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
+        const int count = q8 + (x < r8 ? 1 : 0);
+        while (true) {
+            __syncthreads();  // previous item fully written out; LDS may be reused
+            if (threadIdx.x == 0) *s_next = atomicAdd(&queue_ctr[x], 1);
+            __syncthreads();
+            const int j = *s_next;
+            if (j >= count) break;
+            const int item_idx = order ? order[start + j] : start + j;
+            const WorkItem it = items[item_idx];
+            scan2_item<M, NR, U>(it, item_idx, T, codes, ids, K, L, S, margin, item_hits, item_n, smem);
+        }
+    }
 }
 
 // ================================================================================================
@@ -467,8 +1008,10 @@ __device__ void merge_lists(const cis_hit* __restrict__ src, const int* __restri
 
 template <int CAPM>
 __global__ __launch_bounds__(256) void k_merge_items(const cis_hit* __restrict__ item_hits, const int* __restrict__ item_n,
-                                                     const int64_t* __restrict__ item_off, int limit,
-                                                     cis_hit* __restrict__ out_hits) {
+                                                     const int64_t* __restrict__ item_off, int limit, int S,
+                                                     cis_hit* __restrict__ out_hits, int64_t* __restrict__ out_ids,
+                                                     double* __restrict__ out_dists, int* __restrict__ out_n,
+                                                     int32_t* __restrict__ out_cells, uint32_t* __restrict__ out_pos) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* ka = reinterpret_cast<uint64_t*>(smem);
     uint64_t* kb = ka + CAPM;
@@ -476,8 +1019,11 @@ __global__ __launch_bounds__(256) void k_merge_items(const cis_hit* __restrict__
     int* s_n = reinterpret_cast<int*>(pay + CAPM);
     const int q = blockIdx.x;
     const int64_t a = item_off[q], b = item_off[q + 1];
-    merge_lists<CAPM>(item_hits, item_n, a, (int)(b - a), (int64_t)limit, limit, limit, ka, kb, pay, s_n,
-                      out_hits + (int64_t)q * limit, nullptr, nullptr, nullptr, nullptr, nullptr);
+    const int64_t o = (int64_t)q * limit;
+    merge_lists<CAPM>(item_hits, item_n, a, (int)(b - a), (int64_t)S, S, limit, ka, kb, pay, s_n,
+                      out_hits ? out_hits + o : nullptr, out_ids ? out_ids + o : nullptr,
+                      out_dists ? out_dists + o : nullptr, out_n ? out_n + q : nullptr,
+                      out_cells ? out_cells + o : nullptr, out_pos ? out_pos + o : nullptr);
 }
 
 template <int CAPM>
@@ -538,9 +1084,10 @@ struct cis_index {
     int64_t n_local = 0;
     // per-batch workspace
     DevBuf w_xp, w_cd, w_order, w_sorted, w_plan, w_off, w_items, w_tabs, w_T, w_hits, w_hitn, w_part, w_q,
-        w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos;
+        w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos, w_order2;
     int64_t stats[4] = {0, 0, 0, 0};
     // optional stage timing (hipEvents on the launch stream)
+    bool force_exact_scan = false;  // tests: run every item through the float64 kernel
     bool profiling = false;
     struct ProfRec { hipEvent_t ev[5]; bool has_scan; };
     std::vector<ProfRec> prof;
@@ -575,7 +1122,7 @@ extern "C" void cis_index_destroy(cis_index* ix) {
     DevBuf* bufs[] = {&ix->d_codes, &ix->d_ids, &ix->d_loff, &ix->d_gcount, &ix->w_xp, &ix->w_cd, &ix->w_order,
                       &ix->w_sorted, &ix->w_plan, &ix->w_off, &ix->w_items, &ix->w_tabs, &ix->w_T, &ix->w_hits,
                       &ix->w_hitn, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
-                      &ix->w_ocell, &ix->w_opos};
+                      &ix->w_ocell, &ix->w_opos, &ix->w_order2};
     for (DevBuf* b : bufs) b->release();
     delete ix;
 }
@@ -741,6 +1288,12 @@ extern "C" int cis_index_set_profiling(cis_index* ix, int enable) {
     return CIS_OK;
 }
 
+extern "C" int cis_index_set_scan_mode(cis_index* ix, int mode) {
+    CIS_REQUIRE(ix != nullptr && (mode == 0 || mode == 1), "bad scan mode");
+    ix->force_exact_scan = (mode == 1);
+    return CIS_OK;
+}
+
 extern "C" int cis_index_read_profile(cis_index* ix, double ms[4], int64_t* launches) {
     CIS_REQUIRE(ix != nullptr && ms != nullptr, "NULL argument");
     for (auto& r : ix->prof) {
@@ -771,28 +1324,92 @@ extern "C" int cis_index_last_stats(cis_index* ix, int64_t stats[4]) {
 // ================================================================================================
 template <int M, int CAP, int U>
 static void launch_scan(int64_t n_items, size_t lds, hipStream_t st, const WorkItem* items, const double* T,
-                        const uint8_t* codes, const int64_t* ids, int Mrt, int K, int limit, cis_hit* hits, int* hitn) {
+                        const uint8_t* codes, const int64_t* ids, int Mrt, int K, int limit, int S, const int* flag,
+                        cis_hit* hits, int* hitn) {
     hipLaunchKernelGGL((k_adc_scan<M, CAP, U>), dim3((unsigned)n_items), dim3(256), lds, st, items, T, codes, ids, Mrt,
-                       K, limit, hits, hitn);
+                       K, limit, S, flag, hits, hitn);
 }
 
+// exact float64 kernel (v1); flag != nullptr restricts it to the items the fast kernel flagged
 template <int CAP, int U>
 static void launch_scan_m(int M, int64_t n_items, hipStream_t st, const WorkItem* items, const double* T,
-                          const uint8_t* codes, const int64_t* ids, int K, int limit, cis_hit* hits, int* hitn) {
+                          const uint8_t* codes, const int64_t* ids, int K, int limit, int S, const int* flag,
+                          cis_hit* hits, int* hitn) {
     const size_t lds = (size_t)CAP * 16 + (size_t)M * K * sizeof(double) + 16;
     switch (M) {
-        case 4: launch_scan<4, CAP, U>(n_items, lds, st, items, T, codes, ids, M, K, limit, hits, hitn); break;
-        case 8: launch_scan<8, CAP, U>(n_items, lds, st, items, T, codes, ids, M, K, limit, hits, hitn); break;
-        case 16: launch_scan<16, CAP, U>(n_items, lds, st, items, T, codes, ids, M, K, limit, hits, hitn); break;
-        default: launch_scan<0, CAP, U>(n_items, lds, st, items, T, codes, ids, M, K, limit, hits, hitn); break;
+        case 4: launch_scan<4, CAP, U>(n_items, lds, st, items, T, codes, ids, M, K, limit, S, flag, hits, hitn); break;
+        case 8: launch_scan<8, CAP, U>(n_items, lds, st, items, T, codes, ids, M, K, limit, S, flag, hits, hitn); break;
+        case 16: launch_scan<16, CAP, U>(n_items, lds, st, items, T, codes, ids, M, K, limit, S, flag, hits, hitn); break;
+        default: launch_scan<0, CAP, U>(n_items, lds, st, items, T, codes, ids, M, K, limit, S, flag, hits, hitn); break;
+    }
+}
+
+static void launch_scan_exact(int M, int64_t n_items, hipStream_t st, const WorkItem* items, const double* T,
+                              const uint8_t* codes, const int64_t* ids, int K, int L, int S, const int* flag,
+                              cis_hit* hits, int* hitn) {
+    if (L <= 512) launch_scan_m<1024, 2>(M, n_items, st, items, T, codes, ids, K, L, S, flag, hits, hitn);
+    else if (L <= 1024) launch_scan_m<2048, 4>(M, n_items, st, items, T, codes, ids, K, L, S, flag, hits, hitn);
+    else launch_scan_m<4096, 4>(M, n_items, st, items, T, codes, ids, K, L, S, flag, hits, hitn);
+}
+
+// float32-prefilter kernel (v2): M in {4, 8, 16}, K <= 256, L <= 400
+static bool scan2_supported(int M, int K, int L) { return (M == 4 || M == 8 || M == 16) && K <= 256 && L >= 1 && L <= 448; }
+
+template <int M, int NR>
+static void launch_scan2_t(int64_t n_items, hipStream_t st, const WorkItem* items, const double* T, const uint8_t* codes,
+                           const int64_t* ids, int K, int L, int S, const int* order, int* qctr, cis_hit* hits,
+                           int* hitn) {
+    const size_t lds = (size_t)K * M * 4 + (size_t)4 * NR * 64 * 12 + sizeof(ScanShared) + 16;
+    const float eps = 2.0f * (float)M * 5.9604645e-8f;  // 2 * M * 2^-24
+    const float margin = 1.0f + 3.0f * eps;
+    const int64_t resident = 256 * 5;  // 256 CUs x the 5 workgroups/CU the kernel's VGPR budget admits
+    const unsigned grid = (unsigned)(n_items < resident ? ((n_items + 7) / 8) * 8 : resident);
+    hipLaunchKernelGGL((k_adc_scan2<M, NR, 4>), dim3(grid), dim3(256), lds, st, items, (int)n_items, T, codes, ids, K, L, S,
+                       margin, order, qctr, hits, hitn);
+}
+
+static void launch_scan2(int M, int64_t n_items, hipStream_t st, const WorkItem* items, const double* T,
+                         const uint8_t* codes, const int64_t* ids, int K, int L, int S, const int* order, int* qctr,
+                         cis_hit* hits, int* hitn) {
+    const bool small = L <= 192;
+    if (M == 4) {
+        if (small) launch_scan2_t<4, 4>(n_items, st, items, T, codes, ids, K, L, S, order, qctr, hits, hitn);
+        else launch_scan2_t<4, 8>(n_items, st, items, T, codes, ids, K, L, S, order, qctr, hits, hitn);
+    } else if (M == 8) {
+        if (small) launch_scan2_t<8, 4>(n_items, st, items, T, codes, ids, K, L, S, order, qctr, hits, hitn);
+        else launch_scan2_t<8, 8>(n_items, st, items, T, codes, ids, K, L, S, order, qctr, hits, hitn);
+    } else {
+        if (small) launch_scan2_t<16, 4>(n_items, st, items, T, codes, ids, K, L, S, order, qctr, hits, hitn);
+        else launch_scan2_t<16, 8>(n_items, st, items, T, codes, ids, K, L, S, order, qctr, hits, hitn);
     }
 }
 
 static const int MAX_LIMIT = 3072;
 
 // one sub-batch of queries (device pointers); writes ranked partial hits [nq][L] and visited [nq]
-static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota, int L, cis_hit* d_hits,
-                        int32_t* d_visited, hipStream_t st) {
+struct SearchOut {  // any of these may be null; all are [nq][L] except n_found / visited [nq]
+    cis_hit* hits;
+    int64_t* ids;
+    double* dists;
+    int32_t* n_found;
+    int32_t* cells;
+    uint32_t* pos;
+    int32_t* visited;
+    SearchOut at(int64_t q0, int L) const {
+        SearchOut o = *this;
+        if (o.hits) o.hits += q0 * L;
+        if (o.ids) o.ids += q0 * L;
+        if (o.dists) o.dists += q0 * L;
+        if (o.cells) o.cells += q0 * L;
+        if (o.pos) o.pos += q0 * L;
+        if (o.n_found) o.n_found += q0;
+        if (o.visited) o.visited += q0;
+        return o;
+    }
+};
+
+static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota, int L, const SearchOut& out,
+                        hipStream_t st) {
     cis_model* m = ix->m;
     const int V = m->V, D = m->D, K = m->K, M = m->M, h = m->h, nf = m->nf;
     cis_index::ProfRec pr;
@@ -858,8 +1475,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     CIS_TRY(ix->w_items.reserve((size_t)(n_items + 1) * sizeof(WorkItem)));
     CIS_TRY(ix->w_tabs.reserve((size_t)(n_tabs + 1) * sizeof(TabDesc)));
     CIS_TRY(ix->w_T.reserve((size_t)(n_tabs + 1) * nf * K * sizeof(double)));
-    CIS_TRY(ix->w_hits.reserve((size_t)(n_items + 1) * L * sizeof(cis_hit)));
-    CIS_TRY(ix->w_hitn.reserve((size_t)(n_items + 1) * sizeof(int)));
+    const bool fast = scan2_supported(M, K, L) && !ix->force_exact_scan;
+    const int S = fast ? 4 * L : L;  // hit slots per work item (fast kernel: <= L per wave)
+    CIS_TRY(ix->w_hits.reserve((size_t)(n_items + 1) * S * sizeof(cis_hit)));
+    CIS_TRY(ix->w_hitn.reserve((size_t)(n_items + 1) * 2 * sizeof(int)));
     WorkItem* items = ix->w_items.as<WorkItem>();
     TabDesc* tabs = ix->w_tabs.as<TabDesc>();
     double* T = ix->w_T.as<double>();
@@ -887,9 +1506,25 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         const int64_t* ids = ix->d_ids.as<int64_t>();
         cis_hit* hits = ix->w_hits.as<cis_hit>();
         int* hitn = ix->w_hitn.as<int>();
-        if (L <= 512) launch_scan_m<1024, 2>(M, n_items, st, items, T, codes, ids, K, L, hits, hitn);
-        else if (L <= 1024) launch_scan_m<2048, 4>(M, n_items, st, items, T, codes, ids, K, L, hits, hitn);
-        else launch_scan_m<4096, 4>(M, n_items, st, items, T, codes, ids, K, L, hits, hitn);
+        if (fast) {
+            const int* order = nullptr;
+            const bool sort_items = ix->ncells <= 65536;  // sort the work items by cell for L2 locality (skipped for huge V)
+            CIS_TRY(ix->w_order2.reserve((size_t)(n_items + (sort_items ? ix->ncells : 0) + 16) * sizeof(int)));
+            int* qctr = ix->w_order2.as<int>();
+            CIS_CHECK_HIP(hipMemsetAsync(qctr, 0, 8 * sizeof(int), st));
+            if (sort_items) {
+                int* cell_off = qctr + 8;
+                int* ord = cell_off + ix->ncells;
+                CIS_CHECK_HIP(hipMemsetAsync(cell_off, 0, (size_t)ix->ncells * sizeof(int), st));
+                hipLaunchKernelGGL(k_item_hist, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, cell_off);
+                hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(256), 0, st, cell_off, (int)ix->ncells);
+                hipLaunchKernelGGL(k_item_scatter, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items,
+                                   cell_off, ord);
+                order = ord;
+            }
+            launch_scan2(M, n_items, st, items, T, codes, ids, K, L, S, order, qctr, hits, hitn);
+        }
+        else launch_scan_exact(M, n_items, st, items, T, codes, ids, K, L, S, nullptr, hits, hitn);
         ix->stats[3] += 1;
     }
     // 5. per-query merge
@@ -898,13 +1533,17 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         const cis_hit* hits = ix->w_hits.as<cis_hit>();
         const int* hitn = ix->w_hitn.as<int>();
         if (L <= 512)
-            hipLaunchKernelGGL(k_merge_items<1024>, dim3(nq), dim3(256), (size_t)1024 * 24 + 16, st, hits, hitn, item_off, L, d_hits);
+            hipLaunchKernelGGL(k_merge_items<1024>, dim3(nq), dim3(256), (size_t)1024 * 24 + 16, st, hits, hitn, item_off, L, S, out.hits,
+                               out.ids, out.dists, out.n_found, out.cells, out.pos);
         else if (L <= 1024)
-            hipLaunchKernelGGL(k_merge_items<2048>, dim3(nq), dim3(256), (size_t)2048 * 24 + 16, st, hits, hitn, item_off, L, d_hits);
+            hipLaunchKernelGGL(k_merge_items<2048>, dim3(nq), dim3(256), (size_t)2048 * 24 + 16, st, hits, hitn, item_off, L, S, out.hits,
+                               out.ids, out.dists, out.n_found, out.cells, out.pos);
         else
-            hipLaunchKernelGGL(k_merge_items<4096>, dim3(nq), dim3(256), (size_t)4096 * 24 + 16, st, hits, hitn, item_off, L, d_hits);
+            hipLaunchKernelGGL(k_merge_items<4096>, dim3(nq), dim3(256), (size_t)4096 * 24 + 16, st, hits, hitn, item_off, L, S, out.hits,
+                               out.ids, out.dists, out.n_found, out.cells, out.pos);
     }
-    hipLaunchKernelGGL(k_copy_visited, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, plan, nq, d_visited);
+    if (out.visited)
+        hipLaunchKernelGGL(k_copy_visited, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, plan, nq, out.visited);
     CIS_CHECK_HIP(hipGetLastError());
     CIS_TRY(mark(4));
     if (ix->profiling) ix->prof.push_back(pr);
@@ -924,33 +1563,38 @@ static int effective_limit(int64_t quota, int limit, int* L) {
 
 static const int QUERY_BATCH = 8192;
 
-extern "C" int cis_index_search_partial_dev(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota,
-                                            int limit, cis_hit* d_hits, int32_t* d_visited, void* stream) {
+static int search_all(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota, int L, const SearchOut& out,
+                      hipStream_t st) {
     CIS_REQUIRE(ix != nullptr, "index is NULL");
     CIS_REQUIRE(q_dtype == CIS_F32 || q_dtype == CIS_F64, "q_dtype must be 4 or 8");
     CIS_REQUIRE(nq >= 0, "nq must be >= 0");
-    int L;
-    CIS_TRY(effective_limit(quota, limit, &L));
     CIS_TRY(index_sync(ix));
     CIS_CHECK_HIP(hipSetDevice(ix->m->device));
-    hipStream_t st = (hipStream_t)stream;
     for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
-    if (L == 0 || nq == 0) {
-        // still report visited
-        if (nq == 0) return CIS_OK;
-    }
-    const int Lk = L > 0 ? L : 1;
     for (int a = 0; a < nq; a += QUERY_BATCH) {
         const int bn = (nq - a < QUERY_BATCH) ? (nq - a) : QUERY_BATCH;
         const char* q = (const char*)dQ + (size_t)a * ix->m->D_in * q_dtype;
         if (L > 0) {
-            CIS_TRY(search_batch(ix, q, q_dtype, bn, quota, L, d_hits + (int64_t)a * L, d_visited + a, st));
-        } else {
-            CIS_TRY(ix->w_part.reserve((size_t)bn * Lk * sizeof(cis_hit)));
-            CIS_TRY(search_batch(ix, q, q_dtype, bn, quota, Lk, ix->w_part.as<cis_hit>(), d_visited + a, st));
+            CIS_TRY(search_batch(ix, q, q_dtype, bn, quota, L, out.at(a, L), st));
+        } else {  // limit 0: only `visited` is defined
+            SearchOut o{};
+            o.visited = out.visited ? out.visited + a : nullptr;
+            CIS_TRY(ix->w_part.reserve((size_t)bn * sizeof(cis_hit)));
+            o.hits = ix->w_part.as<cis_hit>();
+            CIS_TRY(search_batch(ix, q, q_dtype, bn, quota, 1, o, st));
         }
     }
     return CIS_OK;
+}
+
+extern "C" int cis_index_search_partial_dev(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota,
+                                            int limit, cis_hit* d_hits, int32_t* d_visited, void* stream) {
+    int L;
+    CIS_TRY(effective_limit(quota, limit, &L));
+    SearchOut o{};
+    o.hits = d_hits;
+    o.visited = d_visited;
+    return search_all(ix, dQ, q_dtype, nq, quota, L, o, (hipStream_t)stream);
 }
 
 static int merge_parts(const cis_hit* d_parts, int world, int nq, int L, int64_t* d_ids, double* d_dists,
@@ -977,17 +1621,13 @@ extern "C" int cis_merge_hits_dev(const cis_hit* d_parts, int world, int nq, int
 extern "C" int cis_index_search_dev(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota, int limit,
                                     int64_t* d_ids, double* d_dists, int32_t* d_n_found, int32_t* d_visited,
                                     int32_t* d_cells, uint32_t* d_pos, void* stream) {
-    CIS_REQUIRE(ix != nullptr, "index is NULL");
     int L;
     CIS_TRY(effective_limit(quota, limit, &L));
     if (nq == 0) return CIS_OK;
-    CIS_TRY(ix->w_part.reserve((size_t)nq * (L > 0 ? L : 1) * sizeof(cis_hit)));
-    CIS_TRY(cis_index_search_partial_dev(ix, dQ, q_dtype, nq, quota, limit, ix->w_part.as<cis_hit>(), d_visited, stream));
-    if (L == 0) {
-        CIS_CHECK_HIP(hipMemsetAsync(d_n_found, 0, (size_t)nq * sizeof(int32_t), (hipStream_t)stream));
-        return CIS_OK;
-    }
-    return merge_parts(ix->w_part.as<cis_hit>(), 1, nq, L, d_ids, d_dists, d_n_found, d_cells, d_pos, (hipStream_t)stream);
+    SearchOut o{};
+    o.ids = d_ids; o.dists = d_dists; o.n_found = d_n_found; o.cells = d_cells; o.pos = d_pos; o.visited = d_visited;
+    if (L == 0 && d_n_found) CIS_CHECK_HIP(hipMemsetAsync(d_n_found, 0, (size_t)nq * sizeof(int32_t), (hipStream_t)stream));
+    return search_all(ix, dQ, q_dtype, nq, quota, L, o, (hipStream_t)stream);
 }
 
 extern "C" int cis_index_search(cis_index* ix, const void* Q, int q_dtype, int nq, int64_t quota, int limit,

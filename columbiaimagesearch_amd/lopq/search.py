@@ -307,6 +307,10 @@ class LOPQSearcherHIP(LOPQSearcherBase):
         return {"candidates": int(st[0]), "items": int(st[1]), "tables": int(st[2]), "scan_launches": int(st[3])}
 
 
+    def set_scan_mode(self, exact_only=False):
+        """Force the exact float64 ADC scan kernel (tests); results are identical either way."""
+        _lib.check(_lib.lib().cis_index_set_scan_mode(self._ix, 1 if exact_only else 0))
+
     def set_profiling(self, enable=True):
         """Record HIP events around the search stages on the launch stream (see read_profile)."""
         _lib.check(_lib.lib().cis_index_set_profiling(self._ix, 1 if enable else 0))

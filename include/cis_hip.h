@@ -166,6 +166,10 @@ int cis_index_last_stats(cis_index* ix, int64_t stats[4]);
  *   ms[2] ADC scan + block top-k                                         ms[3] per-query merge
  *   *launches = number of scan kernel launches accumulated. */
 int cis_index_set_profiling(cis_index* ix, int enable);
+/* ADC scan kernel selection: 0 = automatic (float32-prefilter kernel with exact float64 re-scoring
+ * where it applies, exact float64 kernel otherwise), 1 = exact float64 kernel only.  Both produce
+ * identical results; the switch exists so that tests can prove it. */
+int cis_index_set_scan_mode(cis_index* ix, int mode);
 int cis_index_read_profile(cis_index* ix, double ms[4], int64_t* launches);
 
 #ifdef __cplusplus

@@ -235,3 +235,47 @@ def test_device_entry_points_match_host_entry_points():
     torch.cuda.synchronize()
     np.testing.assert_array_equal(c.cpu().numpy().view(np.uint16), z["coarse"][:5000])
     np.testing.assert_array_equal(f.cpu().numpy(), z["fine"][:5000])
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3"])
+def test_fast_and_exact_scan_kernels_agree(name):
+    """The float32-prefilter scan (exact float64 re-scoring) and the float64 scan return identical
+    ids AND bit-identical distances; M = 4, 8, 16 cover the three lane-rotation layouts."""
+    z, X, Q = load_golden(name)
+    m = hip_model(z)
+    s = _build_searcher(name, z, X, m)
+    for quota, limit in [(10, 10), (1000, 100), (10000, 100), (20000, 300), (100000, 37)]:
+        s.set_scan_mode(exact_only=False)
+        a = s.search_batch(Q, quota=quota, limit=limit)
+        s.set_scan_mode(exact_only=True)
+        b = s.search_batch(Q, quota=quota, limit=limit)
+        s.set_scan_mode(exact_only=False)
+        for k in ("ids", "n_found", "visited"):
+            np.testing.assert_array_equal(a[k], b[k])
+        np.testing.assert_array_equal(a["dists"].view(np.uint64), b["dists"].view(np.uint64))
+
+
+def test_many_exact_ties_fall_back_to_exact_kernel():
+    """Thousands of identical codes in one cell tie exactly in float32 and float64: the fast kernel
+    must hand those work items to the exact kernel, and ties come back in insertion order."""
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    z, X, Q = load_golden("c2")
+    m = hip_model(z)
+    coarse, fine = z["coarse"], z["fine"]
+    s = LOPQSearcherHIP(m)
+    n_dup = 5000
+    dc = np.repeat(coarse[:1], n_dup, 0)
+    df = np.repeat(fine[:1], n_dup, 0)
+    s.add_codes_array(np.concatenate([coarse[:3000], dc, coarse[3000:6000]]),
+                      np.concatenate([fine[:3000], df, fine[3000:6000]]),
+                      np.arange(3000 + n_dup + 3000, dtype=np.int64) + 10)
+    q = X[:1]  # the duplicated vector itself
+    a = s.search_batch(q, quota=50000, limit=100)
+    s.set_scan_mode(exact_only=True)
+    b = s.search_batch(q, quota=50000, limit=100)
+    np.testing.assert_array_equal(a["ids"], b["ids"])
+    np.testing.assert_array_equal(a["dists"].view(np.uint64), b["dists"].view(np.uint64))
+    # item 0 (id 10) and the duplicates (ids 3010...) share the best distance; insertion order within the cell
+    best = a["dists"][0, 0]
+    tied = a["ids"][0][a["dists"][0] == best]
+    assert tied[0] == 10 and (np.diff(tied) > 0).all() and len(tied) == 100
