@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) void k_tables(const CT* __restrict__ X /* [nq]
                                                 const double* __restrict__ Rt, const double* __restrict__ mus,
                                                 const double* __restrict__ subs, const TabDesc* __restrict__ tabs,
                                                 int V, int h, int w, int nf, int K, int D,
-                                                double* __restrict__ T /* [ntab][nf][K] */, PwProg prog_w) {
+                                                double* __restrict__ T /* [ntab][nf][K] */, PwProg prog_w,
+                                                double* __restrict__ px_out /* [ntab][h] or null */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* v = reinterpret_cast<double*>(smem);  // [h]
     double* px = v + h;                           // [h]
@@ -258,12 +259,51 @@ __global__ __launch_bounds__(256) void k_tables(const CT* __restrict__ X /* [nq]
         v[k] = (double)res - mu[k];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < h; i += blockDim.x) {
-        double acc = 0.0;
-        for (int k = 0; k < h; ++k) acc = fma(R[(int64_t)k * h + i], v[k], acc);
-        px[i] = acc;
+    // px = R . v with all 256 threads: `parts` groups of h threads each take a contiguous slice of k
+    // (k-ascending fma chain inside a slice, slices added in order; the reference's BLAS order is
+    // unspecified anyway), partial sums meet in LDS.
+    {
+        const int parts = (h >= 256) ? 1 : (256 / h);
+        double* psum = px + h;  // [parts][h]
+        const int tid = threadIdx.x;
+        if (parts == 1) {
+            for (int i = tid; i < h; i += blockDim.x) {
+                double a0 = 0.0, a1 = 0.0;
+                int k = 0;
+                for (; k + 1 < h; k += 2) {
+                    a0 = fma(R[(int64_t)k * h + i], v[k], a0);
+                    a1 = fma(R[(int64_t)(k + 1) * h + i], v[k + 1], a1);
+                }
+                if (k < h) a0 = fma(R[(int64_t)k * h + i], v[k], a0);
+                px[i] = a0 + a1;
+            }
+        } else {
+            const int part = tid / h, i = tid - part * h;
+            if (part < parts) {
+                const int per = (h + parts - 1) / parts;
+                const int k0 = part * per, k1 = (k0 + per < h) ? k0 + per : h;
+                double a0 = 0.0, a1 = 0.0;
+                int k = k0;
+                for (; k + 1 < k1; k += 2) {
+                    a0 = fma(R[(int64_t)k * h + i], v[k], a0);
+                    a1 = fma(R[(int64_t)(k + 1) * h + i], v[k + 1], a1);
+                }
+                if (k < k1) a0 = fma(R[(int64_t)k * h + i], v[k], a0);
+                psum[part * h + i] = a0 + a1;
+            }
+            __syncthreads();
+            if (tid < h) {
+                double acc = psum[tid];
+                for (int q = 1; q < parts; ++q) acc = acc + psum[q * h + tid];
+                px[tid] = acc;
+            }
+        }
     }
     __syncthreads();
+    if (px_out) {  // two-kernel path: the distance tables are built by k_tables_from_px
+        for (int i = threadIdx.x; i < h; i += blockDim.x) px_out[(int64_t)blockIdx.x * h + i] = px[i];
+        return;
+    }
     double* out = T + (int64_t)blockIdx.x * nf * K;
     for (int e = threadIdx.x; e < nf * K; e += blockDim.x) {
         const int j = e / K, k = e % K;
@@ -274,11 +314,66 @@ __global__ __launch_bounds__(256) void k_tables(const CT* __restrict__ X /* [nq]
     }
 }
 
+// Second half of the table build for the common sub-vector widths: one block = (chunk of 64 table
+// items, fine split j, coarse split z).  Thread k keeps sub-centroid (z, j, k) in registers and walks
+// the chunk, so the 32 KB sub-quantizer is read once per 64 tables instead of once per table (the
+// one-kernel version was bound by L2 reads of the sub-quantizers: 160 KB per table).
+template <int W>
+__global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict__ px /* [ntab][h] */,
+                                                        const TabDesc* __restrict__ tabs, int n_tabs,
+                                                        const double* __restrict__ subs, int h, int nf, int K,
+                                                        double* __restrict__ T /* [ntab][nf][K] */) {
+    __shared__ double sf[64][W];
+    __shared__ int ssplit[64];
+    const int j = blockIdx.y, z = blockIdx.z, k = threadIdx.x;
+    const int t0 = blockIdx.x * 64;
+    const int nt = (n_tabs - t0 < 64) ? (n_tabs - t0) : 64;
+    for (int e = threadIdx.x; e < nt * W; e += 256) {
+        const int t = e / W, i = e - t * W;
+        sf[t][i] = px[(int64_t)(t0 + t) * h + j * W + i];
+    }
+    if (threadIdx.x < nt) ssplit[threadIdx.x] = tabs[t0 + threadIdx.x].split;
+    __syncthreads();
+    if (k >= K) return;
+    double sc[W];
+    const double* src = subs + ((int64_t)(z * nf + j) * K + k) * W;
+#pragma unroll
+    for (int i = 0; i < W; ++i) sc[i] = src[i];
+    for (int t = 0; t < nt; ++t) {
+        if (ssplit[t] != z) continue;
+        const double* f = sf[t];
+        auto elem = [&](int i) -> double { const double df = f[i] - sc[i]; return df * df; };
+        T[((int64_t)(t0 + t) * nf + j) * K + k] = pw_leaf<double>(elem, 0, W);
+    }
+}
+
 // ================================================================================================
 // block-wide bitonic sort of N (power of two) keys (a, b) with an optional payload, in LDS
 // ================================================================================================
 template <int N, int NT, bool PAY>
 __device__ __forceinline__ void block_bitonic(uint64_t* ka, uint64_t* kb, int64_t* pay) {
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < N / 2; t += NT) {
+                const int i = ((t / j) * 2 * j) + (t % j);
+                const int p = i + j;
+                const bool asc = ((i & k) == 0);
+                const uint64_t a0 = ka[i], b0 = kb[i], a1 = ka[p], b1 = kb[p];
+                const bool gt = (a0 > a1) || (a0 == a1 && b0 > b1);
+                if (gt == asc) {
+                    ka[i] = a1; kb[i] = b1; ka[p] = a0; kb[p] = b0;
+                    if (PAY) { const int64_t x = pay[i]; pay[i] = pay[p]; pay[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// same network with the size chosen at run time (N a power of two): the merge sorts only as many
+// slots as it actually filled
+template <int NT, bool PAY>
+__device__ __forceinline__ void block_bitonic_rt(uint64_t* ka, uint64_t* kb, int64_t* pay, int N) {
     for (int k = 2; k <= N; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = threadIdx.x; t < N / 2; t += NT) {
@@ -503,8 +598,9 @@ __device__ __forceinline__ uint32_t wave_kth(const uint32_t (&k)[NR], int i) {  
 struct ScanShared {
     uint64_t wt[4];  // per wave: exact dist bits that >= ceil(limit/4) of its candidates do not exceed
     uint64_t wl[4];  // per wave: exact dist bits that >= limit of its candidates do not exceed
-    float wtf[4];    // the same two, rounded UP to float32, for the hot loop
-    float wlf[4];
+    float bound_f;   // block bound rounded UP to float32 for the hot loop (refreshed at every compaction;
+                     // a lost concurrent update only leaves it looser for a while)
+    int pad0;
     int wcnt[4];     // survivors per wave at the end
 };
 
@@ -521,11 +617,7 @@ static __device__ __forceinline__ void lds_st(uint64_t* p, uint64_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-static __device__ __forceinline__ float block_bound_f32(const ScanShared* sh) {
-    const float t = fmaxf(fmaxf(lds_ld(&sh->wtf[0]), lds_ld(&sh->wtf[1])), fmaxf(lds_ld(&sh->wtf[2]), lds_ld(&sh->wtf[3])));
-    const float l = fminf(fminf(lds_ld(&sh->wlf[0]), lds_ld(&sh->wlf[1])), fminf(lds_ld(&sh->wlf[2]), lds_ld(&sh->wlf[3])));
-    return fminf(t, l);
-}
+static __device__ __forceinline__ float block_bound_f32(const ScanShared* sh) { return lds_ld(&sh->bound_f); }
 static __device__ __forceinline__ uint64_t block_bound_u64(const ScanShared* sh) {
     uint64_t t = lds_ld(&sh->wt[0]);
     uint64_t l = lds_ld(&sh->wl[0]);
@@ -667,11 +759,15 @@ __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt,
         }
     }
     if (lane == 0) {
-        if (boundW < lds_ld(&sh->wt[w])) { lds_st(&sh->wt[w], boundW); lds_st(&sh->wtf[w], __double2float_ru(__longlong_as_double((long long)boundW))); }
-        if (boundL < lds_ld(&sh->wl[w])) { lds_st(&sh->wl[w], boundL); lds_st(&sh->wlf[w], __double2float_ru(__longlong_as_double((long long)boundL))); }
+        if (boundW < lds_ld(&sh->wt[w])) lds_st(&sh->wt[w], boundW);
+        if (boundL < lds_ld(&sh->wl[w])) lds_st(&sh->wl[w], boundL);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     const uint64_t bound = block_bound_u64(sh);
+    if (lane == 0) {
+        const float bf = __double2float_ru(__longlong_as_double((long long)bound));
+        if (bf < lds_ld(&sh->bound_f)) lds_st(&sh->bound_f, bf);
+    }
     int ncnt = 0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -820,7 +916,8 @@ __device__ __forceinline__ void scan2_item(const WorkItem& it, int item_idx, con
         }
         if (tid < 4) {
             sh->wt[tid] = 0x7ff0000000000000ull; sh->wl[tid] = 0x7ff0000000000000ull;
-            sh->wtf[tid] = INF; sh->wlf[tid] = INF; sh->wcnt[tid] = 0;
+            sh->wcnt[tid] = 0;
+            if (tid == 0) sh->bound_f = INF;
         }
     }
     __syncthreads();
@@ -973,9 +1070,11 @@ __device__ void merge_lists(const cis_hit* __restrict__ src, const int* __restri
             e += take;
             if (e >= valid) { ++l; e = 0; }
         }
-        for (int x = n + tid; x < CAPM; x += blockDim.x) { ka[x] = ~0ull; kb[x] = ~0ull; pay[x] = -1; }
+        int ns = 64;  // sort only the next power of two above what was filled
+        while (ns < n) ns <<= 1;
+        for (int x = n + tid; x < ns; x += blockDim.x) { ka[x] = ~0ull; kb[x] = ~0ull; pay[x] = -1; }
         __syncthreads();
-        block_bitonic<CAPM, 256, true>(ka, kb, pay);
+        block_bitonic_rt<256, true>(ka, kb, pay, ns);
         have = n < limit ? n : limit;
         if (l >= n_lists) break;
     }
@@ -1084,7 +1183,7 @@ struct cis_index {
     int64_t n_local = 0;
     // per-batch workspace
     DevBuf w_xp, w_cd, w_order, w_sorted, w_plan, w_off, w_items, w_tabs, w_T, w_hits, w_hitn, w_part, w_q,
-        w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos, w_order2;
+        w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos, w_order2, w_px;
     int64_t stats[4] = {0, 0, 0, 0};
     // optional stage timing (hipEvents on the launch stream)
     bool force_exact_scan = false;  // tests: run every item through the float64 kernel
@@ -1122,7 +1221,7 @@ extern "C" void cis_index_destroy(cis_index* ix) {
     DevBuf* bufs[] = {&ix->d_codes, &ix->d_ids, &ix->d_loff, &ix->d_gcount, &ix->w_xp, &ix->w_cd, &ix->w_order,
                       &ix->w_sorted, &ix->w_plan, &ix->w_off, &ix->w_items, &ix->w_tabs, &ix->w_T, &ix->w_hits,
                       &ix->w_hitn, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
-                      &ix->w_ocell, &ix->w_opos, &ix->w_order2};
+                      &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px};
     for (DevBuf* b : bufs) b->release();
     delete ix;
 }
@@ -1482,21 +1581,36 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     WorkItem* items = ix->w_items.as<WorkItem>();
     TabDesc* tabs = ix->w_tabs.as<TabDesc>();
     double* T = ix->w_T.as<double>();
-    const size_t tab_lds = (size_t)2 * h * sizeof(double);
+    const size_t tab_lds = (size_t)(2 * h + (h < 256 ? 256 : 0)) * sizeof(double);
+    const bool split_tables = (m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) && K <= 256;
+    double* px_buf = nullptr;
+    if (split_tables) {
+        CIS_TRY(ix->w_px.reserve((size_t)(n_tabs + 1) * h * sizeof(double)));
+        px_buf = ix->w_px.as<double>();
+    }
     if (ct == CIS_F32) {
         hipLaunchKernelGGL((k_plan<float, true>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<float>(),
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
                            seg_max, plan, item_off, tab_off, items, tabs);
         if (n_tabs > 0)
             hipLaunchKernelGGL(k_tables<float>, dim3((unsigned)n_tabs), dim3(256), tab_lds, st, (const float*)xc, m->d_Cs32,
-                               m->d_Rt, m->d_mus, m->d_subs, tabs, V, h, m->w, nf, K, D, T, m->prog_w);
+                               m->d_Rt, m->d_mus, m->d_subs, tabs, V, h, m->w, nf, K, D, T, m->prog_w, px_buf);
     } else {
         hipLaunchKernelGGL((k_plan<double, true>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
                            seg_max, plan, item_off, tab_off, items, tabs);
         if (n_tabs > 0)
             hipLaunchKernelGGL(k_tables<double>, dim3((unsigned)n_tabs), dim3(256), tab_lds, st, (const double*)xc,
-                               m->d_Cs64, m->d_Rt, m->d_mus, m->d_subs, tabs, V, h, m->w, nf, K, D, T, m->prog_w);
+                               m->d_Cs64, m->d_Rt, m->d_mus, m->d_subs, tabs, V, h, m->w, nf, K, D, T, m->prog_w, px_buf);
+    }
+    if (split_tables && n_tabs > 0) {
+        dim3 g((unsigned)ceil_div(n_tabs, 64), (unsigned)nf, 2);
+        switch (m->w) {
+            case 4: hipLaunchKernelGGL(k_tables_from_px<4>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T); break;
+            case 8: hipLaunchKernelGGL(k_tables_from_px<8>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T); break;
+            case 16: hipLaunchKernelGGL(k_tables_from_px<16>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T); break;
+            default: hipLaunchKernelGGL(k_tables_from_px<32>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T); break;
+        }
     }
     // 4. ADC scan + block top-k
     CIS_TRY(mark(2));
