@@ -36,6 +36,7 @@ _PROTOS = {
     "cis_last_error": (c_char_p, []),
     "cis_device_count": (c_int, []),
     "cis_set_device": (c_int, [c_int]),
+    "cis_selftest": (c_int, [POINTER(c_int)]),
     "cis_model_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "cis_model_destroy": (None, [c_void_p]),

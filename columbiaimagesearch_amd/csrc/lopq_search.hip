@@ -211,28 +211,51 @@ __global__ void k_item_hist(const WorkItem* __restrict__ items, int64_t n, int* 
     if (i < n) atomicAdd(&cell_cnt[items[i].cell], 1);
 }
 
-__global__ void k_cell_scan(int* __restrict__ cell_cnt /* in: counts, out: exclusive offsets */, int ncells) {
+// counts -> exclusive SLOT offsets per cell (a slot holds up to G items of one cell); the counts are
+// reset to zero so that the scatter can reuse them as cursors.  *n_slots = total number of slots.
+__global__ void k_cell_scan(int* __restrict__ cell_cnt, int* __restrict__ slot_off, int ncells, int G,
+                            int* __restrict__ n_slots) {
     __shared__ int part[256];
     const int tid = threadIdx.x;
     const int per = (ncells + 255) / 256;
     const int a = tid * per, b = (a + per < ncells) ? a + per : ncells;
     int s = 0;
-    for (int c = a; c < b; ++c) s += cell_cnt[c];
+    for (int c = a; c < b; ++c) s += (cell_cnt[c] + G - 1) / G;
     part[tid] = s;
     __syncthreads();
     if (tid == 0) {
         int run = 0;
         for (int k = 0; k < 256; ++k) { const int x = part[k]; part[k] = run; run += x; }
+        *n_slots = run;
     }
     __syncthreads();
     int run = part[tid];
-    for (int c = a; c < b; ++c) { const int x = cell_cnt[c]; cell_cnt[c] = run; run += x; }
+    for (int c = a; c < b; ++c) {
+        const int x = (cell_cnt[c] + G - 1) / G;
+        slot_off[c] = run;
+        cell_cnt[c] = 0;
+        run += x;
+    }
 }
 
-__global__ void k_item_scatter(const WorkItem* __restrict__ items, int64_t n, int* __restrict__ cell_off,
-                               int* __restrict__ order) {
+// slots[(slot_off[cell] + r / G) * G + r % G] = item, r = arrival rank of the item inside its cell
+__global__ void k_item_scatter(const WorkItem* __restrict__ items, int64_t n, const int* __restrict__ slot_off,
+                               int* __restrict__ cursor, int G, int* __restrict__ slots) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) order[atomicAdd(&cell_off[items[i].cell], 1)] = (int)i;
+    if (i >= n) return;
+    const int c = items[i].cell;
+    const int r = atomicAdd(&cursor[c], 1);
+    slots[(slot_off[c] + r / G) * G + (r % G)] = (int)i;
+}
+
+// no sorting (huge V): slot i = item i alone
+__global__ void k_identity_slots(int64_t n, int G, int* __restrict__ slots, int* __restrict__ n_slots) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        slots[i * G] = (int)i;
+        for (int g = 1; g < G; ++g) slots[i * G + g] = -1;
+    }
+    if (i == 0) *n_slots = (int)n;
 }
 
 // ================================================================================================
@@ -552,38 +575,72 @@ __global__ __launch_bounds__(256) void k_adc_scan(const WorkItem* __restrict__ i
 //    identical codes are common in real indexes -- are resolved on (dist, pos), never on float32;
 //  * at the end every wave holds <= `limit` exact hits; they are written as cis_hit and the
 //    per-query merge ranks them by (dist, visit_rank, pos).
-template <int NR>
-__device__ __forceinline__ void wave_bitonic_sort(uint32_t (&k)[NR]) {
+// value of lane (l ^ LJ) for every lane l, on the VALU only (DPP / permlane swaps): the LDS pipe is the
+// scan's bottleneck, so the in-register sorts must not use ds_bpermute.
+template <int LJ>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    if constexpr (LJ == 1) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    } else if constexpr (LJ == 2) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    } else if constexpr (LJ == 4) {
+        const int a = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);      // row_half_mirror: l ^ 7
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, a, 0x1B, 0xF, 0xF, false);        // quad_perm [3,2,1,0]: ^ 3
+    } else if constexpr (LJ == 8) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);  // row_ror:8 == l ^ 8 in a row of 16
+    } else if constexpr (LJ == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // .x = even rows twice, .y = odd rows twice
+        return (threadIdx.x & 16) ? r[0] : r[1];
+    } else {
+        static_assert(LJ == 32, "lane_xor: LJ must be a power of two below 64");
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // .x = low half twice, .y = high half twice
+        return (threadIdx.x & 32) ? r[0] : r[1];
+    }
+}
+
+template <int NR, int KK, int J>
+__device__ __forceinline__ void bitonic_step(uint32_t (&k)[NR]) {
     const int lane = threadIdx.x & 63;
-    constexpr int N = NR * 64;  // element e = lane*NR + r
+    if constexpr (J < NR) {
 #pragma unroll
-    for (int kk = 2; kk <= N; kk <<= 1) {
-#pragma unroll
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            if (j < NR) {
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    if ((r & j) == 0) {
-                        const bool asc = (((lane * NR + r) & kk) == 0);
-                        const uint32_t a = k[r], b = k[r | j];
-                        const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-                        k[r] = asc ? lo : hi;
-                        k[r | j] = asc ? hi : lo;
-                    }
-                }
-            } else {
-                const int lj = j / NR;
-                const bool lower = ((lane & lj) == 0);
-                const bool asc = (((lane * NR) & kk) == 0);
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const uint32_t o = (uint32_t)__shfl_xor((int)k[r], lj);
-                    const uint32_t mn = k[r] < o ? k[r] : o, mx = k[r] < o ? o : k[r];
-                    k[r] = (lower == asc) ? mn : mx;
-                }
+        for (int r = 0; r < NR; ++r) {
+            if ((r & J) == 0) {
+                const bool asc = (((lane * NR + r) & KK) == 0);
+                const uint32_t a = k[r], b = k[r | J];
+                const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+                k[r] = asc ? lo : hi;
+                k[r | J] = asc ? hi : lo;
             }
         }
+    } else {
+        constexpr int LJ = J / NR;
+        const bool lower = ((lane & LJ) == 0);
+        const bool asc = (((lane * NR) & KK) == 0);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const uint32_t o = lane_xor<LJ>(k[r]);
+            const uint32_t mn = k[r] < o ? k[r] : o, mx = k[r] < o ? o : k[r];
+            k[r] = (lower == asc) ? mn : mx;
+        }
     }
+}
+
+template <int NR, int KK, int J>
+__device__ __forceinline__ void bitonic_merge(uint32_t (&k)[NR]) {
+    bitonic_step<NR, KK, J>(k);
+    if constexpr (J > 1) bitonic_merge<NR, KK, J / 2>(k);
+}
+
+template <int NR, int KK>
+__device__ __forceinline__ void bitonic_levels(uint32_t (&k)[NR]) {
+    if constexpr (KK > 2) bitonic_levels<NR, KK / 2>(k);
+    bitonic_merge<NR, KK, KK / 2>(k);
+}
+
+// ascending sort of the NR*64 keys of a wave, element e = lane*NR + r
+template <int NR>
+__device__ __forceinline__ void wave_bitonic_sort(uint32_t (&k)[NR]) {
+    bitonic_levels<NR, NR * 64>(k);
 }
 
 template <int NR>
@@ -595,13 +652,20 @@ __device__ __forceinline__ uint32_t wave_kth(const uint32_t (&k)[NR], int i) {  
     return (uint32_t)__shfl((int)v, i / NR);
 }
 
-struct ScanShared {
-    uint64_t wt[4];  // per wave: exact dist bits that >= ceil(limit/4) of its candidates do not exceed
-    uint64_t wl[4];  // per wave: exact dist bits that >= limit of its candidates do not exceed
+#ifdef CIS_SCAN_COUNTERS
+__device__ unsigned long long g_scan_ctr[8];  // compactions, rescored entries, exact-cut, second sorts, appended
+#define CIS_CTR(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_scan_ctr[i], (unsigned long long)(v)); } while (0)
+#else
+#define CIS_CTR(i, v) do { } while (0)
+#endif
+
+struct ScanShared {  // one per query handled by the workgroup
+    uint64_t wt[8];  // per wave: exact dist bits that >= ceil(limit/NW) of its candidates do not exceed
+    uint64_t wl[8];  // per wave: exact dist bits that >= limit of its candidates do not exceed
     float bound_f;   // block bound rounded UP to float32 for the hot loop (refreshed at every compaction;
                      // a lost concurrent update only leaves it looser for a while)
     int pad0;
-    int wcnt[4];     // survivors per wave at the end
+    int wcnt[8];     // survivors per wave at the end
 };
 
 static __device__ __forceinline__ float lds_ld(const float* p) {
@@ -618,11 +682,12 @@ static __device__ __forceinline__ void lds_st(uint64_t* p, uint64_t v) {
 }
 
 static __device__ __forceinline__ float block_bound_f32(const ScanShared* sh) { return lds_ld(&sh->bound_f); }
+template <int NW>
 static __device__ __forceinline__ uint64_t block_bound_u64(const ScanShared* sh) {
     uint64_t t = lds_ld(&sh->wt[0]);
     uint64_t l = lds_ld(&sh->wl[0]);
 #pragma unroll
-    for (int i = 1; i < 4; ++i) {
+    for (int i = 1; i < NW; ++i) {
         const uint64_t a = lds_ld(&sh->wt[i]), b = lds_ld(&sh->wl[i]);
         t = a > t ? a : t;
         l = b < l ? b : l;
@@ -669,12 +734,15 @@ static __device__ __forceinline__ uint64_t hi_to_bound(uint32_t vhi) {
 // Region entries are always in increasing candidate position (appends are, and the compaction is
 // stable), so among exactly equal distances "first in the region" == "smallest pos".
 // Wave-synchronous: no s_barrier inside.
-template <int M, int NR>
+template <int M, int NR, int NW>
 __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt, int nexact, int L, int Lw,
                                             ScanShared* sh, int w, const uint8_t* __restrict__ codes, int64_t start,
-                                            int K, const double* __restrict__ t0, const double* __restrict__ t1) {
+                                            int K, const double* __restrict__ t0, const double* __restrict__ t1,
+                                            uint32_t& dup_pos) {
     const int lane = threadIdx.x & 63;
     const uint64_t INF64 = 0x7ff0000000000000ull;
+    CIS_CTR(0, 1);
+    CIS_CTR(1, cnt - nexact);
     // new entries: M <= 8 stashed the code itself in the key slot at append time; M = 16 re-reads it
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -719,6 +787,7 @@ __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt,
             g += __popcll(__ballot(keep[r] && hi[r] == vhi));
         }
         int need = L - c_less;  // members of the group {hi == vhi} to keep, 1 <= need <= g
+        CIS_CTR(2, 1);
         if (need >= g) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) keep[r] = keep[r] && hi[r] <= vhi;
@@ -738,6 +807,7 @@ __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt,
             }
             uint32_t vlo = lo_first;
             if (!uniform) {
+                CIS_CTR(3, 1);
                 uint32_t t2[NR];
 #pragma unroll
                 for (int r = 0; r < NR; ++r) t2[r] = (keep[r] && hi[r] == vhi) ? lo[r] : 0xffffffffu;
@@ -754,6 +824,10 @@ __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt,
                 const unsigned long long m = __ballot(tie);
                 const int rank = seen + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
                 keep[r] = keep[r] && (hi[r] < vhi || (hi[r] == vhi && (lo[r] < vlo || (tie && rank < need))));
+                // The cut fell inside a group of exactly equal distances.  Remember one member: every LATER
+                // candidate with the same code has the same distance and a larger position, so it loses
+                // against all L entries kept here and the hot loop may skip it (duplicate codes are common).
+                if (seen == 0 && m) dup_pos = (uint32_t)__shfl((int)pp[r], __ffsll((long long)m) - 1);
                 seen += __popcll(m);
             }
         }
@@ -763,7 +837,7 @@ __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt,
         if (boundL < lds_ld(&sh->wl[w])) lds_st(&sh->wl[w], boundL);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    const uint64_t bound = block_bound_u64(sh);
+    const uint64_t bound = block_bound_u64<NW>(sh);
     if (lane == 0) {
         const float bf = __double2float_ru(__longlong_as_double((long long)bound));
         if (bf < lds_ld(&sh->bound_f)) lds_st(&sh->bound_f, bf);
@@ -784,10 +858,10 @@ __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt,
 }
 
 // Drop entries above the (final) block bound; entries already carry exact keys.  Stable.
-template <int NR>
+template <int NR, int NW>
 __device__ __forceinline__ int wave_filter(uint64_t* rk, uint32_t* rp, int cnt, const ScanShared* sh) {
     const int lane = threadIdx.x & 63;
-    const uint64_t bound = block_bound_u64(sh);
+    const uint64_t bound = block_bound_u64<NW>(sh);
     uint64_t k[NR];
     uint32_t pp[NR];
 #pragma unroll
@@ -891,145 +965,274 @@ __device__ __forceinline__ float adc32(const CodeWords<M>& c, const char* __rest
     return acc;
 }
 
-template <int M, int NR, int U>
-__device__ __forceinline__ void scan2_item(const WorkItem& it, int item_idx, const double* __restrict__ T,
-                                           const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids, int K, int L,
-                                           int S, float margin, cis_hit* __restrict__ item_hits, int* __restrict__ item_n,
-                                           char* smem) {
+// float32 ADC sums of one candidate for G queries at once: the LDS table interleaves the queries,
+// tab[k][j][g], so ONE ds_read (b32 for G=1, b64 for G=2) serves all G queries of the workgroup.
+template <int M, int G>
+__device__ __forceinline__ void adc32g(const CodeWords<M>& c, const char* __restrict__ tab, const RotConsts<M>& rc,
+                                       float (&out)[G]) {
+    constexpr int SH = ((M == 4) ? 4 : (M == 8 ? 5 : 6)) + (G == 2 ? 1 : 0);  // log2(M * G * 4 bytes)
+    uint32_t D[(M + 3) / 4];
+    if constexpr (M == 4) {
+        D[0] = c.w[0];
+    } else if constexpr (M == 8) {
+        D[0] = rc.hsel ? c.w[1] : c.w[0];
+        D[1] = rc.hsel ? c.w[0] : c.w[1];
+    } else {
+        const bool b0 = rc.hsel & 1, b1 = rc.hsel & 2;
+        const uint32_t x01 = b0 ? c.w[1] : c.w[0], y01 = b0 ? c.w[0] : c.w[1];
+        const uint32_t x23 = b0 ? c.w[3] : c.w[2], y23 = b0 ? c.w[2] : c.w[3];
+        D[0] = b1 ? x23 : x01;
+        D[1] = b1 ? y23 : y01;
+        D[2] = b1 ? x01 : x23;
+        D[3] = b1 ? y01 : y23;
+    }
+    if constexpr (G == 1) {
+        float f[M];
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+            const uint32_t k = __builtin_amdgcn_ubfe(D[t >> 2], rc.sh[t & 3], 8);
+            f[t] = *reinterpret_cast<const float*>(tab + ((k << SH) | rc.cj[t]));
+        }
+#pragma unroll
+        for (int st = 1; st < M; st <<= 1)
+#pragma unroll
+            for (int t = 0; t < M; t += 2 * st) f[t] = f[t] + f[t + st];
+        out[0] = f[0];
+    } else {
+        float2 f[M];
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+            const uint32_t k = __builtin_amdgcn_ubfe(D[t >> 2], rc.sh[t & 3], 8);
+            f[t] = *reinterpret_cast<const float2*>(tab + ((k << SH) | (rc.cj[t] << 1)));
+        }
+#pragma unroll
+        for (int st = 1; st < M; st <<= 1)
+#pragma unroll
+            for (int t = 0; t < M; t += 2 * st) { f[t].x = f[t].x + f[t + st].x; f[t].y = f[t].y + f[t + st].y; }
+        out[0] = f[0].x;
+        out[1] = f[0].y;
+    }
+}
+
+// One workgroup (NW waves) scans one cell chunk for `ng` <= G queries that all visit it.
+template <int M, int NR, int U, int G, int NW>
+__device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (&item_idx)[G], int ng,
+                                            const double* __restrict__ T, const uint8_t* __restrict__ codes,
+                                            const int64_t* __restrict__ ids, int K, int L, int S, float margin,
+                                            cis_hit* __restrict__ item_hits, int* __restrict__ item_n, char* smem) {
     constexpr int R = NR * 64;
-    char* tab = smem;                                                       // [K][M] float32
-    uint64_t* rk_all = reinterpret_cast<uint64_t*>(smem + (size_t)K * M * 4);  // [4][R] exact keys
-    uint32_t* rp_all = reinterpret_cast<uint32_t*>(rk_all + 4 * R);            // [4][R] positions
-    ScanShared* sh = reinterpret_cast<ScanShared*>(rp_all + 4 * R);
+    char* tab = smem;                                                              // [K][M][G] float32
+    uint64_t* rk_all = reinterpret_cast<uint64_t*>(smem + (size_t)K * M * G * 4);  // [G][NW][R] exact keys / stashed codes
+    uint32_t* rp_all = reinterpret_cast<uint32_t*>(rk_all + G * NW * R);           // [G][NW][R] positions
+    ScanShared* sh = reinterpret_cast<ScanShared*>(rp_all + G * NW * R);           // [G]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nf = M / 2;
-    const double* t0 = T + (int64_t)it.tab0 * nf * K;
-    const double* t1 = T + (int64_t)it.tab1 * nf * K;
+    constexpr int nf = M / 2;
+    const double* t0[G];
+    const double* t1[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        t0[g] = T + (int64_t)it[g].tab0 * nf * K;
+        t1[g] = T + (int64_t)it[g].tab1 * nf * K;
+    }
     const float INF = __int_as_float(0x7f800000);
     {
         float* tf = reinterpret_cast<float*>(tab);
-        for (int e = tid; e < nf * K; e += 256) {
+        for (int e = tid; e < nf * K; e += NW * 64) {
             const int j = e / K, k = e - j * K;
-            tf[k * M + j] = (float)t0[e];
-            tf[k * M + nf + j] = (float)t1[e];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const bool on = g < ng;  // an absent second query gets +inf tables: nothing ever passes
+                tf[(k * M + j) * G + g] = on ? (float)t0[g][e] : INF;
+                tf[(k * M + nf + j) * G + g] = on ? (float)t1[g][e] : INF;
+            }
         }
-        if (tid < 4) {
-            sh->wt[tid] = 0x7ff0000000000000ull; sh->wl[tid] = 0x7ff0000000000000ull;
-            sh->wcnt[tid] = 0;
-            if (tid == 0) sh->bound_f = INF;
+        if (tid < 8 * G) {
+            const int g = tid >> 3, i = tid & 7;
+            sh[g].wt[i] = 0x7ff0000000000000ull; sh[g].wl[i] = 0x7ff0000000000000ull;
+            sh[g].wcnt[i] = 0;
+            if (i == 0) sh[g].bound_f = INF;
         }
     }
     __syncthreads();
-    uint64_t* rk = rk_all + w * R;
-    uint32_t* rp = rp_all + w * R;
     const RotConsts<M> rc = make_rot<M>(lane);
-    const int Lw = (L + 3) / 4;
-    const int len = it.len;
+    const int Lw = (L + NW - 1) / NW;
+    const int len = it[0].len;
+    const int64_t start = it[0].start;
     const int nit = (len + 64 * U - 1) / (64 * U);
-    int cnt = 0, nexact = 0;
+    int cnt[G], nexact[G];
+    CodeWords<M> dup[G];  // per query: a code whose later copies cannot enter this wave's top-L any more
+    bool has_dup[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { cnt[g] = 0; nexact[g] = 0; has_dup[g] = false; dup[g] = CodeWords<M>(); }
     CodeWords<M> nxt[U];
     if (w < nit) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int p = w * 64 * U + u * 64 + lane;
-            nxt[u] = load_code<M>(codes, it.start + (p < len ? p : len - 1));
+            nxt[u] = load_code<M>(codes, start + (p < len ? p : len - 1));
         }
     }
-    for (int iter = w; iter < nit; iter += 4) {
+    for (int iter = w; iter < nit; iter += NW) {
         const int base = iter * 64 * U;
         CodeWords<M> cur[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-        if (iter + 4 < nit) {  // software prefetch: the next iteration's codes are in flight while this one computes
+        if (iter + NW < nit) {  // software prefetch: the next iteration's codes are in flight while this one computes
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int p = (iter + 4) * 64 * U + u * 64 + lane;
-                nxt[u] = load_code<M>(codes, it.start + (p < len ? p : len - 1));  // tail lanes re-read the last code; masked below
+                const int p = (iter + NW) * 64 * U + u * 64 + lane;
+                nxt[u] = load_code<M>(codes, start + (p < len ? p : len - 1));  // tail lanes re-read the last code; masked below
             }
         }
-        float d[U];
+        float d[U][G];
 #pragma unroll
-        for (int u = 0; u < U; ++u) d[u] = adc32<M>(cur[u], tab, rc);
-        float thrm = block_bound_f32(sh) * margin;
+        for (int u = 0; u < U; ++u) adc32g<M, G>(cur[u], tab, rc, d[u]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g >= ng) break;
+            uint64_t* rk = rk_all + (g * NW + w) * R;
+            uint32_t* rp = rp_all + (g * NW + w) * R;
+            float thrm = block_bound_f32(&sh[g]) * margin;
 #ifdef CIS_PROBE_HOTLOOP
-        thrm = (margin > 100.f) ? thrm : -1.0f;  // probe: nothing passes, only the float32 scan runs
+            thrm = (margin > 100.f) ? thrm : -1.0f;  // probe: nothing passes, only the float32 scan runs
 #endif
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int p = base + u * 64 + lane;
-            bool pass = (p < len) && (d[u] <= thrm);
-            unsigned long long m = __ballot(pass);
-            int n = __popcll(m);
-            if (cnt + n > R) {  // cannot happen right after a compaction: cnt <= L <= R - 64
-                cnt = wave_compact<M, NR>(rk, rp, cnt, nexact, L, Lw, sh, w, codes, it.start, K, t0, t1);
-                nexact = cnt;
-                thrm = block_bound_f32(sh) * margin;
-                pass = pass && (d[u] <= thrm);
-                m = __ballot(pass);
-                n = __popcll(m);
+            for (int u = 0; u < U; ++u) {
+                const int p = base + u * 64 + lane;
+                bool pass = (p < len) && (d[u][g] <= thrm);
+                if (has_dup[g]) {
+                    bool same = true;
+#pragma unroll
+                    for (int i = 0; i < (M + 3) / 4; ++i) same = same && (cur[u].w[i] == dup[g].w[i]);
+                    pass = pass && !same;
+                }
+                unsigned long long m = __ballot(pass);
+                int n = __popcll(m);
+                if (n == 0) continue;
+                if (cnt[g] + n > R) {  // cannot happen right after a compaction: cnt <= L <= R - 64
+                    uint32_t dp = 0xffffffffu;
+                    cnt[g] = wave_compact<M, NR, NW>(rk, rp, cnt[g], nexact[g], L, Lw, &sh[g], w, codes, start, K, t0[g], t1[g], dp);
+                    if (dp != 0xffffffffu) {
+                        dup[g] = load_code<M>(codes, start + (int64_t)__builtin_amdgcn_readfirstlane((int)dp));
+                        has_dup[g] = true;
+                    }
+                    nexact[g] = cnt[g];
+                    thrm = block_bound_f32(&sh[g]) * margin;
+                    pass = pass && (d[u][g] <= thrm);
+                    m = __ballot(pass);
+                    n = __popcll(m);
+                }
+                const int idx = cnt[g] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                if (pass) {
+                    rp[idx] = (uint32_t)p;
+                    if constexpr (M == 4) rk[idx] = cur[u].w[0];  // stash the code; re-scored exactly at the next compaction
+                    if constexpr (M == 8) rk[idx] = ((uint64_t)cur[u].w[1] << 32) | cur[u].w[0];
+                }
+                cnt[g] += n;
+                CIS_CTR(4, n);
             }
-            const int idx = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            if (pass) {
-                rp[idx] = (uint32_t)p;
-                if constexpr (M == 4) rk[idx] = cur[u].w[0];  // stash the code; re-scored exactly at the next compaction
-                if constexpr (M == 8) rk[idx] = ((uint64_t)cur[u].w[1] << 32) | cur[u].w[0];
-            }
-            cnt += n;
         }
     }
-    // publish this wave's final bounds, then filter once more with everybody's final bounds
-    cnt = wave_compact<M, NR>(rk, rp, cnt, nexact, L, Lw, sh, w, codes, it.start, K, t0, t1);
-    __syncthreads();
-    cnt = wave_filter<NR>(rk, rp, cnt, sh);
-    if (lane == 0) sh->wcnt[w] = cnt;
-    __syncthreads();
-    const int c0 = sh->wcnt[0], c1 = sh->wcnt[1], c2 = sh->wcnt[2], c3 = sh->wcnt[3];
-    const int off = (w > 0 ? c0 : 0) + (w > 1 ? c1 : 0) + (w > 2 ? c2 : 0);
-    cis_hit* out = item_hits + (int64_t)item_idx * S + off;  // S >= 4 * L >= c0 + c1 + c2 + c3
-    for (int e = lane; e < cnt; e += 64) {
-        const uint32_t p = rp[e];
-        cis_hit hh;
-        hh.dist = __longlong_as_double((long long)rk[e]);
-        hh.visit_rank = (uint32_t)it.rank;
-        hh.pos = (uint32_t)it.pos0 + p;
-        hh.id = ids[it.start + p];
-        hh.cell = it.cell;
-        hh.reserved = 0;
-        out[e] = hh;
+    // publish every wave's final bounds, then filter once more with everybody's final bounds
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g >= ng) break;
+        uint64_t* rk = rk_all + (g * NW + w) * R;
+        uint32_t* rp = rp_all + (g * NW + w) * R;
+        uint32_t dp = 0xffffffffu;
+        cnt[g] = wave_compact<M, NR, NW>(rk, rp, cnt[g], nexact[g], L, Lw, &sh[g], w, codes, start, K, t0[g], t1[g], dp);
     }
-    if (tid == 0) item_n[item_idx] = c0 + c1 + c2 + c3;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g >= ng) break;
+        uint64_t* rk = rk_all + (g * NW + w) * R;
+        uint32_t* rp = rp_all + (g * NW + w) * R;
+        cnt[g] = wave_filter<NR, NW>(rk, rp, cnt[g], &sh[g]);
+        if (lane == 0) sh[g].wcnt[w] = cnt[g];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g >= ng) break;
+        const uint64_t* rk = rk_all + (g * NW + w) * R;
+        const uint32_t* rp = rp_all + (g * NW + w) * R;
+        int off = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int c = sh[g].wcnt[i];
+            off += (i < w) ? c : 0;
+            total += c;
+        }
+        cis_hit* out = item_hits + (int64_t)item_idx[g] * S + off;  // S >= NW * L >= total
+        for (int e = lane; e < cnt[g]; e += 64) {
+            const uint32_t p = rp[e];
+            cis_hit hh;
+            hh.dist = __longlong_as_double((long long)rk[e]);
+            hh.visit_rank = (uint32_t)it[g].rank;
+            hh.pos = (uint32_t)it[g].pos0 + p;
+            hh.id = ids[start + p];
+            hh.cell = it[g].cell;
+            hh.reserved = 0;
+            out[e] = hh;
+        }
+        if (tid == 0) item_n[item_idx[g]] = total;
+    }
 }
 
-// Persistent launch: (blocks per CU) x 256 workgroups pull work items from eight queues, one per XCD.
-// The work items arrive sorted by coarse cell (`order`); queue x owns the x-th eighth of that list, so
-// the workgroups resident on one XCD (workgroup b runs on XCD b % 8 -- observed dispatch rule, used
-// for speed only) stream the same few cells through that XCD's private L2.  A workgroup whose own
-// queue is empty steals from the others, which removes the tail caused by unequal cell sizes.
-template <int M, int NR, int U>
-__global__ __launch_bounds__(256) void k_adc_scan2(const WorkItem* __restrict__ items, int n_items,
-                                                   const double* __restrict__ T, const uint8_t* __restrict__ codes,
-                                                   const int64_t* __restrict__ ids, int K, int L, int S, float margin,
-                                                   const int* __restrict__ order, int* __restrict__ queue_ctr /* [8], zeroed */,
-                                                   cis_hit* __restrict__ item_hits, int* __restrict__ item_n) {
+// Persistent launch: (blocks per CU) x 256 workgroups pull SLOTS from eight queues, one per XCD.  A
+// slot holds up to G work items of the same coarse cell (slots come from the cell-sorted item list);
+// queue x owns the x-th eighth of the slot list, so the workgroups resident on one XCD (workgroup b
+// runs on XCD b % 8 -- observed dispatch rule, used for speed only) stream the same few cells through
+// that XCD's private L2.  A workgroup whose own queue is empty steals from the others, which removes
+// the tail caused by unequal cell sizes.
+template <int M, int NR, int U, int G, int NW>
+__global__ __launch_bounds__(NW * 64) void k_adc_scan2(const WorkItem* __restrict__ items, const int* __restrict__ slots,
+                                                       const int* __restrict__ n_slots_ptr, const double* __restrict__ T,
+                                                       const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids,
+                                                       int K, int L, int S, float margin,
+                                                       int* __restrict__ queue_ctr /* [8], zeroed */,
+                                                       cis_hit* __restrict__ item_hits, int* __restrict__ item_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int R = NR * 64;
-    int* s_next = reinterpret_cast<int*>(smem + (size_t)K * M * 4 + (size_t)4 * R * 12 + sizeof(ScanShared));
-    const int q8 = n_items >> 3, r8 = n_items & 7;
+    int* s_next = reinterpret_cast<int*>(smem + (size_t)K * M * G * 4 + (size_t)G * NW * R * 12 + G * sizeof(ScanShared));
+    const int n_slots = *n_slots_ptr;
+    const int q8 = n_slots >> 3, r8 = n_slots & 7;
     const int home = blockIdx.x & 7;
     for (int a = 0; a < 8; ++a) {
         const int x = (home + a) & 7;
-        const int start = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
+        const int qstart = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
         const int count = q8 + (x < r8 ? 1 : 0);
         while (true) {
-            __syncthreads();  // previous item fully written out; LDS may be reused
+            __syncthreads();  // previous slot fully written out; LDS may be reused
             if (threadIdx.x == 0) *s_next = atomicAdd(&queue_ctr[x], 1);
             __syncthreads();
             const int j = *s_next;
             if (j >= count) break;
-            const int item_idx = order ? order[start + j] : start + j;
-            const WorkItem it = items[item_idx];
-            scan2_item<M, NR, U>(it, item_idx, T, codes, ids, K, L, S, margin, item_hits, item_n, smem);
+            const int slot = qstart + j;
+            WorkItem it[G];
+            int idx[G];
+            int ng = 0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                idx[g] = slots[slot * G + g];
+                if (idx[g] >= 0) { it[g] = items[idx[g]]; ng = g + 1; }
+                else { it[g] = it[0]; idx[g] = idx[0]; }
+            }
+            if constexpr (G == 2) {
+                // the two items must cover the same chunk of the same cell; otherwise run them one by one
+                if (ng == 2 && (it[0].start != it[1].start || it[0].len != it[1].len)) {
+                    WorkItem one[G] = {it[0], it[0]};
+                    int oi[G] = {idx[0], idx[0]};
+                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, codes, ids, K, L, S, margin, item_hits, item_n, smem);
+                    __syncthreads();
+                    one[0] = it[1]; one[1] = it[1]; oi[0] = idx[1]; oi[1] = idx[1];
+                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, codes, ids, K, L, S, margin, item_hits, item_n, smem);
+                    continue;
+                }
+            }
+            scan2_group<M, NR, U, G, NW>(it, idx, ng, T, codes, ids, K, L, S, margin, item_hits, item_n, smem);
         }
     }
 }
@@ -1387,6 +1590,73 @@ extern "C" int cis_index_set_profiling(cis_index* ix, int enable) {
     return CIS_OK;
 }
 
+// ---- device self test of the wave-level primitives (tests/test_lopq_hip_parity.py) --------------
+template <int LJ>
+__device__ int selftest_xor(uint32_t v) { return lane_xor<LJ>(v) != (uint32_t)__shfl_xor((int)v, LJ) ? 1 : 0; }
+
+template <int NR>
+__device__ int selftest_sort(uint32_t seed) {
+    const int lane = threadIdx.x & 63;
+    uint32_t k[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        uint32_t x = seed ^ (uint32_t)(lane * NR + r) * 2654435761u;
+        x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        k[r] = x % 1000u;  // many duplicates
+    }
+    uint32_t mine[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) mine[r] = k[r];
+    wave_bitonic_sort<NR>(k);
+    int bad = 0;
+    // sortedness: element e <= element e+1 (e = lane*NR + r)
+#pragma unroll
+    for (int r = 0; r + 1 < NR; ++r) bad += k[r] > k[r + 1];
+    const uint32_t nxt = (uint32_t)__shfl_down((int)k[0], 1);
+    if (lane < 63) bad += k[NR - 1] > nxt;
+    // multiset preserved: compare sums and xors
+    uint32_t s0 = 0, s1 = 0, x0 = 0, x1 = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { s0 += mine[r]; s1 += k[r]; x0 ^= mine[r] * 40503u; x1 ^= k[r] * 40503u; }
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += (uint32_t)__shfl_xor((int)s0, o); s1 += (uint32_t)__shfl_xor((int)s1, o);
+        x0 ^= (uint32_t)__shfl_xor((int)x0, o); x1 ^= (uint32_t)__shfl_xor((int)x1, o);
+    }
+    bad += (s0 != s1) + (x0 != x1);
+    return bad;
+}
+
+__global__ void k_selftest(int* __restrict__ errors) {
+    const uint32_t v = (uint32_t)threadIdx.x * 7919u + blockIdx.x * 104729u + 17u;
+    int bad = selftest_xor<1>(v) + selftest_xor<2>(v) + selftest_xor<4>(v) + selftest_xor<8>(v) + selftest_xor<16>(v) +
+              selftest_xor<32>(v);
+    bad += selftest_sort<4>(blockIdx.x * 977u + 1u) + selftest_sort<8>(blockIdx.x * 31u + 5u);
+    if (bad) atomicAdd(errors, bad);
+}
+
+#ifdef CIS_SCAN_COUNTERS
+extern "C" int cis_debug_counters(unsigned long long* out, int reset) {
+    CIS_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_ctr), 8 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        CIS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_scan_ctr), z, sizeof(z)));
+    }
+    return CIS_OK;
+}
+#endif
+
+extern "C" int cis_selftest(int* n_errors) {
+    CIS_REQUIRE(n_errors != nullptr, "NULL argument");
+    CIS_TRY(cis_lazy_init());
+    int* d = nullptr;
+    CIS_CHECK_HIP(hipMalloc((void**)&d, sizeof(int)));
+    CIS_CHECK_HIP(hipMemset(d, 0, sizeof(int)));
+    hipLaunchKernelGGL(k_selftest, dim3(64), dim3(64), 0, nullptr, d);
+    CIS_CHECK_HIP(hipMemcpy(n_errors, d, sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return CIS_OK;
+}
+
 extern "C" int cis_index_set_scan_mode(cis_index* ix, int mode) {
     CIS_REQUIRE(ix != nullptr && (mode == 0 || mode == 1), "bad scan mode");
     ix->force_exact_scan = (mode == 1);
@@ -1451,36 +1721,75 @@ static void launch_scan_exact(int M, int64_t n_items, hipStream_t st, const Work
     else launch_scan_m<4096, 4>(M, n_items, st, items, T, codes, ids, K, L, S, flag, hits, hitn);
 }
 
-// float32-prefilter kernel (v2): M in {4, 8, 16}, K <= 256, L <= 400
+// float32-prefilter kernel (v2): M in {4, 8, 16}, K <= 256, L <= 448
 static bool scan2_supported(int M, int K, int L) { return (M == 4 || M == 8 || M == 16) && K <= 256 && L >= 1 && L <= 448; }
 
-template <int M, int NR>
-static void launch_scan2_t(int64_t n_items, hipStream_t st, const WorkItem* items, const double* T, const uint8_t* codes,
-                           const int64_t* ids, int K, int L, int S, const int* order, int* qctr, cis_hit* hits,
-                           int* hitn) {
-    const size_t lds = (size_t)K * M * 4 + (size_t)4 * NR * 64 * 12 + sizeof(ScanShared) + 16;
-    const float eps = 2.0f * (float)M * 5.9604645e-8f;  // 2 * M * 2^-24
-    const float margin = 1.0f + 3.0f * eps;
-    const int64_t resident = 256 * 5;  // 256 CUs x the 5 workgroups/CU the kernel's VGPR budget admits
-    const unsigned grid = (unsigned)(n_items < resident ? ((n_items + 7) / 8) * 8 : resident);
-    hipLaunchKernelGGL((k_adc_scan2<M, NR, 4>), dim3(grid), dim3(256), lds, st, items, (int)n_items, T, codes, ids, K, L, S,
-                       margin, order, qctr, hits, hitn);
+struct Scan2Geom { int G, NW, U, S; size_t lds; };
+
+// G = 2 queries per workgroup of 8 waves (one 2-query table set shared by 8 waves) when the batch is
+// large enough to find pairs; G = 1 with 4 waves for small batches (latency mode).
+static Scan2Geom scan2_geom(int M, int K, int L, int nq) {
+    Scan2Geom g;
+    const int NR = (L <= 192) ? 4 : 8;
+    g.G = 1;
+    g.NW = 4;
+    g.U = 2;
+    (void)nq;
+    if (const char* e = getenv("CIS_SCAN_GEOM")) {  // experiments: "G,NW,U" out of the instantiated set
+        int a = 0, b = 0, c = 0;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && ((a == 1 && b == 4) || (a == 2 && b == 4 && c == 4) || (a == 2 && b == 8 && c == 2)) && (c == 2 || c == 4)) {
+            g.G = a; g.NW = b; g.U = c;
+        }
+    }
+    g.S = g.NW * L;
+    g.lds = (size_t)K * M * g.G * 4 + (size_t)g.G * g.NW * NR * 64 * 12 + g.G * sizeof(ScanShared) + 16;
+    return g;
 }
 
-static void launch_scan2(int M, int64_t n_items, hipStream_t st, const WorkItem* items, const double* T,
-                         const uint8_t* codes, const int64_t* ids, int K, int L, int S, const int* order, int* qctr,
-                         cis_hit* hits, int* hitn) {
-    const bool small = L <= 192;
-    if (M == 4) {
-        if (small) launch_scan2_t<4, 4>(n_items, st, items, T, codes, ids, K, L, S, order, qctr, hits, hitn);
-        else launch_scan2_t<4, 8>(n_items, st, items, T, codes, ids, K, L, S, order, qctr, hits, hitn);
-    } else if (M == 8) {
-        if (small) launch_scan2_t<8, 4>(n_items, st, items, T, codes, ids, K, L, S, order, qctr, hits, hitn);
-        else launch_scan2_t<8, 8>(n_items, st, items, T, codes, ids, K, L, S, order, qctr, hits, hitn);
-    } else {
-        if (small) launch_scan2_t<16, 4>(n_items, st, items, T, codes, ids, K, L, S, order, qctr, hits, hitn);
-        else launch_scan2_t<16, 8>(n_items, st, items, T, codes, ids, K, L, S, order, qctr, hits, hitn);
+template <int M, int NR, int G, int NW, int U>
+static void launch_scan2_t(int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots, const int* n_slots,
+                           const double* T, const uint8_t* codes, const int64_t* ids, int K, int L, int S, size_t lds,
+                           int* qctr, cis_hit* hits, int* hitn) {
+    const float eps = 2.0f * (float)M * 5.9604645e-8f;  // 2 * M * 2^-24
+    const float margin = 1.0f + 3.0f * eps;
+    const int per_cu = (int)(163840 / lds) < (32 / NW) ? (int)(163840 / lds) : (32 / NW);
+    const int64_t resident = 256 * (per_cu < 1 ? 1 : per_cu);  // persistent grid: what the chip can hold
+    const int64_t want = (n_items + G - 1) / G + 8;
+    const unsigned grid = (unsigned)(want < resident ? ((want + 7) / 8) * 8 : resident);
+    hipLaunchKernelGGL((k_adc_scan2<M, NR, U, G, NW>), dim3(grid), dim3(NW * 64), lds, st, items, slots, n_slots, T, codes, ids,
+                       K, L, S, margin, qctr, hits, hitn);
+}
+
+template <int M, int NR>
+static void launch_scan2_mr(const Scan2Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
+                            const int* n_slots, const double* T, const uint8_t* codes, const int64_t* ids, int K, int L,
+                            int* qctr, cis_hit* hits, int* hitn) {
+#define CIS_SCAN2_CASE(GG, WW, UU)                                                                                    \
+    if (g.G == GG && g.NW == WW && g.U == UU) {                                                                       \
+        launch_scan2_t<M, NR, GG, WW, UU>(n_items, st, items, slots, n_slots, T, codes, ids, K, L, g.S, g.lds, qctr, hits, hitn); \
+        return;                                                                                                       \
     }
+    CIS_SCAN2_CASE(1, 4, 4)
+    CIS_SCAN2_CASE(1, 4, 2)
+    CIS_SCAN2_CASE(2, 4, 4)
+    CIS_SCAN2_CASE(2, 8, 2)
+#undef CIS_SCAN2_CASE
+}
+
+template <int M>
+static void launch_scan2_m(const Scan2Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
+                           const int* n_slots, const double* T, const uint8_t* codes, const int64_t* ids, int K, int L,
+                           int* qctr, cis_hit* hits, int* hitn) {
+    if (L <= 192) launch_scan2_mr<M, 4>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
+    else launch_scan2_mr<M, 8>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
+}
+
+static void launch_scan2(int M, const Scan2Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
+                         const int* n_slots, const double* T, const uint8_t* codes, const int64_t* ids, int K, int L,
+                         int* qctr, cis_hit* hits, int* hitn) {
+    if (M == 4) launch_scan2_m<4>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
+    else if (M == 8) launch_scan2_m<8>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
+    else launch_scan2_m<16>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
 }
 
 static const int MAX_LIMIT = 3072;
@@ -1575,7 +1884,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     CIS_TRY(ix->w_tabs.reserve((size_t)(n_tabs + 1) * sizeof(TabDesc)));
     CIS_TRY(ix->w_T.reserve((size_t)(n_tabs + 1) * nf * K * sizeof(double)));
     const bool fast = scan2_supported(M, K, L) && !ix->force_exact_scan;
-    const int S = fast ? 4 * L : L;  // hit slots per work item (fast kernel: <= L per wave)
+    const Scan2Geom geom = scan2_geom(M, K, L, nq);
+    const int S = fast ? geom.S : L;  // hit slots per work item (fast kernel: <= L per wave)
     CIS_TRY(ix->w_hits.reserve((size_t)(n_items + 1) * S * sizeof(cis_hit)));
     CIS_TRY(ix->w_hitn.reserve((size_t)(n_items + 1) * 2 * sizeof(int)));
     WorkItem* items = ix->w_items.as<WorkItem>();
@@ -1621,22 +1931,29 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         cis_hit* hits = ix->w_hits.as<cis_hit>();
         int* hitn = ix->w_hitn.as<int>();
         if (fast) {
-            const int* order = nullptr;
-            const bool sort_items = ix->ncells <= 65536;  // sort the work items by cell for L2 locality (skipped for huge V)
-            CIS_TRY(ix->w_order2.reserve((size_t)(n_items + (sort_items ? ix->ncells : 0) + 16) * sizeof(int)));
-            int* qctr = ix->w_order2.as<int>();
-            CIS_CHECK_HIP(hipMemsetAsync(qctr, 0, 8 * sizeof(int), st));
+            // slot list: work items grouped by coarse cell (counting sort; skipped for huge V), G per slot
+            const bool sort_items = ix->ncells <= 65536;
+            const int G = geom.G;
+            const int64_t max_slots = sort_items ? (n_items + ix->ncells) / G + ix->ncells + 2 : n_items;
+            CIS_TRY(ix->w_order2.reserve((size_t)(16 + 2 * ix->ncells + max_slots * G) * sizeof(int)));
+            int* qctr = ix->w_order2.as<int>();  // [8] queue counters, [8] n_slots
+            int* n_slots = qctr + 8;
+            int* cell_cnt = qctr + 16;
+            int* slot_off = cell_cnt + ix->ncells;
+            int* slots = slot_off + ix->ncells;
+            CIS_CHECK_HIP(hipMemsetAsync(qctr, 0, 16 * sizeof(int), st));
             if (sort_items) {
-                int* cell_off = qctr + 8;
-                int* ord = cell_off + ix->ncells;
-                CIS_CHECK_HIP(hipMemsetAsync(cell_off, 0, (size_t)ix->ncells * sizeof(int), st));
-                hipLaunchKernelGGL(k_item_hist, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, cell_off);
-                hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(256), 0, st, cell_off, (int)ix->ncells);
+                CIS_CHECK_HIP(hipMemsetAsync(cell_cnt, 0, (size_t)ix->ncells * sizeof(int), st));
+                CIS_CHECK_HIP(hipMemsetAsync(slots, 0xff, (size_t)max_slots * G * sizeof(int), st));
+                hipLaunchKernelGGL(k_item_hist, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, cell_cnt);
+                hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(256), 0, st, cell_cnt, slot_off, (int)ix->ncells, G, n_slots);
                 hipLaunchKernelGGL(k_item_scatter, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items,
-                                   cell_off, ord);
-                order = ord;
+                                   slot_off, cell_cnt, G, slots);
+            } else {
+                hipLaunchKernelGGL(k_identity_slots, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, n_items, G, slots,
+                                   n_slots);
             }
-            launch_scan2(M, n_items, st, items, T, codes, ids, K, L, S, order, qctr, hits, hitn);
+            launch_scan2(M, geom, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
         }
         else launch_scan_exact(M, n_items, st, items, T, codes, ids, K, L, S, nullptr, hits, hitn);
         ix->stats[3] += 1;

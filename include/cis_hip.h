@@ -64,6 +64,9 @@ const char* cis_last_error(void);
 int cis_device_count(void);
 /* Select the device used by handles created afterwards by this process (default 0). */
 int cis_set_device(int device);
+/* Runs a device self test of the wave-level primitives the scan kernel relies on (DPP / permlane
+ * lane exchanges, in-register bitonic sort); *n_errors = 0 when they behave. */
+int cis_selftest(int* n_errors);
 
 /* ---- LOPQ model: replaces lopq.model.LOPQModel / LOPQModelPCA arithmetic --------------------
  * Parameter layout = the reference's parameter tuple (lopq/lopq/model.py:461-473, :841), each

@@ -279,3 +279,12 @@ def test_many_exact_ties_fall_back_to_exact_kernel():
     best = a["dists"][0, 0]
     tied = a["ids"][0][a["dists"][0] == best]
     assert tied[0] == 10 and (np.diff(tied) > 0).all() and len(tied) == 100
+
+
+def test_device_selftest_of_wave_primitives():
+    """DPP / permlane lane exchanges == __shfl_xor, and the in-register bitonic sort sorts."""
+    import ctypes
+    from columbiaimagesearch_amd import _lib
+    n = ctypes.c_int(-1)
+    _lib.check(_lib.lib().cis_selftest(ctypes.byref(n)))
+    assert n.value == 0

@@ -1,0 +1,31 @@
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+sys.argv = [sys.argv[0]]
+import bench
+from columbiaimagesearch_amd import _lib
+from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+model, z = bench.load_model()
+dev = torch.device("cuda", 0)
+centers = torch.as_tensor(bench.mixture_centers(), device=dev)
+N = 10_000_000; chunk = N // 80
+cs, fs = [], []
+for c in range(80):
+    x = bench.gen_chunk(centers, c, chunk, dev)
+    co, fi = model.predict_batch_dev(x); cs.append(co); fs.append(fi)
+coarse = torch.cat(cs).cpu().numpy().view(np.uint16); fine = torch.cat(fs).cpu().numpy()
+s = LOPQSearcherHIP(model); s.add_codes_array(coarse, fine, ids=np.arange(N, dtype=np.int64), dedup=False)
+x0 = bench.gen_chunk(centers, 0, chunk, dev)
+q = bench.make_queries(x0, 0, 8192, dev)
+s.search_batch_dev(q, quota=10000, limit=100); torch.cuda.synchronize()
+L = _lib.lib(); fn = L.cis_debug_counters; fn.restype = ctypes.c_int
+buf = (ctypes.c_ulonglong * 8)()
+fn(buf, 1)
+s.search_batch_dev(q, quota=10000, limit=100); torch.cuda.synchronize()
+fn(buf, 1)
+st = s.last_stats()
+names = ["compactions", "rescored", "exact_cut", "second_sorts", "appended"]
+print({n: int(buf[i]) for i, n in enumerate(names)}, st)
+items = st["items"]
+print("per item: compactions %.1f rescored %.0f appended %.0f second sorts %.2f exact cuts %.1f" % (
+    buf[0] / items, buf[1] / items, buf[4] / items, buf[3] / items, buf[2] / items))
