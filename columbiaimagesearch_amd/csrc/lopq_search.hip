@@ -643,6 +643,30 @@ __device__ __forceinline__ void wave_bitonic_sort(uint32_t (&k)[NR]) {
     bitonic_levels<NR, NR * 64>(k);
 }
 
+template <int LJ>
+__device__ __forceinline__ void wave_minmax_step(uint32_t& mn, uint32_t& mx) {
+    const uint32_t a = lane_xor<LJ>(mn), b = lane_xor<LJ>(mx);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+}
+
+// Smallest v with  #{valid keys <= v} >= target  == the target-th smallest key (1-based), found by
+// bisection on the value range with ballots: ~4 VALU compares per probe instead of a ~650-instruction
+// register sort.  lo/hi must bracket the answer (lo = min key, hi = max key is always fine).
+template <int NR>
+__device__ __forceinline__ uint32_t wave_kth_bisect(const uint32_t (&key)[NR], const bool (&valid)[NR], uint32_t lo,
+                                                    uint32_t hi, int target) {
+    while (lo < hi) {  // wave-uniform
+        const uint32_t p = lo + ((hi - lo) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) c += __popcll(__ballot(valid[r] && key[r] <= p));
+        if (c >= target) hi = p;
+        else lo = p + 1;
+    }
+    return lo;
+}
+
 template <int NR>
 __device__ __forceinline__ uint32_t wave_kth(const uint32_t (&k)[NR], int i) {  // i-th smallest after the sort
     uint32_t v = k[0];
@@ -762,8 +786,9 @@ __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt,
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    uint32_t hi[NR], lo[NR], pp[NR], shi[NR];
+    uint32_t hi[NR], lo[NR], pp[NR];
     bool keep[NR];
+    uint32_t mn = 0xffffffffu, mx = 0u;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int e = r * 64 + lane;
@@ -772,13 +797,18 @@ __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt,
         hi[r] = (uint32_t)(k >> 32);
         lo[r] = (uint32_t)k;
         pp[r] = keep[r] ? rp[e] : 0xffffffffu;
-        shi[r] = hi[r];
+        mn = (keep[r] && hi[r] < mn) ? hi[r] : mn;
+        mx = (keep[r] && hi[r] > mx) ? hi[r] : mx;
     }
-    wave_bitonic_sort<NR>(shi);
-    const uint64_t boundW = (cnt >= Lw) ? hi_to_bound(wave_kth<NR>(shi, Lw - 1)) : INF64;
+    wave_minmax_step<1>(mn, mx); wave_minmax_step<2>(mn, mx); wave_minmax_step<4>(mn, mx);
+    wave_minmax_step<8>(mn, mx); wave_minmax_step<16>(mn, mx); wave_minmax_step<32>(mn, mx);
+    mn = (uint32_t)__builtin_amdgcn_readfirstlane((int)mn);
+    mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
+    uint32_t vhiL = mx;
     uint64_t boundL = INF64;
     if (cnt >= L) {  // cut to this wave's own exact top-L
-        const uint32_t vhi = wave_kth<NR>(shi, L - 1);
+        const uint32_t vhi = wave_kth_bisect<NR>(hi, keep, mn, mx, L);
+        vhiL = vhi;
         boundL = hi_to_bound(vhi);
         int c_less = 0, g = 0;
 #pragma unroll
@@ -832,6 +862,7 @@ __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt,
             }
         }
     }
+    const uint64_t boundW = (cnt >= Lw) ? hi_to_bound(wave_kth_bisect<NR>(hi, keep, mn, vhiL, Lw)) : INF64;
     if (lane == 0) {
         if (boundW < lds_ld(&sh->wt[w])) lds_st(&sh->wt[w], boundW);
         if (boundL < lds_ld(&sh->wl[w])) lds_st(&sh->wl[w], boundL);
@@ -1020,7 +1051,9 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
                                             const double* __restrict__ T, const uint8_t* __restrict__ codes,
                                             const int64_t* __restrict__ ids, int K, int L, int S, float margin,
                                             cis_hit* __restrict__ item_hits, int* __restrict__ item_n, char* smem) {
-    constexpr int R = NR * 64;
+    // region capacity: 8 entries short of the NR*64 keys a wave can hold in registers, so that the
+    // G=2 / 4-wave layout (16 KB tables + 8 regions) stays under 40 KB and four workgroups share a CU
+    constexpr int R = NR * 64 - 8;
     char* tab = smem;                                                              // [K][M][G] float32
     uint64_t* rk_all = reinterpret_cast<uint64_t*>(smem + (size_t)K * M * G * 4);  // [G][NW][R] exact keys / stashed codes
     uint32_t* rp_all = reinterpret_cast<uint32_t*>(rk_all + G * NW * R);           // [G][NW][R] positions
@@ -1195,7 +1228,7 @@ __global__ __launch_bounds__(NW * 64) void k_adc_scan2(const WorkItem* __restric
                                                        int* __restrict__ queue_ctr /* [8], zeroed */,
                                                        cis_hit* __restrict__ item_hits, int* __restrict__ item_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int R = NR * 64;
+    constexpr int R = NR * 64 - 8;
     int* s_next = reinterpret_cast<int*>(smem + (size_t)K * M * G * 4 + (size_t)G * NW * R * 12 + G * sizeof(ScanShared));
     const int n_slots = *n_slots_ptr;
     const int q8 = n_slots >> 3, r8 = n_slots & 7;
@@ -1721,8 +1754,8 @@ static void launch_scan_exact(int M, int64_t n_items, hipStream_t st, const Work
     else launch_scan_m<4096, 4>(M, n_items, st, items, T, codes, ids, K, L, S, flag, hits, hitn);
 }
 
-// float32-prefilter kernel (v2): M in {4, 8, 16}, K <= 256, L <= 448
-static bool scan2_supported(int M, int K, int L) { return (M == 4 || M == 8 || M == 16) && K <= 256 && L >= 1 && L <= 448; }
+// float32-prefilter kernel (v2): M in {4, 8, 16}, K <= 256, L <= 440 (a wave region holds L + 64 entries)
+static bool scan2_supported(int M, int K, int L) { return (M == 4 || M == 8 || M == 16) && K <= 256 && L >= 1 && L <= 440; }
 
 struct Scan2Geom { int G, NW, U, S; size_t lds; };
 
@@ -1730,11 +1763,10 @@ struct Scan2Geom { int G, NW, U, S; size_t lds; };
 // large enough to find pairs; G = 1 with 4 waves for small batches (latency mode).
 static Scan2Geom scan2_geom(int M, int K, int L, int nq) {
     Scan2Geom g;
-    const int NR = (L <= 192) ? 4 : 8;
-    g.G = 1;
+    const int NR = (L <= 184) ? 4 : 8;
+    g.G = (nq >= 64) ? 2 : 1;  // pairs of queries per workgroup when the batch is large enough to find pairs
     g.NW = 4;
-    g.U = 2;
-    (void)nq;
+    g.U = (g.G == 2) ? 4 : 2;
     if (const char* e = getenv("CIS_SCAN_GEOM")) {  // experiments: "G,NW,U" out of the instantiated set
         int a = 0, b = 0, c = 0;
         if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && ((a == 1 && b == 4) || (a == 2 && b == 4 && c == 4) || (a == 2 && b == 8 && c == 2)) && (c == 2 || c == 4)) {
@@ -1742,7 +1774,7 @@ static Scan2Geom scan2_geom(int M, int K, int L, int nq) {
         }
     }
     g.S = g.NW * L;
-    g.lds = (size_t)K * M * g.G * 4 + (size_t)g.G * g.NW * NR * 64 * 12 + g.G * sizeof(ScanShared) + 16;
+    g.lds = (size_t)K * M * g.G * 4 + (size_t)g.G * g.NW * (NR * 64 - 8) * 12 + g.G * sizeof(ScanShared) + 16;
     return g;
 }
 
@@ -1780,7 +1812,7 @@ template <int M>
 static void launch_scan2_m(const Scan2Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
                            const int* n_slots, const double* T, const uint8_t* codes, const int64_t* ids, int K, int L,
                            int* qctr, cis_hit* hits, int* hitn) {
-    if (L <= 192) launch_scan2_mr<M, 4>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
+    if (L <= 184) launch_scan2_mr<M, 4>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
     else launch_scan2_mr<M, 8>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
 }
 
