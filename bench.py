@@ -104,12 +104,20 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from columbiaimagesearch_amd import _lib
+    from columbiaimagesearch_amd.distributed import ShardedSearcher, greedy_cell_owner
     from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
-    from columbiaimagesearch_amd.lopq.search import merge_hits_dev
     _lib.check(_lib.lib().cis_set_device(local_rank))
-    if world > 1:
+    # CIS_BENCH_FORCE_DIST=1 runs the sharded code path (process group, all-gather, merge) even with one
+    # rank -- a smoke test of the N > 1 path on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("CIS_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+        if "RANK" not in os.environ:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
 
     model, z = load_model()
     N = args.n - args.n % (N_CHUNKS * world)
@@ -140,17 +148,13 @@ def main():
     V = model.V
     cell = coarse_h[:, 0].astype(np.int64) * V + coarse_h[:, 1]
     counts = np.bincount(cell, minlength=V * V)
-    shard = None
-    if world > 1:
-        # greedy balance of cell populations over ranks (identical on every rank)
-        owner = np.zeros(V * V, dtype=np.int32)
-        load = np.zeros(world, dtype=np.int64)
-        for cid in np.argsort(-counts, kind="stable"):
-            r = int(np.argmin(load))
-            owner[cid] = r
-            load[r] += counts[cid]
-        shard = (rank, world, owner)
-    searcher = LOPQSearcherHIP(model, shard=shard)
+    if use_dist:
+        # cells -> ranks by greedy balance of the cell populations (identical table on every rank)
+        sharded = ShardedSearcher(model, owner=greedy_cell_owner(counts, world))
+        searcher = sharded.local
+    else:
+        sharded = None
+        searcher = LOPQSearcherHIP(model)
     searcher.add_codes_array(coarse_h, fine_h, ids=np.arange(N, dtype=np.int64), dedup=False)
     build_s = time.time() - t_build
 
@@ -160,14 +164,9 @@ def main():
     qbatches = [make_queries(x0, b, NQ, device) for b in range(min(n_batches, 8))]
 
     def step(q):
-        if world == 1:
+        if sharded is None:
             return searcher.search_batch_dev(q, quota=QUOTA, limit=LIMIT)
-        hits, visited = searcher.search_partial_dev(q, quota=QUOTA, limit=LIMIT)
-        parts = torch.empty((world,) + tuple(hits.shape), dtype=torch.uint8, device=device)
-        dist.all_gather_into_tensor(parts, hits)
-        out = merge_hits_dev(parts)
-        out["visited"] = visited
-        return out
+        return sharded.search_batch_dev(q, quota=QUOTA, limit=LIMIT)  # partial scan -> RCCL all-gather -> merge
 
     for b in range(args.warmup):
         step(qbatches[b % len(qbatches)])
@@ -202,7 +201,7 @@ def main():
     # ---- recall@10 (lopq/lopq/eval.py:92-143 semantics), untimed, rank 0 -----------------------
     recall10 = None
     qr = qbatches[0][:1024].contiguous()
-    res = step(qr) if world > 1 else searcher.search_batch_dev(qr, quota=QUOTA, limit=LIMIT)
+    res = step(qr)
     if rank == 0:
         nn = exact_nn(qr, centers, N, chunk_n, device)
         recall10 = float((res["ids"][:, :10] == nn[:, None]).any(dim=1).float().mean().item())
@@ -276,7 +275,7 @@ def main():
             "build": {"encode_s": encode_s, "total_s": build_s, "encode_vectors_per_s": len(my_chunks) * chunk_n / encode_s},
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

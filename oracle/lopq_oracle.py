@@ -467,6 +467,55 @@ class OracleCSRIndex(object):
         return (np.array([it[0] for _, it in scored], dtype=np.int64), np.array([d for d, _ in scored]), visited)
 
 
+HIT_DTYPE = np.dtype([("dist", "<f8"), ("visit_rank", "<u4"), ("pos", "<u4"), ("id", "<i8"),
+                      ("cell", "<i4"), ("reserved", "<i4")])  # == cis_hit (include/cis_hip.h)
+
+
+def search_partial(index, x, quota, limit, owner, rank):
+    """What ONE shard of a cell-sharded index contributes to a query: the traversal and the quota
+    cut use the cell sizes of the whole index (lopq/lopq/search.py:128-133), only cells with
+    owner[cell] == rank are scanned.  Returns (hits [limit] HIT_DTYPE padded with id = -1, visited)."""
+    m = index.model
+    if m.has_pca:
+        x = apply_pca(m, x)
+    V = m.V
+    out = np.zeros(limit, dtype=HIT_DTYPE)
+    out["id"] = -1
+    out["dist"] = np.inf
+    out["cell"] = -1
+    rows, n, visited = [], 0, 0
+    memo = [{}, {}]
+    for _, (c0, c1) in multisequence(m, x):
+        cid = int(c0) * V + int(c1)
+        a, b = index.offsets[cid], index.offsets[cid + 1]
+        if b > a and owner[cid] == rank:
+            for s, c in ((0, int(c0)), (1, int(c1))):
+                if c not in memo[s]:
+                    memo[s][c] = subquantizer_distances(m, x, (int(c0), int(c1)), coarse_split=s)
+            tabs = memo[0][int(c0)] + memo[1][int(c1)]
+            f = index.fine[a:b]
+            d = np.zeros(b - a)
+            for i in range(len(tabs)):
+                d = d + tabs[i][f[:, i]]
+            for p in range(b - a):
+                rows.append((d[p], visited, p, index.ids[a + p], cid, 0))
+        visited += 1
+        n += b - a
+        if n >= quota:
+            break
+    rows.sort(key=lambda r: (r[0], r[1], r[2]))
+    for i, r in enumerate(rows[:limit]):
+        out[i] = r
+    return out, visited
+
+
+def merge_partials(parts, limit):
+    """Reference merge of per-shard hit lists [world][limit] by (dist, visit_rank, pos)."""
+    allh = np.concatenate([p[p["id"] >= 0] for p in parts])
+    order = np.lexsort((allh["pos"], allh["visit_rank"], allh["dist"]))
+    return allh[order][:limit]
+
+
 def recall_at(true_nn, result_ids, ks=(1, 10, 100)):
     """Fraction of queries whose true nearest neighbour is in the top-k returned ids.
     Semantics of get_recall, lopq/lopq/eval.py:92-143."""

@@ -1,0 +1,85 @@
+"""N > 1 path on CPU: two gloo processes run the cell-sharding protocol of
+columbiaimagesearch_amd/distributed.py with the oracle standing in for the GPU scan.
+
+Checks (a) the product's all_gather_hits plumbing on CPU tensors, (b) that shards built from the
+replicated cell-size table agree on `visited`, and (c) that merging the per-shard lists by
+(dist, visit_rank, pos) reproduces the single-index ranking exactly."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, quota, limit, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from columbiaimagesearch_amd.distributed import all_gather_hits, greedy_cell_owner
+        from oracle import lopq_oracle as O
+        z, X, Q = load_golden(name)
+        m = O.OracleModel.from_npz(z)
+        ix = O.OracleCSRIndex(m, z["coarse"], z["fine"])
+        V = m.V
+        counts = np.diff(ix.offsets)
+        owner = greedy_cell_owner(counts, world)
+        nq = 12
+        hits = np.zeros((nq, limit), dtype=O.HIT_DTYPE)
+        vis = np.zeros(nq, dtype=np.int64)
+        for qi in range(nq):
+            hits[qi], vis[qi] = O.search_partial(ix, Q[qi], quota, limit, owner, rank)
+        t = torch.from_numpy(hits.view(np.uint8).reshape(nq, limit, 32).copy())
+        parts = all_gather_hits(t).numpy().reshape(world, nq, limit * 32).view(O.HIT_DTYPE).reshape(world, nq, limit)
+        ok = True
+        for qi in range(nq):
+            merged = O.merge_partials([parts[w, qi] for w in range(world)], limit)
+            ids, dists, visited = ix.search(Q[qi], quota=quota, limit=limit)
+            ok = ok and visited == vis[qi] and np.array_equal(merged["id"], ids) and np.array_equal(merged["dist"], dists)
+        allv = [torch.zeros(nq, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allv, torch.from_numpy(vis))
+        ok = ok and all(torch.equal(allv[0], v) for v in allv)
+        owned = int((owner == rank).sum())
+        ret[rank] = (ok, owned)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("quota,limit", [(50, 20), (3000, 100)])
+def test_cell_sharded_search_two_gloo_ranks(quota, limit):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, "c2", quota, limit, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert all(ret[r][0] for r in range(world))
+    assert ret[0][1] + ret[1][1] == 256 and min(ret[0][1], ret[1][1]) > 0
+
+
+def test_greedy_owner_is_balanced_and_deterministic():
+    from columbiaimagesearch_amd.distributed import greedy_cell_owner
+    rs = np.random.RandomState(0)
+    counts = rs.randint(0, 100000, size=256)
+    for world in (2, 4, 8):
+        o1, o2 = greedy_cell_owner(counts, world), greedy_cell_owner(counts.copy(), world)
+        assert np.array_equal(o1, o2)
+        load = np.bincount(o1, weights=counts, minlength=world)
+        assert load.max() <= 1.05 * load.mean()
