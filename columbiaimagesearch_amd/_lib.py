@@ -64,6 +64,11 @@ _PROTOS = {
     "cis_merge_hits_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
     "cis_index_last_stats": (c_int, [c_void_p, c_void_p]),
+    "cis_cnn_create": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_int]),
+    "cis_cnn_destroy": (None, [c_void_p]),
+    "cis_cnn_feat_dim": (c_int, [c_int]),
+    "cis_cnn_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "cis_cnn_forward_dev": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "cis_index_set_profiling": (c_int, [c_void_p, c_int]),
     "cis_index_set_scan_mode": (c_int, [c_void_p, c_int]),
     "cis_index_read_profile": (c_int, [c_void_p, c_void_p, POINTER(c_int64)]),

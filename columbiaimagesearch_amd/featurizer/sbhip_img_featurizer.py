@@ -1,0 +1,115 @@
+"""DeepSentibank featurizer on the MI355X.
+
+Mirror of SentiBankPyCaffeImgFeaturizer (cufacesearch/cufacesearch/featurizer/sbpycaffe_img_featurizer.py:22-154):
+same constructor ``(global_conf_in, prefix)``, same configuration keys (``<prefix>sbcaffe_path`` = weights,
+``<prefix>imgmean_path`` = imagenet_mean.npy), same ``featurize(img, bbox=None, img_type="buffer")`` -> 4096
+float32 (un-normalised: the caller normalises, generic_extractor.py:238-248).  Preprocessing stays on the host
+(decode, 256x256 lanczos resize through uint8, centre crop 227, RGB->BGR, mean subtraction: :113-134); the
+forward pass runs in libcis_hip.so.  ``featurize_batch`` is the addition that feeds the GPU whole batches.
+
+Weights: the reference downloads a ``.caffemodel`` (:5); here ``sbcaffe_path`` may be a ``.npz`` with the 14
+arrays ``conv1_w, conv1_b, ..., fc7_w, fc7_b`` in caffe layout (tools/caffemodel_to_npz.py converts).
+"""
+import io
+
+import numpy as np
+
+from .. import _lib
+from .generic_featurizer import GenericFeaturizer
+
+TENSOR_NAMES = ["conv1", "conv2", "conv3", "conv4", "conv5", "fc6", "fc7"]
+INPUT_HW = 227
+FEAT_DIM = 4096
+
+
+class SentiBankNet(object):
+    """The network alone: float32 NCHW batch in, fc7 (post-ReLU) out.  Owns a cis_cnn handle."""
+
+    def __init__(self, weights):
+        arrs = []
+        for n in TENSOR_NAMES:
+            arrs.append(np.ascontiguousarray(weights[n + "_w"], dtype=np.float32))
+            arrs.append(np.ascontiguousarray(weights[n + "_b"], dtype=np.float32))
+        ptrs = (_lib.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        out = _lib.c_void_p()
+        _lib.check(_lib.lib().cis_cnn_create(_lib.ctypes.byref(out), 1, ptrs, len(arrs)))
+        self._h = out.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().cis_cnn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, x):
+        """x: [n,3,227,227] float32 (host) -> [n,4096] float32"""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 4 or x.shape[1:] != (3, INPUT_HW, INPUT_HW):
+            raise ValueError("expected [n,3,227,227] float32, got %r" % (x.shape,))
+        out = np.empty((x.shape[0], FEAT_DIM), dtype=np.float32)
+        _lib.check(_lib.lib().cis_cnn_forward(self._h, _lib.ptr(x), x.shape[0], _lib.ptr(out)))
+        return out
+
+    def forward_dev(self, x, out=None):
+        """x: contiguous float32 CUDA tensor [n,3,227,227] -> CUDA tensor [n,4096]; asynchronous"""
+        import torch
+        if not (x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and tuple(x.shape[1:]) == (3, INPUT_HW, INPUT_HW)):
+            raise ValueError("x must be a contiguous float32 [n,3,227,227] tensor on the GPU")
+        if out is None:
+            out = torch.empty((x.shape[0], FEAT_DIM), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().cis_cnn_forward_dev(self._h, x.data_ptr(), x.shape[0], out.data_ptr(),
+                                                  torch.cuda.current_stream(x.device).cuda_stream))
+        return out
+
+
+class SentiBankHIPImgFeaturizer(GenericFeaturizer):
+    def __init__(self, global_conf_in, prefix="SBPYCAFFEIMGFEAT_"):
+        super(SentiBankHIPImgFeaturizer, self).__init__(global_conf_in, prefix)
+        self.set_pp(pp="SentiBankHIPImgFeaturizer")
+        self.output_blobs = ["fc7"]
+        self.target_size = (256, 256, 3)
+        self.crop_size = (INPUT_HW, INPUT_HW)
+        self.resize_type = "lanczos"  # reference :47
+        self.sbcaffe_path = str(self.get_required_param("sbcaffe_path"))
+        self.imgnetmean_path = str(self.get_required_param("imgmean_path"))
+        # mean image handling as reference :66-80: (3,256,256) BGR mean, centre-cropped to 227
+        imgmean = np.load(self.imgnetmean_path)
+        off = (imgmean.shape[1] - INPUT_HW) // 2
+        self.w_boff = self.h_boff = off
+        self.w_eoff = self.h_eoff = off + INPUT_HW
+        self.mu = np.ascontiguousarray(imgmean[:, off:off + INPUT_HW, off:off + INPUT_HW], dtype=np.float32)
+        self.net = SentiBankNet(self._load_weights(self.sbcaffe_path))
+
+    @staticmethod
+    def _load_weights(path):
+        if path.endswith(".npz"):
+            z = np.load(path)
+            return {k: z[k] for k in z.files}
+        raise NotImplementedError("convert the .caffemodel with tools/caffemodel_to_npz.py and point sbcaffe_path at the .npz")
+
+    def preprocess_img(self, img_buffer):
+        """host-side restatement of reference :113-134 with PIL (caffe.io.load_image -> RGB float [0,1];
+        scipy.misc.imresize goes through uint8 and PIL's LANCZOS; crop; HWC->CHW; RGB->BGR; subtract mean)"""
+        from PIL import Image
+        if isinstance(img_buffer, (bytes, bytearray)):
+            img_buffer = io.BytesIO(img_buffer)
+        im = Image.open(img_buffer)
+        if getattr(im, "n_frames", 1) > 1:
+            im.seek(1)  # reference takes image[1] of a GIF (:123-125)
+        im = im.convert("RGB").resize((self.target_size[1], self.target_size[0]), Image.LANCZOS)
+        a = np.asarray(im, dtype=np.uint8)[self.w_boff:self.w_eoff, self.h_boff:self.h_eoff, :]
+        chw = a.transpose(2, 0, 1)[::-1].astype(np.float32)  # channel swap (2,1,0): RGB -> BGR
+        return chw - self.mu
+
+    def featurize(self, img, bbox=None, img_type="buffer"):
+        """reference :137-154 -> np.ndarray (4096,) float32; `bbox` is ignored there too"""
+        return self.net.forward(self.preprocess_img(img)[None])[0]
+
+    def featurize_batch(self, imgs):
+        """list of image buffers -> [n,4096] float32 in one GPU batch"""
+        return self.net.forward(np.stack([self.preprocess_img(i) for i in imgs]))

@@ -175,6 +175,20 @@ int cis_index_set_profiling(cis_index* ix, int enable);
 int cis_index_set_scan_mode(cis_index* ix, int mode);
 int cis_index_read_profile(cis_index* ix, double ms[4], int64_t* launches);
 
+/* ---- CNN descriptors: replaces the caffe forward behind SentiBankPyCaffeImgFeaturizer.featurize -----
+ * (cufacesearch/cufacesearch/featurizer/sbpycaffe_img_featurizer.py:137-154; network
+ * cufacesearch/cufacesearch/featurizer/data/pycaffe_sentibank.prototxt:1-212).
+ * arch CIS_CNN_SENTIBANK: tensors = {conv1_w, conv1_b, ..., conv5_w, conv5_b, fc6_w, fc6_b, fc7_w, fc7_b}
+ * (14 float32 arrays in caffe layout: conv OIHW with I = in_channels / group, fc [out][in] over the
+ * CHW-flattened blob).  forward: nchw [n][3][227][227] float32 exactly as preprocess_img (:113-134)
+ * produces it (BGR, mean subtracted) -> feats [n][4096] float32 = blobs['fc7'] after the in-place ReLU. */
+#define CIS_CNN_SENTIBANK 1
+int cis_cnn_create(cis_cnn** out, int arch, const float* const* tensors, int n_tensors);
+void cis_cnn_destroy(cis_cnn* c);
+int cis_cnn_feat_dim(int arch);
+int cis_cnn_forward(cis_cnn* c, const float* nchw, int n, float* feats);
+int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float* d_feats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,142 @@
+"""CPU restatement of the DeepSentibank forward pass.  TEST INFRASTRUCTURE ONLY.
+
+The reference computes this in third-party BVLC caffe (CPU mode, batch 1):
+``SentiBankPyCaffeImgFeaturizer.featurize`` cufacesearch/cufacesearch/featurizer/sbpycaffe_img_featurizer.py:137-154
+with the network ``cufacesearch/cufacesearch/featurizer/data/pycaffe_sentibank.prototxt:1-212`` and reads out
+``blobs['fc7']`` AFTER the in-place ReLU (:154; fc8/softmax are computed by caffe but unused).
+
+**Parity unpinned**: caffe is not importable here and the trained weights are not in the tree; the reference's
+own checks compare against a live HBase column (tests/test_compare_sbcmdline*.py).  What pins this oracle is
+(a) the prototxt, layer by layer, and (b) agreement between two independent restatements below -- torch
+(``forward_torch``) and plain numpy (``forward_numpy``) -- on seeded synthetic weights.
+
+caffe layer semantics restated: CONVOLUTION with ``group`` (prototxt :7-16,:47-58,...), RELU, max POOLING 3/2 with
+caffe's ceil-mode output size and windows clipped to the input, LRN ACROSS_CHANNELS
+``b = a / (1 + alpha/n * sum_{window n} a^2)^beta`` (n=5, alpha=1e-4, beta=0.75), INNER_PRODUCT on the CHW-flattened
+blob, DROPOUT = identity at TEST.
+"""
+import numpy as np
+
+# (name, out_channels, kernel, stride, pad, groups)   -- prototxt :7-16, :47-58, :88-98, :105-116, :123-134
+CONVS = [("conv1", 96, 11, 4, 0, 1), ("conv2", 256, 5, 1, 2, 2), ("conv3", 384, 3, 1, 1, 1),
+         ("conv4", 384, 3, 1, 1, 2), ("conv5", 256, 3, 1, 1, 2)]
+FCS = [("fc6", 4096), ("fc7", 4096)]  # prototxt :153-160, :176-183
+POOL_AFTER = {"conv1", "conv2", "conv5"}
+LRN_AFTER = {"conv1", "conv2"}
+LRN_SIZE, LRN_ALPHA, LRN_BETA = 5, 1e-4, 0.75
+INPUT_HW = 227
+FEAT_DIM = 4096
+MAC_PER_IMAGE = 720288768  # multiply-accumulates to fc7
+
+
+def layer_shapes():
+    """[(name, weight shape (caffe OIHW / [out,in]), bias shape)] in forward order."""
+    out = []
+    c, hw = 3, INPUT_HW
+    for name, oc, k, s, p, g in CONVS:
+        out.append((name, (oc, c // g, k, k), (oc,)))
+        hw = (hw + 2 * p - k) // s + 1
+        c = oc
+        if name in POOL_AFTER:
+            hw = int(np.ceil((hw - 3) / 2.0)) + 1
+    fin = c * hw * hw
+    for name, oc in FCS:
+        out.append((name, (oc, fin), (oc,)))
+        fin = oc
+    return out
+
+
+def synthetic_weights(seed=0):
+    """Seeded He-scaled weights in caffe layout (float32): {name_w, name_b}."""
+    rs = np.random.RandomState(seed)
+    w = {}
+    for name, ws, bs in layer_shapes():
+        fan_in = int(np.prod(ws[1:]))
+        w[name + "_w"] = (rs.randn(*ws) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+        w[name + "_b"] = (rs.randn(*bs) * 0.05).astype(np.float32)
+    return w
+
+
+def synthetic_images(n, seed=1):
+    """Mean-subtracted-pixel-like inputs, NCHW float32 (what preprocess_img hands to the net, :113-134)."""
+    return (np.random.RandomState(seed).randn(n, 3, INPUT_HW, INPUT_HW) * 50.0).astype(np.float32)
+
+
+def forward_torch(x, w, upto="fc7"):
+    """float32 forward with torch CPU ops; returns the blob named `upto` (post-ReLU for conv/fc)."""
+    import torch
+    import torch.nn.functional as F
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    with torch.no_grad():
+        for name, oc, k, s, p, g in CONVS:
+            t = F.relu(F.conv2d(t, torch.from_numpy(w[name + "_w"]), torch.from_numpy(w[name + "_b"]), stride=s,
+                                padding=p, groups=g))
+            if name == upto:
+                return t.numpy()
+            if name in POOL_AFTER:
+                t = F.max_pool2d(t, 3, 2, ceil_mode=True)
+                if "pool" + name[-1] == upto:
+                    return t.numpy()
+            if name in LRN_AFTER:
+                t = F.local_response_norm(t, LRN_SIZE, alpha=LRN_ALPHA, beta=LRN_BETA, k=1.0)
+                if "norm" + name[-1] == upto:
+                    return t.numpy()
+        t = t.reshape(t.shape[0], -1)  # CHW flatten, as caffe's InnerProduct sees the blob
+        for name, oc in FCS:
+            t = F.relu(F.linear(t, torch.from_numpy(w[name + "_w"]), torch.from_numpy(w[name + "_b"])))
+            if name == upto:
+                return t.numpy()
+    return t.numpy()
+
+
+def _conv_numpy(x, W, b, s, p, g):
+    n, c, h, wd = x.shape
+    oc, icg, k, _ = W.shape
+    oh, ow = (h + 2 * p - k) // s + 1, (wd + 2 * p - k) // s + 1
+    xp = np.zeros((n, c, h + 2 * p, wd + 2 * p), dtype=np.float64)
+    xp[:, :, p:p + h, p:p + wd] = x
+    out = np.zeros((n, oc, oh, ow), dtype=np.float64)
+    ocg = oc // g
+    for gi in range(g):
+        xs = xp[:, gi * icg:(gi + 1) * icg]
+        Wg = W[gi * ocg:(gi + 1) * ocg].astype(np.float64)
+        for ky in range(k):
+            for kx in range(k):
+                patch = xs[:, :, ky:ky + s * (oh - 1) + 1:s, kx:kx + s * (ow - 1) + 1:s]
+                out[:, gi * ocg:(gi + 1) * ocg] += np.einsum("nchw,oc->nohw", patch, Wg[:, :, ky, kx])
+    return out + b[None, :, None, None]
+
+
+def _pool_numpy(x):
+    n, c, h, w = x.shape
+    oh, ow = int(np.ceil((h - 3) / 2.0)) + 1, int(np.ceil((w - 3) / 2.0)) + 1
+    out = np.full((n, c, oh, ow), -np.inf)
+    for y in range(oh):
+        for xx in range(ow):
+            out[:, :, y, xx] = x[:, :, 2 * y:min(2 * y + 3, h), 2 * xx:min(2 * xx + 3, w)].max(axis=(2, 3))
+    return out
+
+
+def _lrn_numpy(x):
+    n, c, h, w = x.shape
+    sq = x * x
+    acc = np.zeros_like(x)
+    half = LRN_SIZE // 2
+    for ch in range(c):
+        acc[:, ch] = sq[:, max(0, ch - half):min(c, ch + half + 1)].sum(axis=1)
+    return x / np.power(1.0 + (LRN_ALPHA / LRN_SIZE) * acc, LRN_BETA)
+
+
+def forward_numpy(x, w):
+    """Independent float64 numpy restatement (small batches only)."""
+    t = x.astype(np.float64)
+    for name, oc, k, s, p, g in CONVS:
+        t = np.maximum(_conv_numpy(t, w[name + "_w"], w[name + "_b"].astype(np.float64), s, p, g), 0.0)
+        if name in POOL_AFTER:
+            t = _pool_numpy(t)
+        if name in LRN_AFTER:
+            t = _lrn_numpy(t)
+    t = t.reshape(t.shape[0], -1)
+    for name, oc in FCS:
+        t = np.maximum(t.dot(w[name + "_w"].astype(np.float64).T) + w[name + "_b"], 0.0)
+    return t

@@ -1,0 +1,68 @@
+"""GPU parity of the DeepSentibank forward against the CPU restatement (oracle/cnn_oracle.py), seeded synthetic
+weights.  float32 everywhere; the MFMA accumulates k-ascending in float32 like caffe's sgemm would, only the
+order differs => tolerance 2e-4 relative to the feature scale (parity with caffe itself is unpinned)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def net_and_weights():
+    from oracle import cnn_oracle as C
+    from columbiaimagesearch_amd.featurizer import SentiBankNet
+    w = C.synthetic_weights(0)
+    return SentiBankNet(w), w
+
+
+def test_forward_matches_torch_cpu(net_and_weights):
+    from oracle import cnn_oracle as C
+    net, w = net_and_weights
+    x = C.synthetic_images(5, seed=3)  # 5: exercises partial pixel tiles
+    got = net.forward(x)
+    ref = C.forward_torch(x, w)
+    assert got.shape == (5, 4096) and got.dtype == np.float32
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * scale)
+    assert ((got > 0) == (ref > 0)).mean() > 0.999  # post-ReLU read-out (reference :154)
+
+
+def test_batch_equals_single_and_device_entry(net_and_weights):
+    import torch
+    from oracle import cnn_oracle as C
+    net, w = net_and_weights
+    x = C.synthetic_images(3, seed=4)
+    a = net.forward(x)
+    b = np.stack([net.forward(x[i:i + 1])[0] for i in range(3)])
+    np.testing.assert_array_equal(a, b)  # batching must not change a single bit
+    d = net.forward_dev(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d.cpu().numpy(), a)
+
+
+def test_featurizer_surface(tmp_path, net_and_weights):
+    """get_featurizer('sbpycaffe', conf, prefix) -> featurize(buffer) -> (4096,) float32, b64 round trip."""
+    import io
+    from PIL import Image
+    from oracle import cnn_oracle as C
+    from columbiaimagesearch_amd.featurizer import featB64decode, get_feat_size, get_featurizer, normfeatB64encode
+    _, w = net_and_weights
+    np.savez(tmp_path / "w.npz", **w)
+    mean = np.zeros((3, 256, 256)) + np.array([104.0, 116.7, 122.7])[:, None, None]
+    np.save(tmp_path / "mean.npy", mean)
+    conf = {"SBF_sbcaffe_path": str(tmp_path / "w.npz"), "SBF_imgmean_path": str(tmp_path / "mean.npy")}
+    f = get_featurizer("sbpycaffe", conf, prefix="SBF_")
+    rs = np.random.RandomState(0)
+    bufs = []
+    for i in range(2):
+        b = io.BytesIO()
+        Image.fromarray(rs.randint(0, 255, (300 + 40 * i, 280, 3), dtype=np.uint8)).save(b, format="PNG")
+        bufs.append(b.getvalue())
+    feat = f.featurize(bufs[0])
+    assert feat.shape == (get_feat_size("sbpycaffe"),) and feat.dtype == np.float32
+    ref = C.forward_torch(f.preprocess_img(bufs[0])[None], w)[0]
+    np.testing.assert_allclose(feat, ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+    both = f.featurize_batch(bufs)
+    np.testing.assert_array_equal(both[0], feat)
+    back = featB64decode(normfeatB64encode(feat), "sbpycaffe")
+    np.testing.assert_allclose(np.linalg.norm(back), 1.0, rtol=1e-5)
