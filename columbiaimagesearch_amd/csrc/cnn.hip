@@ -26,36 +26,48 @@ struct ConvDesc {
 };
 
 // C[pixel][oc] = sum_k A[pixel][k] * Wp[k][oc] + bias[oc]; block tile BM x BN, 256 threads = 4 waves laid
-// out WAVES_M x WAVES_N, each wave WM x WN MFMA tiles of 32x32.
-template <int WM, int WN, int WAVES_M, int WAVES_N>
+// out WAVES_M x WAVES_N, each wave WM x WN MFMA tiles of 32x32.  K advances 16 at a time through two LDS
+// stages: the next stage's operands are fetched into registers before the MFMAs of the current stage and
+// written to the other LDS buffer after them (one barrier per stage).
+// VEC = channels-last input with ICg % 16 == 0: a stage covers 16 consecutive input channels of ONE kernel tap,
+// so every thread fetches float4s along the channel axis and the tap decode is wave-uniform.
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool VEC>
 __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in, const float* __restrict__ Wp,
                                                     const float* __restrict__ bias, float* __restrict__ out, ConvDesc d) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, BK = 16;
     constexpr int LDA = BM + 4, LDB = BN + 4;
-    __shared__ float As[BK][LDA];  // [k][pixel]
-    __shared__ float Bs[BK][LDB];  // [k][oc]
-    __shared__ int s_iy0[BM], s_ix0[BM];
-    __shared__ int64_t s_base[BM];
+    constexpr int A_VEC = (BM * 4 + 255) / 256;        // float4 fetches per thread per stage (VEC)
+    constexpr int A_SCL = (BM * BK + 255) / 256;       // scalar fetches per thread per stage (!VEC)
+    constexpr int B_VEC = (BK * (BN / 4) + 255) / 256; // float4 fetches of packed weights
+    __shared__ float As[2][BK][LDA];  // [stage][k][pixel]
+    __shared__ float Bs[2][BK][LDB];  // [stage][k][oc]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int g = blockIdx.z;
     const int64_t npix = (int64_t)d.N * d.OH * d.OW;
     const int64_t pix0 = (int64_t)blockIdx.x * BM;
     const int oc0 = blockIdx.y * BN;  // inside the group
-    for (int m = tid; m < BM; m += 256) {
+    // ---- the pixels this thread gathers are the same for every stage: decode them once ----
+    constexpr int NPX = VEC ? A_VEC : A_SCL;
+    int iy0[NPX], ix0[NPX], mloc[NPX];
+    int64_t pbase[NPX];
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+        const int m = VEC ? ((tid >> 2) + 64 * i) : ((tid >> 4) + 16 * i);
+        mloc[i] = m;
         const int64_t p = pix0 + m;
-        if (p < npix) {
+        if (m < BM && p < npix) {
             const int ox = (int)(p % d.OW);
             const int oy = (int)((p / d.OW) % d.OH);
             const int64_t img = p / ((int64_t)d.OW * d.OH);
-            s_iy0[m] = oy * d.stride - d.pad;
-            s_ix0[m] = ox * d.stride - d.pad;
-            s_base[m] = img * d.sN + (int64_t)g * d.ICg * d.sC;
+            iy0[i] = oy * d.stride - d.pad;
+            ix0[i] = ox * d.stride - d.pad;
+            pbase[i] = img * d.sN + (int64_t)g * d.ICg * d.sC;
         } else {
-            s_iy0[m] = -(1 << 28);  // every tap falls outside -> zeros
-            s_ix0[m] = -(1 << 28);
-            s_base[m] = 0;
+            iy0[i] = -(1 << 28);  // every tap falls outside -> zeros
+            ix0[i] = -(1 << 28);
+            pbase[i] = 0;
         }
     }
     f32x16 acc[WM][WN];
@@ -66,50 +78,90 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const float* Wg = Wp + (int64_t)g * d.K * d.OCg;
-    __syncthreads();
-    for (int k0 = 0; k0 < d.K; k0 += BK) {
-        // ---- A tile: im2col gather, lanes along k (contiguous input channels in NHWC) ----
-        {
-            const int kl = tid & 15;
-            const int k = k0 + kl;
-            int ky = 0, kx = 0, ic = 0;
-            const bool kvalid = k < d.K;
-            if (kvalid) {
-                ic = k % d.ICg;
-                const int t = k / d.ICg;
-                kx = t % d.KW;
-                ky = t / d.KW;
-            }
+    const int nkt = (d.K + BK - 1) / BK;
+    // tap decode state: VEC -> of the stage (uniform); !VEC -> of this thread's k = k0 + (tid & 15)
+    int ky = 0, kx = 0, ic = VEC ? 0 : (tid & 15);
+    if (!VEC) {
+        while (ic >= d.ICg) { ic -= d.ICg; if (++kx == d.KW) { kx = 0; ++ky; } }
+    }
+    float4 ra[VEC ? A_VEC : 1];
+    float rs[VEC ? 1 : A_SCL];
+    float4 rb[B_VEC];
+    auto fetch = [&](int kt) {
+        const int k0 = kt * BK;
+        if constexpr (VEC) {
 #pragma unroll
-            for (int i = 0; i < BM / 16; ++i) {
-                const int m = (tid >> 4) + 16 * i;
-                const int iy = s_iy0[m] + ky, ix = s_ix0[m] + kx;
-                float v = 0.f;
-                if (kvalid && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W)
-                    v = in[s_base[m] + (int64_t)ic * d.sC + (int64_t)iy * d.sH + (int64_t)ix * d.sW];
-                As[kl][m] = v;
+            for (int i = 0; i < A_VEC; ++i) {
+                const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mloc[i] < BM && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W)
+                    ra[i] = *reinterpret_cast<const float4*>(in + pbase[i] + (int64_t)iy * d.sH + (int64_t)ix * d.sW + ic + (tid & 3) * 4);
+            }
+        } else {
+            const bool kvalid = (k0 + (tid & 15)) < d.K;
+#pragma unroll
+            for (int i = 0; i < A_SCL; ++i) {
+                const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+                rs[i] = 0.f;
+                if (kvalid && mloc[i] < BM && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W)
+                    rs[i] = in[pbase[i] + (int64_t)ic * d.sC + (int64_t)iy * d.sH + (int64_t)ix * d.sW];
             }
         }
-        // ---- B tile: packed weights [k][oc], float4 along oc ----
-        for (int idx = tid; idx < BK * (BN / 4); idx += 256) {
+#pragma unroll
+        for (int i = 0; i < B_VEC; ++i) {
+            const int idx = tid + 256 * i;
             const int kl = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k0 + kl < d.K && oc0 + n4 < d.OCg) v = *reinterpret_cast<const float4*>(Wg + (int64_t)(k0 + kl) * d.OCg + oc0 + n4);
-            Bs[kl][n4 + 0] = v.x; Bs[kl][n4 + 1] = v.y; Bs[kl][n4 + 2] = v.z; Bs[kl][n4 + 3] = v.w;
+            rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < BK * (BN / 4) && k0 + kl < d.K && oc0 + n4 < d.OCg)
+                rb[i] = *reinterpret_cast<const float4*>(Wg + (int64_t)(k0 + kl) * d.OCg + oc0 + n4);
         }
-        __syncthreads();
+        // advance the tap decode to the next stage
+        ic += BK;
+        while (ic >= d.ICg) { ic -= d.ICg; if (++kx == d.KW) { kx = 0; ++ky; } }
+    };
+    auto stash = [&](int st) {
+        if constexpr (VEC) {
+#pragma unroll
+            for (int i = 0; i < A_VEC; ++i) {
+                if (mloc[i] < BM) {
+                    const int kq = (tid & 3) * 4;
+                    As[st][kq + 0][mloc[i]] = ra[i].x; As[st][kq + 1][mloc[i]] = ra[i].y;
+                    As[st][kq + 2][mloc[i]] = ra[i].z; As[st][kq + 3][mloc[i]] = ra[i].w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_SCL; ++i)
+                if (mloc[i] < BM) As[st][tid & 15][mloc[i]] = rs[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_VEC; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < BK * (BN / 4)) {
+                const int kl = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
+                Bs[st][kl][n4 + 0] = rb[i].x; Bs[st][kl][n4 + 1] = rb[i].y; Bs[st][kl][n4 + 2] = rb[i].z; Bs[st][kl][n4 + 3] = rb[i].w;
+            }
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) fetch(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float a[WM], b[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = As[kk + (lane >> 5)][(wm * WM + i) * 32 + (lane & 31)];
+            for (int i = 0; i < WM; ++i) a[i] = As[cur][kk + (lane >> 5)][(wm * WM + i) * 32 + (lane & 31)];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = Bs[kk + (lane >> 5)][(wn * WN + j) * 32 + (lane & 31)];
+            for (int j = 0; j < WN; ++j) b[j] = Bs[cur][kk + (lane >> 5)][(wn * WN + j) * 32 + (lane & 31)];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (kt + 1 < nkt) stash(cur ^ 1);
         __syncthreads();
     }
     // ---- epilogue: C/D layout col = lane&31 (oc), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel) ----
@@ -266,15 +318,21 @@ extern "C" int cis_cnn_create(cis_cnn** out, int arch, const float* const* tenso
     return CIS_OK;
 }
 
+template <int WM, int WN, int WAVES_M, int WAVES_N>
+static void launch_conv_cfg(const ConvDesc& d, const float* in, const float* w, const float* b, float* out, hipStream_t st) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    const int64_t npix = (int64_t)d.N * d.OH * d.OW;
+    dim3 g((unsigned)ceil_div(npix, BM), (unsigned)ceil_div(d.OCg, BN), (unsigned)d.groups);
+    const bool vec = d.sC == 1 && d.ICg % 16 == 0 && d.C % 4 == 0;
+    if (vec) hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, true>), g, dim3(256), 0, st, in, w, b, out, d);
+    else hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, false>), g, dim3(256), 0, st, in, w, b, out, d);
+}
+
 static void launch_conv(const ConvDesc& d, const float* in, const float* w, const float* b, float* out, hipStream_t st) {
     const int64_t npix = (int64_t)d.N * d.OH * d.OW;
-    if (d.OCg % 96 == 0 && d.OCg % 128 != 0) {  // 96, 192: 128 x 96 tiles
-        dim3 g((unsigned)ceil_div(npix, 128), (unsigned)ceil_div(d.OCg, 96), (unsigned)d.groups);
-        hipLaunchKernelGGL((k_conv_igemm<1, 3, 4, 1>), g, dim3(256), 0, st, in, w, b, out, d);
-    } else {
-        dim3 g((unsigned)ceil_div(npix, 128), (unsigned)ceil_div(d.OCg, 128), (unsigned)d.groups);
-        hipLaunchKernelGGL((k_conv_igemm<2, 2, 2, 2>), g, dim3(256), 0, st, in, w, b, out, d);
-    }
+    if (npix <= 2048) launch_conv_cfg<1, 1, 1, 4>(d, in, w, b, out, st);            // fc layers: 32 x 128 tiles fill the chip
+    else if (d.OCg % 96 == 0 && d.OCg % 128 != 0) launch_conv_cfg<1, 3, 4, 1>(d, in, w, b, out, st);  // 96, 192: 128 x 96
+    else launch_conv_cfg<2, 2, 2, 2>(d, in, w, b, out, st);                          // 128 x 128
 }
 
 extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float* d_feats, void* stream) {
