@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=int(os.environ.get("CIS_BENCH_N", 10_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cnn", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -236,6 +237,35 @@ def main():
                          "%.1f queries/s on %d queries" % (n_loop, QUOTA, LIMIT, n_vec / t_vec, n_vec)}
         parity = {"queries_checked": max(n_loop, n_vec), "ids_bit_exact": ok, "max_rel_dist_err": max_rel}
 
+    # ---- second half of the BASELINE metric: CNN descriptors/s (DeepSentibank forward, batch 256) -------
+    cnn = None
+    if rank == 0 and not args.no_cnn:
+        from oracle.cnn_oracle import synthetic_weights  # seeded synthetic weights (the trained ones are not in the tree)
+        from columbiaimagesearch_amd.featurizer import SentiBankNet
+        del x0
+        torch.cuda.empty_cache()
+        net = SentiBankNet(synthetic_weights(0))
+        B = 256
+        gcn = torch.Generator(device=device)
+        gcn.manual_seed(5)
+        xb = (torch.randn((B, 3, 227, 227), generator=gcn, device=device) * 50.0).contiguous()
+        ob = torch.empty((B, 4096), device=device)
+        for _ in range(2):
+            net.forward_dev(xb, ob)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        reps = 8
+        for _ in range(reps):
+            net.forward_dev(xb, ob)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - tc) / reps
+        flop = 2.0 * 720310816 * B
+        cnn = {"metric": "CNN descriptors/sec (DeepSentibank forward to fc7, batch 256, synthetic weights)",
+               "value": B / dt, "unit": "descriptors/s", "ms_per_batch": dt * 1e3, "dtype": "f32",
+               "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                            "frac": flop / dt / 157.3e12, "flop_per_image": 2 * 720310816}}
+        net.close()
+
     if rank == 0:
         M = model.M
         launches = max(prof["scan_launches"], 1)
@@ -265,11 +295,12 @@ def main():
                        "index_vectors": N, "queries_per_step": NQ, "quota": QUOTA, "limit": LIMIT,
                        "sharding": "by coarse cell over %d GPU(s)%s" % (world, ", RCCL all-gather merge" if world > 1 else ""),
                        "candidates_per_query": cand_all / float(NQ * args.steps)},
-            "roofline": {"bound": "hbm", "kernel": "k_adc_scan", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_adc_scan2", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes / launches,
                          "avg_launch_ms": prof["scan_ms"] / launches, "launches": launches},
             "stage_ms_per_step": {k: prof[k] / args.steps for k in ("front_ms", "tables_ms", "scan_ms", "merge_ms")},
+            "cnn": cnn,
             "cpu_baseline": cpu,
             "parity": parity,
             "build": {"encode_s": encode_s, "total_s": build_s, "encode_vectors_per_s": len(my_chunks) * chunk_n / encode_s},
