@@ -13,7 +13,7 @@ CIS_F32, CIS_F64 = 4, 8
 CIS_OK, CIS_EINVAL, CIS_EHIP, CIS_ENOMEM, CIS_EUNSUPPORTED, CIS_ENODEVICE = 0, -1, -2, -3, -4, -5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcis_hip.so")
+LIB_PATH = os.environ.get("CIS_LIB_PATH") or os.path.join(_HERE, "lib", "libcis_hip.so")  # override: kernel A/B experiments
 
 
 class cis_hit(ctypes.Structure):

@@ -935,6 +935,9 @@ __device__ __forceinline__ RotConsts<M> make_rot(int lane) {
         const int th = t >> 2, tq = t & 3;
         const int j = ((h ^ th) << 2) | ((q + tq) & 3);
         rc.cj[t] = (uint32_t)j << 2;
+#ifdef CIS_SCAN_OPAQUE_CJ
+        asm volatile("" : "+v"(rc.cj[t]));  // keep the M offsets in M registers (else the compiler re-derives half of them per use)
+#endif
     }
     return rc;
 }
@@ -954,6 +957,26 @@ __device__ __forceinline__ CodeWords<M> load_code(const uint8_t* __restrict__ co
     } else {
         const uint4 v = *reinterpret_cast<const uint4*>(codes + p * 16);
         c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
+    }
+    return c;
+}
+
+// the same through a buffer descriptor that covers exactly the chunk being scanned: one 32-bit offset per
+// load instead of 64-bit address arithmetic, and positions past the end of the chunk read as zero
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int M>
+__device__ __forceinline__ CodeWords<M> load_code_buf(__amdgpu_buffer_rsrc_t rs, int p) {
+    CodeWords<M> c;
+    if constexpr (M == 4) {
+        c.w[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, p * 4, 0, 0);
+    } else if constexpr (M == 8) {
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, p * 8, 0, 0);
+        c.w[0] = v[0]; c.w[1] = v[1];
+    } else {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, p * 16, 0, 0);
+        c.w[0] = v[0]; c.w[1] = v[1]; c.w[2] = v[2]; c.w[3] = v[3];
     }
     return c;
 }
@@ -1098,13 +1121,24 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
     bool has_dup[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) { cnt[g] = 0; nexact[g] = 0; has_dup[g] = false; dup[g] = CodeWords<M>(); }
+#ifndef CIS_SCAN_PLAIN_LOADS
+    // buffer descriptor over this chunk's codes, built from wave-uniform values only
+    __amdgpu_buffer_rsrc_t rs;
+    {
+        const uint64_t cbase = (uint64_t)(uintptr_t)(codes + start * M);
+        const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cbase);
+        const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cbase >> 32));
+        const int nbytes = __builtin_amdgcn_readfirstlane(len * M);
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)bhi << 32) | blo), 0, nbytes, 0x00020000);
+    }
+#define CIS_LOAD_CODE(p) load_code_buf<M>(rs, (p))
+#else
+#define CIS_LOAD_CODE(p) load_code<M>(codes, start + ((p) < len ? (p) : len - 1))
+#endif
     CodeWords<M> nxt[U];
     if (w < nit) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int p = w * 64 * U + u * 64 + lane;
-            nxt[u] = load_code<M>(codes, start + (p < len ? p : len - 1));
-        }
+        for (int u = 0; u < U; ++u) nxt[u] = CIS_LOAD_CODE(w * 64 * U + u * 64 + lane);
     }
     for (int iter = w; iter < nit; iter += NW) {
         const int base = iter * 64 * U;
@@ -1113,19 +1147,16 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
         if (iter + NW < nit) {  // software prefetch: the next iteration's codes are in flight while this one computes
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int p = (iter + NW) * 64 * U + u * 64 + lane;
-                nxt[u] = load_code<M>(codes, start + (p < len ? p : len - 1));  // tail lanes re-read the last code; masked below
-            }
+            for (int u = 0; u < U; ++u) nxt[u] = CIS_LOAD_CODE((iter + NW) * 64 * U + u * 64 + lane);  // tail lanes are masked below
         }
         float d[U][G];
 #pragma unroll
         for (int u = 0; u < U; ++u) adc32g<M, G>(cur[u], tab, rc, d[u]);
+        // Fast path: all pass masks of this iteration first (pure VALU + ballots), ONE branch if none is set.
+        unsigned long long pm[U][G];
+        unsigned long long any = 0ull;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            if (g >= ng) break;
-            uint64_t* rk = rk_all + (g * NW + w) * R;
-            uint32_t* rp = rp_all + (g * NW + w) * R;
             float thrm = block_bound_f32(&sh[g]) * margin;
 #ifdef CIS_PROBE_HOTLOOP
             thrm = (margin > 100.f) ? thrm : -1.0f;  // probe: nothing passes, only the float32 scan runs
@@ -1133,16 +1164,30 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int p = base + u * 64 + lane;
-                bool pass = (p < len) && (d[u][g] <= thrm);
+                bool pass = (p < len) && (d[u][g] <= thrm) && (g < ng);
                 if (has_dup[g]) {
                     bool same = true;
 #pragma unroll
                     for (int i = 0; i < (M + 3) / 4; ++i) same = same && (cur[u].w[i] == dup[g].w[i]);
                     pass = pass && !same;
                 }
-                unsigned long long m = __ballot(pass);
+                pm[u][g] = __ballot(pass);
+                any |= pm[u][g];
+            }
+        }
+        if (any == 0ull) continue;  // the usual case: nothing in these 64*U candidates beats a bound
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g >= ng) break;
+            uint64_t* rk = rk_all + (g * NW + w) * R;
+            uint32_t* rp = rp_all + (g * NW + w) * R;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                unsigned long long m = pm[u][g];
+                if (m == 0ull) continue;
+                const int p = base + u * 64 + lane;
+                bool pass = (m >> lane) & 1ull;
                 int n = __popcll(m);
-                if (n == 0) continue;
                 if (cnt[g] + n > R) {  // cannot happen right after a compaction: cnt <= L <= R - 64
                     uint32_t dp = 0xffffffffu;
                     cnt[g] = wave_compact<M, NR, NW>(rk, rp, cnt[g], nexact[g], L, Lw, &sh[g], w, codes, start, K, t0[g], t1[g], dp);
@@ -1151,7 +1196,7 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
                         has_dup[g] = true;
                     }
                     nexact[g] = cnt[g];
-                    thrm = block_bound_f32(&sh[g]) * margin;
+                    const float thrm = block_bound_f32(&sh[g]) * margin;
                     pass = pass && (d[u][g] <= thrm);
                     m = __ballot(pass);
                     n = __popcll(m);
