@@ -1814,7 +1814,7 @@ static Scan2Geom scan2_geom(int M, int K, int L, int nq) {
     g.U = (g.G == 2) ? 4 : 2;
     if (const char* e = getenv("CIS_SCAN_GEOM")) {  // experiments: "G,NW,U" out of the instantiated set
         int a = 0, b = 0, c = 0;
-        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && ((a == 1 && b == 4) || (a == 2 && b == 4 && c == 4) || (a == 2 && b == 8 && c == 2)) && (c == 2 || c == 4)) {
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && ((a == 1 && b == 4) || (a == 2 && b == 4) || (a == 2 && b == 8 && c == 2)) && (c == 2 || c == 4)) {
             g.G = a; g.NW = b; g.U = c;
         }
     }
@@ -1849,6 +1849,7 @@ static void launch_scan2_mr(const Scan2Geom& g, int64_t n_items, hipStream_t st,
     CIS_SCAN2_CASE(1, 4, 4)
     CIS_SCAN2_CASE(1, 4, 2)
     CIS_SCAN2_CASE(2, 4, 4)
+    CIS_SCAN2_CASE(2, 4, 2)
     CIS_SCAN2_CASE(2, 8, 2)
 #undef CIS_SCAN2_CASE
 }
@@ -1872,6 +1873,8 @@ static void launch_scan2(int M, const Scan2Geom& g, int64_t n_items, hipStream_t
 static const int MAX_LIMIT = 3072;
 
 // one sub-batch of queries (device pointers); writes ranked partial hits [nq][L] and visited [nq]
+static const int CIS_RETRY_SMALLER = 1;  // internal: the batch does not fit the workspace budget, halve it
+
 struct SearchOut {  // any of these may be null; all are [nq][L] except n_found / visited [nq]
     cis_hit* hits;
     int64_t* ids;
@@ -1951,10 +1954,18 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     CIS_CHECK_HIP(hipMemcpyAsync(h_tot, totals, sizeof(h_tot), hipMemcpyDeviceToHost, st));
     CIS_CHECK_HIP(hipStreamSynchronize(st));
     const int64_t n_items = h_tot[0], n_tabs = h_tot[1];
+    CIS_REQUIRE(n_items < ((int64_t)1 << 31) && n_tabs < ((int64_t)1 << 31), "query batch too large");
+    {
+        // workspace budget: per-item hit lists and the float64 tables.  A batch that would need more (e.g. an
+        // exhaustive quota: every query visits every cell) is split by the caller and planned again.
+        const bool fast_ = scan2_supported(M, K, L) && !ix->force_exact_scan;
+        const int64_t S_ = fast_ ? scan2_geom(M, K, L, nq).S : L;
+        const double need = (double)n_items * S_ * sizeof(cis_hit) + (double)n_tabs * nf * K * sizeof(double);
+        if (need > 4.0e9 && nq > 1) return CIS_RETRY_SMALLER;
+    }
     ix->stats[0] += h_tot[2];
     ix->stats[1] += n_items;
     ix->stats[2] += n_tabs;
-    CIS_REQUIRE(n_items < ((int64_t)1 << 31) && n_tabs < ((int64_t)1 << 31), "query batch too large");
     // 3. emit items + table list
     CIS_TRY(mark(1));  // the plan read-back above is part of the front end
     CIS_TRY(ix->w_items.reserve((size_t)(n_items + 1) * sizeof(WorkItem)));
@@ -2079,18 +2090,26 @@ static int search_all(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_
     CIS_TRY(index_sync(ix));
     CIS_CHECK_HIP(hipSetDevice(ix->m->device));
     for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
-    for (int a = 0; a < nq; a += QUERY_BATCH) {
-        const int bn = (nq - a < QUERY_BATCH) ? (nq - a) : QUERY_BATCH;
+    int batch = QUERY_BATCH;
+    for (int a = 0; a < nq;) {
+        const int bn = (nq - a < batch) ? (nq - a) : batch;
         const char* q = (const char*)dQ + (size_t)a * ix->m->D_in * q_dtype;
+        int rc;
         if (L > 0) {
-            CIS_TRY(search_batch(ix, q, q_dtype, bn, quota, L, out.at(a, L), st));
+            rc = search_batch(ix, q, q_dtype, bn, quota, L, out.at(a, L), st);
         } else {  // limit 0: only `visited` is defined
             SearchOut o{};
             o.visited = out.visited ? out.visited + a : nullptr;
             CIS_TRY(ix->w_part.reserve((size_t)bn * sizeof(cis_hit)));
             o.hits = ix->w_part.as<cis_hit>();
-            CIS_TRY(search_batch(ix, q, q_dtype, bn, quota, 1, o, st));
+            rc = search_batch(ix, q, q_dtype, bn, quota, 1, o, st);
         }
+        if (rc == CIS_RETRY_SMALLER) {
+            batch = bn > 1 ? bn / 2 : 1;
+            continue;
+        }
+        CIS_TRY(rc);
+        a += bn;
     }
     return CIS_OK;
 }

@@ -288,3 +288,24 @@ def test_device_selftest_of_wave_primitives():
     n = ctypes.c_int(-1)
     _lib.check(_lib.lib().cis_selftest(ctypes.byref(n)))
     assert n.value == 0
+
+
+def test_exhaustive_quota_splits_batches_and_matches_oracle():
+    """quota = N (every query visits every cell): the workspace budget forces the batch to be split and
+    re-planned; results still equal the oracle's."""
+    from oracle import lopq_oracle as O
+    z, X, Q = load_golden("c2")
+    m = hip_model(z)
+    s = _build_searcher("c2", z, X, m)
+    rs = np.random.RandomState(5)
+    Qb = np.concatenate([Q, X[rs.choice(len(X), 4096 - len(Q), replace=False)]])  # 4096 queries x 256 cells
+    quota = len(z["coarse"]) + 1  # can never be filled: every one of the V*V cells is visited
+    r = s.search_batch(Qb, quota=quota, limit=100)
+    assert (r["visited"] == m.V * m.V).all() and (r["n_found"] == 100).all()
+    om = O.OracleModel.from_npz(z)
+    oi = O.OracleCSRIndex(om, z["coarse"], z["fine"])
+    for qi in list(range(8)) + [2000, 4095]:
+        ids, dists, visited = oi.search(Qb[qi], quota=quota, limit=100)
+        assert visited == m.V * m.V
+        np.testing.assert_array_equal(r["ids"][qi], ids)
+        np.testing.assert_allclose(r["dists"][qi], dists, rtol=1e-9)
