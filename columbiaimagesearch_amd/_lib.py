@@ -48,6 +48,9 @@ _PROTOS = {
     "cis_predict_fine": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "cis_subquantizer_distances": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "cis_reconstruct": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "cis_predict_cluster": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
+    "cis_multisequence": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
+                                  POINTER(c_int)]),
     "cis_index_create": (c_int, [POINTER(c_void_p), c_void_p]),
     "cis_index_destroy": (None, [c_void_p]),
     "cis_index_set_shard": (c_int, [c_void_p, c_int, c_int, c_void_p]),

@@ -457,6 +457,7 @@ extern "C" int cis_model_create(cis_model** out, int D_in, int D, int V, int M, 
     return CIS_OK;
 }
 
+
 static inline int grid1(int64_t n, int bs) { return (int)ceil_div(n, bs); }
 
 int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, float* d_out, hipStream_t st) {
@@ -507,6 +508,62 @@ int cis_launch_sqdist(cis_model* m, const void* xc, int ct, int64_t n, int split
                            m->d_Cs64 + (size_t)split * m->V * m->h, n, m->V, m->h, (double*)out, m->prog_h);
     CIS_CHECK_HIP(hipGetLastError());
     return CIS_OK;
+}
+
+int cis_launch_sqdist_generic(const void* X, int ct, int64_t ldx, int xoff, const void* C, int64_t n, int ncent, int d,
+                              void* out, hipStream_t st) {
+    if (n == 0) return CIS_OK;
+    PwProg prog;
+    CIS_TRY(cis_build_pwprog(d, &prog));
+    dim3 g((unsigned)ceil_div(n, 16), (unsigned)ceil_div(ncent, 16));
+    if (ct == CIS_F32)
+        hipLaunchKernelGGL(k_sqdist_rows<float>, g, dim3(256), 0, st, (const float*)X, ldx, xoff, (const float*)C, n, ncent, d,
+                           (float*)out, prog);
+    else
+        hipLaunchKernelGGL(k_sqdist_rows<double>, g, dim3(256), 0, st, (const double*)X, ldx, xoff, (const double*)C, n, ncent,
+                           d, (double*)out, prog);
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
+}
+
+// one temporary device array: uploads `n` elements of src_dtype widened to the compute type ct
+static int upload_as(const void* src, int src_dtype, int ct, size_t n, DevBuf* buf) {
+    CIS_TRY(buf->reserve(n * (size_t)ct + 16));
+    if (src_dtype == ct) {
+        CIS_CHECK_HIP(hipMemcpy(buf->p, src, n * (size_t)ct, hipMemcpyHostToDevice));
+    } else {  // float32 -> float64 is exact
+        std::vector<double> tmp(n);
+        const float* f = (const float*)src;
+        for (size_t i = 0; i < n; ++i) tmp[i] = (double)f[i];
+        CIS_CHECK_HIP(hipMemcpy(buf->p, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return CIS_OK;
+}
+
+extern "C" int cis_predict_cluster(const void* X, int x_dtype, const void* C, int c_dtype, int64_t n, int ncent, int d,
+                                   uint32_t* out) {
+    CIS_REQUIRE((x_dtype == CIS_F32 || x_dtype == CIS_F64) && (c_dtype == CIS_F32 || c_dtype == CIS_F64), "dtype must be 4 or 8");
+    CIS_REQUIRE(n >= 0 && ncent >= 1 && d >= 1 && (n == 0 || (X && C && out)), "bad arguments");
+    if (n == 0) return CIS_OK;
+    CIS_TRY(cis_lazy_init());
+    const int ct = (x_dtype == CIS_F32 && c_dtype == CIS_F32) ? CIS_F32 : CIS_F64;  // numpy promotion
+    DevBuf bx, bc, bd, bo;
+    int rc = CIS_OK;
+    auto done = [&](int r) { bx.release(); bc.release(); bd.release(); bo.release(); return r; };
+    if ((rc = upload_as(X, x_dtype, ct, (size_t)n * d, &bx)) != CIS_OK) return done(rc);
+    if ((rc = upload_as(C, c_dtype, ct, (size_t)ncent * d, &bc)) != CIS_OK) return done(rc);
+    if ((rc = bd.reserve((size_t)n * ncent * ct)) != CIS_OK) return done(rc);
+    if ((rc = bo.reserve((size_t)n * sizeof(uint32_t))) != CIS_OK) return done(rc);
+    if ((rc = cis_launch_sqdist_generic(bx.p, ct, d, 0, bc.p, n, ncent, d, bd.p, nullptr)) != CIS_OK) return done(rc);
+    if (ct == CIS_F32)
+        hipLaunchKernelGGL((k_argmin_rows<float, uint32_t>), dim3(grid1(n, 256)), dim3(256), 0, nullptr, bd.as<float>(), n, ncent,
+                           bo.as<uint32_t>(), 1, 0);
+    else
+        hipLaunchKernelGGL((k_argmin_rows<double, uint32_t>), dim3(grid1(n, 256)), dim3(256), 0, nullptr, bd.as<double>(), n,
+                           ncent, bo.as<uint32_t>(), 1, 0);
+    hipError_t e = hipMemcpy(out, bo.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { cis_set_error("hipMemcpy failed: %s", hipGetErrorString(e)); return done(CIS_EHIP); }
+    return done(CIS_OK);
 }
 
 // coarse ids of n LOPQ-space vectors (already in compute type ct) -> d_coarse [n][2]

@@ -176,6 +176,51 @@ __global__ __launch_bounds__(64) void k_plan(const CT* __restrict__ sorted, cons
     }
 }
 
+// multisequence as a list: the first `max_cells` (dist, cell) pairs of every query, same frontier walk as k_plan
+template <typename CT>
+__global__ __launch_bounds__(64) void k_multiseq_list(const CT* __restrict__ sorted, const uint16_t* __restrict__ order, int V,
+                                                      int max_cells, int32_t* __restrict__ cells, double* __restrict__ dists) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* t = reinterpret_cast<int*>(smem);
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const CT* d0 = sorted + ((int64_t)q * 2 + 0) * V;
+    const CT* d1 = sorted + ((int64_t)q * 2 + 1) * V;
+    const uint16_t* o0 = order + ((int64_t)q * 2 + 0) * V;
+    const uint16_t* o1 = order + ((int64_t)q * 2 + 1) * V;
+    for (int i = lane; i < V; i += 64) t[i] = 0;
+    __syncthreads();
+    int rows = 1;
+    for (int n = 0; n < max_cells; ++n) {
+        uint64_t bk = ~0ull;
+        uint32_t bij = ~0u;
+        for (int i = lane; i < rows; i += 64) {
+            const int j = t[i];
+            if (j >= V) continue;
+            if (i > 0 && t[i - 1] <= j) continue;
+            const uint64_t kb = f2bits((CT)(d0[i] + d1[j]));
+            const uint32_t ij = ((uint32_t)i << 16) | (uint32_t)j;
+            if (kb < bk || (kb == bk && ij < bij)) { bk = kb; bij = ij; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint64_t ok = __shfl_xor(bk, off);
+            const uint32_t oij = __shfl_xor(bij, off);
+            if (ok < bk || (ok == bk && oij < bij)) { bk = ok; bij = oij; }
+        }
+        if (bij == ~0u) break;
+        const int bi = (int)(bij >> 16), bj = (int)(bij & 0xffff);
+        if (lane == 0) {
+            cells[((int64_t)q * max_cells + n) * 2 + 0] = o0[bi];
+            cells[((int64_t)q * max_cells + n) * 2 + 1] = o1[bj];
+            dists[(int64_t)q * max_cells + n] = (double)(CT)(d0[bi] + d1[bj]);
+        }
+        __syncthreads();
+        if (lane == 0) t[bi] = bj + 1;
+        if (bi + 2 > rows) rows = (bi + 2 < V) ? bi + 2 : V;
+        __syncthreads();
+    }
+}
+
 // exclusive scans over the queries of one batch (single block); totals[0]=items, [1]=tables, [2]=cands
 __global__ void k_plan_scan(const PlanOut* __restrict__ plan, int nq, int64_t* __restrict__ item_off,
                             int64_t* __restrict__ tab_off, int64_t* __restrict__ totals) {
@@ -1733,6 +1778,57 @@ extern "C" int cis_selftest(int* n_errors) {
     CIS_CHECK_HIP(hipMemcpy(n_errors, d, sizeof(int), hipMemcpyDeviceToHost));
     (void)hipFree(d);
     return CIS_OK;
+}
+
+extern "C" int cis_multisequence(const void* X, int x_dtype, const void* C0, const void* C1, int c_dtype, int64_t n, int V,
+                                 int h, int max_cells, int32_t* cells, double* dists, int* dist_dtype) {
+    CIS_REQUIRE((x_dtype == CIS_F32 || x_dtype == CIS_F64) && (c_dtype == CIS_F32 || c_dtype == CIS_F64), "dtype must be 4 or 8");
+    CIS_REQUIRE(n >= 0 && V >= 1 && V <= 65535 && h >= 1 && max_cells >= 1 && (n == 0 || (X && C0 && C1 && cells && dists)),
+                "bad arguments");
+    if ((int64_t)max_cells > (int64_t)V * V) max_cells = V * V;
+    const int ct = (x_dtype == CIS_F32 && c_dtype == CIS_F32) ? CIS_F32 : CIS_F64;
+    if (dist_dtype) *dist_dtype = ct;
+    if (n == 0) return CIS_OK;
+    CIS_TRY(cis_lazy_init());
+    const size_t csz = (size_t)ct;
+    DevBuf bx, bc, bd, bs, bo, bcell, bdist;
+    int rc = CIS_OK;
+    auto done = [&](int r) { bx.release(); bc.release(); bd.release(); bs.release(); bo.release(); bcell.release(); bdist.release(); return r; };
+    auto up = [&](const void* src, int dt, size_t cnt, DevBuf* b, size_t off_elems) -> int {
+        if (dt == ct) { CIS_CHECK_HIP(hipMemcpy((char*)b->p + off_elems * csz, src, cnt * csz, hipMemcpyHostToDevice)); return CIS_OK; }
+        std::vector<double> tmp(cnt);
+        for (size_t i = 0; i < cnt; ++i) tmp[i] = (double)((const float*)src)[i];
+        CIS_CHECK_HIP(hipMemcpy((char*)b->p + off_elems * csz, tmp.data(), cnt * sizeof(double), hipMemcpyHostToDevice));
+        return CIS_OK;
+    };
+    if ((rc = bx.reserve((size_t)n * 2 * h * csz)) != CIS_OK) return done(rc);
+    if ((rc = bc.reserve((size_t)2 * V * h * csz)) != CIS_OK) return done(rc);
+    if ((rc = up(X, x_dtype, (size_t)n * 2 * h, &bx, 0)) != CIS_OK) return done(rc);
+    if ((rc = up(C0, c_dtype, (size_t)V * h, &bc, 0)) != CIS_OK) return done(rc);
+    if ((rc = up(C1, c_dtype, (size_t)V * h, &bc, (size_t)V * h)) != CIS_OK) return done(rc);
+    if ((rc = bd.reserve((size_t)2 * n * V * csz)) != CIS_OK) return done(rc);
+    if ((rc = bs.reserve((size_t)2 * n * V * csz)) != CIS_OK) return done(rc);
+    if ((rc = bo.reserve((size_t)2 * n * V * sizeof(uint16_t))) != CIS_OK) return done(rc);
+    if ((rc = bcell.reserve((size_t)n * max_cells * 2 * sizeof(int32_t))) != CIS_OK) return done(rc);
+    if ((rc = bdist.reserve((size_t)n * max_cells * sizeof(double))) != CIS_OK) return done(rc);
+    for (int s = 0; s < 2; ++s)
+        if ((rc = cis_launch_sqdist_generic(bx.p, ct, 2 * h, s * h, (char*)bc.p + (size_t)s * V * h * csz, n, V, h,
+                                            (char*)bd.p + (size_t)s * n * V * csz, nullptr)) != CIS_OK) return done(rc);
+    if (ct == CIS_F32) {
+        hipLaunchKernelGGL(k_rank<float>, dim3((unsigned)n, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, nullptr, bd.as<float>(), (int)n, V,
+                           bo.as<uint16_t>(), bs.as<float>());
+        hipLaunchKernelGGL(k_multiseq_list<float>, dim3((unsigned)n), dim3(64), (size_t)V * sizeof(int), nullptr, bs.as<float>(),
+                           bo.as<uint16_t>(), V, max_cells, bcell.as<int32_t>(), bdist.as<double>());
+    } else {
+        hipLaunchKernelGGL(k_rank<double>, dim3((unsigned)n, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, nullptr, bd.as<double>(), (int)n, V,
+                           bo.as<uint16_t>(), bs.as<double>());
+        hipLaunchKernelGGL(k_multiseq_list<double>, dim3((unsigned)n), dim3(64), (size_t)V * sizeof(int), nullptr, bs.as<double>(),
+                           bo.as<uint16_t>(), V, max_cells, bcell.as<int32_t>(), bdist.as<double>());
+    }
+    hipError_t e = hipMemcpy(cells, bcell.p, (size_t)n * max_cells * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(dists, bdist.p, (size_t)n * max_cells * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { cis_set_error("hipMemcpy failed: %s", hipGetErrorString(e)); return done(CIS_EHIP); }
+    return done(CIS_OK);
 }
 
 extern "C" int cis_index_set_scan_mode(cis_index* ix, int mode) {

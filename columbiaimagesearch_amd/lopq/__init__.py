@@ -1,9 +1,10 @@
 """Drop-in for the reference's vendored ``lopq`` package (lopq/lopq/__init__.py)."""
 from . import model, search, utils
 from .model import LOPQCode, LOPQModel, LOPQModelPCA
-from .search import LOPQSearcher, LOPQSearcherHIP
+from .search import LOPQSearcher, LOPQSearcherHIP, multisequence
 
-__all__ = ["LOPQModel", "LOPQModelPCA", "LOPQSearcher", "LOPQSearcherHIP", "LOPQCode", "model", "search", "utils"]
+__all__ = ["LOPQModel", "LOPQModelPCA", "LOPQSearcher", "LOPQSearcherHIP", "LOPQCode", "multisequence", "model", "search",
+           "utils"]
 
 
 def install_as_lopq():

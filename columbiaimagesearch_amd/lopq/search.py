@@ -26,6 +26,36 @@ def _is_int(x):
     return isinstance(x, (int, np.integer)) and not isinstance(x, (bool, np.bool_))
 
 
+def multisequence_batch(X, centroids, max_cells=64):
+    """First `max_cells` cells of many LOPQ-space vectors at once: (cells [n,max_cells,2] int32, dists
+    [n,max_cells]) in multi-sequence order (reference: lopq/lopq/search.py:13-82)."""
+    C0, C1 = _lib.as_float_matrix(centroids[0]), _lib.as_float_matrix(centroids[1])
+    if C0.dtype != C1.dtype:
+        C0, C1 = C0.astype(np.float64), C1.astype(np.float64)
+    V, h = C0.shape
+    X = _lib.as_float_matrix(X, 2 * h)
+    mc = int(min(max_cells, V * V))
+    cells = np.empty((X.shape[0], mc, 2), dtype=np.int32)
+    dists = np.empty((X.shape[0], mc), dtype=np.float64)
+    dt = _lib.c_int(0)
+    _lib.check(_lib.lib().cis_multisequence(_lib.ptr(X), _lib.dtype_code(X), _lib.ptr(C0), _lib.ptr(C1), _lib.dtype_code(C0),
+                                            X.shape[0], V, h, mc, _lib.ptr(cells), _lib.ptr(dists), _lib.ctypes.byref(dt)))
+    return cells, (dists.astype(np.float32) if dt.value == 4 else dists)
+
+
+def multisequence(x, centroids):
+    """Generator of (dist, (c0, c1)) in multi-sequence order, like the reference's (lopq/lopq/search.py:13-82).
+    Cells are computed on the GPU in growing prefixes (64, 256, ... up to V*V) as the consumer advances."""
+    V = np.asarray(centroids[0]).shape[0]
+    done, want = 0, 64
+    while done < V * V:
+        cells, dists = multisequence_batch(np.asarray(x)[None, :], centroids, max_cells=want)
+        for k in range(done, cells.shape[1]):
+            yield dists[0, k], (int(cells[0, k, 0]), int(cells[0, k, 1]))
+        done = cells.shape[1]
+        want = min(want * 4, V * V)
+
+
 class LOPQSearcherBase(object):
     """Hooks shared by every searcher (reference: lopq/lopq/search.py:85-308)."""
 
@@ -350,4 +380,5 @@ def merge_hits_dev(parts, with_codes=False):
 # written for them keep loading
 LOPQSearcher = LOPQSearcherHIP
 
-__all__ = ["LOPQSearcherBase", "LOPQSearcherHIP", "LOPQSearcher", "LOPQModel", "LOPQModelPCA", "LOPQCode"]
+__all__ = ["LOPQSearcherBase", "LOPQSearcherHIP", "LOPQSearcher", "LOPQModel", "LOPQModelPCA", "LOPQCode",
+           "multisequence", "multisequence_batch", "merge_hits_dev"]

@@ -16,6 +16,19 @@ def concat_new_first(arrs):
     return np.stack([np.asarray(a) for a in arrs], axis=0)
 
 
+def predict_cluster(x, centroids):
+    """Nearest centroid of one vector (or of every row of a matrix), computed on the GPU with the reference's
+    arithmetic (lopq/lopq/utils.py:33-53): returns np.uint8 / uint16 / uint32 like the reference."""
+    from .. import _lib
+    C = _lib.as_float_matrix(centroids)
+    X = _lib.as_float_matrix(x, C.shape[1])
+    out = np.empty(X.shape[0], dtype=np.uint32)
+    _lib.check(_lib.lib().cis_predict_cluster(_lib.ptr(X), _lib.dtype_code(X), _lib.ptr(C), _lib.dtype_code(C), X.shape[0],
+                                              C.shape[0], C.shape[1], _lib.ptr(out)))
+    t = np.uint8 if C.shape[0] <= 256 else (np.uint16 if C.shape[0] <= 65536 else np.uint32)
+    return t(out[0]) if np.ndim(x) == 1 else out.astype(t)
+
+
 def compute_codes_notparallel(data, model):
     """[model.predict(d) for d in data] as ONE batched GPU encode
     (reference: lopq/lopq/utils.py:203-218).  Returns a list of LOPQCode."""

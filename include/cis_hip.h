@@ -110,6 +110,18 @@ int cis_subquantizer_distances(cis_model* m, const void* X, int x_dtype, int64_t
                                const uint16_t* coarse, double* tables);
 int cis_reconstruct(cis_model* m, const uint16_t* coarse, const uint8_t* fine, int64_t n, double* out);
 
+/* predict_cluster (lopq/lopq/utils.py:33-53) against an arbitrary centroid matrix: X [n][d], C [ncent][d];
+ * distances in float32 when both are float32, else float64 (numpy promotion), numpy summation order, first
+ * minimum wins.  out [n] cluster ids. */
+int cis_predict_cluster(const void* X, int x_dtype, const void* C, int c_dtype, int64_t n, int ncent, int d,
+                        uint32_t* out);
+
+/* multisequence (lopq/lopq/search.py:13-82) as a list: for each of n LOPQ-space vectors X [n][2h] the first
+ * max_cells (clamped to V*V) cells in multi-sequence order: cells [n][max_cells][2], dists [n][max_cells]
+ * (the cell distance d0+d1 rounded in *dist_dtype = 4 or 8, the dtype the reference yields). */
+int cis_multisequence(const void* X, int x_dtype, const void* C0, const void* C1, int c_dtype, int64_t n, int V,
+                      int h, int max_cells, int32_t* cells, double* dists, int* dist_dtype);
+
 /* ---- LOPQ index: replaces lopq.search.LOPQSearcher (search.py:310-382) ---------------------- */
 /* The index keeps a borrowed pointer to `m`: destroy the index first. */
 int cis_index_create(cis_index** out, cis_model* m);

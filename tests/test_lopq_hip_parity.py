@@ -309,3 +309,33 @@ def test_exhaustive_quota_splits_batches_and_matches_oracle():
         assert visited == m.V * m.V
         np.testing.assert_array_equal(r["ids"][qi], ids)
         np.testing.assert_allclose(r["dists"][qi], dists, rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["tiny", "c1", "c2"])
+def test_multisequence_and_predict_cluster_functions(name):
+    """module-level multisequence(x, centroids) and utils.predict_cluster(x, centroids), the reference's names."""
+    from columbiaimagesearch_amd.lopq import multisequence
+    from columbiaimagesearch_amd.lopq.search import multisequence_batch
+    from columbiaimagesearch_amd.lopq.utils import predict_cluster
+    from oracle import lopq_oracle as O
+    z, X, Q = load_golden(name)
+    om = O.OracleModel.from_npz(z)
+    m = hip_model(z)
+    Qx = np.concatenate([Q, X[z["sel"][:4]]]) if name == "tiny" else Q
+    Xq = O.apply_pca(om, Qx) if om.has_pca else Qx
+    nq, nc = z["multiseq_cells"].shape[:2]
+    cells, dists = multisequence_batch(Xq[:nq], m.Cs, max_cells=nc)
+    np.testing.assert_array_equal(cells, z["multiseq_cells"][:, :cells.shape[1]])
+    np.testing.assert_array_equal(dists, z["multiseq_dists"][:, :cells.shape[1]].astype(dists.dtype))
+    gen = multisequence(Xq[0], m.Cs)
+    total = m.V * m.V
+    got = [next(gen) for _ in range(min(total, 70))]  # crosses the first 64-cell prefix
+    assert [c for _, c in got[:nc]] == [tuple(c) for c in z["multiseq_cells"][0][:min(nc, len(got))].tolist()][:len(got[:nc])]
+    if total <= 70:
+        assert len(set(c for _, c in got)) == total
+    # predict_cluster against coarse centroids and against a fine sub-quantizer
+    h = m.Cs[0].shape[1]
+    ids = predict_cluster(np.ascontiguousarray(Xq[:, :h]), m.Cs[0])
+    np.testing.assert_array_equal(ids, O.predict_cluster(np.ascontiguousarray(Xq[:, :h]), om.Cs[0]))
+    one = predict_cluster(np.ascontiguousarray(Xq[0, :h]), m.Cs[0])
+    assert one == ids[0] and one.dtype == np.uint8
