@@ -66,3 +66,30 @@ def test_featurizer_surface(tmp_path, net_and_weights):
     np.testing.assert_array_equal(both[0], feat)
     back = featB64decode(normfeatB64encode(feat), "sbpycaffe")
     np.testing.assert_allclose(np.linalg.norm(back), 1.0, rtol=1e-5)
+
+
+def test_batched_extractor_rows_match_single_image_rows(tmp_path, net_and_weights):
+    """GenericExtractor('full', 'sbpycaffe', ...).process_batch == [process_buffer(b) ...], bad images -> failed row."""
+    import io
+    from PIL import Image
+    from columbiaimagesearch_amd.extractor import GenericExtractor
+    from columbiaimagesearch_amd.featurizer import featB64decode
+    _, w = net_and_weights
+    np.savez(tmp_path / "w.npz", **w)
+    np.save(tmp_path / "mean.npy", np.zeros((3, 256, 256)) + 110.0)
+    conf = {"EX_sbcaffe_path": str(tmp_path / "w.npz"), "EX_imgmean_path": str(tmp_path / "mean.npy")}
+    ex = GenericExtractor("full", "sbpycaffe", "image", "ext", "EX_", conf)
+    assert ex.extr_str == "ext:sbpycaffe_feat_full_image" and ex.extr_str_processed.endswith("_processed")
+    rs = np.random.RandomState(1)
+    bufs = []
+    for i in range(3):
+        b = io.BytesIO()
+        Image.fromarray(rs.randint(0, 255, (240 + 30 * i, 320, 3), dtype=np.uint8)).save(b, format="JPEG")
+        bufs.append(b.getvalue())
+    rows = ex.process_batch(bufs[:2] + [b"not an image"] + bufs[2:])
+    assert rows[2] == {"ext:sbpycaffe_feat_full_image_failed": "1"}
+    for r, b in zip([rows[0], rows[1], rows[3]], bufs):
+        one = ex.process_buffer(b)
+        assert r == one and r[ex.extr_str_processed] == "1"
+        f = featB64decode(r[ex.extr_str], "sbpycaffe")
+        assert f.shape == (4096,) and abs(np.linalg.norm(f) - 1.0) < 1e-5
