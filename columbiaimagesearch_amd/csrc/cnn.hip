@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
     for (int j = 0; j < WN; ++j) {
         const int ocl = oc0 + (wn * WN + j) * 32 + (lane & 31);
         if (ocl >= d.OCg) continue;
-        const float bv = bias[g * d.OCg + ocl];
+        const float bv = bias ? bias[g * d.OCg + ocl] : 0.f;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -267,6 +267,53 @@ __global__ void k_maxpool_lrn_nhwc(const float* __restrict__ in, float* __restri
     }
 }
 
+// ---- dlib face ResNet helpers (NHWC) ---------------------------------------------------------------
+// input_rgb_image_sized: (pixel - mean_rgb) / 256
+__global__ void k_normalize_rgb(const float* __restrict__ in, float* __restrict__ out, int64_t npix, float m0, float m1, float m2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * 3) return;
+    const int c = (int)(i % 3);
+    out[i] = (in[i] - (c == 0 ? m0 : (c == 1 ? m1 : m2))) * (1.0f / 256.0f);
+}
+
+// avg_pool<2,2,2,2>, no padding, output floor((H-2)/2)+1
+__global__ void k_avgpool2_nhwc(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C, int OH, int OW) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * OH * OW * C) return;
+    const int c = (int)(i % C);
+    const int ox = (int)((i / C) % OW);
+    const int oy = (int)((i / ((int64_t)C * OW)) % OH);
+    const int64_t n = i / ((int64_t)C * OW * OH);
+    const float* p = in + ((n * H + 2 * oy) * W + 2 * ox) * C + c;
+    out[i] = ((p[0] + p[C]) + (p[(int64_t)W * C] + p[(int64_t)W * C + C])) * 0.25f;
+}
+
+// add_prev + relu: out = relu(a + b) where a, b are zero-padded (bottom/right, channels) to the larger shape
+__global__ void k_add_relu_pad(const float* __restrict__ a, int AH, int AW, int AC, const float* __restrict__ b, int BH, int BW,
+                               int BC, float* __restrict__ out, int N, int OH, int OW, int OC) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * OH * OW * OC) return;
+    const int c = (int)(i % OC);
+    const int x = (int)((i / OC) % OW);
+    const int y = (int)((i / ((int64_t)OC * OW)) % OH);
+    const int64_t n = i / ((int64_t)OC * OW * OH);
+    float v = 0.f;
+    if (y < AH && x < AW && c < AC) v += a[((n * AH + y) * AW + x) * AC + c];
+    if (y < BH && x < BW && c < BC) v += b[((n * BH + y) * BW + x) * BC + c];
+    out[i] = v > 0.f ? v : 0.f;
+}
+
+// avg_pool_everything: [N][H*W][C] -> [N][C]
+__global__ void k_global_avgpool(const float* __restrict__ in, float* __restrict__ out, int N, int HW, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * C) return;
+    const int c = (int)(i % C);
+    const int64_t n = i / C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += in[(n * HW + p) * C + c];
+    out[i] = s / (float)HW;
+}
+
 // ================================================================================================
 // host
 // ================================================================================================
@@ -277,23 +324,31 @@ struct LayerW {
 
 struct cis_cnn {
     int arch = 0, device = 0;
-    LayerW conv[5], fc[2];
-    DevBuf act0, act1, in_buf, out_buf;
+    LayerW conv[5], fc[2];        // DeepSentibank
+    std::vector<LayerW> dl;       // dlib ResNet: conv0, then (a, b) per block, then fc (bias-free); affine layers folded in
+    DevBuf act0, act1, act2, act3, in_buf, out_buf;
 };
+
+// dlib anet_type block plan: (in channels, out channels, down-sampling block)
+struct DlibBlock { int cin, cout, down; };
+static const DlibBlock kDlibBlocks[14] = {{32, 32, 0}, {32, 32, 0}, {32, 32, 0}, {32, 64, 1}, {64, 64, 0}, {64, 64, 0}, {64, 64, 0},
+                                          {64, 128, 1}, {128, 128, 0}, {128, 128, 0}, {128, 256, 1}, {256, 256, 0}, {256, 256, 0},
+                                          {256, 256, 1}};
 
 static const int kConvCfg[5][5] = {  // OC, kernel, stride, pad, groups   (prototxt :7-16,:47-58,:88-98,:105-116,:123-134)
     {96, 11, 4, 0, 1}, {256, 5, 1, 2, 2}, {384, 3, 1, 1, 1}, {384, 3, 1, 1, 2}, {256, 3, 1, 1, 2}};
 static const bool kPoolAfter[5] = {true, true, false, false, true};
 static const bool kLrnAfter[5] = {true, true, false, false, false};
 
-extern "C" int cis_cnn_feat_dim(int arch) { return arch == 1 ? 4096 : 0; }
+extern "C" int cis_cnn_feat_dim(int arch) { return arch == 1 ? 4096 : (arch == 2 ? 128 : 0); }
 
 extern "C" void cis_cnn_destroy(cis_cnn* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (auto& l : c->conv) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
     for (auto& l : c->fc) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
-    c->act0.release(); c->act1.release(); c->in_buf.release(); c->out_buf.release();
+    for (auto& l : c->dl) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
+    c->act0.release(); c->act1.release(); c->act2.release(); c->act3.release(); c->in_buf.release(); c->out_buf.release();
     delete c;
 }
 
@@ -303,11 +358,54 @@ static int upload_f(float** dst, const float* src, size_t n) {
     return CIS_OK;
 }
 
+// conv OIHW + bias with the following per-channel affine (gamma, beta) folded in, packed [K][OC], k = (ky*KW+kx)*IC+ic
+static int pack_conv_affine(LayerW* L, const float* w, const float* b, const float* gam, const float* bet, int OC, int IC, int k) {
+    const int K = k * k * IC;
+    std::vector<float> packed((size_t)K * OC), bias(OC);
+    for (int o = 0; o < OC; ++o) {
+        const float g = gam ? gam[o] : 1.f;
+        bias[o] = g * (b ? b[o] : 0.f) + (bet ? bet[o] : 0.f);
+        for (int ic = 0; ic < IC; ++ic)
+            for (int ky = 0; ky < k; ++ky)
+                for (int kx = 0; kx < k; ++kx)
+                    packed[((size_t)(ky * k + kx) * IC + ic) * OC + o] = g * w[(((size_t)o * IC + ic) * k + ky) * k + kx];
+    }
+    CIS_TRY(upload_f(&L->d_w, packed.data(), packed.size()));
+    CIS_TRY(upload_f(&L->d_b, bias.data(), bias.size()));
+    return CIS_OK;
+}
+
+static int cnn_create_dlib(cis_cnn** out, const float* const* tensors, int n_tensors) {
+    CIS_REQUIRE(tensors != nullptr && n_tensors == 117, "the dlib face ResNet needs 117 tensors (conv0 w,b,gamma,beta; 14 blocks x 2 x (w,b,gamma,beta); fc)");
+    for (int i = 0; i < 117; ++i) CIS_REQUIRE(tensors[i] != nullptr, "tensor %d is NULL", i);
+    CIS_TRY(cis_lazy_init());
+    cis_cnn* c = new cis_cnn();
+    c->arch = 2;
+    c->device = cis_current_device();
+    c->dl.resize(1 + 28 + 1);
+    int rc = pack_conv_affine(&c->dl[0], tensors[0], tensors[1], tensors[2], tensors[3], 32, 3, 7);
+    for (int i = 0; i < 14 && rc == CIS_OK; ++i) {
+        const float* const* t = tensors + 4 + 8 * i;
+        rc = pack_conv_affine(&c->dl[1 + 2 * i], t[0], t[1], t[2], t[3], kDlibBlocks[i].cout, kDlibBlocks[i].cin, 3);
+        if (rc == CIS_OK) rc = pack_conv_affine(&c->dl[2 + 2 * i], t[4], t[5], t[6], t[7], kDlibBlocks[i].cout, kDlibBlocks[i].cout, 3);
+    }
+    if (rc == CIS_OK) {  // fc_no_bias<128>: [128][256] -> packed [256][128]
+        std::vector<float> packed((size_t)256 * 128);
+        for (int o = 0; o < 128; ++o)
+            for (int k = 0; k < 256; ++k) packed[(size_t)k * 128 + o] = tensors[116][(size_t)o * 256 + k];
+        rc = upload_f(&c->dl[29].d_w, packed.data(), packed.size());
+    }
+    if (rc != CIS_OK) { cis_cnn_destroy(c); return rc; }
+    *out = c;
+    return CIS_OK;
+}
+
 extern "C" int cis_cnn_create(cis_cnn** out, int arch, const float* const* tensors, int n_tensors) {
     CIS_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
+    if (arch == 2) return cnn_create_dlib(out, tensors, n_tensors);
     if (arch != 1) {
-        cis_set_error("arch %d: only CIS_CNN_SENTIBANK (1) is built", arch);
+        cis_set_error("arch %d: CIS_CNN_SENTIBANK (1) and CIS_CNN_DLIB_RESNET (2) are built", arch);
         return CIS_EUNSUPPORTED;
     }
     CIS_REQUIRE(tensors != nullptr && n_tensors == 14, "DeepSentibank needs 14 tensors (conv1..conv5, fc6, fc7: weight, bias)");
@@ -374,9 +472,69 @@ static void launch_conv_cfg(const ConvDesc& d, const float* in, const float* w, 
 
 static void launch_conv(const ConvDesc& d, const float* in, const float* w, const float* b, float* out, hipStream_t st) {
     const int64_t npix = (int64_t)d.N * d.OH * d.OW;
-    if (npix <= 2048) launch_conv_cfg<1, 1, 1, 4>(d, in, w, b, out, st);            // fc layers: 32 x 128 tiles fill the chip
+    if (d.OCg <= 32) launch_conv_cfg<1, 1, 4, 1>(d, in, w, b, out, st);                // 128 x 32 tiles
+    else if (d.OCg <= 64) launch_conv_cfg<2, 1, 2, 2>(d, in, w, b, out, st);           // 128 x 64 tiles
+    else if (npix <= 2048) launch_conv_cfg<1, 1, 1, 4>(d, in, w, b, out, st);          // fc layers: 32 x 128 tiles fill the chip
     else if (d.OCg % 96 == 0 && d.OCg % 128 != 0) launch_conv_cfg<1, 3, 4, 1>(d, in, w, b, out, st);  // 96, 192: 128 x 96
     else launch_conv_cfg<2, 2, 2, 2>(d, in, w, b, out, st);                          // 128 x 128
+}
+
+static ConvDesc nhwc_conv(int n, int H, int W, int C, int OC, int k, int stride, int pad, int relu) {
+    ConvDesc d;
+    d.N = n; d.H = H; d.W = W; d.C = C; d.OC = OC; d.KH = d.KW = k; d.stride = stride; d.pad = pad; d.groups = 1;
+    d.OH = (H + 2 * pad - k) / stride + 1;
+    d.OW = (W + 2 * pad - k) / stride + 1;
+    d.ICg = C; d.OCg = OC; d.K = k * k * C;
+    d.sN = (int64_t)H * W * C; d.sC = 1; d.sH = (int64_t)W * C; d.sW = C;
+    d.relu = relu; d.kx_fastest = 0;
+    return d;
+}
+
+// dlib face ResNet: d_in = [n][150][150][3] float32 RGB 0..255 (aligned chips), d_feats = [n][128]
+static int cnn_forward_dlib(cis_cnn* c, const float* d_in, int n, float* d_feats, hipStream_t st) {
+    const size_t big = (size_t)n * 72 * 72 * 32;  // largest activation: first convolution's output
+    CIS_TRY(c->act0.reserve(big * sizeof(float)));
+    CIS_TRY(c->act1.reserve(big * sizeof(float)));
+    CIS_TRY(c->act2.reserve(big * sizeof(float)));
+    CIS_TRY(c->act3.reserve(big * sizeof(float)));
+    float* A = c->act0.as<float>();
+    float* B = c->act1.as<float>();
+    float* T1 = c->act2.as<float>();
+    float* T2 = c->act3.as<float>();
+    auto grid = [](int64_t total) { return dim3((unsigned)ceil_div(total, 256)); };
+    hipLaunchKernelGGL(k_normalize_rgb, grid((int64_t)n * 150 * 150 * 3), dim3(256), 0, st, d_in, A, (int64_t)n * 150 * 150, 122.782f,
+                       117.001f, 104.298f);
+    ConvDesc d0 = nhwc_conv(n, 150, 150, 3, 32, 7, 2, 0, 1);
+    launch_conv(d0, A, c->dl[0].d_w, c->dl[0].d_b, B, st);  // 72 x 72 x 32, affine folded, relu
+    int H = (72 - 3) / 2 + 1, W = H, C = 32;                  // max_pool<3,3,2,2>: 35
+    hipLaunchKernelGGL(k_maxpool_nhwc, grid((int64_t)n * H * W * C), dim3(256), 0, st, B, A, n, 72, 72, C, H, W);
+    float* x = A;      // current activation
+    float* other = B;  // free buffer for the next activation
+    for (int i = 0; i < 14; ++i) {
+        const DlibBlock& b = kDlibBlocks[i];
+        const int s = b.down ? 2 : 1, p = b.down ? 0 : 1;
+        ConvDesc da = nhwc_conv(n, H, W, C, b.cout, 3, s, p, 1);
+        launch_conv(da, x, c->dl[1 + 2 * i].d_w, c->dl[1 + 2 * i].d_b, T1, st);
+        ConvDesc db = nhwc_conv(n, da.OH, da.OW, b.cout, b.cout, 3, 1, 1, 0);
+        launch_conv(db, T1, c->dl[2 + 2 * i].d_w, c->dl[2 + 2 * i].d_b, T2, st);
+        const float* skip = x;
+        int SH = H, SW = W, SC = C;
+        if (b.down) {
+            SH = (H - 2) / 2 + 1; SW = (W - 2) / 2 + 1;
+            hipLaunchKernelGGL(k_avgpool2_nhwc, grid((int64_t)n * SH * SW * C), dim3(256), 0, st, x, T1, n, H, W, C, SH, SW);
+            skip = T1;  // T1 is free again: conv b has consumed it (same stream)
+        }
+        const int OH = db.OH > SH ? db.OH : SH, OW = db.OW > SW ? db.OW : SW, OC = b.cout > SC ? b.cout : SC;
+        hipLaunchKernelGGL(k_add_relu_pad, grid((int64_t)n * OH * OW * OC), dim3(256), 0, st, T2, db.OH, db.OW, b.cout, skip, SH, SW, SC,
+                           other, n, OH, OW, OC);
+        float* t = x; x = other; other = t;
+        H = OH; W = OW; C = OC;
+    }
+    hipLaunchKernelGGL(k_global_avgpool, grid((int64_t)n * C), dim3(256), 0, st, x, other, n, H * W, C);
+    ConvDesc df = nhwc_conv(n, 1, 1, C, 128, 1, 1, 0, 0);
+    launch_conv(df, other, c->dl[29].d_w, nullptr, d_feats, st);
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
 }
 
 extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float* d_feats, void* stream) {
@@ -385,6 +543,7 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
     if (n == 0) return CIS_OK;
     CIS_CHECK_HIP(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
+    if (c->arch == 2) return cnn_forward_dlib(c, d_nchw, n, d_feats, st);
     // largest activation: conv1 output n x 55 x 55 x 96
     const size_t act_elems = (size_t)n * 55 * 55 * 96;
     CIS_TRY(c->act0.reserve(act_elems * sizeof(float)));
@@ -453,11 +612,12 @@ extern "C" int cis_cnn_forward(cis_cnn* c, const float* nchw, int n, float* feat
     CIS_REQUIRE(n >= 0 && (n == 0 || (nchw && feats)), "NULL buffer");
     if (n == 0) return CIS_OK;
     CIS_CHECK_HIP(hipSetDevice(c->device));
-    const size_t in_bytes = (size_t)n * 3 * 227 * 227 * sizeof(float);
+    const int fdim = cis_cnn_feat_dim(c->arch);
+    const size_t in_bytes = (size_t)n * (c->arch == 2 ? 3 * 150 * 150 : 3 * 227 * 227) * sizeof(float);
     CIS_TRY(c->in_buf.reserve(in_bytes));
-    CIS_TRY(c->out_buf.reserve((size_t)n * 4096 * sizeof(float)));
+    CIS_TRY(c->out_buf.reserve((size_t)n * fdim * sizeof(float)));
     CIS_CHECK_HIP(hipMemcpy(c->in_buf.p, nchw, in_bytes, hipMemcpyHostToDevice));
     CIS_TRY(cis_cnn_forward_dev(c, c->in_buf.as<float>(), n, c->out_buf.as<float>(), nullptr));
-    CIS_CHECK_HIP(hipMemcpy(feats, c->out_buf.p, (size_t)n * 4096 * sizeof(float), hipMemcpyDeviceToHost));
+    CIS_CHECK_HIP(hipMemcpy(feats, c->out_buf.p, (size_t)n * fdim * sizeof(float), hipMemcpyDeviceToHost));
     return CIS_OK;
 }

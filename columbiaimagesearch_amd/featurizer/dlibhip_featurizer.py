@@ -1,0 +1,99 @@
+"""dlib face-descriptor featurizer on the MI355X.
+
+Mirror of DLibFeaturizer (cufacesearch/cufacesearch/featurizer/dlib_featurizer.py:50-105): constructor
+``(global_conf_in, prefix)`` reading ``<prefix>pred_path`` (68-landmark shape predictor) and ``<prefix>rec_path``
+(recognition network weights), ``featurize(img, bbox)`` -> 128 float64 values.  The landmark predictor and the chip
+alignment are dlib host code (out of scope, like image decoding); the 29-convolution ResNet runs in libcis_hip.so.
+``featurize_chips`` takes already aligned 150x150 RGB chips and is the batch entry point.
+
+Weights: ``rec_path`` may be a ``.npz`` with the 117 arrays named as oracle/dlib_oracle.py:tensor_names (a converter from
+dlib's ``.dat`` serialisation is not built: the format is dlib-internal and absent from the reference tree).
+"""
+import numpy as np
+
+from .. import _lib
+from .generic_featurizer import GenericFeaturizer
+
+INPUT_HW = 150
+FEAT_DIM = 128
+N_BLOCKS = 14
+
+
+def tensor_names():
+    names = ["conv0_w", "conv0_b", "aff0_g", "aff0_b"]
+    for i in range(N_BLOCKS):
+        for half in ("a", "b"):
+            names += ["b%d%s_w" % (i, half), "b%d%s_b" % (i, half), "b%d%s_g" % (i, half), "b%d%s_beta" % (i, half)]
+    return names + ["fc_w"]
+
+
+class DLibFaceNet(object):
+    """The network alone: chips [n,150,150,3] (uint8 or float, RGB 0..255) -> [n,128] float32."""
+
+    def __init__(self, weights):
+        arrs = [np.ascontiguousarray(weights[n], dtype=np.float32) for n in tensor_names()]
+        ptrs = (_lib.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        out = _lib.c_void_p()
+        _lib.check(_lib.lib().cis_cnn_create(_lib.ctypes.byref(out), 2, ptrs, len(arrs)))
+        self._h = out.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().cis_cnn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, chips):
+        x = np.ascontiguousarray(chips, dtype=np.float32)
+        if x.ndim != 4 or x.shape[1:] != (INPUT_HW, INPUT_HW, 3):
+            raise ValueError("expected chips [n,150,150,3], got %r" % (x.shape,))
+        out = np.empty((x.shape[0], FEAT_DIM), dtype=np.float32)
+        _lib.check(_lib.lib().cis_cnn_forward(self._h, _lib.ptr(x), x.shape[0], _lib.ptr(out)))
+        return out
+
+    def forward_dev(self, x, out=None):
+        """x: contiguous float32 CUDA tensor [n,150,150,3] -> CUDA tensor [n,128]; asynchronous"""
+        import torch
+        if not (x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and tuple(x.shape[1:]) == (INPUT_HW, INPUT_HW, 3)):
+            raise ValueError("x must be a contiguous float32 [n,150,150,3] tensor on the GPU")
+        if out is None:
+            out = torch.empty((x.shape[0], FEAT_DIM), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().cis_cnn_forward_dev(self._h, x.data_ptr(), x.shape[0], out.data_ptr(),
+                                                  torch.cuda.current_stream(x.device).cuda_stream))
+        return out
+
+
+class DLibHIPFeaturizer(GenericFeaturizer):
+    def __init__(self, global_conf_in, prefix="DLIBFEAT_"):
+        super(DLibHIPFeaturizer, self).__init__(global_conf_in, prefix)
+        self.set_pp(pp="DLibHIPFeaturizer")
+        self.pred_path = self.get_param("pred_path")
+        self.rec_path = str(self.get_required_param("rec_path"))
+        if not self.rec_path.endswith(".npz"):
+            raise NotImplementedError("rec_path must be an .npz with the 117 network tensors (dlib .dat is not parsed)")
+        z = np.load(self.rec_path)
+        self.net = DLibFaceNet({k: z[k] for k in z.files})
+        self._sp = None
+
+    def featurize_chips(self, chips):
+        """aligned 150x150 RGB chips -> [n,128] float64 (dtype of the reference's descriptors, featsio.py:34-36)"""
+        return self.net.forward(chips).astype(np.float64)
+
+    def featurize(self, img, bbox=None, img_type="scikit"):
+        """reference :86-105: landmarks on the detected box, aligned chip, network.  Needs dlib for the two host steps."""
+        try:
+            import dlib
+        except ImportError:
+            raise ImportError("dlib is needed for the landmark predictor / chip alignment of featurize(img, bbox); "
+                              "use featurize_chips() with aligned chips")
+        if self._sp is None:
+            self._sp = dlib.shape_predictor(str(self.pred_path))
+        rect = dlib.rectangle(int(bbox["left"]), int(bbox["top"]), int(bbox["right"]), int(bbox["bottom"]))
+        shape = self._sp(img, rect)
+        chip = dlib.get_face_chip(img, shape, size=INPUT_HW, padding=0.25)
+        return self.featurize_chips(np.asarray(chip)[None])[0]

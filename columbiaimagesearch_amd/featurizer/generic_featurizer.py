@@ -1,7 +1,7 @@
 """`get_featurizer` / `get_feat_size` / `GenericFeaturizer` with the reference's names and meaning
 (cufacesearch/cufacesearch/featurizer/generic_featurizer.py:5-71).  ``featurizer_type = "sbhip"`` selects the
 MI355X DeepSentibank featurizer; "sbpycaffe" / "sbcmdline" resolve to it too, so existing configuration files
-keep working.  "dlib" is not built yet."""
+keep working; "dlib" selects the MI355X face-descriptor network."""
 
 
 def get_featurizer(featurizer_type, global_conf, prefix=None):
@@ -10,13 +10,16 @@ def get_featurizer(featurizer_type, global_conf, prefix=None):
         if prefix:
             return SentiBankHIPImgFeaturizer(global_conf, prefix=prefix)
         return SentiBankHIPImgFeaturizer(global_conf)
-    if featurizer_type == "dlib":
-        raise NotImplementedError("the dlib face descriptor network is not built yet (DESIGN.md section 7)")
+    if featurizer_type in ("dlib", "dlibhip"):
+        from .dlibhip_featurizer import DLibHIPFeaturizer
+        if prefix:
+            return DLibHIPFeaturizer(global_conf, prefix=prefix)
+        return DLibHIPFeaturizer(global_conf)
     raise ValueError("[{}:error] Unknown 'featurizer' {}.".format("get_featurizer", featurizer_type))
 
 
 def get_feat_size(featurizer_type):
-    if featurizer_type == "dlib":
+    if featurizer_type in ("dlib", "dlibhip"):
         return 128
     if featurizer_type in ("sbhip", "sbpycaffe", "sbcmdline"):
         return 4096

@@ -195,6 +195,13 @@ int cis_index_read_profile(cis_index* ix, double ms[4], int64_t* launches);
  * CHW-flattened blob).  forward: nchw [n][3][227][227] float32 exactly as preprocess_img (:113-134)
  * produces it (BGR, mean subtracted) -> feats [n][4096] float32 = blobs['fc7'] after the in-place ReLU. */
 #define CIS_CNN_SENTIBANK 1
+/* arch CIS_CNN_DLIB_RESNET: dlib's face-descriptor network behind DLibFeaturizer.featurize
+ * (cufacesearch/cufacesearch/featurizer/dlib_featurizer.py:86-105, compute_face_descriptor :105).  The network
+ * (dlib's anet_type, 29 convolutions) is third-party and not in the reference tree: oracle/dlib_oracle.py restates it.
+ * tensors (117) = conv0 {w OIHW, b, affine gamma, affine beta}, then for each of the 14 residual blocks
+ * {w, b, gamma, beta} of its first and of its second 3x3 convolution, then fc [128][256] (no bias).
+ * forward input: aligned face chips [n][150][150][3] float32 RGB 0..255 (channels last) -> feats [n][128]. */
+#define CIS_CNN_DLIB_RESNET 2
 int cis_cnn_create(cis_cnn** out, int arch, const float* const* tensors, int n_tensors);
 void cis_cnn_destroy(cis_cnn* c);
 int cis_cnn_feat_dim(int arch);

@@ -93,3 +93,23 @@ def test_batched_extractor_rows_match_single_image_rows(tmp_path, net_and_weight
         assert r == one and r[ex.extr_str_processed] == "1"
         f = featB64decode(r[ex.extr_str], "sbpycaffe")
         assert f.shape == (4096,) and abs(np.linalg.norm(f) - 1.0) < 1e-5
+
+
+def test_dlib_resnet_matches_torch_cpu(tmp_path):
+    """dlib face ResNet (29 convolutions, residual adds with zero padding) vs the CPU restatement, synthetic weights."""
+    from oracle import dlib_oracle as D
+    from columbiaimagesearch_amd.featurizer import DLibFaceNet, get_feat_size, get_featurizer
+    w = D.synthetic_weights(0)
+    net = DLibFaceNet(w)
+    chips = D.synthetic_chips(5, seed=2)
+    got = net.forward(chips)
+    ref = D.forward_torch(chips, w)
+    assert got.shape == (5, 128) and got.dtype == np.float32
+    np.testing.assert_allclose(got, ref, rtol=0, atol=3e-4 * np.abs(ref).max())
+    one = np.stack([net.forward(chips[i:i + 1])[0] for i in range(5)])
+    np.testing.assert_array_equal(got, one)
+    np.savez(tmp_path / "rec.npz", **w)
+    f = get_featurizer("dlib", {"D_rec_path": str(tmp_path / "rec.npz")}, prefix="D_")
+    d = f.featurize_chips(chips[:2])
+    assert d.dtype == np.float64 and d.shape == (2, get_feat_size("dlib"))
+    np.testing.assert_array_equal(d, got[:2].astype(np.float64))
