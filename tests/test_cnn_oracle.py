@@ -29,3 +29,16 @@ def test_pooling_is_ceil_mode_and_lrn_divides_alpha_by_n():
     y = np.ones((1, 7, 1, 1))
     out = C._lrn_numpy(y)
     assert np.isclose(out[0, 3, 0, 0], (1 + 1e-4 / 5 * 5) ** -0.75) and np.isclose(out[0, 0, 0, 0], (1 + 1e-4 / 5 * 3) ** -0.75)
+
+
+def test_dlib_oracle_structure_and_shapes():
+    """dlib face network restatement: 29 convolutions, 117 tensors, dlib's size rules give 150 -> 72 -> 35 -> ... -> 3."""
+    from oracle import dlib_oracle as D
+    plan = D.block_plan()
+    assert len(plan) == 14 and sum(1 for p in plan if p[2]) == 4
+    assert len(D.tensor_names()) == 117
+    w = D.synthetic_weights(0)
+    assert w["conv0_w"].shape == (32, 3, 7, 7) and w["fc_w"].shape == (128, 256)
+    out = D.forward_torch(D.synthetic_chips(2, seed=3), w)
+    assert out.shape == (2, 128) and np.isfinite(out).all() and np.abs(out).max() > 0
+    assert D.mac_per_face() == 270854144
