@@ -223,7 +223,8 @@ __global__ __launch_bounds__(64) void k_multiseq_list(const CT* __restrict__ sor
 
 // exclusive scans over the queries of one batch (single block); totals[0]=items, [1]=tables, [2]=cands
 __global__ void k_plan_scan(const PlanOut* __restrict__ plan, int nq, int64_t* __restrict__ item_off,
-                            int64_t* __restrict__ tab_off, int64_t* __restrict__ totals) {
+                            int64_t* __restrict__ tab_off, int64_t* __restrict__ totals,
+                            unsigned long long* __restrict__ qbound /* [nq] -> +inf */) {
     __shared__ int64_t s_items[256], s_tabs[256], s_cand[256];
     const int tid = threadIdx.x;
     const int per = (nq + 255) / 256;
@@ -246,6 +247,7 @@ __global__ void k_plan_scan(const PlanOut* __restrict__ plan, int nq, int64_t* _
     int64_t ri = s_items[tid], rt = s_tabs[tid];
     for (int q = a; q < b; ++q) {
         item_off[q] = ri; tab_off[q] = rt;
+        qbound[q] = 0x7ff0000000000000ull;
         ri += plan[q].n_items; rt += plan[q].ntab0 + plan[q].ntab1;
     }
 }
@@ -718,14 +720,16 @@ __device__ __forceinline__ uint32_t wave_kth(const uint32_t (&k)[NR], int i) {  
 #pragma unroll
     for (int r = 1; r < NR; ++r)
         if ((i % NR) == r) v = k[r];
-    return (uint32_t)__shfl((int)v, i / NR);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, i / NR);
 }
 
 #ifdef CIS_SCAN_COUNTERS
 __device__ unsigned long long g_scan_ctr[8];  // compactions, rescored entries, exact-cut, second sorts, appended
 #define CIS_CTR(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_scan_ctr[i], (unsigned long long)(v)); } while (0)
+#define CIS_CLK() ((long long)__builtin_amdgcn_s_memtime())
 #else
 #define CIS_CTR(i, v) do { } while (0)
+#define CIS_CLK() 0ll
 #endif
 
 struct ScanShared {  // one per query handled by the workgroup
@@ -735,6 +739,7 @@ struct ScanShared {  // one per query handled by the workgroup
                      // a lost concurrent update only leaves it looser for a while)
     int pad0;
     int wcnt[8];     // survivors per wave at the end
+    uint64_t ext;    // bound published by workgroups that scanned OTHER cells for the same query (qbound[q] at start)
 };
 
 static __device__ __forceinline__ float lds_ld(const float* p) {
@@ -761,6 +766,8 @@ static __device__ __forceinline__ uint64_t block_bound_u64(const ScanShared* sh)
         t = a > t ? a : t;
         l = b < l ? b : l;
     }
+    const uint64_t e = lds_ld(&sh->ext);
+    l = e < l ? e : l;
     return t < l ? t : l;
 }
 
@@ -862,7 +869,6 @@ __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt,
             g += __popcll(__ballot(keep[r] && hi[r] == vhi));
         }
         int need = L - c_less;  // members of the group {hi == vhi} to keep, 1 <= need <= g
-        CIS_CTR(2, 1);
         if (need >= g) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) keep[r] = keep[r] && hi[r] <= vhi;
@@ -875,14 +881,13 @@ __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt,
                 const bool in_g = keep[r] && hi[r] == vhi;
                 const unsigned long long m = __ballot(in_g);
                 if (!found && m) {
-                    lo_first = (uint32_t)__shfl((int)lo[r], __ffsll((long long)m) - 1);
+                    lo_first = (uint32_t)__builtin_amdgcn_readlane((int)lo[r], __ffsll((long long)m) - 1);
                     found = true;
                 }
                 if (found) uniform = uniform && (__ballot(in_g && lo[r] != lo_first) == 0ull);
             }
             uint32_t vlo = lo_first;
             if (!uniform) {
-                CIS_CTR(3, 1);
                 uint32_t t2[NR];
 #pragma unroll
                 for (int r = 0; r < NR; ++r) t2[r] = (keep[r] && hi[r] == vhi) ? lo[r] : 0xffffffffu;
@@ -902,7 +907,7 @@ __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt,
                 // The cut fell inside a group of exactly equal distances.  Remember one member: every LATER
                 // candidate with the same code has the same distance and a larger position, so it loses
                 // against all L entries kept here and the hot loop may skip it (duplicate codes are common).
-                if (seen == 0 && m) dup_pos = (uint32_t)__shfl((int)pp[r], __ffsll((long long)m) - 1);
+                if (seen == 0 && m) dup_pos = (uint32_t)__builtin_amdgcn_readlane((int)pp[r], __ffsll((long long)m) - 1);
                 seen += __popcll(m);
             }
         }
@@ -1010,6 +1015,7 @@ __device__ __forceinline__ CodeWords<M> load_code(const uint8_t* __restrict__ co
 // load instead of 64-bit address arithmetic, and positions past the end of the chunk read as zero
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 template <int M>
 __device__ __forceinline__ CodeWords<M> load_code_buf(__amdgpu_buffer_rsrc_t rs, int p) {
@@ -1098,18 +1104,19 @@ __device__ __forceinline__ void adc32g(const CodeWords<M>& c, const char* __rest
             for (int t = 0; t < M; t += 2 * st) f[t] = f[t] + f[t + st];
         out[0] = f[0];
     } else {
-        float2 f[M];
+        // the two queries' entries sit side by side: one ds_read_b64 per table entry, one packed add per tree node
+        f32x2_t f[M];
 #pragma unroll
         for (int t = 0; t < M; ++t) {
             const uint32_t k = __builtin_amdgcn_ubfe(D[t >> 2], rc.sh[t & 3], 8);
-            f[t] = *reinterpret_cast<const float2*>(tab + ((k << SH) | (rc.cj[t] << 1)));
+            f[t] = *reinterpret_cast<const f32x2_t*>(tab + ((k << SH) | (rc.cj[t] << 1)));
         }
 #pragma unroll
         for (int st = 1; st < M; st <<= 1)
 #pragma unroll
-            for (int t = 0; t < M; t += 2 * st) { f[t].x = f[t].x + f[t + st].x; f[t].y = f[t].y + f[t + st].y; }
-        out[0] = f[0].x;
-        out[1] = f[0].y;
+            for (int t = 0; t < M; t += 2 * st) f[t] = f[t] + f[t + st];
+        out[0] = f[0][0];
+        out[1] = f[0][1];
     }
 }
 
@@ -1118,7 +1125,8 @@ template <int M, int NR, int U, int G, int NW>
 __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (&item_idx)[G], int ng,
                                             const double* __restrict__ T, const uint8_t* __restrict__ codes,
                                             const int64_t* __restrict__ ids, int K, int L, int S, float margin,
-                                            cis_hit* __restrict__ item_hits, int* __restrict__ item_n, char* smem) {
+                                            cis_hit* __restrict__ item_hits, int* __restrict__ item_n,
+                                            unsigned long long* __restrict__ qbound, char* smem) {
     // region capacity: 8 entries short of the NR*64 keys a wave can hold in registers, so that the
     // G=2 / 4-wave layout (16 KB tables + 8 regions) stays under 40 KB and four workgroups share a CU
     constexpr int R = NR * 64 - 8;
@@ -1129,6 +1137,9 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int nf = M / 2;
+    const long long clk_begin = CIS_CLK();
+    long long clk_slow = 0, clk_comp = 0;
+    (void)clk_begin; (void)clk_slow; (void)clk_comp;
     const double* t0[G];
     const double* t1[G];
 #pragma unroll
@@ -1152,7 +1163,20 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
             const int g = tid >> 3, i = tid & 7;
             sh[g].wt[i] = 0x7ff0000000000000ull; sh[g].wl[i] = 0x7ff0000000000000ull;
             sh[g].wcnt[i] = 0;
-            if (i == 0) sh[g].bound_f = INF;
+            if (i == 0) {
+                // A distance that >= L candidates of this query in already scanned cells do not exceed: candidates
+                // above it are strictly worse than L others, whichever cell they are in.  Cells of one query are
+                // scanned by different workgroups at different times (the slot list is sorted by cell), so the
+                // later ones start with a tight bound instead of +inf.  Only the amount of work depends on timing.
+#ifndef CIS_SCAN_NO_QBOUND
+                const unsigned long long e = (g < ng) ? __hip_atomic_load(&qbound[it[g].q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                      : 0x7ff0000000000000ull;
+#else
+                const unsigned long long e = 0x7ff0000000000000ull;
+#endif
+                sh[g].ext = e;
+                sh[g].bound_f = __double2float_ru(__longlong_as_double((long long)e));
+            }
         }
     }
     __syncthreads();
@@ -1197,30 +1221,37 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
         float d[U][G];
 #pragma unroll
         for (int u = 0; u < U; ++u) adc32g<M, G>(cur[u], tab, rc, d[u]);
-        // Fast path: all pass masks of this iteration first (pure VALU + ballots), ONE branch if none is set.
+        // Fast path: one compare + ballot per (candidate row, query), ONE branch if no mask is set.  Lanes past
+        // the end of the chunk (last iteration only) get NaN distances, which never compare <=; the duplicate
+        // exclusion is applied in the slow path only.
+        if (base + 64 * U > len) {
+            const float QNAN = __int_as_float(0x7fc00000);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int g = 0; g < G; ++g) d[u][g] = (base + u * 64 + lane < len) ? d[u][g] : QNAN;
+        }
         unsigned long long pm[U][G];
         unsigned long long any = 0ull;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float thrm = block_bound_f32(&sh[g]) * margin;
+            float thrm = (g < ng) ? block_bound_f32(&sh[g]) * margin : -1.0f;
 #ifdef CIS_PROBE_HOTLOOP
             thrm = (margin > 100.f) ? thrm : -1.0f;  // probe: nothing passes, only the float32 scan runs
 #endif
+            const unsigned long long dup_on = has_dup[g] ? ~0ull : 0ull;  // wave-uniform
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int p = base + u * 64 + lane;
-                bool pass = (p < len) && (d[u][g] <= thrm) && (g < ng);
-                if (has_dup[g]) {
-                    bool same = true;
+                bool same = true;
 #pragma unroll
-                    for (int i = 0; i < (M + 3) / 4; ++i) same = same && (cur[u].w[i] == dup[g].w[i]);
-                    pass = pass && !same;
-                }
-                pm[u][g] = __ballot(pass);
+                for (int i = 0; i < (M + 3) / 4; ++i) same = same && (cur[u].w[i] == dup[g].w[i]);
+                pm[u][g] = __ballot(d[u][g] <= thrm) & ~(__ballot(same) & dup_on);
                 any |= pm[u][g];
             }
         }
         if (any == 0ull) continue;  // the usual case: nothing in these 64*U candidates beats a bound
+        const long long clk_s0 = CIS_CLK();
+        CIS_CTR(3, 1);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (g >= ng) break;
@@ -1235,9 +1266,12 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
                 int n = __popcll(m);
                 if (cnt[g] + n > R) {  // cannot happen right after a compaction: cnt <= L <= R - 64
                     uint32_t dp = 0xffffffffu;
+                    const long long clk_c0 = CIS_CLK();
                     cnt[g] = wave_compact<M, NR, NW>(rk, rp, cnt[g], nexact[g], L, Lw, &sh[g], w, codes, start, K, t0[g], t1[g], dp);
+                    clk_comp += CIS_CLK() - clk_c0;
+                    dp = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp);
                     if (dp != 0xffffffffu) {
-                        dup[g] = load_code<M>(codes, start + (int64_t)__builtin_amdgcn_readfirstlane((int)dp));
+                        dup[g] = load_code<M>(codes, start + (int64_t)dp);
                         has_dup[g] = true;
                     }
                     nexact[g] = cnt[g];
@@ -1256,7 +1290,10 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
                 CIS_CTR(4, n);
             }
         }
+        clk_slow += CIS_CLK() - clk_s0;
     }
+    const long long clk_loop_end = CIS_CLK();
+    (void)clk_loop_end;
     // publish every wave's final bounds, then filter once more with everybody's final bounds
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -1274,6 +1311,12 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
         uint32_t* rp = rp_all + (g * NW + w) * R;
         cnt[g] = wave_filter<NR, NW>(rk, rp, cnt[g], &sh[g]);
         if (lane == 0) sh[g].wcnt[w] = cnt[g];
+#ifndef CIS_SCAN_NO_QBOUND
+        if (tid == 0) {
+            const uint64_t b = block_bound_u64<NW>(&sh[g]);
+            if (b < sh[g].ext) atomicMin(&qbound[it[g].q], (unsigned long long)b);
+        }
+#endif
     }
     __syncthreads();
 #pragma unroll
@@ -1302,6 +1345,12 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
         }
         if (tid == 0) item_n[item_idx[g]] = total;
     }
+#ifdef CIS_SCAN_COUNTERS
+    CIS_CTR(5, clk_comp);
+    CIS_CTR(6, clk_slow - clk_comp);
+    CIS_CTR(7, CIS_CLK() - clk_begin);
+    CIS_CTR(2, clk_loop_end - clk_begin);
+#endif
 }
 
 // Persistent launch: (blocks per CU) x 256 workgroups pull SLOTS from eight queues, one per XCD.  A
@@ -1316,7 +1365,8 @@ __global__ __launch_bounds__(NW * 64) void k_adc_scan2(const WorkItem* __restric
                                                        const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids,
                                                        int K, int L, int S, float margin,
                                                        int* __restrict__ queue_ctr /* [8], zeroed */,
-                                                       cis_hit* __restrict__ item_hits, int* __restrict__ item_n) {
+                                                       cis_hit* __restrict__ item_hits, int* __restrict__ item_n,
+                                                       unsigned long long* __restrict__ qbound /* [nq], +inf */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int R = NR * 64 - 8;
     int* s_next = reinterpret_cast<int*>(smem + (size_t)K * M * G * 4 + (size_t)G * NW * R * 12 + G * sizeof(ScanShared));
@@ -1348,14 +1398,14 @@ __global__ __launch_bounds__(NW * 64) void k_adc_scan2(const WorkItem* __restric
                 if (ng == 2 && (it[0].start != it[1].start || it[0].len != it[1].len)) {
                     WorkItem one[G] = {it[0], it[0]};
                     int oi[G] = {idx[0], idx[0]};
-                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, codes, ids, K, L, S, margin, item_hits, item_n, smem);
+                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, codes, ids, K, L, S, margin, item_hits, item_n, qbound, smem);
                     __syncthreads();
                     one[0] = it[1]; one[1] = it[1]; oi[0] = idx[1]; oi[1] = idx[1];
-                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, codes, ids, K, L, S, margin, item_hits, item_n, smem);
+                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, codes, ids, K, L, S, margin, item_hits, item_n, qbound, smem);
                     continue;
                 }
             }
-            scan2_group<M, NR, U, G, NW>(it, idx, ng, T, codes, ids, K, L, S, margin, item_hits, item_n, smem);
+            scan2_group<M, NR, U, G, NW>(it, idx, ng, T, codes, ids, K, L, S, margin, item_hits, item_n, qbound, smem);
         }
     }
 }
@@ -1922,7 +1972,7 @@ static Scan2Geom scan2_geom(int M, int K, int L, int nq) {
 template <int M, int NR, int G, int NW, int U>
 static void launch_scan2_t(int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots, const int* n_slots,
                            const double* T, const uint8_t* codes, const int64_t* ids, int K, int L, int S, size_t lds,
-                           int* qctr, cis_hit* hits, int* hitn) {
+                           int* qctr, cis_hit* hits, int* hitn, unsigned long long* qbound) {
     const float eps = 2.0f * (float)M * 5.9604645e-8f;  // 2 * M * 2^-24
     const float margin = 1.0f + 3.0f * eps;
     const int per_cu = (int)(163840 / lds) < (32 / NW) ? (int)(163840 / lds) : (32 / NW);
@@ -1930,16 +1980,16 @@ static void launch_scan2_t(int64_t n_items, hipStream_t st, const WorkItem* item
     const int64_t want = (n_items + G - 1) / G + 8;
     const unsigned grid = (unsigned)(want < resident ? ((want + 7) / 8) * 8 : resident);
     hipLaunchKernelGGL((k_adc_scan2<M, NR, U, G, NW>), dim3(grid), dim3(NW * 64), lds, st, items, slots, n_slots, T, codes, ids,
-                       K, L, S, margin, qctr, hits, hitn);
+                       K, L, S, margin, qctr, hits, hitn, qbound);
 }
 
 template <int M, int NR>
 static void launch_scan2_mr(const Scan2Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
                             const int* n_slots, const double* T, const uint8_t* codes, const int64_t* ids, int K, int L,
-                            int* qctr, cis_hit* hits, int* hitn) {
+                            int* qctr, cis_hit* hits, int* hitn, unsigned long long* qbound) {
 #define CIS_SCAN2_CASE(GG, WW, UU)                                                                                    \
     if (g.G == GG && g.NW == WW && g.U == UU) {                                                                       \
-        launch_scan2_t<M, NR, GG, WW, UU>(n_items, st, items, slots, n_slots, T, codes, ids, K, L, g.S, g.lds, qctr, hits, hitn); \
+        launch_scan2_t<M, NR, GG, WW, UU>(n_items, st, items, slots, n_slots, T, codes, ids, K, L, g.S, g.lds, qctr, hits, hitn, qbound); \
         return;                                                                                                       \
     }
     CIS_SCAN2_CASE(1, 4, 4)
@@ -1953,17 +2003,17 @@ static void launch_scan2_mr(const Scan2Geom& g, int64_t n_items, hipStream_t st,
 template <int M>
 static void launch_scan2_m(const Scan2Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
                            const int* n_slots, const double* T, const uint8_t* codes, const int64_t* ids, int K, int L,
-                           int* qctr, cis_hit* hits, int* hitn) {
-    if (L <= 184) launch_scan2_mr<M, 4>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
-    else launch_scan2_mr<M, 8>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
+                           int* qctr, cis_hit* hits, int* hitn, unsigned long long* qbound) {
+    if (L <= 184) launch_scan2_mr<M, 4>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn, qbound);
+    else launch_scan2_mr<M, 8>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn, qbound);
 }
 
 static void launch_scan2(int M, const Scan2Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
                          const int* n_slots, const double* T, const uint8_t* codes, const int64_t* ids, int K, int L,
-                         int* qctr, cis_hit* hits, int* hitn) {
-    if (M == 4) launch_scan2_m<4>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
-    else if (M == 8) launch_scan2_m<8>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
-    else launch_scan2_m<16>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
+                         int* qctr, cis_hit* hits, int* hitn, unsigned long long* qbound) {
+    if (M == 4) launch_scan2_m<4>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn, qbound);
+    else if (M == 8) launch_scan2_m<8>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn, qbound);
+    else launch_scan2_m<16>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn, qbound);
 }
 
 static const int MAX_LIMIT = 3072;
@@ -2023,10 +2073,11 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     CIS_TRY(ix->w_sorted.reserve((size_t)2 * nq * V * csz));
     CIS_TRY(ix->w_order.reserve((size_t)2 * nq * V * sizeof(uint16_t)));
     CIS_TRY(ix->w_plan.reserve((size_t)nq * sizeof(PlanOut)));
-    CIS_TRY(ix->w_off.reserve((size_t)(2 * (nq + 1) + 4) * sizeof(int64_t)));
+    CIS_TRY(ix->w_off.reserve((size_t)(2 * (nq + 1) + 4 + nq) * sizeof(int64_t)));
     int64_t* item_off = ix->w_off.as<int64_t>();
     int64_t* tab_off = item_off + (nq + 1);
     int64_t* totals = tab_off + (nq + 1);
+    unsigned long long* qbound = reinterpret_cast<unsigned long long*>(totals + 4);  // per query: cross-cell bound of the scan
     PlanOut* plan = ix->w_plan.as<PlanOut>();
     const int seg_max = nq >= 1024 ? (1 << 20) : (nq >= 64 ? 16384 : 4096);
     for (int s = 0; s < 2; ++s)
@@ -2045,7 +2096,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
                            seg_max, plan, nullptr, nullptr, nullptr, nullptr);
     }
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(256), 0, st, plan, nq, item_off, tab_off, totals);
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(256), 0, st, plan, nq, item_off, tab_off, totals, qbound);
     int64_t h_tot[3];
     CIS_CHECK_HIP(hipMemcpyAsync(h_tot, totals, sizeof(h_tot), hipMemcpyDeviceToHost, st));
     CIS_CHECK_HIP(hipStreamSynchronize(st));
@@ -2137,7 +2188,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                 hipLaunchKernelGGL(k_identity_slots, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, n_items, G, slots,
                                    n_slots);
             }
-            launch_scan2(M, geom, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn);
+            launch_scan2(M, geom, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn, qbound);
         }
         else launch_scan_exact(M, n_items, st, items, T, codes, ids, K, L, S, nullptr, hits, hitn);
         ix->stats[3] += 1;

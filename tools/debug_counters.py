@@ -24,8 +24,10 @@ fn(buf, 1)
 s.search_batch_dev(q, quota=10000, limit=100); torch.cuda.synchronize()
 fn(buf, 1)
 st = s.last_stats()
-names = ["compactions", "rescored", "exact_cut", "second_sorts", "appended"]
-print({n: int(buf[i]) for i, n in enumerate(names)}, st)
+names = ["compactions", "rescored", "clk_loop", "slow_iters", "appended", "clk_compact", "clk_slow", "clk_total"]
+d = {n: int(buf[i]) for i, n in enumerate(names)}
+print(d, st)
 items = st["items"]
-print("per item: compactions %.1f rescored %.0f appended %.0f second sorts %.2f exact cuts %.1f" % (
-    buf[0] / items, buf[1] / items, buf[4] / items, buf[3] / items, buf[2] / items))
+print("per item: compactions %.1f appended %.0f slow iterations %.1f" % (d["compactions"] / items, d["appended"] / items, d["slow_iters"] / items))
+print("wave time shares: compaction in loop %.3f  slow path (excl. compaction) %.3f  loop %.3f  prologue+epilogue %.3f" % (
+    d["clk_compact"] / d["clk_total"], d["clk_slow"] / d["clk_total"], d["clk_loop"] / d["clk_total"], 1 - d["clk_loop"] / d["clk_total"]))
