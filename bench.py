@@ -10,7 +10,8 @@ already resident in HBM: PCA -> coarse ranking -> multisequence plan -> ADC tabl
 top-k -> merge (-> RCCL all-gather + merge when the index is sharded by coarse cell over N GPUs).
 Workload = BASELINE config C4 (10M x 128-d, LOPQModelPCA V=16, M=8, renorm) with the reference
 API's operating point quota=10000, limit=100 (cufacesearch/searcher/searcher_lopqhbase.py:833-838).
-The LOPQ model is the one the reference itself fitted on this generator (tests/golden/c2.npz).
+The data are descriptor-like (anisotropic mixture with a decaying spectrum, codes almost all distinct);
+the LOPQ model is the one the reference itself fitted on this generator (tests/golden/c4.npz).
 
 N > 1 is strong scaling: the same 10M index is sharded by coarse cell, every rank sees the whole
 query batch, scans its own cells and the per-shard top-`limit` lists are all-gathered over RCCL.
@@ -41,7 +42,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.
 
 def load_model():
     from columbiaimagesearch_amd.lopq import LOPQModelPCA
-    z = np.load(os.path.join(REPO, "tests", "golden", "c2.npz"))
+    z = np.load(os.path.join(REPO, "tests", "golden", "c4.npz"))
     nf = int(z["num_fine_splits"])
     subs = tuple([z["subs"][s, j] for j in range(nf)] for s in range(2))
     params = ((z["Cs"][0], z["Cs"][1]), (z["Rs"][0], z["Rs"][1]), (z["mus"][0], z["mus"][1]), subs,
@@ -49,17 +50,23 @@ def load_model():
     return LOPQModelPCA(renorm=bool(z["renorm"]), parameters=params), z
 
 
-def mixture_centers():
-    # same mixture as tests/golden_inputs.c2_inputs (the data the model was trained on)
-    return np.random.RandomState(2).randn(256, 128)
+def mixture_centers(device="cpu"):
+    """Parameters of the descriptor-like generator (tests/golden_inputs.descriptor_params: the distribution the
+    reference fitted tests/golden/c4.npz on), as tensors on `device`."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import golden_inputs as gi
+    basis, scale, centers, mean = gi.descriptor_params(128)
+    return {"noise_map": torch.as_tensor(scale[:, None] * basis.T, device=device),  # z -> (z * scale) . basis^T
+            "centers": torch.as_tensor(centers, device=device), "mean": torch.as_tensor(mean, device=device)}
 
 
-def gen_chunk(centers_dev, chunk, n, device):
+def gen_chunk(P, chunk, n, device):
     """n unit-norm float64 128-d vectors of chunk `chunk` (identical on every rank)."""
     g = torch.Generator(device=device)
     g.manual_seed(1000 + chunk)
-    comp = torch.randint(0, centers_dev.shape[0], (n,), generator=g, device=device)
-    x = centers_dev[comp] + 0.35 * torch.randn((n, centers_dev.shape[1]), generator=g, device=device, dtype=torch.float64)
+    comp = torch.randint(0, P["centers"].shape[0], (n,), generator=g, device=device)
+    z = torch.randn((n, P["centers"].shape[1]), generator=g, device=device, dtype=torch.float64)
+    x = P["mean"] + 0.7 * P["centers"][comp] + 0.7 * (z @ P["noise_map"])
     return x / x.norm(dim=1, keepdim=True)
 
 
@@ -123,7 +130,7 @@ def main():
     model, z = load_model()
     N = args.n - args.n % (N_CHUNKS * world)
     chunk_n = N // N_CHUNKS
-    centers = torch.as_tensor(mixture_centers(), device=device)
+    centers = mixture_centers(device)
 
     # ---- build: data-parallel encode on the GPUs, codes all-gathered, index sharded by cell -----
     t_build = time.time()

@@ -392,7 +392,8 @@ template <int W>
 __global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict__ px /* [ntab][h] */,
                                                         const TabDesc* __restrict__ tabs, int n_tabs,
                                                         const double* __restrict__ subs, int h, int nf, int K,
-                                                        double* __restrict__ T /* [ntab][nf][K] */) {
+                                                        double* __restrict__ T /* [ntab][nf][K] */,
+                                                        float* __restrict__ T32 /* [ntab][K][nf]: the scan's LDS order */) {
     __shared__ double sf[64][W];
     __shared__ int ssplit[64];
     const int j = blockIdx.y, z = blockIdx.z, k = threadIdx.x;
@@ -413,8 +414,19 @@ __global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict
         if (ssplit[t] != z) continue;
         const double* f = sf[t];
         auto elem = [&](int i) -> double { const double df = f[i] - sc[i]; return df * df; };
-        T[((int64_t)(t0 + t) * nf + j) * K + k] = pw_leaf<double>(elem, 0, W);
+        const double v = pw_leaf<double>(elem, 0, W);
+        T[((int64_t)(t0 + t) * nf + j) * K + k] = v;
+        T32[((int64_t)(t0 + t) * K + k) * nf + j] = (float)v;
     }
+}
+
+// float32 copy of the tables in the scan's order, for the configurations that do not go through k_tables_from_px
+__global__ void k_tables_f32(const double* __restrict__ T, int64_t n, int nf, int K, float* __restrict__ T32) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // index into T: (tab, j, k)
+    if (e >= n) return;
+    const int64_t tab = e / ((int64_t)nf * K);
+    const int r = (int)(e - tab * nf * K), j = r / K, k = r - j * K;
+    T32[(tab * K + k) * nf + j] = (float)T[e];
 }
 
 // ================================================================================================
@@ -724,7 +736,7 @@ __device__ __forceinline__ uint32_t wave_kth(const uint32_t (&k)[NR], int i) {  
 }
 
 #ifdef CIS_SCAN_COUNTERS
-__device__ unsigned long long g_scan_ctr[8];  // compactions, rescored entries, exact-cut, second sorts, appended
+__device__ unsigned long long g_scan_ctr[16];  // compactions, rescored entries, exact-cut, second sorts, appended
 #define CIS_CTR(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_scan_ctr[i], (unsigned long long)(v)); } while (0)
 #define CIS_CLK() ((long long)__builtin_amdgcn_s_memtime())
 #else
@@ -805,40 +817,42 @@ static __device__ __forceinline__ uint64_t hi_to_bound(uint32_t vhi) {
     return vhi >= 0x7ff00000u ? 0x7ff0000000000000ull : (((uint64_t)vhi << 32) | 0xffffffffull);
 }
 
-// Exact re-score of the new entries [nexact, cnt), own top-L cut on exact (dist, pos) keys, publication
-// of this wave's bounds, filtering against the block bound.  Returns the new entry count (<= L).
-// Region entries are always in increasing candidate position (appends are, and the compaction is
-// stable), so among exactly equal distances "first in the region" == "smallest pos".
-// Wave-synchronous: no s_barrier inside.
-template <int M, int NR, int NW>
-__device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt, int nexact, int L, int Lw,
-                                            ScanShared* sh, int w, const uint8_t* __restrict__ codes, int64_t start,
-                                            int K, const double* __restrict__ t0, const double* __restrict__ t1,
-                                            uint32_t& dup_pos) {
-    const int lane = threadIdx.x & 63;
-    const uint64_t INF64 = 0x7ff0000000000000ull;
-    CIS_CTR(0, 1);
-    CIS_CTR(1, cnt - nexact);
-    // new entries: M <= 8 stashed the code itself in the key slot at append time; M = 16 re-reads it
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int e = nexact + lane + 64 * i;
-        if (e < cnt) {
-            uint32_t cw[(M + 3) / 4];
-            if constexpr (M <= 8) {
-                const uint64_t c = rk[e];
-                cw[0] = (uint32_t)c;
-                if constexpr (M == 8) cw[1] = (uint32_t)(c >> 32);
-            } else {
-                const uint4 c = *reinterpret_cast<const uint4*>(codes + (start + rp[e]) * 16);
-                cw[0] = c.x; cw[1] = c.y; cw[2] = c.z; cw[3] = c.w;
-            }
-            rk[e] = (uint64_t)__double_as_longlong(adc64_words<M>(cw, K, t0, t1));
-        }
+// one candidate's code as 32-bit words (little-endian bytes = fine codes 0..M-1)
+template <int M>
+struct CodeWords { uint32_t w[(M + 3) / 4]; };
+
+template <int M>
+__device__ __forceinline__ CodeWords<M> load_code(const uint8_t* __restrict__ codes, int64_t p) {
+    CodeWords<M> c;
+    if constexpr (M == 4) {
+        c.w[0] = *reinterpret_cast<const uint32_t*>(codes + p * 4);
+    } else if constexpr (M == 8) {
+        const uint2 v = *reinterpret_cast<const uint2*>(codes + p * 8);
+        c.w[0] = v.x; c.w[1] = v.y;
+    } else {
+        const uint4 v = *reinterpret_cast<const uint4*>(codes + p * 16);
+        c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    uint32_t hi[NR], lo[NR], pp[NR];
+    return c;
+}
+
+// Region entries during the scan are (float32 distance << 32 | candidate position): ordered by (d32, pos) as
+// plain integers, appended with one ds_write_b64.  Two compactions work on them:
+//  * wave_compact_approx (in the loop): float32 only, nothing leaves the CU.  It finds a distance v that at least L
+//    entries do not exceed (ballot bisection that stops as soon as the count is within [L, L+W]), keeps everything
+//    up to v*(1+3eps) -- an entry above that is strictly worse, in exact arithmetic, than the L entries below v --
+//    and publishes the bounds v*(1+2eps) >= the exact distances of those L (resp. ceil(L/NW)) entries.
+//  * wave_compact_exact (fallback when ties make the float32 cut keep too much, and once at the end): fetches the
+//    codes again, re-scores every entry in float64 (table entries summed left to right as search.py:173), cuts to
+//    the exact top-L by (dist, pos) and resolves exact ties by region order.
+// Region entries are always in increasing candidate position (appends are, and the compactions are stable), so
+// among exactly equal distances "first in the region" == "smallest pos".  Wave-synchronous: no s_barrier inside.
+template <int NR, int NW>
+__device__ __forceinline__ int wave_compact_approx(uint64_t* rk, int cnt, int L, int Lw, int cap, float margin, double infl,
+                                                   ScanShared* sh, int w) {
+    const int lane = threadIdx.x & 63;
+    CIS_CTR(0, 1);
+    uint32_t hi[NR], pp[NR];
     bool keep[NR];
     uint32_t mn = 0xffffffffu, mx = 0u;
 #pragma unroll
@@ -847,10 +861,125 @@ __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt,
         keep[r] = e < cnt;
         const uint64_t k = keep[r] ? rk[e] : ~0ull;
         hi[r] = (uint32_t)(k >> 32);
-        lo[r] = (uint32_t)k;
-        pp[r] = keep[r] ? rp[e] : 0xffffffffu;
+        pp[r] = (uint32_t)k;
         mn = (keep[r] && hi[r] < mn) ? hi[r] : mn;
         mx = (keep[r] && hi[r] > mx) ? hi[r] : mx;
+    }
+    wave_minmax_step<1>(mn, mx); wave_minmax_step<2>(mn, mx); wave_minmax_step<4>(mn, mx);
+    wave_minmax_step<8>(mn, mx); wave_minmax_step<16>(mn, mx); wave_minmax_step<32>(mn, mx);
+    mn = (uint32_t)__builtin_amdgcn_readfirstlane((int)mn);
+    mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
+    const uint64_t INF64 = 0x7ff0000000000000ull;
+    // (1) v2 with #{d32 <= v2} in [Lw, Lw + W2] -> this wave's share of the block bound
+    const int W2 = Lw >= 16 ? (Lw >> 3) : 1;
+    uint32_t lo2 = mn, v2 = mx;
+    while (cnt >= Lw && lo2 < v2) {  // wave-uniform
+        const uint32_t p = lo2 + ((v2 - lo2) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) c += __popcll(__ballot(keep[r] && hi[r] <= p));
+        if (c >= Lw) {
+            v2 = p;
+            if (c <= Lw + W2) break;
+        } else {
+            lo2 = p + 1;
+        }
+    }
+    const uint64_t boundW = cnt >= Lw ? (uint64_t)__double_as_longlong((double)__uint_as_float(v2) * infl) : INF64;
+    if (lane == 0) {
+        if (boundW < lds_ld(&sh->wt[w])) lds_st(&sh->wt[w], boundW);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint64_t bound = block_bound_u64<NW>(sh);
+    float bf = __double2float_ru(__longlong_as_double((long long)bound));
+    uint32_t cut = __float_as_uint(bf * margin);  // the hot loop's test
+    int c_thr = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) c_thr += __popcll(__ballot(keep[r] && hi[r] <= cut));
+    int W = cap - L;
+    W = W > 24 ? 24 : (W < 0 ? 0 : W);
+    if (c_thr > L + W) {
+        // (2) the block bound does not thin this wave out (the other waves lag, the good candidates sit in this
+        // wave's stripes, or many distances are equal): cut to the wave's own top L.
+        // v with #{d32 <= v} in [L, L+W], or the exact L-th smallest when ties prevent that
+        uint32_t lo_ = mn, v = mx;
+        while (lo_ < v) {
+            const uint32_t p = lo_ + ((v - lo_) >> 1);
+            int c = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) c += __popcll(__ballot(keep[r] && hi[r] <= p));
+            if (c >= L) {
+                v = p;
+                if (c <= L + W) break;
+            } else {
+                lo_ = p + 1;
+            }
+        }
+        const uint32_t vm = __float_as_uint(__double2float_ru((double)__uint_as_float(v) * (double)margin));
+        int c_keep = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) c_keep += __popcll(__ballot(keep[r] && hi[r] <= vm));
+        if (c_keep > cap) return -1;  // a crowd of (nearly) equal distances, e.g. duplicate codes: resolve exactly
+        const uint64_t boundL = (uint64_t)__double_as_longlong((double)__uint_as_float(v) * infl);
+        if (lane == 0) {
+            if (boundL < lds_ld(&sh->wl[w])) lds_st(&sh->wl[w], boundL);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        bound = block_bound_u64<NW>(sh);
+        bf = __double2float_ru(__longlong_as_double((long long)bound));
+        const uint32_t thr = __float_as_uint(bf * margin);
+        cut = vm < thr ? vm : thr;
+    }
+    if (lane == 0) {
+        if (bf < lds_ld(&sh->bound_f)) lds_st(&sh->bound_f, bf);
+    }
+    int ncnt = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const bool kp = keep[r] && hi[r] <= cut;
+        const unsigned long long m = __ballot(kp);
+        const int idx = ncnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (kp) rk[idx] = ((uint64_t)hi[r] << 32) | pp[r];
+        ncnt += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return ncnt;
+}
+
+// FINAL: leaves exact float64 keys in rk and positions in rp (the output format); otherwise the survivors go back
+// to the (float32 rounded up, position) form.  Returns the new entry count (<= L).
+template <int M, int NR, int NW, bool FINAL>
+__device__ __forceinline__ int wave_compact_exact(uint64_t* rk, uint32_t* rp, int cnt, int L, int Lw,
+                                                  ScanShared* sh, int w, const uint8_t* __restrict__ codes, int64_t start,
+                                                  int K, const double* __restrict__ t0, const double* __restrict__ t1,
+                                                  uint32_t& dup_pos) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t INF64 = 0x7ff0000000000000ull;
+    CIS_CTR(1, 1);
+    uint32_t hi[NR], lo[NR], pp[NR];
+    bool keep[NR];
+    uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int e = r * 64 + lane;
+        keep[r] = e < cnt;
+        pp[r] = keep[r] ? (uint32_t)rk[e] : 0xffffffffu;
+        hi[r] = 0xffffffffu;
+        lo[r] = 0xffffffffu;
+    }
+    {
+        // idle lanes of a row fetch candidate 0; rows past the end are skipped (wave-uniform)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r * 64 >= cnt) break;
+            const CodeWords<M> cw = load_code<M>(codes, start + (keep[r] ? pp[r] : 0u));
+            const uint64_t k = keep[r] ? (uint64_t)__double_as_longlong(adc64_words<M>(cw.w, K, t0, t1)) : ~0ull;
+            hi[r] = (uint32_t)(k >> 32);
+            lo[r] = (uint32_t)k;
+            mn = (keep[r] && hi[r] < mn) ? hi[r] : mn;
+            mx = (keep[r] && hi[r] > mx) ? hi[r] : mx;
+        }
     }
     wave_minmax_step<1>(mn, mx); wave_minmax_step<2>(mn, mx); wave_minmax_step<4>(mn, mx);
     wave_minmax_step<8>(mn, mx); wave_minmax_step<16>(mn, mx); wave_minmax_step<32>(mn, mx);
@@ -930,7 +1059,40 @@ __device__ __forceinline__ int wave_compact(uint64_t* rk, uint32_t* rp, int cnt,
         const bool kp = keep[r] && (k <= bound);
         const unsigned long long m = __ballot(kp);
         const int idx = ncnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-        if (kp) { rk[idx] = k; rp[idx] = pp[r]; }
+        if (kp) {
+            if constexpr (FINAL) {
+                rk[idx] = k;
+                rp[idx] = pp[r];
+            } else {
+                rk[idx] = ((uint64_t)__float_as_uint(__double2float_ru(__longlong_as_double((long long)k))) << 32) | pp[r];
+            }
+        }
+        ncnt += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return ncnt;
+}
+
+// Drop (float32 distance, position) entries above the block bound, with the hot loop's test.  Stable.
+template <int NR, int NW>
+__device__ __forceinline__ int wave_filter_approx(uint64_t* rk, int cnt, float margin, const ScanShared* sh) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t bound = block_bound_u64<NW>(sh);
+    const uint32_t thr = __float_as_uint(__double2float_ru(__longlong_as_double((long long)bound)) * margin);
+    uint64_t k[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int e = r * 64 + lane;
+        k[r] = e < cnt ? rk[e] : ~0ull;
+    }
+    int ncnt = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const bool kp = (r * 64 + lane < cnt) && ((uint32_t)(k[r] >> 32) <= thr);
+        const unsigned long long m = __ballot(kp);
+        const int idx = ncnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (kp) rk[idx] = k[r];
         ncnt += __popcll(m);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -990,25 +1152,6 @@ __device__ __forceinline__ RotConsts<M> make_rot(int lane) {
 #endif
     }
     return rc;
-}
-
-// one candidate's code as 32-bit words (little-endian bytes = fine codes 0..M-1)
-template <int M>
-struct CodeWords { uint32_t w[(M + 3) / 4]; };
-
-template <int M>
-__device__ __forceinline__ CodeWords<M> load_code(const uint8_t* __restrict__ codes, int64_t p) {
-    CodeWords<M> c;
-    if constexpr (M == 4) {
-        c.w[0] = *reinterpret_cast<const uint32_t*>(codes + p * 4);
-    } else if constexpr (M == 8) {
-        const uint2 v = *reinterpret_cast<const uint2*>(codes + p * 8);
-        c.w[0] = v.x; c.w[1] = v.y;
-    } else {
-        const uint4 v = *reinterpret_cast<const uint4*>(codes + p * 16);
-        c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
-    }
-    return c;
 }
 
 // the same through a buffer descriptor that covers exactly the chunk being scanned: one 32-bit offset per
@@ -1123,7 +1266,8 @@ __device__ __forceinline__ void adc32g(const CodeWords<M>& c, const char* __rest
 // One workgroup (NW waves) scans one cell chunk for `ng` <= G queries that all visit it.
 template <int M, int NR, int U, int G, int NW>
 __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (&item_idx)[G], int ng,
-                                            const double* __restrict__ T, const uint8_t* __restrict__ codes,
+                                            const double* __restrict__ T, const float* __restrict__ T32,
+                                            const uint8_t* __restrict__ codes,
                                             const int64_t* __restrict__ ids, int K, int L, int S, float margin,
                                             cis_hit* __restrict__ item_hits, int* __restrict__ item_n,
                                             unsigned long long* __restrict__ qbound, char* smem) {
@@ -1131,15 +1275,17 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
     // G=2 / 4-wave layout (16 KB tables + 8 regions) stays under 40 KB and four workgroups share a CU
     constexpr int R = NR * 64 - 8;
     char* tab = smem;                                                              // [K][M][G] float32
-    uint64_t* rk_all = reinterpret_cast<uint64_t*>(smem + (size_t)K * M * G * 4);  // [G][NW][R] exact keys / stashed codes
-    uint32_t* rp_all = reinterpret_cast<uint32_t*>(rk_all + G * NW * R);           // [G][NW][R] positions
+    uint64_t* rk_all = reinterpret_cast<uint64_t*>(smem + (size_t)K * M * G * 4);  // [G][NW][R] (d32, pos) entries; exact keys at the end
+    uint32_t* rp_all = reinterpret_cast<uint32_t*>(rk_all + G * NW * R);           // [G][NW][R] positions (output stage)
     ScanShared* sh = reinterpret_cast<ScanShared*>(rp_all + G * NW * R);           // [G]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int nf = M / 2;
     const long long clk_begin = CIS_CLK();
-    long long clk_slow = 0, clk_comp = 0;
-    (void)clk_begin; (void)clk_slow; (void)clk_comp;
+    long long clk_slow = 0, clk_comp = 0, clk_exact = 0, clk_final = 0;
+    (void)clk_exact; (void)clk_final;
+    int n_slow = 0, n_app = 0;
+    (void)clk_begin; (void)clk_slow; (void)clk_comp; (void)n_slow; (void)n_app;
     const double* t0[G];
     const double* t1[G];
 #pragma unroll
@@ -1149,14 +1295,35 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
     }
     const float INF = __int_as_float(0x7f800000);
     {
+        // LDS tables from the float32 copies ([K][nf] per (query, half)): 16-byte loads, all in flight together,
+        // then one ds_write per entry that carries both queries' values (G = 2).
         float* tf = reinterpret_cast<float*>(tab);
-        for (int e = tid; e < nf * K; e += NW * 64) {
-            const int j = e / K, k = e - j * K;
+        const int nvec = (nf * K) >> 2;  // float4 per half table (K is a multiple of 4 / nf for the supported shapes)
+        for (int e0 = 0; e0 < nvec; e0 += NW * 64) {
+            const int e = e0 + tid;
+            float4 v[G][2];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const bool on = g < ng;  // an absent second query gets +inf tables: nothing ever passes
-                tf[(k * M + j) * G + g] = on ? (float)t0[g][e] : INF;
-                tf[(k * M + nf + j) * G + g] = on ? (float)t1[g][e] : INF;
+                const bool on = (g < ng) && (e < nvec);  // an absent second query gets +inf tables: nothing ever passes
+                const int eg = e < nvec ? e : 0;
+                v[g][0] = reinterpret_cast<const float4*>(T32 + (int64_t)it[g].tab0 * nf * K)[eg];
+                v[g][1] = reinterpret_cast<const float4*>(T32 + (int64_t)it[g].tab1 * nf * K)[eg];
+                if (!on) { v[g][0] = make_float4(INF, INF, INF, INF); v[g][1] = v[g][0]; }
+            }
+            if (e < nvec) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int f = 4 * e + c, k = f / nf, j = f - k * nf;  // nf is a compile-time power of two
+                        float* dst = tf + (k * M + s2 * nf + j) * G;
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            const float4 q = v[g][s2];
+                            dst[g] = c == 0 ? q.x : (c == 1 ? q.y : (c == 2 ? q.z : q.w));
+                        }
+                    }
+                }
             }
         }
         if (tid < 8 * G) {
@@ -1180,16 +1347,20 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
         }
     }
     __syncthreads();
+    const long long clk_tab_end = CIS_CLK();
+    (void)clk_tab_end;
     const RotConsts<M> rc = make_rot<M>(lane);
     const int Lw = (L + NW - 1) / NW;
     const int len = it[0].len;
     const int64_t start = it[0].start;
     const int nit = (len + 64 * U - 1) / (64 * U);
-    int cnt[G], nexact[G];
+    int cnt[G];
+    constexpr double EPS32 = 2.0 * M * 5.9604644775390625e-8;  // float32 sum vs exact: |d32 - d64| <= EPS32 * d64
+    const double infl = 1.0 + 2.0 * EPS32;
     CodeWords<M> dup[G];  // per query: a code whose later copies cannot enter this wave's top-L any more
     bool has_dup[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) { cnt[g] = 0; nexact[g] = 0; has_dup[g] = false; dup[g] = CodeWords<M>(); }
+    for (int g = 0; g < G; ++g) { cnt[g] = 0; has_dup[g] = false; dup[g] = CodeWords<M>(); }
 #ifndef CIS_SCAN_PLAIN_LOADS
     // buffer descriptor over this chunk's codes, built from wave-uniform values only
     __amdgpu_buffer_rsrc_t rs;
@@ -1251,65 +1422,85 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
         }
         if (any == 0ull) continue;  // the usual case: nothing in these 64*U candidates beats a bound
         const long long clk_s0 = CIS_CLK();
-        CIS_CTR(3, 1);
+        ++n_slow;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (g >= ng) break;
             uint64_t* rk = rk_all + (g * NW + w) * R;
             uint32_t* rp = rp_all + (g * NW + w) * R;
+            // Append row after row while they fit; when one does not, compact (ONE call site per query, whatever U
+            // is), re-test the rows not yet appended against the new bound and go on.  After a compaction
+            // cnt <= R - 64, so the next row always fits and the loop ends after at most U compactions.
+            int u0 = 0;
+            while (true) {
+                bool full = false;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                unsigned long long m = pm[u][g];
-                if (m == 0ull) continue;
-                const int p = base + u * 64 + lane;
-                bool pass = (m >> lane) & 1ull;
-                int n = __popcll(m);
-                if (cnt[g] + n > R) {  // cannot happen right after a compaction: cnt <= L <= R - 64
+                for (int u = 0; u < U; ++u) {
+                    const unsigned long long m = pm[u][g];
+                    if (u < u0 || full || m == 0ull) continue;
+                    const int n = __popcll(m);
+                    if (cnt[g] + n > R) {
+                        full = true;
+                        u0 = u;
+                        continue;
+                    }
+                    const int idx = cnt[g] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    if ((m >> lane) & 1ull) rk[idx] = ((uint64_t)__float_as_uint(d[u][g]) << 32) | (uint32_t)(base + u * 64 + lane);
+                    cnt[g] += n;
+                    n_app += n;
+                    u0 = u + 1;
+                }
+                if (!full) break;
+                const long long clk_c0 = CIS_CLK();
+                int c2 = wave_compact_approx<NR, NW>(rk, cnt[g], L, Lw, R - 64, margin, infl, &sh[g], w);
+                if (c2 < 0) {
                     uint32_t dp = 0xffffffffu;
-                    const long long clk_c0 = CIS_CLK();
-                    cnt[g] = wave_compact<M, NR, NW>(rk, rp, cnt[g], nexact[g], L, Lw, &sh[g], w, codes, start, K, t0[g], t1[g], dp);
-                    clk_comp += CIS_CLK() - clk_c0;
+                    const long long clk_e0 = CIS_CLK();
+                    c2 = wave_compact_exact<M, NR, NW, false>(rk, rp, cnt[g], L, Lw, &sh[g], w, codes, start, K, t0[g], t1[g], dp);
+                    clk_exact += CIS_CLK() - clk_e0;
                     dp = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp);
                     if (dp != 0xffffffffu) {
                         dup[g] = load_code<M>(codes, start + (int64_t)dp);
                         has_dup[g] = true;
                     }
-                    nexact[g] = cnt[g];
-                    const float thrm = block_bound_f32(&sh[g]) * margin;
-                    pass = pass && (d[u][g] <= thrm);
-                    m = __ballot(pass);
-                    n = __popcll(m);
                 }
-                const int idx = cnt[g] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                if (pass) {
-                    rp[idx] = (uint32_t)p;
-                    if constexpr (M == 4) rk[idx] = cur[u].w[0];  // stash the code; re-scored exactly at the next compaction
-                    if constexpr (M == 8) rk[idx] = ((uint64_t)cur[u].w[1] << 32) | cur[u].w[0];
+                cnt[g] = c2;
+                clk_comp += CIS_CLK() - clk_c0;
+                const float thrm = block_bound_f32(&sh[g]) * margin;
+                const unsigned long long dup_on = has_dup[g] ? ~0ull : 0ull;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    bool same = true;
+#pragma unroll
+                    for (int i = 0; i < (M + 3) / 4; ++i) same = same && (cur[u].w[i] == dup[g].w[i]);
+                    pm[u][g] &= __ballot(d[u][g] <= thrm) & ~(__ballot(same) & dup_on);
                 }
-                cnt[g] += n;
-                CIS_CTR(4, n);
             }
         }
         clk_slow += CIS_CLK() - clk_s0;
     }
     const long long clk_loop_end = CIS_CLK();
     (void)clk_loop_end;
-    // publish every wave's final bounds, then filter once more with everybody's final bounds
+    // End of the chunk.  Every wave cuts its region in float32 and publishes its bounds; after the barrier the
+    // block bound is (about) the L-th smallest distance of the whole chunk, so only ~L/NW entries per wave survive
+    // it -- those are the only ones that are re-scored exactly (codes + float64 tables from L2, one row of loads).
+    // The per-query merge kernel ranks the union exactly, so no second exact filter is needed here.
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         if (g >= ng) break;
         uint64_t* rk = rk_all + (g * NW + w) * R;
-        uint32_t* rp = rp_all + (g * NW + w) * R;
-        uint32_t dp = 0xffffffffu;
-        cnt[g] = wave_compact<M, NR, NW>(rk, rp, cnt[g], nexact[g], L, Lw, &sh[g], w, codes, start, K, t0[g], t1[g], dp);
+        if (cnt[g] > 0) cnt[g] = wave_compact_approx<NR, NW>(rk, cnt[g], L, Lw, NR * 64, margin, infl, &sh[g], w);
     }
+    clk_final = CIS_CLK() - clk_loop_end;
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         if (g >= ng) break;
         uint64_t* rk = rk_all + (g * NW + w) * R;
         uint32_t* rp = rp_all + (g * NW + w) * R;
-        cnt[g] = wave_filter<NR, NW>(rk, rp, cnt[g], &sh[g]);
+        cnt[g] = wave_filter_approx<NR, NW>(rk, cnt[g], margin, &sh[g]);
+        uint32_t dp = 0xffffffffu;
+        cnt[g] = wave_compact_exact<M, NR, NW, true>(rk, rp, cnt[g], L, Lw, &sh[g], w, codes, start, K, t0[g], t1[g], dp);
         if (lane == 0) sh[g].wcnt[w] = cnt[g];
 #ifndef CIS_SCAN_NO_QBOUND
         if (tid == 0) {
@@ -1318,6 +1509,8 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
         }
 #endif
     }
+    const long long clk_exact_end = CIS_CLK();
+    (void)clk_exact_end;
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -1346,6 +1539,12 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
         if (tid == 0) item_n[item_idx[g]] = total;
     }
 #ifdef CIS_SCAN_COUNTERS
+    CIS_CTR(3, n_slow);
+    CIS_CTR(8, clk_exact);
+    CIS_CTR(10, clk_exact_end - clk_loop_end);
+    CIS_CTR(11, clk_tab_end - clk_begin);
+    CIS_CTR(9, clk_final);
+    CIS_CTR(4, n_app);
     CIS_CTR(5, clk_comp);
     CIS_CTR(6, clk_slow - clk_comp);
     CIS_CTR(7, CIS_CLK() - clk_begin);
@@ -1360,8 +1559,9 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
 // that XCD's private L2.  A workgroup whose own queue is empty steals from the others, which removes
 // the tail caused by unequal cell sizes.
 template <int M, int NR, int U, int G, int NW>
-__global__ __launch_bounds__(NW * 64) void k_adc_scan2(const WorkItem* __restrict__ items, const int* __restrict__ slots,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_adc_scan2(const WorkItem* __restrict__ items, const int* __restrict__ slots,
                                                        const int* __restrict__ n_slots_ptr, const double* __restrict__ T,
+                                                       const float* __restrict__ T32,
                                                        const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids,
                                                        int K, int L, int S, float margin,
                                                        int* __restrict__ queue_ctr /* [8], zeroed */,
@@ -1398,14 +1598,14 @@ __global__ __launch_bounds__(NW * 64) void k_adc_scan2(const WorkItem* __restric
                 if (ng == 2 && (it[0].start != it[1].start || it[0].len != it[1].len)) {
                     WorkItem one[G] = {it[0], it[0]};
                     int oi[G] = {idx[0], idx[0]};
-                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, codes, ids, K, L, S, margin, item_hits, item_n, qbound, smem);
+                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, T32, codes, ids, K, L, S, margin, item_hits, item_n, qbound, smem);
                     __syncthreads();
                     one[0] = it[1]; one[1] = it[1]; oi[0] = idx[1]; oi[1] = idx[1];
-                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, codes, ids, K, L, S, margin, item_hits, item_n, qbound, smem);
+                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, T32, codes, ids, K, L, S, margin, item_hits, item_n, qbound, smem);
                     continue;
                 }
             }
-            scan2_group<M, NR, U, G, NW>(it, idx, ng, T, codes, ids, K, L, S, margin, item_hits, item_n, qbound, smem);
+            scan2_group<M, NR, U, G, NW>(it, idx, ng, T, T32, codes, ids, K, L, S, margin, item_hits, item_n, qbound, smem);
         }
     }
 }
@@ -1559,7 +1759,7 @@ struct cis_index {
     int64_t n_local = 0;
     // per-batch workspace
     DevBuf w_xp, w_cd, w_order, w_sorted, w_plan, w_off, w_items, w_tabs, w_T, w_hits, w_hitn, w_part, w_q,
-        w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos, w_order2, w_px;
+        w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos, w_order2, w_px, w_T32;
     int64_t stats[4] = {0, 0, 0, 0};
     // optional stage timing (hipEvents on the launch stream)
     bool force_exact_scan = false;  // tests: run every item through the float64 kernel
@@ -1597,7 +1797,7 @@ extern "C" void cis_index_destroy(cis_index* ix) {
     DevBuf* bufs[] = {&ix->d_codes, &ix->d_ids, &ix->d_loff, &ix->d_gcount, &ix->w_xp, &ix->w_cd, &ix->w_order,
                       &ix->w_sorted, &ix->w_plan, &ix->w_off, &ix->w_items, &ix->w_tabs, &ix->w_T, &ix->w_hits,
                       &ix->w_hitn, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
-                      &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px};
+                      &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px, &ix->w_T32};
     for (DevBuf* b : bufs) b->release();
     delete ix;
 }
@@ -1809,9 +2009,9 @@ __global__ void k_selftest(int* __restrict__ errors) {
 
 #ifdef CIS_SCAN_COUNTERS
 extern "C" int cis_debug_counters(unsigned long long* out, int reset) {
-    CIS_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_ctr), 8 * sizeof(unsigned long long)));
+    CIS_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_ctr), 16 * sizeof(unsigned long long)));
     if (reset) {
-        unsigned long long z[8] = {0};
+        unsigned long long z[16] = {0};
         CIS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_scan_ctr), z, sizeof(z)));
     }
     return CIS_OK;
@@ -1946,7 +2146,9 @@ static void launch_scan_exact(int M, int64_t n_items, hipStream_t st, const Work
 }
 
 // float32-prefilter kernel (v2): M in {4, 8, 16}, K <= 256, L <= 440 (a wave region holds L + 64 entries)
-static bool scan2_supported(int M, int K, int L) { return (M == 4 || M == 8 || M == 16) && K <= 256 && L >= 1 && L <= 440; }
+static bool scan2_supported(int M, int K, int L) {
+    return (M == 4 || M == 8 || M == 16) && K <= 256 && ((M / 2) * K) % 4 == 0 && L >= 1 && L <= 440;
+}
 
 struct Scan2Geom { int G, NW, U, S; size_t lds; };
 
@@ -1971,7 +2173,7 @@ static Scan2Geom scan2_geom(int M, int K, int L, int nq) {
 
 template <int M, int NR, int G, int NW, int U>
 static void launch_scan2_t(int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots, const int* n_slots,
-                           const double* T, const uint8_t* codes, const int64_t* ids, int K, int L, int S, size_t lds,
+                           const double* T, const float* T32, const uint8_t* codes, const int64_t* ids, int K, int L, int S, size_t lds,
                            int* qctr, cis_hit* hits, int* hitn, unsigned long long* qbound) {
     const float eps = 2.0f * (float)M * 5.9604645e-8f;  // 2 * M * 2^-24
     const float margin = 1.0f + 3.0f * eps;
@@ -1979,17 +2181,17 @@ static void launch_scan2_t(int64_t n_items, hipStream_t st, const WorkItem* item
     const int64_t resident = 256 * (per_cu < 1 ? 1 : per_cu);  // persistent grid: what the chip can hold
     const int64_t want = (n_items + G - 1) / G + 8;
     const unsigned grid = (unsigned)(want < resident ? ((want + 7) / 8) * 8 : resident);
-    hipLaunchKernelGGL((k_adc_scan2<M, NR, U, G, NW>), dim3(grid), dim3(NW * 64), lds, st, items, slots, n_slots, T, codes, ids,
+    hipLaunchKernelGGL((k_adc_scan2<M, NR, U, G, NW>), dim3(grid), dim3(NW * 64), lds, st, items, slots, n_slots, T, T32, codes, ids,
                        K, L, S, margin, qctr, hits, hitn, qbound);
 }
 
 template <int M, int NR>
 static void launch_scan2_mr(const Scan2Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
-                            const int* n_slots, const double* T, const uint8_t* codes, const int64_t* ids, int K, int L,
+                            const int* n_slots, const double* T, const float* T32, const uint8_t* codes, const int64_t* ids, int K, int L,
                             int* qctr, cis_hit* hits, int* hitn, unsigned long long* qbound) {
 #define CIS_SCAN2_CASE(GG, WW, UU)                                                                                    \
     if (g.G == GG && g.NW == WW && g.U == UU) {                                                                       \
-        launch_scan2_t<M, NR, GG, WW, UU>(n_items, st, items, slots, n_slots, T, codes, ids, K, L, g.S, g.lds, qctr, hits, hitn, qbound); \
+        launch_scan2_t<M, NR, GG, WW, UU>(n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, g.S, g.lds, qctr, hits, hitn, qbound); \
         return;                                                                                                       \
     }
     CIS_SCAN2_CASE(1, 4, 4)
@@ -2002,18 +2204,18 @@ static void launch_scan2_mr(const Scan2Geom& g, int64_t n_items, hipStream_t st,
 
 template <int M>
 static void launch_scan2_m(const Scan2Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
-                           const int* n_slots, const double* T, const uint8_t* codes, const int64_t* ids, int K, int L,
+                           const int* n_slots, const double* T, const float* T32, const uint8_t* codes, const int64_t* ids, int K, int L,
                            int* qctr, cis_hit* hits, int* hitn, unsigned long long* qbound) {
-    if (L <= 184) launch_scan2_mr<M, 4>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn, qbound);
-    else launch_scan2_mr<M, 8>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn, qbound);
+    if (L <= 184) launch_scan2_mr<M, 4>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
+    else launch_scan2_mr<M, 8>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
 }
 
 static void launch_scan2(int M, const Scan2Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
-                         const int* n_slots, const double* T, const uint8_t* codes, const int64_t* ids, int K, int L,
+                         const int* n_slots, const double* T, const float* T32, const uint8_t* codes, const int64_t* ids, int K, int L,
                          int* qctr, cis_hit* hits, int* hitn, unsigned long long* qbound) {
-    if (M == 4) launch_scan2_m<4>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn, qbound);
-    else if (M == 8) launch_scan2_m<8>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn, qbound);
-    else launch_scan2_m<16>(g, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn, qbound);
+    if (M == 4) launch_scan2_m<4>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
+    else if (M == 8) launch_scan2_m<8>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
+    else launch_scan2_m<16>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
 }
 
 static const int MAX_LIMIT = 3072;
@@ -2126,6 +2328,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     WorkItem* items = ix->w_items.as<WorkItem>();
     TabDesc* tabs = ix->w_tabs.as<TabDesc>();
     double* T = ix->w_T.as<double>();
+    CIS_TRY(ix->w_T32.reserve((size_t)(n_tabs + 1) * nf * K * sizeof(float)));
+    float* T32 = ix->w_T32.as<float>();
     const size_t tab_lds = (size_t)(2 * h + (h < 256 ? 256 : 0)) * sizeof(double);
     const bool split_tables = (m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) && K <= 256;
     double* px_buf = nullptr;
@@ -2151,11 +2355,14 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     if (split_tables && n_tabs > 0) {
         dim3 g((unsigned)ceil_div(n_tabs, 64), (unsigned)nf, 2);
         switch (m->w) {
-            case 4: hipLaunchKernelGGL(k_tables_from_px<4>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T); break;
-            case 8: hipLaunchKernelGGL(k_tables_from_px<8>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T); break;
-            case 16: hipLaunchKernelGGL(k_tables_from_px<16>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T); break;
-            default: hipLaunchKernelGGL(k_tables_from_px<32>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T); break;
+            case 4: hipLaunchKernelGGL(k_tables_from_px<4>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32); break;
+            case 8: hipLaunchKernelGGL(k_tables_from_px<8>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32); break;
+            case 16: hipLaunchKernelGGL(k_tables_from_px<16>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32); break;
+            default: hipLaunchKernelGGL(k_tables_from_px<32>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32); break;
         }
+    } else if (fast && n_tabs > 0) {
+        const int64_t ne = n_tabs * nf * K;
+        hipLaunchKernelGGL(k_tables_f32, dim3((unsigned)ceil_div(ne, 256)), dim3(256), 0, st, T, ne, nf, K, T32);
     }
     // 4. ADC scan + block top-k
     CIS_TRY(mark(2));
@@ -2188,7 +2395,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                 hipLaunchKernelGGL(k_identity_slots, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, n_items, G, slots,
                                    n_slots);
             }
-            launch_scan2(M, geom, n_items, st, items, slots, n_slots, T, codes, ids, K, L, qctr, hits, hitn, qbound);
+            launch_scan2(M, geom, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
         }
         else launch_scan_exact(M, n_items, st, items, T, codes, ids, K, L, S, nullptr, hits, hitn);
         ix->stats[3] += 1;

@@ -227,6 +227,12 @@ def make_c2(outdir):
                      [(10, 10), (1000, 100), (10000, 100)])
 
 
+def make_c4(outdir):
+    """Bench model (config C4): 128-d descriptor-like unit vectors, LOPQModelPCA V=16, M=8, renorm."""
+    make_pca_fixture(outdir, "c4", 16, 8, 128, 50000, 100000, 64, gi.c4_inputs(),
+                     [(10, 10), (1000, 100), (10000, 100)])
+
+
 def make_c3(outdir):
     """C3-shaped, scaled down: float32 non-negative features, PCA 320 -> 128, V=16, M=16."""
     make_pca_fixture(outdir, "c3", 16, 16, 128, 20000, 20000, 32, gi.c3_inputs(),
@@ -270,7 +276,7 @@ def make_tiny(outdir):
     np.savez_compressed(os.path.join(outdir, "tiny.npz"), **d)
 
 
-MAKERS = {"tiny": make_tiny, "c1": make_c1, "c2": make_c2, "c3": make_c3, "c3b": make_c3b}
+MAKERS = {"tiny": make_tiny, "c1": make_c1, "c2": make_c2, "c3": make_c3, "c3b": make_c3b, "c4": make_c4}
 
 if __name__ == "__main__":
     tmp = import_reference()

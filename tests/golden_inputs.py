@@ -43,6 +43,34 @@ def c2_inputs():
     return X, Q
 
 
+def descriptor_params(d=128, n_comp=4096, seed=9):
+    """Parameters of the descriptor-like distribution of the bench workload (config C4): an anisotropic mixture
+    whose spectrum decays as j^-1/2 in a random orthonormal basis, with far more (mild) components than the
+    codebooks can memorise, so that the residuals are continuous and LOPQ codes are almost all distinct -- as for
+    real CNN / face descriptors.  (The 256-component isotropic mixture of c2 gives 84 % duplicate codes.)"""
+    rs = np.random.RandomState(seed)
+    basis, _ = np.linalg.qr(rs.randn(d, d))
+    scale = (1.0 + np.arange(d)) ** -0.5
+    centers = (rs.randn(n_comp, d) * scale).dot(basis.T)
+    mean = (0.5 * rs.randn(d) * scale).dot(basis.T)
+    return basis, scale, centers, mean
+
+
+def descriptor_like(n, d, seed, dtype=np.float64):
+    basis, scale, centers, mean = descriptor_params(d)
+    rs = np.random.RandomState(seed)
+    comp = rs.randint(0, centers.shape[0], size=n)
+    x = mean + 0.7 * centers[comp] + 0.7 * (rs.randn(n, d) * scale).dot(basis.T)
+    x /= np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-12)
+    return x.astype(dtype)
+
+
+def c4_inputs():
+    X = descriptor_like(100000, 128, 4, np.float64)
+    Q, _ = perturbed_queries(X, 64, 44)
+    return X, Q
+
+
 def c3_inputs():
     X = gmm_unit(20000, 320, 128, 3, np.float32, nonneg=True)
     Q, _ = perturbed_queries(X, 32, 33)

@@ -10,7 +10,7 @@ from conftest import load_golden, sha1
 
 pytestmark = pytest.mark.gpu
 
-PCA_FIXTURES = ["c2", "c3", "c3b"]
+PCA_FIXTURES = ["c2", "c3", "c3b", "c4"]
 ALL = ["tiny", "c1"] + PCA_FIXTURES
 
 
@@ -237,7 +237,7 @@ def test_device_entry_points_match_host_entry_points():
     np.testing.assert_array_equal(f.cpu().numpy(), z["fine"][:5000])
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4"])
 def test_fast_and_exact_scan_kernels_agree(name):
     """The float32-prefilter scan (exact float64 re-scoring) and the float64 scan return identical
     ids AND bit-identical distances; M = 4, 8, 16 cover the three lane-rotation layouts."""
