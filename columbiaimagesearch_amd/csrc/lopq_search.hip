@@ -1359,6 +1359,7 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
     const double infl = 1.0 + 2.0 * EPS32;
     CodeWords<M> dup[G];  // per query: a code whose later copies cannot enter this wave's top-L any more
     bool has_dup[G];
+    bool any_dup = false;
 #pragma unroll
     for (int g = 0; g < G; ++g) { cnt[g] = 0; has_dup[g] = false; dup[g] = CodeWords<M>(); }
 #ifndef CIS_SCAN_PLAIN_LOADS
@@ -1410,14 +1411,25 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
 #ifdef CIS_PROBE_HOTLOOP
             thrm = (margin > 100.f) ? thrm : -1.0f;  // probe: nothing passes, only the float32 scan runs
 #endif
-            const unsigned long long dup_on = has_dup[g] ? ~0ull : 0ull;  // wave-uniform
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                bool same = true;
-#pragma unroll
-                for (int i = 0; i < (M + 3) / 4; ++i) same = same && (cur[u].w[i] == dup[g].w[i]);
-                pm[u][g] = __ballot(d[u][g] <= thrm) & ~(__ballot(same) & dup_on);
+                pm[u][g] = __ballot(d[u][g] <= thrm);
                 any |= pm[u][g];
+            }
+        }
+        if (any_dup) {  // wave-uniform, rare: drop later copies of a code that already lost a tie-break (see wave_compact_exact)
+            any = 0ull;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const unsigned long long dup_on = has_dup[g] ? ~0ull : 0ull;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    bool same = true;
+#pragma unroll
+                    for (int i = 0; i < (M + 3) / 4; ++i) same = same && (cur[u].w[i] == dup[g].w[i]);
+                    pm[u][g] &= ~(__ballot(same) & dup_on);
+                    any |= pm[u][g];
+                }
             }
         }
         if (any == 0ull) continue;  // the usual case: nothing in these 64*U candidates beats a bound
@@ -1428,6 +1440,28 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
             if (g >= ng) break;
             uint64_t* rk = rk_all + (g * NW + w) * R;
             uint32_t* rp = rp_all + (g * NW + w) * R;
+            int ntot = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) ntot += __popcll(pm[u][g]);
+            if (ntot == 0) continue;  // only the other query has candidates in this iteration
+            if (cnt[g] + ntot <= R) {
+                // The usual case: everything fits.  Straight-line code, no branch per row: every lane stores, the
+                // lanes that did not pass into a scratch slot of their own (this wave's rp area is idle until the end).
+                const int trash = (int)((reinterpret_cast<char*>(rp) - reinterpret_cast<char*>(rk)) >> 3) + lane;
+                int c = cnt[g];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const unsigned long long m = pm[u][g];
+                    const int idx = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, c));
+                    int sel;
+                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(trash), "v"(idx), "s"(m));
+                    rk[sel] = ((uint64_t)__float_as_uint(d[u][g]) << 32) | (uint32_t)(base + u * 64 + lane);
+                    c += __popcll(m);
+                }
+                cnt[g] = c;
+                n_app += ntot;
+                continue;
+            }
             // Append row after row while they fit; when one does not, compact (ONE call site per query, whatever U
             // is), re-test the rows not yet appended against the new bound and go on.  After a compaction
             // cnt <= R - 64, so the next row always fits and the loop ends after at most U compactions.
@@ -1462,6 +1496,7 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
                     if (dp != 0xffffffffu) {
                         dup[g] = load_code<M>(codes, start + (int64_t)dp);
                         has_dup[g] = true;
+                        any_dup = true;
                     }
                 }
                 cnt[g] = c2;
