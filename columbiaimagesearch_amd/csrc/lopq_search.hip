@@ -1269,7 +1269,7 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
                                             const double* __restrict__ T, const float* __restrict__ T32,
                                             const uint8_t* __restrict__ codes,
                                             const int64_t* __restrict__ ids, int K, int L, int S, float margin,
-                                            cis_hit* __restrict__ item_hits, int* __restrict__ item_n,
+                                            uint64_t* __restrict__ item_surv, int* __restrict__ item_n,
                                             unsigned long long* __restrict__ qbound, char* smem) {
     // region capacity: 8 entries short of the NR*64 keys a wave can hold in registers, so that the
     // G=2 / 4-wave layout (16 KB tables + 8 regions) stays under 40 KB and four workgroups share a CU
@@ -1342,7 +1342,8 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
                 const unsigned long long e = 0x7ff0000000000000ull;
 #endif
                 sh[g].ext = e;
-                sh[g].bound_f = __double2float_ru(__longlong_as_double((long long)e));
+                // an absent second query: negative bound, nothing ever passes (its tables are +inf as well)
+                sh[g].bound_f = (g < ng) ? __double2float_ru(__longlong_as_double((long long)e)) : -1.0f;
             }
         }
     }
@@ -1351,8 +1352,10 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
     (void)clk_tab_end;
     const RotConsts<M> rc = make_rot<M>(lane);
     const int Lw = (L + NW - 1) / NW;
-    const int len = it[0].len;
-    const int64_t start = it[0].start;
+    // wave-uniform by construction; tell the compiler so (scalar loop control, scalar tail test)
+    const int len = __builtin_amdgcn_readfirstlane(it[0].len);
+    const int64_t start = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it[0].start >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)it[0].start);
     const int nit = (len + 64 * U - 1) / (64 * U);
     int cnt[G];
     constexpr double EPS32 = 2.0 * M * 5.9604644775390625e-8;  // float32 sum vs exact: |d32 - d64| <= EPS32 * d64
@@ -1407,7 +1410,7 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
         unsigned long long any = 0ull;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float thrm = (g < ng) ? block_bound_f32(&sh[g]) * margin : -1.0f;
+            float thrm = block_bound_f32(&sh[g]) * margin;
 #ifdef CIS_PROBE_HOTLOOP
             thrm = (margin > 100.f) ? thrm : -1.0f;  // probe: nothing passes, only the float32 scan runs
 #endif
@@ -1518,8 +1521,8 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
     (void)clk_loop_end;
     // End of the chunk.  Every wave cuts its region in float32 and publishes its bounds; after the barrier the
     // block bound is (about) the L-th smallest distance of the whole chunk, so only ~L/NW entries per wave survive
-    // it -- those are the only ones that are re-scored exactly (codes + float64 tables from L2, one row of loads).
-    // The per-query merge kernel ranks the union exactly, so no second exact filter is needed here.
+    // it.  The survivors -- a superset of the chunk's exact top L -- leave as (float32 distance, position) pairs;
+    // k_merge_survivors re-scores them in float64 and ranks the query's candidates exactly.
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         if (g >= ng) break;
@@ -1532,10 +1535,7 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
     for (int g = 0; g < G; ++g) {
         if (g >= ng) break;
         uint64_t* rk = rk_all + (g * NW + w) * R;
-        uint32_t* rp = rp_all + (g * NW + w) * R;
         cnt[g] = wave_filter_approx<NR, NW>(rk, cnt[g], margin, &sh[g]);
-        uint32_t dp = 0xffffffffu;
-        cnt[g] = wave_compact_exact<M, NR, NW, true>(rk, rp, cnt[g], L, Lw, &sh[g], w, codes, start, K, t0[g], t1[g], dp);
         if (lane == 0) sh[g].wcnt[w] = cnt[g];
 #ifndef CIS_SCAN_NO_QBOUND
         if (tid == 0) {
@@ -1551,7 +1551,6 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
     for (int g = 0; g < G; ++g) {
         if (g >= ng) break;
         const uint64_t* rk = rk_all + (g * NW + w) * R;
-        const uint32_t* rp = rp_all + (g * NW + w) * R;
         int off = 0, total = 0;
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
@@ -1559,18 +1558,8 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
             off += (i < w) ? c : 0;
             total += c;
         }
-        cis_hit* out = item_hits + (int64_t)item_idx[g] * S + off;  // S >= NW * L >= total
-        for (int e = lane; e < cnt[g]; e += 64) {
-            const uint32_t p = rp[e];
-            cis_hit hh;
-            hh.dist = __longlong_as_double((long long)rk[e]);
-            hh.visit_rank = (uint32_t)it[g].rank;
-            hh.pos = (uint32_t)it[g].pos0 + p;
-            hh.id = ids[start + p];
-            hh.cell = it[g].cell;
-            hh.reserved = 0;
-            out[e] = hh;
-        }
+        uint64_t* out = item_surv + (int64_t)item_idx[g] * S + off;  // S = NW * R >= total
+        for (int e = lane; e < cnt[g]; e += 64) out[e] = rk[e];
         if (tid == 0) item_n[item_idx[g]] = total;
     }
 #ifdef CIS_SCAN_COUNTERS
@@ -1600,7 +1589,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                                                        const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids,
                                                        int K, int L, int S, float margin,
                                                        int* __restrict__ queue_ctr /* [8], zeroed */,
-                                                       cis_hit* __restrict__ item_hits, int* __restrict__ item_n,
+                                                       uint64_t* __restrict__ item_surv, int* __restrict__ item_n,
                                                        unsigned long long* __restrict__ qbound /* [nq], +inf */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int R = NR * 64 - 8;
@@ -1633,14 +1622,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 if (ng == 2 && (it[0].start != it[1].start || it[0].len != it[1].len)) {
                     WorkItem one[G] = {it[0], it[0]};
                     int oi[G] = {idx[0], idx[0]};
-                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, T32, codes, ids, K, L, S, margin, item_hits, item_n, qbound, smem);
+                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, T32, codes, ids, K, L, S, margin, item_surv, item_n, qbound, smem);
                     __syncthreads();
                     one[0] = it[1]; one[1] = it[1]; oi[0] = idx[1]; oi[1] = idx[1];
-                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, T32, codes, ids, K, L, S, margin, item_hits, item_n, qbound, smem);
+                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, T32, codes, ids, K, L, S, margin, item_surv, item_n, qbound, smem);
                     continue;
                 }
             }
-            scan2_group<M, NR, U, G, NW>(it, idx, ng, T, T32, codes, ids, K, L, S, margin, item_hits, item_n, qbound, smem);
+            scan2_group<M, NR, U, G, NW>(it, idx, ng, T, T32, codes, ids, K, L, S, margin, item_surv, item_n, qbound, smem);
         }
     }
 }
@@ -1734,6 +1723,93 @@ __global__ __launch_bounds__(256) void k_merge_items(const cis_hit* __restrict__
                       out_hits ? out_hits + o : nullptr, out_ids ? out_ids + o : nullptr,
                       out_dists ? out_dists + o : nullptr, out_n ? out_n + q : nullptr,
                       out_cells ? out_cells + o : nullptr, out_pos ? out_pos + o : nullptr);
+}
+
+// The float32-prefilter scan hands over, per work item, the (float32 distance << 32 | position) pairs that survived
+// its bounds: a superset of the item's exact top `limit`.  One workgroup per query re-scores them exactly (the code
+// from the index, float64 table entries summed left to right as search.py:173 -- one candidate per thread, so the
+// loads of a whole query are in flight together) and ranks them by (dist, visit_rank, pos).
+template <int CAPM>
+__global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restrict__ surv /* [n_items][S] */,
+                                                         const int* __restrict__ item_n, const int64_t* __restrict__ item_off,
+                                                         const WorkItem* __restrict__ items, const double* __restrict__ T,
+                                                         const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids,
+                                                         int M, int K, int limit, int S,
+                                                         cis_hit* __restrict__ out_hits, int64_t* __restrict__ out_ids,
+                                                         double* __restrict__ out_dists, int* __restrict__ out_n,
+                                                         int32_t* __restrict__ out_cells, uint32_t* __restrict__ out_pos) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* ka = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* kb = ka + CAPM;
+    int64_t* pay = reinterpret_cast<int64_t*>(kb + CAPM);  // (list << 32) | position inside the chunk
+    int* s_n = reinterpret_cast<int*>(pay + CAPM);
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int64_t first = item_off[q];
+    const int n_lists = (int)(item_off[q + 1] - first);
+    const int nf = M / 2;
+    int have = 0, l = 0, e = 0;
+    while (true) {  // rounds: append up to CAPM - have entries, sort, keep `limit`
+        int n = have;
+        int room = CAPM - have;
+        while (l < n_lists && room > 0) {
+            const int valid = item_n[first + l];
+            const int take = (valid - e < room) ? (valid - e) : room;
+            if (take > 0) {
+                const WorkItem it = items[first + l];
+                const double* t0 = T + (int64_t)it.tab0 * nf * K;
+                const double* t1 = T + (int64_t)it.tab1 * nf * K;
+                const uint64_t* src = surv + (first + l) * (int64_t)S + e;
+                for (int x = tid; x < take; x += 256) {
+                    const uint32_t p = (uint32_t)src[x];
+                    ka[n + x] = (uint64_t)__double_as_longlong(adc64_global(codes, it.start + p, M, K, t0, t1));
+                    kb[n + x] = ((uint64_t)(uint32_t)it.rank << 32) | (uint32_t)(it.pos0 + (int)p);
+                    pay[n + x] = ((int64_t)l << 32) | p;
+                }
+            }
+            n += take;
+            room -= take;
+            e += take;
+            if (e >= valid) { ++l; e = 0; }
+        }
+        int ns = 64;
+        while (ns < n) ns <<= 1;
+        for (int x = n + tid; x < ns; x += 256) { ka[x] = ~0ull; kb[x] = ~0ull; pay[x] = -1; }
+        __syncthreads();
+        block_bitonic_rt<256, true>(ka, kb, pay, ns);
+        have = n < limit ? n : limit;
+        if (l >= n_lists) break;
+    }
+    if (tid == 0) *s_n = 0;
+    __syncthreads();
+    int local = 0;
+    for (int x = tid; x < have; x += 256) local += (pay[x] >= 0) ? 1 : 0;
+    if (local) atomicAdd(s_n, local);
+    __syncthreads();
+    const int nv = *s_n;
+    const int64_t o = (int64_t)q * limit;
+    for (int x = tid; x < limit; x += 256) {
+        cis_hit hh;
+        if (x < nv) {
+            const WorkItem it = items[first + (pay[x] >> 32)];
+            hh.dist = __longlong_as_double((long long)ka[x]);
+            hh.visit_rank = (uint32_t)(kb[x] >> 32);
+            hh.pos = (uint32_t)kb[x];
+            hh.id = ids[it.start + (uint32_t)pay[x]];
+            hh.cell = it.cell;
+            hh.reserved = 0;
+        } else {
+            hh.dist = __longlong_as_double(0x7ff0000000000000LL);
+            hh.visit_rank = 0xffffffffu; hh.pos = 0xffffffffu; hh.id = -1; hh.cell = -1; hh.reserved = 0;
+        }
+        if (out_hits) out_hits[o + x] = hh;
+        if (out_ids) {
+            out_ids[o + x] = hh.id;
+            out_dists[o + x] = (x < nv) ? hh.dist : __longlong_as_double(0x7ff8000000000000LL);
+        }
+        if (out_cells) out_cells[o + x] = hh.cell;
+        if (out_pos) out_pos[o + x] = hh.pos;
+    }
+    if (tid == 0 && out_n) out_n[q] = nv;
 }
 
 template <int CAPM>
@@ -2201,7 +2277,7 @@ static Scan2Geom scan2_geom(int M, int K, int L, int nq) {
             g.G = a; g.NW = b; g.U = c;
         }
     }
-    g.S = g.NW * L;
+    g.S = g.NW * (NR * 64 - 8);  // survivor slots per work item: a full region per wave
     g.lds = (size_t)K * M * g.G * 4 + (size_t)g.G * g.NW * (NR * 64 - 8) * 12 + g.G * sizeof(ScanShared) + 16;
     return g;
 }
@@ -2209,7 +2285,7 @@ static Scan2Geom scan2_geom(int M, int K, int L, int nq) {
 template <int M, int NR, int G, int NW, int U>
 static void launch_scan2_t(int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots, const int* n_slots,
                            const double* T, const float* T32, const uint8_t* codes, const int64_t* ids, int K, int L, int S, size_t lds,
-                           int* qctr, cis_hit* hits, int* hitn, unsigned long long* qbound) {
+                           int* qctr, uint64_t* hits, int* hitn, unsigned long long* qbound) {
     const float eps = 2.0f * (float)M * 5.9604645e-8f;  // 2 * M * 2^-24
     const float margin = 1.0f + 3.0f * eps;
     const int per_cu = (int)(163840 / lds) < (32 / NW) ? (int)(163840 / lds) : (32 / NW);
@@ -2223,7 +2299,7 @@ static void launch_scan2_t(int64_t n_items, hipStream_t st, const WorkItem* item
 template <int M, int NR>
 static void launch_scan2_mr(const Scan2Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
                             const int* n_slots, const double* T, const float* T32, const uint8_t* codes, const int64_t* ids, int K, int L,
-                            int* qctr, cis_hit* hits, int* hitn, unsigned long long* qbound) {
+                            int* qctr, uint64_t* hits, int* hitn, unsigned long long* qbound) {
 #define CIS_SCAN2_CASE(GG, WW, UU)                                                                                    \
     if (g.G == GG && g.NW == WW && g.U == UU) {                                                                       \
         launch_scan2_t<M, NR, GG, WW, UU>(n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, g.S, g.lds, qctr, hits, hitn, qbound); \
@@ -2240,14 +2316,14 @@ static void launch_scan2_mr(const Scan2Geom& g, int64_t n_items, hipStream_t st,
 template <int M>
 static void launch_scan2_m(const Scan2Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
                            const int* n_slots, const double* T, const float* T32, const uint8_t* codes, const int64_t* ids, int K, int L,
-                           int* qctr, cis_hit* hits, int* hitn, unsigned long long* qbound) {
+                           int* qctr, uint64_t* hits, int* hitn, unsigned long long* qbound) {
     if (L <= 184) launch_scan2_mr<M, 4>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
     else launch_scan2_mr<M, 8>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
 }
 
 static void launch_scan2(int M, const Scan2Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
                          const int* n_slots, const double* T, const float* T32, const uint8_t* codes, const int64_t* ids, int K, int L,
-                         int* qctr, cis_hit* hits, int* hitn, unsigned long long* qbound) {
+                         int* qctr, uint64_t* hits, int* hitn, unsigned long long* qbound) {
     if (M == 4) launch_scan2_m<4>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
     else if (M == 8) launch_scan2_m<8>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
     else launch_scan2_m<16>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
@@ -2344,7 +2420,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         // exhaustive quota: every query visits every cell) is split by the caller and planned again.
         const bool fast_ = scan2_supported(M, K, L) && !ix->force_exact_scan;
         const int64_t S_ = fast_ ? scan2_geom(M, K, L, nq).S : L;
-        const double need = (double)n_items * S_ * sizeof(cis_hit) + (double)n_tabs * nf * K * sizeof(double);
+        const double need = (double)n_items * S_ * (fast_ ? sizeof(uint64_t) : sizeof(cis_hit)) + (double)n_tabs * nf * K * sizeof(double);
         if (need > 4.0e9 && nq > 1) return CIS_RETRY_SMALLER;
     }
     ix->stats[0] += h_tot[2];
@@ -2358,7 +2434,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     const bool fast = scan2_supported(M, K, L) && !ix->force_exact_scan;
     const Scan2Geom geom = scan2_geom(M, K, L, nq);
     const int S = fast ? geom.S : L;  // hit slots per work item (fast kernel: <= L per wave)
-    CIS_TRY(ix->w_hits.reserve((size_t)(n_items + 1) * S * sizeof(cis_hit)));
+    CIS_TRY(ix->w_hits.reserve((size_t)(n_items + 1) * S * (fast ? sizeof(uint64_t) : sizeof(cis_hit))));
     CIS_TRY(ix->w_hitn.reserve((size_t)(n_items + 1) * 2 * sizeof(int)));
     WorkItem* items = ix->w_items.as<WorkItem>();
     TabDesc* tabs = ix->w_tabs.as<TabDesc>();
@@ -2430,7 +2506,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                 hipLaunchKernelGGL(k_identity_slots, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, n_items, G, slots,
                                    n_slots);
             }
-            launch_scan2(M, geom, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
+            launch_scan2(M, geom, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, qbound);
         }
         else launch_scan_exact(M, n_items, st, items, T, codes, ids, K, L, S, nullptr, hits, hitn);
         ix->stats[3] += 1;
@@ -2440,7 +2516,21 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     {
         const cis_hit* hits = ix->w_hits.as<cis_hit>();
         const int* hitn = ix->w_hitn.as<int>();
-        if (L <= 512)
+        if (fast) {
+            // survivors of the float32 scan: exact re-scoring + ranking (limit <= 440 here)
+            const uint64_t* surv = ix->w_hits.as<uint64_t>();
+            const uint8_t* codes = ix->d_codes.as<uint8_t>();
+            const int64_t* ids = ix->d_ids.as<int64_t>();
+            if (L <= 128)
+                hipLaunchKernelGGL(k_merge_survivors<256>, dim3(nq), dim3(256), (size_t)256 * 24 + 16, st, surv, hitn, item_off, items, T,
+                                   codes, ids, M, K, L, S, out.hits, out.ids, out.dists, out.n_found, out.cells, out.pos);
+            else if (L <= 256)
+                hipLaunchKernelGGL(k_merge_survivors<512>, dim3(nq), dim3(256), (size_t)512 * 24 + 16, st, surv, hitn, item_off, items, T,
+                                   codes, ids, M, K, L, S, out.hits, out.ids, out.dists, out.n_found, out.cells, out.pos);
+            else
+                hipLaunchKernelGGL(k_merge_survivors<1024>, dim3(nq), dim3(256), (size_t)1024 * 24 + 16, st, surv, hitn, item_off, items, T,
+                                   codes, ids, M, K, L, S, out.hits, out.ids, out.dists, out.n_found, out.cells, out.pos);
+        } else if (L <= 512)
             hipLaunchKernelGGL(k_merge_items<1024>, dim3(nq), dim3(256), (size_t)1024 * 24 + 16, st, hits, hitn, item_off, L, S, out.hits,
                                out.ids, out.dists, out.n_found, out.cells, out.pos);
         else if (L <= 1024)
