@@ -297,7 +297,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "recall_at_10": recall10,
-            "config": {"workload": "C4: %d x 128-d float64 unit vectors (256-component mixture), LOPQModelPCA V=16 M=8 "
+            "config": {"workload": "C4: %d x 128-d float64 unit vectors (descriptor-like anisotropic mixture), LOPQModelPCA V=16 M=8 "
                                    "renorm, %d queries/step, quota=%d limit=%d" % (N, NQ, QUOTA, LIMIT),
                        "index_vectors": N, "queries_per_step": NQ, "quota": QUOTA, "limit": LIMIT,
                        "sharding": "by coarse cell over %d GPU(s)%s" % (world, ", RCCL all-gather merge" if world > 1 else ""),

@@ -202,6 +202,29 @@ __global__ void k_pca_finish(const double* __restrict__ Y, float* __restrict__ o
     for (int i = 0; i < D; ++i) out[r * D + i] = (float)(renorm ? (y[i] / nrm) : y[i]);
 }
 
+// The same for 8 <= D <= 128, D % 8 == 0 (the usual descriptor sizes): numpy's pairwise sum is then ONE block of eight
+// interleaved accumulators, r[j] = a[j] + a[8+j] + a[16+j] + ..., combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).
+// Eight lanes own the eight accumulators of a row (same additions in the same order, IEEE addition is commutative),
+// so the loads and stores of a row are contiguous instead of one strided row per thread.
+__global__ __launch_bounds__(256) void k_pca_finish8(const double* __restrict__ Y, float* __restrict__ out, int64_t n, int D) {
+    const int j = threadIdx.x & 7;
+    const int64_t r = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool on = r < n;
+    const double* y = Y + (on ? r : 0) * D;
+    double v0 = y[j];
+    double acc = v0 * v0;
+    for (int i = 8; i < D; i += 8) {
+        const double v = y[i + j];
+        acc = acc + v * v;
+    }
+    acc = acc + __shfl_xor(acc, 1);
+    acc = acc + __shfl_xor(acc, 2);
+    acc = acc + __shfl_xor(acc, 4);
+    const double nrm = sqrt(acc);
+    if (!on) return;
+    for (int i = 0; i < D; i += 8) out[r * D + i + j] = (float)(y[i + j] / nrm);
+}
+
 // out[r][c] = sum_i (X[r][xoff+i] - C[c][i])^2 in numpy's order; 16 rows x 16 centroids / block.
 template <typename T>
 __global__ __launch_bounds__(256) void k_sqdist_rows(const T* __restrict__ X, int64_t ldx, int xoff,
@@ -472,7 +495,10 @@ int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, floa
         hipLaunchKernelGGL((k_pca_gemm<float, false>), g, dim3(256), 0, st, (const float*)dX, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);
     else
         hipLaunchKernelGGL((k_pca_gemm<double, false>), g, dim3(256), 0, st, (const double*)dX, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);
-    hipLaunchKernelGGL(k_pca_finish, dim3(grid1(n, 64)), dim3(64), 0, st, Y, d_out, n, m->D, m->renorm ? 1 : 0, m->prog_D);
+    if (m->renorm && m->D >= 8 && m->D <= 128 && m->D % 8 == 0)
+        hipLaunchKernelGGL(k_pca_finish8, dim3((unsigned)ceil_div(n, 32)), dim3(256), 0, st, Y, d_out, n, m->D);
+    else
+        hipLaunchKernelGGL(k_pca_finish, dim3(grid1(n, 64)), dim3(64), 0, st, Y, d_out, n, m->D, m->renorm ? 1 : 0, m->prog_D);
     CIS_CHECK_HIP(hipGetLastError());
     return CIS_OK;
 }

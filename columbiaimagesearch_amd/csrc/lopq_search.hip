@@ -221,31 +221,57 @@ __global__ __launch_bounds__(64) void k_multiseq_list(const CT* __restrict__ sor
     }
 }
 
-// exclusive scans over the queries of one batch (single block); totals[0]=items, [1]=tables, [2]=cands
-__global__ void k_plan_scan(const PlanOut* __restrict__ plan, int nq, int64_t* __restrict__ item_off,
-                            int64_t* __restrict__ tab_off, int64_t* __restrict__ totals,
-                            unsigned long long* __restrict__ qbound /* [nq] -> +inf */) {
-    __shared__ int64_t s_items[256], s_tabs[256], s_cand[256];
-    const int tid = threadIdx.x;
-    const int per = (nq + 255) / 256;
-    const int a = tid * per, b = (a + per < nq) ? a + per : nq;
+// exclusive scans over the queries of one batch (single block of 1024 threads); totals[0]=items, [1]=tables, [2]=cands
+__global__ __launch_bounds__(1024) void k_plan_scan(const PlanOut* __restrict__ plan, int nq, int64_t* __restrict__ item_off,
+                                                    int64_t* __restrict__ tab_off, int64_t* __restrict__ totals,
+                                                    unsigned long long* __restrict__ qbound /* [nq] -> +inf */) {
+    __shared__ int64_t s_items[16], s_tabs[16], s_cand[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (nq + 1023) / 1024;
+    const int a = tid * per < nq ? tid * per : nq, b = (a + per < nq) ? a + per : nq;
+    // the batch holds <= 8192 queries: <= 8 per thread, loaded together (independent loads) and kept for the second pass
+    int ni[8], nt[8];
     int64_t li = 0, lt = 0, lc = 0;
-    for (int q = a; q < b; ++q) { li += plan[q].n_items; lt += plan[q].ntab0 + plan[q].ntab1; lc += plan[q].ncand; }
-    s_items[tid] = li; s_tabs[tid] = lt; s_cand[tid] = lc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = a + i;
+        const bool on = q < b;
+        const PlanOut pl = plan[on ? q : 0];
+        ni[i] = on ? pl.n_items : 0;
+        nt[i] = on ? pl.ntab0 + pl.ntab1 : 0;
+        li += ni[i]; lt += nt[i]; lc += on ? pl.ncand : 0;
+    }
+    for (int q = a + 8; q < b; ++q) { li += plan[q].n_items; lt += plan[q].ntab0 + plan[q].ntab1; lc += plan[q].ncand; }
+    int64_t xi = li, xt = lt, xc = lc;  // inclusive scans inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t yi = __shfl_up(xi, d), yt = __shfl_up(xt, d), yc = __shfl_up(xc, d);
+        if (lane >= d) { xi += yi; xt += yt; xc += yc; }
+    }
+    if (lane == 63) { s_items[wv] = xi; s_tabs[wv] = xt; s_cand[wv] = xc; }
     __syncthreads();
     if (tid == 0) {
         int64_t ri = 0, rt = 0, rc = 0;
-        for (int k = 0; k < 256; ++k) {
-            const int64_t xi = s_items[k], xt = s_tabs[k];
+        for (int k = 0; k < 16; ++k) {
+            const int64_t yi = s_items[k], yt = s_tabs[k];
             s_items[k] = ri; s_tabs[k] = rt;
-            ri += xi; rt += xt; rc += s_cand[k];
+            ri += yi; rt += yt; rc += s_cand[k];
         }
         totals[0] = ri; totals[1] = rt; totals[2] = rc;
         item_off[nq] = ri; tab_off[nq] = rt;
     }
     __syncthreads();
-    int64_t ri = s_items[tid], rt = s_tabs[tid];
-    for (int q = a; q < b; ++q) {
+    int64_t ri = s_items[wv] + xi - li, rt = s_tabs[wv] + xt - lt;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = a + i;
+        if (q < b) {
+            item_off[q] = ri; tab_off[q] = rt;
+            qbound[q] = 0x7ff0000000000000ull;
+        }
+        ri += ni[i]; rt += nt[i];
+    }
+    for (int q = a + 8; q < b; ++q) {
         item_off[q] = ri; tab_off[q] = rt;
         qbound[q] = 0x7ff0000000000000ull;
         ri += plan[q].n_items; rt += plan[q].ntab0 + plan[q].ntab1;
@@ -253,6 +279,15 @@ __global__ void k_plan_scan(const PlanOut* __restrict__ plan, int nq, int64_t* _
 }
 
 // ---- work items sorted by coarse cell (counting sort; order inside a cell is irrelevant) ----------
+// one launch instead of three memsets: queue counters and per-cell counters to zero, slots to -1 (empty)
+__global__ void k_slots_init(int* __restrict__ qctr16, int* __restrict__ cell_cnt, int ncells, int* __restrict__ slots,
+                             int64_t n_slot_entries) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 16) qctr16[i] = 0;
+    if (i < ncells) cell_cnt[i] = 0;
+    if (i < n_slot_entries) slots[i] = -1;
+}
+
 __global__ void k_item_hist(const WorkItem* __restrict__ items, int64_t n, int* __restrict__ cell_cnt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) atomicAdd(&cell_cnt[items[i].cell], 1);
@@ -393,7 +428,7 @@ __global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict
                                                         const TabDesc* __restrict__ tabs, int n_tabs,
                                                         const double* __restrict__ subs, int h, int nf, int K,
                                                         double* __restrict__ T /* [ntab][nf][K] */,
-                                                        float* __restrict__ T32 /* [ntab][K][nf]: the scan's LDS order */) {
+                                                        float* __restrict__ T32 /* [ntab][nf][K] float32 copy for the scan */) {
     __shared__ double sf[64][W];
     __shared__ int ssplit[64];
     const int j = blockIdx.y, z = blockIdx.z, k = threadIdx.x;
@@ -416,17 +451,15 @@ __global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict
         auto elem = [&](int i) -> double { const double df = f[i] - sc[i]; return df * df; };
         const double v = pw_leaf<double>(elem, 0, W);
         T[((int64_t)(t0 + t) * nf + j) * K + k] = v;
-        T32[((int64_t)(t0 + t) * K + k) * nf + j] = (float)v;
+        T32[((int64_t)(t0 + t) * nf + j) * K + k] = (float)v;
     }
 }
 
-// float32 copy of the tables in the scan's order, for the configurations that do not go through k_tables_from_px
+// float32 copy of the tables for the configurations that do not go through k_tables_from_px
 __global__ void k_tables_f32(const double* __restrict__ T, int64_t n, int nf, int K, float* __restrict__ T32) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // index into T: (tab, j, k)
     if (e >= n) return;
-    const int64_t tab = e / ((int64_t)nf * K);
-    const int r = (int)(e - tab * nf * K), j = r / K, k = r - j * K;
-    T32[(tab * K + k) * nf + j] = (float)T[e];
+    T32[e] = (float)T[e];
 }
 
 // ================================================================================================
@@ -1295,10 +1328,10 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
     }
     const float INF = __int_as_float(0x7f800000);
     {
-        // LDS tables from the float32 copies ([K][nf] per (query, half)): 16-byte loads, all in flight together,
-        // then one ds_write per entry that carries both queries' values (G = 2).
+        // LDS tables from the float32 copies ([nf][K] per (query, half)): 16-byte loads (four consecutive k of one
+        // sub-quantizer), all in flight together, then one ds_write per entry that carries both queries' values.
         float* tf = reinterpret_cast<float*>(tab);
-        const int nvec = (nf * K) >> 2;  // float4 per half table (K is a multiple of 4 / nf for the supported shapes)
+        const int nvec = (nf * K) >> 2;  // K is a multiple of 4 for the supported shapes
         for (int e0 = 0; e0 < nvec; e0 += NW * 64) {
             const int e = e0 + tid;
             float4 v[G][2];
@@ -1311,12 +1344,12 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
                 if (!on) { v[g][0] = make_float4(INF, INF, INF, INF); v[g][1] = v[g][0]; }
             }
             if (e < nvec) {
+                const int j = (4 * e) / K, k0 = 4 * e - j * K;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const int f = 4 * e + c, k = f / nf, j = f - k * nf;  // nf is a compile-time power of two
-                        float* dst = tf + (k * M + s2 * nf + j) * G;
+                        float* dst = tf + ((k0 + c) * M + s2 * nf + j) * G;
 #pragma unroll
                         for (int g = 0; g < G; ++g) {
                             const float4 q = v[g][s2];
@@ -1726,28 +1759,53 @@ __global__ __launch_bounds__(256) void k_merge_items(const cis_hit* __restrict__
 }
 
 // The float32-prefilter scan hands over, per work item, the (float32 distance << 32 | position) pairs that survived
-// its bounds: a superset of the item's exact top `limit`.  One workgroup per query re-scores them exactly (the code
-// from the index, float64 table entries summed left to right as search.py:173 -- one candidate per thread, so the
-// loads of a whole query are in flight together) and ranks them by (dist, visit_rank, pos).
-template <int CAPM>
+// its bounds: a superset of the item's exact top `limit`.  One WAVE per query (four queries per workgroup, no
+// workgroup barrier: a query is a chain of dependent global loads, so what counts is how many queries a CU has in
+// flight) re-scores them exactly -- the code from the index, float64 table entries summed left to right as
+// search.py:173, one candidate per lane -- and ranks them by (dist, visit_rank, pos) with a bitonic sort in LDS.
+static __device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ascending bitonic sort of N (power of two >= 64) 128-bit keys (ka, kb) by one wave
+static __device__ __forceinline__ void wave_bitonic_lds(uint64_t* ka, uint64_t* kb, int N) {
+    const int lane = threadIdx.x & 63;
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (N >> 1); t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i + j;
+                const bool asc = ((i & k) == 0);
+                const uint64_t a0 = ka[i], b0 = kb[i], a1 = ka[p], b1 = kb[p];
+                const bool gt = (a0 > a1) || (a0 == a1 && b0 > b1);
+                if (gt == asc) { ka[i] = a1; kb[i] = b1; ka[p] = a0; kb[p] = b0; }
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
+template <int CAPM, int MT /* 4, 8, 16, or 0 = any M */>
 __global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restrict__ surv /* [n_items][S] */,
                                                          const int* __restrict__ item_n, const int64_t* __restrict__ item_off,
                                                          const WorkItem* __restrict__ items, const double* __restrict__ T,
                                                          const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids,
-                                                         int M, int K, int limit, int S,
+                                                         int nq, int M, int K, int limit, int S,
                                                          cis_hit* __restrict__ out_hits, int64_t* __restrict__ out_ids,
                                                          double* __restrict__ out_dists, int* __restrict__ out_n,
                                                          int32_t* __restrict__ out_cells, uint32_t* __restrict__ out_pos) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* ka = reinterpret_cast<uint64_t*>(smem);
-    uint64_t* kb = ka + CAPM;
-    int64_t* pay = reinterpret_cast<int64_t*>(kb + CAPM);  // (list << 32) | position inside the chunk
-    int* s_n = reinterpret_cast<int*>(pay + CAPM);
-    const int q = blockIdx.x, tid = threadIdx.x;
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wq;
+    if (q >= nq) return;  // whole wave; nothing below synchronises across waves
+    uint64_t* ka = reinterpret_cast<uint64_t*>(smem) + (size_t)wq * 2 * CAPM;
+    uint64_t* kb = ka + CAPM;  // (visit_rank << 32) | position inside the cell
     const int64_t first = item_off[q];
     const int n_lists = (int)(item_off[q + 1] - first);
     const int nf = M / 2;
-    int have = 0, l = 0, e = 0;
+    int have = 0, l = 0, e = 0, total = 0;
     while (true) {  // rounds: append up to CAPM - have entries, sort, keep `limit`
         int n = have;
         int room = CAPM - have;
@@ -1759,47 +1817,75 @@ __global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restr
                 const double* t0 = T + (int64_t)it.tab0 * nf * K;
                 const double* t1 = T + (int64_t)it.tab1 * nf * K;
                 const uint64_t* src = surv + (first + l) * (int64_t)S + e;
-                for (int x = tid; x < take; x += 256) {
-                    const uint32_t p = (uint32_t)src[x];
-                    ka[n + x] = (uint64_t)__double_as_longlong(adc64_global(codes, it.start + p, M, K, t0, t1));
-                    kb[n + x] = ((uint64_t)(uint32_t)it.rank << 32) | (uint32_t)(it.pos0 + (int)p);
-                    pay[n + x] = ((int64_t)l << 32) | p;
+                if constexpr (MT == 0) {
+                    for (int x = lane; x < take; x += 64) {
+                        const uint32_t p = (uint32_t)src[x];
+                        ka[n + x] = (uint64_t)__double_as_longlong(adc64_global(codes, it.start + p, M, K, t0, t1));
+                        kb[n + x] = ((uint64_t)(uint32_t)it.rank << 32) | (uint32_t)(it.pos0 + (int)p);
+                    }
+                } else {
+                    // four candidates per lane at a time: positions, then codes, then 4 x M table entries in flight together
+                    for (int x0 = 0; x0 < take; x0 += 256) {
+                        uint32_t p[4];
+                        bool on[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int x = x0 + i * 64 + lane;
+                            on[i] = x < take;
+                            p[i] = on[i] ? (uint32_t)src[x] : 0u;
+                        }
+                        CodeWords<MT> cw[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) cw[i] = load_code<MT>(codes, it.start + p[i]);
+                        double dd[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dd[i] = adc64_words<MT>(cw[i].w, K, t0, t1);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int x = x0 + i * 64 + lane;
+                            if (on[i]) {
+                                ka[n + x] = (uint64_t)__double_as_longlong(dd[i]);
+                                kb[n + x] = ((uint64_t)(uint32_t)it.rank << 32) | (uint32_t)(it.pos0 + (int)p[i]);
+                            }
+                        }
+                    }
                 }
             }
             n += take;
+            total += take;
             room -= take;
             e += take;
             if (e >= valid) { ++l; e = 0; }
         }
         int ns = 64;
         while (ns < n) ns <<= 1;
-        for (int x = n + tid; x < ns; x += 256) { ka[x] = ~0ull; kb[x] = ~0ull; pay[x] = -1; }
-        __syncthreads();
-        block_bitonic_rt<256, true>(ka, kb, pay, ns);
+        for (int x = n + lane; x < ns; x += 64) { ka[x] = ~0ull; kb[x] = ~0ull; }
+        wave_lds_sync();
+        wave_bitonic_lds(ka, kb, ns);
         have = n < limit ? n : limit;
         if (l >= n_lists) break;
     }
-    if (tid == 0) *s_n = 0;
-    __syncthreads();
-    int local = 0;
-    for (int x = tid; x < have; x += 256) local += (pay[x] >= 0) ? 1 : 0;
-    if (local) atomicAdd(s_n, local);
-    __syncthreads();
-    const int nv = *s_n;
+    const int nv = total < limit ? total : limit;
     const int64_t o = (int64_t)q * limit;
-    for (int x = tid; x < limit; x += 256) {
+    for (int x = lane; x < limit; x += 64) {
         cis_hit hh;
+        hh.dist = __longlong_as_double(0x7ff0000000000000LL);
+        hh.visit_rank = 0xffffffffu; hh.pos = 0xffffffffu; hh.id = -1; hh.cell = -1; hh.reserved = 0;
         if (x < nv) {
-            const WorkItem it = items[first + (pay[x] >> 32)];
-            hh.dist = __longlong_as_double((long long)ka[x]);
-            hh.visit_rank = (uint32_t)(kb[x] >> 32);
-            hh.pos = (uint32_t)kb[x];
-            hh.id = ids[it.start + (uint32_t)pay[x]];
-            hh.cell = it.cell;
-            hh.reserved = 0;
-        } else {
-            hh.dist = __longlong_as_double(0x7ff0000000000000LL);
-            hh.visit_rank = 0xffffffffu; hh.pos = 0xffffffffu; hh.id = -1; hh.cell = -1; hh.reserved = 0;
+            const uint32_t rank = (uint32_t)(kb[x] >> 32), pos = (uint32_t)kb[x];
+            // the work item this hit came from: same cell (visit rank), chunk that contains the position
+            for (int li = 0; li < n_lists; ++li) {
+                const WorkItem it = items[first + li];
+                const uint32_t rel = pos - (uint32_t)it.pos0;
+                if ((uint32_t)it.rank == rank && rel < (uint32_t)it.len) {
+                    hh.dist = __longlong_as_double((long long)ka[x]);
+                    hh.visit_rank = rank;
+                    hh.pos = pos;
+                    hh.id = ids[it.start + rel];
+                    hh.cell = it.cell;
+                    break;
+                }
+            }
         }
         if (out_hits) out_hits[o + x] = hh;
         if (out_ids) {
@@ -1809,7 +1895,7 @@ __global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restr
         if (out_cells) out_cells[o + x] = hh.cell;
         if (out_pos) out_pos[o + x] = hh.pos;
     }
-    if (tid == 0 && out_n) out_n[q] = nv;
+    if (lane == 0 && out_n) out_n[q] = nv;
 }
 
 template <int CAPM>
@@ -2258,7 +2344,7 @@ static void launch_scan_exact(int M, int64_t n_items, hipStream_t st, const Work
 
 // float32-prefilter kernel (v2): M in {4, 8, 16}, K <= 256, L <= 440 (a wave region holds L + 64 entries)
 static bool scan2_supported(int M, int K, int L) {
-    return (M == 4 || M == 8 || M == 16) && K <= 256 && ((M / 2) * K) % 4 == 0 && L >= 1 && L <= 440;
+    return (M == 4 || M == 8 || M == 16) && K <= 256 && K % 4 == 0 && L >= 1 && L <= 440;
 }
 
 struct Scan2Geom { int G, NW, U, S; size_t lds; };
@@ -2409,7 +2495,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
                            seg_max, plan, nullptr, nullptr, nullptr, nullptr);
     }
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(256), 0, st, plan, nq, item_off, tab_off, totals, qbound);
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, plan, nq, item_off, tab_off, totals, qbound);
     int64_t h_tot[3];
     CIS_CHECK_HIP(hipMemcpyAsync(h_tot, totals, sizeof(h_tot), hipMemcpyDeviceToHost, st));
     CIS_CHECK_HIP(hipStreamSynchronize(st));
@@ -2494,15 +2580,16 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             int* cell_cnt = qctr + 16;
             int* slot_off = cell_cnt + ix->ncells;
             int* slots = slot_off + ix->ncells;
-            CIS_CHECK_HIP(hipMemsetAsync(qctr, 0, 16 * sizeof(int), st));
             if (sort_items) {
-                CIS_CHECK_HIP(hipMemsetAsync(cell_cnt, 0, (size_t)ix->ncells * sizeof(int), st));
-                CIS_CHECK_HIP(hipMemsetAsync(slots, 0xff, (size_t)max_slots * G * sizeof(int), st));
+                const int64_t ninit = max_slots * G > ix->ncells ? max_slots * G : ix->ncells;
+                hipLaunchKernelGGL(k_slots_init, dim3((unsigned)ceil_div(ninit < 16 ? 16 : ninit, 256)), dim3(256), 0, st, qctr,
+                                   cell_cnt, (int)ix->ncells, slots, max_slots * G);
                 hipLaunchKernelGGL(k_item_hist, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, cell_cnt);
                 hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(256), 0, st, cell_cnt, slot_off, (int)ix->ncells, G, n_slots);
                 hipLaunchKernelGGL(k_item_scatter, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items,
                                    slot_off, cell_cnt, G, slots);
             } else {
+                CIS_CHECK_HIP(hipMemsetAsync(qctr, 0, 16 * sizeof(int), st));
                 hipLaunchKernelGGL(k_identity_slots, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, n_items, G, slots,
                                    n_slots);
             }
@@ -2521,15 +2608,19 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             const uint64_t* surv = ix->w_hits.as<uint64_t>();
             const uint8_t* codes = ix->d_codes.as<uint8_t>();
             const int64_t* ids = ix->d_ids.as<int64_t>();
-            if (L <= 128)
-                hipLaunchKernelGGL(k_merge_survivors<256>, dim3(nq), dim3(256), (size_t)256 * 24 + 16, st, surv, hitn, item_off, items, T,
-                                   codes, ids, M, K, L, S, out.hits, out.ids, out.dists, out.n_found, out.cells, out.pos);
-            else if (L <= 256)
-                hipLaunchKernelGGL(k_merge_survivors<512>, dim3(nq), dim3(256), (size_t)512 * 24 + 16, st, surv, hitn, item_off, items, T,
-                                   codes, ids, M, K, L, S, out.hits, out.ids, out.dists, out.n_found, out.cells, out.pos);
-            else
-                hipLaunchKernelGGL(k_merge_survivors<1024>, dim3(nq), dim3(256), (size_t)1024 * 24 + 16, st, surv, hitn, item_off, items, T,
-                                   codes, ids, M, K, L, S, out.hits, out.ids, out.dists, out.n_found, out.cells, out.pos);
+#define CIS_MERGE_SURV(CAP, MT)                                                                                              \
+    hipLaunchKernelGGL((k_merge_survivors<CAP, MT>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), (size_t)4 * CAP * 16, st, surv,  \
+                       hitn, item_off, items, T, codes, ids, nq, M, K, L, S, out.hits, out.ids, out.dists, out.n_found,        \
+                       out.cells, out.pos)
+#define CIS_MERGE_SURV_M(CAP)                                                                          \
+    do {                                                                                               \
+        if (M == 4) CIS_MERGE_SURV(CAP, 4); else if (M == 8) CIS_MERGE_SURV(CAP, 8); else CIS_MERGE_SURV(CAP, 16); \
+    } while (0)
+            if (L <= 128) CIS_MERGE_SURV_M(256);
+            else if (L <= 256) CIS_MERGE_SURV_M(512);
+            else CIS_MERGE_SURV_M(1024);
+#undef CIS_MERGE_SURV_M
+#undef CIS_MERGE_SURV
         } else if (L <= 512)
             hipLaunchKernelGGL(k_merge_items<1024>, dim3(nq), dim3(256), (size_t)1024 * 24 + 16, st, hits, hitn, item_off, L, S, out.hits,
                                out.ids, out.dists, out.n_found, out.cells, out.pos);
