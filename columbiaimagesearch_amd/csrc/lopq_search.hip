@@ -1296,6 +1296,44 @@ __device__ __forceinline__ void adc32g(const CodeWords<M>& c, const char* __rest
     }
 }
 
+// adc32g for two queries in two halves, so that the table reads of the NEXT candidate row can be issued before
+// the adds of the current one (the LDS pipe and the VALU then work at the same time inside one wave)
+template <int M>
+__device__ __forceinline__ void adc32_issue2(const CodeWords<M>& c, const char* __restrict__ tab, const RotConsts<M>& rc,
+                                             f32x2_t (&f)[M]) {
+    constexpr int SH = ((M == 4) ? 4 : (M == 8 ? 5 : 6)) + 1;  // log2(M * 2 * 4 bytes)
+    uint32_t D[(M + 3) / 4];
+    if constexpr (M == 4) {
+        D[0] = c.w[0];
+    } else if constexpr (M == 8) {
+        D[0] = rc.hsel ? c.w[1] : c.w[0];
+        D[1] = rc.hsel ? c.w[0] : c.w[1];
+    } else {
+        const bool b0 = rc.hsel & 1, b1 = rc.hsel & 2;
+        const uint32_t x01 = b0 ? c.w[1] : c.w[0], y01 = b0 ? c.w[0] : c.w[1];
+        const uint32_t x23 = b0 ? c.w[3] : c.w[2], y23 = b0 ? c.w[2] : c.w[3];
+        D[0] = b1 ? x23 : x01;
+        D[1] = b1 ? y23 : y01;
+        D[2] = b1 ? x01 : x23;
+        D[3] = b1 ? y01 : y23;
+    }
+#pragma unroll
+    for (int t = 0; t < M; ++t) {
+        const uint32_t k = __builtin_amdgcn_ubfe(D[t >> 2], rc.sh[t & 3], 8);
+        f[t] = *reinterpret_cast<const f32x2_t*>(tab + ((k << SH) | (rc.cj[t] << 1)));
+    }
+}
+
+template <int M>
+__device__ __forceinline__ void adc32_reduce2(f32x2_t (&f)[M], float (&out)[2]) {
+#pragma unroll
+    for (int st = 1; st < M; st <<= 1)
+#pragma unroll
+        for (int t = 0; t < M; t += 2 * st) f[t] = f[t] + f[t + st];
+    out[0] = f[0][0];
+    out[1] = f[0][1];
+}
+
 // One workgroup (NW waves) scans one cell chunk for `ng` <= G queries that all visit it.
 template <int M, int NR, int U, int G, int NW>
 __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (&item_idx)[G], int ng,
@@ -1427,8 +1465,23 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
             for (int u = 0; u < U; ++u) nxt[u] = CIS_LOAD_CODE((iter + NW) * 64 * U + u * 64 + lane);  // tail lanes are masked below
         }
         float d[U][G];
+#ifndef CIS_SCAN_NO_PIPELINE
+        if constexpr (G == 2) {
+            f32x2_t fbuf[2][M];
+            adc32_issue2<M>(cur[0], tab, rc, fbuf[0]);
 #pragma unroll
-        for (int u = 0; u < U; ++u) adc32g<M, G>(cur[u], tab, rc, d[u]);
+            for (int u = 0; u < U; ++u) {
+                if (u + 1 < U) adc32_issue2<M>(cur[u + 1], tab, rc, fbuf[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                adc32_reduce2<M>(fbuf[u & 1], d[u]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
+#endif
+        {
+#pragma unroll
+            for (int u = 0; u < U; ++u) adc32g<M, G>(cur[u], tab, rc, d[u]);
+        }
         // Fast path: one compare + ballot per (candidate row, query), ONE branch if no mask is set.  Lanes past
         // the end of the chunk (last iteration only) get NaN distances, which never compare <=; the duplicate
         // exclusion is applied in the slow path only.
