@@ -2014,9 +2014,9 @@ struct cis_index {
     // optional stage timing (hipEvents on the launch stream)
     bool force_exact_scan = false;  // tests: run every item through the float64 kernel
     bool profiling = false;
-    struct ProfRec { hipEvent_t ev[5]; bool has_scan; };
+    struct ProfRec { hipEvent_t ev[6]; bool has_scan; };  // ev[5]: just before the scan kernel (after slot building)
     std::vector<ProfRec> prof;
-    double prof_ms[4] = {0, 0, 0, 0};
+    double prof_ms[5] = {0, 0, 0, 0, 0};
     int64_t prof_launches = 0;
 
     bool owns(int64_t cell) const {
@@ -2337,7 +2337,7 @@ extern "C" int cis_index_set_scan_mode(cis_index* ix, int mode) {
     return CIS_OK;
 }
 
-extern "C" int cis_index_read_profile(cis_index* ix, double ms[4], int64_t* launches) {
+extern "C" int cis_index_read_profile(cis_index* ix, double ms[5], int64_t* launches) {
     CIS_REQUIRE(ix != nullptr && ms != nullptr, "NULL argument");
     for (auto& r : ix->prof) {
         CIS_CHECK_HIP(hipEventSynchronize(r.ev[4]));
@@ -2346,11 +2346,17 @@ extern "C" int cis_index_read_profile(cis_index* ix, double ms[4], int64_t* laun
             CIS_CHECK_HIP(hipEventElapsedTime(&t, r.ev[i], r.ev[i + 1]));
             ix->prof_ms[i] += t;
         }
-        if (r.has_scan) ix->prof_launches += 1;
+        if (r.has_scan) {
+            float t = 0.f;
+            CIS_CHECK_HIP(hipEventElapsedTime(&t, r.ev[5], r.ev[3]));
+            ix->prof_ms[4] += t;
+            ix->prof_launches += 1;
+            (void)hipEventDestroy(r.ev[5]);
+        }
         for (int i = 0; i < 5; ++i) (void)hipEventDestroy(r.ev[i]);
     }
     ix->prof.clear();
-    for (int i = 0; i < 4; ++i) { ms[i] = ix->prof_ms[i]; ix->prof_ms[i] = 0; }
+    for (int i = 0; i < 5; ++i) { ms[i] = ix->prof_ms[i]; ix->prof_ms[i] = 0; }
     if (launches) *launches = ix->prof_launches;
     ix->prof_launches = 0;
     return CIS_OK;
@@ -2646,9 +2652,13 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                 hipLaunchKernelGGL(k_identity_slots, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, n_items, G, slots,
                                    n_slots);
             }
+            CIS_TRY(mark(5));
             launch_scan2(M, geom, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, qbound);
         }
-        else launch_scan_exact(M, n_items, st, items, T, codes, ids, K, L, S, nullptr, hits, hitn);
+        else {
+            CIS_TRY(mark(5));
+            launch_scan_exact(M, n_items, st, items, T, codes, ids, K, L, S, nullptr, hits, hitn);
+        }
         ix->stats[3] += 1;
     }
     // 5. per-query merge

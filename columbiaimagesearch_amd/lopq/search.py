@@ -347,11 +347,11 @@ class LOPQSearcherHIP(LOPQSearcherBase):
 
     def read_profile(self):
         """Accumulated stage times in ms since the last read (waits for the recorded events)."""
-        ms = np.zeros(4, dtype=np.float64)
+        ms = np.zeros(5, dtype=np.float64)
         n = _lib.c_int64(0)
         _lib.check(_lib.lib().cis_index_read_profile(self._ix, _lib.ptr(ms), _lib.ctypes.byref(n)))
         return {"front_ms": float(ms[0]), "tables_ms": float(ms[1]), "scan_ms": float(ms[2]),
-                "merge_ms": float(ms[3]), "scan_launches": int(n.value)}
+                "merge_ms": float(ms[3]), "scan_kernel_ms": float(ms[4]), "scan_launches": int(n.value)}
 
 
 def merge_hits_dev(parts, with_codes=False):

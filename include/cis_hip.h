@@ -178,14 +178,15 @@ int cis_index_last_stats(cis_index* ix, int64_t stats[4]);
  * roofline).  While enabled every search records events around its stages; read_profile waits for
  * them, returns the accumulated milliseconds since the previous read and clears the accumulators:
  *   ms[0] front end (PCA, coarse distances, rank, multisequence plan)   ms[1] ADC tables
- *   ms[2] ADC scan + block top-k                                         ms[3] per-query merge
+ *   ms[2] ADC scan stage (slot list + scan kernel)                        ms[3] per-query merge
+ *   ms[4] the ADC scan kernel alone (events right before and after its launch)
  *   *launches = number of scan kernel launches accumulated. */
 int cis_index_set_profiling(cis_index* ix, int enable);
 /* ADC scan kernel selection: 0 = automatic (float32-prefilter kernel with exact float64 re-scoring
  * where it applies, exact float64 kernel otherwise), 1 = exact float64 kernel only.  Both produce
  * identical results; the switch exists so that tests can prove it. */
 int cis_index_set_scan_mode(cis_index* ix, int mode);
-int cis_index_read_profile(cis_index* ix, double ms[4], int64_t* launches);
+int cis_index_read_profile(cis_index* ix, double ms[5], int64_t* launches);
 
 /* ---- CNN descriptors: replaces the caffe forward behind SentiBankPyCaffeImgFeaturizer.featurize -----
  * (cufacesearch/cufacesearch/featurizer/sbpycaffe_img_featurizer.py:137-154; network

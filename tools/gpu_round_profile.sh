@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/gpu_round_profile.sh <tag>
+# full evidence run: GPU tests, default bench line, rocprofv3 kernel stats of the same command, PMC passes (FETCH / WRITE / SQ)
+tag=$1
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -3 > gpurun_out/${tag}_pytest_gpu.txt
+python bench.py > gpurun_out/${tag}_bench_full.log 2>&1
+grep '^{' gpurun_out/${tag}_bench_full.log | tail -1 > gpurun_out/${tag}_bench_line.json
+tools/gpu_bench_profile.sh ${tag} --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_summary.txt 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  tools/gpu_pmc.sh ${tag}_$c "$c" --steps 3 --warmup 1 --no-cpu-baseline --no-cnn > /dev/null 2>&1
+done
+tools/gpu_pmc.sh ${tag}_sq "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY" --steps 3 --warmup 1 --no-cpu-baseline --no-cnn > /dev/null 2>&1
+tools/gpu_pmc.sh ${tag}_l2 "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" --steps 3 --warmup 1 --no-cpu-baseline --no-cnn > /dev/null 2>&1
+cat gpurun_out/${tag}_pytest_gpu.txt; cat gpurun_out/${tag}_summary.txt | head -40; grep adc_scan gpurun_out/${tag}_*_pmc.csv
