@@ -24,6 +24,8 @@ struct ConvDesc {
     int64_t sN, sC, sH, sW;  // input strides in elements (NCHW for the first layer, NHWC afterwards)
     int relu;
     int kx_fastest;          // K ordering of the packed weights: 0: k = (ky*KW+kx)*ICg+ic, 1: k = (ic*KH+ky)*KW+kx (NCHW input)
+    int splitk = 1;          // > 1 (groups == 1, vector path only): blockIdx.z owns a K range and writes raw partial sums
+    int64_t part_stride = 0; // elements between the partial outputs of consecutive K ranges
 };
 
 // C[pixel][oc] = sum_k A[pixel][k] * Wp[k][oc] + bias[oc]; block tile BM x BN, 256 threads = 4 waves laid
@@ -45,7 +47,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
     __shared__ float Bs[2][BK][LDB];  // [stage][k][oc]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int g = blockIdx.z;
+    const int g = d.splitk > 1 ? 0 : blockIdx.z;
+    const int ksplit = d.splitk > 1 ? blockIdx.z : 0;
     const int64_t npix = (int64_t)d.N * d.OH * d.OW;
     const int64_t pix0 = (int64_t)blockIdx.x * BM;
     const int oc0 = blockIdx.y * BN;  // inside the group
@@ -79,9 +82,19 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const float* Wg = Wp + (int64_t)g * d.K * d.OCg;
-    const int nkt = (d.K + BK - 1) / BK;
+    const int nkt_all = (d.K + BK - 1) / BK;
+    const int nkt_per = (nkt_all + d.splitk - 1) / d.splitk;
+    const int kt_begin = ksplit * nkt_per;
+    const int nkt = (kt_begin + nkt_per < nkt_all) ? kt_begin + nkt_per : nkt_all;  // one past this block's last K tile
     // tap decode state: VEC -> of the stage (uniform); !VEC -> of this thread's k = k0 + (tid & 15)
     int ky = 0, kx = 0, ic = 0;
+    if (VEC && kt_begin > 0) {  // start of this block's K range
+        const int k0 = kt_begin * BK;
+        ic = k0 % d.ICg;
+        const int t = k0 / d.ICg;
+        kx = t % d.KW;
+        ky = t / d.KW;
+    }
     if (!VEC) {
         if (d.kx_fastest) {
             kx = tid & 15;
@@ -155,10 +168,12 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
             }
         }
     };
-    fetch(0);
-    stash(0);
+    if (kt_begin < nkt) {
+        fetch(kt_begin);
+        stash(kt_begin & 1);
+    }
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt_begin; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) fetch(kt + 1);
 #pragma unroll
@@ -189,9 +204,13 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int64_t p = pix0 + (wm * WM + i) * 32 + row;
                 if (p < npix) {
-                    float v = acc[i][j][r] + bv;
-                    if (d.relu) v = v > 0.f ? v : 0.f;
-                    out[p * d.OC + g * d.OCg + ocl] = v;
+                    if (d.splitk > 1) {
+                        out[(int64_t)ksplit * d.part_stride + p * d.OC + ocl] = acc[i][j][r];  // raw partial sum
+                    } else {
+                        float v = acc[i][j][r] + bv;
+                        if (d.relu) v = v > 0.f ? v : 0.f;
+                        out[p * d.OC + g * d.OCg + ocl] = v;
+                    }
                 }
             }
         }
@@ -265,6 +284,54 @@ __global__ void k_maxpool_lrn_nhwc(const float* __restrict__ in, float* __restri
         for (int cc = (c - half < 0 ? 0 : c - half); cc <= (c + half >= C ? C - 1 : c + half); ++cc) s = fmaf(sp[cc], sp[cc], s);
         out[pix * C + c] = sp[c] * powf(1.0f + (alpha / (float)size) * s, -beta);
     }
+}
+
+// The same with four channels per thread (16-byte loads and stores) and several output pixels per block;
+// x^-0.75 as rsqrt(x) * rsqrt(sqrt(x)) (the network's beta), powf otherwise.
+__global__ __launch_bounds__(256) void k_maxpool_lrn_nhwc_v4(const float* __restrict__ in, float* __restrict__ out, int N, int H,
+                                                             int W, int C, int OH, int OW, int size, float alpha, float beta,
+                                                             int ppb /* pixels per block */) {
+    extern __shared__ float sp[];  // [ppb][C]
+    const int tpp = C >> 2;        // threads per pixel
+    const int lp = threadIdx.x / tpp, lc = (threadIdx.x - lp * tpp) << 2;
+    const int64_t total = (int64_t)N * OH * OW;
+    const int64_t pix = (int64_t)blockIdx.x * ppb + lp;
+    const bool on = lp < ppb && pix < total;
+    if (on) {
+        const int ox = (int)(pix % OW);
+        const int oy = (int)((pix / OW) % OH);
+        const int64_t n = pix / ((int64_t)OW * OH);
+        float4 m = make_float4(-3.402823466e38f, -3.402823466e38f, -3.402823466e38f, -3.402823466e38f);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int y = oy * 2 + dy;
+            if (y >= H) break;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int x = ox * 2 + dx;
+                if (x >= W) break;
+                const float4 v = *reinterpret_cast<const float4*>(in + ((n * H + y) * W + x) * C + lc);
+                m.x = v.x > m.x ? v.x : m.x; m.y = v.y > m.y ? v.y : m.y;
+                m.z = v.z > m.z ? v.z : m.z; m.w = v.w > m.w ? v.w : m.w;
+            }
+        }
+        *reinterpret_cast<float4*>(sp + lp * C + lc) = m;
+    }
+    __syncthreads();
+    if (!on) return;
+    const int half = size / 2;
+    const float* row = sp + lp * C;
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lc + i;
+        float s = 0.f;
+        for (int cc = (c - half < 0 ? 0 : c - half); cc <= (c + half >= C ? C - 1 : c + half); ++cc) s = fmaf(row[cc], row[cc], s);
+        const float base = 1.0f + (alpha / (float)size) * s;
+        const float sc = (beta == 0.75f) ? rsqrtf(base) * rsqrtf(sqrtf(base)) : powf(base, -beta);
+        r[i] = row[c] * sc;
+    }
+    *reinterpret_cast<float4*>(out + pix * C + lc) = make_float4(r[0], r[1], r[2], r[3]);
 }
 
 // ---- dlib face ResNet helpers (NHWC) ---------------------------------------------------------------
@@ -460,11 +527,26 @@ extern "C" int cis_cnn_create(cis_cnn** out, int arch, const float* const* tenso
     return CIS_OK;
 }
 
+// out = relu?(bias + part[0] + part[1] + ...) in that order (deterministic), four outputs per thread
+__global__ void k_splitk_reduce(const float* __restrict__ part, int splitk, int64_t part_stride, const float* __restrict__ bias,
+                                float* __restrict__ out, int64_t n4, int OC, int relu) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int oc = (int)((i * 4) % OC);
+    float4 a = bias ? *reinterpret_cast<const float4*>(bias + oc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < splitk; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)s * part_stride + i * 4);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (relu) { a.x = a.x > 0.f ? a.x : 0.f; a.y = a.y > 0.f ? a.y : 0.f; a.z = a.z > 0.f ? a.z : 0.f; a.w = a.w > 0.f ? a.w : 0.f; }
+    *reinterpret_cast<float4*>(out + i * 4) = a;
+}
+
 template <int WM, int WN, int WAVES_M, int WAVES_N>
 static void launch_conv_cfg(const ConvDesc& d, const float* in, const float* w, const float* b, float* out, hipStream_t st) {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
     const int64_t npix = (int64_t)d.N * d.OH * d.OW;
-    dim3 g((unsigned)ceil_div(npix, BM), (unsigned)ceil_div(d.OCg, BN), (unsigned)d.groups);
+    dim3 g((unsigned)ceil_div(npix, BM), (unsigned)ceil_div(d.OCg, BN), (unsigned)(d.splitk > 1 ? d.splitk : d.groups));
     const bool vec = d.sC == 1 && d.ICg % 16 == 0 && d.C % 4 == 0;
     if (vec) hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, true>), g, dim3(256), 0, st, in, w, b, out, d);
     else hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, false>), g, dim3(256), 0, st, in, w, b, out, d);
@@ -548,6 +630,7 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
     const size_t act_elems = (size_t)n * 55 * 55 * 96;
     CIS_TRY(c->act0.reserve(act_elems * sizeof(float)));
     CIS_TRY(c->act1.reserve(act_elems * sizeof(float)));
+    CIS_TRY(c->act2.reserve((size_t)4 * n * 4096 * sizeof(float)));  // split-K partial sums of the fc layers
     float* bufs[2] = {c->act0.as<float>(), c->act1.as<float>()};
     const float* cur = d_nchw;
     int which = 0;
@@ -572,9 +655,15 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
         if (kPoolAfter[l] && kLrnAfter[l]) {
             const int OH = (H - 3 + 1) / 2 + 1, OW = (W - 3 + 1) / 2 + 1;
             float* po = bufs[which];
-            const int threads = C <= 64 ? 64 : (C <= 128 ? 128 : 256);
-            hipLaunchKernelGGL(k_maxpool_lrn_nhwc, dim3((unsigned)((int64_t)n * OH * OW)), dim3(threads), (size_t)C * sizeof(float), st,
-                               cur, po, n, H, W, C, OH, OW, 5, 1e-4f, 0.75f);
+            if (C % 4 == 0 && C <= 1024) {
+                const int tpp = C / 4, ppb = 256 / tpp;
+                hipLaunchKernelGGL(k_maxpool_lrn_nhwc_v4, dim3((unsigned)ceil_div((int64_t)n * OH * OW, ppb)), dim3(256),
+                                   (size_t)ppb * C * sizeof(float), st, cur, po, n, H, W, C, OH, OW, 5, 1e-4f, 0.75f, ppb);
+            } else {
+                const int threads = C <= 64 ? 64 : (C <= 128 ? 128 : 256);
+                hipLaunchKernelGGL(k_maxpool_lrn_nhwc, dim3((unsigned)((int64_t)n * OH * OW)), dim3(threads), (size_t)C * sizeof(float), st,
+                                   cur, po, n, H, W, C, OH, OW, 5, 1e-4f, 0.75f);
+            }
             cur = po; which ^= 1; H = OH; W = OW;
         } else if (kPoolAfter[l]) {
             const int OH = (H - 3 + 1) / 2 + 1, OW = (W - 3 + 1) / 2 + 1;
@@ -600,7 +689,20 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
         d.relu = 1;
         d.kx_fastest = 0;
         float* o = (l == 1) ? d_feats : bufs[which];
-        launch_conv(d, cur, c->fc[l].d_w, c->fc[l].d_b, o, st);
+        // few output tiles (n x 4096) and a long K: split K over four blocks per tile so that every CU holds several
+        // workgroups (the K loop is a chain of dependent loads), then add the partial sums in a fixed order
+        const int splitk = (fin % 16 == 0 && (int64_t)n * 4096 % 4 == 0 && n <= 4096) ? 4 : 1;
+        if (splitk > 1) {
+            d.splitk = splitk;
+            d.part_stride = (int64_t)n * 4096;
+            float* part = c->act2.as<float>();
+            launch_conv(d, cur, c->fc[l].d_w, nullptr, part, st);
+            const int64_t n4 = (int64_t)n * 4096 / 4;
+            hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, part, splitk, d.part_stride,
+                               c->fc[l].d_b, o, n4, 4096, 1);
+        } else {
+            launch_conv(d, cur, c->fc[l].d_w, c->fc[l].d_b, o, st);
+        }
         cur = o; which ^= 1; fin = 4096;
     }
     CIS_CHECK_HIP(hipGetLastError());
