@@ -554,11 +554,18 @@ static void launch_conv_cfg(const ConvDesc& d, const float* in, const float* w, 
 
 static void launch_conv(const ConvDesc& d, const float* in, const float* w, const float* b, float* out, hipStream_t st) {
     const int64_t npix = (int64_t)d.N * d.OH * d.OW;
+    const int z = d.splitk > 1 ? d.splitk : d.groups;
+    auto blocks = [&](int bm, int bn) { return ceil_div(npix, bm) * ceil_div(d.OCg, bn) * z; };
+    const int64_t want = 2 * 256;  // at least two workgroups per CU, else a smaller tile
     if (d.OCg <= 32) launch_conv_cfg<1, 1, 4, 1>(d, in, w, b, out, st);                // 128 x 32 tiles
-    else if (d.OCg <= 64) launch_conv_cfg<2, 1, 2, 2>(d, in, w, b, out, st);           // 128 x 64 tiles
     else if (npix <= 2048) launch_conv_cfg<1, 1, 1, 4>(d, in, w, b, out, st);          // fc layers: 32 x 128 tiles fill the chip
-    else if (d.OCg % 96 == 0 && d.OCg % 128 != 0) launch_conv_cfg<1, 3, 4, 1>(d, in, w, b, out, st);  // 96, 192: 128 x 96
-    else launch_conv_cfg<2, 2, 2, 2>(d, in, w, b, out, st);                          // 128 x 128
+    else if (d.OCg <= 64) {
+        if (blocks(128, 64) >= want) launch_conv_cfg<2, 1, 2, 2>(d, in, w, b, out, st);   // 128 x 64 tiles
+        else launch_conv_cfg<1, 1, 2, 2>(d, in, w, b, out, st);                           // 64 x 64
+    } else if (d.OCg % 96 == 0 && d.OCg % 128 != 0) launch_conv_cfg<1, 3, 4, 1>(d, in, w, b, out, st);  // 96, 192: 128 x 96
+    else if (blocks(128, 128) >= want) launch_conv_cfg<2, 2, 2, 2>(d, in, w, b, out, st);  // 128 x 128
+    else if (blocks(128, 64) >= want) launch_conv_cfg<2, 1, 2, 2>(d, in, w, b, out, st);   // 128 x 64
+    else launch_conv_cfg<1, 1, 2, 2>(d, in, w, b, out, st);                               // 64 x 64
 }
 
 static ConvDesc nhwc_conv(int n, int H, int W, int C, int OC, int k, int stride, int pad, int relu) {
