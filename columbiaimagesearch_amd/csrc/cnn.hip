@@ -26,6 +26,8 @@ struct ConvDesc {
     int kx_fastest;          // K ordering of the packed weights: 0: k = (ky*KW+kx)*ICg+ic, 1: k = (ic*KH+ky)*KW+kx (NCHW input)
     int splitk = 1;          // > 1 (groups == 1, vector path only): blockIdx.z owns a K range and writes raw partial sums
     int64_t part_stride = 0; // elements between the partial outputs of consecutive K ranges
+    const float* res = nullptr;  // residual input [npix][resC] added before the ReLU (channels >= resC get nothing): dlib add_prev
+    int resC = 0;
 };
 
 // C[pixel][oc] = sum_k A[pixel][k] * Wp[k][oc] + bias[oc]; block tile BM x BN, 256 threads = 4 waves laid
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
                         out[(int64_t)ksplit * d.part_stride + p * d.OC + ocl] = acc[i][j][r];  // raw partial sum
                     } else {
                         float v = acc[i][j][r] + bv;
+                        if (d.res && ocl < d.resC) v += d.res[p * d.resC + ocl];
                         if (d.relu) v = v > 0.f ? v : 0.f;
                         out[p * d.OC + g * d.OCg + ocl] = v;
                     }
@@ -605,17 +608,32 @@ static int cnn_forward_dlib(cis_cnn* c, const float* d_in, int n, float* d_feats
         ConvDesc da = nhwc_conv(n, H, W, C, b.cout, 3, s, p, 1);
         launch_conv(da, x, c->dl[1 + 2 * i].d_w, c->dl[1 + 2 * i].d_b, T1, st);
         ConvDesc db = nhwc_conv(n, da.OH, da.OW, b.cout, b.cout, 3, 1, 1, 0);
-        launch_conv(db, T1, c->dl[2 + 2 * i].d_w, c->dl[2 + 2 * i].d_b, T2, st);
-        const float* skip = x;
         int SH = H, SW = W, SC = C;
-        if (b.down) {
-            SH = (H - 2) / 2 + 1; SW = (W - 2) / 2 + 1;
-            hipLaunchKernelGGL(k_avgpool2_nhwc, grid((int64_t)n * SH * SW * C), dim3(256), 0, st, x, T1, n, H, W, C, SH, SW);
-            skip = T1;  // T1 is free again: conv b has consumed it (same stream)
-        }
+        if (b.down) { SH = (H - 2) / 2 + 1; SW = (W - 2) / 2 + 1; }
         const int OH = db.OH > SH ? db.OH : SH, OW = db.OW > SW ? db.OW : SW, OC = b.cout > SC ? b.cout : SC;
-        hipLaunchKernelGGL(k_add_relu_pad, grid((int64_t)n * OH * OW * OC), dim3(256), 0, st, T2, db.OH, db.OW, b.cout, skip, SH, SW, SC,
-                           other, n, OH, OW, OC);
+        // add_prev + relu inside the second convolution's epilogue when both branches have the output's spatial size
+        // (the residual may have fewer channels); the two smallest down blocks grow spatially and keep the separate pass
+        const bool fuse = db.OH == OH && db.OW == OW && SH == OH && SW == OW && OC == b.cout;
+        const float* skip = x;
+        if (b.down) {
+            // the pooled skip branch goes to T2 when fused (T1 still feeds the second convolution), else to T1 afterwards
+            if (fuse) {
+                hipLaunchKernelGGL(k_avgpool2_nhwc, grid((int64_t)n * SH * SW * C), dim3(256), 0, st, x, T2, n, H, W, C, SH, SW);
+                skip = T2;
+            }
+        }
+        if (fuse) {
+            db.res = skip; db.resC = SC; db.relu = 1;
+            launch_conv(db, T1, c->dl[2 + 2 * i].d_w, c->dl[2 + 2 * i].d_b, other, st);
+        } else {
+            launch_conv(db, T1, c->dl[2 + 2 * i].d_w, c->dl[2 + 2 * i].d_b, T2, st);
+            if (b.down) {
+                hipLaunchKernelGGL(k_avgpool2_nhwc, grid((int64_t)n * SH * SW * C), dim3(256), 0, st, x, T1, n, H, W, C, SH, SW);
+                skip = T1;  // T1 is free again: conv b has consumed it (same stream)
+            }
+            hipLaunchKernelGGL(k_add_relu_pad, grid((int64_t)n * OH * OW * OC), dim3(256), 0, st, T2, db.OH, db.OW, b.cout, skip, SH, SW, SC,
+                               other, n, OH, OW, OC);
+        }
         float* t = x; x = other; other = t;
         H = OH; W = OW; C = OC;
     }
