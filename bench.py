@@ -312,9 +312,18 @@ def main():
             "parity": parity,
             "build": {"encode_s": encode_s, "total_s": build_s, "encode_vectors_per_s": len(my_chunks) * chunk_n / encode_s},
         }
-        print(json.dumps(line))
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the last thing on stdout: flush what native libraries (the RCCL banner) still hold in C stdio first
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
