@@ -135,8 +135,9 @@ __global__ __launch_bounds__(256) void k_pca_gemm(const TX* __restrict__ X, cons
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-    for (int k0 = 0; k0 < D_in; k0 += 16) {
-        // stage A: 64 rows x 16 k  (1024 elements, 4 per thread)
+    // register prefetch: the global loads of slab k0+16 are in flight while slab k0 is multiplied
+    double ra[4], rb[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = tid + e * 256;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void k_pca_gemm(const TX* __restrict__ X, cons
                     v = (double)X[(row0 + r) * D_in + k0 + k] - mu[k0 + k];
                 }
             }
-            sA[k][r] = v;
+            ra[e] = v;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -158,9 +159,19 @@ __global__ __launch_bounds__(256) void k_pca_gemm(const TX* __restrict__ X, cons
             const int k = idx / 64, c = idx % 64;
             double v = 0.0;
             if (k0 + k < D_in && col0 + c < D) v = P[(int64_t)(k0 + k) * D + col0 + c];
-            sB[k][c] = v;
+            rb[e] = v;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < D_in; k0 += 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            sA[idx % 16][idx / 16] = ra[e];
+            sB[idx / 64][idx % 64] = rb[e];
         }
         __syncthreads();
+        if (k0 + 16 < D_in) fetch(k0 + 16);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             double a[4], b[4];

@@ -224,7 +224,8 @@ __global__ __launch_bounds__(64) void k_multiseq_list(const CT* __restrict__ sor
 // exclusive scans over the queries of one batch (single block of 1024 threads); totals[0]=items, [1]=tables, [2]=cands
 __global__ __launch_bounds__(1024) void k_plan_scan(const PlanOut* __restrict__ plan, int nq, int64_t* __restrict__ item_off,
                                                     int64_t* __restrict__ tab_off, int64_t* __restrict__ totals,
-                                                    unsigned long long* __restrict__ qbound /* [nq] -> +inf */) {
+                                                    unsigned long long* __restrict__ qbound /* [nq] -> +inf */,
+                                                    volatile int64_t* __restrict__ host_totals /* pinned, mapped */) {
     __shared__ int64_t s_items[16], s_tabs[16], s_cand[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int per = (nq + 1023) / 1024;
@@ -258,6 +259,8 @@ __global__ __launch_bounds__(1024) void k_plan_scan(const PlanOut* __restrict__ 
             ri += yi; rt += yt; rc += s_cand[k];
         }
         totals[0] = ri; totals[1] = rt; totals[2] = rc;
+        host_totals[0] = ri; host_totals[1] = rt; host_totals[2] = rc;  // straight into pinned host memory: no staged copy
+        __threadfence_system();
         item_off[nq] = ri; tab_off[nq] = rt;
     }
     __syncthreads();
@@ -2014,6 +2017,8 @@ struct cis_index {
     // optional stage timing (hipEvents on the launch stream)
     bool force_exact_scan = false;  // tests: run every item through the float64 kernel
     bool profiling = false;
+    int64_t* h_totals = nullptr;    // pinned, device-mapped: the plan totals land here without a copy
+    int64_t* d_h_totals = nullptr;
     struct ProfRec { hipEvent_t ev[6]; bool has_scan; };  // ev[5]: just before the scan kernel (after slot building)
     std::vector<ProfRec> prof;
     double prof_ms[5] = {0, 0, 0, 0, 0};
@@ -2049,6 +2054,7 @@ extern "C" void cis_index_destroy(cis_index* ix) {
                       &ix->w_hitn, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
                       &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px, &ix->w_T32};
     for (DevBuf* b : bufs) b->release();
+    if (ix->h_totals) (void)hipHostFree(ix->h_totals);
     delete ix;
 }
 
@@ -2554,9 +2560,12 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
                            seg_max, plan, nullptr, nullptr, nullptr, nullptr);
     }
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, plan, nq, item_off, tab_off, totals, qbound);
-    int64_t h_tot[3];
-    CIS_CHECK_HIP(hipMemcpyAsync(h_tot, totals, sizeof(h_tot), hipMemcpyDeviceToHost, st));
+    if (!ix->h_totals) {
+        CIS_CHECK_HIP(hipHostMalloc((void**)&ix->h_totals, 4 * sizeof(int64_t), hipHostMallocMapped));
+        CIS_CHECK_HIP(hipHostGetDevicePointer((void**)&ix->d_h_totals, ix->h_totals, 0));
+    }
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, plan, nq, item_off, tab_off, totals, qbound, ix->d_h_totals);
+    volatile int64_t* h_tot = ix->h_totals;
     CIS_CHECK_HIP(hipStreamSynchronize(st));
     const int64_t n_items = h_tot[0], n_tabs = h_tot[1];
     CIS_REQUIRE(n_items < ((int64_t)1 << 31) && n_tabs < ((int64_t)1 << 31), "query batch too large");
@@ -2568,7 +2577,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         const double need = (double)n_items * S_ * (fast_ ? sizeof(uint64_t) : sizeof(cis_hit)) + (double)n_tabs * nf * K * sizeof(double);
         if (need > 4.0e9 && nq > 1) return CIS_RETRY_SMALLER;
     }
-    ix->stats[0] += h_tot[2];
+    ix->stats[0] += (int64_t)h_tot[2];
     ix->stats[1] += n_items;
     ix->stats[2] += n_tabs;
     // 3. emit items + table list
@@ -2757,6 +2766,69 @@ extern "C" int cis_index_search_partial_dev(cis_index* ix, const void* dQ, int q
     return search_all(ix, dQ, q_dtype, nq, quota, L, o, (hipStream_t)stream);
 }
 
+// exclusive scan of the per-query hit counts (single block) and the packing of the valid row prefixes
+__global__ __launch_bounds__(1024) void k_pack_scan(const int32_t* __restrict__ cnt, int nq, int64_t* __restrict__ off,
+                                                    int64_t* __restrict__ total) {
+    __shared__ int64_t s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int64_t run = 0;  // all queries before this block-sized chunk
+    for (int base = 0; base < nq; base += 1024) {
+        const int q = base + tid;
+        const int64_t c = q < nq ? cnt[q] : 0;
+        int64_t x = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_w[wv] = x;
+        __syncthreads();
+        int64_t wp = 0, all = 0;
+        for (int k = 0; k < 16; ++k) { const int64_t y = s_w[k]; if (k < wv) wp += y; all += y; }
+        if (q < nq) off[q] = run + wp + x - c;
+        run += all;
+        __syncthreads();
+    }
+    if (tid == 0) *total = run;
+}
+
+__global__ void k_pack_hits(const cis_hit* __restrict__ dense /* [nq][L] */, const int32_t* __restrict__ cnt,
+                            const int64_t* __restrict__ off, int nq, int L, cis_hit* __restrict__ packed) {
+    const int q = blockIdx.x;
+    const int c = cnt[q];
+    const int64_t o = off[q];
+    for (int x = threadIdx.x; x < c; x += blockDim.x) packed[o + x] = dense[(int64_t)q * L + x];
+}
+
+extern "C" int cis_index_search_partial_packed_dev(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota, int limit,
+                                                   cis_hit* d_packed, int32_t* d_cnt, int64_t* d_off, int64_t* d_total,
+                                                   int32_t* d_visited, void* stream) {
+    int L;
+    CIS_TRY(effective_limit(quota, limit, &L));
+    CIS_REQUIRE(ix != nullptr && d_cnt && d_off && d_total && (L == 0 || d_packed), "NULL buffer");
+    hipStream_t st = (hipStream_t)stream;
+    if (nq == 0 || L == 0) {
+        CIS_CHECK_HIP(hipMemsetAsync(d_total, 0, sizeof(int64_t), st));
+        if (nq > 0) {
+            CIS_CHECK_HIP(hipMemsetAsync(d_cnt, 0, (size_t)nq * sizeof(int32_t), st));
+            CIS_CHECK_HIP(hipMemsetAsync(d_off, 0, (size_t)nq * sizeof(int64_t), st));
+        }
+        if (nq == 0) return CIS_OK;
+    }
+    CIS_CHECK_HIP(hipSetDevice(ix->m->device));
+    CIS_TRY(ix->w_part.reserve((size_t)nq * (L > 0 ? L : 1) * sizeof(cis_hit)));
+    SearchOut o{};
+    o.hits = ix->w_part.as<cis_hit>();
+    o.n_found = d_cnt;
+    o.visited = d_visited;
+    CIS_TRY(search_all(ix, dQ, q_dtype, nq, quota, L, o, st));
+    if (L == 0) return CIS_OK;
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, d_cnt, nq, d_off, d_total);
+    hipLaunchKernelGGL(k_pack_hits, dim3(nq), dim3(64), 0, st, ix->w_part.as<cis_hit>(), d_cnt, d_off, nq, L, d_packed);
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
+}
+
 static int merge_parts(const cis_hit* d_parts, int world, int nq, int L, int64_t* d_ids, double* d_dists,
                        int32_t* d_nf, int32_t* d_cells, uint32_t* d_pos, hipStream_t st) {
     if (nq == 0 || L == 0) return CIS_OK;
@@ -2766,6 +2838,104 @@ static int merge_parts(const cis_hit* d_parts, int world, int nq, int L, int64_t
         hipLaunchKernelGGL(k_merge_parts<2048>, dim3(nq), dim3(256), (size_t)2048 * 24 + 16, st, d_parts, world, nq, L, d_ids, d_dists, d_nf, d_cells, d_pos);
     else
         hipLaunchKernelGGL(k_merge_parts<4096>, dim3(nq), dim3(256), (size_t)4096 * 24 + 16, st, d_parts, world, nq, L, d_ids, d_dists, d_nf, d_cells, d_pos);
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
+}
+
+// Merge of PACKED per-shard hit lists: shard w contributed parts[w*stride + off[w*nq+q] .. + cnt[w*nq+q]) for query q
+// (its valid hits only, in query order).  One wave per query; same ranking key as everywhere: (dist, visit_rank, pos).
+template <int CAPM>
+__global__ __launch_bounds__(256) void k_merge_packed(const cis_hit* __restrict__ parts, int world, int64_t stride,
+                                                      const int64_t* __restrict__ off, const int32_t* __restrict__ cnt, int nq,
+                                                      int limit, int64_t* __restrict__ out_ids, double* __restrict__ out_dists,
+                                                      int* __restrict__ out_n, int32_t* __restrict__ out_cells,
+                                                      uint32_t* __restrict__ out_pos) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wq;
+    if (q >= nq) return;
+    uint64_t* ka = reinterpret_cast<uint64_t*>(smem) + (size_t)wq * 3 * CAPM;
+    uint64_t* kb = ka + CAPM;
+    uint64_t* pay = kb + CAPM;  // index of the hit in parts
+    int have = 0, l = 0, e = 0, total = 0;
+    while (true) {
+        int n = have;
+        int room = CAPM - have;
+        while (l < world && room > 0) {
+            const int valid = cnt[(int64_t)l * nq + q];
+            const int take = (valid - e < room) ? (valid - e) : room;
+            const int64_t base = (int64_t)l * stride + off[(int64_t)l * nq + q] + e;
+            for (int x = lane; x < take; x += 64) {
+                const cis_hit hh = parts[base + x];
+                ka[n + x] = (uint64_t)__double_as_longlong(hh.dist);
+                kb[n + x] = ((uint64_t)hh.visit_rank << 32) | hh.pos;
+                pay[n + x] = (uint64_t)(base + x);
+            }
+            n += take; total += take; room -= take; e += take;
+            if (e >= valid) { ++l; e = 0; }
+        }
+        int ns = 64;
+        while (ns < n) ns <<= 1;
+        for (int x = n + lane; x < ns; x += 64) { ka[x] = ~0ull; kb[x] = ~0ull; pay[x] = ~0ull; }
+        wave_lds_sync();
+        // bitonic sort with payload
+        for (int k = 2; k <= ns; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = lane; t < (ns >> 1); t += 64) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int p = i + j;
+                    const bool asc = ((i & k) == 0);
+                    const uint64_t a0 = ka[i], b0 = kb[i], a1 = ka[p], b1 = kb[p];
+                    const bool gt = (a0 > a1) || (a0 == a1 && b0 > b1);
+                    if (gt == asc) {
+                        ka[i] = a1; kb[i] = b1; ka[p] = a0; kb[p] = b0;
+                        const uint64_t y = pay[i]; pay[i] = pay[p]; pay[p] = y;
+                    }
+                }
+                wave_lds_sync();
+            }
+        }
+        have = n < limit ? n : limit;
+        if (l >= world) break;
+    }
+    const int nv = total < limit ? total : limit;
+    const int64_t o = (int64_t)q * limit;
+    for (int x = lane; x < limit; x += 64) {
+        int64_t id = -1;
+        double dist = __longlong_as_double(0x7ff8000000000000LL);
+        int32_t cell = -1;
+        uint32_t pos = 0xffffffffu;
+        if (x < nv) {
+            const cis_hit hh = parts[pay[x]];
+            id = hh.id; dist = hh.dist; cell = hh.cell; pos = hh.pos;
+        }
+        out_ids[o + x] = id;
+        out_dists[o + x] = dist;
+        if (out_cells) out_cells[o + x] = cell;
+        if (out_pos) out_pos[o + x] = pos;
+    }
+    if (lane == 0 && out_n) out_n[q] = nv;
+}
+
+extern "C" int cis_merge_packed_dev(const cis_hit* d_parts, int world, int64_t stride, const int64_t* d_off,
+                                    const int32_t* d_cnt, int nq, int limit, int64_t* d_ids, double* d_dists,
+                                    int32_t* d_n_found, int32_t* d_cells, uint32_t* d_pos, void* stream) {
+    CIS_REQUIRE(world >= 1 && nq >= 0 && limit >= 0 && limit <= MAX_LIMIT && stride >= 0, "bad merge arguments");
+    CIS_REQUIRE(nq == 0 || limit == 0 || (d_parts && d_off && d_cnt && d_ids && d_dists), "NULL buffer");
+    CIS_TRY(cis_lazy_init());
+    if (nq == 0 || limit == 0) return CIS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g((unsigned)ceil_div(nq, 4));
+    if (limit <= 128)
+        hipLaunchKernelGGL(k_merge_packed<256>, g, dim3(256), (size_t)4 * 3 * 256 * 8, st, d_parts, world, stride, d_off, d_cnt, nq, limit,
+                           d_ids, d_dists, d_n_found, d_cells, d_pos);
+    else if (limit <= 512)
+        hipLaunchKernelGGL(k_merge_packed<1024>, g, dim3(256), (size_t)4 * 3 * 1024 * 8, st, d_parts, world, stride, d_off, d_cnt, nq,
+                           limit, d_ids, d_dists, d_n_found, d_cells, d_pos);
+    else {
+        cis_set_error("packed merge supports limit <= 512");
+        return CIS_EUNSUPPORTED;
+    }
     CIS_CHECK_HIP(hipGetLastError());
     return CIS_OK;
 }

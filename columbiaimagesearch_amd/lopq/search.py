@@ -330,6 +330,22 @@ class LOPQSearcherHIP(LOPQSearcherBase):
                                                            visited.data_ptr(), stream))
         return hits, visited
 
+    def search_partial_packed_dev(self, q, quota=10, limit=None):
+        """This shard's ranked hits packed for the exchange: dict(packed int64 [nq*L, 4] (first `total` rows valid),
+        cnt int32 [nq], off int64 [nq], total int64 [1], visited int32 [nq], L)."""
+        import torch
+        L, code, stream = self._dev_args(q, quota, limit)
+        nq = q.shape[0]
+        dev = q.device
+        out = {"packed": torch.empty((max(nq * L, 1), 4), dtype=torch.int64, device=dev),
+               "cnt": torch.empty(nq, dtype=torch.int32, device=dev), "off": torch.empty(nq, dtype=torch.int64, device=dev),
+               "total": torch.empty(1, dtype=torch.int64, device=dev), "visited": torch.empty(nq, dtype=torch.int32, device=dev),
+               "L": L}
+        _lib.check(_lib.lib().cis_index_search_partial_packed_dev(
+            self._ix, q.data_ptr(), code, nq, int(quota), -1 if limit is None else int(limit), out["packed"].data_ptr(),
+            out["cnt"].data_ptr(), out["off"].data_ptr(), out["total"].data_ptr(), out["visited"].data_ptr(), stream))
+        return out
+
     def last_stats(self):
         """Counters of the last search: candidates scanned, work items, tables, scan launches."""
         st = np.zeros(4, dtype=np.int64)
@@ -376,9 +392,45 @@ def merge_hits_dev(parts, with_codes=False):
     return out
 
 
+def pack_hits_dev(hits):
+    """Valid hits of a partial result [nq, L, 32] (uint8) packed in query order: (packed [total, 4] int64, cnt [nq] int32).
+    Valid hits are a prefix of every row (id >= 0).  The boolean indexing synchronises with the device."""
+    import torch
+    nq, L = int(hits.shape[0]), int(hits.shape[1])
+    hv = hits.view(torch.int64).view(nq, L, 4)
+    valid = hv[:, :, 2] >= 0
+    return hv[valid], valid.sum(dim=1, dtype=torch.int32)
+
+
+def merge_packed_dev(parts, off, cnt, nq, L, with_codes=False):
+    """Merge packed per-shard hit lists: parts [world, stride, 4] int64 (cis_hit records), off [world, nq] int64,
+    cnt [world, nq] int32 -> dict like search_batch_dev.  This is what follows the all-gather over xGMI: only valid
+    hits travel (about nq*L records in total instead of world*nq*L)."""
+    import torch
+    world, stride = int(parts.shape[0]), int(parts.shape[1])
+    if not (parts.is_cuda and parts.is_contiguous() and parts.dtype == torch.int64 and parts.shape[2] == 4):
+        raise ValueError("parts must be a contiguous int64 [world, stride, 4] tensor on the GPU")
+    if not (off.is_contiguous() and off.dtype == torch.int64 and cnt.is_contiguous() and cnt.dtype == torch.int32
+            and tuple(off.shape) == (world, nq) and tuple(cnt.shape) == (world, nq)):
+        raise ValueError("off / cnt must be contiguous [world, nq] int64 / int32 tensors")
+    dev = parts.device
+    out = {"ids": torch.empty((nq, L), dtype=torch.int64, device=dev),
+           "dists": torch.empty((nq, L), dtype=torch.float64, device=dev),
+           "n_found": torch.zeros(nq, dtype=torch.int32, device=dev)}
+    if with_codes:
+        out["cells"] = torch.empty((nq, L), dtype=torch.int32, device=dev)
+        out["pos"] = torch.empty((nq, L), dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().cis_merge_packed_dev(parts.data_ptr(), world, stride, off.data_ptr(), cnt.data_ptr(), nq, L,
+                                               out["ids"].data_ptr(), out["dists"].data_ptr(), out["n_found"].data_ptr(),
+                                               out["cells"].data_ptr() if with_codes else None,
+                                               out["pos"].data_ptr() if with_codes else None,
+                                               torch.cuda.current_stream(dev).cuda_stream))
+    return out
+
+
 # the reference's other class names resolve to the HIP searcher so that config strings and pickles
 # written for them keep loading
 LOPQSearcher = LOPQSearcherHIP
 
 __all__ = ["LOPQSearcherBase", "LOPQSearcherHIP", "LOPQSearcher", "LOPQModel", "LOPQModelPCA", "LOPQCode",
-           "multisequence", "multisequence_batch", "merge_hits_dev"]
+           "multisequence", "multisequence_batch", "merge_hits_dev", "merge_packed_dev", "pack_hits_dev"]

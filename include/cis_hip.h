@@ -163,11 +163,22 @@ int cis_index_get_codes(cis_index* ix, const int32_t* cells, const uint32_t* pos
  * id = -1, dist = +inf), d_visited [nq] (identical on every rank). */
 int cis_index_search_partial_dev(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota,
                                  int limit, cis_hit* d_hits, int32_t* d_visited, void* stream);
+/* The same, packed for the exchange: d_cnt[q] valid hits of query q at d_packed[d_off[q] ..], queries in order,
+ * *d_total hits in all (d_packed needs room for nq * L records; only the first *d_total are written). */
+int cis_index_search_partial_packed_dev(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota, int limit,
+                                        cis_hit* d_packed, int32_t* d_cnt, int64_t* d_off, int64_t* d_total,
+                                        int32_t* d_visited, void* stream);
 /* Sharded search, step 2 (after the all-gather): merge `world` partial lists
  * d_parts [world][nq][L] into the final ranking. */
 int cis_merge_hits_dev(const cis_hit* d_parts, int world, int nq, int limit, int64_t* d_ids,
                        double* d_dists, int32_t* d_n_found, int32_t* d_cells /* or NULL */,
                        uint32_t* d_pos /* or NULL */, void* stream);
+
+/* The same for PACKED partial lists (what travels over xGMI): shard w contributed its valid hits only, in query
+ * order, d_parts[w*stride + d_off[w*nq + q] .. + d_cnt[w*nq + q]) for query q.  limit <= 512. */
+int cis_merge_packed_dev(const cis_hit* d_parts, int world, int64_t stride, const int64_t* d_off /* [world][nq] */,
+                         const int32_t* d_cnt /* [world][nq] */, int nq, int limit, int64_t* d_ids, double* d_dists,
+                         int32_t* d_n_found, int32_t* d_cells /* or NULL */, uint32_t* d_pos /* or NULL */, void* stream);
 
 /* Counters of the last search on this handle (for bench.py's roofline):
  *   stats[0] candidates scanned (sum over queries of retrieved items on this shard)

@@ -49,6 +49,17 @@ def _worker(rank, world, port, name, quota, limit, ret):
             merged = O.merge_partials([parts[w, qi] for w in range(world)], limit)
             ids, dists, visited = ix.search(Q[qi], quota=quota, limit=limit)
             ok = ok and visited == vis[qi] and np.array_equal(merged["id"], ids) and np.array_equal(merged["dist"], dists)
+        # the packed exchange (valid hits only) carries the same lists
+        from columbiaimagesearch_amd.distributed import exchange_packed
+        hv = torch.from_numpy(hits.view(np.int64).reshape(nq, limit, 4).copy())
+        valid = hv[:, :, 2] >= 0
+        pparts, off, cnt_all = exchange_packed(hv[valid], valid.sum(dim=1, dtype=torch.int32))
+        for w in range(world):
+            for qi in range(nq):
+                c, o = int(cnt_all[w, qi]), int(off[w, qi])
+                lst = pparts[w, o:o + c].numpy().view(O.HIT_DTYPE).reshape(-1)
+                ref_lst = parts[w, qi][parts[w, qi]["id"] >= 0]
+                ok = ok and np.array_equal(lst, ref_lst)
         allv = [torch.zeros(nq, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(allv, torch.from_numpy(vis))
         ok = ok and all(torch.equal(allv[0], v) for v in allv)

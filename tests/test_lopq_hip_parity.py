@@ -217,6 +217,28 @@ def test_cell_sharded_search_equals_single(name, world):
         a, b = out["dists"].cpu().numpy(), ref["dists"]
         np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
         np.testing.assert_array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+        # the packed exchange format (what ShardedSearcher sends over RCCL): valid hits only, padded to the largest shard
+        from columbiaimagesearch_amd.lopq.search import merge_packed_dev, pack_hits_dev
+        packed = [pack_hits_dev(h) for h in parts]
+        stride = max(max(int(pk.shape[0]) for pk, _ in packed), 1)
+        buf = torch.zeros((world, stride, 4), dtype=torch.int64, device="cuda")
+        for r, (pk, _) in enumerate(packed):
+            buf[r, :pk.shape[0]] = pk
+        cnt = torch.stack([c for _, c in packed]).contiguous()
+        off = (torch.cumsum(cnt, dim=1, dtype=torch.int64) - cnt).contiguous()
+        out2 = merge_packed_dev(buf, off, cnt, len(Q), limit)
+        torch.cuda.synchronize()
+        for sh, (pk, c) in zip(shards, packed):  # the library's own packing == packing the dense partial list
+            pp = sh.search_partial_packed_dev(q, quota=quota, limit=limit)
+            tot = int(pp["total"].item())
+            assert tot == int(pk.shape[0])
+            assert torch.equal(pp["packed"][:tot], pk) and torch.equal(pp["cnt"], c)
+            assert torch.equal(pp["off"], torch.cumsum(c, 0, dtype=torch.int64) - c)
+        np.testing.assert_array_equal(out2["ids"].cpu().numpy(), ref["ids"])
+        np.testing.assert_array_equal(out2["n_found"].cpu().numpy(), ref["n_found"])
+        a2 = out2["dists"].cpu().numpy()
+        np.testing.assert_array_equal(np.isnan(a2), np.isnan(b))
+        np.testing.assert_array_equal(a2[~np.isnan(a2)], b[~np.isnan(b)])
 
 
 def test_device_entry_points_match_host_entry_points():
