@@ -113,3 +113,28 @@ def test_dlib_resnet_matches_torch_cpu(tmp_path):
     d = f.featurize_chips(chips[:2])
     assert d.dtype == np.float64 and d.shape == (2, get_feat_size("dlib"))
     np.testing.assert_array_equal(d, got[:2].astype(np.float64))
+
+
+def test_batch_ingest_matches_per_item_chain():
+    """CNN -> L2 normalise -> LOPQ encode -> insert on the GPU == the same chain item by item through the host surfaces."""
+    import torch
+    from conftest import load_golden
+    from oracle import dlib_oracle as D
+    from columbiaimagesearch_amd.featurizer import DLibFaceNet
+    from columbiaimagesearch_amd.ingest import BatchIngest
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    from test_lopq_hip_parity import hip_model
+    z, X, Q = load_golden("c2")  # 128-d PCA model: the dlib descriptor size
+    model = hip_model(z)
+    net = DLibFaceNet(D.synthetic_weights(0))
+    chips = D.synthetic_chips(6, seed=5)
+    s = LOPQSearcherHIP(model)
+    ing = BatchIngest(net, model, s, feat_dtype=torch.float64)
+    x = torch.as_tensor(chips, dtype=torch.float32).cuda().contiguous()
+    assert ing.ingest_batch(x, ids=np.arange(100, 106)) == 6 and s.get_nb_indexed() == 6
+    feats = net.forward(chips).astype(np.float64)
+    feats /= np.linalg.norm(feats, axis=1, keepdims=True)
+    coarse, fine = model.predict_batch(feats)
+    for i in range(6):
+        items = s.get_cell((int(coarse[i, 0]), int(coarse[i, 1])))
+        assert any(it[0] == 100 + i and tuple(it[1][1]) == tuple(int(v) for v in fine[i]) for it in items)
