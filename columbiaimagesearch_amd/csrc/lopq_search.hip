@@ -2940,6 +2940,51 @@ extern "C" int cis_merge_packed_dev(const cis_hit* d_parts, int world, int64_t s
     return CIS_OK;
 }
 
+// ---- exact re-ranking with resident features (searcher_lopqhbase.py:864-912): true L2 distance of a query to the
+// original features of its first `L` results.  One wave per (query, result); arithmetic in the feature dtype like
+// np.linalg.norm(normed_feat - res_fts[pos]) (float32 features -> float32 distance), returned as float64.
+template <typename T>
+__global__ __launch_bounds__(256) void k_rerank(const T* __restrict__ feats, int64_t n_feats, int D, const T* __restrict__ Q,
+                                                const int64_t* __restrict__ rows, int64_t n_pairs, int L,
+                                                double* __restrict__ dists) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= n_pairs) return;
+    const int64_t r = rows[pair];
+    if (r < 0 || r >= n_feats) {  // feature not resident: the caller keeps the ADC distance (reference :889-893)
+        if (lane == 0) dists[pair] = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
+    const T* x = feats + r * D;
+    const T* q = Q + (pair / L) * D;
+    T acc = (T)0;
+    for (int i = lane; i < D; i += 64) {
+        const T df = q[i] - x[i];
+        acc = fma(df, df, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc = acc + __shfl_xor(acc, o);
+    if (lane == 0) dists[pair] = (double)(T)sqrt(acc);
+}
+
+extern "C" int cis_rerank_dev(const void* d_feats, int f_dtype, int64_t n_feats, int D, const void* d_q, int nq,
+                              const int64_t* d_rows, int L, double* d_dists, void* stream) {
+    CIS_REQUIRE(f_dtype == CIS_F32 || f_dtype == CIS_F64, "f_dtype must be 4 or 8");
+    CIS_REQUIRE(n_feats >= 0 && D > 0 && nq >= 0 && L >= 0, "bad re-ranking arguments");
+    if (nq == 0 || L == 0) return CIS_OK;
+    CIS_REQUIRE(d_feats && d_q && d_rows && d_dists, "NULL buffer");
+    CIS_TRY(cis_lazy_init());
+    const int64_t n_pairs = (int64_t)nq * L;
+    const dim3 g((unsigned)ceil_div(n_pairs, 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (f_dtype == CIS_F32)
+        hipLaunchKernelGGL(k_rerank<float>, g, dim3(256), 0, st, (const float*)d_feats, n_feats, D, (const float*)d_q, d_rows, n_pairs, L, d_dists);
+    else
+        hipLaunchKernelGGL(k_rerank<double>, g, dim3(256), 0, st, (const double*)d_feats, n_feats, D, (const double*)d_q, d_rows, n_pairs, L, d_dists);
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
+}
+
 extern "C" int cis_merge_hits_dev(const cis_hit* d_parts, int world, int nq, int limit, int64_t* d_ids,
                                   double* d_dists, int32_t* d_n_found, int32_t* d_cells, uint32_t* d_pos,
                                   void* stream) {

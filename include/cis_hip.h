@@ -180,6 +180,13 @@ int cis_merge_packed_dev(const cis_hit* d_parts, int world, int64_t stride, cons
                          const int32_t* d_cnt /* [world][nq] */, int nq, int limit, int64_t* d_ids, double* d_dists,
                          int32_t* d_n_found, int32_t* d_cells /* or NULL */, uint32_t* d_pos /* or NULL */, void* stream);
 
+/* Exact re-ranking with features resident in HBM (cufacesearch/cufacesearch/searcher/searcher_lopqhbase.py:864-912:
+ * dist = np.linalg.norm(normed_feat - res_fts[pos]) for the first results of a query).  d_feats [n_feats][D] and
+ * d_q [nq][D] in f_dtype (4 = float32, 8 = float64; the distance is computed in that type, NOT squared), d_rows [nq][L]
+ * = feature row of each result (-1: not resident -> NaN, the caller keeps the ADC distance as the reference does). */
+int cis_rerank_dev(const void* d_feats, int f_dtype, int64_t n_feats, int D, const void* d_q, int nq,
+                   const int64_t* d_rows, int L, double* d_dists, void* stream);
+
 /* Counters of the last search on this handle (for bench.py's roofline):
  *   stats[0] candidates scanned (sum over queries of retrieved items on this shard)
  *   stats[1] (query, cell) work items   stats[2] ADC tables built   stats[3] scan kernel launches */

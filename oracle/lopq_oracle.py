@@ -524,3 +524,22 @@ def recall_at(true_nn, result_ids, ks=(1, 10, 100)):
         hits = sum(1 for t, r in zip(true_nn, result_ids) if t in list(r[:k]))
         out[k] = hits / float(len(true_nn))
     return out
+
+
+def rerank(q, feats_by_id, results, rerank_nb, max_returned=None, near_dup_th=None):
+    """Exact re-ranking restated from cufacesearch/cufacesearch/searcher/searcher_lopqhbase.py:864-912.
+    results: list of (id, adc_dist) in ADC order; feats_by_id: {id: feature} (a missing id keeps its ADC distance,
+    :889-893).  dist = np.linalg.norm(q - feat) in the features' dtype (:887); near-duplicate filter and the
+    max_returned cut use the index BEFORE the re-order (:894-899); final order = np.argsort(dists) (:902-903)."""
+    results = results[:min(rerank_nb, len(results))]
+    ids, dists = [], []
+    for ires, (rid, adc) in enumerate(results):
+        dist = adc
+        if rid in feats_by_id:
+            dist = np.linalg.norm(q - feats_by_id[rid])
+        if near_dup_th is None or dist <= near_dup_th:
+            if not max_returned or ires < max_returned:
+                ids.append(rid)
+                dists.append(dist)
+    order = np.argsort(dists, axis=0, kind="stable") if ids else []
+    return [ids[i] for i in order], [dists[i] for i in order]

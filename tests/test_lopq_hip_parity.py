@@ -361,3 +361,32 @@ def test_multisequence_and_predict_cluster_functions(name):
     np.testing.assert_array_equal(ids, O.predict_cluster(np.ascontiguousarray(Xq[:, :h]), om.Cs[0]))
     one = predict_cluster(np.ascontiguousarray(Xq[0, :h]), m.Cs[0])
     assert one == ids[0] and one.dtype == np.uint8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_exact_rerank_matches_reference_semantics(dtype):
+    """True-L2 re-ranking with resident features == the restated searcher_lopqhbase.py:864-912 loop (missing features
+    keep the ADC distance, near-duplicate threshold, max_returned on the pre-sort index)."""
+    import torch
+    from oracle import lopq_oracle as O
+    from columbiaimagesearch_amd.rerank import ResidentFeatures
+    rs = np.random.RandomState(3)
+    n, D, nq, L = 500, 96, 7, 20
+    feats = rs.randn(n, D).astype(dtype)
+    feats /= np.linalg.norm(feats, axis=1, keepdims=True)
+    Q = (feats[rs.randint(0, n, nq)] + 0.05 * rs.randn(nq, D)).astype(dtype)
+    ids = np.stack([rs.choice(n + 40, L, replace=False) for _ in range(nq)]).astype(np.int64)  # some ids have no feature
+    ids[2, 15:] = -1
+    adc = np.sort(rs.rand(nq, L), axis=1)
+    adc[2, 15:] = np.nan
+    rf = ResidentFeatures(torch.as_tensor(feats).cuda().contiguous())
+    for kw in [dict(rerank_nb=12), dict(rerank_nb=20, max_returned=8), dict(rerank_nb=20, near_dup_th=1.0)]:
+        got = rf.rerank(torch.as_tensor(Q).cuda().contiguous(), ids, adc, **kw)
+        for qi in range(nq):
+            res = [(int(ids[qi, i]), float(adc[qi, i])) for i in range(L) if ids[qi, i] >= 0]
+            fb = {int(i): feats[i] for i in ids[qi] if 0 <= i < n}
+            eids, ed = O.rerank(Q[qi], fb, res, kw["rerank_nb"], kw.get("max_returned"), kw.get("near_dup_th"))
+            gids, gd = got[qi]
+            assert [int(i) for i in gids] == [int(i) for i in eids]
+            np.testing.assert_allclose(gd, np.asarray(ed, dtype=np.float64), rtol=2e-6 if dtype == np.float32 else 1e-13)
