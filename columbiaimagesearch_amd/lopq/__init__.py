@@ -1,9 +1,9 @@
 """Drop-in for the reference's vendored ``lopq`` package (lopq/lopq/__init__.py)."""
 from . import model, search, utils
 from .model import LOPQCode, LOPQModel, LOPQModelPCA
-from .search import LOPQSearcher, LOPQSearcherHIP, multisequence
+from .search import LOPQSearcher, LOPQSearcherHIP, LOPQSearcherLMDB, multisequence
 
-__all__ = ["LOPQModel", "LOPQModelPCA", "LOPQSearcher", "LOPQSearcherHIP", "LOPQCode", "multisequence", "model", "search",
+__all__ = ["LOPQModel", "LOPQModelPCA", "LOPQSearcher", "LOPQSearcherHIP", "LOPQSearcherLMDB", "LOPQCode", "multisequence", "model", "search",
            "utils"]
 
 

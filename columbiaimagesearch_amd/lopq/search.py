@@ -428,9 +428,131 @@ def merge_packed_dev(parts, off, cnt, nq, L, with_codes=False):
     return out
 
 
-# the reference's other class names resolve to the HIP searcher so that config strings and pickles
-# written for them keep loading
+class LOPQSearcherLMDB(LOPQSearcherBase):
+    """LOPQSearcherLMDB (lopq/lopq/search.py:385-499) with the index on the GPU.
+
+    What distinguishes the LMDB searcher from the dict one is kept exactly: an entry's key is the cell (2 x uint16,
+    ``array('H')`` :425-427) followed by ``bytes(id)`` (:462, the py2 ``str`` of the id); ``put`` REPLACES an existing
+    key (:465, last write wins -- the dict searcher keeps the first); ``get_cell`` walks the keys in byte order
+    (:482-499), so items of a cell -- and therefore results with equal distances -- come in key order; ids come back
+    through ``id_lambda``.  The key/value store lives on the host (a dict; mirrored into LMDB at ``lmdb_path`` when the
+    ``lmdb`` module is importable, which it is not in the build image, so persistence is untested); the device index is
+    rebuilt in key order before the first search after an insert."""
+
+    def __init__(self, model, lmdb_path=None, id_lambda=int):
+        super(LOPQSearcherLMDB, self).__init__()
+        self.model = model
+        self.lmdb_path = lmdb_path
+        self.id_lambda = id_lambda
+        self._store = {}   # cell (c0, c1) -> {key suffix bytes: fine tuple}
+        self._dev = None   # LOPQSearcherHIP over the key-ordered arrays
+        self._suffix_of_slot = []
+        self.env = None
+        if lmdb_path is not None:
+            try:
+                import lmdb
+            except ImportError:
+                lmdb = None
+            if lmdb is not None:
+                self.env = lmdb.open(self.lmdb_path, map_size=1024 * 1000000 * 32, max_dbs=1)  # :416
+                self.index_db = self.env.open_db(b"index")
+                with self.env.begin(db=self.index_db) as txn:
+                    for key, value in txn.cursor():
+                        self._store.setdefault(self.decode_cell(key[:4]), {})[bytes(key[4:])] = self.decode_fine_codes(value)
+        self.nb_indexed = sum(len(v) for v in self._store.values())
+
+    @staticmethod
+    def encode_cell(cell):
+        import array
+        return array.array("H", [int(cell[0]), int(cell[1])]).tobytes()
+
+    @staticmethod
+    def decode_cell(cell_bytes):
+        import array
+        a = array.array("H")
+        a.frombytes(bytes(cell_bytes))
+        return tuple(a.tolist())
+
+    @staticmethod
+    def encode_fine_codes(fine):
+        return bytes(bytearray(int(v) for v in fine))
+
+    @staticmethod
+    def decode_fine_codes(fine_bytes):
+        return tuple(bytearray(fine_bytes))
+
+    @staticmethod
+    def _key_suffix(item_id):
+        return str(item_id).encode("latin1") if not isinstance(item_id, bytes) else item_id  # py2 bytes(id) == str(id)
+
+    def get_nb_indexed(self):
+        self.nb_indexed = sum(len(v) for v in self._store.values())
+        return self.nb_indexed
+
+    def add_codes(self, codes, ids=None):
+        id_iter = count() if ids is None else iter(ids)
+        txn = self.env.begin(db=self.index_db, write=True) if self.env is not None else None
+        try:
+            for item_id, code in zip(id_iter, codes):
+                cell = (int(code[0][0]), int(code[0][1]))
+                fine = tuple(int(v) for v in code[1])
+                suffix = self._key_suffix(item_id)
+                self._store.setdefault(cell, {})[suffix] = fine  # put(): an existing key is overwritten
+                if txn is not None:
+                    txn.put(self.encode_cell(cell) + suffix, self.encode_fine_codes(fine))
+        finally:
+            if txn is not None:
+                txn.commit()
+                self.env.sync()
+        self._dev = None
+        self.get_nb_indexed()
+
+    def add_codes_array(self, coarse, fine, ids=None, dedup=True):
+        coarse = np.asarray(coarse).reshape(-1, 2)
+        fine = np.asarray(fine).reshape(coarse.shape[0], -1)
+        self.add_codes([((c[0], c[1]), tuple(f)) for c, f in zip(coarse, fine)], ids)
+
+    def get_cell(self, cell):
+        ct = _code_dtype(self.model.V)
+        c = (int(cell[0]), int(cell[1]))
+        items = self._store.get(c, {})
+        return [(self.id_lambda(k), LOPQCode((ct(c[0]), ct(c[1])), items[k])) for k in sorted(items)]
+
+    def _device_index(self):
+        if self._dev is None:
+            cells = sorted(self._store)
+            n = sum(len(self._store[c]) for c in cells)
+            coarse = np.empty((n, 2), dtype=np.uint16)
+            fine = np.empty((n, self.model.M), dtype=np.uint8)
+            self._suffix_of_slot = []
+            i = 0
+            for c in cells:
+                items = self._store[c]
+                for k in sorted(items):  # byte order of the keys inside the cell = the cursor's order
+                    coarse[i] = c
+                    fine[i] = items[k]
+                    self._suffix_of_slot.append(k)
+                    i += 1
+            self._dev = LOPQSearcherHIP(self.model)
+            if n:
+                self._dev.add_codes_array(coarse, fine, ids=np.arange(n, dtype=np.int64), dedup=False)
+        return self._dev
+
+    def search_batch(self, X, quota=10, limit=None, with_codes=False):
+        """ids are slots of the key-ordered arrays: map with ``caller_ids``."""
+        return self._device_index().search_batch(X, quota=quota, limit=limit, with_codes=with_codes)
+
+    def caller_ids(self, dev_ids):
+        return [self.id_lambda(self._suffix_of_slot[int(i)]) for i in dev_ids if i >= 0]
+
+    def search(self, x, quota=10, limit=None, with_dists=False):
+        dev = self._device_index()
+        results, visited = dev.search(x, quota=quota, limit=limit, with_dists=with_dists)
+        return [r._replace(id=self.id_lambda(self._suffix_of_slot[int(r.id)])) for r in results], visited
+
+
+# the reference's dict searcher's name resolves to the HIP searcher so that config strings written for it keep working
 LOPQSearcher = LOPQSearcherHIP
 
-__all__ = ["LOPQSearcherBase", "LOPQSearcherHIP", "LOPQSearcher", "LOPQModel", "LOPQModelPCA", "LOPQCode",
+__all__ = ["LOPQSearcherBase", "LOPQSearcherHIP", "LOPQSearcher", "LOPQSearcherLMDB", "LOPQModel", "LOPQModelPCA", "LOPQCode",
            "multisequence", "multisequence_batch", "merge_hits_dev", "merge_packed_dev", "pack_hits_dev"]

@@ -543,3 +543,27 @@ def rerank(q, feats_by_id, results, rerank_nb, max_returned=None, near_dup_th=No
                 dists.append(dist)
     order = np.argsort(dists, axis=0, kind="stable") if ids else []
     return [ids[i] for i in order], [dists[i] for i in order]
+
+
+class OracleKeyOrderIndex(OracleIndex):
+    """The LMDB searcher's index semantics (lopq/lopq/search.py:385-499) without LMDB: key = cell + bytes(id) (py2:
+    str(id)); put() replaces an existing key (:465); get_cell walks keys in byte order (:482-499); ids come back through
+    id_lambda.  **Parity unpinned**: the reference class needs the `lmdb` module, absent here, so no golden vector could
+    be generated from it; this follows its source."""
+
+    def __init__(self, model, id_lambda=int):
+        OracleIndex.__init__(self, model)
+        self.id_lambda = id_lambda
+        self.store = {}
+
+    def add_codes(self, codes, ids=None):
+        if ids is None:
+            ids = range(len(codes))
+        for item_id, code in zip(ids, codes):
+            cell = (int(code[0][0]), int(code[0][1]))
+            self.store.setdefault(cell, {})[str(item_id).encode("latin1")] = LOPQCode(tuple(code[0]), tuple(code[1]))
+        self.nb_indexed = sum(len(v) for v in self.store.values())
+
+    def get_cell(self, cell):
+        items = self.store.get((int(cell[0]), int(cell[1])), {})
+        return [(self.id_lambda(k), items[k]) for k in sorted(items)]

@@ -390,3 +390,35 @@ def test_exact_rerank_matches_reference_semantics(dtype):
             gids, gd = got[qi]
             assert [int(i) for i in gids] == [int(i) for i in eids]
             np.testing.assert_allclose(gd, np.asarray(ed, dtype=np.float64), rtol=2e-6 if dtype == np.float32 else 1e-13)
+
+
+@pytest.mark.gpu
+def test_lmdb_order_searcher_matches_key_order_restatement():
+    """LOPQSearcherLMDB semantics on the GPU index: byte order of str(id) inside a cell decides ties, a re-added id
+    replaces its code (last write wins), ids come back through id_lambda."""
+    from oracle import lopq_oracle as O
+    from columbiaimagesearch_amd.lopq import LOPQSearcherLMDB
+    z, X, Q = load_golden("c2")
+    m = hip_model(z)
+    om = O.OracleModel.from_npz(z)
+    n = 3000
+    coarse, fine = z["coarse"][:n], z["fine"][:n]
+    codes = [((int(c[0]), int(c[1])), tuple(int(v) for v in f)) for c, f in zip(coarse, fine)]
+    ids = [(i * 7919) % 10007 for i in range(n)]  # distinct, not monotone: "10" sorts before "9" as bytes
+    s = LOPQSearcherLMDB(m)
+    o = O.OracleKeyOrderIndex(om)
+    s.add_codes(codes, ids); o.add_codes(codes, ids)
+    # duplicates of one code in one cell (ties) and an overwrite of an existing id with another code
+    dup = [codes[0]] * 12
+    dup_ids = [5, 40, 300, 31, 299, 1000003, 20, 2, 100, 1, 11, 3]
+    s.add_codes(dup, dup_ids); o.add_codes(dup, dup_ids)
+    s.add_codes([codes[1]], [ids[0]]); o.add_codes([codes[1]], [ids[0]])
+    assert s.get_nb_indexed() == o.nb_indexed
+    cell = codes[0][0]
+    assert [(i, tuple(int(v) for v in c[1])) for i, c in s.get_cell(cell)] == [(i, tuple(c[1])) for i, c in o.get_cell(cell)]
+    for qi in range(8):
+        for quota, limit in [(10, 10), (400, 50)]:
+            got, vis = s.search(Q[qi], quota=quota, limit=limit, with_dists=True)
+            res, evis = o.search(Q[qi], quota=quota, limit=limit)
+            assert vis == evis and [r.id for r in got] == [r[0] for r in res]
+            np.testing.assert_allclose([r.dist for r in got], [r[2] for r in res], rtol=1e-9)
