@@ -2480,7 +2480,76 @@ static void launch_scan2(int M, const Scan2Geom& g, int64_t n_items, hipStream_t
     else launch_scan2_m<16>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
 }
 
-static const int MAX_LIMIT = 3072;
+// ---- large `limit` (above what the LDS top-k kernels hold): exact distance of EVERY candidate, stable segmented
+// radix sort per query (rocPRIM, csrc/lopq_sort.hip).  Candidates are laid out in retrieval order (items of a query
+// in visit order, positions ascending), so a stable sort on the distance alone yields the (dist, visit_rank, pos)
+// ranking = the reference's stable sorted() over the retrieved list (search.py:210).
+int cis_seg_sort_u64(void* temp, size_t* temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint64_t* vals_in,
+                     uint64_t* vals_out, int64_t n, int nseg, const int64_t* seg_begin, hipStream_t st);
+int cis_exclusive_scan_i64(void* temp, size_t* temp_bytes, const int64_t* in, int64_t* out, int64_t n, hipStream_t st);
+
+__global__ void k_item_lens(const WorkItem* __restrict__ items, int64_t n, int64_t* __restrict__ lens) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) lens[i] = items[i].len;
+}
+
+__global__ void k_seg_begin(const int64_t* __restrict__ cand_start, const int64_t* __restrict__ item_off, int nq, int64_t n_items,
+                            int64_t n_cand, int64_t* __restrict__ seg) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nq) return;
+    const int64_t it = item_off[q];
+    seg[q] = (q == nq || it >= n_items) ? n_cand : cand_start[it];
+}
+
+__global__ __launch_bounds__(256) void k_adc_all(const WorkItem* __restrict__ items, const int64_t* __restrict__ cand_start,
+                                                 const double* __restrict__ T, const uint8_t* __restrict__ codes, int M, int K,
+                                                 uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
+    const WorkItem it = items[blockIdx.x];
+    const int nf = M / 2;
+    const double* t0 = T + (int64_t)it.tab0 * nf * K;
+    const double* t1 = T + (int64_t)it.tab1 * nf * K;
+    const int64_t o = cand_start[blockIdx.x];
+    for (int p = blockIdx.y * blockDim.x + threadIdx.x; p < it.len; p += gridDim.y * blockDim.x) {
+        keys[o + p] = (uint64_t)__double_as_longlong(adc64_global(codes, it.start + p, M, K, t0, t1));
+        vals[o + p] = ((uint64_t)blockIdx.x << 32) | (uint32_t)p;
+    }
+}
+
+__global__ void k_emit_sorted(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ vals, const int64_t* __restrict__ seg,
+                              const WorkItem* __restrict__ items, const int64_t* __restrict__ ids, int nq, int limit,
+                              cis_hit* __restrict__ out_hits, int64_t* __restrict__ out_ids, double* __restrict__ out_dists,
+                              int* __restrict__ out_n, int32_t* __restrict__ out_cells, uint32_t* __restrict__ out_pos) {
+    const int q = blockIdx.y;
+    const int64_t a = seg[q], n = seg[q + 1] - a;
+    const int nv = (int)(n < limit ? n : limit);
+    const int64_t o = (int64_t)q * limit;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < limit; x += gridDim.x * blockDim.x) {
+        cis_hit hh;
+        hh.dist = __longlong_as_double(0x7ff0000000000000LL);
+        hh.visit_rank = 0xffffffffu; hh.pos = 0xffffffffu; hh.id = -1; hh.cell = -1; hh.reserved = 0;
+        if (x < nv) {
+            const uint64_t v = vals[a + x];
+            const WorkItem it = items[v >> 32];
+            const uint32_t p = (uint32_t)v;
+            hh.dist = __longlong_as_double((long long)keys[a + x]);
+            hh.visit_rank = (uint32_t)it.rank;
+            hh.pos = (uint32_t)it.pos0 + p;
+            hh.id = ids[it.start + p];
+            hh.cell = it.cell;
+        }
+        if (out_hits) out_hits[o + x] = hh;
+        if (out_ids) {
+            out_ids[o + x] = hh.id;
+            out_dists[o + x] = (x < nv) ? hh.dist : __longlong_as_double(0x7ff8000000000000LL);
+        }
+        if (out_cells) out_cells[o + x] = hh.cell;
+        if (out_pos) out_pos[o + x] = hh.pos;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && out_n) out_n[q] = nv;
+}
+
+static const int MAX_LDS_LIMIT = 3072;  // ranked results per query the LDS top-k kernels hold
+static const int MAX_LIMIT = 1 << 24;  // with the sorted path: bounded by the workspace only
 
 // one sub-batch of queries (device pointers); writes ranked partial hits [nq][L] and visited [nq]
 static const int CIS_RETRY_SMALLER = 1;  // internal: the batch does not fit the workspace budget, halve it
@@ -2574,7 +2643,9 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         // exhaustive quota: every query visits every cell) is split by the caller and planned again.
         const bool fast_ = scan2_supported(M, K, L) && !ix->force_exact_scan;
         const int64_t S_ = fast_ ? scan2_geom(M, K, L, nq).S : L;
-        const double need = (double)n_items * S_ * (fast_ ? sizeof(uint64_t) : sizeof(cis_hit)) + (double)n_tabs * nf * K * sizeof(double);
+        double need = (double)n_items * S_ * (fast_ ? sizeof(uint64_t) : sizeof(cis_hit)) + (double)n_tabs * nf * K * sizeof(double);
+        if (L > MAX_LDS_LIMIT)  // sorted path: two key and two value buffers over every candidate
+            need = 32.0 * (double)h_tot[2] + (double)n_tabs * nf * K * sizeof(double);
         if (need > 4.0e9 && nq > 1) return CIS_RETRY_SMALLER;
     }
     ix->stats[0] += (int64_t)h_tot[2];
@@ -2585,10 +2656,11 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     CIS_TRY(ix->w_items.reserve((size_t)(n_items + 1) * sizeof(WorkItem)));
     CIS_TRY(ix->w_tabs.reserve((size_t)(n_tabs + 1) * sizeof(TabDesc)));
     CIS_TRY(ix->w_T.reserve((size_t)(n_tabs + 1) * nf * K * sizeof(double)));
+    const bool big = L > MAX_LDS_LIMIT;  // ranked by a segmented sort over all candidates (below)
     const bool fast = scan2_supported(M, K, L) && !ix->force_exact_scan;
     const Scan2Geom geom = scan2_geom(M, K, L, nq);
     const int S = fast ? geom.S : L;  // hit slots per work item (fast kernel: <= L per wave)
-    CIS_TRY(ix->w_hits.reserve((size_t)(n_items + 1) * S * (fast ? sizeof(uint64_t) : sizeof(cis_hit))));
+    if (!big) CIS_TRY(ix->w_hits.reserve((size_t)(n_items + 1) * S * (fast ? sizeof(uint64_t) : sizeof(cis_hit))));
     CIS_TRY(ix->w_hitn.reserve((size_t)(n_items + 1) * 2 * sizeof(int)));
     WorkItem* items = ix->w_items.as<WorkItem>();
     TabDesc* tabs = ix->w_tabs.as<TabDesc>();
@@ -2628,6 +2700,48 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     } else if (fast && n_tabs > 0) {
         const int64_t ne = n_tabs * nf * K;
         hipLaunchKernelGGL(k_tables_f32, dim3((unsigned)ceil_div(ne, 256)), dim3(256), 0, st, T, ne, nf, K, T32);
+    }
+    if (big) {
+        // 4'. every candidate's exact distance, stable segmented sort per query, first `limit` of every segment
+        CIS_TRY(mark(2));
+        const int64_t n_cand = (int64_t)h_tot[2];
+        CIS_REQUIRE(n_cand < ((int64_t)1 << 32), "query batch too large for the sorted path");
+        const uint8_t* codes = ix->d_codes.as<uint8_t>();
+        const int64_t* ids = ix->d_ids.as<int64_t>();
+        size_t scan_tmp = 0, sort_tmp = 0;
+        CIS_TRY(cis_exclusive_scan_i64(nullptr, &scan_tmp, nullptr, nullptr, n_items + 1, st));
+        CIS_TRY(cis_seg_sort_u64(nullptr, &sort_tmp, nullptr, nullptr, nullptr, nullptr, n_cand, nq, nullptr, st));
+        const size_t tmp_bytes = ((scan_tmp > sort_tmp ? scan_tmp : sort_tmp) + 255) & ~(size_t)255;
+        const size_t n_i64 = (size_t)2 * (n_items + 1) + (size_t)(nq + 2);
+        CIS_TRY(ix->w_hits.reserve(n_i64 * 8 + (size_t)4 * (n_cand + 1) * 8 + tmp_bytes + 256));
+        int64_t* lens = ix->w_hits.as<int64_t>();
+        int64_t* cand_start = lens + (n_items + 1);
+        int64_t* seg = cand_start + (n_items + 1);
+        uint64_t* keys_in = reinterpret_cast<uint64_t*>(seg + (nq + 2));
+        uint64_t* keys_out = keys_in + (n_cand + 1);
+        uint64_t* vals_in = keys_out + (n_cand + 1);
+        uint64_t* vals_out = vals_in + (n_cand + 1);
+        void* tmp = reinterpret_cast<void*>(((uintptr_t)(vals_out + (n_cand + 1)) + 255) & ~(uintptr_t)255);
+        if (n_items > 0) {
+            hipLaunchKernelGGL(k_item_lens, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, lens);
+            size_t b = tmp_bytes;
+            CIS_TRY(cis_exclusive_scan_i64(tmp, &b, lens, cand_start, n_items, st));
+        }
+        hipLaunchKernelGGL(k_seg_begin, dim3((unsigned)ceil_div(nq + 1, 256)), dim3(256), 0, st, cand_start, item_off, nq, n_items, n_cand, seg);
+        if (n_items > 0) {
+            hipLaunchKernelGGL(k_adc_all, dim3((unsigned)n_items, 8), dim3(256), 0, st, items, cand_start, T, codes, M, K, keys_in, vals_in);
+            size_t b = tmp_bytes;
+            CIS_TRY(cis_seg_sort_u64(tmp, &b, keys_in, keys_out, vals_in, vals_out, n_cand, nq, seg, st));
+        }
+        CIS_TRY(mark(3));
+        hipLaunchKernelGGL(k_emit_sorted, dim3((unsigned)ceil_div(L, 1024) < 64 ? (unsigned)ceil_div(L, 1024) : 64, (unsigned)nq), dim3(256), 0, st,
+                           keys_out, vals_out, seg, items, ids, nq, L, out.hits, out.ids, out.dists, out.n_found, out.cells, out.pos);
+        if (out.visited)
+            hipLaunchKernelGGL(k_copy_visited, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, plan, nq, out.visited);
+        CIS_CHECK_HIP(hipGetLastError());
+        CIS_TRY(mark(4));
+        if (ix->profiling) ix->prof.push_back(pr);
+        return CIS_OK;
     }
     // 4. ADC scan + block top-k
     CIS_TRY(mark(2));
@@ -2988,7 +3102,7 @@ extern "C" int cis_rerank_dev(const void* d_feats, int f_dtype, int64_t n_feats,
 extern "C" int cis_merge_hits_dev(const cis_hit* d_parts, int world, int nq, int limit, int64_t* d_ids,
                                   double* d_dists, int32_t* d_n_found, int32_t* d_cells, uint32_t* d_pos,
                                   void* stream) {
-    CIS_REQUIRE(world >= 1 && nq >= 0 && limit >= 0 && limit <= MAX_LIMIT, "bad merge arguments");
+    CIS_REQUIRE(world >= 1 && nq >= 0 && limit >= 0 && limit <= MAX_LDS_LIMIT, "bad merge arguments (limit <= 3072)");
     CIS_TRY(cis_lazy_init());
     return merge_parts(d_parts, world, nq, limit, d_ids, d_dists, d_n_found, d_cells, d_pos, (hipStream_t)stream);
 }

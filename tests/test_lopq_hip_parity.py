@@ -422,3 +422,31 @@ def test_lmdb_order_searcher_matches_key_order_restatement():
             res, evis = o.search(Q[qi], quota=quota, limit=limit)
             assert vis == evis and [r.id for r in got] == [r[0] for r in res]
             np.testing.assert_allclose([r.dist for r in got], [r[2] for r in res], rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_large_limit_sorted_path_matches_oracle():
+    """limit above the LDS top-k capacity (here limit=None => limit=quota=5000, search.py:213-214): every candidate is
+    scored exactly and a stable segmented sort ranks them; ties (duplicates) keep retrieval order."""
+    from oracle import lopq_oracle as O
+    z, X, Q = load_golden("c2")
+    m = hip_model(z)
+    s = _build_searcher("c2", z, X, m)
+    dup_c, dup_f = np.repeat(z["coarse"][:1], 40, 0), np.repeat(z["fine"][:1], 40, 0)
+    s.add_codes_array(dup_c, dup_f, ids=np.arange(900000, 900040), dedup=False)
+    om = O.OracleModel.from_npz(z)
+    oi = O.OracleCSRIndex(om, np.concatenate([z["coarse"], dup_c]), np.concatenate([z["fine"], dup_f]),
+                          ids=np.concatenate([np.arange(len(z["coarse"])), np.arange(900000, 900040)]))
+    nq = 6
+    Qx = np.concatenate([Q[:nq - 1], X[:1]])  # the last query sits on the duplicated vector
+    for quota, limit in [(5000, None), (20000, 4000)]:
+        r = s.search_batch(Qx, quota=quota, limit=limit)
+        L = quota if limit is None else limit
+        assert r["ids"].shape == (nq, L)
+        for qi in range(nq):
+            ids, dists, visited = oi.search(Qx[qi], quota=quota, limit=limit)
+            n = len(ids)
+            assert r["n_found"][qi] == n and r["visited"][qi] == visited
+            np.testing.assert_array_equal(r["ids"][qi, :n], ids)
+            np.testing.assert_allclose(r["dists"][qi, :n], dists, rtol=1e-9)
+            assert (r["ids"][qi, n:] == -1).all()
