@@ -51,12 +51,18 @@ static __device__ __forceinline__ uint64_t f2bits(float f) { return (uint64_t)__
 // ================================================================================================
 // Ascending order of the V coarse distances of one (query, split).  Distances are >= 0 so their
 // bit patterns order like the values (NaN sorts last, as np.argsort does).  Ties -> lower index.
+// counters of the table groups are split GRP_SUB ways by query index: 16 k atomics on 32 addresses would serialise
+static const int GRP_SUB = 32;
+
 template <typename CT>
 __global__ void k_rank(const CT* __restrict__ dist /* [2][nq][V] */, int nq, int V,
-                       uint16_t* __restrict__ order /* [nq][2][V] */, CT* __restrict__ sorted /* [nq][2][V] */) {
+                       uint16_t* __restrict__ order /* [nq][2][V] */, CT* __restrict__ sorted /* [nq][2][V] */,
+                       int* __restrict__ grp /* [4V]: tables per (split, cluster) and cursors, zeroed here for k_plan */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* sb = reinterpret_cast<uint64_t*>(smem);
     const int q = blockIdx.x, s = blockIdx.y;
+    if (q == 0 && s == 0)
+        for (int i = threadIdx.x; i < 4 * V * GRP_SUB; i += blockDim.x) grp[i] = 0;
     const CT* d = dist + ((int64_t)s * nq + q) * V;
     for (int v = threadIdx.x; v < V; v += blockDim.x) sb[v] = f2bits(d[v]);
     __syncthreads();
@@ -81,7 +87,9 @@ __global__ __launch_bounds__(64) void k_plan(const CT* __restrict__ sorted, cons
                                              const int64_t* __restrict__ gcount, const int64_t* __restrict__ loff,
                                              int nq, int V, int64_t quota, int seg_max, PlanOut* __restrict__ plan,
                                              const int64_t* __restrict__ item_off, const int64_t* __restrict__ tab_off,
-                                             WorkItem* __restrict__ items, TabDesc* __restrict__ tabs) {
+                                             WorkItem* __restrict__ items, TabDesc* __restrict__ tabs,
+                                             int* __restrict__ grp_cnt /* [2V] */, const int* __restrict__ grp_base /* [2V] */,
+                                             int* __restrict__ grp_cur /* [2V] */, int* __restrict__ tab_order /* [n_tabs] */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* t = reinterpret_cast<int*>(smem);  // [V]
     const int q = blockIdx.x;
@@ -164,6 +172,11 @@ __global__ __launch_bounds__(64) void k_plan(const CT* __restrict__ sorted, cons
             p.visited = visited; p.n_items = n_items; p.ntab0 = max_i + 1; p.ntab1 = max_j + 1; p.ncand = ncand;
             plan[q] = p;
         }
+        // tables per (split, cluster): k_tables handles the tables of one cluster together (one read of R[c])
+        for (int i = lane; i < max_i + 1 + max_j + 1; i += 64) {
+            const int g = i <= max_i ? (int)o0[i] : V + (int)o1[i - (max_i + 1)];
+            atomicAdd(&grp_cnt[g * GRP_SUB + (q % GRP_SUB)], 1);
+        }
     } else {
         const int nt0 = plan[q].ntab0, nt1 = plan[q].ntab1;
         for (int i = lane; i < nt0 + nt1; i += 64) {
@@ -172,6 +185,8 @@ __global__ __launch_bounds__(64) void k_plan(const CT* __restrict__ sorted, cons
             if (i < nt0) { td.split = 0; td.cluster = o0[i]; }
             else { td.split = 1; td.cluster = o1[i - nt0]; }
             tabs[tbase + i] = td;
+            const int g = (td.split * V + td.cluster) * GRP_SUB + (q % GRP_SUB);
+            tab_order[grp_base[g] + atomicAdd(&grp_cur[g], 1)] = (int)(tbase + i);  // order inside a group does not matter
         }
     }
 }
@@ -225,9 +240,25 @@ __global__ __launch_bounds__(64) void k_multiseq_list(const CT* __restrict__ sor
 __global__ __launch_bounds__(1024) void k_plan_scan(const PlanOut* __restrict__ plan, int nq, int64_t* __restrict__ item_off,
                                                     int64_t* __restrict__ tab_off, int64_t* __restrict__ totals,
                                                     unsigned long long* __restrict__ qbound /* [nq] -> +inf */,
-                                                    volatile int64_t* __restrict__ host_totals /* pinned, mapped */) {
+                                                    volatile int64_t* __restrict__ host_totals /* pinned, mapped */,
+                                                    const int* __restrict__ grp_cnt, int* __restrict__ grp_base, int n_groups) {
     __shared__ int64_t s_items[16], s_tabs[16], s_cand[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (wv == 15) {  // exclusive scan of the table-group counters by one wave, 64 at a time
+        int run = 0;
+        for (int g0 = 0; g0 < n_groups; g0 += 64) {
+            const int g = g0 + lane;
+            const int c = g < n_groups ? grp_cnt[g] : 0;
+            int x = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(x, d);
+                if (lane >= d) x += y;
+            }
+            if (g < n_groups) grp_base[g] = run + x - c;
+            run += __shfl(x, 63);
+        }
+    }
     const int per = (nq + 1023) / 1024;
     const int a = tid * per < nq ? tid * per : nq, b = (a + per < nq) ? a + per : nq;
     // the batch holds <= 8192 queries: <= 8 per thread, loaded together (independent loads) and kept for the second pass
@@ -352,11 +383,13 @@ __global__ __launch_bounds__(256) void k_tables(const CT* __restrict__ X /* [nq]
                                                 const double* __restrict__ subs, const TabDesc* __restrict__ tabs,
                                                 int V, int h, int w, int nf, int K, int D,
                                                 double* __restrict__ T /* [ntab][nf][K] */, PwProg prog_w,
-                                                double* __restrict__ px_out /* [ntab][h] or null */) {
+                                                double* __restrict__ px_out /* [ntab][h] or null */,
+                                                const int* __restrict__ tab_order, int first) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* v = reinterpret_cast<double*>(smem);  // [h]
     double* px = v + h;                           // [h]
-    const TabDesc td = tabs[blockIdx.x];
+    const int tab = tab_order ? tab_order[first + blockIdx.x] : first + (int)blockIdx.x;
+    const TabDesc td = tabs[tab];
     const int s = td.split, c = td.cluster;
     const CT* x = X + (int64_t)td.q * D + s * h;
     const CT* Cc = Cs + ((int64_t)s * V + c) * h;
@@ -409,10 +442,10 @@ __global__ __launch_bounds__(256) void k_tables(const CT* __restrict__ X /* [nq]
     }
     __syncthreads();
     if (px_out) {  // two-kernel path: the distance tables are built by k_tables_from_px
-        for (int i = threadIdx.x; i < h; i += blockDim.x) px_out[(int64_t)blockIdx.x * h + i] = px[i];
+        for (int i = threadIdx.x; i < h; i += blockDim.x) px_out[(int64_t)tab * h + i] = px[i];
         return;
     }
-    double* out = T + (int64_t)blockIdx.x * nf * K;
+    double* out = T + (int64_t)tab * nf * K;
     for (int e = threadIdx.x; e < nf * K; e += blockDim.x) {
         const int j = e / K, k = e % K;
         const double* sc = subs + ((int64_t)(s * nf + j) * K + k) * w;
@@ -426,6 +459,112 @@ __global__ __launch_bounds__(256) void k_tables(const CT* __restrict__ X /* [nq]
 // items, fine split j, coarse split z).  Thread k keeps sub-centroid (z, j, k) in registers and walks
 // the chunk, so the 32 KB sub-quantizer is read once per 64 tables instead of once per table (the
 // one-kernel version was bound by L2 reads of the sub-quantizers: 160 KB per table).
+// The projection px = R[c] . ((x - C[c]) - mu[c]) for TB tables of ONE (split, cluster) group per block: the tables
+// arrive grouped by cluster (tab_order), so the 8*h*h bytes of R[c] are read once per TB tables instead of once per
+// table (k_tables is bound by exactly that L2 traffic).  Same arithmetic as k_tables, table by table: `parts` slices
+// of k, two interleaved fma chains per slice, slices added in order.  h <= 256, two-kernel path only (px_out).
+template <typename CT, int TB>
+__global__ __launch_bounds__(256) void k_tables_group(const CT* __restrict__ X, const CT* __restrict__ Cs,
+                                                      const double* __restrict__ Rt, const double* __restrict__ mus,
+                                                      const TabDesc* __restrict__ tabs, const int* __restrict__ tab_order,
+                                                      int n_tabs, int V, int h, int D, double* __restrict__ px_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* v = reinterpret_cast<double*>(smem);  // [TB][h]
+    double* psum = v + TB * h;                     // [parts][TB][h]
+    __shared__ int s_tab[TB];
+    __shared__ int s_same;
+    const int tid = threadIdx.x;
+    const int first = blockIdx.x * TB;
+    const int nt = (n_tabs - first < TB) ? (n_tabs - first) : TB;
+    if (tid < TB) s_tab[tid] = tid < nt ? tab_order[first + tid] : -1;
+    __syncthreads();
+    const TabDesc td0 = tabs[s_tab[0]];
+    if (tid == 0) {
+        int same = 1;
+        for (int t = 1; t < nt; ++t) {
+            const TabDesc td = tabs[s_tab[t]];
+            same &= (td.split == td0.split && td.cluster == td0.cluster);
+        }
+        s_same = same;
+    }
+    for (int e = tid; e < nt * h; e += 256) {
+        const int t = e / h, k = e - t * h;
+        const TabDesc td = tabs[s_tab[t]];
+        const CT* x = X + (int64_t)td.q * D + td.split * h;
+        const CT* Cc = Cs + ((int64_t)td.split * V + td.cluster) * h;
+        const double* mu = mus + ((int64_t)td.split * V + td.cluster) * h;
+        const CT res = x[k] - Cc[k];  // rounds in CT (float32 when both are float32), model.py:635
+        v[t * h + k] = (double)res - mu[k];
+    }
+    __syncthreads();
+    const int parts = 256 / h;  // h <= 256 and a power-of-two divisor of 256 is not required: idle threads past parts*h
+    const int part = tid / h, i = tid - part * h;
+    const int per = (h + parts - 1) / parts;
+    const int k0 = part * per, k1 = (k0 + per < h) ? k0 + per : h;
+    if (s_same) {
+        const double* R = Rt + ((int64_t)td0.split * V + td0.cluster) * h * h;
+        if (part < parts) {
+            double a0[TB], a1[TB];
+#pragma unroll
+            for (int t = 0; t < TB; ++t) { a0[t] = 0.0; a1[t] = 0.0; }
+            int k = k0;
+            for (; k + 1 < k1; k += 2) {
+                const double r0 = R[(int64_t)k * h + i], r1 = R[(int64_t)(k + 1) * h + i];
+#pragma unroll
+                for (int t = 0; t < TB; ++t) {
+                    a0[t] = fma(r0, v[t * h + k], a0[t]);
+                    a1[t] = fma(r1, v[t * h + k + 1], a1[t]);
+                }
+            }
+            if (k < k1) {
+                const double r0 = R[(int64_t)k * h + i];
+#pragma unroll
+                for (int t = 0; t < TB; ++t) a0[t] = fma(r0, v[t * h + k], a0[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < TB; ++t) psum[(part * TB + t) * h + i] = a0[t] + a1[t];
+        }
+    } else {  // a block that straddles two groups: every table with its own R
+        for (int t = 0; t < nt; ++t) {
+            const TabDesc td = tabs[s_tab[t]];
+            const double* R = Rt + ((int64_t)td.split * V + td.cluster) * h * h;
+            if (part < parts) {
+                double a0 = 0.0, a1 = 0.0;
+                int k = k0;
+                for (; k + 1 < k1; k += 2) {
+                    a0 = fma(R[(int64_t)k * h + i], v[t * h + k], a0);
+                    a1 = fma(R[(int64_t)(k + 1) * h + i], v[t * h + k + 1], a1);
+                }
+                if (k < k1) a0 = fma(R[(int64_t)k * h + i], v[t * h + k], a0);
+                psum[(part * TB + t) * h + i] = a0 + a1;
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < nt * h; e += 256) {
+        const int t = e / h, ii = e - t * h;
+        double acc = psum[t * h + ii];
+        for (int q = 1; q < parts; ++q) acc = acc + psum[(q * TB + t) * h + ii];
+        px_out[(int64_t)s_tab[t] * h + ii] = acc;
+    }
+}
+
+template <typename CT>
+static void launch_tables(int64_t n_tabs, size_t tab_lds, hipStream_t st, const CT* X, const CT* Cs, const double* Rt,
+                          const double* mus, const double* subs, const TabDesc* tabs, const int* tab_order, int V, int h, int w,
+                          int nf, int K, int D, double* T, PwProg prog_w, double* px_out) {
+    constexpr int TB = 8;
+    if (px_out && h <= 256 && 256 / h >= 1 && !getenv("CIS_TABLES_UNGROUPED")) {
+        const int parts = 256 / h;
+        const size_t lds = (size_t)(TB * h + parts * TB * h) * sizeof(double);
+        hipLaunchKernelGGL((k_tables_group<CT, TB>), dim3((unsigned)ceil_div(n_tabs, TB)), dim3(256), lds, st, X, Cs, Rt, mus, tabs,
+                           tab_order, (int)n_tabs, V, h, D, px_out);
+    } else {
+        hipLaunchKernelGGL(k_tables<CT>, dim3((unsigned)n_tabs), dim3(256), tab_lds, st, X, Cs, Rt, mus, subs, tabs, V, h, w, nf, K, D, T,
+                           prog_w, px_out, (const int*)nullptr, 0);
+    }
+}
+
 template <int W>
 __global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict__ px /* [ntab][h] */,
                                                         const TabDesc* __restrict__ tabs, int n_tabs,
@@ -2012,7 +2151,7 @@ struct cis_index {
     int64_t n_local = 0;
     // per-batch workspace
     DevBuf w_xp, w_cd, w_order, w_sorted, w_plan, w_off, w_items, w_tabs, w_T, w_hits, w_hitn, w_part, w_q,
-        w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos, w_order2, w_px, w_T32;
+        w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos, w_order2, w_px, w_T32, w_grp, w_tord;
     int64_t stats[4] = {0, 0, 0, 0};
     // optional stage timing (hipEvents on the launch stream)
     bool force_exact_scan = false;  // tests: run every item through the float64 kernel
@@ -2052,7 +2191,7 @@ extern "C" void cis_index_destroy(cis_index* ix) {
     DevBuf* bufs[] = {&ix->d_codes, &ix->d_ids, &ix->d_loff, &ix->d_gcount, &ix->w_xp, &ix->w_cd, &ix->w_order,
                       &ix->w_sorted, &ix->w_plan, &ix->w_off, &ix->w_items, &ix->w_tabs, &ix->w_T, &ix->w_hits,
                       &ix->w_hitn, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
-                      &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px, &ix->w_T32};
+                      &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px, &ix->w_T32, &ix->w_grp, &ix->w_tord};
     for (DevBuf* b : bufs) b->release();
     if (ix->h_totals) (void)hipHostFree(ix->h_totals);
     delete ix;
@@ -2317,17 +2456,19 @@ extern "C" int cis_multisequence(const void* X, int x_dtype, const void* C0, con
     if ((rc = bo.reserve((size_t)2 * n * V * sizeof(uint16_t))) != CIS_OK) return done(rc);
     if ((rc = bcell.reserve((size_t)n * max_cells * 2 * sizeof(int32_t))) != CIS_OK) return done(rc);
     if ((rc = bdist.reserve((size_t)n * max_cells * sizeof(double))) != CIS_OK) return done(rc);
+    DevBuf bgrp;
+    if ((rc = bgrp.reserve((size_t)4 * V * GRP_SUB * sizeof(int))) != CIS_OK) return done(rc);
     for (int s = 0; s < 2; ++s)
         if ((rc = cis_launch_sqdist_generic(bx.p, ct, 2 * h, s * h, (char*)bc.p + (size_t)s * V * h * csz, n, V, h,
                                             (char*)bd.p + (size_t)s * n * V * csz, nullptr)) != CIS_OK) return done(rc);
     if (ct == CIS_F32) {
         hipLaunchKernelGGL(k_rank<float>, dim3((unsigned)n, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, nullptr, bd.as<float>(), (int)n, V,
-                           bo.as<uint16_t>(), bs.as<float>());
+                           bo.as<uint16_t>(), bs.as<float>(), bgrp.as<int>());
         hipLaunchKernelGGL(k_multiseq_list<float>, dim3((unsigned)n), dim3(64), (size_t)V * sizeof(int), nullptr, bs.as<float>(),
                            bo.as<uint16_t>(), V, max_cells, bcell.as<int32_t>(), bdist.as<double>());
     } else {
         hipLaunchKernelGGL(k_rank<double>, dim3((unsigned)n, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, nullptr, bd.as<double>(), (int)n, V,
-                           bo.as<uint16_t>(), bs.as<double>());
+                           bo.as<uint16_t>(), bs.as<double>(), bgrp.as<int>());
         hipLaunchKernelGGL(k_multiseq_list<double>, dim3((unsigned)n), dim3(64), (size_t)V * sizeof(int), nullptr, bs.as<double>(),
                            bo.as<uint16_t>(), V, max_cells, bcell.as<int32_t>(), bdist.as<double>());
     }
@@ -2612,28 +2753,32 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     int64_t* totals = tab_off + (nq + 1);
     unsigned long long* qbound = reinterpret_cast<unsigned long long*>(totals + 4);  // per query: cross-cell bound of the scan
     PlanOut* plan = ix->w_plan.as<PlanOut>();
+    CIS_TRY(ix->w_grp.reserve((size_t)(6 * V * GRP_SUB + 2) * sizeof(int)));
+    int* grp_cnt = ix->w_grp.as<int>();         // [2V][GRP_SUB] tables per (split, cluster, query % GRP_SUB)
+    int* grp_cur = grp_cnt + 2 * V * GRP_SUB;    // cursors
+    int* grp_base = grp_cnt + 4 * V * GRP_SUB;   // exclusive scan
     const int seg_max = nq >= 1024 ? (1 << 20) : (nq >= 64 ? 16384 : 4096);
     for (int s = 0; s < 2; ++s)
         CIS_TRY(cis_launch_sqdist(m, xc, ct, nq, s, (char*)ix->w_cd.p + (size_t)s * nq * V * csz, st));
     const size_t plan_lds = (size_t)V * sizeof(int);
     if (ct == CIS_F32) {
         hipLaunchKernelGGL(k_rank<float>, dim3(nq, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, st, ix->w_cd.as<float>(), nq, V,
-                           ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>());
+                           ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
         hipLaunchKernelGGL((k_plan<float, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<float>(),
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
-                           seg_max, plan, nullptr, nullptr, nullptr, nullptr);
+                           seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr);
     } else {
         hipLaunchKernelGGL(k_rank<double>, dim3(nq, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, st, ix->w_cd.as<double>(), nq,
-                           V, ix->w_order.as<uint16_t>(), ix->w_sorted.as<double>());
+                           V, ix->w_order.as<uint16_t>(), ix->w_sorted.as<double>(), grp_cnt);
         hipLaunchKernelGGL((k_plan<double, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
-                           seg_max, plan, nullptr, nullptr, nullptr, nullptr);
+                           seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr);
     }
     if (!ix->h_totals) {
         CIS_CHECK_HIP(hipHostMalloc((void**)&ix->h_totals, 4 * sizeof(int64_t), hipHostMallocMapped));
         CIS_CHECK_HIP(hipHostGetDevicePointer((void**)&ix->d_h_totals, ix->h_totals, 0));
     }
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, plan, nq, item_off, tab_off, totals, qbound, ix->d_h_totals);
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, plan, nq, item_off, tab_off, totals, qbound, ix->d_h_totals, grp_cnt, grp_base, 2 * V * GRP_SUB);
     volatile int64_t* h_tot = ix->h_totals;
     CIS_CHECK_HIP(hipStreamSynchronize(st));
     const int64_t n_items = h_tot[0], n_tabs = h_tot[1];
@@ -2664,6 +2809,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     CIS_TRY(ix->w_hitn.reserve((size_t)(n_items + 1) * 2 * sizeof(int)));
     WorkItem* items = ix->w_items.as<WorkItem>();
     TabDesc* tabs = ix->w_tabs.as<TabDesc>();
+    CIS_TRY(ix->w_tord.reserve((size_t)(n_tabs + 1) * sizeof(int)));
+    int* tab_order = ix->w_tord.as<int>();  // table indices grouped by (split, cluster)
     double* T = ix->w_T.as<double>();
     CIS_TRY(ix->w_T32.reserve((size_t)(n_tabs + 1) * nf * K * sizeof(float)));
     float* T32 = ix->w_T32.as<float>();
@@ -2677,17 +2824,17 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     if (ct == CIS_F32) {
         hipLaunchKernelGGL((k_plan<float, true>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<float>(),
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
-                           seg_max, plan, item_off, tab_off, items, tabs);
+                           seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order);
         if (n_tabs > 0)
-            hipLaunchKernelGGL(k_tables<float>, dim3((unsigned)n_tabs), dim3(256), tab_lds, st, (const float*)xc, m->d_Cs32,
-                               m->d_Rt, m->d_mus, m->d_subs, tabs, V, h, m->w, nf, K, D, T, m->prog_w, px_buf);
+            launch_tables<float>(n_tabs, tab_lds, st, (const float*)xc, m->d_Cs32, m->d_Rt, m->d_mus, m->d_subs, tabs, tab_order, V, h,
+                                 m->w, nf, K, D, T, m->prog_w, px_buf);
     } else {
         hipLaunchKernelGGL((k_plan<double, true>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
-                           seg_max, plan, item_off, tab_off, items, tabs);
+                           seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order);
         if (n_tabs > 0)
-            hipLaunchKernelGGL(k_tables<double>, dim3((unsigned)n_tabs), dim3(256), tab_lds, st, (const double*)xc,
-                               m->d_Cs64, m->d_Rt, m->d_mus, m->d_subs, tabs, V, h, m->w, nf, K, D, T, m->prog_w, px_buf);
+            launch_tables<double>(n_tabs, tab_lds, st, (const double*)xc, m->d_Cs64, m->d_Rt, m->d_mus, m->d_subs, tabs, tab_order, V,
+                                  h, m->w, nf, K, D, T, m->prog_w, px_buf);
     }
     if (split_tables && n_tabs > 0) {
         dim3 g((unsigned)ceil_div(n_tabs, 64), (unsigned)nf, 2);
