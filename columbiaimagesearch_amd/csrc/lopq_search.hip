@@ -649,6 +649,32 @@ __device__ __forceinline__ void block_bitonic_rt(uint64_t* ka, uint64_t* kb, int
     }
 }
 
+// k_rank for wide coarse vocabularies (production configs go up to V = 4096): the rank by counting above is O(V^2)
+// per (query, split); here the (distance bits, centroid index) pairs are sorted in LDS -- the index as second key
+// reproduces "first minimum wins" among equal distances.
+template <typename CT>
+__global__ __launch_bounds__(256) void k_rank_sort(const CT* __restrict__ dist /* [2][nq][V] */, int nq, int V, int Vp2,
+                                                   uint16_t* __restrict__ order, CT* __restrict__ sorted, int* __restrict__ grp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* ka = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* kb = ka + Vp2;
+    const int q = blockIdx.x, s = blockIdx.y;
+    if (q == 0 && s == 0)
+        for (int i = threadIdx.x; i < 4 * V * GRP_SUB; i += blockDim.x) grp[i] = 0;
+    const CT* d = dist + ((int64_t)s * nq + q) * V;
+    for (int v = threadIdx.x; v < Vp2; v += 256) {
+        ka[v] = v < V ? f2bits(d[v]) : ~0ull;
+        kb[v] = v < V ? (uint64_t)v : ~0ull;
+    }
+    __syncthreads();
+    block_bitonic_rt<256, false>(ka, kb, nullptr, Vp2);
+    for (int r = threadIdx.x; r < V; r += 256) {
+        const int v = (int)kb[r];
+        order[((int64_t)q * 2 + s) * V + r] = (uint16_t)v;
+        sorted[((int64_t)q * 2 + s) * V + r] = d[v];
+    }
+}
+
 // ================================================================================================
 // kernel: ADC scan + block top-k   (lopq/lopq/search.py:166-175, :210-215)
 // ================================================================================================
@@ -2761,15 +2787,25 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     for (int s = 0; s < 2; ++s)
         CIS_TRY(cis_launch_sqdist(m, xc, ct, nq, s, (char*)ix->w_cd.p + (size_t)s * nq * V * csz, st));
     const size_t plan_lds = (size_t)V * sizeof(int);
+    int Vp2 = 64;
+    while (Vp2 < V) Vp2 <<= 1;
     if (ct == CIS_F32) {
-        hipLaunchKernelGGL(k_rank<float>, dim3(nq, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, st, ix->w_cd.as<float>(), nq, V,
-                           ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
+        if (V > 256 && Vp2 <= 4096)
+            hipLaunchKernelGGL(k_rank_sort<float>, dim3(nq, 2), dim3(256), (size_t)Vp2 * 16, st, ix->w_cd.as<float>(), nq, V, Vp2,
+                               ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
+        else
+            hipLaunchKernelGGL(k_rank<float>, dim3(nq, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, st, ix->w_cd.as<float>(), nq, V,
+                               ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
         hipLaunchKernelGGL((k_plan<float, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<float>(),
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
                            seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr);
     } else {
-        hipLaunchKernelGGL(k_rank<double>, dim3(nq, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, st, ix->w_cd.as<double>(), nq,
-                           V, ix->w_order.as<uint16_t>(), ix->w_sorted.as<double>(), grp_cnt);
+        if (V > 256 && Vp2 <= 4096)
+            hipLaunchKernelGGL(k_rank_sort<double>, dim3(nq, 2), dim3(256), (size_t)Vp2 * 16, st, ix->w_cd.as<double>(), nq, V, Vp2,
+                               ix->w_order.as<uint16_t>(), ix->w_sorted.as<double>(), grp_cnt);
+        else
+            hipLaunchKernelGGL(k_rank<double>, dim3(nq, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, st, ix->w_cd.as<double>(), nq,
+                               V, ix->w_order.as<uint16_t>(), ix->w_sorted.as<double>(), grp_cnt);
         hipLaunchKernelGGL((k_plan<double, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
                            seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr);

@@ -450,3 +450,52 @@ def test_large_limit_sorted_path_matches_oracle():
             np.testing.assert_array_equal(r["ids"][qi, :n], ids)
             np.testing.assert_allclose(r["dists"][qi, :n], dists, rtol=1e-9)
             assert (r["ids"][qi, n:] == -1).all()
+
+
+def _random_model(V, M, K, D, seed, dtype=np.float32):
+    """Untrained model of a given shape (production configs use V = 256 ... 4096, conf/*.json): centroids drawn from the
+    data distribution, random orthogonal local rotations."""
+    from oracle import lopq_oracle as O
+    from columbiaimagesearch_amd.lopq import LOPQModel
+    rs = np.random.RandomState(seed)
+    h, w, nf = D // 2, D // M, M // 2
+    Cs = [rs.randn(V, h).astype(dtype) for _ in range(2)]
+    Rs = [np.stack([np.linalg.qr(rs.randn(h, h))[0] for _ in range(V)]) for _ in range(2)]
+    mus = [rs.randn(V, h) * 0.05 for _ in range(2)]
+    subs = [[rs.randn(K, w) * 0.6 for _ in range(nf)] for _ in range(2)]
+    return LOPQModel(parameters=(tuple(Cs), tuple(Rs), tuple(mus), tuple(subs))), O.OracleModel(Cs, Rs, mus, subs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,M,K,D", [(300, 8, 64, 32), (1024, 4, 256, 16), (4096, 4, 16, 16)])
+def test_wide_coarse_vocabulary_matches_oracle(V, M, K, D):
+    """V > 256 (uint16 coarse codes, V*V up to a million cells, mostly empty): encode and search parity."""
+    from oracle import lopq_oracle as O
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    m, om = _random_model(V, M, K, D, seed=V)
+    rs = np.random.RandomState(1)
+    X = rs.randn(6000, D).astype(np.float32)
+    Q = rs.randn(10, D).astype(np.float32)
+    coarse, fine = m.predict_batch(X)
+    oc, of = O.predict_batch(om, X) if hasattr(O, "predict_batch") else (None, None)
+    if oc is None:
+        codes = [O.predict(om, x) for x in X[:500]]
+        oc = np.array([c[0] for c in codes]); of = np.array([c[1] for c in codes])
+        np.testing.assert_array_equal(coarse[:500], oc); np.testing.assert_array_equal(fine[:500], of)
+    else:
+        np.testing.assert_array_equal(coarse, oc); np.testing.assert_array_equal(fine, of)
+    assert coarse.dtype == np.uint16 and int(coarse.max()) >= 256
+    s = LOPQSearcherHIP(m)
+    s.add_codes_array(coarse, fine)
+    oi = O.OracleCSRIndex(om, coarse, fine)
+    # with V = 4096 nearly all of the 16.7 M cells are empty: a quota of 20 already walks ~10^4 cells in the oracle's heap
+    settings = [(5, 5), (200, 50)] if V <= 1024 else [(5, 5), (20, 20)]
+    Q = Q if V <= 1024 else Q[:4]
+    for quota, limit in settings:
+        r = s.search_batch(Q, quota=quota, limit=limit)
+        for qi in range(len(Q)):
+            ids, dists, visited = oi.search(Q[qi], quota=quota, limit=limit)
+            n = len(ids)
+            assert r["n_found"][qi] == n and r["visited"][qi] == visited
+            np.testing.assert_array_equal(r["ids"][qi, :n], ids)
+            np.testing.assert_allclose(r["dists"][qi, :n], dists, rtol=1e-9)
