@@ -1515,8 +1515,8 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
     constexpr int R = NR * 64 - 8;
     char* tab = smem;                                                              // [K][M][G] float32
     uint64_t* rk_all = reinterpret_cast<uint64_t*>(smem + (size_t)K * M * G * 4);  // [G][NW][R] (d32, pos) entries; exact keys at the end
-    uint32_t* rp_all = reinterpret_cast<uint32_t*>(rk_all + G * NW * R);           // [G][NW][R] positions (output stage)
-    ScanShared* sh = reinterpret_cast<ScanShared*>(rp_all + G * NW * R);           // [G]
+    uint64_t* tr_all = rk_all + G * NW * R;                                        // [G][NW][64] scratch slots of the branch-free append
+    ScanShared* sh = reinterpret_cast<ScanShared*>(tr_all + G * NW * 64);          // [G]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int nf = M / 2;
@@ -1696,15 +1696,16 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
         for (int g = 0; g < G; ++g) {
             if (g >= ng) break;
             uint64_t* rk = rk_all + (g * NW + w) * R;
-            uint32_t* rp = rp_all + (g * NW + w) * R;
+            uint64_t* tr = tr_all + (g * NW + w) * 64;
+            uint32_t* rp = nullptr;  // positions array of the exact compaction's final form: not used inside the loop
             int ntot = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) ntot += __popcll(pm[u][g]);
             if (ntot == 0) continue;  // only the other query has candidates in this iteration
             if (cnt[g] + ntot <= R) {
                 // The usual case: everything fits.  Straight-line code, no branch per row: every lane stores, the
-                // lanes that did not pass into a scratch slot of their own (this wave's rp area is idle until the end).
-                const int trash = (int)((reinterpret_cast<char*>(rp) - reinterpret_cast<char*>(rk)) >> 3) + lane;
+                // lanes that did not pass into a scratch slot of their own.
+                const int trash = (int)(tr - rk) + lane;
                 int c = cnt[g];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -1847,7 +1848,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                                                        unsigned long long* __restrict__ qbound /* [nq], +inf */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int R = NR * 64 - 8;
-    int* s_next = reinterpret_cast<int*>(smem + (size_t)K * M * G * 4 + (size_t)G * NW * R * 12 + G * sizeof(ScanShared));
+    int* s_next = reinterpret_cast<int*>(smem + (size_t)K * M * G * 4 + (size_t)G * NW * (R + 64) * 8 + G * sizeof(ScanShared));
     const int n_slots = *n_slots_ptr;
     const int q8 = n_slots >> 3, r8 = n_slots & 7;
     const int home = blockIdx.x & 7;
@@ -2596,7 +2597,7 @@ static Scan2Geom scan2_geom(int M, int K, int L, int nq) {
         }
     }
     g.S = g.NW * (NR * 64 - 8);  // survivor slots per work item: a full region per wave
-    g.lds = (size_t)K * M * g.G * 4 + (size_t)g.G * g.NW * (NR * 64 - 8) * 12 + g.G * sizeof(ScanShared) + 16;
+    g.lds = (size_t)K * M * g.G * 4 + (size_t)g.G * g.NW * (NR * 64 - 8 + 64) * 8 + g.G * sizeof(ScanShared) + 16;
     return g;
 }
 
