@@ -1464,12 +1464,20 @@ __device__ __forceinline__ void adc32g(const CodeWords<M>& c, const char* __rest
     }
 }
 
-// adc32g for two queries in two halves, so that the table reads of the NEXT candidate row can be issued before
-// the adds of the current one (the LDS pipe and the VALU then work at the same time inside one wave)
-template <int M>
-__device__ __forceinline__ void adc32_issue2(const CodeWords<M>& c, const char* __restrict__ tab, const RotConsts<M>& rc,
-                                             f32x2_t (&f)[M]) {
-    constexpr int SH = ((M == 4) ? 4 : (M == 8 ? 5 : 6)) + 1;  // log2(M * 2 * 4 bytes)
+// adc32g for G = 2 or 4 queries in two halves, so that the table reads of the NEXT candidate row can be issued before
+// the adds of the current one (the LDS pipe and the VALU then work at the same time inside one wave).  The G queries'
+// entries sit side by side: one ds_read_b64 / ds_read_b128 per table entry, packed adds per tree node.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int G> struct AdcVec;
+template <> struct AdcVec<2> { typedef f32x2_t type; };
+template <> struct AdcVec<4> { typedef f32x4_t type; };
+
+template <int M, int G>
+__device__ __forceinline__ void adc32_issue(const CodeWords<M>& c, const char* __restrict__ tab, const RotConsts<M>& rc,
+                                            typename AdcVec<G>::type (&f)[M]) {
+    typedef typename AdcVec<G>::type VT;
+    constexpr int LG = (G == 2) ? 1 : 2;
+    constexpr int SH = ((M == 4) ? 4 : (M == 8 ? 5 : 6)) + LG;  // log2(M * G * 4 bytes)
     uint32_t D[(M + 3) / 4];
     if constexpr (M == 4) {
         D[0] = c.w[0];
@@ -1488,18 +1496,18 @@ __device__ __forceinline__ void adc32_issue2(const CodeWords<M>& c, const char* 
 #pragma unroll
     for (int t = 0; t < M; ++t) {
         const uint32_t k = __builtin_amdgcn_ubfe(D[t >> 2], rc.sh[t & 3], 8);
-        f[t] = *reinterpret_cast<const f32x2_t*>(tab + ((k << SH) | (rc.cj[t] << 1)));
+        f[t] = *reinterpret_cast<const VT*>(tab + ((k << SH) | (rc.cj[t] << LG)));
     }
 }
 
-template <int M>
-__device__ __forceinline__ void adc32_reduce2(f32x2_t (&f)[M], float (&out)[2]) {
+template <int M, int G>
+__device__ __forceinline__ void adc32_reduce(typename AdcVec<G>::type (&f)[M], float (&out)[G]) {
 #pragma unroll
     for (int st = 1; st < M; st <<= 1)
 #pragma unroll
         for (int t = 0; t < M; t += 2 * st) f[t] = f[t] + f[t + st];
-    out[0] = f[0][0];
-    out[1] = f[0][1];
+#pragma unroll
+    for (int g = 0; g < G; ++g) out[g] = f[0][g];
 }
 
 // One workgroup (NW waves) scans one cell chunk for `ng` <= G queries that all visit it.
@@ -1634,14 +1642,14 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
         }
         float d[U][G];
 #ifndef CIS_SCAN_NO_PIPELINE
-        if constexpr (G == 2) {
-            f32x2_t fbuf[2][M];
-            adc32_issue2<M>(cur[0], tab, rc, fbuf[0]);
+        if constexpr (G >= 2) {
+            typename AdcVec<G>::type fbuf[2][M];
+            adc32_issue<M, G>(cur[0], tab, rc, fbuf[0]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (u + 1 < U) adc32_issue2<M>(cur[u + 1], tab, rc, fbuf[(u + 1) & 1]);
+                if (u + 1 < U) adc32_issue<M, G>(cur[u + 1], tab, rc, fbuf[(u + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                adc32_reduce2<M>(fbuf[u & 1], d[u]);
+                adc32_reduce<M, G>(fbuf[u & 1], d[u]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else
@@ -1838,7 +1846,7 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
 // that XCD's private L2.  A workgroup whose own queue is empty steals from the others, which removes
 // the tail caused by unequal cell sizes.
 template <int M, int NR, int U, int G, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_adc_scan2(const WorkItem* __restrict__ items, const int* __restrict__ slots,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(G == 4 ? 2 : 4, 4))) void k_adc_scan2(const WorkItem* __restrict__ items, const int* __restrict__ slots,
                                                        const int* __restrict__ n_slots_ptr, const double* __restrict__ T,
                                                        const float* __restrict__ T32,
                                                        const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids,
@@ -1872,15 +1880,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 if (idx[g] >= 0) { it[g] = items[idx[g]]; ng = g + 1; }
                 else { it[g] = it[0]; idx[g] = idx[0]; }
             }
-            if constexpr (G == 2) {
-                // the two items must cover the same chunk of the same cell; otherwise run them one by one
-                if (ng == 2 && (it[0].start != it[1].start || it[0].len != it[1].len)) {
-                    WorkItem one[G] = {it[0], it[0]};
-                    int oi[G] = {idx[0], idx[0]};
-                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, T32, codes, ids, K, L, S, margin, item_surv, item_n, qbound, smem);
-                    __syncthreads();
-                    one[0] = it[1]; one[1] = it[1]; oi[0] = idx[1]; oi[1] = idx[1];
-                    scan2_group<M, NR, U, G, NW>(one, oi, 1, T, T32, codes, ids, K, L, S, margin, item_surv, item_n, qbound, smem);
+            if constexpr (G >= 2) {
+                // the items of a slot must cover the same chunk of the same cell; otherwise run them one by one
+                bool same = true;
+#pragma unroll
+                for (int g = 1; g < G; ++g) same = same && (g >= ng || (it[g].start == it[0].start && it[g].len == it[0].len));
+                if (!same) {
+                    for (int g2 = 0; g2 < ng; ++g2) {
+                        WorkItem one[G];
+                        int oi[G];
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            one[g] = it[0]; oi[g] = idx[0];
+#pragma unroll
+                            for (int gg = 1; gg < G; ++gg)
+                                if (gg == g2) { one[g] = it[gg]; oi[g] = idx[gg]; }
+                        }
+                        if (g2 > 0) __syncthreads();
+                        scan2_group<M, NR, U, G, NW>(one, oi, 1, T, T32, codes, ids, K, L, S, margin, item_surv, item_n, qbound, smem);
+                    }
                     continue;
                 }
             }
@@ -2592,7 +2610,7 @@ static Scan2Geom scan2_geom(int M, int K, int L, int nq) {
     g.U = (g.G == 2) ? 4 : 2;
     if (const char* e = getenv("CIS_SCAN_GEOM")) {  // experiments: "G,NW,U" out of the instantiated set
         int a = 0, b = 0, c = 0;
-        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && ((a == 1 && b == 4) || (a == 2 && b == 4) || (a == 2 && b == 8 && c == 2)) && (c == 2 || c == 4)) {
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && ((a == 1 && b == 4) || (a == 2 && b == 4) || (a == 2 && b == 8 && c == 2) || (a == 4 && b == 4 && c == 4 && NR == 4)) && (c == 2 || c == 4)) {
             g.G = a; g.NW = b; g.U = c;
         }
     }
@@ -2629,6 +2647,7 @@ static void launch_scan2_mr(const Scan2Geom& g, int64_t n_items, hipStream_t st,
     CIS_SCAN2_CASE(2, 4, 4)
     CIS_SCAN2_CASE(2, 4, 2)
     CIS_SCAN2_CASE(2, 8, 2)
+    if constexpr (NR == 4) { CIS_SCAN2_CASE(4, 4, 4) }  // four queries per workgroup: measured slower (72 KB of LDS -> 2 workgroups per CU)
 #undef CIS_SCAN2_CASE
 }
 
