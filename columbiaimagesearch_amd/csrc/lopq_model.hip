@@ -266,6 +266,37 @@ __global__ void k_argmin_rows(const T* __restrict__ dist, int64_t n, int ncent, 
     out[r * ostride + ooff] = (TO)bi;
 }
 
+// Fine codes in one pass (predict_fine, lopq/lopq/model.py:575-602 -> predict_cluster, lopq/lopq/utils.py:33-53): a thread
+// owns one (vector, sub-quantizer), keeps its w projected values in registers, walks the K sub-centroids staged in LDS
+// (every lane reads the same address: broadcast) and keeps the first minimum.  Every distance is summed exactly as numpy
+// does for n = w <= 128 (pw_leaf); nothing but the code leaves the kernel -- the n x K distance matrix of the two-kernel
+// path (k_sqdist_rows + k_argmin_rows) is 134 MB per sub-quantizer and chunk.
+template <int W>
+__global__ __launch_bounds__(256) void k_fine_codes(const double* __restrict__ proj /* [n][D] */, int D,
+                                                    const double* __restrict__ subs /* [M][K][W] */, int64_t n, int K, int M,
+                                                    uint8_t* __restrict__ fine /* [n][M] */) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sc = reinterpret_cast<double*>(smem);  // [K][W]
+    const int j = blockIdx.y;
+    const double* src = subs + (size_t)j * K * W;
+    for (int e = threadIdx.x; e < K * W; e += 256) sc[e] = src[e];
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    double x[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) x[i] = proj[r * D + j * W + i];
+    double best = 0.0;
+    int bi = 0;
+    for (int k = 0; k < K; ++k) {
+        const double* c = sc + k * W;
+        auto elem = [&](int i) -> double { const double df = x[i] - c[i]; return df * df; };
+        const double dd = pw_leaf<double>(elem, 0, W);
+        if (k == 0 || dd < best) { best = dd; bi = k; }
+    }
+    fine[r * M + j] = (uint8_t)bi;
+}
+
 // ---- grouping rows by coarse cluster so that a tile of 64 vectors shares one rotation ----------
 struct ProjTile { int split, cluster, start, count; };
 
@@ -660,6 +691,18 @@ static int dev_project(cis_model* m, const void* xc, int ct, int64_t n, const ui
 
 static int dev_fine_from_proj(cis_model* m, const double* d_proj, int64_t n, uint8_t* d_fine, hipStream_t st) {
     if (n == 0) return CIS_OK;
+    if (m->K <= 256 && (m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) && !getenv("CIS_ENCODE_TWO_KERNEL")) {
+        const dim3 gf((unsigned)ceil_div(n, 256), (unsigned)m->M);
+        const size_t lds = (size_t)m->K * m->w * sizeof(double);
+        switch (m->w) {
+            case 4: hipLaunchKernelGGL(k_fine_codes<4>, gf, dim3(256), lds, st, d_proj, m->D, m->d_subs, n, m->K, m->M, d_fine); break;
+            case 8: hipLaunchKernelGGL(k_fine_codes<8>, gf, dim3(256), lds, st, d_proj, m->D, m->d_subs, n, m->K, m->M, d_fine); break;
+            case 16: hipLaunchKernelGGL(k_fine_codes<16>, gf, dim3(256), lds, st, d_proj, m->D, m->d_subs, n, m->K, m->M, d_fine); break;
+            default: hipLaunchKernelGGL(k_fine_codes<32>, gf, dim3(256), lds, st, d_proj, m->D, m->d_subs, n, m->K, m->M, d_fine); break;
+        }
+        CIS_CHECK_HIP(hipGetLastError());
+        return CIS_OK;
+    }
     CIS_TRY(m->ws_dist.reserve((size_t)n * (m->V > m->K ? m->V : m->K) * sizeof(double)));
     double* dist = m->ws_dist.as<double>();
     dim3 g((unsigned)ceil_div(n, 16), (unsigned)ceil_div(m->K, 16));

@@ -244,18 +244,31 @@ __global__ __launch_bounds__(1024) void k_plan_scan(const PlanOut* __restrict__ 
                                                     const int* __restrict__ grp_cnt, int* __restrict__ grp_base, int n_groups) {
     __shared__ int64_t s_items[16], s_tabs[16], s_cand[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (wv == 15) {  // exclusive scan of the table-group counters by one wave, 64 at a time
+    if (wv == 15) {  // exclusive scan of the table-group counters by one wave: 64 x 16 at a time, loads issued together
         int run = 0;
-        for (int g0 = 0; g0 < n_groups; g0 += 64) {
-            const int g = g0 + lane;
-            const int c = g < n_groups ? grp_cnt[g] : 0;
-            int x = c;
+        for (int g0 = 0; g0 < n_groups; g0 += 1024) {
+            int c[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int g = g0 + lane * 16 + i;
+                c[i] = g < n_groups ? grp_cnt[g] : 0;
+            }
+            int tot = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tot += c[i];
+            int x = tot;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const int y = __shfl_up(x, d);
                 if (lane >= d) x += y;
             }
-            if (g < n_groups) grp_base[g] = run + x - c;
+            int r = run + x - tot;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int g = g0 + lane * 16 + i;
+                if (g < n_groups) grp_base[g] = r;
+                r += c[i];
+            }
             run += __shfl(x, 63);
         }
     }
