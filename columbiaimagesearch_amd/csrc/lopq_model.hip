@@ -300,46 +300,105 @@ __global__ __launch_bounds__(256) void k_fine_codes(const double* __restrict__ p
 // ---- grouping rows by coarse cluster so that a tile of 64 vectors shares one rotation ----------
 struct ProjTile { int split, cluster, start, count; };
 
-__global__ void k_group_hist(const uint16_t* __restrict__ coarse, int64_t n, int V, int* __restrict__ counts) {
+// Workgroup-aggregated: a histogram of the block's rows in LDS first, then one global atomic per non-empty bin (65536
+// rows hammering 2V counters one by one serialise in the L2).  V <= 1024 uses the LDS path.
+__global__ __launch_bounds__(256) void k_group_hist(const uint16_t* __restrict__ coarse, int64_t n, int V, int* __restrict__ counts) {
+    extern __shared__ int s_bins[];  // [2V] or nothing
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    atomicAdd(&counts[coarse[r * 2 + 0]], 1);
-    atomicAdd(&counts[V + coarse[r * 2 + 1]], 1);
+    if (V > 1024) {
+        if (r < n) {
+            atomicAdd(&counts[coarse[r * 2 + 0]], 1);
+            atomicAdd(&counts[V + coarse[r * 2 + 1]], 1);
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < 2 * V; i += 256) s_bins[i] = 0;
+    __syncthreads();
+    if (r < n) {
+        atomicAdd(&s_bins[coarse[r * 2 + 0]], 1);
+        atomicAdd(&s_bins[V + coarse[r * 2 + 1]], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * V; i += 256)
+        if (s_bins[i]) atomicAdd(&counts[i], s_bins[i]);
 }
 
 // single block: exclusive scans over the 2V (split, cluster) bins; emits the tile descriptors.
-__global__ void k_group_scan(const int* __restrict__ counts, int V, int* __restrict__ offsets,
-                             int* __restrict__ cursor, ProjTile* __restrict__ tiles, int* __restrict__ n_tiles,
-                             int tile_rows) {
-    if (threadIdx.x != 0) return;
-    int nt = 0;
-    for (int s = 0; s < 2; ++s) {
-        int off = 0;
-        for (int c = 0; c < V; ++c) {
-            const int cnt = counts[s * V + c];
-            offsets[s * V + c] = off;
-            cursor[s * V + c] = 0;
-            for (int t = 0; t < cnt; t += tile_rows) {
-                ProjTile pt;
-                pt.split = s; pt.cluster = c; pt.start = off + t;
-                pt.count = (cnt - t < tile_rows) ? (cnt - t) : tile_rows;
-                tiles[nt++] = pt;
+__global__ __launch_bounds__(256) void k_group_scan(const int* __restrict__ counts, int V, int* __restrict__ offsets,
+                                                    int* __restrict__ cursor, ProjTile* __restrict__ tiles, int* __restrict__ n_tiles,
+                                                    int tile_rows) {
+    extern __shared__ int s_tbase[];  // [2V] first tile of every bin (V <= 1024), else single-thread emission
+    const bool par = V <= 1024;
+    if (threadIdx.x == 0) {
+        int nt = 0;
+        for (int s = 0; s < 2; ++s) {
+            int off = 0;
+            for (int c = 0; c < V; ++c) {
+                const int cnt = counts[s * V + c];
+                offsets[s * V + c] = off;
+                cursor[s * V + c] = 0;
+                if (par) {
+                    s_tbase[s * V + c] = nt;
+                    nt += (cnt + tile_rows - 1) / tile_rows;
+                } else {
+                    for (int t = 0; t < cnt; t += tile_rows) {
+                        ProjTile pt;
+                        pt.split = s; pt.cluster = c; pt.start = off + t;
+                        pt.count = (cnt - t < tile_rows) ? (cnt - t) : tile_rows;
+                        tiles[nt++] = pt;
+                    }
+                }
+                off += cnt;
             }
-            off += cnt;
+        }
+        *n_tiles = nt;
+    }
+    if (!par) return;
+    __syncthreads();
+    // the tiles of a bin are written by the threads of the block together (bins one after the other)
+    for (int b = 0; b < 2 * V; ++b) {
+        const int cnt = counts[b], nb = (cnt + tile_rows - 1) / tile_rows;
+        for (int t = threadIdx.x; t < nb; t += 256) {
+            ProjTile pt;
+            pt.split = b / V; pt.cluster = b - pt.split * V; pt.start = offsets[b] + t * tile_rows;
+            pt.count = (cnt - t * tile_rows < tile_rows) ? (cnt - t * tile_rows) : tile_rows;
+            tiles[s_tbase[b] + t] = pt;
         }
     }
-    *n_tiles = nt;
 }
 
-__global__ void k_group_scatter(const uint16_t* __restrict__ coarse, int64_t n, int V,
-                                const int* __restrict__ offsets, int* __restrict__ cursor,
-                                int* __restrict__ perm /* [2][n] */) {
+__global__ __launch_bounds__(256) void k_group_scatter(const uint16_t* __restrict__ coarse, int64_t n, int V,
+                                                       const int* __restrict__ offsets, int* __restrict__ cursor,
+                                                       int* __restrict__ perm /* [2][n] */) {
+    extern __shared__ int s_bins[];  // [2V] counts, then [2V] reserved bases
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    for (int s = 0; s < 2; ++s) {
-        const int c = coarse[r * 2 + s];
-        const int p = offsets[s * V + c] + atomicAdd(&cursor[s * V + c], 1);
-        perm[(int64_t)s * n + p] = (int)r;
+    if (V > 1024) {
+        if (r >= n) return;
+        for (int s = 0; s < 2; ++s) {
+            const int c = coarse[r * 2 + s];
+            const int p = offsets[s * V + c] + atomicAdd(&cursor[s * V + c], 1);
+            perm[(int64_t)s * n + p] = (int)r;
+        }
+        return;
+    }
+    // rank inside the block through LDS atomics, one global atomic per non-empty bin reserves the block's range
+    int* s_base = s_bins + 2 * V;
+    for (int i = threadIdx.x; i < 2 * V; i += 256) s_bins[i] = 0;
+    __syncthreads();
+    int c[2] = {0, 0}, lr[2] = {0, 0};
+    if (r < n) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            c[s] = s * V + coarse[r * 2 + s];
+            lr[s] = atomicAdd(&s_bins[c[s]], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * V; i += 256) s_base[i] = s_bins[i] ? atomicAdd(&cursor[i], s_bins[i]) : 0;
+    __syncthreads();
+    if (r < n) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) perm[(int64_t)s * n + offsets[c[s]] + s_base[c[s]] + lr[s]] = (int)r;
     }
 }
 
@@ -675,9 +734,11 @@ static int dev_project(cis_model* m, const void* xc, int ct, int64_t n, const ui
     int* perm = n_tiles + 4;
     ProjTile* tiles = reinterpret_cast<ProjTile*>(perm + 2 * n);
     CIS_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)2 * V * sizeof(int), st));
-    hipLaunchKernelGGL(k_group_hist, dim3(grid1(n, 256)), dim3(256), 0, st, d_coarse, n, V, counts);
-    hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(64), 0, st, counts, V, offsets, cursor, tiles, n_tiles, 64);
-    hipLaunchKernelGGL(k_group_scatter, dim3(grid1(n, 256)), dim3(256), 0, st, d_coarse, n, V, offsets, cursor, perm);
+    const size_t bins_lds = V <= 1024 ? (size_t)4 * V * sizeof(int) : 0;
+    hipLaunchKernelGGL(k_group_hist, dim3(grid1(n, 256)), dim3(256), bins_lds, st, d_coarse, n, V, counts);
+    hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(256), V <= 1024 ? (size_t)2 * V * sizeof(int) : 0, st, counts, V, offsets, cursor, tiles,
+                       n_tiles, 64);
+    hipLaunchKernelGGL(k_group_scatter, dim3(grid1(n, 256)), dim3(256), bins_lds, st, d_coarse, n, V, offsets, cursor, perm);
     dim3 g((unsigned)max_tiles, (unsigned)ceil_div(m->h, 64));
     if (ct == CIS_F32)
         hipLaunchKernelGGL(k_project_tiles<float>, g, dim3(256), 0, st, (const float*)xc, m->d_Cs32, m->d_Rt, m->d_mus,
