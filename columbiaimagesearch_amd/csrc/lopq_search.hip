@@ -236,13 +236,19 @@ __global__ __launch_bounds__(64) void k_multiseq_list(const CT* __restrict__ sor
     }
 }
 
-// exclusive scans over the queries of one batch (single block of 1024 threads); totals[0]=items, [1]=tables, [2]=cands
+// exclusive scans over the queries of one batch (single block of 1024 threads); totals[0]=items, [1]=tables, [2]=cands.
+// Thread t owns queries t, t + 1024, ... (<= 8 rounds for a batch of 8192): every load and store of a wave is
+// contiguous -- with eight consecutive queries per thread the wave touched 64 cache lines per instruction and this
+// one-CU kernel took 21 us.  Round r, wave w: inclusive wave scans of all rounds at once, wave totals through LDS.
 __global__ __launch_bounds__(1024) void k_plan_scan(const PlanOut* __restrict__ plan, int nq, int64_t* __restrict__ item_off,
                                                     int64_t* __restrict__ tab_off, int64_t* __restrict__ totals,
                                                     unsigned long long* __restrict__ qbound /* [nq] -> +inf */,
                                                     volatile int64_t* __restrict__ host_totals /* pinned, mapped */,
                                                     const int* __restrict__ grp_cnt, int* __restrict__ grp_base, int n_groups) {
-    __shared__ int64_t s_items[16], s_tabs[16], s_cand[16];
+    constexpr int R = 8;  // rounds held in registers; more queries than 8192 take the slow tail loop below
+    __shared__ int s_wi[R][16], s_wt[R][16];  // wave totals per round
+    __shared__ int64_t s_cand[16];
+    __shared__ int64_t s_base_i[R][16], s_base_t[R][16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (wv == 15) {  // exclusive scan of the table-group counters by one wave: 64 x 16 at a time, loads issued together
         int run = 0;
@@ -272,60 +278,75 @@ __global__ __launch_bounds__(1024) void k_plan_scan(const PlanOut* __restrict__ 
             run += __shfl(x, 63);
         }
     }
-    const int per = (nq + 1023) / 1024;
-    const int a = tid * per < nq ? tid * per : nq, b = (a + per < nq) ? a + per : nq;
-    // the batch holds <= 8192 queries: <= 8 per thread, loaded together (independent loads) and kept for the second pass
-    int ni[8], nt[8];
-    int64_t li = 0, lt = 0, lc = 0;
+    int ni[R], nt[R], xi[R], xt[R];
+    int64_t lc = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int q = a + i;
-        const bool on = q < b;
+    for (int r = 0; r < R; ++r) {
+        const int q = r * 1024 + tid;
+        const bool on = q < nq;
         const PlanOut pl = plan[on ? q : 0];
-        ni[i] = on ? pl.n_items : 0;
-        nt[i] = on ? pl.ntab0 + pl.ntab1 : 0;
-        li += ni[i]; lt += nt[i]; lc += on ? pl.ncand : 0;
+        ni[r] = on ? pl.n_items : 0;
+        nt[r] = on ? pl.ntab0 + pl.ntab1 : 0;
+        lc += on ? pl.ncand : 0;
+        xi[r] = ni[r]; xt[r] = nt[r];
     }
-    for (int q = a + 8; q < b; ++q) { li += plan[q].n_items; lt += plan[q].ntab0 + plan[q].ntab1; lc += plan[q].ncand; }
-    int64_t xi = li, xt = lt, xc = lc;  // inclusive scans inside the wave
+    for (int q = R * 1024 + tid; q < nq; q += 1024) lc += plan[q].ncand;  // batches above 8192 queries (not used today)
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const int64_t yi = __shfl_up(xi, d), yt = __shfl_up(xt, d), yc = __shfl_up(xc, d);
-        if (lane >= d) { xi += yi; xt += yt; xc += yc; }
-    }
-    if (lane == 63) { s_items[wv] = xi; s_tabs[wv] = xt; s_cand[wv] = xc; }
-    __syncthreads();
-    if (tid == 0) {
-        int64_t ri = 0, rt = 0, rc = 0;
-        for (int k = 0; k < 16; ++k) {
-            const int64_t yi = s_items[k], yt = s_tabs[k];
-            s_items[k] = ri; s_tabs[k] = rt;
-            ri += yi; rt += yt; rc += s_cand[k];
-        }
-        totals[0] = ri; totals[1] = rt; totals[2] = rc;
-        host_totals[0] = ri; host_totals[1] = rt; host_totals[2] = rc;  // straight into pinned host memory: no staged copy
-        __threadfence_system();
-        item_off[nq] = ri; tab_off[nq] = rt;
-    }
-    __syncthreads();
-    int64_t ri = s_items[wv] + xi - li, rt = s_tabs[wv] + xt - lt;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int q = a + i;
-        if (q < b) {
-            item_off[q] = ri; tab_off[q] = rt;
+        for (int r = 0; r < R; ++r) {
+            const int yi = __shfl_up(xi[r], d), yt = __shfl_up(xt[r], d);
+            if (lane >= d) { xi[r] += yi; xt[r] += yt; }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) lc += __shfl_xor(lc, d);
+    if (lane == 63) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { s_wi[r][wv] = xi[r]; s_wt[r][wv] = xt[r]; }
+    }
+    if (lane == 0) s_cand[wv] = lc;
+    __syncthreads();
+    if (wv == 0) {  // exclusive scan over the R x 16 (round, wave) totals: two consecutive entries per lane
+        const int e0 = 2 * lane, e1 = 2 * lane + 1;
+        const int a_i = (&s_wi[0][0])[e0], b_i = (&s_wi[0][0])[e1], a_t = (&s_wt[0][0])[e0], b_t = (&s_wt[0][0])[e1];
+        int64_t xi2 = (int64_t)a_i + b_i, xt2 = (int64_t)a_t + b_t;
+        const int64_t own_i = xi2, own_t = xt2;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t yi = __shfl_up(xi2, d), yt = __shfl_up(xt2, d);
+            if (lane >= d) { xi2 += yi; xt2 += yt; }
+        }
+        (&s_base_i[0][0])[e0] = xi2 - own_i; (&s_base_i[0][0])[e1] = xi2 - own_i + a_i;
+        (&s_base_t[0][0])[e0] = xt2 - own_t; (&s_base_t[0][0])[e1] = xt2 - own_t + a_t;
+        int64_t ri = __shfl(xi2, 63), rt = __shfl(xt2, 63);
+        int64_t rc = lane < 16 ? s_cand[lane] : 0;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) rc += __shfl_xor(rc, d);
+        if (lane == 0) {
+            for (int q = R * 1024; q < nq; ++q) {  // queries beyond R * 1024 (slow path): sequential
+                item_off[q] = ri; tab_off[q] = rt;
+                qbound[q] = 0x7ff0000000000000ull;
+                ri += plan[q].n_items; rt += plan[q].ntab0 + plan[q].ntab1;
+            }
+            totals[0] = ri; totals[1] = rt; totals[2] = rc;
+            host_totals[0] = ri; host_totals[1] = rt; host_totals[2] = rc;  // straight into pinned host memory: no staged copy
+            __threadfence_system();
+            item_off[nq] = ri; tab_off[nq] = rt;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int q = r * 1024 + tid;
+        if (q < nq) {
+            item_off[q] = s_base_i[r][wv] + xi[r] - ni[r];
+            tab_off[q] = s_base_t[r][wv] + xt[r] - nt[r];
             qbound[q] = 0x7ff0000000000000ull;
         }
-        ri += ni[i]; rt += nt[i];
-    }
-    for (int q = a + 8; q < b; ++q) {
-        item_off[q] = ri; tab_off[q] = rt;
-        qbound[q] = 0x7ff0000000000000ull;
-        ri += plan[q].n_items; rt += plan[q].ntab0 + plan[q].ntab1;
     }
 }
 
-// ---- work items sorted by coarse cell (counting sort; order inside a cell is irrelevant) ----------
 // one launch instead of three memsets: queue counters and per-cell counters to zero, slots to -1 (empty)
 __global__ void k_slots_init(int* __restrict__ qctr16, int* __restrict__ cell_cnt, int ncells, int* __restrict__ slots,
                              int64_t n_slot_entries) {
