@@ -3,6 +3,7 @@
 Bars (north_star): coarse/fine codes, cell order (visited), candidate ids bit-exact; float64 ADC
 distances within 1e-9 relative (north_star asks 1e-4); apply_PCA float32 within 1 ulp.
 """
+import os
 import numpy as np
 import pytest
 
@@ -499,3 +500,13 @@ def test_wide_coarse_vocabulary_matches_oracle(V, M, K, D):
             assert r["n_found"][qi] == n and r["visited"][qi] == visited
             np.testing.assert_array_equal(r["ids"][qi, :n], ids)
             np.testing.assert_allclose(r["dists"][qi, :n], dists, rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_randomised_parity_fuzz():
+    """Random model shapes / duplicate-heavy data / quota and limit over all three ranking paths (tools/fuzz_parity.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(60, 11) == 0

@@ -1,0 +1,62 @@
+"""Randomised GPU-vs-oracle parity: random model shapes, data with many duplicate codes and near-ties, random quota / limit
+(all three ranking paths: float32-prefilter scan, float64 scan, segmented sort).  Usage: python tools/fuzz_parity.py [cases] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import lopq_oracle as O
+from columbiaimagesearch_amd.lopq import LOPQModel, LOPQSearcherHIP
+
+def run(cases, seed0):
+  bad = 0
+  for case in range(cases):
+      rs = np.random.RandomState(seed0 * 1000 + case)
+      M = int(rs.choice([4, 8, 16]))
+      K = int(rs.choice([16, 64, 256]))
+      V = int(rs.choice([2, 4, 16, 40]))
+      w = int(rs.choice([2, 4, 8]))
+      D = M * w
+      h, nf = D // 2, M // 2
+      dt = rs.choice([np.float32, np.float64])
+      Cs = [rs.randn(V, h).astype(dt) for _ in range(2)]
+      Rs = [np.stack([np.linalg.qr(rs.randn(h, h))[0] for _ in range(V)]) for _ in range(2)]
+      mus = [rs.randn(V, h) * 0.05 for _ in range(2)]
+      subs = [[rs.randn(K, w) * rs.choice([0.1, 0.6]) for _ in range(nf)] for _ in range(2)]
+      m = LOPQModel(parameters=(tuple(Cs), tuple(Rs), tuple(mus), tuple(subs)))
+      om = O.OracleModel(Cs, Rs, mus, subs)
+      n = int(rs.choice([300, 5000, 60000]))
+      base = rs.randn(max(n // int(rs.choice([1, 3, 50])), 1), D)  # few distinct points -> many duplicate codes
+      X = (base[rs.randint(0, len(base), n)] + rs.choice([0.0, 1e-3, 0.3]) * rs.randn(n, D)).astype(dt)
+      nq = int(rs.choice([24, 96, 300]))  # >= 64: two queries per workgroup in the scan
+      Q = (X[rs.randint(0, n, nq)] + 0.05 * rs.randn(nq, D)).astype(dt)
+      coarse, fine = m.predict_batch(X)
+      s = LOPQSearcherHIP(m)
+      s.add_codes_array(coarse, fine, dedup=False)
+      oi = O.OracleCSRIndex(om, coarse, fine)
+      quota = int(rs.choice([1, 10, 100, 1000, 10000]))
+      limit = rs.choice([None, 1, 7, 100, 184, 185, 300, 440, 441, 1000, 4000])
+      limit = None if limit is None else int(limit)
+      if limit is None and quota > 20000:
+          limit = 100
+      r = s.search_batch(Q, quota=quota, limit=limit)
+      ok = True
+      for qi in range(nq):
+          ids, dists, visited = oi.search(Q[qi], quota=quota, limit=limit)
+          k = len(ids)
+          if not (r["n_found"][qi] == k and r["visited"][qi] == visited and np.array_equal(r["ids"][qi, :k], ids)
+                  and np.allclose(r["dists"][qi, :k], dists, rtol=1e-9, atol=0)):
+              ok = False
+              print("MISMATCH case %d query %d: M=%d K=%d V=%d w=%d n=%d quota=%d limit=%s dtype=%s found %d/%d" % (
+                  case, qi, M, K, V, w, n, quota, limit, np.dtype(dt).name, r["n_found"][qi], k))
+              break
+      bad += 0 if ok else 1
+      s.close()
+  return bad
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    t0 = time.time()
+    bad = run(cases, seed0)
+    print("fuzz: %d cases, %d mismatching, %.1f s" % (cases, bad, time.time() - t0))
+    sys.exit(1 if bad else 0)
