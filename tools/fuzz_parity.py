@@ -29,6 +29,11 @@ def run(cases, seed0):
       nq = int(rs.choice([24, 96, 300]))  # >= 64: two queries per workgroup in the scan
       Q = (X[rs.randint(0, n, nq)] + 0.05 * rs.randn(nq, D)).astype(dt)
       coarse, fine = m.predict_batch(X)
+      oc, of = O.compute_codes(om, X[:3000])  # encode parity: bit-exact codes (numpy summation order, first minimum)
+      if not (np.array_equal(coarse[:3000], oc) and np.array_equal(fine[:3000], of)):
+          bad += 1
+          print("ENCODE MISMATCH case %d: M=%d K=%d V=%d w=%d dtype=%s: %d coarse, %d fine rows differ" % (
+              case, M, K, V, w, np.dtype(dt).name, int((coarse[:3000] != oc).any(1).sum()), int((fine[:3000] != of).any(1).sum())))
       s = LOPQSearcherHIP(m)
       s.add_codes_array(coarse, fine, dedup=False)
       oi = O.OracleCSRIndex(om, coarse, fine)
