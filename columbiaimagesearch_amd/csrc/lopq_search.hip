@@ -356,17 +356,29 @@ __global__ void k_slots_init(int* __restrict__ qctr16, int* __restrict__ cell_cn
     if (i < n_slot_entries) slots[i] = -1;
 }
 
-__global__ void k_item_hist(const WorkItem* __restrict__ items, int64_t n, int* __restrict__ cell_cnt) {
+// Sort key of a work item.  The slot list is cut into eight queues (one per XCD) by cell range; inside a queue the
+// items of every query's FIRST visited cell come first, sorted by cell, then all the others, sorted by cell: the
+// first cell usually holds the best candidates, so by the time the other cells of a query are scanned its bound
+// (qbound) is already tight and they run the hot loop only.
+static __device__ __forceinline__ int q8_begin(int x, int ncells) { return (int)(((int64_t)x * ncells + 7) / 8); }
+static __device__ __forceinline__ int slot_key(const WorkItem& it, int ncells) {
+    const int x = (int)(((int64_t)it.cell * 8) / ncells);
+    const int b = q8_begin(x, ncells), sz = q8_begin(x + 1, ncells) - b;
+    return 2 * b + (it.rank > 0 ? sz : 0) + (it.cell - b);
+}
+
+__global__ void k_item_hist(const WorkItem* __restrict__ items, int64_t n, int* __restrict__ cell_cnt, int ncells) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&cell_cnt[items[i].cell], 1);
+    if (i < n) atomicAdd(&cell_cnt[slot_key(items[i], ncells)], 1);
 }
 
 // counts -> exclusive SLOT offsets per cell (a slot holds up to G items of one cell); the counts are
 // reset to zero so that the scatter can reuse them as cursors.  *n_slots = total number of slots.
-__global__ void k_cell_scan(int* __restrict__ cell_cnt, int* __restrict__ slot_off, int ncells, int G,
-                            int* __restrict__ n_slots) {
+__global__ void k_cell_scan(int* __restrict__ cell_cnt, int* __restrict__ slot_off, int nkeys, int G,
+                            int* __restrict__ n_slots, int* __restrict__ qstart /* [9] first slot of every queue */) {
     __shared__ int part[256];
     const int tid = threadIdx.x;
+    const int ncells = nkeys;  // (keys, two per cell)
     const int per = (ncells + 255) / 256;
     const int a = tid * per, b = (a + per < ncells) ? a + per : ncells;
     int s = 0;
@@ -386,26 +398,33 @@ __global__ void k_cell_scan(int* __restrict__ cell_cnt, int* __restrict__ slot_o
         cell_cnt[c] = 0;
         run += x;
     }
+    __syncthreads();
+    if (tid < 8) {  // queue x starts at the first key of its cell range
+        const int k0 = 2 * q8_begin(tid, nkeys / 2);
+        qstart[tid] = k0 < nkeys ? slot_off[k0] : *n_slots;
+    }
+    if (tid == 8) qstart[8] = *n_slots;
 }
 
 // slots[(slot_off[cell] + r / G) * G + r % G] = item, r = arrival rank of the item inside its cell
 __global__ void k_item_scatter(const WorkItem* __restrict__ items, int64_t n, const int* __restrict__ slot_off,
-                               int* __restrict__ cursor, int G, int* __restrict__ slots) {
+                               int* __restrict__ cursor, int G, int* __restrict__ slots, int ncells) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int c = items[i].cell;
+    const int c = slot_key(items[i], ncells);
     const int r = atomicAdd(&cursor[c], 1);
     slots[(slot_off[c] + r / G) * G + (r % G)] = (int)i;
 }
 
 // no sorting (huge V): slot i = item i alone
-__global__ void k_identity_slots(int64_t n, int G, int* __restrict__ slots, int* __restrict__ n_slots) {
+__global__ void k_identity_slots(int64_t n, int G, int* __restrict__ slots, int* __restrict__ n_slots, int* __restrict__ qstart) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         slots[i * G] = (int)i;
         for (int g = 1; g < G; ++g) slots[i * G + g] = -1;
     }
     if (i == 0) *n_slots = (int)n;
+    if (i < 9) qstart[i] = (int)((n * i) / 8);  // equal eighths
 }
 
 // ================================================================================================
@@ -1891,13 +1910,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(G == 4 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int R = NR * 64 - 8;
     int* s_next = reinterpret_cast<int*>(smem + (size_t)K * M * G * 4 + (size_t)G * NW * (R + 64) * 8 + G * sizeof(ScanShared));
-    const int n_slots = *n_slots_ptr;
-    const int q8 = n_slots >> 3, r8 = n_slots & 7;
+    const int* qs = n_slots_ptr + 8;  // [9] queue starts, written by the slot builder
     const int home = blockIdx.x & 7;
     for (int a = 0; a < 8; ++a) {
         const int x = (home + a) & 7;
-        const int qstart = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
-        const int count = q8 + (x < r8 ? 1 : 0);
+        const int qstart = qs[x];
+        const int count = qs[x + 1] - qstart;
         while (true) {
             __syncthreads();  // previous slot fully written out; LDS may be reused
             if (threadIdx.x == 0) *s_next = atomicAdd(&queue_ctr[x], 1);
@@ -2644,7 +2662,7 @@ static Scan2Geom scan2_geom(int M, int K, int L, int nq) {
     g.U = (g.G == 2) ? 4 : 2;
     if (const char* e = getenv("CIS_SCAN_GEOM")) {  // experiments: "G,NW,U" out of the instantiated set
         int a = 0, b = 0, c = 0;
-        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && ((a == 1 && b == 4) || (a == 2 && b == 4) || (a == 2 && b == 8 && c == 2) || (a == 4 && b == 4 && c == 4 && NR == 4)) && (c == 2 || c == 4)) {
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && ((a == 1 && b == 4) || (a == 2 && b == 4) || (a == 2 && b == 8 && c == 2) || (a == 2 && (b == 1 || b == 2) && c == 4) || (a == 4 && b == 4 && c == 4 && NR == 4)) && (c == 2 || c == 4)) {
             g.G = a; g.NW = b; g.U = c;
         }
     }
@@ -2681,6 +2699,8 @@ static void launch_scan2_mr(const Scan2Geom& g, int64_t n_items, hipStream_t st,
     CIS_SCAN2_CASE(2, 4, 4)
     CIS_SCAN2_CASE(2, 4, 2)
     CIS_SCAN2_CASE(2, 8, 2)
+    CIS_SCAN2_CASE(2, 1, 4)
+    CIS_SCAN2_CASE(2, 2, 4)
     if constexpr (NR == 4) { CIS_SCAN2_CASE(4, 4, 4) }  // four queries per workgroup: measured slower (72 KB of LDS -> 2 workgroups per CU)
 #undef CIS_SCAN2_CASE
 }
@@ -2992,25 +3012,28 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             // slot list: work items grouped by coarse cell (counting sort; skipped for huge V), G per slot
             const bool sort_items = ix->ncells <= 65536;
             const int G = geom.G;
-            const int64_t max_slots = sort_items ? (n_items + ix->ncells) / G + ix->ncells + 2 : n_items;
-            CIS_TRY(ix->w_order2.reserve((size_t)(16 + 2 * ix->ncells + max_slots * G) * sizeof(int)));
-            int* qctr = ix->w_order2.as<int>();  // [8] queue counters, [8] n_slots
+            const int64_t nkeys = 2 * ix->ncells;
+            const int64_t max_slots = sort_items ? (n_items + nkeys) / G + nkeys + 2 : n_items;
+            CIS_TRY(ix->w_order2.reserve((size_t)(32 + 2 * nkeys + max_slots * G) * sizeof(int)));
+            int* qctr = ix->w_order2.as<int>();  // [8] queue counters, [8] n_slots (first), [9] queue starts
             int* n_slots = qctr + 8;
-            int* cell_cnt = qctr + 16;
-            int* slot_off = cell_cnt + ix->ncells;
-            int* slots = slot_off + ix->ncells;
+            int* qstart = qctr + 16;
+            int* cell_cnt = qctr + 32;
+            int* slot_off = cell_cnt + nkeys;
+            int* slots = slot_off + nkeys;
             if (sort_items) {
-                const int64_t ninit = max_slots * G > ix->ncells ? max_slots * G : ix->ncells;
+                const int64_t ninit = max_slots * G > nkeys ? max_slots * G : nkeys;
                 hipLaunchKernelGGL(k_slots_init, dim3((unsigned)ceil_div(ninit < 16 ? 16 : ninit, 256)), dim3(256), 0, st, qctr,
-                                   cell_cnt, (int)ix->ncells, slots, max_slots * G);
-                hipLaunchKernelGGL(k_item_hist, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, cell_cnt);
-                hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(256), 0, st, cell_cnt, slot_off, (int)ix->ncells, G, n_slots);
+                                   cell_cnt, (int)nkeys, slots, max_slots * G);
+                hipLaunchKernelGGL(k_item_hist, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, cell_cnt,
+                                   (int)ix->ncells);
+                hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(256), 0, st, cell_cnt, slot_off, (int)nkeys, G, n_slots, qstart);
                 hipLaunchKernelGGL(k_item_scatter, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items,
-                                   slot_off, cell_cnt, G, slots);
+                                   slot_off, cell_cnt, G, slots, (int)ix->ncells);
             } else {
                 CIS_CHECK_HIP(hipMemsetAsync(qctr, 0, 16 * sizeof(int), st));
-                hipLaunchKernelGGL(k_identity_slots, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, n_items, G, slots,
-                                   n_slots);
+                hipLaunchKernelGGL(k_identity_slots, dim3((unsigned)ceil_div(n_items < 9 ? 9 : n_items, 256)), dim3(256), 0, st, n_items, G,
+                                   slots, n_slots, qstart);
             }
             CIS_TRY(mark(5));
             launch_scan2(M, geom, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, qbound);
