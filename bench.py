@@ -107,6 +107,9 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if os.environ.get("CIS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0  # functional test of the N > 1 protocol on a 1-GPU box (with CIS_BENCH_BACKEND=gloo: RCCL refuses shared devices)
+    backend = os.environ.get("CIS_BENCH_BACKEND", "nccl")
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
@@ -123,9 +126,9 @@ def main():
         if "RANK" not in os.environ:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            dist.init_process_group(backend, rank=0, world_size=1, device_id=device if backend == "nccl" else None)
         else:
-            dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+            dist.init_process_group(backend, device_id=device if backend == "nccl" else None)  # nccl == RCCL on ROCm
 
     model, z = load_model()
     N = args.n - args.n % (N_CHUNKS * world)
@@ -150,11 +153,9 @@ def main():
     torch.cuda.synchronize()
     encode_s = sum(a.elapsed_time(b) for a, b in ev) / 1e3  # without the synthetic data generation
     if world > 1:
-        call = torch.empty((world,) + tuple(coarse.shape), dtype=coarse.dtype, device=device)
-        fall = torch.empty((world,) + tuple(fine.shape), dtype=fine.dtype, device=device)
-        dist.all_gather_into_tensor(call, coarse)
-        dist.all_gather_into_tensor(fall, fine)
-        coarse, fine = call.reshape(-1, 2), fall.reshape(-1, fine.shape[1])
+        from columbiaimagesearch_amd.distributed import all_gather_stack
+        coarse = all_gather_stack(coarse).reshape(-1, 2)
+        fine = all_gather_stack(fine).reshape(-1, fine.shape[1])
     coarse_h = coarse.cpu().numpy().view(np.uint16)
     fine_h = fine.cpu().numpy()
     V = model.V

@@ -30,19 +30,33 @@ def greedy_cell_owner(cell_counts, world):
     return owner
 
 
-def all_gather_hits(hits, group=None):
-    """All-gather the per-rank hit lists: [nq, L, 32] uint8 -> [world, nq, L, 32] (same device)."""
+def all_gather_stack(x, group=None):
+    """All-gather equal-shaped tensors -> [world, *x.shape].  The collective writes into the CONCATENATED form
+    ([world * n, ...]), which both RCCL and gloo accept; the stacked view is free."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(hits.shape), dtype=hits.dtype, device=hits.device)
+    x = x.contiguous()
+    shape, dtype = tuple(x.shape), x.dtype
+    if dtype not in (torch.uint8, torch.int32, torch.int64, torch.float32, torch.float64):
+        # RCCL / gloo know no 16-bit integers (the coarse codes): the bytes travel as uint8
+        x = x.reshape(-1).view(torch.uint8)
+    flat = x.reshape(-1)
+    out = torch.empty(world * flat.shape[0], dtype=flat.dtype, device=flat.device)
     try:
-        dist.all_gather_into_tensor(out, hits.contiguous(), group=group)
+        dist.all_gather_into_tensor(out, flat, group=group)
     except (RuntimeError, NotImplementedError):  # backends without the fused form
-        parts = [torch.empty_like(hits) for _ in range(world)]
-        dist.all_gather(parts, hits.contiguous(), group=group)
-        out = torch.stack(parts)
-    return out
+        parts = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(parts, flat, group=group)
+        out = torch.cat(parts)
+    if out.dtype != dtype:
+        out = out.view(dtype)
+    return out.reshape((world,) + shape)
+
+
+def all_gather_hits(hits, group=None):
+    """All-gather the per-rank hit lists: [nq, L, 32] uint8 -> [world, nq, L, 32] (same device)."""
+    return all_gather_stack(hits, group)
 
 
 def exchange_packed(packed, cnt, group=None):
@@ -54,26 +68,13 @@ def exchange_packed(packed, cnt, group=None):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     nq = int(cnt.shape[0])
-    cnt_all = torch.empty((world, nq), dtype=torch.int32, device=cnt.device)
-    try:
-        dist.all_gather_into_tensor(cnt_all, cnt.contiguous(), group=group)
-    except (RuntimeError, NotImplementedError):
-        lst = [torch.empty_like(cnt) for _ in range(world)]
-        dist.all_gather(lst, cnt.contiguous(), group=group)
-        cnt_all = torch.stack(lst)
+    cnt_all = all_gather_stack(cnt, group)
     csum = torch.cumsum(cnt_all, dim=1, dtype=torch.int64)
     stride = max(int(csum[:, -1].max().item()), 1) if nq else 1
     mine = packed[:stride]
     if mine.shape[0] < stride:  # a buffer sized for this rank's own total only
         mine = torch.cat([mine, torch.zeros((stride - mine.shape[0], 4), dtype=packed.dtype, device=packed.device)])
-    mine = mine.contiguous()
-    parts = torch.empty((world, stride, 4), dtype=torch.int64, device=packed.device)
-    try:
-        dist.all_gather_into_tensor(parts, mine, group=group)
-    except (RuntimeError, NotImplementedError):
-        lst = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(lst, mine, group=group)
-        parts = torch.stack(lst)
+    parts = all_gather_stack(mine.contiguous(), group)
     return parts, (csum - cnt_all).contiguous(), cnt_all
 
 

@@ -8,7 +8,7 @@ from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
 model, z = bench.load_model()
 dev = torch.device("cuda", 0)
 centers = bench.mixture_centers(dev)
-N = 10_000_000; chunk = N // 80
+N = int(os.environ.get("CIS_DBG_N", 10_000_000)); chunk = N // 80
 cs, fs = [], []
 for c in range(80):
     x = bench.gen_chunk(centers, c, chunk, dev)
