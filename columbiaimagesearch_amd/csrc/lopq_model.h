@@ -35,6 +35,7 @@ int cis_dev_coarse_type(cis_model* m, const void* d_xp, int xp_dtype, int64_t n,
 // squared distances of n compute-type vectors to the V coarse centroids of `split`, numpy order:
 // out [n][V] of the compute type.
 int cis_launch_sqdist(cis_model* m, const void* xc, int ct, int64_t n, int split, void* out, hipStream_t st);
+int cis_launch_sqdist_both(cis_model* m, const void* xc, int ct, int64_t n, void* out /* [2][n][V] */, hipStream_t st);
 // generic: out[r][c] = numpy-order squared distance of X[r][xoff .. xoff+d) to C[c][0..d), both of compute type ct
 int cis_launch_sqdist_generic(const void* X, int ct, int64_t ldx, int xoff, const void* C, int64_t n, int ncent, int d,
                               void* out, hipStream_t st);

@@ -624,6 +624,33 @@ int cis_dev_coarse_type(cis_model* m, const void* d_xp, int xp_dtype, int64_t n,
     return CIS_OK;
 }
 
+// both coarse halves in one launch: blockIdx.z = split; out = [2][n][V]
+template <typename T>
+__global__ __launch_bounds__(256) void k_sqdist_rows2(const T* __restrict__ X, int64_t ldx, int h, const T* __restrict__ C,
+                                                      int64_t n, int ncent, T* __restrict__ out, PwProg prog) {
+    const int s = blockIdx.z;
+    const int c = blockIdx.y * 16 + (threadIdx.x % 16);
+    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x / 16);
+    if (r >= n || c >= ncent) return;
+    const T* x = X + r * ldx + s * h;
+    const T* cc = C + ((int64_t)s * ncent + c) * h;
+    auto elem = [&](int i) -> T { const T df = x[i] - cc[i]; return df * df; };
+    out[((int64_t)s * n + r) * ncent + c] = pw_sum<T>(prog, elem);
+}
+
+int cis_launch_sqdist_both(cis_model* m, const void* xc, int ct, int64_t n, void* out, hipStream_t st) {
+    if (n == 0) return CIS_OK;
+    dim3 g((unsigned)ceil_div(n, 16), (unsigned)ceil_div(m->V, 16), 2);
+    if (ct == CIS_F32)
+        hipLaunchKernelGGL(k_sqdist_rows2<float>, g, dim3(256), 0, st, (const float*)xc, (int64_t)m->D, m->h, m->d_Cs32, n, m->V,
+                           (float*)out, m->prog_h);
+    else
+        hipLaunchKernelGGL(k_sqdist_rows2<double>, g, dim3(256), 0, st, (const double*)xc, (int64_t)m->D, m->h, m->d_Cs64, n, m->V,
+                           (double*)out, m->prog_h);
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
+}
+
 int cis_launch_sqdist(cis_model* m, const void* xc, int ct, int64_t n, int split, void* out, hipStream_t st) {
     if (n == 0) return CIS_OK;
     dim3 g((unsigned)ceil_div(n, 16), (unsigned)ceil_div(m->V, 16));

@@ -2858,8 +2858,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     int* grp_cur = grp_cnt + 2 * V * GRP_SUB;    // cursors
     int* grp_base = grp_cnt + 4 * V * GRP_SUB;   // exclusive scan
     const int seg_max = nq >= 1024 ? (1 << 20) : (nq >= 64 ? 16384 : 4096);
-    for (int s = 0; s < 2; ++s)
-        CIS_TRY(cis_launch_sqdist(m, xc, ct, nq, s, (char*)ix->w_cd.p + (size_t)s * nq * V * csz, st));
+    CIS_TRY(cis_launch_sqdist_both(m, xc, ct, nq, ix->w_cd.p, st));
     const size_t plan_lds = (size_t)V * sizeof(int);
     int Vp2 = 64;
     while (Vp2 < V) Vp2 <<= 1;
