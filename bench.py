@@ -252,7 +252,7 @@ def main():
     # ---- second half of the BASELINE metric: CNN descriptors/s (DeepSentibank forward, batch 256) -------
     cnn = None
     if rank == 0 and not args.no_cnn:
-        from oracle.cnn_oracle import synthetic_weights  # seeded synthetic weights (the trained ones are not in the tree)
+        from columbiaimagesearch_amd.featurizer.synthetic import sentibank_weights as synthetic_weights  # seeded (trained weights are not in the tree)
         from columbiaimagesearch_amd.featurizer import SentiBankNet
         del x0
         torch.cuda.empty_cache()

@@ -47,19 +47,16 @@ def layer_shapes():
 
 
 def synthetic_weights(seed=0):
-    """Seeded He-scaled weights in caffe layout (float32): {name_w, name_b}."""
-    rs = np.random.RandomState(seed)
-    w = {}
-    for name, ws, bs in layer_shapes():
-        fan_in = int(np.prod(ws[1:]))
-        w[name + "_w"] = (rs.randn(*ws) * np.sqrt(2.0 / fan_in)).astype(np.float32)
-        w[name + "_b"] = (rs.randn(*bs) * 0.05).astype(np.float32)
-    return w
+    """Seeded He-scaled weights in caffe layout (float32): {name_w, name_b} (the generator lives in the package: bench.py and
+    the tools feed the same weights to the HIP forward without importing the oracle)."""
+    from columbiaimagesearch_amd.featurizer.synthetic import sentibank_weights
+    return sentibank_weights(seed)
 
 
 def synthetic_images(n, seed=1):
     """Mean-subtracted-pixel-like inputs, NCHW float32 (what preprocess_img hands to the net, :113-134)."""
-    return (np.random.RandomState(seed).randn(n, 3, INPUT_HW, INPUT_HW) * 50.0).astype(np.float32)
+    from columbiaimagesearch_amd.featurizer.synthetic import sentibank_images
+    return sentibank_images(n, seed)
 
 
 def forward_torch(x, w, upto="fc7"):

@@ -46,32 +46,15 @@ def tensor_names():
 
 
 def synthetic_weights(seed=0):
-    """Seeded weights: conv OIHW, per-channel affine gamma/beta, fc [128][256] (float32)."""
-    rs = np.random.RandomState(seed)
-    w = {}
-
-    def conv(name, oc, ic, k):
-        w[name + "_w"] = (rs.randn(oc, ic, k, k) * np.sqrt(2.0 / (ic * k * k))).astype(np.float32)
-        w[name + "_b"] = (rs.randn(oc) * 0.02).astype(np.float32)
-
-    def affine(g, b, c):
-        w[g] = (1.0 + 0.1 * rs.randn(c)).astype(np.float32)
-        w[b] = (0.05 * rs.randn(c)).astype(np.float32)
-
-    conv("conv0", 32, 3, 7)
-    affine("aff0_g", "aff0_b", 32)
-    for i, (cin, cout, down) in enumerate(block_plan()):
-        conv("b%da" % i, cout, cin, 3)
-        affine("b%da_g" % i, "b%da_beta" % i, cout)
-        conv("b%db" % i, cout, cout, 3)
-        affine("b%db_g" % i, "b%db_beta" % i, cout)
-    w["fc_w"] = (rs.randn(128, 256) * np.sqrt(1.0 / 256)).astype(np.float32)
-    return w
+    """Seeded weights: conv OIHW, per-channel affine gamma/beta, fc [128][256] (float32); generator in the package."""
+    from columbiaimagesearch_amd.featurizer.synthetic import dlib_weights
+    return dlib_weights(seed)
 
 
 def synthetic_chips(n, seed=1):
     """n aligned face chips, uint8 RGB [n,150,150,3] (what get_face_chip would hand to the network)."""
-    return np.random.RandomState(seed).randint(0, 256, size=(n, INPUT_HW, INPUT_HW, 3)).astype(np.uint8)
+    from columbiaimagesearch_amd.featurizer.synthetic import dlib_chips
+    return dlib_chips(n, seed)
 
 
 def _pad_to(t, shape):

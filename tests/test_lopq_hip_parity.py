@@ -504,9 +504,9 @@ def test_wide_coarse_vocabulary_matches_oracle(V, M, K, D):
 
 @pytest.mark.gpu
 def test_randomised_parity_fuzz():
-    """Random model shapes / duplicate-heavy data / quota and limit over all three ranking paths (tools/fuzz_parity.py)."""
+    """Random model shapes / duplicate-heavy data / quota and limit over all three ranking paths (tests/tools/fuzz_parity.py)."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "tools", "fuzz_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(60, 11) == 0

@@ -3,7 +3,7 @@
 parity spot check against the oracle.  The model has the right shapes but synthetic (untrained) parameters: PCA = random
 orthonormal basis, coarse centroids drawn from projected data, random local rotations, sub-centroids drawn from residuals."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from columbiaimagesearch_amd.lopq import LOPQModelPCA, LOPQSearcherHIP
 

@@ -1,7 +1,7 @@
 """Randomised GPU-vs-oracle parity: random model shapes, data with many duplicate codes and near-ties, random quota / limit
-(all three ranking paths: float32-prefilter scan, float64 scan, segmented sort).  Usage: python tools/fuzz_parity.py [cases] [seed]"""
+(all three ranking paths: float32-prefilter scan, float64 scan, segmented sort).  Usage: python tests/tools/fuzz_parity.py [cases] [seed]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import lopq_oracle as O
 from columbiaimagesearch_amd.lopq import LOPQModel, LOPQSearcherHIP

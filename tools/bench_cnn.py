@@ -2,10 +2,10 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import cnn_oracle as C
+from columbiaimagesearch_amd.featurizer.synthetic import sentibank_weights
 from columbiaimagesearch_amd.featurizer import SentiBankNet
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-net = SentiBankNet(C.synthetic_weights(0))
+net = SentiBankNet(sentibank_weights(0))
 x = (torch.randn(B, 3, 227, 227, device="cuda") * 50).contiguous()
 out = torch.empty(B, 4096, device="cuda")
 for _ in range(2):

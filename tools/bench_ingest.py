@@ -3,7 +3,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import cnn_oracle as C
+from columbiaimagesearch_amd.featurizer.synthetic import sentibank_weights
 from columbiaimagesearch_amd.featurizer import SentiBankNet
 from columbiaimagesearch_amd.ingest import BatchIngest
 from columbiaimagesearch_amd.lopq import LOPQModelPCA, LOPQSearcherHIP
@@ -22,7 +22,7 @@ def synthetic_c3_model(seed=0, D_in=4096, D=256, V=16, M=16, K=256):
 
 B = 256
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-net = SentiBankNet(C.synthetic_weights(0))
+net = SentiBankNet(sentibank_weights(0))
 model = synthetic_c3_model()
 s = LOPQSearcherHIP(model)
 ing = BatchIngest(net, model, s)
