@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import lopq_oracle as O
-from columbiaimagesearch_amd.lopq import LOPQModel, LOPQSearcherHIP
+from columbiaimagesearch_amd.lopq import LOPQModel, LOPQModelPCA, LOPQSearcherHIP
 
 def run(cases, seed0):
   bad = 0
@@ -21,13 +21,24 @@ def run(cases, seed0):
       Rs = [np.stack([np.linalg.qr(rs.randn(h, h))[0] for _ in range(V)]) for _ in range(2)]
       mus = [rs.randn(V, h) * 0.05 for _ in range(2)]
       subs = [[rs.randn(K, w) * rs.choice([0.1, 0.6]) for _ in range(nf)] for _ in range(2)]
-      m = LOPQModel(parameters=(tuple(Cs), tuple(Rs), tuple(mus), tuple(subs)))
-      om = O.OracleModel(Cs, Rs, mus, subs)
+      use_pca = rs.rand() < 0.35  # PCA front end (renorm on/off), input wider than the LOPQ space
+      if use_pca:
+          D_in = D + int(rs.choice([0, 5, 40]))
+          P = np.linalg.qr(rs.randn(D_in, D_in))[0][:, :D]
+          pmu = rs.randn(D_in) * 0.1
+          renorm = bool(rs.rand() < 0.5)
+          Cs = [c.astype(np.float32) for c in Cs]  # apply_PCA hands float32 to the coarse stage
+          m = LOPQModelPCA(renorm=renorm, parameters=(tuple(Cs), tuple(Rs), tuple(mus), tuple(subs), P, pmu))
+          om = O.OracleModel(Cs, Rs, mus, subs, pca_P=P, pca_mu=pmu, renorm=renorm)
+      else:
+          D_in = D
+          m = LOPQModel(parameters=(tuple(Cs), tuple(Rs), tuple(mus), tuple(subs)))
+          om = O.OracleModel(Cs, Rs, mus, subs)
       n = int(rs.choice([300, 5000, 60000]))
-      base = rs.randn(max(n // int(rs.choice([1, 3, 50])), 1), D)  # few distinct points -> many duplicate codes
-      X = (base[rs.randint(0, len(base), n)] + rs.choice([0.0, 1e-3, 0.3]) * rs.randn(n, D)).astype(dt)
+      base = rs.randn(max(n // int(rs.choice([1, 3, 50])), 1), D_in)  # few distinct points -> many duplicate codes
+      X = (base[rs.randint(0, len(base), n)] + rs.choice([0.0, 1e-3, 0.3]) * rs.randn(n, D_in)).astype(dt)
       nq = int(rs.choice([24, 96, 300]))  # >= 64: two queries per workgroup in the scan
-      Q = (X[rs.randint(0, n, nq)] + 0.05 * rs.randn(nq, D)).astype(dt)
+      Q = (X[rs.randint(0, n, nq)] + 0.05 * rs.randn(nq, D_in)).astype(dt)
       coarse, fine = m.predict_batch(X)
       oc, of = O.compute_codes(om, X[:3000])  # encode parity: bit-exact codes (numpy summation order, first minimum)
       if not (np.array_equal(coarse[:3000], oc) and np.array_equal(fine[:3000], of)):
@@ -53,6 +64,33 @@ def run(cases, seed0):
               print("MISMATCH case %d query %d: M=%d K=%d V=%d w=%d n=%d quota=%d limit=%s dtype=%s found %d/%d" % (
                   case, qi, M, K, V, w, n, quota, limit, np.dtype(dt).name, r["n_found"][qi], k))
               break
+      if ok and limit is not None and limit <= 512 and rs.rand() < 0.3:
+          # the same index cut into three cell shards: packed partial lists merged == the single index
+          import torch
+          from columbiaimagesearch_amd.lopq.search import merge_packed_dev
+          qd = torch.as_tensor(Q).cuda().contiguous()
+          world = 3
+          parts, cnts = [], []
+          for rk in range(world):
+              sh = LOPQSearcherHIP(m, shard=(rk, world))
+              sh.add_codes_array(coarse, fine, dedup=False)
+              pp = sh.search_partial_packed_dev(qd, quota=quota, limit=limit)
+              tot = int(pp["total"].item())
+              parts.append(pp["packed"][:tot].clone()); cnts.append(pp["cnt"].clone())
+              sh.close()
+          stride = max(max(int(p_.shape[0]) for p_ in parts), 1)
+          buf = torch.zeros((world, stride, 4), dtype=torch.int64, device="cuda")
+          for rk in range(world):
+              buf[rk, :parts[rk].shape[0]] = parts[rk]
+          cnt = torch.stack(cnts).contiguous()
+          off = (torch.cumsum(cnt, dim=1, dtype=torch.int64) - cnt).contiguous()
+          o2 = merge_packed_dev(buf, off, cnt, nq, limit)
+          torch.cuda.synchronize()
+          a, b = o2["dists"].cpu().numpy(), r["dists"]
+          if not (np.array_equal(o2["ids"].cpu().numpy(), r["ids"]) and np.array_equal(o2["n_found"].cpu().numpy(), r["n_found"])
+                  and np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])):
+              ok = False
+              print("SHARDED MISMATCH case %d: M=%d K=%d V=%d n=%d quota=%d limit=%s" % (case, M, K, V, n, quota, limit))
       bad += 0 if ok else 1
       s.close()
   return bad
