@@ -76,7 +76,43 @@ def project_to_local(residuals, assign, R, mu):
     return out
 
 
+def kmeans_pp_init(data, k, rs, sample=20000):
+    """k-means++ seeding (Arthur & Vassilvitskii) on a subsample, on the host: k sequential draws."""
+    n = data.shape[0]
+    x = np.asarray(data[rs.choice(n, min(n, sample), replace=False)], dtype=np.float64)
+    C = np.empty((k, x.shape[1]))
+    C[0] = x[rs.randint(len(x))]
+    d2 = ((x - C[0]) ** 2).sum(axis=1)
+    for j in range(1, k):
+        tot = d2.sum()
+        C[j] = x[rs.randint(len(x))] if tot <= 0 else x[np.searchsorted(np.cumsum(d2), rs.rand() * tot)]
+        d2 = np.minimum(d2, ((x - C[j]) ** 2).sum(axis=1))
+    return C
+
+
+def kmeans_hip(data, k, iters, n_init=1, random_state=None):
+    """Lloyd iterations on the GPU (cis_kmeans) from k-means++ seeds drawn on the host; best of n_init by inertia.
+    Counterpart of the scikit-learn call of the reference (lopq/lopq/model.py:359-372,:417-432); float32."""
+    from .. import _lib
+    x = np.ascontiguousarray(data, dtype=np.float32)
+    n, d = x.shape
+    rs = np.random.RandomState(random_state)
+    best, best_inertia = None, np.inf
+    for _ in range(max(int(n_init), 1)):
+        C = np.ascontiguousarray(kmeans_pp_init(x, k, rs), dtype=np.float32)
+        inertia = _lib.ctypes.c_double(0.0)
+        _lib.check(_lib.lib().cis_kmeans(_lib.ptr(x), n, d, k, int(iters), _lib.ptr(C), None, _lib.ctypes.byref(inertia)))
+        if inertia.value < best_inertia:
+            best, best_inertia = C, inertia.value
+    return best.astype(np.float64), best_inertia
+
+
+KMEANS_BACKEND = "sklearn"  # "hip": Lloyd iterations on the GPU where the codebook fits the kernel (k * d <= 7680)
+
+
 def _kmeans(data, k, iters, n_init, random_state):
+    if KMEANS_BACKEND == "hip" and k * data.shape[1] <= 7680:
+        return kmeans_hip(data, k, iters, n_init, random_state)[0]
     from sklearn.cluster import MiniBatchKMeans
     km = MiniBatchKMeans(n_clusters=k, init="k-means++", max_iter=iters, n_init=n_init, batch_size=10000,
                          verbose=False, random_state=random_state)

@@ -187,6 +187,12 @@ int cis_merge_packed_dev(const cis_hit* d_parts, int world, int64_t stride, cons
 int cis_rerank_dev(const void* d_feats, int f_dtype, int64_t n_feats, int D, const void* d_q, int nq,
                    const int64_t* d_rows, int L, double* d_dists, void* stream);
 
+/* Lloyd iterations for training the coarse and fine codebooks (lopq/lopq/model.py:339-437 uses scikit-learn k-means;
+ * k-means is not bit-reproducible across libraries, so this is judged by distortion).  X [n][d] float32 (host),
+ * centroids [k][d] float32: initial centroids in, trained centroids out; k * d <= 7680.  assign [n] (or NULL) and *inertia
+ * (sum of squared distances, or NULL) refer to the returned centroids. */
+int cis_kmeans(const float* X, int64_t n, int d, int k, int iters, float* centroids, int32_t* assign, double* inertia);
+
 /* Counters of the last search on this handle (for bench.py's roofline):
  *   stats[0] candidates scanned (sum over queries of retrieved items on this shard)
  *   stats[1] (query, cell) work items   stats[2] ADC tables built   stats[3] scan kernel launches */
