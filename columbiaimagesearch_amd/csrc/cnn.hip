@@ -26,6 +26,8 @@ struct ConvDesc {
     int kx_fastest;          // K ordering of the packed weights: 0: k = (ky*KW+kx)*ICg+ic, 1: k = (ic*KH+ky)*KW+kx (NCHW input)
     int splitk = 1;          // > 1 (groups == 1, vector path only): blockIdx.z owns a K range and writes raw partial sums
     int64_t part_stride = 0; // elements between the partial outputs of consecutive K ranges
+    int runq = 0;            // > 0: "row-run" gather of the 3-channel first layer (vector path): K is cut per kernel row into runq
+                             // float4 of contiguous NHWC input (KW*C floats, zero-weight padded), k = ky*4*runq + (kx*C + ic)
     const float* res = nullptr;  // residual input [npix][resC] added before the ReLU (channels >= resC get nothing): dlib add_prev
     int resC = 0;
 };
@@ -112,12 +114,25 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
     auto fetch = [&](int kt) {
         const int k0 = kt * BK;
         if constexpr (VEC) {
+            if (d.runq > 0) {
+                // this thread's float4 along K: kernel row ky, quad jq of that row's contiguous run (no padding: pad == 0)
+                const int kq = kt * 4 + (tid & 3);
+                const int rky = kq / d.runq, jq = kq - rky * d.runq;
 #pragma unroll
-            for (int i = 0; i < A_VEC; ++i) {
-                const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (mloc[i] < BM && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W)
-                    ra[i] = *reinterpret_cast<const float4*>(in + pbase[i] + (int64_t)iy * d.sH + (int64_t)ix * d.sW + ic + (tid & 3) * 4);
+                for (int i = 0; i < A_VEC; ++i) {
+                    const int iy = iy0[i] + rky;
+                    ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (mloc[i] < BM && rky < d.KH && iy >= 0 && iy < d.H)
+                        ra[i] = *reinterpret_cast<const float4*>(in + pbase[i] + (int64_t)iy * d.sH + (int64_t)ix0[i] * d.sW + jq * 4);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < A_VEC; ++i) {
+                    const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+                    ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (mloc[i] < BM && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W)
+                        ra[i] = *reinterpret_cast<const float4*>(in + pbase[i] + (int64_t)iy * d.sH + (int64_t)ix * d.sW + ic + (tid & 3) * 4);
+                }
             }
         } else {
             const bool kvalid = (k0 + (tid & 15)) < d.K;
@@ -337,6 +352,19 @@ __global__ __launch_bounds__(256) void k_maxpool_lrn_nhwc_v4(const float* __rest
     *reinterpret_cast<float4*>(out + pix * C + lc) = make_float4(r[0], r[1], r[2], r[3]);
 }
 
+// NCHW [n][3][H][W] -> NHWC rows of `pitch` floats (W*3 rounded up to a multiple of 4: every row starts 16-byte aligned)
+__global__ void k_nchw3_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int64_t n_rows /* n*H */, int H, int W, int pitch) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (row, x)
+    if (i >= n_rows * W) return;
+    const int x = (int)(i % W);
+    const int64_t row = i / W;
+    const int64_t img = row / H;
+    const int y = (int)(row - img * H);
+    const float* p = in + (img * 3 * H + y) * W + x;
+    float* o = out + row * pitch + x * 3;
+    o[0] = p[0]; o[1] = p[(int64_t)H * W]; o[2] = p[(int64_t)2 * H * W];
+}
+
 // ---- dlib face ResNet helpers (NHWC) ---------------------------------------------------------------
 // input_rgb_image_sized: (pixel - mean_rgb) / 256
 __global__ void k_normalize_rgb(const float* __restrict__ in, float* __restrict__ out, int64_t npix, float m0, float m1, float m2) {
@@ -491,6 +519,23 @@ extern "C" int cis_cnn_create(cis_cnn** out, int arch, const float* const* tenso
         const int OC = kConvCfg[l][0], k = kConvCfg[l][1], s = kConvCfg[l][2], p = kConvCfg[l][3], g = kConvCfg[l][4];
         const int ICg = C / g, OCg = OC / g, K = k * k * ICg;
         const float* w = tensors[2 * l];  // caffe OIHW: [OC][ICg][k][k]
+        if (l == 0) {
+            // first layer: row-run K order for the vector gather over NHWC rows: k = ky * RUNP + (kx * 3 + ic), RUNP = 36
+            // (33 real taps of a kernel row + 3 zero weights), K' = 11 * 36
+            const int RUNP = ((k * C + 3) / 4) * 4, Kp = k * RUNP;
+            std::vector<float> pr((size_t)Kp * OC, 0.f);
+            for (int o = 0; o < OC; ++o)
+                for (int ic = 0; ic < C; ++ic)
+                    for (int ky = 0; ky < k; ++ky)
+                        for (int kx = 0; kx < k; ++kx)
+                            pr[(size_t)(ky * RUNP + kx * C + ic) * OC + o] = w[(((size_t)o * C + ic) * k + ky) * k + kx];
+            if ((rc = upload_f(&c->conv[l].d_w, pr.data(), pr.size())) != CIS_OK) return fail(rc);
+            if ((rc = upload_f(&c->conv[l].d_b, tensors[2 * l + 1], OC)) != CIS_OK) return fail(rc);
+            hw = (hw + 2 * p - k) / s + 1;
+            C = OC;
+            if (kPoolAfter[l]) hw = (hw - 3 + 1) / 2 + 1;
+            continue;
+        }
         std::vector<float> packed((size_t)g * K * OCg);
         for (int gi = 0; gi < g; ++gi)
             for (int o = 0; o < OCg; ++o)
@@ -550,7 +595,7 @@ static void launch_conv_cfg(const ConvDesc& d, const float* in, const float* w, 
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
     const int64_t npix = (int64_t)d.N * d.OH * d.OW;
     dim3 g((unsigned)ceil_div(npix, BM), (unsigned)ceil_div(d.OCg, BN), (unsigned)(d.splitk > 1 ? d.splitk : d.groups));
-    const bool vec = d.sC == 1 && d.ICg % 16 == 0 && d.C % 4 == 0;
+    const bool vec = (d.sC == 1 && d.ICg % 16 == 0 && d.C % 4 == 0) || d.runq > 0;
     if (vec) hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, true>), g, dim3(256), 0, st, in, w, b, out, d);
     else hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, false>), g, dim3(256), 0, st, in, w, b, out, d);
 }
@@ -672,8 +717,21 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
         if (nchw) { d.sN = (int64_t)C * H * W; d.sC = (int64_t)H * W; d.sH = W; d.sW = 1; }
         else { d.sN = (int64_t)H * W * C; d.sC = 1; d.sH = (int64_t)W * C; d.sW = C; }
         d.relu = 1;
-        d.kx_fastest = 0;  // measured: kx-fastest K ordering for the NCHW first layer is slower (0.83 vs 0.73 ms)
+        d.kx_fastest = 0;
         float* o = bufs[which];
+        if (l == 0) {
+            // first layer: the NCHW batch is re-laid as NHWC rows (pitch 684 floats) once, then every (pixel, kernel row)
+            // is a run of 33 contiguous floats gathered with aligned 16-byte loads instead of 363 scalar loads per pixel
+            const int pitch = ((W * 3 + 3) / 4) * 4;
+            CIS_TRY(c->act3.reserve(((size_t)n * H * pitch + 16) * sizeof(float)));
+            float* xt = c->act3.as<float>();
+            hipLaunchKernelGGL(k_nchw3_to_nhwc, dim3((unsigned)ceil_div((int64_t)n * H * W, 256)), dim3(256), 0, st, cur, xt,
+                               (int64_t)n * H, H, W, pitch);
+            d.sN = (int64_t)H * pitch; d.sC = 1; d.sH = pitch; d.sW = 3;
+            d.runq = ((d.KW * 3 + 3) / 4);      // 9 float4 per kernel row
+            d.K = d.KH * d.runq * 4;            // 396
+            cur = xt;
+        }
         launch_conv(d, cur, c->conv[l].d_w, c->conv[l].d_b, o, st);
         cur = o; which ^= 1; nchw = false;
         H = d.OH; W = d.OW; C = d.OC;
