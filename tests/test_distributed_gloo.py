@@ -60,6 +60,12 @@ def _worker(rank, world, port, name, quota, limit, ret):
                 lst = pparts[w, o:o + c].numpy().view(O.HIT_DTYPE).reshape(-1)
                 ref_lst = parts[w, qi][parts[w, qi]["id"] >= 0]
                 ok = ok and np.array_equal(lst, ref_lst)
+        # 16-bit coarse codes travel as bytes (neither RCCL nor gloo has an int16 collective)
+        from columbiaimagesearch_amd.distributed import all_gather_stack
+        c16 = (torch.arange(6, dtype=torch.int16).reshape(3, 2) + 1000 * rank)
+        g16 = all_gather_stack(c16)
+        ok = ok and g16.dtype == torch.int16 and tuple(g16.shape) == (world, 3, 2)
+        ok = ok and all(torch.equal(g16[w], torch.arange(6, dtype=torch.int16).reshape(3, 2) + 1000 * w) for w in range(world))
         allv = [torch.zeros(nq, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(allv, torch.from_numpy(vis))
         ok = ok and all(torch.equal(allv[0], v) for v in allv)
