@@ -2079,7 +2079,7 @@ static __device__ __forceinline__ void wave_bitonic_lds(uint64_t* ka, uint64_t* 
     }
 }
 
-template <int CAPM, int MT /* 4, 8, 16, or 0 = any M */>
+template <int CAPM, int MT /* 4, 8, 16, or 0 = any M */, int NEMAX /* 4 or 8: survivors per lane the fast path may hold */>
 __global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restrict__ surv /* [n_items][S] */,
                                                          const int* __restrict__ item_n, const int64_t* __restrict__ item_off,
                                                          const WorkItem* __restrict__ items, const double* __restrict__ T,
@@ -2098,7 +2098,112 @@ __global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restr
     const int n_lists = (int)(item_off[q + 1] - first);
     const int nf = M / 2;
     int have = 0, l = 0, e = 0, total = 0;
-    while (true) {  // rounds: append up to CAPM - have entries, sort, keep `limit`
+    bool done_fast = false;
+    if constexpr (MT != 0) {
+        // Usual case: <= 4 lists, <= 256 survivors in all.  The survivors carry their float32 distances: find the value v
+        // that `limit` of them do not exceed (ballot bisection in registers) and drop everything above v*(1+3eps) BEFORE
+        // the exact re-scoring -- strictly worse, in exact arithmetic, than the `limit` entries below v (the scan's own
+        // argument).  ~limit/130 of the table reads, and the sort runs on 128 keys instead of 256.
+        int cntl[4] = {0, 0, 0, 0}, n_total = 0;
+        if (n_lists <= 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < n_lists) cntl[i] = item_n[first + i];
+                n_total += cntl[i];
+            }
+        }
+        auto fast = [&](auto ne_tag) -> bool {
+            constexpr int NE = decltype(ne_tag)::value;  // survivors per lane
+            uint32_t hi[NE], pp[NE];
+            int li[NE];
+            bool valid[NE];
+            uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const int x = lane + 64 * i;
+                valid[i] = x < n_total;
+                int lst = 0, off = x;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (lst == j && off >= cntl[j]) { off -= cntl[j]; lst = j + 1; }
+                li[i] = lst;
+                const uint64_t ent = valid[i] ? surv[(first + lst) * (int64_t)S + off] : ~0ull;
+                hi[i] = (uint32_t)(ent >> 32);
+                pp[i] = (uint32_t)ent;
+                mn = (valid[i] && hi[i] < mn) ? hi[i] : mn;
+                mx = (valid[i] && hi[i] > mx) ? hi[i] : mx;
+            }
+            uint32_t thr = 0xffffffffu;
+            if (n_total > limit) {
+                wave_minmax_step<1>(mn, mx); wave_minmax_step<2>(mn, mx); wave_minmax_step<4>(mn, mx);
+                wave_minmax_step<8>(mn, mx); wave_minmax_step<16>(mn, mx); wave_minmax_step<32>(mn, mx);
+                mn = (uint32_t)__builtin_amdgcn_readfirstlane((int)mn);
+                mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
+                const uint32_t v = wave_kth_bisect<NE>(hi, valid, mn, mx, limit);
+                const float margin = 1.0f + 3.0f * (2.0f * (float)MT * 5.9604645e-8f);
+                thr = __float_as_uint(__double2float_ru((double)__uint_as_float(v) * (double)margin));
+            }
+            int kept = 0;
+            int idx[NE];
+            bool keep[NE];
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                keep[i] = valid[i] && hi[i] <= thr;
+                const unsigned long long m = __ballot(keep[i]);
+                idx[i] = kept + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                kept += __popcll(m);
+            }
+            if (kept > CAPM) return false;  // a crowd of equal float32 distances: the general rounds below
+            WorkItem its[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) its[i] = items[first + (i < n_lists ? i : 0)];
+            // exact re-scoring of the kept entries, four per lane at a time: codes first, then 4 x M table entries in flight
+#pragma unroll
+            for (int i0 = 0; i0 < NE; i0 += 4) {
+                int64_t startv[4];
+                const double* t0v[4];
+                const double* t1v[4];
+                uint32_t rankv[4], pos0v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    WorkItem it = its[0];
+#pragma unroll
+                    for (int j = 1; j < 4; ++j)
+                        if (li[i0 + i] == j) it = its[j];
+                    startv[i] = it.start; rankv[i] = (uint32_t)it.rank; pos0v[i] = (uint32_t)it.pos0;
+                    t0v[i] = T + (int64_t)it.tab0 * nf * K;
+                    t1v[i] = T + (int64_t)it.tab1 * nf * K;
+                }
+                CodeWords<MT> cw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cw[i] = load_code<MT>(codes, startv[i] + (keep[i0 + i] ? pp[i0 + i] : 0u));
+                double dd[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dd[i] = adc64_words<MT>(cw[i].w, K, t0v[i], t1v[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (keep[i0 + i]) {
+                        ka[idx[i0 + i]] = (uint64_t)__double_as_longlong(dd[i]);
+                        kb[idx[i0 + i]] = ((uint64_t)rankv[i] << 32) | (uint32_t)(pos0v[i] + pp[i0 + i]);
+                    }
+                }
+            }
+            int ns = 64;
+            while (ns < kept) ns <<= 1;
+            for (int x = kept + lane; x < ns; x += 64) { ka[x] = ~0ull; kb[x] = ~0ull; }
+            wave_lds_sync();
+            wave_bitonic_lds(ka, kb, ns);
+            total = kept;
+            return true;
+        };
+        if (n_lists >= 1 && n_lists <= 4) {
+            if (n_total <= 256) done_fast = fast(std::integral_constant<int, 4>());
+            else if (NEMAX >= 8 && n_total <= 512) {
+                if constexpr (NEMAX >= 8) done_fast = fast(std::integral_constant<int, 8>());
+            }
+        }
+    }
+    while (!done_fast) {  // rounds: append up to CAPM - have entries, sort, keep `limit`
         int n = have;
         int room = CAPM - have;
         while (l < n_lists && room > 0) {
@@ -3053,10 +3158,19 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             const uint64_t* surv = ix->w_hits.as<uint64_t>();
             const uint8_t* codes = ix->d_codes.as<uint8_t>();
             const int64_t* ids = ix->d_ids.as<int64_t>();
+            // several lists per query (short cells): the variant whose fast path holds 512 survivors per query
+            const bool many = n_items > nq + nq / 4;
 #define CIS_MERGE_SURV(CAP, MT)                                                                                              \
-    hipLaunchKernelGGL((k_merge_survivors<CAP, MT>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), (size_t)4 * CAP * 16, st, surv,  \
-                       hitn, item_off, items, T, codes, ids, nq, M, K, L, S, out.hits, out.ids, out.dists, out.n_found,        \
-                       out.cells, out.pos)
+    do {                                                                                                                     \
+        if (many)                                                                                                            \
+            hipLaunchKernelGGL((k_merge_survivors<CAP, MT, 8>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), (size_t)4 * CAP * 16, st, \
+                               surv, hitn, item_off, items, T, codes, ids, nq, M, K, L, S, out.hits, out.ids, out.dists,     \
+                               out.n_found, out.cells, out.pos);                                                             \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((k_merge_survivors<CAP, MT, 4>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), (size_t)4 * CAP * 16, st, \
+                               surv, hitn, item_off, items, T, codes, ids, nq, M, K, L, S, out.hits, out.ids, out.dists,     \
+                               out.n_found, out.cells, out.pos);                                                             \
+    } while (0)
 #define CIS_MERGE_SURV_M(CAP)                                                                          \
     do {                                                                                               \
         if (M == 4) CIS_MERGE_SURV(CAP, 4); else if (M == 8) CIS_MERGE_SURV(CAP, 8); else CIS_MERGE_SURV(CAP, 16); \
