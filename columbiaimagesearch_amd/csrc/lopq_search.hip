@@ -2087,11 +2087,13 @@ __global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restr
                                                          int nq, int M, int K, int limit, int S,
                                                          cis_hit* __restrict__ out_hits, int64_t* __restrict__ out_ids,
                                                          double* __restrict__ out_dists, int* __restrict__ out_n,
-                                                         int32_t* __restrict__ out_cells, uint32_t* __restrict__ out_pos) {
+                                                         int32_t* __restrict__ out_cells, uint32_t* __restrict__ out_pos,
+                                                         const PlanOut* __restrict__ plan, int32_t* __restrict__ out_visited) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wq;
     if (q >= nq) return;  // whole wave; nothing below synchronises across waves
+    if (lane == 0 && out_visited) out_visited[q] = plan[q].visited;
     uint64_t* ka = reinterpret_cast<uint64_t*>(smem) + (size_t)wq * 2 * CAPM;
     uint64_t* kb = ka + CAPM;  // (visit_rank << 32) | position inside the cell
     const int64_t first = item_off[q];
@@ -3165,11 +3167,11 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (many)                                                                                                            \
             hipLaunchKernelGGL((k_merge_survivors<CAP, MT, 8>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), (size_t)4 * CAP * 16, st, \
                                surv, hitn, item_off, items, T, codes, ids, nq, M, K, L, S, out.hits, out.ids, out.dists,     \
-                               out.n_found, out.cells, out.pos);                                                             \
+                               out.n_found, out.cells, out.pos, plan, out.visited);                                          \
         else                                                                                                                 \
             hipLaunchKernelGGL((k_merge_survivors<CAP, MT, 4>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), (size_t)4 * CAP * 16, st, \
                                surv, hitn, item_off, items, T, codes, ids, nq, M, K, L, S, out.hits, out.ids, out.dists,     \
-                               out.n_found, out.cells, out.pos);                                                             \
+                               out.n_found, out.cells, out.pos, plan, out.visited);                                          \
     } while (0)
 #define CIS_MERGE_SURV_M(CAP)                                                                          \
     do {                                                                                               \
@@ -3190,7 +3192,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             hipLaunchKernelGGL(k_merge_items<4096>, dim3(nq), dim3(256), (size_t)4096 * 24 + 16, st, hits, hitn, item_off, L, S, out.hits,
                                out.ids, out.dists, out.n_found, out.cells, out.pos);
     }
-    if (out.visited)
+    if (out.visited && !fast)  // the survivor merge writes `visited` itself
         hipLaunchKernelGGL(k_copy_visited, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, plan, nq, out.visited);
     CIS_CHECK_HIP(hipGetLastError());
     CIS_TRY(mark(4));
