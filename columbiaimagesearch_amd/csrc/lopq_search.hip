@@ -2359,7 +2359,7 @@ struct cis_index {
     int64_t stats[4] = {0, 0, 0, 0};
     // optional stage timing (hipEvents on the launch stream)
     bool force_exact_scan = false;  // tests: run every item through the float64 kernel
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 events around the scan kernel only, 2 events around every stage
     int64_t* h_totals = nullptr;    // pinned, device-mapped: the plan totals land here without a copy
     int64_t* d_h_totals = nullptr;
     struct ProfRec { hipEvent_t ev[6]; bool has_scan; };  // ev[5]: just before the scan kernel (after slot building)
@@ -2558,7 +2558,7 @@ extern "C" int cis_index_get_codes(cis_index* ix, const int32_t* cells, const ui
 
 extern "C" int cis_index_set_profiling(cis_index* ix, int enable) {
     CIS_REQUIRE(ix != nullptr, "index is NULL");
-    ix->profiling = enable != 0;
+    ix->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return CIS_OK;
 }
 
@@ -2691,20 +2691,22 @@ extern "C" int cis_index_set_scan_mode(cis_index* ix, int mode) {
 extern "C" int cis_index_read_profile(cis_index* ix, double ms[5], int64_t* launches) {
     CIS_REQUIRE(ix != nullptr && ms != nullptr, "NULL argument");
     for (auto& r : ix->prof) {
-        CIS_CHECK_HIP(hipEventSynchronize(r.ev[4]));
+        hipEvent_t last = r.ev[4] ? r.ev[4] : r.ev[3];
+        if (last) CIS_CHECK_HIP(hipEventSynchronize(last));
         for (int i = 0; i < 4; ++i) {
+            if (!r.ev[i] || !r.ev[i + 1]) continue;
             float t = 0.f;
             CIS_CHECK_HIP(hipEventElapsedTime(&t, r.ev[i], r.ev[i + 1]));
             ix->prof_ms[i] += t;
         }
-        if (r.has_scan) {
+        if (r.has_scan && r.ev[5] && r.ev[3]) {
             float t = 0.f;
             CIS_CHECK_HIP(hipEventElapsedTime(&t, r.ev[5], r.ev[3]));
             ix->prof_ms[4] += t;
             ix->prof_launches += 1;
-            (void)hipEventDestroy(r.ev[5]);
         }
-        for (int i = 0; i < 5; ++i) (void)hipEventDestroy(r.ev[i]);
+        for (int i = 0; i < 6; ++i)
+            if (r.ev[i]) (void)hipEventDestroy(r.ev[i]);
     }
     ix->prof.clear();
     for (int i = 0; i < 5; ++i) { ms[i] = ix->prof_ms[i]; ix->prof_ms[i] = 0; }
@@ -2929,8 +2931,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     const int V = m->V, D = m->D, K = m->K, M = m->M, h = m->h, nf = m->nf;
     cis_index::ProfRec pr;
     pr.has_scan = false;
+    for (int i = 0; i < 6; ++i) pr.ev[i] = nullptr;
     auto mark = [&](int i) -> int {
         if (!ix->profiling) return CIS_OK;
+        if (ix->profiling == 1 && i != 5 && i != 3) return CIS_OK;  // level 1: only the pair around the scan kernel
         CIS_CHECK_HIP(hipEventCreate(&pr.ev[i]));
         CIS_CHECK_HIP(hipEventRecord(pr.ev[i], st));
         return CIS_OK;

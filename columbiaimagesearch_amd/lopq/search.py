@@ -357,9 +357,10 @@ class LOPQSearcherHIP(LOPQSearcherBase):
         """Force the exact float64 ADC scan kernel (tests); results are identical either way."""
         _lib.check(_lib.lib().cis_index_set_scan_mode(self._ix, 1 if exact_only else 0))
 
-    def set_profiling(self, enable=True):
-        """Record HIP events around the search stages on the launch stream (see read_profile)."""
-        _lib.check(_lib.lib().cis_index_set_profiling(self._ix, 1 if enable else 0))
+    def set_profiling(self, enable=True, scan_only=False):
+        """Record HIP events on the launch stream (see read_profile): around every stage, or (scan_only) just the pair
+        around the scan kernel -- every recorded event is a small bubble between kernels."""
+        _lib.check(_lib.lib().cis_index_set_profiling(self._ix, 0 if not enable else (1 if scan_only else 2)))
 
     def read_profile(self):
         """Accumulated stage times in ms since the last read (waits for the recorded events)."""

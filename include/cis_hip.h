@@ -205,7 +205,7 @@ int cis_index_last_stats(cis_index* ix, int64_t stats[4]);
  *   ms[2] ADC scan stage (slot list + scan kernel)                        ms[3] per-query merge
  *   ms[4] the ADC scan kernel alone (events right before and after its launch)
  *   *launches = number of scan kernel launches accumulated. */
-int cis_index_set_profiling(cis_index* ix, int enable);
+int cis_index_set_profiling(cis_index* ix, int level /* 0 off, 1 only the pair of events around the scan kernel (ms[4]), 2 every stage */);
 /* ADC scan kernel selection: 0 = automatic (float32-prefilter kernel with exact float64 re-scoring
  * where it applies, exact float64 kernel otherwise), 1 = exact float64 kernel only.  Both produce
  * identical results; the switch exists so that tests can prove it. */
