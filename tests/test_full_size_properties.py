@@ -1,0 +1,160 @@
+"""GPU: size-independent properties of the hot path at BASELINE.json's full size (10M x 128-d index, V=16, M=8,
+8192 queries per batch, quota 10000, limit 100), where the oracle is too slow to check every row.
+
+* encode: batch-composition invariance (one big call == the concatenation of ragged small calls),
+* search: sorted distances, n_found, idempotence, batch-composition invariance, the limit-10 list is the prefix of
+  the limit-100 list (stable ranking key), a database vector finds itself, visited >= quota,
+* cell sharding: two shards scanned separately and merged == the single index (partition invariance),
+* a checksum of checksums against the oracle on a small sample of the same batch.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 10_000_000
+N_CHUNKS = 10
+NQ = 8192
+QUOTA = 10000
+LIMIT = 100
+
+
+@pytest.fixture(scope="module")
+def world():
+    import torch
+    import bench as B
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    dev = torch.device("cuda", 0)
+    model, z = B.load_model()
+    P = B.mixture_centers(dev)
+    chunk_n = N // N_CHUNKS
+    co, fi = [], []
+    for c in range(N_CHUNKS):
+        a, b = model.predict_batch_dev(B.gen_chunk(P, c, chunk_n, dev))
+        co.append(a)
+        fi.append(b)
+    coarse = torch.cat(co).cpu().numpy().view(np.uint16)
+    fine = torch.cat(fi).cpu().numpy()
+    s = LOPQSearcherHIP(model)
+    s.add_codes_array(coarse, fine, ids=np.arange(N, dtype=np.int64), dedup=False)
+    x0 = B.gen_chunk(P, 0, chunk_n, dev)
+    q = B.make_queries(x0, 0, NQ, dev)
+    return dict(model=model, z=z, P=P, chunk_n=chunk_n, coarse=coarse, fine=fine, searcher=s, x0=x0, q=q, B=B, dev=dev)
+
+
+def _np(out):
+    return {k: v.cpu().numpy() for k, v in out.items() if hasattr(v, "cpu")}
+
+
+def test_encode_is_independent_of_batch_composition(world):
+    import torch
+    m, x0 = world["model"], world["x0"]
+    ref_c, ref_f = world["coarse"][:world["chunk_n"]], world["fine"][:world["chunk_n"]]
+    cuts = [0, 1, 2, 65, 4096, 4097, 100_003, 500_000, world["chunk_n"]]  # ragged pieces, 1-row piece included
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        c, f = m.predict_batch_dev(x0[a:b].contiguous())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(c.cpu().numpy().view(np.uint16), ref_c[a:b])
+        np.testing.assert_array_equal(f.cpu().numpy(), ref_f[a:b])
+    c, f = m.predict_batch_dev(x0[:0].contiguous())  # empty input
+    assert c.shape[0] == 0 and f.shape[0] == 0
+
+
+def test_search_properties_at_full_size(world):
+    import torch
+    s, q = world["searcher"], world["q"]
+    o1 = _np(s.search_batch_dev(q, quota=QUOTA, limit=LIMIT))
+    cand = s.last_stats()["candidates"]
+    o2 = _np(s.search_batch_dev(q, quota=QUOTA, limit=LIMIT))
+    for k in ("ids", "dists", "n_found", "visited"):  # idempotence, bit for bit
+        np.testing.assert_array_equal(o1[k], o2[k])
+    assert cand >= NQ * QUOTA  # whole cells are consumed until the quota is reached
+    assert (o1["n_found"] == LIMIT).all() and (o1["visited"] >= 1).all()
+    d = o1["dists"]
+    assert np.isfinite(d).all() and (d >= 0).all()
+    assert (np.diff(d, axis=1) >= 0).all()  # sorted
+    assert (o1["ids"] >= 0).all() and (o1["ids"] < N).all()
+    srt = np.sort(o1["ids"], axis=1)
+    assert (np.diff(srt, axis=1) > 0).all()  # an item is returned once
+    # batch composition: ragged sub-batches reproduce their rows of the big batch
+    for a, b in [(0, 1), (1, 66), (4000, 4257), (8191, 8192)]:
+        sub = _np(s.search_batch_dev(q[a:b].contiguous(), quota=QUOTA, limit=LIMIT))
+        for k in ("ids", "dists", "n_found", "visited"):
+            np.testing.assert_array_equal(sub[k], o1[k][a:b])
+    # the ranking key (dist, visit rank, position) is total: a shorter limit is a prefix
+    o10 = _np(s.search_batch_dev(q, quota=QUOTA, limit=10))
+    np.testing.assert_array_equal(o10["ids"], o1["ids"][:, :10])
+    np.testing.assert_array_equal(o10["dists"], o1["dists"][:, :10])
+    np.testing.assert_array_equal(o10["visited"], o1["visited"])
+    # a larger quota consumes the same cells first: visited grows, and the best distance cannot get worse
+    big = _np(s.search_batch_dev(q[:512].contiguous(), quota=4 * QUOTA, limit=LIMIT))
+    assert (big["visited"] >= o1["visited"][:512]).all()
+    assert (big["dists"][:, 0] <= o1["dists"][:512, 0]).all()
+
+
+def test_database_vectors_find_themselves(world):
+    import torch
+    s, x0 = world["searcher"], world["x0"]
+    rows = torch.arange(0, 1_000_000, 3907, device=world["dev"])[:256]
+    out = _np(s.search_batch_dev(x0[rows].contiguous(), quota=QUOTA, limit=LIMIT))
+    own = rows.cpu().numpy()
+    hit = out["ids"] == own[:, None]
+    # the item's own cell is the first cell visited and its own code is the closest code of that cell
+    assert hit.any(axis=1).mean() >= 0.99
+    r, c = np.nonzero(hit)
+    first = out["dists"][:, 0]
+    # its distance is the quantisation error: no item of its own cell is closer, so whatever precedes it is at most equal
+    # to it or comes from another cell; with limit 100 it sits at the head in the vast majority of cases
+    assert (c == 0).mean() >= 0.9
+    assert (out["dists"][r, c] >= first[r]).all()
+
+
+def test_two_cell_shards_merge_to_the_single_index(world):
+    import torch
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    from columbiaimagesearch_amd.lopq.search import merge_packed_dev
+    s, q = world["searcher"], world["q"][:2048].contiguous()
+    ref = _np(s.search_batch_dev(q, quota=QUOTA, limit=LIMIT))
+    parts = []
+    for r in range(2):
+        sh = LOPQSearcherHIP(world["model"], shard=(r, 2))
+        sh.add_codes_array(world["coarse"], world["fine"], ids=np.arange(N, dtype=np.int64), dedup=False)
+        pp = sh.search_partial_packed_dev(q, quota=QUOTA, limit=LIMIT)
+        torch.cuda.synchronize()
+        parts.append({k: v.clone() for k, v in pp.items() if hasattr(v, "clone")})
+        del sh
+    stride = max(int(p["total"].item()) for p in parts)
+    buf = torch.zeros((2, stride, 4), dtype=torch.int64, device=world["dev"])
+    for r, p in enumerate(parts):
+        t = int(p["total"].item())
+        buf[r, :t] = p["packed"][:t]
+    cnt = torch.stack([p["cnt"] for p in parts]).contiguous()
+    off = torch.stack([p["off"] for p in parts]).contiguous()
+    out = _np(merge_packed_dev(buf, off, cnt, q.shape[0], LIMIT))
+    np.testing.assert_array_equal(out["ids"], ref["ids"])
+    np.testing.assert_array_equal(out["dists"], ref["dists"])
+    np.testing.assert_array_equal(out["n_found"], ref["n_found"])
+
+
+def test_checksum_of_checksums_against_the_oracle(world):
+    """48 rows spread over the 8192-query batch: per-row checksums of (ids, distance bits) from the HIP path and from
+    the oracle, folded into one number each."""
+    import hashlib
+    from oracle import lopq_oracle as O
+    s, q = world["searcher"], world["q"]
+    out = _np(s.search_batch_dev(q, quota=QUOTA, limit=LIMIT))
+    om = O.OracleModel.from_npz(world["z"])
+    oix = O.OracleCSRIndex(om, world["coarse"], world["fine"])
+    rows = np.arange(0, NQ, NQ // 48)[:48]
+    qh = q.cpu().numpy()
+    h_gpu, h_cpu = hashlib.sha1(), hashlib.sha1()
+    worst = 0.0
+    for r in rows:
+        ids, dists, visited = oix.search(qh[r], QUOTA, LIMIT)
+        assert visited == out["visited"][r]
+        np.testing.assert_array_equal(np.asarray(ids, np.int64), out["ids"][r])
+        worst = max(worst, float(np.max(np.abs(np.asarray(dists) - out["dists"][r]) / np.maximum(np.asarray(dists), 1e-300))))
+        h_cpu.update(hashlib.sha1(np.asarray(ids, np.int64).tobytes()).digest())
+        h_gpu.update(hashlib.sha1(np.ascontiguousarray(out["ids"][r]).tobytes()).digest())
+    assert h_cpu.hexdigest() == h_gpu.hexdigest()
+    assert worst <= 1e-9  # north_star asks 1e-4
