@@ -2835,7 +2835,7 @@ static void launch_scan2(int M, const Scan2Geom& g, int64_t n_items, hipStream_t
 // in visit order, positions ascending), so a stable sort on the distance alone yields the (dist, visit_rank, pos)
 // ranking = the reference's stable sorted() over the retrieved list (search.py:210).
 int cis_seg_sort_u64(void* temp, size_t* temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint64_t* vals_in,
-                     uint64_t* vals_out, int64_t n, int nseg, const int64_t* seg_begin, hipStream_t st);
+                     uint64_t* vals_out, int64_t n, int nseg, const int64_t* seg_begin, const int64_t* seg_end, hipStream_t st);
 int cis_exclusive_scan_i64(void* temp, size_t* temp_bytes, const int64_t* in, int64_t* out, int64_t n, hipStream_t st);
 
 __global__ void k_item_lens(const WorkItem* __restrict__ items, int64_t n, int64_t* __restrict__ lens) {
@@ -2861,16 +2861,18 @@ __global__ __launch_bounds__(256) void k_adc_all(const WorkItem* __restrict__ it
     const int64_t o = cand_start[blockIdx.x];
     for (int p = blockIdx.y * blockDim.x + threadIdx.x; p < it.len; p += gridDim.y * blockDim.x) {
         keys[o + p] = (uint64_t)__double_as_longlong(adc64_global(codes, it.start + p, M, K, t0, t1));
-        vals[o + p] = ((uint64_t)blockIdx.x << 32) | (uint32_t)p;
+        if (vals) vals[o + p] = ((uint64_t)blockIdx.x << 32) | (uint32_t)p;
     }
 }
 
 __global__ void k_emit_sorted(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ vals, const int64_t* __restrict__ seg,
+                              const int* __restrict__ nsel, int64_t stride,
                               const WorkItem* __restrict__ items, const int64_t* __restrict__ ids, int nq, int limit,
                               cis_hit* __restrict__ out_hits, int64_t* __restrict__ out_ids, double* __restrict__ out_dists,
                               int* __restrict__ out_n, int32_t* __restrict__ out_cells, uint32_t* __restrict__ out_pos) {
     const int q = blockIdx.y;
-    const int64_t a = seg[q], n = seg[q + 1] - a;
+    // segments: contiguous (seg[q] .. seg[q + 1]) or, after the selection kernel, nsel[q] entries at q * stride
+    const int64_t a = nsel ? (int64_t)q * stride : seg[q], n = nsel ? (int64_t)nsel[q] : seg[q + 1] - a;
     const int nv = (int)(n < limit ? n : limit);
     const int64_t o = (int64_t)q * limit;
     for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < limit; x += gridDim.x * blockDim.x) {
@@ -2898,8 +2900,275 @@ __global__ void k_emit_sorted(const uint64_t* __restrict__ keys, const uint64_t*
     if (blockIdx.x == 0 && threadIdx.x == 0 && out_n) out_n[q] = nv;
 }
 
+
+// ---- `limit` between the float32-prefilter kernel's 440 and the candidate count: radix SELECT before any sort.
+// k_adc_all has written the exact float64 distance of every candidate in retrieval order (keys; positive doubles
+// order like their bit patterns).  One workgroup per query finds the `limit`-th smallest (distance, retrieval index)
+// pair -- the cut of the reference's stable sorted()[:limit] (search.py:210-216):
+//   A. min / max of the segment -> the bits all keys share are skipped;
+//   B. most-significant-digit radix passes (11 bits, LDS histogram) narrow to the bin holding the limit-th key until
+//      that bin has <= SEL_CAND keys (or every bit is fixed: a crowd of exact ties);
+//   C. the bin's keys are sorted in LDS by (key, index) and the r-th is the cut; for a crowd of ties the cut index is
+//      found by counting equal keys in retrieval order;
+//   D. an ORDER-PRESERVING gather of everything <= cut (block prefix sums): exactly min(n, limit) pairs in retrieval
+//      order.  limit <= 3072: sorted in LDS by (key, index) and written ranked; above: written in retrieval order for
+//      the stable segmented sort, which now sees limit instead of n entries per query.
+static const int SEL_THREADS = 512;
+static const int SEL_BITS = 11;
+static const int SEL_CAND = 1024;
+static const int SEL_PER = 4;  // consecutive keys per thread and chunk in the ordered passes
+
+__device__ __forceinline__ int sel_wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// exclusive prefix of v over the workgroup and the total; sm: one int per wave (contains two barriers)
+__device__ __forceinline__ int sel_block_excl_scan(int v, int* sm, int* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int inc = sel_wave_incl_scan(v);
+    __syncthreads();
+    if (lane == 63) sm[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int i = 0; i < nw; ++i) {
+        const int x = sm[i];
+        if (i < w) base += x;
+        tot += x;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+__device__ __forceinline__ bool sel_pair_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) {
+    return ka < kb || (ka == kb && ia < ib);
+}
+
+// ascending bitonic sort of n2 (power of two) (key, index) pairs in LDS by the whole workgroup
+__device__ __forceinline__ void sel_block_bitonic(uint64_t* key, uint32_t* idx, int n2) {
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const uint64_t ka = key[lo], kb = key[hi];
+                const uint32_t ia = idx[lo], ib = idx[hi];
+                if (sel_pair_less(kb, ib, ka, ia) == up) {
+                    key[lo] = kb; key[hi] = ka;
+                    idx[lo] = ib; idx[hi] = ia;
+                }
+            }
+        }
+    __syncthreads();
+}
+
+// the candidate reference (work item << 32 | offset in the item's cell) of retrieval index g (global over the batch)
+__device__ __forceinline__ uint64_t sel_val_of(int64_t g, const int64_t* __restrict__ cand_start, int64_t it_lo, int64_t it_hi) {
+    while (it_hi - it_lo > 1) {  // last item with cand_start <= g
+        const int64_t mid = (it_lo + it_hi) >> 1;
+        if (cand_start[mid] <= g) it_lo = mid; else it_hi = mid;
+    }
+    return ((uint64_t)it_lo << 32) | (uint32_t)(g - cand_start[it_lo]);
+}
+
+struct SelShared {
+    unsigned long long mn, mx;
+    int bin, less, cnt, cn;
+    unsigned int cut_idx;
+    int wsum[SEL_THREADS / 64];
+};
+
+template <bool SORT_LDS>
+__global__ __launch_bounds__(SEL_THREADS) void k_select_topl(const uint64_t* __restrict__ keys, const int64_t* __restrict__ seg,
+                                                              const int64_t* __restrict__ cand_start, const int64_t* __restrict__ item_off,
+                                                              int64_t n_items, int L, int P2, int64_t stride, uint64_t* __restrict__ sel_keys,
+                                                              uint64_t* __restrict__ sel_vals, int* __restrict__ nsel,
+                                                              int64_t* __restrict__ seg_b, int64_t* __restrict__ seg_e) {
+    extern __shared__ __align__(16) unsigned char sel_lds[];
+    // LDS: [okey P2][oidx P2] (SORT_LDS) | union { hist 2048 u32 ; ckey 1024 u64 + cidx 1024 u32 } | SelShared
+    uint64_t* okey = reinterpret_cast<uint64_t*>(sel_lds);
+    uint32_t* oidx = reinterpret_cast<uint32_t*>(okey + (SORT_LDS ? P2 : 0));
+    unsigned char* un = reinterpret_cast<unsigned char*>(oidx + (SORT_LDS ? P2 : 0));
+    unsigned int* hist = reinterpret_cast<unsigned int*>(un);
+    uint64_t* ckey = reinterpret_cast<uint64_t*>(un);
+    uint32_t* cidx = reinterpret_cast<uint32_t*>(ckey + SEL_CAND);
+    SelShared* sh = reinterpret_cast<SelShared*>(un + SEL_CAND * 12);
+    const int q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int64_t a = seg[q];
+    const int64_t n64 = seg[q + 1] - a;
+    const unsigned int n = (unsigned int)n64;  // a query's candidates fit 32 bits (the batch total does)
+    const uint64_t* __restrict__ k = keys + a;
+    const int nv = n64 < (int64_t)L ? (int)n64 : L;
+    uint64_t cut_key = ~0ull;
+    unsigned int cut_idx = 0xffffffffu;
+    if (n64 > (int64_t)L) {
+        // A. range of the keys
+        if (tid == 0) { sh->mn = ~0ull; sh->mx = 0ull; }
+        __syncthreads();
+        {
+            uint64_t mn = ~0ull, mx = 0ull;
+            for (unsigned int i = tid; i < n; i += nt) {
+                const uint64_t v = k[i];
+                mn = v < mn ? v : mn;
+                mx = v > mx ? v : mx;
+            }
+            atomicMin(&sh->mn, (unsigned long long)mn);
+            atomicMax(&sh->mx, (unsigned long long)mx);
+        }
+        __syncthreads();
+        const uint64_t mn = sh->mn, mx = sh->mx;
+        int hi_shift = (mn == mx) ? 0 : 64 - __clzll((long long)(mn ^ mx));  // bits [0, hi_shift) differ somewhere
+        uint64_t prefix = hi_shift >= 64 ? 0ull : (mn >> hi_shift);
+        int r = L;            // rank (1-based) of the cut among the keys that share `prefix`
+        unsigned int c = n;   // keys that share `prefix`
+        // B. radix passes
+        while (hi_shift > 0 && c > (unsigned)SEL_CAND) {
+            const int bits = hi_shift < SEL_BITS ? hi_shift : SEL_BITS;
+            const int shift = hi_shift - bits;
+            const unsigned int mask = (1u << bits) - 1u;
+            for (int b = tid; b < (1 << SEL_BITS); b += nt) hist[b] = 0;
+            __syncthreads();
+            for (unsigned int i = tid; i < n; i += nt) {
+                const uint64_t v = k[i];
+                if (hi_shift >= 64 || (v >> hi_shift) == prefix) atomicAdd(&hist[(unsigned int)(v >> shift) & mask], 1u);
+            }
+            __syncthreads();
+            const int per = (1 << SEL_BITS) / SEL_THREADS;
+            unsigned int cb[per];
+            int local = 0;
+#pragma unroll
+            for (int j = 0; j < per; ++j) { cb[j] = hist[tid * per + j]; local += (int)cb[j]; }
+            int tot;
+            int run = sel_block_excl_scan(local, sh->wsum, &tot);
+#pragma unroll
+            for (int j = 0; j < per; ++j) {
+                if (run < r && r <= run + (int)cb[j]) { sh->bin = tid * per + j; sh->less = run; sh->cnt = (int)cb[j]; }
+                run += (int)cb[j];
+            }
+            __syncthreads();
+            r -= sh->less;
+            c = (unsigned int)sh->cnt;
+            prefix = (prefix << bits) | (uint64_t)sh->bin;
+            hi_shift = shift;
+            __syncthreads();
+        }
+        if (c <= (unsigned)SEL_CAND) {
+            // C. the threshold bin's keys, ranked in LDS
+            if (tid == 0) sh->cn = 0;
+            __syncthreads();
+            for (unsigned int i = tid; i < n; i += nt) {
+                const uint64_t v = k[i];
+                if (hi_shift >= 64 || (v >> hi_shift) == prefix) {
+                    const int j = atomicAdd(&sh->cn, 1);
+                    ckey[j] = v;
+                    cidx[j] = i;
+                }
+            }
+            __syncthreads();
+            int c2 = 64;
+            while (c2 < (int)c) c2 <<= 1;
+            for (int j = (int)c + tid; j < c2; j += nt) { ckey[j] = ~0ull; cidx[j] = 0xffffffffu; }
+            sel_block_bitonic(ckey, cidx, c2);
+            cut_key = ckey[r - 1];
+            cut_idx = cidx[r - 1];
+            __syncthreads();
+        } else {
+            // a crowd of exact ties at the cut (every bit fixed): the first r of them in retrieval order
+            cut_key = prefix;
+            int base = 0;
+            for (unsigned int i0 = 0; i0 < n; i0 += (unsigned)nt) {
+                const unsigned int i = i0 + tid;
+                const int f = (i < n && k[i] == cut_key) ? 1 : 0;
+                int tot;
+                const int ex = sel_block_excl_scan(f, sh->wsum, &tot);
+                if (f && base + ex == r - 1) sh->cut_idx = i;
+                base += tot;
+                if (base >= r) break;
+            }
+            __syncthreads();
+            cut_idx = sh->cut_idx;
+            __syncthreads();
+        }
+    }
+    // D. order-preserving gather of the pairs <= cut
+    const int64_t it_lo = item_off[q];
+    int64_t it_hi = item_off[q + 1];
+    if (it_hi > n_items) it_hi = n_items;
+    const int64_t ob = (int64_t)q * stride;
+    int base = 0;
+    for (unsigned int i0 = 0; i0 < n && base < nv; i0 += (unsigned)(nt * SEL_PER)) {
+        const unsigned int i = i0 + tid * SEL_PER;
+        uint64_t v[SEL_PER];
+        int f[SEL_PER], local = 0;
+#pragma unroll
+        for (int j = 0; j < SEL_PER; ++j) {
+            v[j] = (i + j < n) ? k[i + j] : 0ull;
+            f[j] = (i + j < n) && (v[j] < cut_key || (v[j] == cut_key && i + j <= cut_idx));
+            local += f[j];
+        }
+        int tot;
+        int o = base + sel_block_excl_scan(local, sh->wsum, &tot);
+#pragma unroll
+        for (int j = 0; j < SEL_PER; ++j)
+            if (f[j]) {
+                if (SORT_LDS) {
+                    okey[o] = v[j];
+                    oidx[o] = i + j;
+                } else {
+                    sel_keys[ob + o] = v[j];
+                    sel_vals[ob + o] = sel_val_of(a + i + j, cand_start, it_lo, it_hi);
+                }
+                ++o;
+            }
+        base += tot;
+    }
+    if (SORT_LDS) {
+        __syncthreads();
+        int n2 = 64;
+        while (n2 < nv) n2 <<= 1;
+        for (int j = nv + tid; j < n2; j += nt) { okey[j] = ~0ull; oidx[j] = 0xffffffffu; }
+        sel_block_bitonic(okey, oidx, n2);
+        for (int j = tid; j < nv; j += nt) {
+            sel_keys[ob + j] = okey[j];
+            sel_vals[ob + j] = sel_val_of(a + oidx[j], cand_start, it_lo, it_hi);
+        }
+    }
+    if (tid == 0) {
+        nsel[q] = nv;
+        if (seg_b) { seg_b[q] = ob; seg_e[q] = ob + nv; }
+    }
+}
+
 static const int MAX_LDS_LIMIT = 3072;  // ranked results per query the LDS top-k kernels hold
 static const int MAX_LIMIT = 1 << 24;  // with the sorted path: bounded by the workspace only
+
+// how the all-candidates path ranks: select (k_select_topl) when it shrinks the sort, LDS-ranked for limit <= 3072
+struct SelectPlan { bool select, sort_lds; int64_t stride; int p2; size_t lds; };
+static SelectPlan select_plan(int L, int nq, int64_t n_cand) {
+    SelectPlan sp;
+    sp.stride = (int64_t)L < n_cand ? (int64_t)L : (n_cand > 0 ? n_cand : 1);
+    sp.sort_lds = L <= MAX_LDS_LIMIT;
+    sp.select = sp.sort_lds || (double)nq * (double)sp.stride <= 0.5 * (double)n_cand;
+    if (getenv("CIS_NO_SELECT")) sp.select = sp.sort_lds = false;  // experiments: the full segmented sort
+    if (!sp.select) sp.sort_lds = false;
+    sp.p2 = 64;
+    while (sp.p2 < L && sp.sort_lds) sp.p2 <<= 1;
+    sp.lds = (sp.sort_lds ? (size_t)sp.p2 * 12 : 0) + (size_t)SEL_CAND * 12 + sizeof(SelShared) + 16;
+    return sp;
+}
+
+// limit above the float32-prefilter kernel's 440: rank through the all-candidates path (the LDS top-k kernel of the exact
+// scan holds up to 3072 but slows down steeply with limit)
+static bool use_all_path(const cis_index* ix, int M, int K, int L) {
+    if (L > MAX_LDS_LIMIT) return true;
+    return !ix->force_exact_scan && L > 440;
+}
 
 // one sub-batch of queries (device pointers); writes ranked partial hits [nq][L] and visited [nq]
 static const int CIS_RETRY_SMALLER = 1;  // internal: the batch does not fit the workspace budget, halve it
@@ -3009,8 +3278,11 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         const bool fast_ = scan2_supported(M, K, L) && !ix->force_exact_scan;
         const int64_t S_ = fast_ ? scan2_geom(M, K, L, nq).S : L;
         double need = (double)n_items * S_ * (fast_ ? sizeof(uint64_t) : sizeof(cis_hit)) + (double)n_tabs * nf * K * sizeof(double);
-        if (L > MAX_LDS_LIMIT)  // sorted path: two key and two value buffers over every candidate
-            need = 32.0 * (double)h_tot[2] + (double)n_tabs * nf * K * sizeof(double);
+        if (use_all_path(ix, M, K, L)) {  // every candidate's key, plus the selected pairs or the full sort's buffers
+            const SelectPlan sp_ = select_plan(L, nq, (int64_t)h_tot[2]);
+            need = (sp_.select ? 8.0 * (double)h_tot[2] + (sp_.sort_lds ? 16.0 : 32.0) * (double)nq * (double)sp_.stride : 32.0 * (double)h_tot[2]) +
+                   (double)n_tabs * nf * K * sizeof(double);
+        }
         if (need > 4.0e9 && nq > 1) return CIS_RETRY_SMALLER;
     }
     ix->stats[0] += (int64_t)h_tot[2];
@@ -3021,7 +3293,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     CIS_TRY(ix->w_items.reserve((size_t)(n_items + 1) * sizeof(WorkItem)));
     CIS_TRY(ix->w_tabs.reserve((size_t)(n_tabs + 1) * sizeof(TabDesc)));
     CIS_TRY(ix->w_T.reserve((size_t)(n_tabs + 1) * nf * K * sizeof(double)));
-    const bool big = L > MAX_LDS_LIMIT;  // ranked by a segmented sort over all candidates (below)
+    const bool big = use_all_path(ix, M, K, L);  // ranked over all candidates' exact distances (below)
     const bool fast = scan2_supported(M, K, L) && !ix->force_exact_scan;
     const Scan2Geom geom = scan2_geom(M, K, L, nq);
     const int S = fast ? geom.S : L;  // hit slots per work item (fast kernel: <= L per wave)
@@ -3069,40 +3341,74 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         hipLaunchKernelGGL(k_tables_f32, dim3((unsigned)ceil_div(ne, 256)), dim3(256), 0, st, T, ne, nf, K, T32);
     }
     if (big) {
-        // 4'. every candidate's exact distance, stable segmented sort per query, first `limit` of every segment
+        // 4'. every candidate's exact distance; then per query either a radix select of the `limit` best (ranked in LDS
+        // for limit <= 3072, by a stable segmented sort of the selected pairs above) or, when `limit` is of the order
+        // of the candidate count, the stable segmented sort of everything
         CIS_TRY(mark(2));
         const int64_t n_cand = (int64_t)h_tot[2];
         CIS_REQUIRE(n_cand < ((int64_t)1 << 32), "query batch too large for the sorted path");
         const uint8_t* codes = ix->d_codes.as<uint8_t>();
         const int64_t* ids = ix->d_ids.as<int64_t>();
+        const SelectPlan sp = select_plan(L, nq, n_cand);
+        const int64_t n_sel = sp.select ? (int64_t)nq * sp.stride : 0;
         size_t scan_tmp = 0, sort_tmp = 0;
         CIS_TRY(cis_exclusive_scan_i64(nullptr, &scan_tmp, nullptr, nullptr, n_items + 1, st));
-        CIS_TRY(cis_seg_sort_u64(nullptr, &sort_tmp, nullptr, nullptr, nullptr, nullptr, n_cand, nq, nullptr, st));
+        if (!sp.sort_lds)
+            CIS_TRY(cis_seg_sort_u64(nullptr, &sort_tmp, nullptr, nullptr, nullptr, nullptr, sp.select ? n_sel : n_cand, nq, nullptr, nullptr, st));
         const size_t tmp_bytes = ((scan_tmp > sort_tmp ? scan_tmp : sort_tmp) + 255) & ~(size_t)255;
-        const size_t n_i64 = (size_t)2 * (n_items + 1) + (size_t)(nq + 2);
-        CIS_TRY(ix->w_hits.reserve(n_i64 * 8 + (size_t)4 * (n_cand + 1) * 8 + tmp_bytes + 256));
+        const size_t n_i64 = (size_t)2 * (n_items + 1) + (size_t)4 * (nq + 2);
+        const size_t n_pairs = sp.select ? (size_t)(n_cand + 1) + (size_t)(sp.sort_lds ? 2 : 4) * (n_sel + 1) : (size_t)4 * (n_cand + 1);
+        CIS_TRY(ix->w_hits.reserve(n_i64 * 8 + n_pairs * 8 + tmp_bytes + 256));
         int64_t* lens = ix->w_hits.as<int64_t>();
         int64_t* cand_start = lens + (n_items + 1);
         int64_t* seg = cand_start + (n_items + 1);
-        uint64_t* keys_in = reinterpret_cast<uint64_t*>(seg + (nq + 2));
-        uint64_t* keys_out = keys_in + (n_cand + 1);
-        uint64_t* vals_in = keys_out + (n_cand + 1);
-        uint64_t* vals_out = vals_in + (n_cand + 1);
-        void* tmp = reinterpret_cast<void*>(((uintptr_t)(vals_out + (n_cand + 1)) + 255) & ~(uintptr_t)255);
+        int64_t* seg_b = seg + (nq + 2);
+        int64_t* seg_e = seg_b + (nq + 2);
+        int* nsel = reinterpret_cast<int*>(seg_e + (nq + 2));
+        uint64_t* keys_in = reinterpret_cast<uint64_t*>(seg_e + 2 * (nq + 2));
+        uint64_t* b1 = keys_in + (n_cand + 1);  // full sort: keys_out, vals_in, vals_out; select: sel_keys, sel_vals[, sorted copies]
+        const size_t bl = sp.select ? (size_t)(n_sel + 1) : (size_t)(n_cand + 1);
+        uint64_t* b2 = b1 + bl;
+        uint64_t* b3 = b2 + bl;
+        uint64_t* b4 = b3 + bl;
+        void* tmp = reinterpret_cast<void*>(((uintptr_t)(sp.select ? (sp.sort_lds ? b3 : b3 + 2 * bl) : b4) + 255) & ~(uintptr_t)255);
         if (n_items > 0) {
             hipLaunchKernelGGL(k_item_lens, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, lens);
             size_t b = tmp_bytes;
             CIS_TRY(cis_exclusive_scan_i64(tmp, &b, lens, cand_start, n_items, st));
         }
         hipLaunchKernelGGL(k_seg_begin, dim3((unsigned)ceil_div(nq + 1, 256)), dim3(256), 0, st, cand_start, item_off, nq, n_items, n_cand, seg);
-        if (n_items > 0) {
-            hipLaunchKernelGGL(k_adc_all, dim3((unsigned)n_items, 8), dim3(256), 0, st, items, cand_start, T, codes, M, K, keys_in, vals_in);
-            size_t b = tmp_bytes;
-            CIS_TRY(cis_seg_sort_u64(tmp, &b, keys_in, keys_out, vals_in, vals_out, n_cand, nq, seg, st));
+        const uint64_t *rk = nullptr, *rv = nullptr;  // ranked pairs
+        if (!sp.select) {
+            uint64_t *keys_out = b1, *vals_in = b2, *vals_out = b3;
+            if (n_items > 0) {
+                hipLaunchKernelGGL(k_adc_all, dim3((unsigned)n_items, 8), dim3(256), 0, st, items, cand_start, T, codes, M, K, keys_in, vals_in);
+                size_t b = tmp_bytes;
+                CIS_TRY(cis_seg_sort_u64(tmp, &b, keys_in, keys_out, vals_in, vals_out, n_cand, nq, seg, seg + 1, st));
+            }
+            rk = keys_out; rv = vals_out;
+        } else {
+            uint64_t *sel_keys = b1, *sel_vals = b2;
+            if (n_items > 0)
+                hipLaunchKernelGGL(k_adc_all, dim3((unsigned)n_items, 8), dim3(256), 0, st, items, cand_start, T, codes, M, K, keys_in,
+                                   (uint64_t*)nullptr);
+            if (sp.sort_lds) {
+                hipLaunchKernelGGL(k_select_topl<true>, dim3((unsigned)nq), dim3(SEL_THREADS), sp.lds, st, keys_in, seg, cand_start, item_off,
+                                   n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, (int64_t*)nullptr, (int64_t*)nullptr);
+                rk = sel_keys; rv = sel_vals;
+            } else {
+                uint64_t *srt_keys = b3, *srt_vals = b3 + bl;
+                hipLaunchKernelGGL(k_select_topl<false>, dim3((unsigned)nq), dim3(SEL_THREADS), sp.lds, st, keys_in, seg, cand_start, item_off,
+                                   n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, seg_b, seg_e);
+                size_t b = tmp_bytes;
+                CIS_TRY(cis_seg_sort_u64(tmp, &b, sel_keys, srt_keys, sel_vals, srt_vals, n_sel, nq, seg_b, seg_e, st));
+                rk = srt_keys; rv = srt_vals;
+            }
         }
         CIS_TRY(mark(3));
         hipLaunchKernelGGL(k_emit_sorted, dim3((unsigned)ceil_div(L, 1024) < 64 ? (unsigned)ceil_div(L, 1024) : 64, (unsigned)nq), dim3(256), 0, st,
-                           keys_out, vals_out, seg, items, ids, nq, L, out.hits, out.ids, out.dists, out.n_found, out.cells, out.pos);
+                           rk, rv, seg, sp.select ? nsel : (const int*)nullptr, sp.stride, items, ids, nq, L, out.hits, out.ids, out.dists,
+                           out.n_found, out.cells, out.pos);
         if (out.visited)
             hipLaunchKernelGGL(k_copy_visited, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, plan, nq, out.visited);
         CIS_CHECK_HIP(hipGetLastError());

@@ -12,11 +12,11 @@
 
 // Two-call convention like rocPRIM's: temp == nullptr -> only *temp_bytes is set.
 int cis_seg_sort_u64(void* temp, size_t* temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint64_t* vals_in,
-                     uint64_t* vals_out, int64_t n, int nseg, const int64_t* seg_begin /* [nseg + 1] */, hipStream_t st) {
+                     uint64_t* vals_out, int64_t n, int nseg, const int64_t* seg_begin, const int64_t* seg_end, hipStream_t st) {
     CIS_REQUIRE(n >= 0 && n < ((int64_t)1 << 32) && nseg >= 0, "segmented sort: size out of range");
     size_t bytes = *temp_bytes;
     CIS_CHECK_HIP(rocprim::segmented_radix_sort_pairs(temp, bytes, keys_in, keys_out, vals_in, vals_out, (unsigned int)n,
-                                                      (unsigned int)nseg, seg_begin, seg_begin + 1, 0, 64, st));
+                                                      (unsigned int)nseg, seg_begin, seg_end, 0, 64, st));
     *temp_bytes = bytes;
     return CIS_OK;
 }

@@ -453,6 +453,51 @@ def test_large_limit_sorted_path_matches_oracle():
             assert (r["ids"][qi, n:] == -1).all()
 
 
+@pytest.mark.gpu
+def test_select_path_matches_oracle_and_exact_kernel():
+    """limit above the float32-prefilter kernel's 440: every candidate is scored exactly, a per-query radix select finds
+    the cut of the stable ranking, the selected pairs are ranked in LDS (limit <= 3072) or by the segmented sort (above).
+    Covers: cut inside a crowd of > 1024 exact ties (retrieval order decides), cut inside a small tie group, segments
+    shorter than the limit, both select modes, and the full-sort fallback (limit of the order of the candidate count)."""
+    from oracle import lopq_oracle as O
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    z, X, Q = load_golden("c2")
+    m = hip_model(z)
+    coarse, fine = z["coarse"], z["fine"]
+    n_dup = 3000
+    dc, df = np.repeat(coarse[:1], n_dup, 0), np.repeat(fine[:1], n_dup, 0)
+    sc, sf = np.repeat(coarse[1:2], 7, 0), np.repeat(fine[1:2], 7, 0)
+    C = np.concatenate([coarse[:20000], dc, coarse[20000:], sc])
+    F = np.concatenate([fine[:20000], df, fine[20000:], sf])
+    ids = np.arange(len(C), dtype=np.int64) * 3 + 1
+    s = LOPQSearcherHIP(m)
+    s.add_codes_array(C, F, ids, dedup=False)
+    oi = O.OracleCSRIndex(O.OracleModel.from_npz(z), C, F, ids=ids)
+    Qx = np.concatenate([Q[:5], X[:2]])  # the last two queries sit on the duplicated vectors
+    nq = len(Qx)
+    cases = [(10000, 441), (10000, 1000), (10000, 3072), (40000, 2500), (200, 3000), (60000, 3073), (100000, 4000),
+             (5000, None)]
+    for quota, limit in cases:
+        r = s.search_batch(Qx, quota=quota, limit=limit)
+        L = quota if limit is None else limit
+        assert r["ids"].shape == (nq, L)
+        for qi in range(nq):
+            oid, od, visited = oi.search(Qx[qi], quota=quota, limit=limit)
+            n = len(oid)
+            assert r["n_found"][qi] == n and r["visited"][qi] == visited, (quota, limit, qi)
+            np.testing.assert_array_equal(r["ids"][qi, :n], oid, err_msg=str((quota, limit, qi)))
+            np.testing.assert_allclose(r["dists"][qi, :n], od, rtol=1e-9)
+            assert (r["ids"][qi, n:] == -1).all()
+    # same bits as the exact scan kernel's LDS top-k (the path these limits took before)
+    a = s.search_batch(Qx, quota=10000, limit=700)
+    s.set_scan_mode(exact_only=True)
+    b = s.search_batch(Qx, quota=10000, limit=700)
+    s.set_scan_mode(exact_only=False)
+    np.testing.assert_array_equal(a["ids"], b["ids"])
+    np.testing.assert_array_equal(a["dists"].view(np.uint64), b["dists"].view(np.uint64))
+    np.testing.assert_array_equal(a["visited"], b["visited"])
+
+
 def _random_model(V, M, K, D, seed, dtype=np.float32):
     """Untrained model of a given shape (production configs use V = 256 ... 4096, conf/*.json): centroids drawn from the
     data distribution, random orthogonal local rotations."""
