@@ -2851,18 +2851,104 @@ __global__ void k_seg_begin(const int64_t* __restrict__ cand_start, const int64_
     seg[q] = (q == nq || it >= n_items) ? n_cand : cand_start[it];
 }
 
+// per-query range of the keys (for the selection kernel): workgroup reduction in LDS, one pair of global atomics
+__device__ __forceinline__ void publish_key_range(uint64_t mn, uint64_t mx, unsigned long long* __restrict__ qmin,
+                                                  unsigned long long* __restrict__ qmax, int q) {
+    __shared__ unsigned long long s_mm[2];
+    if (threadIdx.x == 0) { s_mm[0] = ~0ull; s_mm[1] = 0ull; }
+    __syncthreads();
+    if (mn <= mx) {
+        atomicMin(&s_mm[0], (unsigned long long)mn);
+        atomicMax(&s_mm[1], (unsigned long long)mx);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_mm[0] <= s_mm[1]) {
+        atomicMin(&qmin[q], s_mm[0]);
+        atomicMax(&qmax[q], s_mm[1]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_adc_all(const WorkItem* __restrict__ items, const int64_t* __restrict__ cand_start,
                                                  const double* __restrict__ T, const uint8_t* __restrict__ codes, int M, int K,
-                                                 uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
+                                                 uint64_t* __restrict__ keys, uint64_t* __restrict__ vals,
+                                                 unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax) {
     const WorkItem it = items[blockIdx.x];
     const int nf = M / 2;
     const double* t0 = T + (int64_t)it.tab0 * nf * K;
     const double* t1 = T + (int64_t)it.tab1 * nf * K;
     const int64_t o = cand_start[blockIdx.x];
+    uint64_t mn = ~0ull, mx = 0ull;
     for (int p = blockIdx.y * blockDim.x + threadIdx.x; p < it.len; p += gridDim.y * blockDim.x) {
-        keys[o + p] = (uint64_t)__double_as_longlong(adc64_global(codes, it.start + p, M, K, t0, t1));
+        const uint64_t kk = (uint64_t)__double_as_longlong(adc64_global(codes, it.start + p, M, K, t0, t1));
+        keys[o + p] = kk;
+        mn = kk < mn ? kk : mn;
+        mx = kk > mx ? kk : mx;
         if (vals) vals[o + p] = ((uint64_t)blockIdx.x << 32) | (uint32_t)p;
     }
+    if (qmin) publish_key_range(mn, mx, qmin, qmax, it.q);
+}
+
+// the same with the item's two table halves staged in LDS (M in {4, 8, 16}, K <= 256): the lookups of a cell's candidates
+// are random reads of 2 * nf * K float64 entries, served from LDS instead of L2
+template <int MT>
+__global__ __launch_bounds__(256) void k_adc_all_lds(const WorkItem* __restrict__ items, const int64_t* __restrict__ cand_start,
+                                                     const double* __restrict__ T, const uint8_t* __restrict__ codes, int K,
+                                                     uint64_t* __restrict__ keys, uint64_t* __restrict__ vals,
+                                                     unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax) {
+    extern __shared__ __align__(16) double adc_tab[];  // [MT][K]
+    const WorkItem it = items[blockIdx.x];
+    int nch = (it.len + 2047) / 2048;  // workgroups that share this item (<= gridDim.y): ~2048 candidates each at least
+    nch = nch < 1 ? 1 : (nch > (int)gridDim.y ? (int)gridDim.y : nch);
+    if ((int)blockIdx.y >= nch) return;
+    constexpr int nf = MT / 2;
+    const double* t0 = T + (int64_t)it.tab0 * nf * K;
+    const double* t1 = T + (int64_t)it.tab1 * nf * K;
+    for (int e = threadIdx.x; e < nf * K; e += 256) {
+        adc_tab[e] = t0[e];
+        adc_tab[nf * K + e] = t1[e];
+    }
+    __syncthreads();
+    const double* l0 = adc_tab;
+    const double* l1 = adc_tab + nf * K;
+    const int64_t o = cand_start[blockIdx.x];
+    const int step = nch * 256;
+    int p = blockIdx.y * 256 + threadIdx.x;
+    uint64_t mn = ~0ull, mx = 0ull;
+    for (; p + step < it.len; p += 2 * step) {  // two candidates in flight
+        const CodeWords<MT> ca = load_code<MT>(codes, it.start + p);
+        const CodeWords<MT> cb = load_code<MT>(codes, it.start + p + step);
+        const uint64_t ka = (uint64_t)__double_as_longlong(adc64_words<MT>(ca.w, K, l0, l1));
+        const uint64_t kb = (uint64_t)__double_as_longlong(adc64_words<MT>(cb.w, K, l0, l1));
+        keys[o + p] = ka;
+        keys[o + p + step] = kb;
+        const uint64_t lo = ka < kb ? ka : kb, hi = ka < kb ? kb : ka;
+        mn = lo < mn ? lo : mn;
+        mx = hi > mx ? hi : mx;
+        if (vals) {
+            vals[o + p] = ((uint64_t)blockIdx.x << 32) | (uint32_t)p;
+            vals[o + p + step] = ((uint64_t)blockIdx.x << 32) | (uint32_t)(p + step);
+        }
+    }
+    if (p < it.len) {
+        const CodeWords<MT> ca = load_code<MT>(codes, it.start + p);
+        const uint64_t ka = (uint64_t)__double_as_longlong(adc64_words<MT>(ca.w, K, l0, l1));
+        keys[o + p] = ka;
+        mn = ka < mn ? ka : mn;
+        mx = ka > mx ? ka : mx;
+        if (vals) vals[o + p] = ((uint64_t)blockIdx.x << 32) | (uint32_t)p;
+    }
+    if (qmin) publish_key_range(mn, mx, qmin, qmax, it.q);
+}
+
+static void launch_adc_all(int64_t n_items, hipStream_t st, const WorkItem* items, const int64_t* cand_start, const double* T,
+                           const uint8_t* codes, int M, int K, uint64_t* keys, uint64_t* vals, unsigned long long* qmin,
+                           unsigned long long* qmax) {
+    const dim3 g((unsigned)n_items, 8);
+    const size_t lds = (size_t)M * K * sizeof(double);
+    if (K <= 256 && M == 4) hipLaunchKernelGGL(k_adc_all_lds<4>, g, dim3(256), lds, st, items, cand_start, T, codes, K, keys, vals, qmin, qmax);
+    else if (K <= 256 && M == 8) hipLaunchKernelGGL(k_adc_all_lds<8>, g, dim3(256), lds, st, items, cand_start, T, codes, K, keys, vals, qmin, qmax);
+    else if (K <= 256 && M == 16) hipLaunchKernelGGL(k_adc_all_lds<16>, g, dim3(256), lds, st, items, cand_start, T, codes, K, keys, vals, qmin, qmax);
+    else hipLaunchKernelGGL(k_adc_all, g, dim3(256), 0, st, items, cand_start, T, codes, M, K, keys, vals, qmin, qmax);
 }
 
 __global__ void k_emit_sorted(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ vals, const int64_t* __restrict__ seg,
@@ -2978,8 +3064,7 @@ __device__ __forceinline__ uint64_t sel_val_of(int64_t g, const int64_t* __restr
 }
 
 struct SelShared {
-    unsigned long long mn, mx;
-    int bin, less, cnt, cn;
+    int bin, less, cnt, cn, on;
     unsigned int cut_idx;
     int wsum[SEL_THREADS / 64];
 };
@@ -2987,7 +3072,9 @@ struct SelShared {
 template <bool SORT_LDS>
 __global__ __launch_bounds__(SEL_THREADS) void k_select_topl(const uint64_t* __restrict__ keys, const int64_t* __restrict__ seg,
                                                               const int64_t* __restrict__ cand_start, const int64_t* __restrict__ item_off,
-                                                              int64_t n_items, int L, int P2, int64_t stride, uint64_t* __restrict__ sel_keys,
+                                                              const unsigned long long* __restrict__ qmin,
+                                                              const unsigned long long* __restrict__ qmax, int64_t n_items, int L, int P2,
+                                                              int64_t stride, uint64_t* __restrict__ sel_keys,
                                                               uint64_t* __restrict__ sel_vals, int* __restrict__ nsel,
                                                               int64_t* __restrict__ seg_b, int64_t* __restrict__ seg_e) {
     extern __shared__ __align__(16) unsigned char sel_lds[];
@@ -3007,22 +3094,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_topl(const uint64_t* __r
     const int nv = n64 < (int64_t)L ? (int)n64 : L;
     uint64_t cut_key = ~0ull;
     unsigned int cut_idx = 0xffffffffu;
+    bool gathered = false;  // SORT_LDS: the list is already in LDS (unordered)
     if (n64 > (int64_t)L) {
-        // A. range of the keys
-        if (tid == 0) { sh->mn = ~0ull; sh->mx = 0ull; }
-        __syncthreads();
-        {
-            uint64_t mn = ~0ull, mx = 0ull;
-            for (unsigned int i = tid; i < n; i += nt) {
-                const uint64_t v = k[i];
-                mn = v < mn ? v : mn;
-                mx = v > mx ? v : mx;
-            }
-            atomicMin(&sh->mn, (unsigned long long)mn);
-            atomicMax(&sh->mx, (unsigned long long)mx);
-        }
-        __syncthreads();
-        const uint64_t mn = sh->mn, mx = sh->mx;
+        // A. range of the keys: published by the distance kernel
+        const uint64_t mn = qmin[q], mx = qmax[q];
         int hi_shift = (mn == mx) ? 0 : 64 - __clzll((long long)(mn ^ mx));  // bits [0, hi_shift) differ somewhere
         uint64_t prefix = hi_shift >= 64 ? 0ull : (mn >> hi_shift);
         int r = L;            // rank (1-based) of the cut among the keys that share `prefix`
@@ -3034,6 +3109,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_topl(const uint64_t* __r
             const unsigned int mask = (1u << bits) - 1u;
             for (int b = tid; b < (1 << SEL_BITS); b += nt) hist[b] = 0;
             __syncthreads();
+#pragma unroll 4
             for (unsigned int i = tid; i < n; i += nt) {
                 const uint64_t v = k[i];
                 if (hi_shift >= 64 || (v >> hi_shift) == prefix) atomicAdd(&hist[(unsigned int)(v >> shift) & mask], 1u);
@@ -3060,14 +3136,20 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_topl(const uint64_t* __r
         }
         if (c <= (unsigned)SEL_CAND) {
             // C. the threshold bin's keys, ranked in LDS
-            if (tid == 0) sh->cn = 0;
+            if (tid == 0) { sh->cn = 0; sh->on = 0; }
             __syncthreads();
+#pragma unroll 4
             for (unsigned int i = tid; i < n; i += nt) {
                 const uint64_t v = k[i];
-                if (hi_shift >= 64 || (v >> hi_shift) == prefix) {
+                const uint64_t hv = hi_shift >= 64 ? 0ull : (v >> hi_shift);
+                if (hv == prefix) {
                     const int j = atomicAdd(&sh->cn, 1);
                     ckey[j] = v;
                     cidx[j] = i;
+                } else if (SORT_LDS && hv < prefix) {  // below the threshold bin: in, whatever the order (ranked in LDS below)
+                    const int j = atomicAdd(&sh->on, 1);
+                    okey[j] = v;
+                    oidx[j] = i;
                 }
             }
             __syncthreads();
@@ -3077,6 +3159,11 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_topl(const uint64_t* __r
             sel_block_bitonic(ckey, cidx, c2);
             cut_key = ckey[r - 1];
             cut_idx = cidx[r - 1];
+            if (SORT_LDS) {  // the first r of the bin complete the list
+                const int on = sh->on;
+                for (int j = tid; j < r; j += nt) { okey[on + j] = ckey[j]; oidx[on + j] = cidx[j]; }
+                gathered = true;
+            }
             __syncthreads();
         } else {
             // a crowd of exact ties at the cut (every bit fixed): the first r of them in retrieval order
@@ -3102,6 +3189,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_topl(const uint64_t* __r
     if (it_hi > n_items) it_hi = n_items;
     const int64_t ob = (int64_t)q * stride;
     int base = 0;
+    if (!gathered)
     for (unsigned int i0 = 0; i0 < n && base < nv; i0 += (unsigned)(nt * SEL_PER)) {
         const unsigned int i = i0 + tid * SEL_PER;
         uint64_t v[SEL_PER];
@@ -3356,7 +3444,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (!sp.sort_lds)
             CIS_TRY(cis_seg_sort_u64(nullptr, &sort_tmp, nullptr, nullptr, nullptr, nullptr, sp.select ? n_sel : n_cand, nq, nullptr, nullptr, st));
         const size_t tmp_bytes = ((scan_tmp > sort_tmp ? scan_tmp : sort_tmp) + 255) & ~(size_t)255;
-        const size_t n_i64 = (size_t)2 * (n_items + 1) + (size_t)4 * (nq + 2);
+        const size_t n_i64 = (size_t)2 * (n_items + 1) + (size_t)6 * (nq + 2);
         const size_t n_pairs = sp.select ? (size_t)(n_cand + 1) + (size_t)(sp.sort_lds ? 2 : 4) * (n_sel + 1) : (size_t)4 * (n_cand + 1);
         CIS_TRY(ix->w_hits.reserve(n_i64 * 8 + n_pairs * 8 + tmp_bytes + 256));
         int64_t* lens = ix->w_hits.as<int64_t>();
@@ -3365,7 +3453,9 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         int64_t* seg_b = seg + (nq + 2);
         int64_t* seg_e = seg_b + (nq + 2);
         int* nsel = reinterpret_cast<int*>(seg_e + (nq + 2));
-        uint64_t* keys_in = reinterpret_cast<uint64_t*>(seg_e + 2 * (nq + 2));
+        unsigned long long* qmin = reinterpret_cast<unsigned long long*>(seg_e + 2 * (nq + 2));
+        unsigned long long* qmax = qmin + (nq + 2);
+        uint64_t* keys_in = reinterpret_cast<uint64_t*>(qmax + (nq + 2));
         uint64_t* b1 = keys_in + (n_cand + 1);  // full sort: keys_out, vals_in, vals_out; select: sel_keys, sel_vals[, sorted copies]
         const size_t bl = sp.select ? (size_t)(n_sel + 1) : (size_t)(n_cand + 1);
         uint64_t* b2 = b1 + bl;
@@ -3382,24 +3472,25 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (!sp.select) {
             uint64_t *keys_out = b1, *vals_in = b2, *vals_out = b3;
             if (n_items > 0) {
-                hipLaunchKernelGGL(k_adc_all, dim3((unsigned)n_items, 8), dim3(256), 0, st, items, cand_start, T, codes, M, K, keys_in, vals_in);
+                launch_adc_all(n_items, st, items, cand_start, T, codes, M, K, keys_in, vals_in, nullptr, nullptr);
                 size_t b = tmp_bytes;
                 CIS_TRY(cis_seg_sort_u64(tmp, &b, keys_in, keys_out, vals_in, vals_out, n_cand, nq, seg, seg + 1, st));
             }
             rk = keys_out; rv = vals_out;
         } else {
             uint64_t *sel_keys = b1, *sel_vals = b2;
+            CIS_CHECK_HIP(hipMemsetAsync(qmin, 0xff, (size_t)(nq + 2) * 8, st));
+            CIS_CHECK_HIP(hipMemsetAsync(qmax, 0, (size_t)(nq + 2) * 8, st));
             if (n_items > 0)
-                hipLaunchKernelGGL(k_adc_all, dim3((unsigned)n_items, 8), dim3(256), 0, st, items, cand_start, T, codes, M, K, keys_in,
-                                   (uint64_t*)nullptr);
+                launch_adc_all(n_items, st, items, cand_start, T, codes, M, K, keys_in, nullptr, qmin, qmax);
             if (sp.sort_lds) {
                 hipLaunchKernelGGL(k_select_topl<true>, dim3((unsigned)nq), dim3(SEL_THREADS), sp.lds, st, keys_in, seg, cand_start, item_off,
-                                   n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, (int64_t*)nullptr, (int64_t*)nullptr);
+                                   qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, (int64_t*)nullptr, (int64_t*)nullptr);
                 rk = sel_keys; rv = sel_vals;
             } else {
                 uint64_t *srt_keys = b3, *srt_vals = b3 + bl;
                 hipLaunchKernelGGL(k_select_topl<false>, dim3((unsigned)nq), dim3(SEL_THREADS), sp.lds, st, keys_in, seg, cand_start, item_off,
-                                   n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, seg_b, seg_e);
+                                   qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, seg_b, seg_e);
                 size_t b = tmp_bytes;
                 CIS_TRY(cis_seg_sort_u64(tmp, &b, sel_keys, srt_keys, sel_vals, srt_vals, n_sel, nq, seg_b, seg_e, st));
                 rk = srt_keys; rv = srt_vals;
