@@ -2359,6 +2359,7 @@ struct cis_index {
     int64_t stats[4] = {0, 0, 0, 0};
     // optional stage timing (hipEvents on the launch stream)
     bool force_exact_scan = false;  // tests: run every item through the float64 kernel
+    bool force_prefilter_scan = false;  // tests: the float32-prefilter kernel also for small batches
     int profiling = 0;  // 0 off, 1 events around the scan kernel only, 2 events around every stage
     int64_t* h_totals = nullptr;    // pinned, device-mapped: the plan totals land here without a copy
     int64_t* d_h_totals = nullptr;
@@ -2683,8 +2684,9 @@ extern "C" int cis_multisequence(const void* X, int x_dtype, const void* C0, con
 }
 
 extern "C" int cis_index_set_scan_mode(cis_index* ix, int mode) {
-    CIS_REQUIRE(ix != nullptr && (mode == 0 || mode == 1), "bad scan mode");
+    CIS_REQUIRE(ix != nullptr && (mode == 0 || mode == 1 || mode == 2), "bad scan mode");
     ix->force_exact_scan = (mode == 1);
+    ix->force_prefilter_scan = (mode == 2);
     return CIS_OK;
 }
 
@@ -3253,9 +3255,24 @@ static SelectPlan select_plan(int L, int nq, int64_t n_cand) {
 
 // limit above the float32-prefilter kernel's 440: rank through the all-candidates path (the LDS top-k kernel of the exact
 // scan holds up to 3072 but slows down steeply with limit)
-static bool use_all_path(const cis_index* ix, int M, int K, int L) {
+// Largest batch at which the all-candidates path beats the float32-prefilter scan for limit <= 440 (measured with
+// tools/bench_limits.py on the bench index, 40 k candidates per query): a small batch has too few (query, cell) work items
+// to fill the persistent scan kernel, and its per-wave regions grow with limit, while scoring every candidate with one
+// workgroup per 2048 of them and selecting per query costs the same 0.18-0.4 ms whatever the limit.
+static int small_batch_nq(int L) {
+    static const int forced = getenv("CIS_SMALL_NQ") ? atoi(getenv("CIS_SMALL_NQ")) : -1;  // experiments
+    if (forced >= 0) return forced;
+    if (L <= 16) return 0;
+    if (L <= 184) return 63;
+    if (L <= 300) return 256;
+    return 512;
+}
+
+static bool use_all_path(const cis_index* ix, int M, int K, int L, int nq) {
     if (L > MAX_LDS_LIMIT) return true;
-    return !ix->force_exact_scan && L > 440;
+    if (ix->force_exact_scan) return false;
+    if (L > 440) return true;
+    return !ix->force_prefilter_scan && nq <= small_batch_nq(L);
 }
 
 // one sub-batch of queries (device pointers); writes ranked partial hits [nq][L] and visited [nq]
@@ -3366,7 +3383,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         const bool fast_ = scan2_supported(M, K, L) && !ix->force_exact_scan;
         const int64_t S_ = fast_ ? scan2_geom(M, K, L, nq).S : L;
         double need = (double)n_items * S_ * (fast_ ? sizeof(uint64_t) : sizeof(cis_hit)) + (double)n_tabs * nf * K * sizeof(double);
-        if (use_all_path(ix, M, K, L)) {  // every candidate's key, plus the selected pairs or the full sort's buffers
+        if (use_all_path(ix, M, K, L, nq)) {  // every candidate's key, plus the selected pairs or the full sort's buffers
             const SelectPlan sp_ = select_plan(L, nq, (int64_t)h_tot[2]);
             need = (sp_.select ? 8.0 * (double)h_tot[2] + (sp_.sort_lds ? 16.0 : 32.0) * (double)nq * (double)sp_.stride : 32.0 * (double)h_tot[2]) +
                    (double)n_tabs * nf * K * sizeof(double);
@@ -3381,7 +3398,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     CIS_TRY(ix->w_items.reserve((size_t)(n_items + 1) * sizeof(WorkItem)));
     CIS_TRY(ix->w_tabs.reserve((size_t)(n_tabs + 1) * sizeof(TabDesc)));
     CIS_TRY(ix->w_T.reserve((size_t)(n_tabs + 1) * nf * K * sizeof(double)));
-    const bool big = use_all_path(ix, M, K, L);  // ranked over all candidates' exact distances (below)
+    const bool big = use_all_path(ix, M, K, L, nq);  // ranked over all candidates' exact distances (below)
     const bool fast = scan2_supported(M, K, L) && !ix->force_exact_scan;
     const Scan2Geom geom = scan2_geom(M, K, L, nq);
     const int S = fast ? geom.S : L;  // hit slots per work item (fast kernel: <= L per wave)

@@ -126,6 +126,8 @@ class LOPQSearcherHIP(LOPQSearcherBase):
         L = _lib.lib()
         _lib.check(L.cis_index_create(_lib.ctypes.byref(out), self.model._handle()))
         self._ix = out.value
+        if type(self).default_prefilter_only:
+            _lib.check(L.cis_index_set_scan_mode(self._ix, 2))
         if self._shard is not None:
             rank, world = self._shard[0], self._shard[1]
             owner = None
@@ -353,9 +355,15 @@ class LOPQSearcherHIP(LOPQSearcherBase):
         return {"candidates": int(st[0]), "items": int(st[1]), "tables": int(st[2]), "scan_launches": int(st[3])}
 
 
-    def set_scan_mode(self, exact_only=False):
-        """Force the exact float64 ADC scan kernel (tests); results are identical either way."""
-        _lib.check(_lib.lib().cis_index_set_scan_mode(self._ix, 1 if exact_only else 0))
+    default_prefilter_only = False  # tests: new searchers keep the float32-prefilter kernel for small batches too
+
+    def set_scan_mode(self, exact_only=False, prefilter_only=None):
+        """Routing of limit <= 440 (tests; results are identical on every route): exact_only forces the float64 scan
+        kernel, prefilter_only keeps the float32-prefilter kernel for small batches, which otherwise take the
+        all-candidates path (shorter kernel chain at low occupancy)."""
+        if prefilter_only is None:
+            prefilter_only = type(self).default_prefilter_only
+        _lib.check(_lib.lib().cis_index_set_scan_mode(self._ix, 1 if exact_only else (2 if prefilter_only else 0)))
 
     def set_profiling(self, enable=True, scan_only=False):
         """Record HIP events on the launch stream (see read_profile): around every stage, or (scan_only) just the pair

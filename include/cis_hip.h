@@ -206,9 +206,11 @@ int cis_index_last_stats(cis_index* ix, int64_t stats[4]);
  *   ms[4] the ADC scan kernel alone (events right before and after its launch)
  *   *launches = number of scan kernel launches accumulated. */
 int cis_index_set_profiling(cis_index* ix, int level /* 0 off, 1 only the pair of events around the scan kernel (ms[4]), 2 every stage */);
-/* ADC scan kernel selection: 0 = automatic (float32-prefilter kernel with exact float64 re-scoring
- * where it applies, exact float64 kernel otherwise), 1 = exact float64 kernel only.  Both produce
- * identical results; the switch exists so that tests can prove it. */
+/* Ranking route selection: 0 = automatic (limit <= 440: float32-prefilter scan kernel with exact float64 re-scoring
+ * where it applies -- small batches take the all-candidates path instead: exact distances of every candidate, radix
+ * select; exact float64 scan kernel otherwise), 1 = exact float64 scan kernel wherever it applies (limit <= 3072),
+ * 2 = like 0 but the float32-prefilter kernel also for small batches.  All routes produce identical results; the
+ * switch exists so that tests can prove it. */
 int cis_index_set_scan_mode(cis_index* ix, int mode);
 int cis_index_read_profile(cis_index* ix, double ms[5], int64_t* launches);
 

@@ -14,6 +14,22 @@ pytestmark = pytest.mark.gpu
 PCA_FIXTURES = ["c2", "c3", "c3b", "c4"]
 ALL = ["tiny", "c1"] + PCA_FIXTURES
 
+_ROUTE_FREE = ("encode", "near_tie", "model_pieces", "selftest", "multisequence", "rerank", "kmeans", "select_path",
+               "large_limit")
+
+
+@pytest.fixture(autouse=True, params=["auto", "prefilter"])
+def route(request):
+    """Every search test runs on both routes of limit <= 440: "auto" (small batches -- what most fixtures are -- take the
+    all-candidates path: exact distances + radix select) and "prefilter" (the float32-prefilter scan kernel whatever the
+    batch size, i.e. the kernel the large batches of bench.py run)."""
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    if request.param == "prefilter" and any(k in request.node.name for k in _ROUTE_FREE):
+        pytest.skip("does not depend on the search route")
+    LOPQSearcherHIP.default_prefilter_only = request.param == "prefilter"
+    yield request.param
+    LOPQSearcherHIP.default_prefilter_only = False
+
 
 def hip_model(z):
     from columbiaimagesearch_amd.lopq import LOPQModel, LOPQModelPCA
@@ -293,7 +309,12 @@ def test_many_exact_ties_fall_back_to_exact_kernel():
                       np.concatenate([fine[:3000], df, fine[3000:6000]]),
                       np.arange(3000 + n_dup + 3000, dtype=np.int64) + 10)
     q = X[:1]  # the duplicated vector itself
+    s.set_scan_mode(prefilter_only=True)
     a = s.search_batch(q, quota=50000, limit=100)
+    s.set_scan_mode(exact_only=False, prefilter_only=False)  # the all-candidates path (a batch of one): tie crowd cut by retrieval order
+    c = s.search_batch(q, quota=50000, limit=100)
+    np.testing.assert_array_equal(a["ids"], c["ids"])
+    np.testing.assert_array_equal(a["dists"].view(np.uint64), c["dists"].view(np.uint64))
     s.set_scan_mode(exact_only=True)
     b = s.search_batch(q, quota=50000, limit=100)
     np.testing.assert_array_equal(a["ids"], b["ids"])

@@ -53,6 +53,7 @@ def run(cases, seed0):
       limit = None if limit is None else int(limit)
       if limit is None and quota > 20000:
           limit = 100
+      s.set_scan_mode(prefilter_only=bool(rs.rand() < 0.5))  # small batches: float32-prefilter kernel or all-candidates path
       r = s.search_batch(Q, quota=quota, limit=limit)
       ok = True
       for qi in range(nq):
