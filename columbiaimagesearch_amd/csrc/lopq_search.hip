@@ -2853,6 +2853,40 @@ __global__ void k_seg_begin(const int64_t* __restrict__ cand_start, const int64_
     seg[q] = (q == nq || it >= n_items) ? n_cand : cand_start[it];
 }
 
+// candidate layout of the all-candidates path in one launch: exclusive scan of the work items' lengths (cand_start),
+// the per-query segment starts (seg[q] = first candidate of query q, seg[nq] = n_cand) and the reset of the key ranges
+__global__ __launch_bounds__(1024) void k_cand_layout(const WorkItem* __restrict__ items, int64_t n_items, const int64_t* __restrict__ item_off,
+                                                      int nq, int64_t n_cand, int64_t* cand_start, int64_t* __restrict__ seg,
+                                                      unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax) {
+    __shared__ int64_t s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t chunk = (n_items + 1023) / 1024;
+    const int64_t lo = tid * chunk, hi = lo + chunk < n_items ? lo + chunk : n_items;
+    int64_t sum = 0;
+    for (int64_t i = lo; i < hi; ++i) sum += items[i].len;
+    int64_t x = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_w[wv] = x;
+    __syncthreads();
+    int64_t run = x - sum;
+    for (int w = 0; w < wv; ++w) run += s_w[w];
+    for (int64_t i = lo; i < hi; ++i) {
+        __hip_atomic_store(&cand_start[i], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        run += items[i].len;
+    }
+    __threadfence();
+    __syncthreads();
+    for (int q = tid; q <= nq; q += 1024) {
+        const int64_t it = item_off[q];
+        seg[q] = (q == nq || it >= n_items) ? n_cand : __hip_atomic_load(&cand_start[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (qmin && q < nq) { qmin[q] = ~0ull; qmax[q] = 0ull; }
+    }
+}
+
 // per-query range of the keys (for the selection kernel): workgroup reduction in LDS, one pair of global atomics
 __device__ __forceinline__ void publish_key_range(uint64_t mn, uint64_t mx, unsigned long long* __restrict__ qmin,
                                                   unsigned long long* __restrict__ qmax, int q) {
@@ -3456,11 +3490,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         const int64_t* ids = ix->d_ids.as<int64_t>();
         const SelectPlan sp = select_plan(L, nq, n_cand);
         const int64_t n_sel = sp.select ? (int64_t)nq * sp.stride : 0;
-        size_t scan_tmp = 0, sort_tmp = 0;
-        CIS_TRY(cis_exclusive_scan_i64(nullptr, &scan_tmp, nullptr, nullptr, n_items + 1, st));
+        size_t sort_tmp = 0;
         if (!sp.sort_lds)
             CIS_TRY(cis_seg_sort_u64(nullptr, &sort_tmp, nullptr, nullptr, nullptr, nullptr, sp.select ? n_sel : n_cand, nq, nullptr, nullptr, st));
-        const size_t tmp_bytes = ((scan_tmp > sort_tmp ? scan_tmp : sort_tmp) + 255) & ~(size_t)255;
+        const size_t tmp_bytes = (sort_tmp + 255) & ~(size_t)255;
         const size_t n_i64 = (size_t)2 * (n_items + 1) + (size_t)6 * (nq + 2);
         const size_t n_pairs = sp.select ? (size_t)(n_cand + 1) + (size_t)(sp.sort_lds ? 2 : 4) * (n_sel + 1) : (size_t)4 * (n_cand + 1);
         CIS_TRY(ix->w_hits.reserve(n_i64 * 8 + n_pairs * 8 + tmp_bytes + 256));
@@ -3479,12 +3512,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         uint64_t* b3 = b2 + bl;
         uint64_t* b4 = b3 + bl;
         void* tmp = reinterpret_cast<void*>(((uintptr_t)(sp.select ? (sp.sort_lds ? b3 : b3 + 2 * bl) : b4) + 255) & ~(uintptr_t)255);
-        if (n_items > 0) {
-            hipLaunchKernelGGL(k_item_lens, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, lens);
-            size_t b = tmp_bytes;
-            CIS_TRY(cis_exclusive_scan_i64(tmp, &b, lens, cand_start, n_items, st));
-        }
-        hipLaunchKernelGGL(k_seg_begin, dim3((unsigned)ceil_div(nq + 1, 256)), dim3(256), 0, st, cand_start, item_off, nq, n_items, n_cand, seg);
+        hipLaunchKernelGGL(k_cand_layout, dim3(1), dim3(1024), 0, st, items, n_items, item_off, nq, n_cand, cand_start, seg,
+                           sp.select ? qmin : (unsigned long long*)nullptr, qmax);
         const uint64_t *rk = nullptr, *rv = nullptr;  // ranked pairs
         if (!sp.select) {
             uint64_t *keys_out = b1, *vals_in = b2, *vals_out = b3;
@@ -3496,8 +3525,6 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             rk = keys_out; rv = vals_out;
         } else {
             uint64_t *sel_keys = b1, *sel_vals = b2;
-            CIS_CHECK_HIP(hipMemsetAsync(qmin, 0xff, (size_t)(nq + 2) * 8, st));
-            CIS_CHECK_HIP(hipMemsetAsync(qmax, 0, (size_t)(nq + 2) * 8, st));
             if (n_items > 0)
                 launch_adc_all(n_items, st, items, cand_start, T, codes, M, K, keys_in, nullptr, qmin, qmax);
             if (sp.sort_lds) {
