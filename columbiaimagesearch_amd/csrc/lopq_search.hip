@@ -15,6 +15,7 @@
 //   PCA -> coarse distances (numpy order) -> per-split rank -> multisequence plan (count) ->
 //   exclusive scan -> plan (emit work items + table list) -> ADC tables -> ADC scan + block
 //   top-k -> per-query merge -> ids/dists.
+#include <chrono>
 #include <algorithm>
 #include <unordered_set>
 
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(64) void k_multiseq_list(const CT* __restrict__ sor
 __global__ __launch_bounds__(1024) void k_plan_scan(const PlanOut* __restrict__ plan, int nq, int64_t* __restrict__ item_off,
                                                     int64_t* __restrict__ tab_off, int64_t* __restrict__ totals,
                                                     unsigned long long* __restrict__ qbound /* [nq] -> +inf */,
-                                                    volatile int64_t* __restrict__ host_totals /* pinned, mapped */,
+                                                    volatile int64_t* __restrict__ host_totals /* pinned, mapped */, int64_t seq,
                                                     const int* __restrict__ grp_cnt, int* __restrict__ grp_base, int n_groups) {
     constexpr int R = 8;  // rounds held in registers; more queries than 8192 take the slow tail loop below
     __shared__ int s_wi[R][16], s_wt[R][16];  // wave totals per round
@@ -331,6 +332,8 @@ __global__ __launch_bounds__(1024) void k_plan_scan(const PlanOut* __restrict__ 
             }
             totals[0] = ri; totals[1] = rt; totals[2] = rc;
             host_totals[0] = ri; host_totals[1] = rt; host_totals[2] = rc;  // straight into pinned host memory: no staged copy
+            __threadfence_system();
+            host_totals[3] = seq;  // the host polls this word (the totals above are visible before it)
             __threadfence_system();
             item_off[nq] = ri; tab_off[nq] = rt;
         }
@@ -2363,6 +2366,7 @@ struct cis_index {
     int profiling = 0;  // 0 off, 1 events around the scan kernel only, 2 events around every stage
     int64_t* h_totals = nullptr;    // pinned, device-mapped: the plan totals land here without a copy
     int64_t* d_h_totals = nullptr;
+    int64_t plan_seq = 0;           // sequence number of the last plan whose totals were requested
     struct ProfRec { hipEvent_t ev[6]; bool has_scan; };  // ev[5]: just before the scan kernel (after slot building)
     std::vector<ProfRec> prof;
     double prof_ms[5] = {0, 0, 0, 0, 0};
@@ -3403,12 +3407,29 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                            seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr);
     }
     if (!ix->h_totals) {
-        CIS_CHECK_HIP(hipHostMalloc((void**)&ix->h_totals, 4 * sizeof(int64_t), hipHostMallocMapped));
+        CIS_CHECK_HIP(hipHostMalloc((void**)&ix->h_totals, 4 * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
         CIS_CHECK_HIP(hipHostGetDevicePointer((void**)&ix->d_h_totals, ix->h_totals, 0));
+        ix->h_totals[3] = 0;
     }
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, plan, nq, item_off, tab_off, totals, qbound, ix->d_h_totals, grp_cnt, grp_base, 2 * V * GRP_SUB);
+    const int64_t seq = ++ix->plan_seq;
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, plan, nq, item_off, tab_off, totals, qbound, ix->d_h_totals, seq, grp_cnt, grp_base, 2 * V * GRP_SUB);
     volatile int64_t* h_tot = ix->h_totals;
-    CIS_CHECK_HIP(hipStreamSynchronize(st));
+    {
+        // the plan totals size the rest of the batch: poll the pinned sequence word (a blocking stream synchronisation
+        // wakes up tens of microseconds late); past 2 ms -- a stream busy with the caller's earlier work, or an error --
+        // fall back to the blocking wait
+        static const bool no_poll = getenv("CIS_NO_POLL") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool got = false;
+        while (!no_poll) {
+            if (__atomic_load_n(&ix->h_totals[3], __ATOMIC_ACQUIRE) == seq) { got = true; break; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+        if (!got) {
+            CIS_CHECK_HIP(hipStreamSynchronize(st));
+            CIS_REQUIRE(__atomic_load_n(&ix->h_totals[3], __ATOMIC_ACQUIRE) == seq, "plan totals did not arrive");
+        }
+    }
     const int64_t n_items = h_tot[0], n_tabs = h_tot[1];
     CIS_REQUIRE(n_items < ((int64_t)1 << 31) && n_tabs < ((int64_t)1 << 31), "query batch too large");
     {
