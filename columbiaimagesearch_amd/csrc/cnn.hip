@@ -424,7 +424,7 @@ struct cis_cnn {
     int arch = 0, device = 0;
     LayerW conv[5], fc[2];        // DeepSentibank
     std::vector<LayerW> dl;       // dlib ResNet: conv0, then (a, b) per block, then fc (bias-free); affine layers folded in
-    DevBuf act0, act1, act2, act3, in_buf, out_buf;
+    DevBuf act0, act1, act2, act3, part, in_buf, out_buf;
 };
 
 // dlib anet_type block plan: (in channels, out channels, down-sampling block)
@@ -446,7 +446,7 @@ extern "C" void cis_cnn_destroy(cis_cnn* c) {
     for (auto& l : c->conv) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
     for (auto& l : c->fc) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
     for (auto& l : c->dl) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
-    c->act0.release(); c->act1.release(); c->act2.release(); c->act3.release(); c->in_buf.release(); c->out_buf.release();
+    c->act0.release(); c->act1.release(); c->act2.release(); c->act3.release(); c->part.release(); c->in_buf.release(); c->out_buf.release();
     delete c;
 }
 
@@ -577,13 +577,17 @@ extern "C" int cis_cnn_create(cis_cnn** out, int arch, const float* const* tenso
 
 // out = relu?(bias + part[0] + part[1] + ...) in that order (deterministic), four outputs per thread
 __global__ void k_splitk_reduce(const float* __restrict__ part, int splitk, int64_t part_stride, const float* __restrict__ bias,
-                                float* __restrict__ out, int64_t n4, int OC, int relu) {
+                                float* __restrict__ out, int64_t n4, int OC, int relu, const float* __restrict__ res, int resC) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const int oc = (int)((i * 4) % OC);
     float4 a = bias ? *reinterpret_cast<const float4*>(bias + oc) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < splitk; ++s) {
         const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)s * part_stride + i * 4);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (res && oc < resC) {  // residual branch (resC % 4 == 0 channels, zero-padded above)
+        const float4 v = *reinterpret_cast<const float4*>(res + ((i * 4) / OC) * resC + oc);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
     if (relu) { a.x = a.x > 0.f ? a.x : 0.f; a.y = a.y > 0.f ? a.y : 0.f; a.z = a.z > 0.f ? a.z : 0.f; a.w = a.w > 0.f ? a.w : 0.f; }
@@ -627,6 +631,34 @@ static ConvDesc nhwc_conv(int n, int H, int W, int C, int OC, int k, int stride,
     return d;
 }
 
+// A convolution whose output has too few tiles to fill the chip (the deep, spatially small layers of the dlib net: 16-256
+// workgroups walking K = 1152 ... 2304 serially) splits K over blockIdx.z and adds the partial sums in a fixed order,
+// together with bias, residual branch and ReLU (k_splitk_reduce).
+static int conv_fill_chip(cis_cnn* c, ConvDesc d, const float* in, const float* w, const float* b, float* out, hipStream_t st) {
+    const int64_t npix = (int64_t)d.N * d.OH * d.OW;
+    const bool vec = d.sC == 1 && d.ICg % 16 == 0 && d.C % 4 == 0 && d.groups == 1 && d.OC % 4 == 0 && d.runq == 0;
+    const int64_t tiles = npix <= 2048 ? ceil_div(npix, 32) * ceil_div((int64_t)d.OCg, 128) : ceil_div(npix, 64) * ceil_div((int64_t)d.OCg, 64);
+    const int nkt = d.K / 16;
+    int splitk = 1;
+    static const bool off = getenv("CIS_CNN_NO_SPLITK") != nullptr;
+    while (!off && vec && d.OCg > 32 && tiles * splitk < 512 && splitk < 32 && nkt / (splitk * 2) >= 6) splitk *= 2;
+    if (splitk == 1) {
+        launch_conv(d, in, w, b, out, st);
+        return CIS_OK;
+    }
+    CIS_TRY(c->part.reserve((size_t)splitk * npix * d.OC * sizeof(float)));
+    float* part = c->part.as<float>();
+    ConvDesc dp = d;
+    dp.splitk = splitk;
+    dp.part_stride = npix * d.OC;
+    dp.res = nullptr; dp.resC = 0;
+    launch_conv(dp, in, w, nullptr, part, st);
+    const int64_t n4 = npix * d.OC / 4;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, part, splitk, dp.part_stride, b, out, n4, d.OC,
+                       d.relu, d.res, d.resC);
+    return CIS_OK;
+}
+
 // dlib face ResNet: d_in = [n][150][150][3] float32 RGB 0..255 (aligned chips), d_feats = [n][128]
 static int cnn_forward_dlib(cis_cnn* c, const float* d_in, int n, float* d_feats, hipStream_t st) {
     const size_t big = (size_t)n * 72 * 72 * 32;  // largest activation: first convolution's output
@@ -651,7 +683,7 @@ static int cnn_forward_dlib(cis_cnn* c, const float* d_in, int n, float* d_feats
         const DlibBlock& b = kDlibBlocks[i];
         const int s = b.down ? 2 : 1, p = b.down ? 0 : 1;
         ConvDesc da = nhwc_conv(n, H, W, C, b.cout, 3, s, p, 1);
-        launch_conv(da, x, c->dl[1 + 2 * i].d_w, c->dl[1 + 2 * i].d_b, T1, st);
+        CIS_TRY(conv_fill_chip(c, da, x, c->dl[1 + 2 * i].d_w, c->dl[1 + 2 * i].d_b, T1, st));
         ConvDesc db = nhwc_conv(n, da.OH, da.OW, b.cout, b.cout, 3, 1, 1, 0);
         int SH = H, SW = W, SC = C;
         if (b.down) { SH = (H - 2) / 2 + 1; SW = (W - 2) / 2 + 1; }
@@ -669,9 +701,9 @@ static int cnn_forward_dlib(cis_cnn* c, const float* d_in, int n, float* d_feats
         }
         if (fuse) {
             db.res = skip; db.resC = SC; db.relu = 1;
-            launch_conv(db, T1, c->dl[2 + 2 * i].d_w, c->dl[2 + 2 * i].d_b, other, st);
+            CIS_TRY(conv_fill_chip(c, db, T1, c->dl[2 + 2 * i].d_w, c->dl[2 + 2 * i].d_b, other, st));
         } else {
-            launch_conv(db, T1, c->dl[2 + 2 * i].d_w, c->dl[2 + 2 * i].d_b, T2, st);
+            CIS_TRY(conv_fill_chip(c, db, T1, c->dl[2 + 2 * i].d_w, c->dl[2 + 2 * i].d_b, T2, st));
             if (b.down) {
                 hipLaunchKernelGGL(k_avgpool2_nhwc, grid((int64_t)n * SH * SW * C), dim3(256), 0, st, x, T1, n, H, W, C, SH, SW);
                 skip = T1;  // T1 is free again: conv b has consumed it (same stream)
@@ -782,7 +814,7 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
             launch_conv(d, cur, c->fc[l].d_w, nullptr, part, st);
             const int64_t n4 = (int64_t)n * 4096 / 4;
             hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, part, splitk, d.part_stride,
-                               c->fc[l].d_b, o, n4, 4096, 1);
+                               c->fc[l].d_b, o, n4, 4096, 1, (const float*)nullptr, 0);
         } else {
             launch_conv(d, cur, c->fc[l].d_w, c->fc[l].d_b, o, st);
         }
