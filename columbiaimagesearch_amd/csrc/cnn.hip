@@ -401,6 +401,15 @@ __global__ void k_normalize_rgb(const float* __restrict__ in, float* __restrict_
     out[i] = (in[i] - (c == 0 ? m0 : (c == 1 ? m1 : m2))) * (1.0f / 256.0f);
 }
 
+// the same into 4-float pixels (R, G, B, 0): every pixel is one aligned float4, so the first convolution's kernel rows are
+// runs of KW float4 (row-run gather of k_conv_igemm)
+__global__ void k_normalize_rgb4(const float* __restrict__ in, float* __restrict__ out, int64_t npix, float m0, float m1, float m2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const float r = in[i * 3], g = in[i * 3 + 1], b = in[i * 3 + 2];
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4((r - m0) * (1.0f / 256.0f), (g - m1) * (1.0f / 256.0f), (b - m2) * (1.0f / 256.0f), 0.f);
+}
+
 // avg_pool<2,2,2,2>, no padding, output floor((H-2)/2)+1
 __global__ void k_avgpool2_nhwc(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C, int OH, int OW) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -484,16 +493,18 @@ static int upload_f(float** dst, const float* src, size_t n) {
 }
 
 // conv OIHW + bias with the following per-channel affine (gamma, beta) folded in, packed [K][OC], k = (ky*KW+kx)*IC+ic
-static int pack_conv_affine(LayerW* L, const float* w, const float* b, const float* gam, const float* bet, int OC, int IC, int k) {
-    const int K = k * k * IC;
-    std::vector<float> packed((size_t)K * OC), bias(OC);
+static int pack_conv_affine(LayerW* L, const float* w, const float* b, const float* gam, const float* bet, int OC, int IC, int k,
+                            int ICp = 0 /* > IC: input pixels padded to ICp channels (zero weights) */) {
+    if (ICp < IC) ICp = IC;
+    const int K = k * k * ICp;
+    std::vector<float> packed((size_t)K * OC, 0.f), bias(OC);
     for (int o = 0; o < OC; ++o) {
         const float g = gam ? gam[o] : 1.f;
         bias[o] = g * (b ? b[o] : 0.f) + (bet ? bet[o] : 0.f);
         for (int ic = 0; ic < IC; ++ic)
             for (int ky = 0; ky < k; ++ky)
                 for (int kx = 0; kx < k; ++kx)
-                    packed[((size_t)(ky * k + kx) * IC + ic) * OC + o] = g * w[(((size_t)o * IC + ic) * k + ky) * k + kx];
+                    packed[((size_t)(ky * k + kx) * ICp + ic) * OC + o] = g * w[(((size_t)o * IC + ic) * k + ky) * k + kx];
     }
     CIS_TRY(upload_f(&L->d_w, packed.data(), packed.size()));
     CIS_TRY(upload_f(&L->d_b, bias.data(), bias.size()));
@@ -508,7 +519,7 @@ static int cnn_create_dlib(cis_cnn** out, const float* const* tensors, int n_ten
     c->arch = 2;
     c->device = cis_current_device();
     c->dl.resize(1 + 28 + 1);
-    int rc = pack_conv_affine(&c->dl[0], tensors[0], tensors[1], tensors[2], tensors[3], 32, 3, 7);
+    int rc = pack_conv_affine(&c->dl[0], tensors[0], tensors[1], tensors[2], tensors[3], 32, 3, 7, 4);  // (R, G, B, 0) pixels
     for (int i = 0; i < 14 && rc == CIS_OK; ++i) {
         const float* const* t = tensors + 4 + 8 * i;
         rc = pack_conv_affine(&c->dl[1 + 2 * i], t[0], t[1], t[2], t[3], kDlibBlocks[i].cout, kDlibBlocks[i].cin, 3);
@@ -698,9 +709,13 @@ static int cnn_forward_dlib(cis_cnn* c, const float* d_in, int n, float* d_feats
     float* T1 = c->act2.as<float>();
     float* T2 = c->act3.as<float>();
     auto grid = [](int64_t total) { return dim3((unsigned)ceil_div(total, 256)); };
-    hipLaunchKernelGGL(k_normalize_rgb, grid((int64_t)n * 150 * 150 * 3), dim3(256), 0, st, d_in, A, (int64_t)n * 150 * 150, 122.782f,
+    hipLaunchKernelGGL(k_normalize_rgb4, grid((int64_t)n * 150 * 150), dim3(256), 0, st, d_in, A, (int64_t)n * 150 * 150, 122.782f,
                        117.001f, 104.298f);
     ConvDesc d0 = nhwc_conv(n, 150, 150, 3, 32, 7, 2, 0, 1);
+    // (R, G, B, 0) pixels: a kernel row is a run of 7 aligned float4, k = ky * 28 + kx * 4 + c (weights packed to match)
+    d0.sN = (int64_t)150 * 150 * 4; d0.sH = 150 * 4; d0.sW = 4;
+    d0.runq = 7;
+    d0.K = 7 * 28;
     launch_conv(d0, A, c->dl[0].d_w, c->dl[0].d_b, B, st);  // 72 x 72 x 32, affine folded, relu
     int H = (72 - 3) / 2 + 1, W = H, C = 32;                  // max_pool<3,3,2,2>: 35
     hipLaunchKernelGGL(k_maxpool_nhwc_v4, grid((int64_t)n * H * W * C / 4), dim3(256), 0, st, B, A, n, 72, 72, C, H, W);
