@@ -3039,7 +3039,7 @@ __global__ void k_emit_sorted(const uint64_t* __restrict__ keys, const uint64_t*
 //   D. an ORDER-PRESERVING gather of everything <= cut (block prefix sums): exactly min(n, limit) pairs in retrieval
 //      order.  limit <= 3072: sorted in LDS by (key, index) and written ranked; above: written in retrieval order for
 //      the stable segmented sort, which now sees limit instead of n entries per query.
-static const int SEL_THREADS = 512;
+static const int SEL_THREADS = 1024;  // largest workgroup of the selection kernel (small batches); large batches use 512
 static const int SEL_BITS = 11;
 static const int SEL_CAND = 1024;
 static const int SEL_PER = 4;  // consecutive keys per thread and chunk in the ordered passes
@@ -3109,8 +3109,8 @@ struct SelShared {
     int wsum[SEL_THREADS / 64];
 };
 
-template <bool SORT_LDS>
-__global__ __launch_bounds__(SEL_THREADS) void k_select_topl(const uint64_t* __restrict__ keys, const int64_t* __restrict__ seg,
+template <bool SORT_LDS, int NT>
+__global__ __launch_bounds__(NT) void k_select_topl(const uint64_t* __restrict__ keys, const int64_t* __restrict__ seg,
                                                               const int64_t* __restrict__ cand_start, const int64_t* __restrict__ item_off,
                                                               const unsigned long long* __restrict__ qmin,
                                                               const unsigned long long* __restrict__ qmax, int64_t n_items, int L, int P2,
@@ -3155,7 +3155,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_topl(const uint64_t* __r
                 if (hi_shift >= 64 || (v >> hi_shift) == prefix) atomicAdd(&hist[(unsigned int)(v >> shift) & mask], 1u);
             }
             __syncthreads();
-            const int per = (1 << SEL_BITS) / SEL_THREADS;
+            constexpr int per = (1 << SEL_BITS) / NT;
             unsigned int cb[per];
             int local = 0;
 #pragma unroll
@@ -3549,13 +3549,22 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             if (n_items > 0)
                 launch_adc_all(n_items, st, items, cand_start, T, codes, M, K, keys_in, nullptr, qmin, qmax);
             if (sp.sort_lds) {
-                hipLaunchKernelGGL(k_select_topl<true>, dim3((unsigned)nq), dim3(SEL_THREADS), sp.lds, st, keys_in, seg, cand_start, item_off,
-                                   qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, (int64_t*)nullptr, (int64_t*)nullptr);
+                // fewer queries than CUs: one large workgroup per query walks its keys faster; else two 512-thread ones per CU
+                if (nq <= 256)
+                    hipLaunchKernelGGL((k_select_topl<true, 1024>), dim3((unsigned)nq), dim3(1024), sp.lds, st, keys_in, seg, cand_start, item_off,
+                                       qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, (int64_t*)nullptr, (int64_t*)nullptr);
+                else
+                    hipLaunchKernelGGL((k_select_topl<true, 512>), dim3((unsigned)nq), dim3(512), sp.lds, st, keys_in, seg, cand_start, item_off,
+                                       qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, (int64_t*)nullptr, (int64_t*)nullptr);
                 rk = sel_keys; rv = sel_vals;
             } else {
                 uint64_t *srt_keys = b3, *srt_vals = b3 + bl;
-                hipLaunchKernelGGL(k_select_topl<false>, dim3((unsigned)nq), dim3(SEL_THREADS), sp.lds, st, keys_in, seg, cand_start, item_off,
-                                   qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, seg_b, seg_e);
+                if (nq <= 256)
+                    hipLaunchKernelGGL((k_select_topl<false, 1024>), dim3((unsigned)nq), dim3(1024), sp.lds, st, keys_in, seg, cand_start, item_off,
+                                       qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, seg_b, seg_e);
+                else
+                    hipLaunchKernelGGL((k_select_topl<false, 512>), dim3((unsigned)nq), dim3(512), sp.lds, st, keys_in, seg, cand_start, item_off,
+                                       qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, seg_b, seg_e);
                 size_t b = tmp_bytes;
                 CIS_TRY(cis_seg_sort_u64(tmp, &b, sel_keys, srt_keys, sel_vals, srt_vals, n_sel, nq, seg_b, seg_e, st));
                 rk = srt_keys; rv = srt_vals;
