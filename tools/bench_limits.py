@@ -19,13 +19,16 @@ s.add_codes_array(torch.cat(co).cpu().numpy().view(np.uint16), torch.cat(fi).cpu
 x0 = B.gen_chunk(P, 0, N // NCH, dev)
 nq = int(os.environ.get("NQ", 8192))
 q = B.make_queries(x0, 0, nq, dev)
+host = os.environ.get("HOST") == "1"  # host-pointer entry point (cis_index_search): PCIe copies in and out included
+qh = q.cpu().numpy()
+run = (lambda limit: s.search_batch(qh, quota=10000, limit=limit)) if host else (lambda limit: s.search_batch_dev(q, quota=10000, limit=limit))
 for limit in [int(v) for v in os.environ.get("LIMITS", "10,100,440,441,1000,3072,3073,10000").split(",")]:
     for _ in range(2):
-        s.search_batch_dev(q, quota=10000, limit=limit)
+        run(limit)
     torch.cuda.synchronize(); t = time.perf_counter()
     reps = 5
     for _ in range(reps):
-        s.search_batch_dev(q, quota=10000, limit=limit)
+        run(limit)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t) / reps * 1e3
     print("limit %6d  %8.3f ms/batch  %10.0f queries/s" % (limit, ms, nq / ms * 1e3), flush=True)
