@@ -15,7 +15,7 @@ PCA_FIXTURES = ["c2", "c3", "c3b", "c4"]
 ALL = ["tiny", "c1"] + PCA_FIXTURES
 
 _ROUTE_FREE = ("encode", "near_tie", "model_pieces", "selftest", "multisequence", "rerank", "kmeans", "select_path",
-               "large_limit")
+               "large_limit", "fuzz")
 
 
 @pytest.fixture(autouse=True, params=["auto", "prefilter"])
@@ -576,6 +576,10 @@ def test_randomised_parity_fuzz():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(60, 11) == 0
+    # shapes outside the specialised kernels (M not in {4, 8, 16}, K not a multiple of 4 / not a power of two): the float64
+    # scan kernel and the global-table distance kernel of the all-candidates path
+    mod.MS, mod.KS = [2, 6, 12, 32], [10, 100, 256]
+    assert mod.run(30, 12) == 0
 
 
 @pytest.mark.gpu

@@ -6,12 +6,16 @@ import numpy as np
 from oracle import lopq_oracle as O
 from columbiaimagesearch_amd.lopq import LOPQModel, LOPQModelPCA, LOPQSearcherHIP
 
+# FUZZ_M / FUZZ_K: other shapes, e.g. FUZZ_M=2,6,12,32 FUZZ_K=10,100,256 (the generic kernels: float64 scan, global-table distances)
+MS = [int(v) for v in os.environ.get("FUZZ_M", "4,8,16").split(",")]
+KS = [int(v) for v in os.environ.get("FUZZ_K", "16,64,256").split(",")]
+
 def run(cases, seed0):
   bad = 0
   for case in range(cases):
       rs = np.random.RandomState(seed0 * 1000 + case)
-      M = int(rs.choice([4, 8, 16]))
-      K = int(rs.choice([16, 64, 256]))
+      M = int(rs.choice(MS))
+      K = int(rs.choice(KS))
       V = int(rs.choice([2, 4, 16, 40]))
       w = int(rs.choice([2, 4, 8]))
       D = M * w
