@@ -523,8 +523,13 @@ template <typename CT, int TB>
 __global__ __launch_bounds__(256) void k_tables_group(const CT* __restrict__ X, const CT* __restrict__ Cs,
                                                       const double* __restrict__ Rt, const double* __restrict__ mus,
                                                       const TabDesc* __restrict__ tabs, const int* __restrict__ tab_order,
-                                                      int n_tabs, int V, int h, int D, double* __restrict__ px_out) {
+                                                      int n_tabs, int V, int h, int D, double* __restrict__ px_out,
+                                                      const int64_t* __restrict__ d_totals /* null, or the plan totals: n_tabs is a bound */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (d_totals) {
+        n_tabs = (int)d_totals[1];
+        if ((int)blockIdx.x * TB >= n_tabs) return;
+    }
     double* v = reinterpret_cast<double*>(smem);  // [TB][h]
     double* psum = v + TB * h;                     // [parts][TB][h]
     __shared__ int s_tab[TB];
@@ -608,13 +613,13 @@ __global__ __launch_bounds__(256) void k_tables_group(const CT* __restrict__ X, 
 template <typename CT>
 static void launch_tables(int64_t n_tabs, size_t tab_lds, hipStream_t st, const CT* X, const CT* Cs, const double* Rt,
                           const double* mus, const double* subs, const TabDesc* tabs, const int* tab_order, int V, int h, int w,
-                          int nf, int K, int D, double* T, PwProg prog_w, double* px_out) {
+                          int nf, int K, int D, double* T, PwProg prog_w, double* px_out, const int64_t* d_totals = nullptr) {
     constexpr int TB = 8;
     if (px_out && h <= 256 && 256 / h >= 1 && !getenv("CIS_TABLES_UNGROUPED")) {
         const int parts = 256 / h;
         const size_t lds = (size_t)(TB * h + parts * TB * h) * sizeof(double);
         hipLaunchKernelGGL((k_tables_group<CT, TB>), dim3((unsigned)ceil_div(n_tabs, TB)), dim3(256), lds, st, X, Cs, Rt, mus, tabs,
-                           tab_order, (int)n_tabs, V, h, D, px_out);
+                           tab_order, (int)n_tabs, V, h, D, px_out, d_totals);
     } else {
         hipLaunchKernelGGL(k_tables<CT>, dim3((unsigned)n_tabs), dim3(256), tab_lds, st, X, Cs, Rt, mus, subs, tabs, V, h, w, nf, K, D, T,
                            prog_w, px_out, (const int*)nullptr, 0);
@@ -626,11 +631,16 @@ __global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict
                                                         const TabDesc* __restrict__ tabs, int n_tabs,
                                                         const double* __restrict__ subs, int h, int nf, int K,
                                                         double* __restrict__ T /* [ntab][nf][K] */,
-                                                        float* __restrict__ T32 /* [ntab][nf][K] float32 copy for the scan */) {
+                                                        float* __restrict__ T32 /* [ntab][nf][K] float32 copy for the scan */,
+                                                        const int64_t* __restrict__ d_totals /* null, or the plan totals: n_tabs is a bound */) {
     __shared__ double sf[64][W];
     __shared__ int ssplit[64];
     const int j = blockIdx.y, z = blockIdx.z, k = threadIdx.x;
     const int t0 = blockIdx.x * 64;
+    if (d_totals) {
+        n_tabs = (int)d_totals[1];
+        if (t0 >= n_tabs) return;
+    }
     const int nt = (n_tabs - t0 < 64) ? (n_tabs - t0) : 64;
     for (int e = threadIdx.x; e < nt * W; e += 256) {
         const int t = e / W, i = e - t * W;
@@ -2367,6 +2377,8 @@ struct cis_index {
     int64_t* h_totals = nullptr;    // pinned, device-mapped: the plan totals land here without a copy
     int64_t* d_h_totals = nullptr;
     int64_t plan_seq = 0;           // sequence number of the last plan whose totals were requested
+    int64_t stats_pending_seq = 0;  // != 0: the last batch did not read its totals back; last_stats waits for this plan
+    int64_t n_total = 0, max_cell = 0, nonempty_cells = 0;  // over all shards (gcount): bounds for such batches
     struct ProfRec { hipEvent_t ev[6]; bool has_scan; };  // ev[5]: just before the scan kernel (after slot building)
     std::vector<ProfRec> prof;
     double prof_ms[5] = {0, 0, 0, 0, 0};
@@ -2519,6 +2531,13 @@ static int index_sync(cis_index* ix) {
     }
     CIS_CHECK_HIP(hipMemcpy(ix->d_loff.p, ix->csr_off.data(), (size_t)(nc + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     CIS_CHECK_HIP(hipMemcpy(ix->d_gcount.p, ix->gcount.data(), (size_t)nc * sizeof(int64_t), hipMemcpyHostToDevice));
+    ix->n_total = 0; ix->max_cell = 0; ix->nonempty_cells = 0;
+    for (int64_t c = 0; c < nc; ++c) {
+        const int64_t g = ix->gcount[c];
+        ix->n_total += g;
+        ix->max_cell = g > ix->max_cell ? g : ix->max_cell;
+        ix->nonempty_cells += g > 0;
+    }
     ix->dirty = false;
     return CIS_OK;
 }
@@ -2723,6 +2742,13 @@ extern "C" int cis_index_read_profile(cis_index* ix, double ms[5], int64_t* laun
 
 extern "C" int cis_index_last_stats(cis_index* ix, int64_t stats[4]) {
     CIS_REQUIRE(ix != nullptr && stats != nullptr, "NULL argument");
+    if (ix->stats_pending_seq) {  // the last batch ran on bounds: its totals are in the pinned words once its plan has run
+        if (__atomic_load_n(&ix->h_totals[3], __ATOMIC_ACQUIRE) != ix->stats_pending_seq) CIS_CHECK_HIP(hipDeviceSynchronize());
+        ix->stats[0] += ix->h_totals[2];
+        ix->stats[1] += ix->h_totals[0];
+        ix->stats[2] += ix->h_totals[1];
+        ix->stats_pending_seq = 0;
+    }
     for (int i = 0; i < 4; ++i) stats[i] = ix->stats[i];
     return CIS_OK;
 }
@@ -2861,8 +2887,10 @@ __global__ void k_seg_begin(const int64_t* __restrict__ cand_start, const int64_
 // the per-query segment starts (seg[q] = first candidate of query q, seg[nq] = n_cand) and the reset of the key ranges
 __global__ __launch_bounds__(1024) void k_cand_layout(const WorkItem* __restrict__ items, int64_t n_items, const int64_t* __restrict__ item_off,
                                                       int nq, int64_t n_cand, int64_t* cand_start, int64_t* __restrict__ seg,
-                                                      unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax) {
+                                                      unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax,
+                                                      const int64_t* __restrict__ d_totals /* null, or the plan totals (arguments are bounds) */) {
     __shared__ int64_t s_w[16];
+    if (d_totals) { n_items = d_totals[0]; n_cand = d_totals[2]; }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t chunk = (n_items + 1023) / 1024;
     const int64_t lo = tid * chunk, hi = lo + chunk < n_items ? lo + chunk : n_items;
@@ -2911,7 +2939,9 @@ __device__ __forceinline__ void publish_key_range(uint64_t mn, uint64_t mx, unsi
 __global__ __launch_bounds__(256) void k_adc_all(const WorkItem* __restrict__ items, const int64_t* __restrict__ cand_start,
                                                  const double* __restrict__ T, const uint8_t* __restrict__ codes, int M, int K,
                                                  uint64_t* __restrict__ keys, uint64_t* __restrict__ vals,
-                                                 unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax) {
+                                                 unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax,
+                                                 const int64_t* __restrict__ d_totals /* null, or the plan totals: gridDim.x is a bound */) {
+    if (d_totals && (int64_t)blockIdx.x >= d_totals[0]) return;
     const WorkItem it = items[blockIdx.x];
     const int nf = M / 2;
     const double* t0 = T + (int64_t)it.tab0 * nf * K;
@@ -2934,8 +2964,10 @@ template <int MT>
 __global__ __launch_bounds__(256) void k_adc_all_lds(const WorkItem* __restrict__ items, const int64_t* __restrict__ cand_start,
                                                      const double* __restrict__ T, const uint8_t* __restrict__ codes, int K,
                                                      uint64_t* __restrict__ keys, uint64_t* __restrict__ vals,
-                                                     unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax) {
+                                                     unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax,
+                                                     const int64_t* __restrict__ d_totals /* null, or the plan totals: gridDim.x is a bound */) {
     extern __shared__ __align__(16) double adc_tab[];  // [MT][K]
+    if (d_totals && (int64_t)blockIdx.x >= d_totals[0]) return;
     const WorkItem it = items[blockIdx.x];
     int nch = (it.len + 2047) / 2048;  // workgroups that share this item (<= gridDim.y): ~2048 candidates each at least
     nch = nch < 1 ? 1 : (nch > (int)gridDim.y ? (int)gridDim.y : nch);
@@ -2982,13 +3014,13 @@ __global__ __launch_bounds__(256) void k_adc_all_lds(const WorkItem* __restrict_
 
 static void launch_adc_all(int64_t n_items, hipStream_t st, const WorkItem* items, const int64_t* cand_start, const double* T,
                            const uint8_t* codes, int M, int K, uint64_t* keys, uint64_t* vals, unsigned long long* qmin,
-                           unsigned long long* qmax) {
+                           unsigned long long* qmax, const int64_t* d_totals = nullptr) {
     const dim3 g((unsigned)n_items, 8);
     const size_t lds = (size_t)M * K * sizeof(double);
-    if (K <= 256 && M == 4) hipLaunchKernelGGL(k_adc_all_lds<4>, g, dim3(256), lds, st, items, cand_start, T, codes, K, keys, vals, qmin, qmax);
-    else if (K <= 256 && M == 8) hipLaunchKernelGGL(k_adc_all_lds<8>, g, dim3(256), lds, st, items, cand_start, T, codes, K, keys, vals, qmin, qmax);
-    else if (K <= 256 && M == 16) hipLaunchKernelGGL(k_adc_all_lds<16>, g, dim3(256), lds, st, items, cand_start, T, codes, K, keys, vals, qmin, qmax);
-    else hipLaunchKernelGGL(k_adc_all, g, dim3(256), 0, st, items, cand_start, T, codes, M, K, keys, vals, qmin, qmax);
+    if (K <= 256 && M == 4) hipLaunchKernelGGL(k_adc_all_lds<4>, g, dim3(256), lds, st, items, cand_start, T, codes, K, keys, vals, qmin, qmax, d_totals);
+    else if (K <= 256 && M == 8) hipLaunchKernelGGL(k_adc_all_lds<8>, g, dim3(256), lds, st, items, cand_start, T, codes, K, keys, vals, qmin, qmax, d_totals);
+    else if (K <= 256 && M == 16) hipLaunchKernelGGL(k_adc_all_lds<16>, g, dim3(256), lds, st, items, cand_start, T, codes, K, keys, vals, qmin, qmax, d_totals);
+    else hipLaunchKernelGGL(k_adc_all, g, dim3(256), 0, st, items, cand_start, T, codes, M, K, keys, vals, qmin, qmax, d_totals);
 }
 
 __global__ void k_emit_sorted(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ vals, const int64_t* __restrict__ seg,
@@ -3414,7 +3446,26 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     const int64_t seq = ++ix->plan_seq;
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, plan, nq, item_off, tab_off, totals, qbound, ix->d_h_totals, seq, grp_cnt, grp_base, 2 * V * GRP_SUB);
     volatile int64_t* h_tot = ix->h_totals;
+    // A small batch on the all-candidates path does not wait for the plan totals: the workspace is sized by upper bounds
+    // (every query stops within quota + largest cell candidates, in at most `nonempty cells` cells) and the kernels
+    // below read the real totals from device memory -- no host round trip in the middle of the batch.
+    const int64_t* d_tot = nullptr;
+    int64_t n_items = 0, n_tabs = 0, n_cand_all = 0;
     {
+        static const bool no_bounds = getenv("CIS_NO_BOUNDS") != nullptr;
+        const int64_t per_q = (quota < ix->n_total ? quota : ix->n_total) + ix->max_cell;
+        const int64_t items_q = ix->nonempty_cells + per_q / seg_max + 2;
+        const bool split_ok = (m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) && K <= 256;
+        if (!no_bounds && nq <= 64 && L <= MAX_LDS_LIMIT && split_ok && use_all_path(ix, M, K, L, nq) && items_q <= 4096 &&
+            (double)nq * (double)per_q < 64.0e6) {
+            d_tot = totals;
+            n_items = (int64_t)nq * items_q;
+            n_tabs = (int64_t)nq * 2 * V;
+            n_cand_all = (int64_t)nq * per_q;
+            ix->stats_pending_seq = seq;
+        }
+    }
+    if (!d_tot) {
         // the plan totals size the rest of the batch: poll the pinned sequence word (a blocking stream synchronisation
         // wakes up tens of microseconds late); past 2 ms -- a stream busy with the caller's earlier work, or an error --
         // fall back to the blocking wait
@@ -3429,8 +3480,12 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             CIS_CHECK_HIP(hipStreamSynchronize(st));
             CIS_REQUIRE(__atomic_load_n(&ix->h_totals[3], __ATOMIC_ACQUIRE) == seq, "plan totals did not arrive");
         }
+        n_items = h_tot[0]; n_tabs = h_tot[1]; n_cand_all = h_tot[2];
+        ix->stats_pending_seq = 0;
+        ix->stats[0] += n_cand_all;
+        ix->stats[1] += n_items;
+        ix->stats[2] += n_tabs;
     }
-    const int64_t n_items = h_tot[0], n_tabs = h_tot[1];
     CIS_REQUIRE(n_items < ((int64_t)1 << 31) && n_tabs < ((int64_t)1 << 31), "query batch too large");
     {
         // workspace budget: per-item hit lists and the float64 tables.  A batch that would need more (e.g. an
@@ -3439,15 +3494,12 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         const int64_t S_ = fast_ ? scan2_geom(M, K, L, nq).S : L;
         double need = (double)n_items * S_ * (fast_ ? sizeof(uint64_t) : sizeof(cis_hit)) + (double)n_tabs * nf * K * sizeof(double);
         if (use_all_path(ix, M, K, L, nq)) {  // every candidate's key, plus the selected pairs or the full sort's buffers
-            const SelectPlan sp_ = select_plan(L, nq, (int64_t)h_tot[2]);
-            need = (sp_.select ? 8.0 * (double)h_tot[2] + (sp_.sort_lds ? 16.0 : 32.0) * (double)nq * (double)sp_.stride : 32.0 * (double)h_tot[2]) +
+            const SelectPlan sp_ = select_plan(L, nq, n_cand_all);
+            need = (sp_.select ? 8.0 * (double)n_cand_all + (sp_.sort_lds ? 16.0 : 32.0) * (double)nq * (double)sp_.stride : 32.0 * (double)n_cand_all) +
                    (double)n_tabs * nf * K * sizeof(double);
         }
         if (need > 4.0e9 && nq > 1) return CIS_RETRY_SMALLER;
     }
-    ix->stats[0] += (int64_t)h_tot[2];
-    ix->stats[1] += n_items;
-    ix->stats[2] += n_tabs;
     // 3. emit items + table list
     CIS_TRY(mark(1));  // the plan read-back above is part of the front end
     CIS_TRY(ix->w_items.reserve((size_t)(n_items + 1) * sizeof(WorkItem)));
@@ -3479,22 +3531,22 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                            seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order);
         if (n_tabs > 0)
             launch_tables<float>(n_tabs, tab_lds, st, (const float*)xc, m->d_Cs32, m->d_Rt, m->d_mus, m->d_subs, tabs, tab_order, V, h,
-                                 m->w, nf, K, D, T, m->prog_w, px_buf);
+                                 m->w, nf, K, D, T, m->prog_w, px_buf, d_tot);
     } else {
         hipLaunchKernelGGL((k_plan<double, true>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
                            seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order);
         if (n_tabs > 0)
             launch_tables<double>(n_tabs, tab_lds, st, (const double*)xc, m->d_Cs64, m->d_Rt, m->d_mus, m->d_subs, tabs, tab_order, V,
-                                  h, m->w, nf, K, D, T, m->prog_w, px_buf);
+                                  h, m->w, nf, K, D, T, m->prog_w, px_buf, d_tot);
     }
     if (split_tables && n_tabs > 0) {
         dim3 g((unsigned)ceil_div(n_tabs, 64), (unsigned)nf, 2);
         switch (m->w) {
-            case 4: hipLaunchKernelGGL(k_tables_from_px<4>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32); break;
-            case 8: hipLaunchKernelGGL(k_tables_from_px<8>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32); break;
-            case 16: hipLaunchKernelGGL(k_tables_from_px<16>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32); break;
-            default: hipLaunchKernelGGL(k_tables_from_px<32>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32); break;
+            case 4: hipLaunchKernelGGL(k_tables_from_px<4>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32, d_tot); break;
+            case 8: hipLaunchKernelGGL(k_tables_from_px<8>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32, d_tot); break;
+            case 16: hipLaunchKernelGGL(k_tables_from_px<16>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32, d_tot); break;
+            default: hipLaunchKernelGGL(k_tables_from_px<32>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32, d_tot); break;
         }
     } else if (fast && n_tabs > 0) {
         const int64_t ne = n_tabs * nf * K;
@@ -3505,7 +3557,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         // for limit <= 3072, by a stable segmented sort of the selected pairs above) or, when `limit` is of the order
         // of the candidate count, the stable segmented sort of everything
         CIS_TRY(mark(2));
-        const int64_t n_cand = (int64_t)h_tot[2];
+        const int64_t n_cand = n_cand_all;
         CIS_REQUIRE(n_cand < ((int64_t)1 << 32), "query batch too large for the sorted path");
         const uint8_t* codes = ix->d_codes.as<uint8_t>();
         const int64_t* ids = ix->d_ids.as<int64_t>();
@@ -3534,7 +3586,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         uint64_t* b4 = b3 + bl;
         void* tmp = reinterpret_cast<void*>(((uintptr_t)(sp.select ? (sp.sort_lds ? b3 : b3 + 2 * bl) : b4) + 255) & ~(uintptr_t)255);
         hipLaunchKernelGGL(k_cand_layout, dim3(1), dim3(1024), 0, st, items, n_items, item_off, nq, n_cand, cand_start, seg,
-                           sp.select ? qmin : (unsigned long long*)nullptr, qmax);
+                           sp.select ? qmin : (unsigned long long*)nullptr, qmax, d_tot);
         const uint64_t *rk = nullptr, *rv = nullptr;  // ranked pairs
         if (!sp.select) {
             uint64_t *keys_out = b1, *vals_in = b2, *vals_out = b3;
@@ -3547,7 +3599,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         } else {
             uint64_t *sel_keys = b1, *sel_vals = b2;
             if (n_items > 0)
-                launch_adc_all(n_items, st, items, cand_start, T, codes, M, K, keys_in, nullptr, qmin, qmax);
+                launch_adc_all(n_items, st, items, cand_start, T, codes, M, K, keys_in, nullptr, qmin, qmax, d_tot);
             if (sp.sort_lds) {
                 // fewer queries than CUs: one large workgroup per query walks its keys faster; else two 512-thread ones per CU
                 if (nq <= 256)
@@ -3696,6 +3748,7 @@ static int search_all(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_
     CIS_TRY(index_sync(ix));
     CIS_CHECK_HIP(hipSetDevice(ix->m->device));
     for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
+    ix->stats_pending_seq = 0;
     int batch = QUERY_BATCH;
     for (int a = 0; a < nq;) {
         const int bn = (nq - a < batch) ? (nq - a) : batch;
