@@ -119,27 +119,30 @@ __global__ void k_to_f64(const TI* __restrict__ in, double* __restrict__ out, in
     for (; i < n; i += stride) out[i] = (double)in[i];
 }
 
-// Y[n][D] = (X - mu) . P, float64, 64x64 tile per 256-thread block, 4x4 outputs per thread.
-template <typename TX, bool SUBF32>
+// Y[n][D] = (X - mu) . P, float64, (16 TM) x 64 tile per 256-thread block, TM x 4 outputs per thread (TM = 4: 64 rows;
+// TM = 2: 32 rows, twice the workgroups -- a batch of 8192 x 128 is only 256 tiles of 64 x 64, one per CU, with nothing to
+// hide the load latency of its eight K slabs behind).
+template <typename TX, bool SUBF32, int TM>
 __global__ __launch_bounds__(256) void k_pca_gemm(const TX* __restrict__ X, const double* __restrict__ mu,
                                                   const double* __restrict__ P, double* __restrict__ Y,
                                                   int64_t n, int D_in, int D) {
-    __shared__ double sA[16][64 + 1];  // [k][row]
+    constexpr int BM = 16 * TM;
+    __shared__ double sA[16][BM + 1];  // [k][row]
     __shared__ double sB[16][64];      // [k][col]
     const int tid = threadIdx.x;
-    const int tr = tid / 16, tc = tid % 16;  // thread micro-tile origin: rows tr*4.., cols tc*4..
-    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int tr = tid / 16, tc = tid % 16;  // thread micro-tile origin: rows tr*TM.., cols tc*4..
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int col0 = blockIdx.y * 64;
-    double acc[4][4];
+    double acc[TM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
     // register prefetch: the global loads of slab k0+16 are in flight while slab k0 is multiplied
-    double ra[4], rb[4];
+    double ra[TM], rb[4];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < TM; ++e) {
             const int idx = tid + e * 256;
             const int r = idx / 16, k = idx % 16;
             double v = 0.0;
@@ -165,30 +168,34 @@ __global__ __launch_bounds__(256) void k_pca_gemm(const TX* __restrict__ X, cons
     fetch(0);
     for (int k0 = 0; k0 < D_in; k0 += 16) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < TM; ++e) {
             const int idx = tid + e * 256;
             sA[idx % 16][idx / 16] = ra[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
             sB[idx / 64][idx % 64] = rb[e];
         }
         __syncthreads();
         if (k0 + 16 < D_in) fetch(k0 + 16);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            double a[4], b[4];
+            double a[TM], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = sA[k][tr * 4 + i];
+            for (int i = 0; i < TM; ++i) a[i] = sA[k][tr * TM + i];
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = sB[k][tc * 4 + j];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t r = row0 + tr * 4 + i;
+    for (int i = 0; i < TM; ++i) {
+        const int64_t r = row0 + tr * TM + i;
         if (r >= n) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -589,13 +596,18 @@ int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, floa
     if (n == 0) return CIS_OK;
     CIS_TRY(m->ws_y64.reserve((size_t)n * m->D * sizeof(double)));
     double* Y = m->ws_y64.as<double>();
-    dim3 g((unsigned)ceil_div(n, 64), (unsigned)ceil_div(m->D, 64));
-    if (x_dtype == CIS_F32 && m->pca_mu_f32)
-        hipLaunchKernelGGL((k_pca_gemm<float, true>), g, dim3(256), 0, st, (const float*)dX, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);
-    else if (x_dtype == CIS_F32)
-        hipLaunchKernelGGL((k_pca_gemm<float, false>), g, dim3(256), 0, st, (const float*)dX, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);
-    else
-        hipLaunchKernelGGL((k_pca_gemm<double, false>), g, dim3(256), 0, st, (const double*)dX, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);
+    // 64-row tiles when they fill the chip twice over, 32-row tiles otherwise
+    const bool small = ceil_div(n, 64) * ceil_div(m->D, 64) < 512;
+    dim3 g((unsigned)ceil_div(n, small ? 32 : 64), (unsigned)ceil_div(m->D, 64));
+#define CIS_PCA_LAUNCH(TX, SUB, XP)                                                                                              \
+    do {                                                                                                                          \
+        if (small) hipLaunchKernelGGL((k_pca_gemm<TX, SUB, 2>), g, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
+        else hipLaunchKernelGGL((k_pca_gemm<TX, SUB, 4>), g, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);       \
+    } while (0)
+    if (x_dtype == CIS_F32 && m->pca_mu_f32) CIS_PCA_LAUNCH(float, true, (const float*)dX);
+    else if (x_dtype == CIS_F32) CIS_PCA_LAUNCH(float, false, (const float*)dX);
+    else CIS_PCA_LAUNCH(double, false, (const double*)dX);
+#undef CIS_PCA_LAUNCH
     if (m->renorm && m->D >= 8 && m->D <= 128 && m->D % 8 == 0)
         hipLaunchKernelGGL(k_pca_finish8, dim3((unsigned)ceil_div(n, 32)), dim3(256), 0, st, Y, d_out, n, m->D);
     else
