@@ -3332,7 +3332,6 @@ static SelectPlan select_plan(int L, int nq, int64_t n_cand) {
 static int small_batch_nq(int L) {
     static const int forced = getenv("CIS_SMALL_NQ") ? atoi(getenv("CIS_SMALL_NQ")) : -1;  // experiments
     if (forced >= 0) return forced;
-    if (L <= 16) return 0;
     if (L <= 184) return 63;
     if (L <= 300) return 256;
     return 512;
