@@ -60,6 +60,14 @@ def _worker(rank, world, port, name, quota, limit, ret):
                 lst = pparts[w, o:o + c].numpy().view(O.HIT_DTYPE).reshape(-1)
                 ref_lst = parts[w, qi][parts[w, qi]["id"] >= 0]
                 ok = ok and np.array_equal(lst, ref_lst)
+        # the any-limit merge of the packed lists (stable sorts by pos/visit_rank, dist, query) reproduces the single index
+        from columbiaimagesearch_amd.distributed import merge_packed_sorted
+        mo = merge_packed_sorted(pparts, off, cnt_all, nq, limit)
+        for qi in range(nq):
+            ids, dists, _ = ix.search(Q[qi], quota=quota, limit=limit)
+            k = int(mo["n_found"][qi])
+            ok = ok and k == len(ids) and np.array_equal(mo["ids"][qi, :k].numpy(), ids)
+            ok = ok and np.array_equal(mo["dists"][qi, :k].numpy(), dists) and bool((mo["ids"][qi, k:] == -1).all())
         # 16-bit coarse codes travel as bytes (neither RCCL nor gloo has an int16 collective)
         from columbiaimagesearch_amd.distributed import all_gather_stack
         c16 = (torch.arange(6, dtype=torch.int16).reshape(3, 2) + 1000 * rank)
@@ -75,7 +83,7 @@ def _worker(rank, world, port, name, quota, limit, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("quota,limit", [(50, 20), (3000, 100)])
+@pytest.mark.parametrize("quota,limit", [(50, 20), (3000, 100), (3000, 700)])
 def test_cell_sharded_search_two_gloo_ranks(quota, limit):
     world = 2
     port = _free_port()

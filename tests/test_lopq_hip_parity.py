@@ -258,6 +258,43 @@ def test_cell_sharded_search_equals_single(name, world):
         np.testing.assert_array_equal(a2[~np.isnan(a2)], b[~np.isnan(b)])
 
 
+@pytest.mark.gpu
+def test_sharded_any_limit_merge_equals_single():
+    """limit above the 512 records per query of the one-wave merge kernel (and above the 3072 of the dense one): the
+    shards' packed lists are merged by stable device sorts (distributed.merge_packed_sorted) -- same result as one index."""
+    import torch
+    from columbiaimagesearch_amd.distributed import merge_packed_sorted
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    z, X, Q = load_golden("c2")
+    m = hip_model(z)
+    single = _build_searcher("c2", z, X, m)
+    world = 3
+    shards = []
+    for r in range(world):
+        s = LOPQSearcherHIP(m, shard=(r, world))
+        s.add_codes_array(z["coarse"], z["fine"], None)
+        shards.append(s)
+    q = torch.as_tensor(Q[:9]).cuda().contiguous()
+    for quota, limit in [(5000, 700), (20000, 4000), (2500, None)]:
+        ref = single.search_batch(Q[:9], quota=quota, limit=limit)
+        L = ref["ids"].shape[1]
+        pp = [s.search_partial_packed_dev(q, quota=quota, limit=limit) for s in shards]
+        torch.cuda.synchronize()
+        stride = max(max(int(p["total"].item()) for p in pp), 1)
+        buf = torch.zeros((world, stride, 4), dtype=torch.int64, device="cuda")
+        for r, p in enumerate(pp):
+            t = int(p["total"].item())
+            buf[r, :t] = p["packed"][:t]
+        cnt = torch.stack([p["cnt"] for p in pp]).contiguous()
+        off = torch.stack([p["off"] for p in pp]).contiguous()
+        out = merge_packed_sorted(buf, off, cnt, 9, L)
+        np.testing.assert_array_equal(out["ids"].cpu().numpy(), ref["ids"])
+        np.testing.assert_array_equal(out["n_found"].cpu().numpy(), ref["n_found"])
+        a, b = out["dists"].cpu().numpy(), ref["dists"]
+        np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+        np.testing.assert_array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+
+
 def test_device_entry_points_match_host_entry_points():
     import torch
     z, X, Q = load_golden("c2")
