@@ -18,4 +18,6 @@ tools/gpu_pmc.sh ${tag}_l2 "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" --steps 3 
 rm -rf /tmp/prof_lim; LIMITS=1000,10000 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_lim -o r -- python tools/bench_limits.py > /dev/null 2>&1
 python tools/kstats.py /tmp/prof_lim/r_kernel_stats.csv "adc_all|select|emit_sorted|rocprim|cand_layout" > gpurun_out/${tag}_limits_kernels.txt 2>&1
 { python tools/bench_dlib.py 256; python tools/bench_dlib.py 32; python tools/bench_cnn.py; } 2>&1 | grep batch > gpurun_out/${tag}_cnn.txt
-cat gpurun_out/${tag}_pytest_gpu.txt; cat gpurun_out/${tag}_limits.txt gpurun_out/${tag}_limits_kernels.txt gpurun_out/${tag}_cnn.txt; cat gpurun_out/${tag}_summary.txt | head -40; grep adc_scan gpurun_out/${tag}_*_pmc.csv
+tools/gpu_pmc_cnn.sh ${tag} > /dev/null 2>&1
+{ for net in cnn dlib; do echo "== tools/bench_$net.py =="; python tools/mfma_pmc_summary.py gpurun_out/${tag}_${net}_mfma_pmc.csv; done; } > gpurun_out/${tag}_mfma_utilisation.txt 2>&1
+cat gpurun_out/${tag}_pytest_gpu.txt; cat gpurun_out/${tag}_mfma_utilisation.txt gpurun_out/${tag}_limits.txt gpurun_out/${tag}_limits_kernels.txt gpurun_out/${tag}_cnn.txt; cat gpurun_out/${tag}_summary.txt | head -40; grep adc_scan gpurun_out/${tag}_*_pmc.csv
