@@ -3452,7 +3452,9 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     int64_t n_items = 0, n_tabs = 0, n_cand_all = 0;
     {
         static const bool no_bounds = getenv("CIS_NO_BOUNDS") != nullptr;
-        const int64_t per_q = (quota < ix->n_total ? quota : ix->n_total) + ix->max_cell;
+        // quota <= 0 still visits one cell (search.py:131-132: the test follows the first append)
+        const int64_t q_eff = quota < 0 ? 0 : quota;
+        const int64_t per_q = (q_eff < ix->n_total ? q_eff : ix->n_total) + ix->max_cell;
         const int64_t items_q = ix->nonempty_cells + per_q / seg_max + 2;
         const bool split_ok = (m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) && K <= 256;
         if (!no_bounds && nq <= 64 && L <= MAX_LDS_LIMIT && split_ok && use_all_path(ix, M, K, L, nq) && items_q <= 4096 &&

@@ -6,8 +6,9 @@ Mirror of DLibFeaturizer (cufacesearch/cufacesearch/featurizer/dlib_featurizer.p
 alignment are dlib host code (out of scope, like image decoding); the 29-convolution ResNet runs in libcis_hip.so.
 ``featurize_chips`` takes already aligned 150x150 RGB chips and is the batch entry point.
 
-Weights: ``rec_path`` may be a ``.npz`` with the 117 arrays named as oracle/dlib_oracle.py:tensor_names (a converter from
-dlib's ``.dat`` serialisation is not built: the format is dlib-internal and absent from the reference tree).
+Weights: ``rec_path`` is an ``.npz`` with the 117 arrays of ``tensor_names()``, or the XML that dlib's own
+``net_to_xml`` writes from ``dlib_face_recognition_resnet_model_v1.dat`` (featurizer/dlib_weights.py; the ``.dat`` itself
+is dlib's private C++ stream format -- INTEGRATION.md section 4 gives the six-line export program).
 """
 import numpy as np
 
@@ -74,18 +75,40 @@ class DLibHIPFeaturizer(GenericFeaturizer):
         self.set_pp(pp="DLibHIPFeaturizer")
         self.pred_path = self.get_param("pred_path")
         self.rec_path = str(self.get_required_param("rec_path"))
-        if not self.rec_path.endswith(".npz"):
-            raise NotImplementedError("rec_path must be an .npz with the 117 network tensors (dlib .dat is not parsed)")
-        z = np.load(self.rec_path)
-        self.net = DLibFaceNet({k: z[k] for k in z.files})
+        if self.rec_path.endswith(".npz"):
+            z = np.load(self.rec_path)
+            weights = {k: z[k] for k in z.files}
+        elif self.rec_path.endswith(".xml"):
+            from .dlib_weights import weights_from_net_xml
+            weights = weights_from_net_xml(self.rec_path)
+        else:
+            raise NotImplementedError("rec_path must be the net_to_xml export (.xml) of the dlib .dat, or an .npz with the "
+                                      "117 network tensors -- see INTEGRATION.md section 4 (dlib's .dat stream is not parsed)")
+        self.net = DLibFaceNet(weights)
         self._sp = None
+        self.chip_fn = None  # (img, bbox) -> aligned 150x150x3 chip; default: dlib landmarks + get_face_chip
 
     def featurize_chips(self, chips):
         """aligned 150x150 RGB chips -> [n,128] float64 (dtype of the reference's descriptors, featsio.py:34-36)"""
         return self.net.forward(chips).astype(np.float64)
 
+    def featurize_dets(self, img, dets):
+        """All detections of one image in ONE forward pass -> [n,128] float64 (the reference calls featurize once per
+        detection, generic_extractor.py:238)."""
+        if len(img.shape) == 2:
+            img = np.stack([img] * 3, axis=-1)  # reference :97-99 gray2rgb
+        return self.featurize_chips(np.stack([self._chip(img, d) for d in dets]))
+
     def featurize(self, img, bbox=None, img_type="scikit"):
-        """reference :86-105: landmarks on the detected box, aligned chip, network.  Needs dlib for the two host steps."""
+        """reference :86-105: landmarks on the detected box, aligned chip, network.  Needs dlib for the two host steps
+        (or `chip_fn`)."""
+        if len(img.shape) == 2:
+            img = np.stack([img] * 3, axis=-1)
+        return self.featurize_chips(np.asarray(self._chip(img, bbox))[None])[0]
+
+    def _chip(self, img, bbox):
+        if self.chip_fn is not None:
+            return np.asarray(self.chip_fn(img, bbox))
         try:
             import dlib
         except ImportError:
@@ -95,5 +118,4 @@ class DLibHIPFeaturizer(GenericFeaturizer):
             self._sp = dlib.shape_predictor(str(self.pred_path))
         rect = dlib.rectangle(int(bbox["left"]), int(bbox["top"]), int(bbox["right"]), int(bbox["bottom"]))
         shape = self._sp(img, rect)
-        chip = dlib.get_face_chip(img, shape, size=INPUT_HW, padding=0.25)
-        return self.featurize_chips(np.asarray(chip)[None])[0]
+        return np.asarray(dlib.get_face_chip(img, shape, size=INPUT_HW, padding=0.25))

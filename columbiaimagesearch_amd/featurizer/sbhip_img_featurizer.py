@@ -7,8 +7,9 @@ float32 (un-normalised: the caller normalises, generic_extractor.py:238-248).  P
 (decode, 256x256 lanczos resize through uint8, centre crop 227, RGB->BGR, mean subtraction: :113-134); the
 forward pass runs in libcis_hip.so.  ``featurize_batch`` is the addition that feeds the GPU whole batches.
 
-Weights: the reference downloads a ``.caffemodel`` (:5); here ``sbcaffe_path`` may be a ``.npz`` with the 14
-arrays ``conv1_w, conv1_b, ..., fc7_w, fc7_b`` in caffe layout (tools/caffemodel_to_npz.py converts).
+Weights: ``sbcaffe_path`` is the reference's ``.caffemodel`` (:5,56-61), read by featurizer/caffemodel.py (a
+hand-written NetParameter/BlobProto wire-format reader: no caffe, no protoc), or a ``.npz`` with the 14 arrays
+``conv1_w, conv1_b, ..., fc7_w, fc7_b`` in caffe layout.
 """
 import io
 
@@ -90,18 +91,34 @@ class SentiBankHIPImgFeaturizer(GenericFeaturizer):
         if path.endswith(".npz"):
             z = np.load(path)
             return {k: z[k] for k in z.files}
-        raise NotImplementedError("convert the .caffemodel with tools/caffemodel_to_npz.py and point sbcaffe_path at the .npz")
+        from .caffemodel import sentibank_weights
+        return sentibank_weights(path)  # the reference's file: a serialised caffe NetParameter
+
+    @staticmethod
+    def bytescale(data, low=0, high=255):
+        """scipy.misc.bytescale as imresize -> toimage applies it to the float image caffe.io.load_image returns:
+        the image's own min..max is stretched to 0..255 before the resize (so a low-contrast image is NOT resized
+        as its uint8 self).  float32 arithmetic like the reference's (float32 image, python-float scale)."""
+        cmin, cmax = data.min(), data.max()
+        cscale = cmax - cmin
+        if cscale == 0:
+            cscale = 1
+        scale = float(high - low) / cscale
+        bytedata = (data - cmin) * data.dtype.type(scale) + data.dtype.type(low)
+        return (bytedata.clip(low, high) + data.dtype.type(0.5)).astype(np.uint8)
 
     def preprocess_img(self, img_buffer):
-        """host-side restatement of reference :113-134 with PIL (caffe.io.load_image -> RGB float [0,1];
-        scipy.misc.imresize goes through uint8 and PIL's LANCZOS; crop; HWC->CHW; RGB->BGR; subtract mean)"""
+        """host-side restatement of reference :113-134 with PIL: caffe.io.load_image -> RGB float32 in [0,1]
+        (skimage.img_as_float(...).astype(float32)); scipy.misc.imresize = toimage (bytescale: min..max -> 0..255,
+        uint8) + PIL LANCZOS resize to 256x256; centre crop 227; HWC->CHW; RGB->BGR; subtract the cropped mean."""
         from PIL import Image
         if isinstance(img_buffer, (bytes, bytearray)):
             img_buffer = io.BytesIO(img_buffer)
         im = Image.open(img_buffer)
         if getattr(im, "n_frames", 1) > 1:
             im.seek(1)  # reference takes image[1] of a GIF (:123-125)
-        im = im.convert("RGB").resize((self.target_size[1], self.target_size[0]), Image.LANCZOS)
+        img = (np.asarray(im.convert("RGB"), dtype=np.uint8) / 255.0).astype(np.float32)
+        im = Image.fromarray(self.bytescale(img), mode="RGB").resize((self.target_size[1], self.target_size[0]), Image.LANCZOS)
         a = np.asarray(im, dtype=np.uint8)[self.w_boff:self.w_eoff, self.h_boff:self.h_eoff, :]
         chw = a.transpose(2, 0, 1)[::-1].astype(np.float32)  # channel swap (2,1,0): RGB -> BGR
         return chw - self.mu

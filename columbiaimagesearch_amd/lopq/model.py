@@ -26,10 +26,15 @@ def _code_dtype(n):
 
 
 class _Handle(object):
-    """Owns a cis_model*; rebuilt when the parameter arrays are replaced."""
+    """Owns a cis_model*; rebuilt when the parameter arrays are replaced.  Keeps the arrays it was built from
+    alive, so that "same objects" (the cache test) cannot be fooled by a recycled id()."""
 
-    def __init__(self, ptr, key):
-        self.ptr, self.key = ptr, key
+    def __init__(self, ptr, arrays, renorm):
+        self.ptr, self.arrays, self.renorm = ptr, arrays, renorm
+
+    def matches(self, arrays, renorm):
+        return (self.renorm == renorm and len(self.arrays) == len(arrays)
+                and all(a is b for a, b in zip(self.arrays, arrays)))
 
     def __del__(self):
         try:
@@ -66,6 +71,7 @@ class LOPQModel(object):
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop("_hip", None)
+        state.pop("_dims", None)
         return state
 
     # -- device handle ---------------------------------------------------------------------------
@@ -73,15 +79,19 @@ class LOPQModel(object):
         return None, None, False
 
     def _handle(self):
+        return self._handle_obj().ptr
+
+    def _handle_obj(self):
+        """The _Handle owning the device copy of the current parameters.  A searcher keeps this object (not just
+        the pointer): the index borrows the cis_model*, which must outlive it even if the model is re-fitted."""
         if self.Cs is None or self.Rs is None or self.mus is None or self.subquantizers is None:
             raise ValueError("model has no parameters yet: call fit() or pass parameters=")
         P, pmu, renorm = self._pca_params()
         arrays = [self.Cs[0], self.Cs[1], self.Rs[0], self.Rs[1], self.mus[0], self.mus[1]]
         arrays += list(self.subquantizers[0]) + list(self.subquantizers[1]) + [P, pmu]
-        key = tuple(id(a) for a in arrays) + (bool(renorm),)
         h = self.__dict__.get("_hip")
-        if h is not None and h.key == key:
-            return h.ptr
+        if h is not None and h.matches(arrays, bool(renorm)):
+            return h
         C0, C1 = np.asarray(self.Cs[0]), np.asarray(self.Cs[1])
         coarse_f32 = (C0.dtype == np.float32 and C1.dtype == np.float32)
         cdt = np.float32 if coarse_f32 else np.float64
@@ -111,9 +121,9 @@ class LOPQModel(object):
                                       _lib.CIS_F32 if coarse_f32 else _lib.CIS_F64, _lib.ptr(Cs), _lib.ptr(Rs),
                                       _lib.ptr(mus), _lib.ptr(subs), _lib.ptr(P), _lib.ptr(pmu),
                                       _lib.CIS_F32 if mu_f32 else _lib.CIS_F64, 1 if renorm else 0))
-        self.__dict__["_hip"] = _Handle(out.value, key)
+        self.__dict__["_hip"] = _Handle(out.value, arrays, bool(renorm))
         self.__dict__["_dims"] = (D_in, D)
-        return out.value
+        return self.__dict__["_hip"]
 
     @property
     def dim(self):

@@ -124,8 +124,11 @@ class LOPQSearcherHIP(LOPQSearcherBase):
     def _open(self):
         out = _lib.c_void_p()
         L = _lib.lib()
-        _lib.check(L.cis_index_create(_lib.ctypes.byref(out), self.model._handle()))
+        # the index borrows the cis_model* (include/cis_hip.h): hold the owning object for the index's lifetime
+        self._model_handle = self.model._handle_obj()
+        _lib.check(L.cis_index_create(_lib.ctypes.byref(out), self._model_handle.ptr))
         self._ix = out.value
+        self._input_dim = self.model.__dict__["_dims"][0]  # of the parameters this index was built on
         if type(self).default_prefilter_only:
             _lib.check(L.cis_index_set_scan_mode(self._ix, 2))
         if self._shard is not None:
@@ -237,7 +240,7 @@ class LOPQSearcherHIP(LOPQSearcherBase):
             ``dists`` [nq,L] float64 squared ADC distances (NaN padded), ``n_found`` [nq],
             ``visited`` [nq] and, if with_codes, ``cells`` / ``pos`` locating every result.
         """
-        X = _lib.as_float_matrix(X, self.model.input_dim)
+        X = _lib.as_float_matrix(X, self._input_dim)
         nq = X.shape[0]
         L = int(quota) if limit is None else int(limit)
         L = max(L, 0)
@@ -290,8 +293,8 @@ class LOPQSearcherHIP(LOPQSearcherBase):
     # -- device-resident entry points (torch tensors are only the memory/stream plumbing) ---------
     def _dev_args(self, q, quota, limit):
         import torch
-        if not (q.is_cuda and q.is_contiguous() and q.dim() == 2 and q.shape[1] == self.model.input_dim):
-            raise ValueError("q must be a contiguous [nq, %d] tensor on the GPU" % self.model.input_dim)
+        if not (q.is_cuda and q.is_contiguous() and q.dim() == 2 and q.shape[1] == self._input_dim):
+            raise ValueError("q must be a contiguous [nq, %d] tensor on the GPU" % self._input_dim)
         if q.dtype not in (torch.float32, torch.float64):
             raise ValueError("q must be float32 or float64")
         L = int(quota) if limit is None else int(limit)
@@ -494,6 +497,12 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
     def _key_suffix(item_id):
         return str(item_id).encode("latin1") if not isinstance(item_id, bytes) else item_id  # py2 bytes(id) == str(id)
 
+    def _id_of_suffix(self, suffix):
+        """id_lambda receives what the reference's py2 code hands it: the key suffix as a ``str`` (:489, ``key[4:]`` of
+        a py2 byte string).  The production searcher passes ``id_lambda=str`` (searcher_lopqhbase.py:204-206), and
+        ``str(b'sha1')`` under py3 would be the repr "b'sha1'" -- so the bytes are decoded first."""
+        return self.id_lambda(suffix.decode("latin1"))
+
     def get_nb_indexed(self):
         self.nb_indexed = sum(len(v) for v in self._store.values())
         return self.nb_indexed
@@ -525,7 +534,7 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
         ct = _code_dtype(self.model.V)
         c = (int(cell[0]), int(cell[1]))
         items = self._store.get(c, {})
-        return [(self.id_lambda(k), LOPQCode((ct(c[0]), ct(c[1])), items[k])) for k in sorted(items)]
+        return [(self._id_of_suffix(k), LOPQCode((ct(c[0]), ct(c[1])), items[k])) for k in sorted(items)]
 
     def _device_index(self):
         if self._dev is None:
@@ -552,12 +561,12 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
         return self._device_index().search_batch(X, quota=quota, limit=limit, with_codes=with_codes)
 
     def caller_ids(self, dev_ids):
-        return [self.id_lambda(self._suffix_of_slot[int(i)]) for i in dev_ids if i >= 0]
+        return [self._id_of_suffix(self._suffix_of_slot[int(i)]) for i in dev_ids if i >= 0]
 
     def search(self, x, quota=10, limit=None, with_dists=False):
         dev = self._device_index()
         results, visited = dev.search(x, quota=quota, limit=limit, with_dists=with_dists)
-        return [r._replace(id=self.id_lambda(self._suffix_of_slot[int(r.id)])) for r in results], visited
+        return [r._replace(id=self._id_of_suffix(self._suffix_of_slot[int(r.id)])) for r in results], visited
 
 
 # the reference's dict searcher's name resolves to the HIP searcher so that config strings written for it keep working

@@ -566,4 +566,5 @@ class OracleKeyOrderIndex(OracleIndex):
 
     def get_cell(self, cell):
         items = self.store.get((int(cell[0]), int(cell[1])), {})
-        return [(self.id_lambda(k), items[k]) for k in sorted(items)]
+        # py2: key[4:] is a str; the production caller passes id_lambda=str (searcher_lopqhbase.py:204-206)
+        return [(self.id_lambda(k.decode("latin1")), items[k]) for k in sorted(items)]

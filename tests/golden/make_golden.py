@@ -190,7 +190,7 @@ def make_c1(outdir):
     np.savez_compressed(os.path.join(outdir, "c1.npz"), **d)
 
 
-def make_pca_fixture(outdir, name, V, M, pca_dims, n_index, n_train, nq, inputs, settings):
+def make_pca_fixture(outdir, name, V, M, pca_dims, n_index, n_train, nq, inputs, settings, pca_subsample=None):
     from lopq import LOPQModelPCA, LOPQSearcher
     from lopq.utils import compute_codes_notparallel
     X, Q = inputs
@@ -198,7 +198,7 @@ def make_pca_fixture(outdir, name, V, M, pca_dims, n_index, n_train, nq, inputs,
     t = time.time()
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
-        m.fit(X[:n_train], pca_dims=pca_dims, n_init=1, random_state=4321)
+        m.fit(X[:n_train], pca_dims=pca_dims, n_init=1, random_state=4321, pca_subsample=pca_subsample)
     print("%s fit %.1fs  Cs %s Rs %s" % (name, time.time() - t, m.Cs[0].dtype, m.Rs[0].dtype))
     Xi = X[:n_index]
     with contextlib.redirect_stdout(io.StringIO()):
@@ -245,6 +245,67 @@ def make_c3b(outdir):
                      [(10, 10), (1000, 100)])
 
 
+def make_c3full(outdir):
+    """C3 at its TRUE shape: float32 non-negative 4096-d features, PCA 4096 -> 256 (pca_dims of
+    conf/conf_search_sbpycaffe_release.json:12), V=16, M=16 (h=128, w=16).  The reference fits everything
+    (PCA on the first 2500 training vectors: its per-sample np.outer loop costs 0.1 s per 4096-d sample)."""
+    make_pca_fixture(outdir, "c3full", 16, 16, 256, 4000, 6000, 32, gi.c3full_inputs(),
+                     [(10, 10), (1000, 100), (10000, 100)], pca_subsample=2500)
+
+
+def make_pk(outdir):
+    """What production stores (SURVEY.md section 8b gotcha iii / 8f row 2): the model OBJECT pickled by the storer
+    (cufacesearch/storer/local.py:58) and a per-update codes dict {id: [coarse, fine]} built exactly as
+    searcher_lopqhbase.py:503-512 does, both pickled from the real reference classes (module ``lopq.model``), plus
+    the expected codes / search results as arrays.  Protocol 2 = the highest a python-2 writer could have used."""
+    import pickle
+    from lopq import LOPQModel, LOPQModelPCA, LOPQSearcher
+    from lopq.utils import compute_codes_notparallel
+    import contextlib, io
+    X, Q = gi.pk_inputs()
+    sub = os.path.join(outdir, "pk")
+    os.makedirs(sub, exist_ok=True)
+    d = {"inputs_sha1": np.array(sha1(X) + sha1(Q))}
+    for tag, m, fitkw in (("lopq", LOPQModel(V=4, M=4, subquantizer_clusters=16), {}),
+                          ("lopq_pca", LOPQModelPCA(V=4, M=4, subquantizer_clusters=16, renorm=True), {"pca_dims": 16})):
+        Xm = X[:, :16] if tag == "lopq" else X
+        Qm = Q[:, :16] if tag == "lopq" else Q
+        with contextlib.redirect_stdout(io.StringIO()):
+            m.fit(Xm[:2000], n_init=1, random_state=11, **fitkw)
+            codes = compute_codes_notparallel(Xm, m)
+        det_ids = ["%040x_%d" % (i * 2654435761 % (1 << 61), i % 3) for i in range(len(Xm))]  # sha1-like strings
+        codes_dict = dict()
+        for i, code in enumerate(codes):  # searcher_lopqhbase.py:506-512
+            codes_dict[det_ids[i]] = [code.coarse, code.fine]
+        with open(os.path.join(sub, "model_%s.pkl" % tag), "wb") as f:
+            pickle.dump(m, f, protocol=2)
+        with open(os.path.join(sub, "codes_%s.pkl" % tag), "wb") as f:
+            pickle.dump(codes_dict, f, protocol=2)
+        s = LOPQSearcher(m)
+        s.add_codes_from_dict(codes_dict)
+        coarse, fine = codes_to_arrays(codes)
+        d["%s_coarse" % tag], d["%s_fine" % tag] = coarse, fine
+        d["%s_nb_indexed" % tag] = np.int64(s.get_nb_indexed())
+        d["%s_attrs" % tag] = np.array(sorted(m.__dict__))
+        # ranked ids as positions in det_ids (ids are strings)
+        pos_of = {k: i for i, k in enumerate(det_ids)}
+        for quota, limit in ((20, 10), (500, 50)):
+            ids = -np.ones((len(Qm), limit), dtype=np.int64)
+            dists = np.full((len(Qm), limit), np.nan)
+            vis = np.zeros(len(Qm), dtype=np.int64)
+            for qi, q in enumerate(Qm):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    res, v = s.search(q, quota=quota, limit=limit, with_dists=True)
+                vis[qi] = v
+                for r, item in enumerate(res):
+                    ids[qi, r] = pos_of[item.id]
+                    dists[qi, r] = item.dist
+            d["%s_q%d_l%d_ids" % (tag, quota, limit)] = ids
+            d["%s_q%d_l%d_dists" % (tag, quota, limit)] = dists
+            d["%s_q%d_l%d_visited" % (tag, quota, limit)] = vis
+    np.savez_compressed(os.path.join(sub, "expected.npz"), **d)
+
+
 def make_tiny(outdir):
     """Edge cases: float64 centroids, K=16, empty cells, duplicates, explicit ids, limit=None."""
     from lopq import LOPQModel, LOPQSearcher
@@ -276,7 +337,8 @@ def make_tiny(outdir):
     np.savez_compressed(os.path.join(outdir, "tiny.npz"), **d)
 
 
-MAKERS = {"tiny": make_tiny, "c1": make_c1, "c2": make_c2, "c3": make_c3, "c3b": make_c3b, "c4": make_c4}
+MAKERS = {"tiny": make_tiny, "c1": make_c1, "c2": make_c2, "c3": make_c3, "c3b": make_c3b, "c4": make_c4,
+          "c3full": make_c3full, "pk": make_pk}
 
 if __name__ == "__main__":
     tmp = import_reference()
@@ -284,6 +346,7 @@ if __name__ == "__main__":
         names = sys.argv[1:] or list(MAKERS)
         for n in names:
             MAKERS[n](HERE)
-            print("wrote", n, os.path.getsize(os.path.join(HERE, n + ".npz")) // 1024, "KiB")
+            out = os.path.join(HERE, n + ".npz")
+            print("wrote", n, (os.path.getsize(out) // 1024) if os.path.exists(out) else "", "KiB")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

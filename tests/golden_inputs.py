@@ -83,6 +83,22 @@ def c3b_inputs():
     return X, Q
 
 
+def c3full_inputs():
+    """C3 at its true input width: 6000 x 4096 float32 non-negative unit vectors (post-ReLU-like), 32 queries."""
+    X = gmm_unit(6000, 4096, 64, 6, np.float32, nonneg=True)
+    Q, _ = perturbed_queries(X, 32, 66)
+    return X, Q
+
+
+def pk_inputs():
+    """Inputs of the pickled-model fixtures (tests/golden/pk): 3000 x 24 float64, 8 queries."""
+    rs = np.random.RandomState(5150)
+    centers = rs.randn(40, 24)
+    X = centers[rs.randint(0, 40, size=3000)] + 0.5 * rs.randn(3000, 24)
+    Q = X[rs.choice(3000, 8, replace=False)] + 0.05 * rs.randn(8, 24)
+    return X, Q
+
+
 def tiny_inputs():
     rs = np.random.RandomState(7)
     X = rs.randn(4000, 8)  # float64 -> float64 coarse centroids

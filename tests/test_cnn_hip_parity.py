@@ -138,3 +138,52 @@ def test_batch_ingest_matches_per_item_chain():
     for i in range(6):
         items = s.get_cell((int(coarse[i, 0]), int(coarse[i, 1])))
         assert any(it[0] == 100 + i and tuple(it[1][1]) == tuple(int(v) for v in fine[i]) for it in items)
+
+
+def test_c5_sentibank_ingest_against_oracle(net_and_weights):
+    """BASELINE config C5 at its true shapes: DeepSentibank batch -> L2 normalise (float32, featsio.py:13-22) ->
+    LOPQModelPCA 4096 -> 256, V=16, M=16 (the reference-fitted c3full model) -> insert.  Bars: the CNN features
+    against the CPU restatement (float tolerance), the device normalisation against numpy's within 2 float32 ulp, and
+    -- the parity claim -- the codes of the GPU chain BIT-EXACT against oracle.compute_codes on the same normalised
+    HIP features; then the index answers queries like the oracle index built from those codes."""
+    import torch
+    from conftest import load_golden
+    from oracle import cnn_oracle as C
+    from oracle import lopq_oracle as O
+    from columbiaimagesearch_amd.ingest import BatchIngest, l2_normalize_dev
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    from test_lopq_hip_parity import hip_model
+    net, w = net_and_weights
+    z, X, Q = load_golden("c3full")
+    model = hip_model(z)
+    om = O.OracleModel.from_npz(z)
+    n = 48
+    imgs = C.synthetic_images(n, seed=9)
+    x = torch.from_numpy(imgs).cuda()
+    feats = net.forward_dev(x)
+    ref = C.forward_torch(imgs[:4], w)
+    np.testing.assert_allclose(feats[:4].cpu().numpy(), ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+    normed = l2_normalize_dev(feats).contiguous()
+    f_host = feats.cpu().numpy()
+    want_normed = np.stack([f / np.linalg.norm(f) for f in f_host])  # featsio.normfeatB64encode's arithmetic
+    got_normed = normed.cpu().numpy()
+    assert got_normed.dtype == np.float32
+    np.testing.assert_allclose(got_normed, want_normed, rtol=2.4e-7, atol=0)
+    s = LOPQSearcherHIP(model)
+    ing = BatchIngest(net, model, s)
+    coarse_d, fine_d = ing.encode_batch_dev(x)
+    coarse = coarse_d.cpu().numpy().view(np.uint16)
+    fine = fine_d.cpu().numpy()
+    oc, of = O.compute_codes(om, got_normed)
+    np.testing.assert_array_equal(coarse, oc)
+    np.testing.assert_array_equal(fine, of)
+    ids = np.arange(5000, 5000 + n)
+    assert ing.ingest_batch(x, ids=ids) == n and s.get_nb_indexed() == n
+    oi = O.OracleCSRIndex(om, oc, of, ids=ids)
+    r = s.search_batch(got_normed[:8], quota=30, limit=20)
+    for qi in range(8):
+        wid, wd, wv = oi.search(got_normed[qi], quota=30, limit=20)
+        k = int(r["n_found"][qi])
+        assert k == len(wid) and int(r["visited"][qi]) == wv
+        np.testing.assert_array_equal(r["ids"][qi, :k], wid)
+        np.testing.assert_allclose(r["dists"][qi, :k], wd, rtol=1e-9, atol=1e-12)

@@ -11,7 +11,7 @@ from conftest import load_golden, sha1
 
 pytestmark = pytest.mark.gpu
 
-PCA_FIXTURES = ["c2", "c3", "c3b", "c4"]
+PCA_FIXTURES = ["c2", "c3", "c3b", "c4", "c3full"]
 ALL = ["tiny", "c1"] + PCA_FIXTURES
 
 _ROUTE_FREE = ("encode", "near_tie", "model_pieces", "selftest", "multisequence", "rerank", "kmeans", "select_path",

@@ -10,7 +10,7 @@ import pytest
 from conftest import load_golden, sha1
 from oracle import lopq_oracle as O
 
-PCA_FIXTURES = ["c2", "c3", "c3b", "c4"]
+PCA_FIXTURES = ["c2", "c3", "c3b", "c4", "c3full"]
 ALL = ["tiny", "c1"] + PCA_FIXTURES
 
 

@@ -1,0 +1,273 @@
+"""The surfaces cufacesearch actually calls, against objects produced by the real reference (tests/golden/pk, made
+by tests/golden/make_golden.py:make_pk): the storer's pickled ``lopq.model`` objects (storer/local.py:58,75,
+searcher_lopqhbase.py:113), ``compute_codes_notparallel(data, model)`` (searcher_lopqhbase.py:503), the per-update
+codes dict ``{id: [coarse, fine]}`` (:506-512) fed to ``add_codes_from_dict`` (:757), ``add_data``
+(lopq/lopq/search.py:94-108), ``add_codes_from_local`` (:245-263), the LMDB searcher with the production
+``id_lambda=str`` (searcher_lopqhbase.py:204-206) and the detector branch of ``GenericExtractor.process_buffer``
+(generic_extractor.py:236-247)."""
+import base64
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, has_gpu, sha1
+
+PK = os.path.join(GOLDEN, "pk")
+TAGS = ["lopq", "lopq_pca"]
+
+
+@pytest.fixture()
+def as_lopq():
+    """``import lopq`` resolves to the HIP package for the duration of a test (what INTEGRATION.md section 1 does)."""
+    saved = {k: sys.modules.get(k) for k in ("lopq", "lopq.model", "lopq.search", "lopq.utils")}
+    import columbiaimagesearch_amd.lopq as L
+    L.install_as_lopq()
+    yield L
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+
+
+def _inputs(tag):
+    import golden_inputs as gi
+    X, Q = gi.pk_inputs()
+    z = dict(np.load(os.path.join(PK, "expected.npz")))
+    assert str(z["inputs_sha1"]) == sha1(X) + sha1(Q)
+    if tag == "lopq":
+        X, Q = np.ascontiguousarray(X[:, :16]), np.ascontiguousarray(Q[:, :16])
+    return X, Q, z
+
+
+def _det_ids(n):
+    return ["%040x_%d" % (i * 2654435761 % (1 << 61), i % 3) for i in range(n)]
+
+
+def _load(name):
+    with open(os.path.join(PK, name), "rb") as f:
+        return pickle.load(f, encoding="latin1")  # SURVEY.md section 8b gotcha iii
+
+
+# ---- CPU: the pickles resolve to our classes with the reference's attribute set; the oracle agrees with them ------
+@pytest.mark.parametrize("tag", TAGS)
+def test_pickled_reference_model_loads_as_our_class(as_lopq, tag):
+    m = _load("model_%s.pkl" % tag)
+    X, Q, z = _inputs(tag)
+    want_cls = as_lopq.LOPQModelPCA if tag == "lopq_pca" else as_lopq.LOPQModel
+    assert type(m) is want_cls
+    assert sorted(m.__dict__) == [str(a) for a in z["%s_attrs" % tag]]  # exactly the reference's attributes
+    assert (m.V, m.M, m.subquantizer_clusters, m.num_coarse_splits, m.num_fine_splits) == (4, 4, 16, 2, 2)
+    # and pickling our object again keeps that attribute set (no device handle leaks into the pickle)
+    m2 = pickle.loads(pickle.dumps(m, protocol=2))
+    assert sorted(m2.__dict__) == sorted(m.__dict__)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_oracle_matches_pickled_reference_codes(as_lopq, tag):
+    from oracle import lopq_oracle as O
+    m = _load("model_%s.pkl" % tag)
+    X, Q, z = _inputs(tag)
+    om = O.OracleModel(m.Cs, m.Rs, m.mus, m.subquantizers, getattr(m, "pca_P", None), getattr(m, "pca_mu", None),
+                       getattr(m, "renorm", False))
+    coarse, fine = O.compute_codes(om, X)
+    np.testing.assert_array_equal(coarse, z["%s_coarse" % tag])
+    np.testing.assert_array_equal(fine, z["%s_fine" % tag])
+    codes = _load("codes_%s.pkl" % tag)
+    ids = _det_ids(len(X))
+    assert len(codes) == len(X)
+    for i in (0, 1, 17, len(X) - 1):
+        c, f = codes[ids[i]]
+        assert tuple(int(v) for v in c) == tuple(coarse[i]) and tuple(int(v) for v in f) == tuple(fine[i])
+
+
+def test_lmdb_searcher_hands_str_to_id_lambda():
+    """the production searcher is LOPQSearcherLMDB(model, path, id_lambda=str); ids are sha1
+    strings.  get_cell is host-side, so this part runs without a GPU."""
+    from columbiaimagesearch_amd.lopq.search import LOPQSearcherLMDB
+
+    class M(object):
+        V, M = 4, 4
+    s = LOPQSearcherLMDB(M(), None, id_lambda=str)
+    ids = ["da39a3ee5e6b4b0d3255bfef95601890afd80709", "0a4d55a8d778e5022fab701977c5d840bbc486d0_12_34_56_78"]
+    s.add_codes([((1, 2), (0, 1, 2, 3)), ((1, 2), (3, 2, 1, 0))], ids)
+    cell = s.get_cell((1, 2))
+    assert [i for i, _ in cell] == sorted(ids)  # key (byte) order, and plain str -- not "b'...'"
+    assert all(type(i) is str for i, _ in cell)
+    assert cell[0][1].fine == (3, 2, 1, 0) and s.get_nb_indexed() == 2
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------
+gpu = pytest.mark.gpu
+
+
+def _check_searches(searcher, tag, Q, z, ids, by_position=True):
+    for quota, limit in ((20, 10), (500, 50)):
+        key = "%s_q%d_l%d" % (tag, quota, limit)
+        for qi, q in enumerate(Q):
+            res, visited = searcher.search(q, quota=quota, limit=limit, with_dists=True)
+            want = z[key + "_ids"][qi]
+            want = want[want >= 0]
+            assert visited == int(z[key + "_visited"][qi])
+            assert [r.id for r in res] == [ids[p] for p in want]
+            np.testing.assert_allclose([r.dist for r in res], z[key + "_dists"][qi][:len(want)], rtol=1e-9, atol=1e-12)
+
+
+@gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_compute_codes_notparallel_on_pickled_model(as_lopq, tag):
+    """searcher_lopqhbase.py:497-512 line by line, with `lopq` = this package: the codes dict equals the one the
+    reference pickled -- keys, tuple lengths, values and the numpy scalar type predict_cluster picks."""
+    from lopq.utils import compute_codes_notparallel, compute_codes_parallel
+    m = _load("model_%s.pkl" % tag)
+    X, Q, z = _inputs(tag)
+    det_ids = _det_ids(len(X))
+    data = [x for x in X]  # the reference passes a LIST of feature arrays (:485-487)
+    codes = compute_codes_notparallel(data, m)
+    codes_dict = dict()
+    for i, code in enumerate(codes):
+        codes_dict[det_ids[i]] = [code.coarse, code.fine]
+    want = _load("codes_%s.pkl" % tag)
+    assert codes_dict.keys() == want.keys()
+    for k in want:
+        assert codes_dict[k][0] == tuple(want[k][0]) and codes_dict[k][1] == tuple(want[k][1])
+    k = det_ids[5]
+    assert all(type(v) is type(w) for v, w in zip(codes_dict[k][0], want[k][0]))  # np.uint8 coarse ids
+    assert all(type(v) is type(w) for v, w in zip(codes_dict[k][1], want[k][1]))
+    par = list(compute_codes_parallel(data[:100], m, 4))
+    assert par == codes[:100]
+    one = m.predict(X[7])  # the per-vector call compute_partition makes
+    assert one == codes[7] and type(one).__name__ == "LOPQCode"
+
+
+@gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_cold_start_from_pickled_codes_dict(as_lopq, tag):
+    """searcher_lopqhbase.py:655-770 (load_codes): model from the storer, codes dicts from the storer, add_codes_from_dict,
+    then search_from_feats' call `search(feat, quota, limit, with_dists=True)` -- results of the real reference."""
+    from lopq import LOPQSearcher
+    m = _load("model_%s.pkl" % tag)
+    X, Q, z = _inputs(tag)
+    s = LOPQSearcher(m)
+    s.add_codes_from_dict(_load("codes_%s.pkl" % tag))
+    assert s.get_nb_indexed() == int(z["%s_nb_indexed" % tag])
+    _check_searches(s, tag, Q, z, _det_ids(len(X)))
+    res, _ = s.search(Q[0], quota=20, limit=10, with_dists=False)
+    assert res[0]._fields == ("id", "code")
+    code = res[0].code
+    want = _load("codes_%s.pkl" % tag)[res[0].id]
+    assert tuple(code.coarse) == tuple(want[0]) and tuple(code.fine) == tuple(want[1])
+
+
+@gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_add_data_and_add_codes_from_local(as_lopq, tag, tmp_path):
+    from lopq import LOPQSearcher
+    m = _load("model_%s.pkl" % tag)
+    X, Q, z = _inputs(tag)
+    ids = _det_ids(len(X))
+    # insertion order of the expected results = iteration order of the codes dict = det_ids order (py3 dicts)
+    s = LOPQSearcher(m)
+    s.add_data(X, ids=ids, num_procs=4)
+    assert s.get_nb_indexed() == len(X)
+    _check_searches(s, tag, Q, z, ids)
+    # default ids of add_data are positions
+    s2 = LOPQSearcher(m)
+    s2.add_data(X)
+    _check_searches(s2, tag, Q, z, list(range(len(X))))
+    # the text format of add_codes_from_local: "id<TAB>[[c0, c1], [f0, ...]]", one file or Spark part-* files
+    codes = _load("codes_%s.pkl" % tag)
+    d = tmp_path / "rdd"
+    d.mkdir()
+    half = len(ids) // 2
+    for name, part in (("part-00000", ids[:half]), ("part-00001", ids[half:])):
+        with open(str(d / name), "wt") as f:
+            for k in part:
+                f.write("%s\t%s\n" % (k, [[int(v) for v in codes[k][0]], [int(v) for v in codes[k][1]]]))
+    s3 = LOPQSearcher(m)
+    s3.add_codes_from_local(str(d))
+    assert s3.get_nb_indexed() == len(ids)
+    _check_searches(s3, tag, Q, z, ids)
+
+
+@gpu
+def test_lmdb_searcher_string_ids_end_to_end(as_lopq):
+    """id_lambda=str with sha1-like ids through search(): ids come back as the caller's strings, ranking (ties in key
+    order, last write wins) equals the source restatement of the LMDB searcher."""
+    from lopq.search import LOPQSearcherLMDB
+    from oracle import lopq_oracle as O
+    tag = "lopq_pca"
+    m = _load("model_%s.pkl" % tag)
+    X, Q, z = _inputs(tag)
+    codes = _load("codes_%s.pkl" % tag)
+    ids = _det_ids(len(X))
+    s = LOPQSearcherLMDB(m, None, id_lambda=str)
+    s.add_codes_from_dict(codes)
+    s.add_codes([codes[ids[3]]] * 5, ["dup_%d" % i for i in range(5)])  # equal distances: key order decides
+    s.add_codes([codes[ids[10]]], [ids[4]])                              # same cell or not: a put() of an existing key
+    om = O.OracleModel(m.Cs, m.Rs, m.mus, m.subquantizers, m.pca_P, m.pca_mu, m.renorm)
+    oi = O.OracleKeyOrderIndex(om, id_lambda=str)
+    oi.add_codes([codes[k] for k in ids], ids)
+    oi.add_codes([codes[ids[3]]] * 5, ["dup_%d" % i for i in range(5)])
+    oi.add_codes([codes[ids[10]]], [ids[4]])
+    assert s.get_nb_indexed() == oi.nb_indexed
+    for q in list(Q) + [X[3]]:
+        res, visited = s.search(q, quota=200, limit=40, with_dists=True)
+        wres, wvis = oi.search(q, quota=200, limit=40, with_dists=True)
+        assert visited == wvis
+        assert all(type(r.id) is str for r in res)
+        assert [r.id for r in res] == [w[0] for w in wres]
+        np.testing.assert_allclose([r.dist for r in res], [w[2] for w in wres], rtol=1e-9, atol=1e-12)
+
+
+@gpu
+def test_extractor_detector_rows(tmp_path):
+    """generic_extractor.py:236-247: one column per detection, `<extr_str>_<l>_<t>_<r>_<b>_<score>`, value = base64 of the
+    L2-normalised float64 descriptor; an image without detections keeps processed = "0"."""
+    import io
+    from PIL import Image
+    from columbiaimagesearch_amd.extractor.generic_extractor import GenericExtractor
+    from columbiaimagesearch_amd.featurizer.featsio import featB64decode
+    from oracle import dlib_oracle as DO
+    w = DO.synthetic_weights(2)
+    wpath = str(tmp_path / "dlib_w.npz")
+    np.savez(wpath, **w)
+
+    class FakeDetector(object):
+        def detect_from_buffer_noinfos(self, img_buffer, up_sample=1):
+            img = np.asarray(Image.open(io.BytesIO(img_buffer)).convert("RGB"))
+            if img.shape[0] < 200:
+                return img, []
+            return img, [{"left": 10, "top": 20, "right": 160, "bottom": 170, "score": 1.25},
+                         {"left": 40, "top": 30, "right": 190, "bottom": 180, "score": 0.5}]
+
+    def chip_fn(img, bbox):
+        return img[bbox["top"]:bbox["bottom"], bbox["left"]:bbox["right"], :]
+
+    conf = {"DLIBFEAT_pred_path": "unused", "DLIBFEAT_rec_path": wpath}
+    ex = GenericExtractor("dlib", "dlib", "face", "ext", "DLIBFEAT_", conf, detector=FakeDetector())
+    ex.featurizer.chip_fn = chip_fn
+    rs = np.random.RandomState(3)
+    bufs = []
+    for hw in (240, 120):
+        b = io.BytesIO()
+        Image.fromarray(rs.randint(0, 256, size=(hw, 260, 3)).astype(np.uint8)).save(b, format="PNG")
+        bufs.append(b.getvalue())
+    rows = ex.process_batch(bufs + [b"not an image"])
+    base = "ext:dlib_feat_dlib_face"
+    assert sorted(rows[0]) == sorted([base + "_processed", base + "_10_20_160_170_1.25", base + "_40_30_190_180_0.5"])
+    assert rows[0][base + "_processed"] == "1"
+    assert rows[1] == {base + "_processed": "0"}
+    assert rows[2] == {base + "_failed": "1"}
+    img = np.asarray(Image.open(io.BytesIO(bufs[0])).convert("RGB"))
+    chips = np.stack([img[20:170, 10:160], img[30:180, 40:190]])
+    want = DO.forward_torch(chips, w).astype(np.float64)
+    want /= np.linalg.norm(want, axis=1, keepdims=True)
+    for k, ref in zip((base + "_10_20_160_170_1.25", base + "_40_30_190_180_0.5"), want):
+        got = featB64decode(rows[0][k], "dlib")
+        assert got.dtype == np.float64 and got.shape == (128,)
+        np.testing.assert_allclose(got, ref, atol=2e-4)
+    assert ex.process_buffer(bufs[0]) == rows[0]  # the reference's per-image entry point
