@@ -8,18 +8,25 @@
 A "step" = one pass of the search hot path over one batch of 8192 synthetic queries that are
 already resident in HBM: PCA -> coarse ranking -> multisequence plan -> ADC tables -> ADC scan +
 top-k -> merge (-> RCCL all-gather + merge when the index is sharded by coarse cell over N GPUs).
-Workload = BASELINE config C4 (10M x 128-d, LOPQModelPCA V=16, M=8, renorm) with the reference
-API's operating point quota=10000, limit=100 (cufacesearch/searcher/searcher_lopqhbase.py:833-838).
-The data are descriptor-like (anisotropic mixture with a decaying spectrum, codes almost all distinct);
-the LOPQ model is the one the reference itself fitted on this generator (tests/golden/c4.npz).
+Operating point of the reference API: quota=10000, limit=100 (cufacesearch/searcher/searcher_lopqhbase.py:833-838).
 
-N > 1 is strong scaling: the same 10M index is sharded by coarse cell, every rank sees the whole
-query batch, scans its own cells and the per-shard top-`limit` lists are all-gathered over RCCL.
+--config selects the BASELINE.json workload (default c4 = the one the metric is quoted on):
+  c4  10M x 128-d float64, LOPQModelPCA V=16 M=8 renorm (model fitted by the reference: tests/golden/c4.npz);
+      descriptor-like data (anisotropic mixture with a decaying spectrum, codes almost all distinct)
+  c2  the same generator and model at 1M vectors (dlib-descriptor shape)
+  c3  1M x 4096-d float32 >= 0 (post-ReLU-like), LOPQModelPCA 4096 -> 256, V=16 M=16 renorm (model fitted by the
+      reference on this generator: tests/golden/c3full.npz)
 
-Extra objects in the JSON line: "roofline" for the ADC scan kernel (algorithmic bytes =
-candidates x M, time from HIP events recorded on the launch stream inside the library) and
-"cpu_baseline" = the oracle (numpy restatement of the reference, reference-shaped per-candidate
-loop, 1 core) timed on this host on a bounded sample of the same queries, rank 0 at N=1 only.
+N > 1 is strong scaling by default: the same index is sharded by coarse cell, every rank sees the whole
+query batch, scans its own cells and the per-shard top-`limit` lists are all-gathered over RCCL
+(--scaling weak: every rank brings its own --n vectors, the index grows with N).
+
+Extra objects in the JSON line: "roofline" for the ADC scan kernel (algorithmic bytes = candidates x M, time from
+HIP events recorded on the launch stream inside the library); "cpu_baseline" = the oracle (numpy restatement of the
+reference) timed on this host on bounded samples of the same workload, rank 0 at N=1 only: `value` is the
+reference-shaped per-candidate loop on 1 core, the other fields are the all-core vectorised search, encode
+(1 core loop / all cores) and the torch-CPU DeepSentibank forward (batch 1 x cores, batch 256); "cnn" / "dlib" =
+the descriptor networks (MFMA roofline); "pcie_inclusive" = the same step through the host-pointer entry point.
 """
 import argparse
 import json
@@ -38,11 +45,18 @@ NQ = 8192          # queries per step
 QUOTA, LIMIT = 10000, 100
 N_CHUNKS = 80      # the database is generated in 80 equal chunks with per-chunk seeds
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+F32_MFMA_PEAK_TFLOPS = 157.3
+
+CONFIGS = {
+    "c4": {"n": 10_000_000, "fixture": "c4", "gen": "descriptor", "d_in": 128, "label": "C4"},
+    "c2": {"n": 1_000_000, "fixture": "c4", "gen": "descriptor", "d_in": 128, "label": "C2"},
+    "c3": {"n": 1_000_000, "fixture": "c3full", "gen": "relu_mixture", "d_in": 4096, "label": "C3"},
+}
 
 
-def load_model():
+def load_model(fixture):
     from columbiaimagesearch_amd.lopq import LOPQModelPCA
-    z = np.load(os.path.join(REPO, "tests", "golden", "c4.npz"))
+    z = np.load(os.path.join(REPO, "tests", "golden", fixture + ".npz"))
     nf = int(z["num_fine_splits"])
     subs = tuple([z["subs"][s, j] for j in range(nf)] for s in range(2))
     params = ((z["Cs"][0], z["Cs"][1]), (z["Rs"][0], z["Rs"][1]), (z["mus"][0], z["mus"][1]), subs,
@@ -50,21 +64,29 @@ def load_model():
     return LOPQModelPCA(renorm=bool(z["renorm"]), parameters=params), z
 
 
-def mixture_centers(device="cpu"):
-    """Parameters of the descriptor-like generator (tests/golden_inputs.descriptor_params: the distribution the
-    reference fitted tests/golden/c4.npz on), as tensors on `device`."""
+def mixture_centers(gen, device="cpu"):
+    """Parameters of the synthetic generators, as tensors on `device`: "descriptor" = tests/golden_inputs.descriptor_params
+    (the distribution the reference fitted tests/golden/c4.npz on); "relu_mixture" = golden_inputs.gmm_unit(.., 4096, 64,
+    seed 6, nonneg) whose 64 centres the reference fitted tests/golden/c3full.npz on."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import golden_inputs as gi
+    if gen == "relu_mixture":
+        centers = np.random.RandomState(6).randn(64, 4096)
+        return {"gen": gen, "centers": torch.as_tensor(centers, device=device, dtype=torch.float32)}
     basis, scale, centers, mean = gi.descriptor_params(128)
-    return {"noise_map": torch.as_tensor(scale[:, None] * basis.T, device=device),  # z -> (z * scale) . basis^T
+    return {"gen": gen, "noise_map": torch.as_tensor(scale[:, None] * basis.T, device=device),  # z -> (z * scale) . basis^T
             "centers": torch.as_tensor(centers, device=device), "mean": torch.as_tensor(mean, device=device)}
 
 
 def gen_chunk(P, chunk, n, device):
-    """n unit-norm float64 128-d vectors of chunk `chunk` (identical on every rank)."""
+    """n unit-norm vectors of chunk `chunk` (identical on every rank): float64 128-d, or float32 4096-d >= 0."""
     g = torch.Generator(device=device)
     g.manual_seed(1000 + chunk)
     comp = torch.randint(0, P["centers"].shape[0], (n,), generator=g, device=device)
+    if P["gen"] == "relu_mixture":
+        x = torch.randn((n, P["centers"].shape[1]), generator=g, device=device, dtype=torch.float32)
+        x = torch.clamp_(x.mul_(0.35).add_(P["centers"][comp]), min=0.0)
+        return x.div_(x.norm(dim=1, keepdim=True).clamp_(min=1e-12))
     z = torch.randn((n, P["centers"].shape[1]), generator=g, device=device, dtype=torch.float64)
     x = P["mean"] + 0.7 * P["centers"][comp] + 0.7 * (z @ P["noise_map"])
     return x / x.norm(dim=1, keepdim=True)
@@ -75,17 +97,24 @@ def make_queries(x0, batch, nq, device):
     g = torch.Generator(device=device)
     g.manual_seed(77000 + batch)
     idx = torch.randint(0, x0.shape[0], (nq,), generator=g, device=device)
-    q = x0[idx] + 0.05 * torch.randn((nq, x0.shape[1]), generator=g, device=device, dtype=torch.float64) / np.sqrt(x0.shape[1])
+    q = x0[idx] + 0.05 * torch.randn((nq, x0.shape[1]), generator=g, device=device, dtype=x0.dtype) / np.sqrt(x0.shape[1])
     return (q / q.norm(dim=1, keepdim=True)).contiguous()
 
 
-def exact_nn(queries, centers_dev, n_total, chunk_n, device):
-    """True nearest neighbour ids (exact L2 on the unit sphere = max dot), streamed over chunks."""
+def exact_nn(queries, centers_dev, n_total, chunk_n, device, pca=None):
+    """True nearest neighbour ids in the space LOPQ works in (lopq/lopq/eval.py:92-143): exact L2 between unit vectors
+    = max dot, streamed over chunks; `pca` = (mu, P) float32 tensors applies (x - mu) . P + renormalisation first."""
+    def space(x):
+        x = x.float()
+        if pca is not None:
+            x = (x - pca[0]) @ pca[1]
+            x = x / x.norm(dim=1, keepdim=True)
+        return x
     best = torch.full((queries.shape[0],), -2.0, device=device, dtype=torch.float32)
     arg = torch.zeros(queries.shape[0], dtype=torch.int64, device=device)
-    qf = queries.float()
+    qf = space(queries)
     for c in range(n_total // chunk_n):
-        x = gen_chunk(centers_dev, c, chunk_n, device).float()
+        x = space(gen_chunk(centers_dev, c, chunk_n, device))
         s = qf @ x.t()
         v, i = s.max(dim=1)
         upd = v > best
@@ -99,10 +128,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=int(os.environ.get("CIS_BENCH_N", 10_000_000)))
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=os.environ.get("CIS_BENCH_CONFIG", "c4"))
+    ap.add_argument("--n", type=int, default=int(os.environ.get("CIS_BENCH_N", 0)), help="index vectors (default: the config's)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cnn", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-pointer leg (profiling runs)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.n <= 0:
+        args.n = cfg["n"]
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -130,10 +165,11 @@ def main():
         else:
             dist.init_process_group(backend, device_id=device if backend == "nccl" else None)  # nccl == RCCL on ROCm
 
-    model, z = load_model()
-    N = args.n - args.n % (N_CHUNKS * world)
+    model, z = load_model(cfg["fixture"])
+    N = args.n * (world if args.scaling == "weak" else 1)
+    N -= N % (N_CHUNKS * world)
     chunk_n = N // N_CHUNKS
-    centers = mixture_centers(device)
+    centers = mixture_centers(cfg["gen"], device)
 
     # ---- build: data-parallel encode on the GPUs, codes all-gathered, index sharded by cell -----
     t_build = time.time()
@@ -224,20 +260,40 @@ def main():
     qr = qbatches[0][:1024].contiguous()
     res = step(qr)
     if rank == 0:
-        nn = exact_nn(qr, centers, N, chunk_n, device)
+        pca = None
+        if cfg["gen"] == "relu_mixture":  # the 4096 -> 256 PCA changes the metric: neighbours are defined after it
+            pca = (torch.as_tensor(z["pca_mu"], device=device, dtype=torch.float32),
+                   torch.as_tensor(z["pca_P"], device=device, dtype=torch.float32))
+        nn = exact_nn(qr, centers, N, chunk_n, device, pca)
         recall10 = float((res["ids"][:, :10] == nn[:, None]).any(dim=1).float().mean().item())
 
-    # ---- CPU baseline + parity spot check: oracle on a bounded sample (rank 0, N=1) ------------
+    # ---- the same step through the host-pointer entry point (PCIe in and out), untimed for `value` ----------
+    pcie = None
+    if rank == 0 and world == 1 and not args.no_pcie:
+        qh_all = qbatches[0].cpu().numpy()
+        searcher.search_batch(qh_all, quota=QUOTA, limit=LIMIT)
+        tp = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            searcher.search_batch(qh_all, quota=QUOTA, limit=LIMIT)
+        dtp = (time.perf_counter() - tp) / reps
+        pcie = {"value": NQ / dtp, "unit": "queries/s", "ms_per_step": dtp * 1e3,
+                "note": "cis_index_search: host query matrix in, host ids/dists/counts out, pageable memory"}
+
+    # ---- CPU baseline + parity spot check: oracle on bounded samples (rank 0, N=1) ----------------
     cpu = None
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import shutil
+        import tempfile
+        from oracle import cpu_bench
         from oracle import lopq_oracle as O
         om = O.OracleModel.from_npz(z)
         oix = O.OracleCSRIndex(om, coarse_h, fine_h)
         qh = qr.cpu().numpy()
         gi, gd = res["ids"].cpu().numpy(), res["dists"].cpu().numpy()
         n_loop, t_loop, ok, max_rel = 0, 0.0, True, 0.0
-        while t_loop < 12.0 and n_loop < 256:
+        while t_loop < 10.0 and n_loop < 256:
             tq = time.perf_counter()
             ids, dd, _ = oix.search_loop(qh[n_loop], quota=QUOTA, limit=LIMIT)
             t_loop += time.perf_counter() - tq
@@ -245,57 +301,106 @@ def main():
             max_rel = max(max_rel, float(np.max(np.abs(gd[n_loop, :len(ids)] - dd) / np.maximum(dd, 1e-300))))
             n_loop += 1
         n_vec, t_vec = 0, 0.0
-        while t_vec < 5.0 and n_vec < 1024:
+        while t_vec < 4.0 and n_vec < 1024:
             tq = time.perf_counter()
             ids, dd, _ = oix.search(qh[n_vec], quota=QUOTA, limit=LIMIT)
             t_vec += time.perf_counter() - tq
             ok = ok and bool((gi[n_vec, :len(ids)] == ids).all())
             n_vec += 1
+        cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+        # encode, reference-shaped per-vector loop (lopq/lopq/utils.py:203-218), 1 core
+        enc_x = gen_chunk(centers, 1, 8192, device).cpu().numpy()
+        n_el, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 4.0 and n_el < len(enc_x):
+            O.compute_codes_loop(om, enc_x[n_el:n_el + 16])
+            n_el += 16
+        enc_loop = n_el / (time.perf_counter() - t0)
+        # all cores: one single-threaded worker per core (the reference deploys N single-threaded processes)
+        workdir = tempfile.mkdtemp(prefix="cis_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            cpu_bench.export_index(workdir, oix, qh, os.path.join(REPO, "tests", "golden", cfg["fixture"] + ".npz"), enc_x)
+            srch_all, n_sa, _ = cpu_bench.run_pool("search", workdir, 6.0, cores)
+            enc_all, n_ea, _ = cpu_bench.run_pool("encode", workdir, 4.0, cores)
+            cnn1_all, n_c1, _ = (None, 0, 0) if args.no_cnn else cpu_bench.run_pool("cnn1", workdir, 5.0, cores)
+        finally:
+            shutil.rmtree(workdir, ignore_errors=True)
+        cnn256 = None
+        if not args.no_cnn:
+            from oracle import cnn_oracle as C
+            wts = C.synthetic_weights(0)
+            xi = C.synthetic_images(256, seed=2)
+            torch.set_num_threads(cores)
+            C.forward_torch(xi[:32], wts)
+            t0 = time.perf_counter()
+            C.forward_torch(xi, wts)
+            cnn256 = 256 / (time.perf_counter() - t0)
         cpu = {"value": n_loop / t_loop, "unit": "queries/s", "cores": 1, "kind": "port",
-               "sample": "%d queries of the timed workload (quota=%d, limit=%d, 10M index) through the oracle's "
-                         "reference-shaped per-candidate loop (search.py:166-175); vectorised numpy restatement: "
-                         "%.1f queries/s on %d queries" % (n_loop, QUOTA, LIMIT, n_vec / t_vec, n_vec)}
+               "sample": "%d queries of the timed workload (quota=%d, limit=%d, %d-vector index) through the oracle's "
+                         "reference-shaped per-candidate loop (search.py:166-175)" % (n_loop, QUOTA, LIMIT, N),
+               "search_vectorised_1core_qps": n_vec / t_vec,
+               "search_vectorised_allcore_qps": srch_all, "allcore_workers": cores,
+               "encode_loop_1core_vps": enc_loop, "encode_vectorised_allcore_vps": enc_all,
+               "cnn_torch_cpu_batch1_x_cores_ips": cnn1_all, "cnn_torch_cpu_batch256_ips": cnn256,
+               "samples": "vectorised search: %d queries on 1 core, %d queries over %d single-threaded workers (6 s); encode: %d "
+                          "vectors per-vector loop on 1 core, %d vectors over the workers (4 s); DeepSentibank torch-CPU: %d "
+                          "images batch 1 over the workers (5 s), one batch of 256 on %d threads"
+                          % (n_vec, n_sa, cores, n_el, n_ea, n_c1, cores)}
         parity = {"queries_checked": max(n_loop, n_vec), "ids_bit_exact": ok, "max_rel_dist_err": max_rel}
 
-    # ---- second half of the BASELINE metric: CNN descriptors/s (DeepSentibank forward, batch 256) -------
+    # ---- second half of the BASELINE metric: CNN descriptors/s (batch 256, synthetic weights) ------------
     cnn = None
+    dlib = None
     if rank == 0 and not args.no_cnn:
-        from columbiaimagesearch_amd.featurizer.synthetic import sentibank_weights as synthetic_weights  # seeded (trained weights are not in the tree)
-        from columbiaimagesearch_amd.featurizer import SentiBankNet
+        from columbiaimagesearch_amd.featurizer.synthetic import dlib_weights, sentibank_weights  # seeded (trained weights are not in the tree)
+        from columbiaimagesearch_amd.featurizer import DLibFaceNet, SentiBankNet
         del x0
         torch.cuda.empty_cache()
-        net = SentiBankNet(synthetic_weights(0))
         B = 256
         gcn = torch.Generator(device=device)
         gcn.manual_seed(5)
+
+        def time_net(net, xb, ob, reps=8):
+            for _ in range(2):
+                net.forward_dev(xb, ob)
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            for _ in range(reps):
+                net.forward_dev(xb, ob)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - tc) / reps
+
+        net = SentiBankNet(sentibank_weights(0))
         xb = (torch.randn((B, 3, 227, 227), generator=gcn, device=device) * 50.0).contiguous()
-        ob = torch.empty((B, 4096), device=device)
-        for _ in range(2):
-            net.forward_dev(xb, ob)
-        torch.cuda.synchronize()
-        tc = time.perf_counter()
-        reps = 8
-        for _ in range(reps):
-            net.forward_dev(xb, ob)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - tc) / reps
+        dt = time_net(net, xb, torch.empty((B, 4096), device=device))
         flop = 2.0 * 720310816 * B
         cnn = {"metric": "CNN descriptors/sec (DeepSentibank forward to fc7, batch 256, synthetic weights)",
                "value": B / dt, "unit": "descriptors/s", "ms_per_batch": dt * 1e3, "dtype": "f32",
-               "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                            "frac": flop / dt / 157.3e12, "flop_per_image": 2 * 720310816}}
+               "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": flop / dt / (F32_MFMA_PEAK_TFLOPS * 1e12), "flop_per_image": 2 * 720310816}}
+        net.close()
+        del xb
+        net = DLibFaceNet(dlib_weights(0))
+        xb = (torch.rand((B, 150, 150, 3), generator=gcn, device=device) * 255).contiguous()
+        dt = time_net(net, xb, torch.empty((B, 128), device=device))
+        flop = 2.0 * 270854144 * B  # multiply-accumulates per face: oracle/dlib_oracle.py:mac_per_face
+        dlib = {"metric": "CNN descriptors/sec (dlib face ResNet forward, batch 256 aligned chips, synthetic weights)",
+                "value": B / dt, "unit": "descriptors/s", "ms_per_batch": dt * 1e3, "dtype": "f32",
+                "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": flop / dt / (F32_MFMA_PEAK_TFLOPS * 1e12), "flop_per_image": 2 * 270854144}}
         net.close()
 
     if rank == 0:
         M = model.M
         launches = max(prof["scan_launches"], 1)
-        scan_s = prof["scan_kernel_ms"] / 1e3  # HIP events right around the k_adc_scan2 launches, on their stream
+        scan_s = prof["scan_kernel_ms"] / 1e3  # HIP events right around the scan kernel launches, on their stream
         algo_bytes = cand * M  # this rank's scan kernel
         achieved = algo_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "scan_traffic.json")
-        if os.path.exists(tpath):
+        # HBM traffic comes from rocprofv3 --pmc passes of this command (tools/gpu_round_profile.sh), not from this run
+        traffic, traffic_src = None, None
+        tpath = os.path.join(REPO, "profiles", "scan_traffic_%s.json" % args.config)
+        if os.path.exists(tpath) and world == 1:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic_src = "from_profile: profiles/scan_traffic_%s.json (separate rocprofv3 --pmc passes of this command)" % args.config
         line = {
             "metric": "queries/sec @ recall@10 on 10M LOPQ index",
             "value": NQ * args.steps / elapsed,
@@ -305,25 +410,32 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "recall_at_10": recall10,
-            "config": {"workload": "C4: %d x 128-d float64 unit vectors (descriptor-like anisotropic mixture), LOPQModelPCA V=16 M=8 "
-                                   "renorm, %d queries/step, quota=%d limit=%d" % (N, NQ, QUOTA, LIMIT),
-                       "index_vectors": N, "queries_per_step": NQ, "quota": QUOTA, "limit": LIMIT,
+            "config": {"workload": "%s: %d x %d-d %s unit vectors (%s), LOPQModelPCA %d -> %d V=%d M=%d renorm (fitted by the "
+                                   "reference, tests/golden/%s.npz), %d queries/step, quota=%d limit=%d"
+                                   % (cfg["label"], N, cfg["d_in"], "float32 >= 0" if cfg["gen"] == "relu_mixture" else "float64",
+                                      "post-ReLU-like 64-component mixture" if cfg["gen"] == "relu_mixture" else "descriptor-like anisotropic mixture",
+                                      cfg["d_in"], model.dim, model.V, M, cfg["fixture"], NQ, QUOTA, LIMIT),
+                       "name": args.config, "index_vectors": N, "queries_per_step": NQ, "quota": QUOTA, "limit": LIMIT,
                        "sharding": "by coarse cell over %d GPU(s)%s" % (world, ", RCCL all-gather merge" if world > 1 else ""),
                        "candidates_per_query": cand_all / float(NQ * args.steps)},
             "roofline": {"bound": "hbm", "kernel": "k_adc_scan2", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes / launches,
                          "avg_launch_ms": prof["scan_kernel_ms"] / launches, "launches": launches},
             "stage_ms_per_step": {k: stage_prof[k] / n_stage for k in ("front_ms", "tables_ms", "scan_ms", "merge_ms", "scan_kernel_ms")},
+            "encode": {"value": len(my_chunks) * chunk_n / encode_s, "unit": "vectors/s", "vectors": len(my_chunks) * chunk_n,
+                       "note": "cis_encode_dev on this rank's share of the index build, HIP events around the encode calls"},
+            "pcie_inclusive": pcie,
             "cnn": cnn,
+            "dlib": dlib,
             "cpu_baseline": cpu,
             "parity": parity,
-            "build": {"encode_s": encode_s, "total_s": build_s, "encode_vectors_per_s": len(my_chunks) * chunk_n / encode_s},
+            "build": {"encode_s": encode_s, "total_s": build_s},
         }
     if use_dist:
         dist.barrier()

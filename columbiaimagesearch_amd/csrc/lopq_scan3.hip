@@ -1,0 +1,828 @@
+// ADC scan v3: 16-bit fixed-point tables, four queries per workgroup, 4-byte region entries.
+//
+// Replaces the inner loop of lopq/lopq/search.py:137-177 (compute_distances: dist = sum_i T[i][fine_i]) for large
+// query batches.  Same division of labour as the float32-prefilter kernel (k_adc_scan2, lopq_search.hip): the scan
+// only REJECTS candidates that are provably outside the exact top `limit`; k_merge_survivors re-scores the survivors
+// in float64 in the reference's order and ranks them by (dist, visit_rank, pos).  What changes is the arithmetic of
+// the prefilter, because k_adc_scan2 is bound by LDS reads and VALU issue, not by HBM (profiles/r01i_*):
+//
+//  * The two half tables of a (query, cell) pair are quantised when they are staged in LDS:
+//        q[j][k] = trunc(T32[j][k] * qinv),   qinv = cap / max(T32) * (1 - 2^-20),  cap = floor(65535 / M)
+//    so that a candidate's sum s = sum_j q[j][code_j] fits 16 bits and brackets the exact float64 distance d:
+//        s <= d * qinv * (1 + 2^-23)        and        d * qinv < (s + M) * (1 + 2^-22).
+//    Integer sums have no accumulation error, so the bracket is tighter than float16 and costs half the LDS bytes
+//    and half the adds of float32: entry (k, j) holds the values of FOUR queries in 8 bytes (tab[k][j][g] uint16),
+//    one ds_read_b64 serves four queries and two v_pk_add_u16 add them.
+//  * Every bound that leaves a wave is an exact-distance upper bound in float64 bits, as in k_adc_scan2 (wt/wl per
+//    wave, `ext` from other cells of the query via qbound[]): "at least `limit` candidates seen so far do not exceed
+//    it".  A bound B becomes the integer threshold thr = floor(B * qinv * (1 + 2^-22)) + 1; s > thr implies
+//    d >= s / (qinv (1 + 2^-23)) > B: strictly worse than `limit` others.  A quantised value v that >= n entries do
+//    not exceed becomes the published bound (v + M) * (1 + 2^-21) / qinv >= their exact distances.
+//  * Region entries are (s << 16 | position in the chunk): 4 bytes, ordered by (s, pos) as integers; chunks are at
+//    most 65536 candidates.  Four queries x four waves x 312 entries = 20 KB next to 16 KB of tables (M = 8): four
+//    workgroups per CU at G = 4, which the float32 layout could not reach (72 KB).
+//  * Crowds of equal sums (duplicate codes: the integer cut cannot thin them) fall back to the exact compaction:
+//    codes fetched again, float64 distances summed left to right (search.py:173), cut on (dist, pos), one code of
+//    the tie group remembered so that its later copies are skipped in the hot loop -- as in k_adc_scan2.
+//
+// Survivors leave as (float(s) << 32 | pos) 8-byte pairs, the format k_merge_survivors reads; their high words are
+// only ordered inside one work item (each item has its own scale), so the merge re-scores all of them (cut = 0).
+#include "scan_common.h"
+
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+
+static __device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) + __builtin_bit_cast(u16x2_t, b)));
+}
+// per 16-bit half: max(a - b, 0)
+static __device__ __forceinline__ uint32_t pk_subsat_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
+
+static const int S3G = 4;  // queries per workgroup
+
+#ifdef CIS_S3_COUNTERS
+__device__ unsigned long long g_s3_ctr[16];  // cycle counters of wave 0 of every workgroup (tools/debug_counters3.py)
+#define S3_CLK() ((long long)__builtin_amdgcn_s_memtime())
+#define S3_CTR(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_s3_ctr[i], (unsigned long long)(v)); } while (0)
+extern "C" int cis_debug_counters3(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s3_ctr), 16 * sizeof(unsigned long long)) != hipSuccess) return -2;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_s3_ctr), z, sizeof(z)) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#else
+#define S3_CLK() 0ll
+#define S3_CTR(i, v) do { } while (0)
+#endif
+
+struct Scan3Shared {  // one per query handled by the workgroup
+    uint64_t wt[8];   // per wave: exact-distance bound (float64 bits) that >= ceil(limit/NW) of its candidates do not exceed
+    uint64_t wl[8];   // per wave: ... that >= limit of its candidates do not exceed
+    uint64_t ext;     // bound published by workgroups that scanned OTHER cells/chunks of the query (qbound[q] at start)
+    double inv_up;    // qinv * (1 + 2^-22): exact bound -> integer threshold
+    double ub;        // (1 + 2^-21) / qinv: quantised value (+ M) -> exact-distance upper bound
+    uint32_t thr;     // the hot loop's integer threshold (refreshed at every compaction; a lost concurrent update only
+                      // leaves it looser for a while)
+    int wcnt[8];      // survivors per wave at the end
+    int pad;
+};
+
+static __device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+static __device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int NW>
+static __device__ __forceinline__ uint64_t block_bound3(const Scan3Shared* sh) {
+    uint64_t t = lds_ld(&sh->wt[0]);
+    uint64_t l = lds_ld(&sh->wl[0]);
+#pragma unroll
+    for (int i = 1; i < NW; ++i) {
+        const uint64_t a = lds_ld(&sh->wt[i]), b = lds_ld(&sh->wl[i]);
+        t = a > t ? a : t;
+        l = b < l ? b : l;
+    }
+    const uint64_t e = lds_ld(&sh->ext);
+    l = e < l ? e : l;
+    return t < l ? t : l;
+}
+
+struct QScale { double inv_up, ub; };  // a query's scales (Scan3Shared), read where a compaction needs them
+static __device__ __forceinline__ QScale load_scale(const Scan3Shared* sh) {
+    QScale q;
+    q.inv_up = sh->inv_up;
+    q.ub = sh->ub;
+    return q;
+}
+
+static __device__ __forceinline__ uint32_t bound_to_thr(uint64_t bound_bits, double inv_up) {
+    if (bound_bits >= 0x7ff0000000000000ull) return 65534u;
+    const double x = __longlong_as_double((long long)bound_bits) * inv_up;
+    return x >= 65533.0 ? 65534u : (uint32_t)x + 1u;
+}
+static __device__ __forceinline__ uint64_t val_to_bound(uint32_t v, int M, double ub) {
+    return (uint64_t)__double_as_longlong((double)(v + (uint32_t)M) * ub);  // ub carries the inflation (1 + 2^-21)
+}
+
+// In-loop compaction on the 16-bit sums only (wave-synchronous, nothing leaves the CU): see wave_compact_approx of
+// k_adc_scan2 -- same two steps, integer margins.  Returns the new count, or -1 when a crowd of equal sums keeps
+// more than `cap` entries (resolve exactly).
+template <int M, int NR, int NW>
+__device__ __forceinline__ int wave_compact3(uint32_t* rk, int cnt, int L, int Lw, int cap, const QScale& qs, Scan3Shared* sh, int w) {
+    const int lane = threadIdx.x & 63;
+    uint32_t ent[NR], s[NR];
+    bool keep[NR];
+    uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int e = r * 64 + lane;
+        keep[r] = e < cnt;
+        ent[r] = keep[r] ? rk[e] : 0xffffffffu;
+        s[r] = ent[r] >> 16;
+        mn = (keep[r] && s[r] < mn) ? s[r] : mn;
+        mx = (keep[r] && s[r] > mx) ? s[r] : mx;
+    }
+    wave_minmax_step<1>(mn, mx); wave_minmax_step<2>(mn, mx); wave_minmax_step<4>(mn, mx);
+    wave_minmax_step<8>(mn, mx); wave_minmax_step<16>(mn, mx); wave_minmax_step<32>(mn, mx);
+    mn = (uint32_t)__builtin_amdgcn_readfirstlane((int)mn);
+    mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
+    const uint64_t INF64 = 0x7ff0000000000000ull;
+    // (1) v2 with #{s <= v2} in [Lw, Lw + W2] -> this wave's share of the block bound
+    const int W2 = Lw >= 16 ? (Lw >> 3) : 1;
+    uint32_t lo2 = mn, v2 = mx;
+    while (cnt >= Lw && lo2 < v2) {  // wave-uniform
+        const uint32_t p = lo2 + ((v2 - lo2) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) c += __popcll(__ballot(keep[r] && s[r] <= p));
+        if (c >= Lw) {
+            v2 = p;
+            if (c <= Lw + W2) break;
+        } else {
+            lo2 = p + 1;
+        }
+    }
+    const uint64_t boundW = cnt >= Lw ? val_to_bound(v2, M, qs.ub) : INF64;
+    if (lane == 0) {
+        if (boundW < lds_ld(&sh->wt[w])) lds_st(&sh->wt[w], boundW);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint32_t thr = bound_to_thr(block_bound3<NW>(sh), qs.inv_up);
+    uint32_t cut = thr;
+    int c_thr = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) c_thr += __popcll(__ballot(keep[r] && s[r] <= cut));
+    int W = cap - L;
+    W = W > 24 ? 24 : (W < 0 ? 0 : W);
+    if (c_thr > L + W) {
+        // (2) the block bound does not thin this wave out: cut to the wave's own top L.  v with #{s <= v} in [L, L+W],
+        // or the L-th smallest sum when ties prevent that; everything up to v + M stays (an entry above that is
+        // strictly worse, in exact arithmetic, than the L entries that do not exceed v).
+        uint32_t lo_ = mn, v = mx;
+        while (lo_ < v) {
+            const uint32_t p = lo_ + ((v - lo_) >> 1);
+            int c = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) c += __popcll(__ballot(keep[r] && s[r] <= p));
+            if (c >= L) {
+                v = p;
+                if (c <= L + W) break;
+            } else {
+                lo_ = p + 1;
+            }
+        }
+        const uint32_t vm = v + (uint32_t)M;
+        int c_keep = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) c_keep += __popcll(__ballot(keep[r] && s[r] <= vm));
+        if (c_keep > cap) return -1;  // a crowd of (nearly) equal sums, e.g. duplicate codes: resolve exactly
+        const uint64_t boundL = val_to_bound(v, M, qs.ub);
+        if (lane == 0) {
+            if (boundL < lds_ld(&sh->wl[w])) lds_st(&sh->wl[w], boundL);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        thr = bound_to_thr(block_bound3<NW>(sh), qs.inv_up);
+        cut = vm < thr ? vm : thr;
+    }
+    if (lane == 0) {
+        if (thr < lds_ld(&sh->thr)) lds_st(&sh->thr, thr);
+    }
+    int ncnt = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const bool kp = keep[r] && s[r] <= cut;
+        const unsigned long long m = __ballot(kp);
+        const int idx = ncnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (kp) rk[idx] = ent[r];
+        ncnt += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return ncnt;
+}
+
+// Exact compaction (crowds of equal sums): every entry is re-scored in float64 -- code from the index, table entries
+// from global memory summed left to right (search.py:173) -- the cut is exact on (dist, pos), ties by region order
+// (= position order: appends are in increasing position and the compactions are stable).  Survivors keep their
+// 16-bit sums.  Returns the new count (<= L).  dup_pos: a member of a tie group the cut went through (its later
+// copies lose against all L entries kept here), or 0xffffffff.
+template <int M, int NR, int NW>
+__device__ __forceinline__ int wave_compact3_exact(uint32_t* rk, int cnt, int L, int Lw, const QScale& qs, Scan3Shared* sh, int w,
+                                                   const uint8_t* __restrict__ codes, int64_t start, int K,
+                                                   const double* __restrict__ t0, const double* __restrict__ t1, uint32_t& dup_pos) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t INF64 = 0x7ff0000000000000ull;
+    uint32_t hi[NR], lo[NR], ent[NR];
+    bool keep[NR];
+    uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int e = r * 64 + lane;
+        keep[r] = e < cnt;
+        ent[r] = keep[r] ? rk[e] : 0xffffffffu;
+        hi[r] = 0xffffffffu;
+        lo[r] = 0xffffffffu;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        if (r * 64 >= cnt) break;  // wave-uniform
+        const CodeWords<M> cw = load_code<M>(codes, start + (keep[r] ? (ent[r] & 0xffffu) : 0u));
+        const uint64_t k = keep[r] ? (uint64_t)__double_as_longlong(adc64_words<M>(cw.w, K, t0, t1)) : ~0ull;
+        hi[r] = (uint32_t)(k >> 32);
+        lo[r] = (uint32_t)k;
+        mn = (keep[r] && hi[r] < mn) ? hi[r] : mn;
+        mx = (keep[r] && hi[r] > mx) ? hi[r] : mx;
+    }
+    wave_minmax_step<1>(mn, mx); wave_minmax_step<2>(mn, mx); wave_minmax_step<4>(mn, mx);
+    wave_minmax_step<8>(mn, mx); wave_minmax_step<16>(mn, mx); wave_minmax_step<32>(mn, mx);
+    mn = (uint32_t)__builtin_amdgcn_readfirstlane((int)mn);
+    mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
+    uint32_t vhiL = mx;
+    uint64_t boundL = INF64;
+    if (cnt >= L) {  // cut to this wave's own exact top-L
+        const uint32_t vhi = wave_kth_bisect<NR>(hi, keep, mn, mx, L);
+        vhiL = vhi;
+        boundL = hi_to_bound(vhi);
+        int c_less = 0, g = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            c_less += __popcll(__ballot(keep[r] && hi[r] < vhi));
+            g += __popcll(__ballot(keep[r] && hi[r] == vhi));
+        }
+        int need = L - c_less;  // members of the group {hi == vhi} to keep, 1 <= need <= g
+        if (need >= g) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) keep[r] = keep[r] && hi[r] <= vhi;
+        } else {
+            uint32_t lo_first = 0;
+            bool found = false, uniform = true;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const bool in_g = keep[r] && hi[r] == vhi;
+                const unsigned long long m = __ballot(in_g);
+                if (!found && m) {
+                    lo_first = (uint32_t)__builtin_amdgcn_readlane((int)lo[r], __ffsll((long long)m) - 1);
+                    found = true;
+                }
+                if (found) uniform = uniform && (__ballot(in_g && lo[r] != lo_first) == 0ull);
+            }
+            uint32_t vlo = lo_first;
+            if (!uniform) {
+                uint32_t t2[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) t2[r] = (keep[r] && hi[r] == vhi) ? lo[r] : 0xffffffffu;
+                wave_bitonic_sort<NR>(t2);
+                vlo = wave_kth<NR>(t2, need - 1);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) need -= __popcll(__ballot(keep[r] && hi[r] == vhi && lo[r] < vlo));
+            }
+            int seen = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const bool tie = keep[r] && hi[r] == vhi && lo[r] == vlo;
+                const unsigned long long m = __ballot(tie);
+                const int rank = seen + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                keep[r] = keep[r] && (hi[r] < vhi || (hi[r] == vhi && (lo[r] < vlo || (tie && rank < need))));
+                if (seen == 0 && m) dup_pos = (uint32_t)__builtin_amdgcn_readlane((int)(ent[r] & 0xffffu), __ffsll((long long)m) - 1);
+                seen += __popcll(m);
+            }
+        }
+    }
+    const uint64_t boundW = (cnt >= Lw) ? hi_to_bound(wave_kth_bisect<NR>(hi, keep, mn, vhiL, Lw)) : INF64;
+    if (lane == 0) {
+        if (boundW < lds_ld(&sh->wt[w])) lds_st(&sh->wt[w], boundW);
+        if (boundL < lds_ld(&sh->wl[w])) lds_st(&sh->wl[w], boundL);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const uint64_t bound = block_bound3<NW>(sh);
+    if (lane == 0) {
+        const uint32_t thr = bound_to_thr(bound, qs.inv_up);
+        if (thr < lds_ld(&sh->thr)) lds_st(&sh->thr, thr);
+    }
+    int ncnt = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const uint64_t k = ((uint64_t)hi[r] << 32) | lo[r];
+        const bool kp = keep[r] && (k <= bound);
+        const unsigned long long m = __ballot(kp);
+        const int idx = ncnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (kp) rk[idx] = ent[r];
+        ncnt += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return ncnt;
+}
+
+// Drop entries above the block bound (hot loop's test).  Stable.
+template <int NR, int NW>
+__device__ __forceinline__ int wave_filter3(uint32_t* rk, int cnt, const QScale& qs, const Scan3Shared* sh) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t thr = bound_to_thr(block_bound3<NW>(sh), qs.inv_up);
+    uint32_t k[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int e = r * 64 + lane;
+        k[r] = e < cnt ? rk[e] : 0xffffffffu;
+    }
+    int ncnt = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const bool kp = (r * 64 + lane < cnt) && ((k[r] >> 16) <= thr);
+        const unsigned long long m = __ballot(kp);
+        const int idx = ncnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (kp) rk[idx] = k[r];
+        ncnt += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return ncnt;
+}
+
+// table reads of one candidate for the four queries: M x ds_read_b64, lane-rotated sub-quantizer order (make_rot)
+template <int M>
+__device__ __forceinline__ void adc16_issue(const CodeWords<M>& c, const char* __restrict__ tab, const RotConsts<M>& rc, u32x2_t (&f)[M]) {
+    constexpr int SH = ((M == 4) ? 2 : (M == 8 ? 3 : 4)) + 3;  // log2(M * 8 bytes): one k-row of the table
+    uint32_t D[(M + 3) / 4];
+    if constexpr (M == 4) {
+        D[0] = c.w[0];
+    } else if constexpr (M == 8) {
+        D[0] = rc.hsel ? c.w[1] : c.w[0];
+        D[1] = rc.hsel ? c.w[0] : c.w[1];
+    } else {
+        const bool b0 = rc.hsel & 1, b1 = rc.hsel & 2;
+        const uint32_t x01 = b0 ? c.w[1] : c.w[0], y01 = b0 ? c.w[0] : c.w[1];
+        const uint32_t x23 = b0 ? c.w[3] : c.w[2], y23 = b0 ? c.w[2] : c.w[3];
+        D[0] = b1 ? x23 : x01;
+        D[1] = b1 ? y23 : y01;
+        D[2] = b1 ? x01 : x23;
+        D[3] = b1 ? y01 : y23;
+    }
+#pragma unroll
+    for (int t = 0; t < M; ++t) {
+        const uint32_t k = __builtin_amdgcn_ubfe(D[t >> 2], rc.sh[t & 3], 8);
+        f[t] = *reinterpret_cast<const u32x2_t*>(tab + ((k << SH) | (rc.cj[t] << 1)));
+    }
+}
+
+template <int M>
+__device__ __forceinline__ u32x2_t adc16_reduce(u32x2_t (&f)[M]) {
+#pragma unroll
+    for (int st = 1; st < M; st <<= 1)
+#pragma unroll
+        for (int t = 0; t < M; t += 2 * st) {
+            f[t][0] = pk_add_u16(f[t][0], f[t + st][0]);
+            f[t][1] = pk_add_u16(f[t][1], f[t + st][1]);
+        }
+    return f[0];
+}
+
+// One workgroup (NW waves) scans one cell chunk (<= 65536 candidates) for `ng` <= 4 queries that all visit it.
+template <int M, int NR, int U, int NW>
+__device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, const int (&item_idx)[S3G], int ng,
+                                            const double* __restrict__ T, const float* __restrict__ T32,
+                                            const uint8_t* __restrict__ codes, int K, int L, int S,
+                                            uint64_t* __restrict__ item_surv, int* __restrict__ item_n,
+                                            unsigned long long* __restrict__ qbound, char* smem) {
+    constexpr int G = S3G;
+    constexpr int R = NR * 64 - 8;
+    constexpr int nf = M / 2;
+    constexpr uint32_t CAP = 65535u / M;
+    char* tab = smem;                                                              // [K][M][G] uint16
+    uint32_t* rk_all = reinterpret_cast<uint32_t*>(smem + (size_t)K * M * G * 2);  // [G][NW][R] (s << 16 | pos)
+    uint32_t* tr_all = rk_all + G * NW * R;                                        // [G][NW][64] scratch of the branch-free append
+    Scan3Shared* sh = reinterpret_cast<Scan3Shared*>(tr_all + G * NW * 64);        // [G]
+    float* smax = reinterpret_cast<float*>(sh + G);                                // [G][NW] table maxima of the prologue
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long c0 = S3_CLK();
+    // item_idx[] is wave-uniform (scalar registers); item fields are (re)loaded through scalar loads where they are used
+    const WorkItem it0 = items[item_idx[0]];
+    {
+        int tab0[G], tab1[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) { tab0[g] = items[item_idx[g]].tab0; tab1[g] = items[item_idx[g]].tab1; }
+        // Tables: float32 copies ([nf][K] per (query, half)) -> registers (16-byte loads, all in flight) -> per-query
+        // maximum (wave reduction on the VALU, NW partial maxima through LDS) -> 16-bit entries -> LDS, one 8-byte
+        // store per (k, j) that carries the four queries' values.
+        const int nvec = (nf * K) >> 2;                    // float4 per half table; K is a multiple of 4
+        constexpr int PER = (nf * 256 / 4 + NW * 64 - 1) / (NW * 64);  // float4 per thread and half for K <= 256
+        float4 v[PER][G][2];
+        float mxv[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) mxv[g] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = i * NW * 64 + tid;
+            const int eg = e < nvec ? e : 0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                v[i][g][0] = reinterpret_cast<const float4*>(T32 + (int64_t)tab0[g] * nf * K)[eg];
+                v[i][g][1] = reinterpret_cast<const float4*>(T32 + (int64_t)tab1[g] * nf * K)[eg];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const float4 q = v[i][g][s2];
+                    mxv[g] = fmaxf(mxv[g], fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
+                }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            uint32_t b = __float_as_uint(mxv[g]), dummy = 0;  // entries are >= 0: unsigned order of the bits == float order
+            wave_minmax_step<1>(dummy, b); wave_minmax_step<2>(dummy, b); wave_minmax_step<4>(dummy, b);
+            wave_minmax_step<8>(dummy, b); wave_minmax_step<16>(dummy, b); wave_minmax_step<32>(dummy, b);
+            if (lane == 0) smax[g * NW + w] = __uint_as_float(b);
+        }
+        if (tid < 8 * G) {
+            const int g = tid >> 3, i = tid & 7;
+            sh[g].wt[i] = 0x7ff0000000000000ull; sh[g].wl[i] = 0x7ff0000000000000ull;
+            sh[g].wcnt[i] = 0;
+        }
+        S3_CTR(1, S3_CLK() - c0);
+        __syncthreads();
+        S3_CTR(2, S3_CLK() - c0);
+        float qinv[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float mxT = smax[g * NW];
+#pragma unroll
+            for (int i = 1; i < NW; ++i) mxT = fmaxf(mxT, smax[g * NW + i]);
+            mxT = fmaxf(mxT, 1e-30f);
+            // qinv = cap / max * (1 - 2^-20): T32 * qinv, rounded, stays below cap (no clamping, so the bracket holds);
+            // a table that holds inf / NaN gets qinv = 0 (all sums 0: everything survives to the exact re-scoring)
+            float qi = ((float)CAP / mxT) * (1.0f - 9.5367431640625e-7f);
+            qi = (mxT < 3.0e38f) ? qi : 0.0f;
+            qi = (qi < 3.0e38f) ? qi : 3.0e38f;
+            qinv[g] = qi;
+        }
+        if (tid < G) {
+            const int g = tid;
+            float qi = qinv[0];
+#pragma unroll
+            for (int gg = 1; gg < G; ++gg) qi = (g == gg) ? qinv[gg] : qi;
+            const double inv_up = (double)qi * (1.0 + 2.384185791015625e-7);
+            sh[g].inv_up = inv_up;
+            sh[g].ub = qi > 0.0f ? (1.0 + 4.76837158203125e-7) / (double)qi : __longlong_as_double(0x7ff0000000000000LL);
+            // A distance that >= L candidates of this query in already scanned cells do not exceed (see k_adc_scan2)
+            const unsigned long long e = (g < ng) ? __hip_atomic_load(&qbound[items[item_idx[g]].q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                  : 0x7ff0000000000000ull;
+            sh[g].ext = e;
+            // an absent query: threshold 0 and maximal table entries, nothing ever passes
+            sh[g].thr = (g < ng) ? bound_to_thr(e, inv_up) : 0u;
+#ifdef CIS_S3_PROBE_NOPASS
+            sh[g].thr = 0u;  // probe: nothing passes, only the fixed-point scan runs
+#endif
+        }
+        uint32_t* tw = reinterpret_cast<uint32_t*>(tab);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = i * NW * 64 + tid;
+            if (e < nvec) {
+                const int j = (4 * e) / K, k0 = 4 * e - j * K;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        uint32_t qv[G];
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            const float4 q = v[i][g][s2];
+                            const float x = c == 0 ? q.x : (c == 1 ? q.y : (c == 2 ? q.z : q.w));
+                            qv[g] = (g < ng) ? (uint32_t)(x * qinv[g]) : CAP;  // truncation: a lower bound of x * qinv
+                            qv[g] = qv[g] > CAP ? CAP : qv[g];                 // (NaN / garbage guard; never taken for finite tables)
+                        }
+                        u32x2_t pk;
+                        pk[0] = qv[0] | (qv[1] << 16);
+                        pk[1] = qv[2] | (qv[3] << 16);
+                        *reinterpret_cast<u32x2_t*>(tw + (((k0 + c) * M + s2 * nf + j) << 1)) = pk;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    S3_CTR(3, S3_CLK() - c0);
+    const RotConsts<M> rc = make_rot<M>(lane);
+    const int Lw = (L + NW - 1) / NW;
+    const int len = __builtin_amdgcn_readfirstlane(it0.len);
+    const int64_t start = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it0.start >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)it0.start);
+#ifdef CIS_S3_PROBE_NOLOOP
+    const int nit = 0;  // probe: prologue + epilogue only
+#else
+    const int nit = (len + 64 * U - 1) / (64 * U);
+#endif
+    int cnt[G];
+    CodeWords<M> dup[G];  // per query: a code whose later copies cannot enter this wave's top-L any more
+    bool has_dup[G];
+    bool any_dup = false;
+#pragma unroll
+    for (int g = 0; g < G; ++g) { cnt[g] = 0; has_dup[g] = false; dup[g] = CodeWords<M>(); }
+    // buffer descriptor over this chunk's codes (wave-uniform): 32-bit offsets, positions past the end read zero
+    __amdgpu_buffer_rsrc_t rs;
+    {
+        const uint64_t cbase = (uint64_t)(uintptr_t)(codes + start * M);
+        const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cbase);
+        const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cbase >> 32));
+        const int nbytes = __builtin_amdgcn_readfirstlane(len * M);
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)bhi << 32) | blo), 0, nbytes, 0x00020000);
+    }
+    const uint32_t* thr_words = &sh[0].thr;
+    constexpr int THR_STRIDE = sizeof(Scan3Shared) / 4;
+    CodeWords<M> nxt[U];
+    if (w < nit) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[u] = load_code_buf<M>(rs, w * 64 * U + u * 64 + lane);
+    }
+    for (int iter = w; iter < nit; iter += NW) {
+        const int base = iter * 64 * U;
+        CodeWords<M> cur[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        if (iter + NW < nit) {  // software prefetch: the next iteration's codes are in flight while this one computes
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = load_code_buf<M>(rs, (iter + NW) * 64 * U + u * 64 + lane);
+        }
+        u32x2_t d[U];
+        {
+            u32x2_t fbuf[2][M];
+            adc16_issue<M>(cur[0], tab, rc, fbuf[0]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (u + 1 < U) adc16_issue<M>(cur[u + 1], tab, rc, fbuf[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                d[u] = adc16_reduce<M>(fbuf[u & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // thresholds of the four queries, packed like the sums; thr + 1 - s, saturated at 0, is non-zero iff s <= thr
+        uint32_t th[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) th[g] = lds_ld(thr_words + g * THR_STRIDE);
+        const uint32_t t01 = (th[0] + 1u) | ((th[1] + 1u) << 16), t23 = (th[2] + 1u) | ((th[3] + 1u) << 16);
+        unsigned long long anym[U];
+        unsigned long long any = 0ull;
+        const bool tail = base + 64 * U > len;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t x = pk_subsat_u16(t01, d[u][0]) | pk_subsat_u16(t23, d[u][1]);
+            anym[u] = __ballot(x != 0u && (!tail || base + u * 64 + lane < len));
+            any |= anym[u];
+        }
+        if (any == 0ull) continue;  // the usual case: nothing in these 64*U candidates beats a bound
+        unsigned long long pm[U][G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const unsigned long long dup_on = (any_dup && has_dup[g]) ? ~0ull : 0ull;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t sg = (g & 1) ? (d[u][g >> 1] >> 16) : (d[u][g >> 1] & 0xffffu);
+                pm[u][g] = __ballot(sg <= th[g]) & anym[u];
+                if (any_dup) {  // wave-uniform, rare: later copies of a code that already lost a tie-break
+                    bool same = true;
+#pragma unroll
+                    for (int i = 0; i < (M + 3) / 4; ++i) same = same && (cur[u].w[i] == dup[g].w[i]);
+                    pm[u][g] &= ~(__ballot(same) & dup_on);
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g >= ng) break;
+            uint32_t* rk = rk_all + (g * NW + w) * R;
+            uint32_t* tr = tr_all + (g * NW + w) * 64;
+            int ntot = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) ntot += __popcll(pm[u][g]);
+            if (ntot == 0) continue;
+            auto entry = [&](int u) -> uint32_t {
+                const uint32_t sg = (g & 1) ? (d[u][g >> 1] >> 16) : (d[u][g >> 1] & 0xffffu);
+                return (sg << 16) | (uint32_t)(base + u * 64 + lane);
+            };
+            if (cnt[g] + ntot <= R) {
+                // everything fits: straight-line code, the lanes that did not pass store into a scratch slot of their own
+                const int trash = (int)(tr - rk) + lane;
+                int c = cnt[g];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const unsigned long long m = pm[u][g];
+                    const int idx = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, c));
+                    int sel;
+                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(trash), "v"(idx), "s"(m));
+                    rk[sel] = entry(u);
+                    c += __popcll(m);
+                }
+                cnt[g] = c;
+                continue;
+            }
+            // Append row after row while they fit; when one does not, compact, re-test the rows not yet appended
+            // against the new threshold and go on (after a compaction cnt <= R - 64, so the next row always fits).
+            int u0 = 0;
+            while (true) {
+                bool full = false;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const unsigned long long m = pm[u][g];
+                    if (u < u0 || full || m == 0ull) continue;
+                    const int n = __popcll(m);
+                    if (cnt[g] + n > R) {
+                        full = true;
+                        u0 = u;
+                        continue;
+                    }
+                    const int idx = cnt[g] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    if ((m >> lane) & 1ull) rk[idx] = entry(u);
+                    cnt[g] += n;
+                    u0 = u + 1;
+                }
+                if (!full) break;
+                const QScale qsg = load_scale(&sh[g]);
+                int c2 = wave_compact3<M, NR, NW>(rk, cnt[g], L, Lw, R - 64, qsg, &sh[g], w);
+                if (c2 < 0) {
+                    uint32_t dp = 0xffffffffu;
+                    const WorkItem itg = items[item_idx[g]];
+                    c2 = wave_compact3_exact<M, NR, NW>(rk, cnt[g], L, Lw, qsg, &sh[g], w, codes, start, K,
+                                                        T + (int64_t)itg.tab0 * nf * K, T + (int64_t)itg.tab1 * nf * K, dp);
+                    dp = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp);
+                    if (dp != 0xffffffffu) {
+                        dup[g] = load_code<M>(codes, start + (int64_t)dp);
+                        has_dup[g] = true;
+                        any_dup = true;
+                    }
+                }
+                cnt[g] = c2;
+                const uint32_t thg = lds_ld(&sh[g].thr);
+                const unsigned long long dup_on = has_dup[g] ? ~0ull : 0ull;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t sg = (g & 1) ? (d[u][g >> 1] >> 16) : (d[u][g >> 1] & 0xffffu);
+                    bool same = true;
+#pragma unroll
+                    for (int i = 0; i < (M + 3) / 4; ++i) same = same && (cur[u].w[i] == dup[g].w[i]);
+                    pm[u][g] &= __ballot(sg <= thg) & ~(__ballot(same) & dup_on);
+                }
+            }
+        }
+    }
+    S3_CTR(4, S3_CLK() - c0);
+    // End of the chunk: every wave cuts its region and publishes its bounds; after the barrier the block bound is
+    // (about) the L-th smallest distance of the whole chunk, so only ~L/NW entries per wave survive it.
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g >= ng) break;
+        uint32_t* rk = rk_all + (g * NW + w) * R;
+        // cap = NR*64 >= cnt: the cut never reports a crowd here (ties beyond L + M stay; the merge resolves them exactly)
+        if (cnt[g] > 0) cnt[g] = wave_compact3<M, NR, NW>(rk, cnt[g], L, Lw, NR * 64, load_scale(&sh[g]), &sh[g], w);
+    }
+    S3_CTR(5, S3_CLK() - c0);
+    __syncthreads();
+    S3_CTR(6, S3_CLK() - c0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g >= ng) break;
+        uint32_t* rk = rk_all + (g * NW + w) * R;
+        cnt[g] = wave_filter3<NR, NW>(rk, cnt[g], load_scale(&sh[g]), &sh[g]);
+        if (lane == 0) sh[g].wcnt[w] = cnt[g];
+        if (tid == 0) {
+            const uint64_t b = block_bound3<NW>(&sh[g]);
+            if (b < sh[g].ext) atomicMin(&qbound[items[item_idx[g]].q], (unsigned long long)b);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g >= ng) break;
+        const uint32_t* rk = rk_all + (g * NW + w) * R;
+        int off = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int c = sh[g].wcnt[i];
+            off += (i < w) ? c : 0;
+            total += c;
+        }
+        uint64_t* out = item_surv + (int64_t)item_idx[g] * S + off;  // S = NW * R >= total
+        for (int e = lane; e < cnt[g]; e += 64) {
+            const uint32_t x = rk[e];
+            out[e] = ((uint64_t)__float_as_uint((float)(x >> 16)) << 32) | (x & 0xffffu);
+        }
+        if (tid == 0) item_n[item_idx[g]] = total;
+    }
+    S3_CTR(7, S3_CLK() - c0);
+    S3_CTR(0, 1);
+}
+
+// Persistent launch over the slot queues, as k_adc_scan2: (workgroups per CU) x 256 workgroups pull slots (<= 4 work
+// items of one cell chunk) from eight queues, one per XCD; a workgroup whose own queue is empty steals.
+template <int M, int NR, int U, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_adc_scan3(
+    const WorkItem* __restrict__ items, const int* __restrict__ slots, const int* __restrict__ n_slots_ptr,
+    const double* __restrict__ T, const float* __restrict__ T32, const uint8_t* __restrict__ codes, int K, int L, int S,
+    int* __restrict__ queue_ctr /* [8], zeroed */, uint64_t* __restrict__ item_surv, int* __restrict__ item_n,
+    unsigned long long* __restrict__ qbound /* [nq], +inf */) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int G = S3G;
+    constexpr int R = NR * 64 - 8;
+    int* s_next = reinterpret_cast<int*>(smem + (size_t)K * M * G * 2 + (size_t)G * NW * (R + 64) * 4 + G * sizeof(Scan3Shared) +
+                                         (size_t)G * NW * sizeof(float));
+    const int* qs = n_slots_ptr + 8;  // [9] queue starts, written by the slot builder
+    const int home = blockIdx.x & 7;
+    const long long k0 = S3_CLK();
+    for (int a = 0; a < 8; ++a) {
+        const int x = (home + a) & 7;
+        const int qstart = qs[x];
+        const int count = qs[x + 1] - qstart;
+        while (true) {
+            const long long q0 = S3_CLK();
+            __syncthreads();  // previous slot fully written out; LDS may be reused
+            if (threadIdx.x == 0) *s_next = atomicAdd(&queue_ctr[x], 1);
+            __syncthreads();
+            const int j = __builtin_amdgcn_readfirstlane(*s_next);  // wave-uniform: everything derived from it stays scalar
+            S3_CTR(8, S3_CLK() - q0);
+            if (j >= count) break;
+            const int slot = qstart + j;
+            int idx[G];
+            int ng = 0;
+            bool same = true;  // the items of a slot must cover the same chunk of the same cell; otherwise run them one by one
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                idx[g] = slots[slot * G + g];
+                if (idx[g] >= 0) {
+                    ng = g + 1;
+                    same = same && items[idx[g]].start == items[idx[0]].start && items[idx[g]].len == items[idx[0]].len;
+                } else {
+                    idx[g] = idx[0];
+                }
+            }
+            if (!same) {
+                for (int g2 = 0; g2 < ng; ++g2) {
+                    int oi[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        oi[g] = idx[0];
+#pragma unroll
+                        for (int gg = 1; gg < G; ++gg)
+                            if (gg == g2) oi[g] = idx[gg];
+                    }
+                    if (g2 > 0) __syncthreads();
+                    scan3_group<M, NR, U, NW>(items, oi, 1, T, T32, codes, K, L, S, item_surv, item_n, qbound, smem);
+                }
+                continue;
+            }
+            scan3_group<M, NR, U, NW>(items, idx, ng, T, T32, codes, K, L, S, item_surv, item_n, qbound, smem);
+        }
+    }
+    S3_CTR(9, S3_CLK() - k0);
+    S3_CTR(10, 1);
+}
+
+bool scan3_supported(int M, int K, int L) {
+    return (M == 4 || M == 8 || M == 16) && K <= 256 && K % 4 == 0 && L >= 1 && L <= 440;
+}
+
+Scan3Geom scan3_geom(int M, int K, int L) {
+    Scan3Geom g;
+    const int NR = (L <= 184) ? 4 : 8;
+    g.G = S3G;
+    g.NW = 4;
+    g.U = 4;
+    g.S = g.NW * (NR * 64 - 8);
+    g.lds = (size_t)K * M * g.G * 2 + (size_t)g.G * g.NW * (NR * 64 - 8 + 64) * 4 + g.G * sizeof(Scan3Shared) +
+            (size_t)g.G * g.NW * sizeof(float) + 16;
+    return g;
+}
+
+template <int M, int NR>
+static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
+                           const int* n_slots, const double* T, const float* T32, const uint8_t* codes, int K, int L, int* qctr,
+                           uint64_t* hits, int* hitn, unsigned long long* qbound) {
+    constexpr int NW = 4, U = 4;
+    const int per_cu = (int)(163840 / g.lds) < (16 / NW) ? (int)(163840 / g.lds) : (16 / NW);
+    const int64_t resident = 256 * (per_cu < 1 ? 1 : per_cu);  // persistent grid: what the chip can hold
+    const int64_t want = (n_items + g.G - 1) / g.G + 8;
+    const unsigned grid = (unsigned)(want < resident ? ((want + 7) / 8) * 8 : resident);
+    hipLaunchKernelGGL((k_adc_scan3<M, NR, U, NW>), dim3(grid), dim3(NW * 64), g.lds, st, items, slots, n_slots, T, T32, codes, K, L,
+                       g.S, qctr, hits, hitn, qbound);
+}
+
+void launch_scan3(int M, const Scan3Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
+                  const int* n_slots, const double* T, const float* T32, const uint8_t* codes, int K, int L, int* qctr,
+                  uint64_t* hits, int* hitn, unsigned long long* qbound) {
+#define CIS_S3(MM)                                                                                                              \
+    do {                                                                                                                        \
+        if (L <= 184) launch_scan3_t<MM, 4>(g, n_items, st, items, slots, n_slots, T, T32, codes, K, L, qctr, hits, hitn, qbound);  \
+        else launch_scan3_t<MM, 8>(g, n_items, st, items, slots, n_slots, T, T32, codes, K, L, qctr, hits, hitn, qbound);           \
+    } while (0)
+    if (M == 4) CIS_S3(4);
+    else if (M == 8) CIS_S3(8);
+    else CIS_S3(16);
+#undef CIS_S3
+}

@@ -20,29 +20,11 @@
 #include <unordered_set>
 
 #include "lopq_model.h"
+#include "scan_common.h"
 
 // ================================================================================================
 // device structures
 // ================================================================================================
-struct WorkItem {
-    int q;          // query index inside the batch
-    int rank;       // multisequence visit rank of the cell
-    int tab0, tab1; // indices of the two half tables
-    int64_t start;  // first candidate (position in codes/ids)
-    int len;        // candidates in this chunk
-    int pos0;       // insertion position of the first candidate inside its cell
-    int cell;       // c0 * V + c1
-    int pad;
-};
-
-struct TabDesc {
-    int q, split, cluster, pad;
-};
-
-struct PlanOut {  // per query
-    int visited, n_items, ntab0, ntab1;
-    int64_t ncand;
-};
 
 static __device__ __forceinline__ uint64_t f2bits(double d) { return (uint64_t)__double_as_longlong(d); }
 static __device__ __forceinline__ uint64_t f2bits(float f) { return (uint64_t)__float_as_uint(f); }
@@ -901,106 +883,6 @@ __global__ __launch_bounds__(256) void k_adc_scan(const WorkItem* __restrict__ i
 //    identical codes are common in real indexes -- are resolved on (dist, pos), never on float32;
 //  * at the end every wave holds <= `limit` exact hits; they are written as cis_hit and the
 //    per-query merge ranks them by (dist, visit_rank, pos).
-// value of lane (l ^ LJ) for every lane l, on the VALU only (DPP / permlane swaps): the LDS pipe is the
-// scan's bottleneck, so the in-register sorts must not use ds_bpermute.
-template <int LJ>
-__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
-    if constexpr (LJ == 1) {
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-    } else if constexpr (LJ == 2) {
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    } else if constexpr (LJ == 4) {
-        const int a = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);      // row_half_mirror: l ^ 7
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, a, 0x1B, 0xF, 0xF, false);        // quad_perm [3,2,1,0]: ^ 3
-    } else if constexpr (LJ == 8) {
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);  // row_ror:8 == l ^ 8 in a row of 16
-    } else if constexpr (LJ == 16) {
-        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // .x = even rows twice, .y = odd rows twice
-        return (threadIdx.x & 16) ? r[0] : r[1];
-    } else {
-        static_assert(LJ == 32, "lane_xor: LJ must be a power of two below 64");
-        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // .x = low half twice, .y = high half twice
-        return (threadIdx.x & 32) ? r[0] : r[1];
-    }
-}
-
-template <int NR, int KK, int J>
-__device__ __forceinline__ void bitonic_step(uint32_t (&k)[NR]) {
-    const int lane = threadIdx.x & 63;
-    if constexpr (J < NR) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            if ((r & J) == 0) {
-                const bool asc = (((lane * NR + r) & KK) == 0);
-                const uint32_t a = k[r], b = k[r | J];
-                const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-                k[r] = asc ? lo : hi;
-                k[r | J] = asc ? hi : lo;
-            }
-        }
-    } else {
-        constexpr int LJ = J / NR;
-        const bool lower = ((lane & LJ) == 0);
-        const bool asc = (((lane * NR) & KK) == 0);
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const uint32_t o = lane_xor<LJ>(k[r]);
-            const uint32_t mn = k[r] < o ? k[r] : o, mx = k[r] < o ? o : k[r];
-            k[r] = (lower == asc) ? mn : mx;
-        }
-    }
-}
-
-template <int NR, int KK, int J>
-__device__ __forceinline__ void bitonic_merge(uint32_t (&k)[NR]) {
-    bitonic_step<NR, KK, J>(k);
-    if constexpr (J > 1) bitonic_merge<NR, KK, J / 2>(k);
-}
-
-template <int NR, int KK>
-__device__ __forceinline__ void bitonic_levels(uint32_t (&k)[NR]) {
-    if constexpr (KK > 2) bitonic_levels<NR, KK / 2>(k);
-    bitonic_merge<NR, KK, KK / 2>(k);
-}
-
-// ascending sort of the NR*64 keys of a wave, element e = lane*NR + r
-template <int NR>
-__device__ __forceinline__ void wave_bitonic_sort(uint32_t (&k)[NR]) {
-    bitonic_levels<NR, NR * 64>(k);
-}
-
-template <int LJ>
-__device__ __forceinline__ void wave_minmax_step(uint32_t& mn, uint32_t& mx) {
-    const uint32_t a = lane_xor<LJ>(mn), b = lane_xor<LJ>(mx);
-    mn = a < mn ? a : mn;
-    mx = b > mx ? b : mx;
-}
-
-// Smallest v with  #{valid keys <= v} >= target  == the target-th smallest key (1-based), found by
-// bisection on the value range with ballots: ~4 VALU compares per probe instead of a ~650-instruction
-// register sort.  lo/hi must bracket the answer (lo = min key, hi = max key is always fine).
-template <int NR>
-__device__ __forceinline__ uint32_t wave_kth_bisect(const uint32_t (&key)[NR], const bool (&valid)[NR], uint32_t lo,
-                                                    uint32_t hi, int target) {
-    while (lo < hi) {  // wave-uniform
-        const uint32_t p = lo + ((hi - lo) >> 1);
-        int c = 0;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) c += __popcll(__ballot(valid[r] && key[r] <= p));
-        if (c >= target) hi = p;
-        else lo = p + 1;
-    }
-    return lo;
-}
-
-template <int NR>
-__device__ __forceinline__ uint32_t wave_kth(const uint32_t (&k)[NR], int i) {  // i-th smallest after the sort
-    uint32_t v = k[0];
-#pragma unroll
-    for (int r = 1; r < NR; ++r)
-        if ((i % NR) == r) v = k[r];
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, i / NR);
-}
 
 #ifdef CIS_SCAN_COUNTERS
 __device__ unsigned long long g_scan_ctr[16];  // compactions, rescored entries, exact-cut, second sorts, appended
@@ -1021,18 +903,6 @@ struct ScanShared {  // one per query handled by the workgroup
     uint64_t ext;    // bound published by workgroups that scanned OTHER cells for the same query (qbound[q] at start)
 };
 
-static __device__ __forceinline__ float lds_ld(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-static __device__ __forceinline__ uint64_t lds_ld(const uint64_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-static __device__ __forceinline__ void lds_st(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-static __device__ __forceinline__ void lds_st(uint64_t* p, uint64_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 
 static __device__ __forceinline__ float block_bound_f32(const ScanShared* sh) { return lds_ld(&sh->bound_f); }
 template <int NW>
@@ -1061,47 +931,6 @@ static __device__ __forceinline__ double adc64_global(const uint8_t* __restrict_
     return d;
 }
 
-// exact float64 distance from the code words (little-endian bytes = fine codes 0..M-1)
-template <int M>
-static __device__ __forceinline__ double adc64_words(const uint32_t (&cw)[(M + 3) / 4], int K, const double* __restrict__ t0,
-                                                     const double* __restrict__ t1) {
-    constexpr int nf = M / 2;
-    double f[M];
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-        const uint32_t c = (cw[j >> 2] >> (8 * (j & 3))) & 255u;
-        f[j] = (j < nf) ? t0[j * K + c] : t1[(j - nf) * K + c];
-    }
-    double d = f[0];
-#pragma unroll
-    for (int j = 1; j < M; ++j) d = d + f[j];
-    return d;
-}
-
-// hi word -> the largest float64 bit pattern with that hi word (a distance no smaller than any
-// distance whose bits start with `vhi`); infinities stay infinite
-static __device__ __forceinline__ uint64_t hi_to_bound(uint32_t vhi) {
-    return vhi >= 0x7ff00000u ? 0x7ff0000000000000ull : (((uint64_t)vhi << 32) | 0xffffffffull);
-}
-
-// one candidate's code as 32-bit words (little-endian bytes = fine codes 0..M-1)
-template <int M>
-struct CodeWords { uint32_t w[(M + 3) / 4]; };
-
-template <int M>
-__device__ __forceinline__ CodeWords<M> load_code(const uint8_t* __restrict__ codes, int64_t p) {
-    CodeWords<M> c;
-    if constexpr (M == 4) {
-        c.w[0] = *reinterpret_cast<const uint32_t*>(codes + p * 4);
-    } else if constexpr (M == 8) {
-        const uint2 v = *reinterpret_cast<const uint2*>(codes + p * 8);
-        c.w[0] = v.x; c.w[1] = v.y;
-    } else {
-        const uint4 v = *reinterpret_cast<const uint4*>(codes + p * 16);
-        c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
-    }
-    return c;
-}
 
 // Region entries during the scan are (float32 distance << 32 | candidate position): ordered by (d32, pos) as
 // plain integers, appended with one ds_write_b64.  Two compactions work on them:
@@ -1394,53 +1223,6 @@ __device__ __forceinline__ int wave_filter(uint64_t* rk, uint32_t* rp, int cnt, 
     return ncnt;
 }
 
-template <int M>
-struct RotConsts {
-    uint32_t sh[4];   // bit offset of the byte used at sub-step tq inside the selected dword
-    uint32_t cj[M];   // (table index << 2) for step t
-    uint32_t hsel;    // which dword this lane starts with
-};
-
-template <int M>
-__device__ __forceinline__ RotConsts<M> make_rot(int lane) {
-    RotConsts<M> rc;
-    const int r = lane & (M - 1);
-    const int h = r >> 2, q = r & 3;
-    rc.hsel = (uint32_t)h;
-#pragma unroll
-    for (int tq = 0; tq < 4; ++tq) rc.sh[tq] = 8u * (uint32_t)((q + tq) & 3);
-#pragma unroll
-    for (int t = 0; t < M; ++t) {
-        const int th = t >> 2, tq = t & 3;
-        const int j = ((h ^ th) << 2) | ((q + tq) & 3);
-        rc.cj[t] = (uint32_t)j << 2;
-#ifdef CIS_SCAN_OPAQUE_CJ
-        asm volatile("" : "+v"(rc.cj[t]));  // keep the M offsets in M registers (else the compiler re-derives half of them per use)
-#endif
-    }
-    return rc;
-}
-
-// the same through a buffer descriptor that covers exactly the chunk being scanned: one 32-bit offset per
-// load instead of 64-bit address arithmetic, and positions past the end of the chunk read as zero
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-template <int M>
-__device__ __forceinline__ CodeWords<M> load_code_buf(__amdgpu_buffer_rsrc_t rs, int p) {
-    CodeWords<M> c;
-    if constexpr (M == 4) {
-        c.w[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, p * 4, 0, 0);
-    } else if constexpr (M == 8) {
-        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, p * 8, 0, 0);
-        c.w[0] = v[0]; c.w[1] = v[1];
-    } else {
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, p * 16, 0, 0);
-        c.w[0] = v[0]; c.w[1] = v[1]; c.w[2] = v[2]; c.w[3] = v[3];
-    }
-    return c;
-}
 
 // float32 ADC sum of one candidate with the lane-rotated table order (see header comment)
 template <int M>
@@ -2101,7 +1883,8 @@ __global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restr
                                                          cis_hit* __restrict__ out_hits, int64_t* __restrict__ out_ids,
                                                          double* __restrict__ out_dists, int* __restrict__ out_n,
                                                          int32_t* __restrict__ out_cells, uint32_t* __restrict__ out_pos,
-                                                         const PlanOut* __restrict__ plan, int32_t* __restrict__ out_visited) {
+                                                         const PlanOut* __restrict__ plan, int32_t* __restrict__ out_visited,
+                                                         int surv_cut /* the survivors' high words are float32 distances comparable across the query's lists */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wq;
@@ -2149,7 +1932,7 @@ __global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restr
                 mx = (valid[i] && hi[i] > mx) ? hi[i] : mx;
             }
             uint32_t thr = 0xffffffffu;
-            if (n_total > limit) {
+            if (n_total > limit && surv_cut) {
                 wave_minmax_step<1>(mn, mx); wave_minmax_step<2>(mn, mx); wave_minmax_step<4>(mn, mx);
                 wave_minmax_step<8>(mn, mx); wave_minmax_step<16>(mn, mx); wave_minmax_step<32>(mn, mx);
                 mn = (uint32_t)__builtin_amdgcn_readfirstlane((int)mn);
@@ -2372,6 +2155,8 @@ struct cis_index {
     int64_t stats[4] = {0, 0, 0, 0};
     // optional stage timing (hipEvents on the launch stream)
     bool force_exact_scan = false;  // tests: run every item through the float64 kernel
+    bool force_scan2 = false;       // scan mode 2: the float32-prefilter kernel whatever the batch size
+    bool force_scan3 = false;       // scan mode 3: the 16-bit fixed-point kernel whatever the batch size
     bool force_prefilter_scan = false;  // tests: the float32-prefilter kernel also for small batches
     int profiling = 0;  // 0 off, 1 events around the scan kernel only, 2 events around every stage
     int64_t* h_totals = nullptr;    // pinned, device-mapped: the plan totals land here without a copy
@@ -2707,9 +2492,11 @@ extern "C" int cis_multisequence(const void* X, int x_dtype, const void* C0, con
 }
 
 extern "C" int cis_index_set_scan_mode(cis_index* ix, int mode) {
-    CIS_REQUIRE(ix != nullptr && (mode == 0 || mode == 1 || mode == 2), "bad scan mode");
+    CIS_REQUIRE(ix != nullptr && mode >= 0 && mode <= 3, "bad scan mode");
     ix->force_exact_scan = (mode == 1);
-    ix->force_prefilter_scan = (mode == 2);
+    ix->force_prefilter_scan = (mode == 2 || mode == 3);
+    ix->force_scan2 = (mode == 2);
+    ix->force_scan3 = (mode == 3);
     return CIS_OK;
 }
 
@@ -3411,7 +3198,12 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     int* grp_cnt = ix->w_grp.as<int>();         // [2V][GRP_SUB] tables per (split, cluster, query % GRP_SUB)
     int* grp_cur = grp_cnt + 2 * V * GRP_SUB;    // cursors
     int* grp_base = grp_cnt + 4 * V * GRP_SUB;   // exclusive scan
-    const int seg_max = nq >= 1024 ? (1 << 20) : (nq >= 64 ? 16384 : 4096);
+    // scan v3 (16-bit fixed-point tables, four queries per workgroup) for large batches; its region entries hold 16-bit
+    // positions, so a chunk is at most 65536 candidates.  scan_mode 3 forces it for any batch size (tests).
+    static const int env_scan = getenv("CIS_FORCE_SCAN") ? atoi(getenv("CIS_FORCE_SCAN")) : 0;  // A/B runs: 2 or 3
+    const bool use3 = !ix->force_exact_scan && scan3_supported(M, K, L) && !use_all_path(ix, M, K, L, nq) &&
+                      (ix->force_scan3 || (nq >= 256 && !ix->force_scan2 && env_scan == 3));  // opt-in until it beats k_adc_scan2 on every shape
+    const int seg_max = use3 ? (nq >= 64 ? 65536 : 4096) : (nq >= 1024 ? (1 << 20) : (nq >= 64 ? 16384 : 4096));
     CIS_TRY(cis_launch_sqdist_both(m, xc, ct, nq, ix->w_cd.p, st));
     const size_t plan_lds = (size_t)V * sizeof(int);
     int Vp2 = 64;
@@ -3645,7 +3437,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (fast) {
             // slot list: work items grouped by coarse cell (counting sort; skipped for huge V), G per slot
             const bool sort_items = ix->ncells <= 65536;
-            const int G = geom.G;
+            const Scan3Geom geom3 = scan3_geom(M, K, L);
+            const int G = use3 ? geom3.G : geom.G;
             const int64_t nkeys = 2 * ix->ncells;
             const int64_t max_slots = sort_items ? (n_items + nkeys) / G + nkeys + 2 : n_items;
             CIS_TRY(ix->w_order2.reserve((size_t)(32 + 2 * nkeys + max_slots * G) * sizeof(int)));
@@ -3670,7 +3463,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                                    slots, n_slots, qstart);
             }
             CIS_TRY(mark(5));
-            launch_scan2(M, geom, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, qbound);
+            if (use3)
+                launch_scan3(M, geom3, n_items, st, items, slots, n_slots, T, T32, codes, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, qbound);
+            else
+                launch_scan2(M, geom, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, qbound);
         }
         else {
             CIS_TRY(mark(5));
@@ -3695,11 +3491,11 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (many)                                                                                                            \
             hipLaunchKernelGGL((k_merge_survivors<CAP, MT, 8>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), (size_t)4 * CAP * 16, st, \
                                surv, hitn, item_off, items, T, codes, ids, nq, M, K, L, S, out.hits, out.ids, out.dists,     \
-                               out.n_found, out.cells, out.pos, plan, out.visited);                                          \
+                               out.n_found, out.cells, out.pos, plan, out.visited, use3 ? 0 : 1);                            \
         else                                                                                                                 \
             hipLaunchKernelGGL((k_merge_survivors<CAP, MT, 4>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), (size_t)4 * CAP * 16, st, \
                                surv, hitn, item_off, items, T, codes, ids, nq, M, K, L, S, out.hits, out.ids, out.dists,     \
-                               out.n_found, out.cells, out.pos, plan, out.visited);                                          \
+                               out.n_found, out.cells, out.pos, plan, out.visited, use3 ? 0 : 1);                            \
     } while (0)
 #define CIS_MERGE_SURV_M(CAP)                                                                          \
     do {                                                                                               \

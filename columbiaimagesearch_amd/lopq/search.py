@@ -129,7 +129,9 @@ class LOPQSearcherHIP(LOPQSearcherBase):
         _lib.check(L.cis_index_create(_lib.ctypes.byref(out), self._model_handle.ptr))
         self._ix = out.value
         self._input_dim = self.model.__dict__["_dims"][0]  # of the parameters this index was built on
-        if type(self).default_prefilter_only:
+        if type(self).default_scan_mode:
+            _lib.check(L.cis_index_set_scan_mode(self._ix, type(self).default_scan_mode))
+        elif type(self).default_prefilter_only:
             _lib.check(L.cis_index_set_scan_mode(self._ix, 2))
         if self._shard is not None:
             rank, world = self._shard[0], self._shard[1]
@@ -358,15 +360,19 @@ class LOPQSearcherHIP(LOPQSearcherBase):
         return {"candidates": int(st[0]), "items": int(st[1]), "tables": int(st[2]), "scan_launches": int(st[3])}
 
 
-    default_prefilter_only = False  # tests: new searchers keep the float32-prefilter kernel for small batches too
+    default_prefilter_only = False  # tests: new searchers keep the float32-prefilter kernel for every batch size
+    default_scan_mode = 0           # tests: 3 = new searchers run the 16-bit fixed-point kernel for every batch size
 
-    def set_scan_mode(self, exact_only=False, prefilter_only=None):
+    def set_scan_mode(self, exact_only=False, prefilter_only=None, mode=None):
         """Routing of limit <= 440 (tests; results are identical on every route): exact_only forces the float64 scan
-        kernel, prefilter_only keeps the float32-prefilter kernel for small batches, which otherwise take the
-        all-candidates path (shorter kernel chain at low occupancy)."""
-        if prefilter_only is None:
-            prefilter_only = type(self).default_prefilter_only
-        _lib.check(_lib.lib().cis_index_set_scan_mode(self._ix, 1 if exact_only else (2 if prefilter_only else 0)))
+        kernel, prefilter_only the float32-prefilter kernel for every batch size (small batches otherwise take the
+        all-candidates path: shorter kernel chain at low occupancy; large ones the 16-bit fixed-point kernel);
+        mode = the raw cis_index_set_scan_mode value (3: the 16-bit fixed-point kernel for every batch size)."""
+        if mode is None:
+            if prefilter_only is None:
+                prefilter_only = type(self).default_prefilter_only
+            mode = 1 if exact_only else (2 if prefilter_only else type(self).default_scan_mode)
+        _lib.check(_lib.lib().cis_index_set_scan_mode(self._ix, int(mode)))
 
     def set_profiling(self, enable=True, scan_only=False):
         """Record HIP events on the launch stream (see read_profile): around every stage, or (scan_only) just the pair

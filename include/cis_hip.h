@@ -206,11 +206,12 @@ int cis_index_last_stats(cis_index* ix, int64_t stats[4]);
  *   ms[4] the ADC scan kernel alone (events right before and after its launch)
  *   *launches = number of scan kernel launches accumulated. */
 int cis_index_set_profiling(cis_index* ix, int level /* 0 off, 1 only the pair of events around the scan kernel (ms[4]), 2 every stage */);
-/* Ranking route selection: 0 = automatic (limit <= 440: float32-prefilter scan kernel with exact float64 re-scoring
- * where it applies -- small batches take the all-candidates path instead: exact distances of every candidate, radix
- * select; exact float64 scan kernel otherwise), 1 = exact float64 scan kernel wherever it applies (limit <= 3072),
- * 2 = like 0 but the float32-prefilter kernel also for small batches.  All routes produce identical results; the
- * switch exists so that tests can prove it. */
+/* Ranking route selection: 0 = automatic (limit <= 440: a prefilter scan kernel with exact float64 re-scoring of its
+ * survivors -- the 16-bit fixed-point kernel k_adc_scan3 for batches of >= 256 queries, the float32 kernel k_adc_scan2
+ * below that; small batches take the all-candidates path instead: exact distances of every candidate, radix select;
+ * exact float64 scan kernel otherwise), 1 = exact float64 scan kernel wherever it applies (limit <= 3072),
+ * 2 = the float32-prefilter kernel for every batch size, 3 = the 16-bit fixed-point kernel for every batch size.
+ * All routes produce identical results; the switch exists so that tests can prove it. */
 int cis_index_set_scan_mode(cis_index* ix, int mode);
 int cis_index_read_profile(cis_index* ix, double ms[5], int64_t* launches);
 

@@ -25,8 +25,8 @@ def world():
     import bench as B
     from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
     dev = torch.device("cuda", 0)
-    model, z = B.load_model()
-    P = B.mixture_centers(dev)
+    model, z = B.load_model("c4")
+    P = B.mixture_centers("descriptor", dev)
     chunk_n = N // N_CHUNKS
     co, fi = [], []
     for c in range(N_CHUNKS):
