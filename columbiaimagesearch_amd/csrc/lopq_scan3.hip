@@ -344,11 +344,9 @@ __device__ __forceinline__ int wave_filter3(uint32_t* rk, int cnt, const QScale&
     return ncnt;
 }
 
-// table reads of one candidate for the four queries: M x ds_read_b64, lane-rotated sub-quantizer order (make_rot)
+// one candidate's code words in this lane's rotated order (make_rot): D[t >> 2] holds the byte used at step t
 template <int M>
-__device__ __forceinline__ void adc16_issue(const CodeWords<M>& c, const char* __restrict__ tab, const RotConsts<M>& rc, u32x2_t (&f)[M]) {
-    constexpr int SH = ((M == 4) ? 2 : (M == 8 ? 3 : 4)) + 3;  // log2(M * 8 bytes): one k-row of the table
-    uint32_t D[(M + 3) / 4];
+__device__ __forceinline__ void rot_words(const CodeWords<M>& c, const RotConsts<M>& rc, uint32_t (&D)[(M + 3) / 4]) {
     if constexpr (M == 4) {
         D[0] = c.w[0];
     } else if constexpr (M == 8) {
@@ -363,41 +361,57 @@ __device__ __forceinline__ void adc16_issue(const CodeWords<M>& c, const char* _
         D[2] = b1 ? x01 : x23;
         D[3] = b1 ? y01 : y23;
     }
+}
+
+// The pipeline unit of the hot loop: OCT table reads (ds_read_b64, four queries each) of one candidate -- steps
+// [o*OCT, (o+1)*OCT) of the lane-rotated sub-quantizer order -- and their sum.  M = 16 is two units per candidate, so
+// that the register footprint of the reads in flight is the same for every M.
+template <int M, int OCT>
+__device__ __forceinline__ void adc16_issue(const uint32_t (&D)[(M + 3) / 4], int o, const char* __restrict__ tab,
+                                            const RotConsts<M>& rc, u32x2_t (&f)[OCT]) {
+    constexpr int SH = ((M == 4) ? 2 : (M == 8 ? 3 : 4)) + 3;  // log2(M * 8 bytes): one k-row of the table
 #pragma unroll
-    for (int t = 0; t < M; ++t) {
+    for (int i = 0; i < OCT; ++i) {
+        const int t = o * OCT + i;
         const uint32_t k = __builtin_amdgcn_ubfe(D[t >> 2], rc.sh[t & 3], 8);
-        f[t] = *reinterpret_cast<const u32x2_t*>(tab + ((k << SH) | (rc.cj[t] << 1)));
+        f[i] = *reinterpret_cast<const u32x2_t*>(tab + ((k << SH) | (rc.cj[t] << 1)));
     }
 }
 
-template <int M>
-__device__ __forceinline__ u32x2_t adc16_reduce(u32x2_t (&f)[M]) {
+// two independent chains (queries 0-1 and 2-3), interleaved: no back-to-back dependent packed adds
+template <int OCT>
+__device__ __forceinline__ u32x2_t adc16_sum(const u32x2_t (&f)[OCT]) {
+    uint32_t a0 = f[0][0], a1 = f[0][1];
 #pragma unroll
-    for (int st = 1; st < M; st <<= 1)
-#pragma unroll
-        for (int t = 0; t < M; t += 2 * st) {
-            f[t][0] = pk_add_u16(f[t][0], f[t + st][0]);
-            f[t][1] = pk_add_u16(f[t][1], f[t + st][1]);
-        }
-    return f[0];
+    for (int i = 1; i < OCT; ++i) {
+        a0 = pk_add_u16(a0, f[i][0]);
+        a1 = pk_add_u16(a1, f[i][1]);
+    }
+    u32x2_t r;
+    r[0] = a0; r[1] = a1;
+    return r;
 }
+
+static __device__ __forceinline__ uint32_t ld16(const uint16_t* p) { return *reinterpret_cast<const volatile uint16_t*>(p); }
+static __device__ __forceinline__ void st16(uint16_t* p, uint32_t v) { *reinterpret_cast<volatile uint16_t*>(p) = (uint16_t)v; }
 
 // One workgroup (NW waves) scans one cell chunk (<= 65536 candidates) for `ng` <= 4 queries that all visit it.
 template <int M, int NR, int U, int NW>
-__device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, const int (&item_idx)[S3G], int ng,
+__device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, const TabDesc* __restrict__ tabs,
+                                            const int (&item_idx)[S3G], int ng,
                                             const double* __restrict__ T, const float* __restrict__ T32,
                                             const uint8_t* __restrict__ codes, int K, int L, int S,
-                                            uint64_t* __restrict__ item_surv, int* __restrict__ item_n,
+                                            uint64_t* __restrict__ item_surv, int* __restrict__ item_n, float* __restrict__ item_slack,
                                             unsigned long long* __restrict__ qbound, char* smem) {
     constexpr int G = S3G;
     constexpr int R = NR * 64 - 8;
     constexpr int nf = M / 2;
+    constexpr int OCT = M >= 8 ? 8 : 4, NU = M / OCT;
     constexpr uint32_t CAP = 65535u / M;
     char* tab = smem;                                                              // [K][M][G] uint16
     uint32_t* rk_all = reinterpret_cast<uint32_t*>(smem + (size_t)K * M * G * 2);  // [G][NW][R] (s << 16 | pos)
-    uint32_t* tr_all = rk_all + G * NW * R;                                        // [G][NW][64] scratch of the branch-free append
-    Scan3Shared* sh = reinterpret_cast<Scan3Shared*>(tr_all + G * NW * 64);        // [G]
-    float* smax = reinterpret_cast<float*>(sh + G);                                // [G][NW] table maxima of the prologue
+    Scan3Shared* sh = reinterpret_cast<Scan3Shared*>(rk_all + G * NW * R);         // [G]
+    uint16_t* thr1 = reinterpret_cast<uint16_t*>(sh + G);                          // [G] hot-loop thresholds + 1, packed like the sums
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long c0 = S3_CLK();
@@ -405,57 +419,12 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
     const WorkItem it0 = items[item_idx[0]];
     {
         int tab0[G], tab1[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) { tab0[g] = items[item_idx[g]].tab0; tab1[g] = items[item_idx[g]].tab1; }
-        // Tables: float32 copies ([nf][K] per (query, half)) -> registers (16-byte loads, all in flight) -> per-query
-        // maximum (wave reduction on the VALU, NW partial maxima through LDS) -> 16-bit entries -> LDS, one 8-byte
-        // store per (k, j) that carries the four queries' values.
-        const int nvec = (nf * K) >> 2;                    // float4 per half table; K is a multiple of 4
-        constexpr int PER = (nf * 256 / 4 + NW * 64 - 1) / (NW * 64);  // float4 per thread and half for K <= 256
-        float4 v[PER][G][2];
-        float mxv[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) mxv[g] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e = i * NW * 64 + tid;
-            const int eg = e < nvec ? e : 0;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                v[i][g][0] = reinterpret_cast<const float4*>(T32 + (int64_t)tab0[g] * nf * K)[eg];
-                v[i][g][1] = reinterpret_cast<const float4*>(T32 + (int64_t)tab1[g] * nf * K)[eg];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < PER; ++i)
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const float4 q = v[i][g][s2];
-                    mxv[g] = fmaxf(mxv[g], fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
-                }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            uint32_t b = __float_as_uint(mxv[g]), dummy = 0;  // entries are >= 0: unsigned order of the bits == float order
-            wave_minmax_step<1>(dummy, b); wave_minmax_step<2>(dummy, b); wave_minmax_step<4>(dummy, b);
-            wave_minmax_step<8>(dummy, b); wave_minmax_step<16>(dummy, b); wave_minmax_step<32>(dummy, b);
-            if (lane == 0) smax[g * NW + w] = __uint_as_float(b);
-        }
-        if (tid < 8 * G) {
-            const int g = tid >> 3, i = tid & 7;
-            sh[g].wt[i] = 0x7ff0000000000000ull; sh[g].wl[i] = 0x7ff0000000000000ull;
-            sh[g].wcnt[i] = 0;
-        }
-        S3_CTR(1, S3_CLK() - c0);
-        __syncthreads();
-        S3_CTR(2, S3_CLK() - c0);
         float qinv[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float mxT = smax[g * NW];
-#pragma unroll
-            for (int i = 1; i < NW; ++i) mxT = fmaxf(mxT, smax[g * NW + i]);
+            tab0[g] = items[item_idx[g]].tab0; tab1[g] = items[item_idx[g]].tab1;
+            // largest entry of the query's two half tables (k_tables_from_px leaves it in TabDesc::pad, float32 bits)
+            float mxT = fmaxf(__int_as_float(tabs[tab0[g]].pad), __int_as_float(tabs[tab1[g]].pad));
             mxT = fmaxf(mxT, 1e-30f);
             // qinv = cap / max * (1 - 2^-20): T32 * qinv, rounded, stays below cap (no clamping, so the bracket holds);
             // a table that holds inf / NaN gets qinv = 0 (all sums 0: everything survives to the exact re-scoring)
@@ -470,45 +439,62 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
 #pragma unroll
             for (int gg = 1; gg < G; ++gg) qi = (g == gg) ? qinv[gg] : qi;
             const double inv_up = (double)qi * (1.0 + 2.384185791015625e-7);
+            const double ub = qi > 0.0f ? (1.0 + 4.76837158203125e-7) / (double)qi : __longlong_as_double(0x7ff0000000000000LL);
             sh[g].inv_up = inv_up;
-            sh[g].ub = qi > 0.0f ? (1.0 + 4.76837158203125e-7) / (double)qi : __longlong_as_double(0x7ff0000000000000LL);
+            sh[g].ub = ub;
             // A distance that >= L candidates of this query in already scanned cells do not exceed (see k_adc_scan2)
             const unsigned long long e = (g < ng) ? __hip_atomic_load(&qbound[items[item_idx[g]].q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                                   : 0x7ff0000000000000ull;
             sh[g].ext = e;
-            // an absent query: threshold 0 and maximal table entries, nothing ever passes
-            sh[g].thr = (g < ng) ? bound_to_thr(e, inv_up) : 0u;
+            // an absent query: threshold 0 (thr1 = 0: the saturated difference is never non-zero) and maximal table entries
+            uint32_t thr = (g < ng) ? bound_to_thr(e, inv_up) : 0u;
 #ifdef CIS_S3_PROBE_NOPASS
-            sh[g].thr = 0u;  // probe: nothing passes, only the fixed-point scan runs
+            thr = 0u;  // probe: nothing passes, only the fixed-point scan runs
+            if (true) { sh[g].thr = 0u; thr1[g] = 0; } else
 #endif
+            { sh[g].thr = thr; thr1[g] = (uint16_t)((g < ng) ? thr + 1u : 0u); }
+            // what the merge may assume about a survivor: exact distance >= (its float32 upper bound) - slack
+            if (g < ng) item_slack[item_idx[g]] = __double2float_ru(ub * ((double)M + 0.1));
         }
+        if (tid < 8 * G) {
+            const int g = tid >> 3, i = tid & 7;
+            sh[g].wt[i] = 0x7ff0000000000000ull; sh[g].wl[i] = 0x7ff0000000000000ull;
+            sh[g].wcnt[i] = 0;
+        }
+        // Tables: float32 copies ([nf][K] per (query, half)) -> 16-bit entries -> LDS, one 8-byte store per (k, j) that
+        // carries the four queries' values; NW*64 float4 per half and round, eight 16-byte loads in flight per thread.
+        const int nvec = (nf * K) >> 2;  // float4 per half table; K is a multiple of 4
         uint32_t* tw = reinterpret_cast<uint32_t*>(tab);
+#pragma unroll 1
+        for (int e = tid; e < nvec; e += NW * 64) {
+            float4 v[G][2];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e = i * NW * 64 + tid;
-            if (e < nvec) {
-                const int j = (4 * e) / K, k0 = 4 * e - j * K;
+            for (int g = 0; g < G; ++g) {
+                v[g][0] = reinterpret_cast<const float4*>(T32 + (int64_t)tab0[g] * nf * K)[e];
+                v[g][1] = reinterpret_cast<const float4*>(T32 + (int64_t)tab1[g] * nf * K)[e];
+            }
+            const int j = (4 * e) / K, k0 = 4 * e - j * K;
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
+            for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        uint32_t qv[G];
+                for (int c = 0; c < 4; ++c) {
+                    uint32_t qv[G];
 #pragma unroll
-                        for (int g = 0; g < G; ++g) {
-                            const float4 q = v[i][g][s2];
-                            const float x = c == 0 ? q.x : (c == 1 ? q.y : (c == 2 ? q.z : q.w));
-                            qv[g] = (g < ng) ? (uint32_t)(x * qinv[g]) : CAP;  // truncation: a lower bound of x * qinv
-                            qv[g] = qv[g] > CAP ? CAP : qv[g];                 // (NaN / garbage guard; never taken for finite tables)
-                        }
-                        u32x2_t pk;
-                        pk[0] = qv[0] | (qv[1] << 16);
-                        pk[1] = qv[2] | (qv[3] << 16);
-                        *reinterpret_cast<u32x2_t*>(tw + (((k0 + c) * M + s2 * nf + j) << 1)) = pk;
+                    for (int g = 0; g < G; ++g) {
+                        const float4 q = v[g][s2];
+                        const float x = c == 0 ? q.x : (c == 1 ? q.y : (c == 2 ? q.z : q.w));
+                        qv[g] = (g < ng) ? (uint32_t)(x * qinv[g]) : CAP;  // truncation: a lower bound of x * qinv
+                        qv[g] = qv[g] > CAP ? CAP : qv[g];                 // (NaN / garbage guard; never taken for finite tables)
                     }
+                    u32x2_t pk;
+                    pk[0] = qv[0] | (qv[1] << 16);
+                    pk[1] = qv[2] | (qv[3] << 16);
+                    *reinterpret_cast<u32x2_t*>(tw + (((k0 + c) * M + s2 * nf + j) << 1)) = pk;
                 }
             }
         }
     }
+    S3_CTR(1, S3_CLK() - c0);
     __syncthreads();
     S3_CTR(3, S3_CLK() - c0);
     const RotConsts<M> rc = make_rot<M>(lane);
@@ -536,8 +522,6 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
         const int nbytes = __builtin_amdgcn_readfirstlane(len * M);
         rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)bhi << 32) | blo), 0, nbytes, 0x00020000);
     }
-    const uint32_t* thr_words = &sh[0].thr;
-    constexpr int THR_STRIDE = sizeof(Scan3Shared) / 4;
     CodeWords<M> nxt[U];
     if (w < nit) {
 #pragma unroll
@@ -554,44 +538,69 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
         }
         u32x2_t d[U];
         {
-            u32x2_t fbuf[2][M];
-            adc16_issue<M>(cur[0], tab, rc, fbuf[0]);
+            // U * NU units; the reads of unit q+1 are issued before the adds of unit q
+            u32x2_t fbuf[2][OCT];
+            uint32_t D[2][(M + 3) / 4];
+            rot_words<M>(cur[0], rc, D[0]);
+            adc16_issue<M, OCT>(D[0], 0, tab, rc, fbuf[0]);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (u + 1 < U) adc16_issue<M>(cur[u + 1], tab, rc, fbuf[(u + 1) & 1]);
+            for (int q = 0; q < U * NU; ++q) {
+                const int u = q / NU, o = q % NU;
+                if (q + 1 < U * NU) {
+                    const int u1 = (q + 1) / NU, o1 = (q + 1) % NU;
+                    if (o1 == 0) rot_words<M>(cur[u1], rc, D[u1 & 1]);
+                    adc16_issue<M, OCT>(D[u1 & 1], o1, tab, rc, fbuf[(q + 1) & 1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                d[u] = adc16_reduce<M>(fbuf[u & 1]);
+                const u32x2_t part = adc16_sum<OCT>(fbuf[q & 1]);
+                if (o == 0) {
+                    d[u] = part;
+                } else {
+                    d[u][0] = pk_add_u16(d[u][0], part[0]);
+                    d[u][1] = pk_add_u16(d[u][1], part[1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // thresholds of the four queries, packed like the sums; thr + 1 - s, saturated at 0, is non-zero iff s <= thr
-        uint32_t th[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) th[g] = lds_ld(thr_words + g * THR_STRIDE);
-        const uint32_t t01 = (th[0] + 1u) | ((th[1] + 1u) << 16), t23 = (th[2] + 1u) | ((th[3] + 1u) << 16);
+        // thresholds + 1 of the four queries, packed like the sums: (thr + 1) - s, saturated at 0, is non-zero iff s <= thr
+        const u32x2_t tpk = *reinterpret_cast<const volatile u32x2_t*>(thr1);
         unsigned long long anym[U];
         unsigned long long any = 0ull;
-        const bool tail = base + 64 * U > len;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t x = pk_subsat_u16(t01, d[u][0]) | pk_subsat_u16(t23, d[u][1]);
-            anym[u] = __ballot(x != 0u && (!tail || base + u * 64 + lane < len));
-            any |= anym[u];
+            const uint32_t x = pk_subsat_u16(tpk[0], d[u][0]) | pk_subsat_u16(tpk[1], d[u][1]);
+            anym[u] = __ballot(x != 0u);
         }
-        if (any == 0ull) continue;  // the usual case: nothing in these 64*U candidates beats a bound
-        unsigned long long pm[U][G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const unsigned long long dup_on = (any_dup && has_dup[g]) ? ~0ull : 0ull;
+        if (base + 64 * U > len) {  // last iteration: lanes past the end of the chunk (wave-uniform masks)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                const int n = len - base - u * 64;
+                anym[u] &= n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) any |= anym[u];
+        if (any == 0ull) continue;  // nothing in these 64*U candidates beats a bound
+        const uint32_t s01 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tpk[0]);
+        const uint32_t s23 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tpk[1]);
+        unsigned long long pm[U][G];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (anym[u] == 0ull) {  // scalar branch: passes are sparse, most rows of an iteration have none
+#pragma unroll
+                for (int g = 0; g < G; ++g) pm[u][g] = 0ull;
+                continue;
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
                 const uint32_t sg = (g & 1) ? (d[u][g >> 1] >> 16) : (d[u][g >> 1] & 0xffffu);
-                pm[u][g] = __ballot(sg <= th[g]) & anym[u];
+                const uint32_t t1 = (g & 1) ? ((g >> 1) ? s23 >> 16 : s01 >> 16) : ((g >> 1) ? s23 & 0xffffu : s01 & 0xffffu);
+                pm[u][g] = __ballot(sg < t1) & anym[u];
                 if (any_dup) {  // wave-uniform, rare: later copies of a code that already lost a tie-break
                     bool same = true;
 #pragma unroll
                     for (int i = 0; i < (M + 3) / 4; ++i) same = same && (cur[u].w[i] == dup[g].w[i]);
-                    pm[u][g] &= ~(__ballot(same) & dup_on);
+                    pm[u][g] &= ~(__ballot(same) & (has_dup[g] ? ~0ull : 0ull));
                 }
             }
         }
@@ -599,7 +608,6 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
         for (int g = 0; g < G; ++g) {
             if (g >= ng) break;
             uint32_t* rk = rk_all + (g * NW + w) * R;
-            uint32_t* tr = tr_all + (g * NW + w) * 64;
             int ntot = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) ntot += __popcll(pm[u][g]);
@@ -608,17 +616,14 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
                 const uint32_t sg = (g & 1) ? (d[u][g >> 1] >> 16) : (d[u][g >> 1] & 0xffffu);
                 return (sg << 16) | (uint32_t)(base + u * 64 + lane);
             };
-            if (cnt[g] + ntot <= R) {
-                // everything fits: straight-line code, the lanes that did not pass store into a scratch slot of their own
-                const int trash = (int)(tr - rk) + lane;
+            if (cnt[g] + ntot <= R) {  // everything fits: only the rows that have a pass touch the region
                 int c = cnt[g];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const unsigned long long m = pm[u][g];
+                    if (m == 0ull) continue;
                     const int idx = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, c));
-                    int sel;
-                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel) : "v"(trash), "v"(idx), "s"(m));
-                    rk[sel] = entry(u);
+                    if ((m >> lane) & 1ull) rk[idx] = entry(u);
                     c += __popcll(m);
                 }
                 cnt[g] = c;
@@ -661,6 +666,7 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
                 }
                 cnt[g] = c2;
                 const uint32_t thg = lds_ld(&sh[g].thr);
+                if (lane == 0) st16(&thr1[g], thg + 1u);  // the hot loop's copy (a stale overwrite only leaves it looser for a while)
                 const unsigned long long dup_on = has_dup[g] ? ~0ull : 0ull;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -684,20 +690,21 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
         if (cnt[g] > 0) cnt[g] = wave_compact3<M, NR, NW>(rk, cnt[g], L, Lw, NR * 64, load_scale(&sh[g]), &sh[g], w);
     }
     S3_CTR(5, S3_CLK() - c0);
-    __syncthreads();
+    if constexpr (NW > 1) __syncthreads();
     S3_CTR(6, S3_CLK() - c0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         if (g >= ng) break;
         uint32_t* rk = rk_all + (g * NW + w) * R;
-        cnt[g] = wave_filter3<NR, NW>(rk, cnt[g], load_scale(&sh[g]), &sh[g]);
+        const QScale qsg = load_scale(&sh[g]);
+        if constexpr (NW > 1) cnt[g] = wave_filter3<NR, NW>(rk, cnt[g], qsg, &sh[g]);  // one wave: its own cut was the block bound
         if (lane == 0) sh[g].wcnt[w] = cnt[g];
         if (tid == 0) {
             const uint64_t b = block_bound3<NW>(&sh[g]);
             if (b < sh[g].ext) atomicMin(&qbound[items[item_idx[g]].q], (unsigned long long)b);
         }
     }
-    __syncthreads();
+    if constexpr (NW > 1) __syncthreads();
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         if (g >= ng) break;
@@ -705,14 +712,17 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
         int off = 0, total = 0;
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const int c = sh[g].wcnt[i];
+            const int c = (NW > 1) ? sh[g].wcnt[i] : cnt[g];
             off += (i < w) ? c : 0;
             total += c;
         }
+        // a survivor leaves as (float32 upper bound of its exact distance, rounded up) << 32 | position
+        const double ub = sh[g].ub;
         uint64_t* out = item_surv + (int64_t)item_idx[g] * S + off;  // S = NW * R >= total
         for (int e = lane; e < cnt[g]; e += 64) {
             const uint32_t x = rk[e];
-            out[e] = ((uint64_t)__float_as_uint((float)(x >> 16)) << 32) | (x & 0xffffu);
+            const float hi = __double2float_ru((double)((x >> 16) + (uint32_t)M) * ub);
+            out[e] = ((uint64_t)__float_as_uint(hi) << 32) | (x & 0xffffu);
         }
         if (tid == 0) item_n[item_idx[g]] = total;
     }
@@ -722,17 +732,17 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
 
 // Persistent launch over the slot queues, as k_adc_scan2: (workgroups per CU) x 256 workgroups pull slots (<= 4 work
 // items of one cell chunk) from eight queues, one per XCD; a workgroup whose own queue is empty steals.
-template <int M, int NR, int U, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_adc_scan3(
-    const WorkItem* __restrict__ items, const int* __restrict__ slots, const int* __restrict__ n_slots_ptr,
-    const double* __restrict__ T, const float* __restrict__ T32, const uint8_t* __restrict__ codes, int K, int L, int S,
-    int* __restrict__ queue_ctr /* [8], zeroed */, uint64_t* __restrict__ item_surv, int* __restrict__ item_n,
+template <int M, int NR, int U, int NW, int WPE>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_adc_scan3(
+    const WorkItem* __restrict__ items, const TabDesc* __restrict__ tabs, const int* __restrict__ slots,
+    const int* __restrict__ n_slots_ptr, const double* __restrict__ T, const float* __restrict__ T32,
+    const uint8_t* __restrict__ codes, int K, int L, int S, int* __restrict__ queue_ctr /* [8], zeroed */,
+    uint64_t* __restrict__ item_surv, int* __restrict__ item_n, float* __restrict__ item_slack,
     unsigned long long* __restrict__ qbound /* [nq], +inf */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int G = S3G;
     constexpr int R = NR * 64 - 8;
-    int* s_next = reinterpret_cast<int*>(smem + (size_t)K * M * G * 2 + (size_t)G * NW * (R + 64) * 4 + G * sizeof(Scan3Shared) +
-                                         (size_t)G * NW * sizeof(float));
+    int* s_next = reinterpret_cast<int*>(smem + (size_t)K * M * G * 2 + (size_t)G * NW * R * 4 + G * sizeof(Scan3Shared) + 16);
     const int* qs = n_slots_ptr + 8;  // [9] queue starts, written by the slot builder
     const int home = blockIdx.x & 7;
     const long long k0 = S3_CLK();
@@ -742,10 +752,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         const int count = qs[x + 1] - qstart;
         while (true) {
             const long long q0 = S3_CLK();
-            __syncthreads();  // previous slot fully written out; LDS may be reused
-            if (threadIdx.x == 0) *s_next = atomicAdd(&queue_ctr[x], 1);
-            __syncthreads();
-            const int j = __builtin_amdgcn_readfirstlane(*s_next);  // wave-uniform: everything derived from it stays scalar
+            int j;
+            if constexpr (NW > 1) {
+                __syncthreads();  // previous slot fully written out; LDS may be reused
+                if (threadIdx.x == 0) *s_next = atomicAdd(&queue_ctr[x], 1);
+                __syncthreads();
+                j = __builtin_amdgcn_readfirstlane(*s_next);  // wave-uniform: everything derived from it stays scalar
+            } else {
+                int t = 0;
+                if (threadIdx.x == 0) t = atomicAdd(&queue_ctr[x], 1);
+                j = __builtin_amdgcn_readfirstlane(t);
+            }
             S3_CTR(8, S3_CLK() - q0);
             if (j >= count) break;
             const int slot = qstart + j;
@@ -773,11 +790,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                             if (gg == g2) oi[g] = idx[gg];
                     }
                     if (g2 > 0) __syncthreads();
-                    scan3_group<M, NR, U, NW>(items, oi, 1, T, T32, codes, K, L, S, item_surv, item_n, qbound, smem);
+                    scan3_group<M, NR, U, NW>(items, tabs, oi, 1, T, T32, codes, K, L, S, item_surv, item_n, item_slack, qbound, smem);
                 }
                 continue;
             }
-            scan3_group<M, NR, U, NW>(items, idx, ng, T, T32, codes, K, L, S, item_surv, item_n, qbound, smem);
+            scan3_group<M, NR, U, NW>(items, tabs, idx, ng, T, T32, codes, K, L, S, item_surv, item_n, item_slack, qbound, smem);
         }
     }
     S3_CTR(9, S3_CLK() - k0);
@@ -788,41 +805,58 @@ bool scan3_supported(int M, int K, int L) {
     return (M == 4 || M == 8 || M == 16) && K <= 256 && K % 4 == 0 && L >= 1 && L <= 440;
 }
 
-Scan3Geom scan3_geom(int M, int K, int L) {
+// NW = waves per workgroup: every wave of a workgroup pays one compaction per query when its region first fills and
+// one at the end of the chunk, so short chunks want few waves (less of the chunk's time goes to selection), long ones
+// four (more waves share one 16 KB table set).
+Scan3Geom scan3_geom(int M, int K, int L, int64_t avg_chunk) {
     Scan3Geom g;
     const int NR = (L <= 184) ? 4 : 8;
     g.G = S3G;
-    g.NW = 4;
+    g.NW = 4;  // measured (profiles/r02c_scan3_nw.txt): 2 and 1 waves lose more to latency than they save in selections
+    (void)avg_chunk;
+    if (const char* e = getenv("CIS_SCAN3_NW")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) g.NW = v;
+    }
     g.U = 4;
     g.S = g.NW * (NR * 64 - 8);
-    g.lds = (size_t)K * M * g.G * 2 + (size_t)g.G * g.NW * (NR * 64 - 8 + 64) * 4 + g.G * sizeof(Scan3Shared) +
-            (size_t)g.G * g.NW * sizeof(float) + 16;
+    g.lds = (size_t)K * M * g.G * 2 + (size_t)g.G * g.NW * (NR * 64 - 8) * 4 + g.G * sizeof(Scan3Shared) + 16 + 16;
     return g;
 }
 
-template <int M, int NR>
-static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
-                           const int* n_slots, const double* T, const float* T32, const uint8_t* codes, int K, int L, int* qctr,
-                           uint64_t* hits, int* hitn, unsigned long long* qbound) {
-    constexpr int NW = 4, U = 4;
-    const int per_cu = (int)(163840 / g.lds) < (16 / NW) ? (int)(163840 / g.lds) : (16 / NW);
+template <int M, int NR, int NW>
+static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const TabDesc* tabs,
+                           const int* slots, const int* n_slots, const double* T, const float* T32, const uint8_t* codes, int K,
+                           int L, int* qctr, uint64_t* hits, int* hitn, float* slack, unsigned long long* qbound) {
+    constexpr int U = 4;
+    // waves per SIMD the kernel is compiled for (register budget): what the LDS footprint lets a CU hold anyway
+    constexpr int WPE = M == 16 ? (NW == 4 ? 3 : 2) : (NW == 4 ? 4 : (NW == 2 ? 3 : 2));
+    const int by_lds = (int)(163840 / g.lds), by_waves = (WPE * 4) / NW;
+    const int per_cu = by_lds < by_waves ? by_lds : by_waves;
     const int64_t resident = 256 * (per_cu < 1 ? 1 : per_cu);  // persistent grid: what the chip can hold
     const int64_t want = (n_items + g.G - 1) / g.G + 8;
     const unsigned grid = (unsigned)(want < resident ? ((want + 7) / 8) * 8 : resident);
-    hipLaunchKernelGGL((k_adc_scan3<M, NR, U, NW>), dim3(grid), dim3(NW * 64), g.lds, st, items, slots, n_slots, T, T32, codes, K, L,
-                       g.S, qctr, hits, hitn, qbound);
+    hipLaunchKernelGGL((k_adc_scan3<M, NR, U, NW, WPE>), dim3(grid), dim3(NW * 64), g.lds, st, items, tabs, slots, n_slots, T, T32,
+                       codes, K, L, g.S, qctr, hits, hitn, slack, qbound);
 }
 
-void launch_scan3(int M, const Scan3Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
-                  const int* n_slots, const double* T, const float* T32, const uint8_t* codes, int K, int L, int* qctr,
-                  uint64_t* hits, int* hitn, unsigned long long* qbound) {
-#define CIS_S3(MM)                                                                                                              \
-    do {                                                                                                                        \
-        if (L <= 184) launch_scan3_t<MM, 4>(g, n_items, st, items, slots, n_slots, T, T32, codes, K, L, qctr, hits, hitn, qbound);  \
-        else launch_scan3_t<MM, 8>(g, n_items, st, items, slots, n_slots, T, T32, codes, K, L, qctr, hits, hitn, qbound);           \
+void launch_scan3(int M, const Scan3Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const TabDesc* tabs,
+                  const int* slots, const int* n_slots, const double* T, const float* T32, const uint8_t* codes, int K, int L,
+                  int* qctr, uint64_t* hits, int* hitn, float* slack, unsigned long long* qbound) {
+#define CIS_S3_NW(MM, RR)                                                                                                                       \
+    do {                                                                                                                                        \
+        if (g.NW == 4) launch_scan3_t<MM, RR, 4>(g, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, hits, hitn, slack, qbound);      \
+        else if (g.NW == 2) launch_scan3_t<MM, RR, 2>(g, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, hits, hitn, slack, qbound); \
+        else launch_scan3_t<MM, RR, 1>(g, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, hits, hitn, slack, qbound);                \
+    } while (0)
+#define CIS_S3(MM)                   \
+    do {                             \
+        if (L <= 184) CIS_S3_NW(MM, 4); \
+        else CIS_S3_NW(MM, 8);       \
     } while (0)
     if (M == 4) CIS_S3(4);
     else if (M == 8) CIS_S3(8);
     else CIS_S3(16);
 #undef CIS_S3
+#undef CIS_S3_NW
 }

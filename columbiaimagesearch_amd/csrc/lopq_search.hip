@@ -610,7 +610,7 @@ static void launch_tables(int64_t n_tabs, size_t tab_lds, hipStream_t st, const 
 
 template <int W>
 __global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict__ px /* [ntab][h] */,
-                                                        const TabDesc* __restrict__ tabs, int n_tabs,
+                                                        TabDesc* __restrict__ tabs, int n_tabs,
                                                         const double* __restrict__ subs, int h, int nf, int K,
                                                         double* __restrict__ T /* [ntab][nf][K] */,
                                                         float* __restrict__ T32 /* [ntab][nf][K] float32 copy for the scan */,
@@ -630,9 +630,9 @@ __global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict
     }
     if (threadIdx.x < nt) ssplit[threadIdx.x] = tabs[t0 + threadIdx.x].split;
     __syncthreads();
-    if (k >= K) return;
+    const bool on = k < K;  // all lanes stay in the loop: the per-table maximum below is a full-wave reduction
     double sc[W];
-    const double* src = subs + ((int64_t)(z * nf + j) * K + k) * W;
+    const double* src = subs + ((int64_t)(z * nf + j) * K + (on ? k : 0)) * W;
 #pragma unroll
     for (int i = 0; i < W; ++i) sc[i] = src[i];
     for (int t = 0; t < nt; ++t) {
@@ -640,16 +640,27 @@ __global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict
         const double* f = sf[t];
         auto elem = [&](int i) -> double { const double df = f[i] - sc[i]; return df * df; };
         const double v = pw_leaf<double>(elem, 0, W);
-        T[((int64_t)(t0 + t) * nf + j) * K + k] = v;
-        T32[((int64_t)(t0 + t) * nf + j) * K + k] = (float)v;
+        const float v32 = (float)v;
+        if (on) {
+            T[((int64_t)(t0 + t) * nf + j) * K + k] = v;
+            T32[((int64_t)(t0 + t) * nf + j) * K + k] = v32;
+        }
+        // largest float32 entry of the table (entries are >= 0: the bit patterns order like the values), for the
+        // fixed-point scan's scale (lopq_scan3.hip); TabDesc::pad was zeroed when the descriptor was written
+        uint32_t b = on ? __float_as_uint(v32) : 0u, dummy = 0u;
+        wave_minmax_step<1>(dummy, b); wave_minmax_step<2>(dummy, b); wave_minmax_step<4>(dummy, b);
+        wave_minmax_step<8>(dummy, b); wave_minmax_step<16>(dummy, b); wave_minmax_step<32>(dummy, b);
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(&tabs[t0 + t].pad), b);
     }
 }
 
 // float32 copy of the tables for the configurations that do not go through k_tables_from_px
-__global__ void k_tables_f32(const double* __restrict__ T, int64_t n, int nf, int K, float* __restrict__ T32) {
+__global__ void k_tables_f32(const double* __restrict__ T, int64_t n, int nf, int K, float* __restrict__ T32, TabDesc* __restrict__ tabs) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // index into T: (tab, j, k)
     if (e >= n) return;
-    T32[e] = (float)T[e];
+    const float v = (float)T[e];
+    T32[e] = v;
+    atomicMax(reinterpret_cast<unsigned int*>(&tabs[e / ((int64_t)nf * K)].pad), __float_as_uint(v));  // see k_tables_from_px
 }
 
 // ================================================================================================
@@ -1884,7 +1895,9 @@ __global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restr
                                                          double* __restrict__ out_dists, int* __restrict__ out_n,
                                                          int32_t* __restrict__ out_cells, uint32_t* __restrict__ out_pos,
                                                          const PlanOut* __restrict__ plan, int32_t* __restrict__ out_visited,
-                                                         int surv_cut /* the survivors' high words are float32 distances comparable across the query's lists */) {
+                                                         const float* __restrict__ item_slack /* null: the survivors' high words are float32
+                                                         distances within eps of the exact ones (k_adc_scan2); else they are upper bounds of
+                                                         the exact distances, at most item_slack[item] above them (k_adc_scan3) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wq;
@@ -1932,14 +1945,22 @@ __global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restr
                 mx = (valid[i] && hi[i] > mx) ? hi[i] : mx;
             }
             uint32_t thr = 0xffffffffu;
-            if (n_total > limit && surv_cut) {
+            float vub = __int_as_float(0x7f800000);  // scan3 survivors: a distance that `limit` of them do not exceed
+            float sl[4] = {0.f, 0.f, 0.f, 0.f};
+            if (n_total > limit) {
                 wave_minmax_step<1>(mn, mx); wave_minmax_step<2>(mn, mx); wave_minmax_step<4>(mn, mx);
                 wave_minmax_step<8>(mn, mx); wave_minmax_step<16>(mn, mx); wave_minmax_step<32>(mn, mx);
                 mn = (uint32_t)__builtin_amdgcn_readfirstlane((int)mn);
                 mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
                 const uint32_t v = wave_kth_bisect<NE>(hi, valid, mn, mx, limit);
-                const float margin = 1.0f + 3.0f * (2.0f * (float)MT * 5.9604645e-8f);
-                thr = __float_as_uint(__double2float_ru((double)__uint_as_float(v) * (double)margin));
+                if (item_slack) {
+                    vub = __uint_as_float(v);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sl[i] = (i < n_lists) ? item_slack[first + i] : 0.f;
+                } else {
+                    const float margin = 1.0f + 3.0f * (2.0f * (float)MT * 5.9604645e-8f);
+                    thr = __float_as_uint(__double2float_ru((double)__uint_as_float(v) * (double)margin));
+                }
             }
             int kept = 0;
             int idx[NE];
@@ -1947,6 +1968,10 @@ __global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restr
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
                 keep[i] = valid[i] && hi[i] <= thr;
+                if (item_slack) {  // strictly worse than `limit` others only if even its lower bound is above vub
+                    const float s_i = li[i] == 0 ? sl[0] : (li[i] == 1 ? sl[1] : (li[i] == 2 ? sl[2] : sl[3]));
+                    keep[i] = valid[i] && ((double)__uint_as_float(hi[i]) - (double)s_i <= (double)vub);  // exact in float64
+                }
                 const unsigned long long m = __ballot(keep[i]);
                 idx[i] = kept + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
                 kept += __popcll(m);
@@ -2150,6 +2175,7 @@ struct cis_index {
     DevBuf d_codes, d_ids, d_loff, d_gcount;
     int64_t n_local = 0;
     // per-batch workspace
+    DevBuf w_slack;  // per work item: see k_merge_survivors
     DevBuf w_xp, w_cd, w_order, w_sorted, w_plan, w_off, w_items, w_tabs, w_T, w_hits, w_hitn, w_part, w_q,
         w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos, w_order2, w_px, w_T32, w_grp, w_tord;
     int64_t stats[4] = {0, 0, 0, 0};
@@ -2196,7 +2222,7 @@ extern "C" void cis_index_destroy(cis_index* ix) {
     if (ix->m) (void)hipSetDevice(ix->m->device);
     DevBuf* bufs[] = {&ix->d_codes, &ix->d_ids, &ix->d_loff, &ix->d_gcount, &ix->w_xp, &ix->w_cd, &ix->w_order,
                       &ix->w_sorted, &ix->w_plan, &ix->w_off, &ix->w_items, &ix->w_tabs, &ix->w_T, &ix->w_hits,
-                      &ix->w_hitn, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
+                      &ix->w_hitn, &ix->w_slack, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
                       &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px, &ix->w_T32, &ix->w_grp, &ix->w_tord};
     for (DevBuf* b : bufs) b->release();
     if (ix->h_totals) (void)hipHostFree(ix->h_totals);
@@ -3201,8 +3227,11 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     // scan v3 (16-bit fixed-point tables, four queries per workgroup) for large batches; its region entries hold 16-bit
     // positions, so a chunk is at most 65536 candidates.  scan_mode 3 forces it for any batch size (tests).
     static const int env_scan = getenv("CIS_FORCE_SCAN") ? atoi(getenv("CIS_FORCE_SCAN")) : 0;  // A/B runs: 2 or 3
+    // Automatic routing picks it where it measured faster than k_adc_scan2 (profiles/r02*): short cells (a batch that
+    // visits about quota / (n_total / cells) + 1 cells per query, each shorter than 8192 codes) at M <= 8.
+    const bool short_cells = ix->nonempty_cells > 0 && ix->n_total / ix->nonempty_cells < 8192 && M <= 8;
     const bool use3 = !ix->force_exact_scan && scan3_supported(M, K, L) && !use_all_path(ix, M, K, L, nq) &&
-                      (ix->force_scan3 || (nq >= 256 && !ix->force_scan2 && env_scan == 3));  // opt-in until it beats k_adc_scan2 on every shape
+                      (ix->force_scan3 || (nq >= 256 && !ix->force_scan2 && (env_scan == 3 || (env_scan == 0 && short_cells))));
     const int seg_max = use3 ? (nq >= 64 ? 65536 : 4096) : (nq >= 1024 ? (1 << 20) : (nq >= 64 ? 16384 : 4096));
     CIS_TRY(cis_launch_sqdist_both(m, xc, ct, nq, ix->w_cd.p, st));
     const size_t plan_lds = (size_t)V * sizeof(int);
@@ -3301,9 +3330,11 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     const bool big = use_all_path(ix, M, K, L, nq);  // ranked over all candidates' exact distances (below)
     const bool fast = scan2_supported(M, K, L) && !ix->force_exact_scan;
     const Scan2Geom geom = scan2_geom(M, K, L, nq);
-    const int S = fast ? geom.S : L;  // hit slots per work item (fast kernel: <= L per wave)
+    const Scan3Geom geom3 = scan3_geom(M, K, L, n_items > 0 ? n_cand_all / n_items : 0);
+    const int S = fast ? (use3 ? geom3.S : geom.S) : L;  // hit slots per work item (fast kernels: a full region per wave)
     if (!big) CIS_TRY(ix->w_hits.reserve((size_t)(n_items + 1) * S * (fast ? sizeof(uint64_t) : sizeof(cis_hit))));
     CIS_TRY(ix->w_hitn.reserve((size_t)(n_items + 1) * 2 * sizeof(int)));
+    if (use3) CIS_TRY(ix->w_slack.reserve((size_t)(n_items + 1) * sizeof(float)));
     WorkItem* items = ix->w_items.as<WorkItem>();
     TabDesc* tabs = ix->w_tabs.as<TabDesc>();
     CIS_TRY(ix->w_tord.reserve((size_t)(n_tabs + 1) * sizeof(int)));
@@ -3343,7 +3374,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         }
     } else if (fast && n_tabs > 0) {
         const int64_t ne = n_tabs * nf * K;
-        hipLaunchKernelGGL(k_tables_f32, dim3((unsigned)ceil_div(ne, 256)), dim3(256), 0, st, T, ne, nf, K, T32);
+        hipLaunchKernelGGL(k_tables_f32, dim3((unsigned)ceil_div(ne, 256)), dim3(256), 0, st, T, ne, nf, K, T32, tabs);
     }
     if (big) {
         // 4'. every candidate's exact distance; then per query either a radix select of the `limit` best (ranked in LDS
@@ -3437,7 +3468,6 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (fast) {
             // slot list: work items grouped by coarse cell (counting sort; skipped for huge V), G per slot
             const bool sort_items = ix->ncells <= 65536;
-            const Scan3Geom geom3 = scan3_geom(M, K, L);
             const int G = use3 ? geom3.G : geom.G;
             const int64_t nkeys = 2 * ix->ncells;
             const int64_t max_slots = sort_items ? (n_items + nkeys) / G + nkeys + 2 : n_items;
@@ -3464,7 +3494,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             }
             CIS_TRY(mark(5));
             if (use3)
-                launch_scan3(M, geom3, n_items, st, items, slots, n_slots, T, T32, codes, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, qbound);
+                launch_scan3(M, geom3, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, ix->w_slack.as<float>(), qbound);
             else
                 launch_scan2(M, geom, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, qbound);
         }
@@ -3491,11 +3521,11 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (many)                                                                                                            \
             hipLaunchKernelGGL((k_merge_survivors<CAP, MT, 8>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), (size_t)4 * CAP * 16, st, \
                                surv, hitn, item_off, items, T, codes, ids, nq, M, K, L, S, out.hits, out.ids, out.dists,     \
-                               out.n_found, out.cells, out.pos, plan, out.visited, use3 ? 0 : 1);                            \
+                               out.n_found, out.cells, out.pos, plan, out.visited, use3 ? ix->w_slack.as<float>() : (const float*)nullptr);                            \
         else                                                                                                                 \
             hipLaunchKernelGGL((k_merge_survivors<CAP, MT, 4>), dim3((unsigned)ceil_div(nq, 4)), dim3(256), (size_t)4 * CAP * 16, st, \
                                surv, hitn, item_off, items, T, codes, ids, nq, M, K, L, S, out.hits, out.ids, out.dists,     \
-                               out.n_found, out.cells, out.pos, plan, out.visited, use3 ? 0 : 1);                            \
+                               out.n_found, out.cells, out.pos, plan, out.visited, use3 ? ix->w_slack.as<float>() : (const float*)nullptr);                            \
     } while (0)
 #define CIS_MERGE_SURV_M(CAP)                                                                          \
     do {                                                                                               \

@@ -230,7 +230,7 @@ __device__ __forceinline__ CodeWords<M> load_code_buf(__amdgpu_buffer_rsrc_t rs,
 // ---- ADC scan v3 (lopq_scan3.hip): 16-bit fixed-point tables, four queries per workgroup ---------------------------
 struct Scan3Geom { int G, NW, U, S; size_t lds; };
 bool scan3_supported(int M, int K, int L);
-Scan3Geom scan3_geom(int M, int K, int L);
-void launch_scan3(int M, const Scan3Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
-                  const int* n_slots, const double* T, const float* T32, const uint8_t* codes, int K, int L, int* qctr,
-                  uint64_t* hits, int* hitn, unsigned long long* qbound);
+Scan3Geom scan3_geom(int M, int K, int L, int64_t avg_chunk /* candidates per work item of the batch */);
+void launch_scan3(int M, const Scan3Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const TabDesc* tabs,
+                  const int* slots, const int* n_slots, const double* T, const float* T32, const uint8_t* codes, int K, int L,
+                  int* qctr, uint64_t* hits, int* hitn, float* slack, unsigned long long* qbound);
