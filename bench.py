@@ -188,23 +188,25 @@ def main():
     fine = torch.cat(fine_l)
     torch.cuda.synchronize()
     encode_s = sum(a.elapsed_time(b) for a, b in ev) / 1e3  # without the synthetic data generation
-    if world > 1:
-        from columbiaimagesearch_amd.distributed import all_gather_stack
-        coarse = all_gather_stack(coarse).reshape(-1, 2)
-        fine = all_gather_stack(fine).reshape(-1, fine.shape[1])
     coarse_h = coarse.cpu().numpy().view(np.uint16)
     fine_h = fine.cpu().numpy()
     V = model.V
+    # this rank encoded chunks [first, first + len(my_chunks)): ids are positions in the whole database
+    my_ids = np.arange(my_chunks[0] * chunk_n, (my_chunks[-1] + 1) * chunk_n, dtype=np.int64)
     cell = coarse_h[:, 0].astype(np.int64) * V + coarse_h[:, 1]
     counts = np.bincount(cell, minlength=V * V)
     if use_dist:
-        # cells -> ranks by greedy balance of the cell populations (identical table on every rank)
-        sharded = ShardedSearcher(model, owner=greedy_cell_owner(counts, world))
+        # cells -> ranks by greedy balance of the cell populations: the table must be identical on every rank, so the
+        # per-cell counts are summed over the ranks first (V*V int64); then every code travels ONCE, to its owner
+        ct_all = torch.from_numpy(counts).to(device if backend == "nccl" else "cpu")
+        dist.all_reduce(ct_all)
+        sharded = ShardedSearcher(model, owner=greedy_cell_owner(ct_all.cpu().numpy(), world))
         searcher = sharded.local
+        sharded.add_codes_routed(coarse_h, fine_h, my_ids, dedup=False)
     else:
         sharded = None
         searcher = LOPQSearcherHIP(model)
-    searcher.add_codes_array(coarse_h, fine_h, ids=np.arange(N, dtype=np.int64), dedup=False)
+        searcher.add_codes_array(coarse_h, fine_h, ids=my_ids, dedup=False)
     build_s = time.time() - t_build
 
     # ---- queries (resident in HBM before the timed region) --------------------------------------
@@ -229,9 +231,21 @@ def main():
     t0 = time.perf_counter()
     cand = 0
     out = None
-    for b in range(args.steps):
-        out = step(qbatches[(args.warmup + b) % len(qbatches)])
+    if sharded is None:
+        for b in range(args.steps):
+            out = step(qbatches[(args.warmup + b) % len(qbatches)])
+            cand += searcher.last_stats()["candidates"]
+    else:
+        # steps are independent batches: the exchange + merge of batch b (side stream, RCCL) overlap the partial search
+        # of batch b+1 (compute stream)
+        h = sharded.search_begin(qbatches[args.warmup % len(qbatches)], quota=QUOTA, limit=LIMIT)
         cand += searcher.last_stats()["candidates"]
+        for b in range(1, args.steps):
+            h2 = sharded.search_begin(qbatches[(args.warmup + b) % len(qbatches)], quota=QUOTA, limit=LIMIT)
+            cand += searcher.last_stats()["candidates"]
+            out = sharded.search_end(h)
+            h = h2
+        out = sharded.search_end(h)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

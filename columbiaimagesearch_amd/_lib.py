@@ -54,6 +54,8 @@ _PROTOS = {
     "cis_index_create": (c_int, [POINTER(c_void_p), c_void_p]),
     "cis_index_destroy": (None, [c_void_p]),
     "cis_index_set_shard": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "cis_index_cell_counts": (c_int, [c_void_p, c_void_p]),
+    "cis_index_add_remote_counts": (c_int, [c_void_p, c_void_p]),
     "cis_index_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(c_int64)]),
     "cis_index_size": (c_int64, [c_void_p]),
     "cis_index_get_cell": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, POINTER(c_int64)]),

@@ -2287,6 +2287,29 @@ extern "C" int cis_index_add(cis_index* ix, const int64_t* ids, const uint16_t* 
     return CIS_OK;
 }
 
+// Cell-sharded insert with routed codes (columbiaimagesearch_amd/distributed.py:add_codes_routed): a rank is handed only
+// the codes of the cells it owns; the sizes of the other cells -- which drive the quota cut of every query on every
+// rank (search.py:128-133) -- arrive as per-cell increments summed over the owners.
+extern "C" int cis_index_cell_counts(cis_index* ix, int64_t* counts) {
+    CIS_REQUIRE(ix != nullptr && counts != nullptr, "NULL argument");
+    for (int64_t c = 0; c < ix->ncells; ++c) counts[c] = ix->gcount[c];
+    return CIS_OK;
+}
+
+extern "C" int cis_index_add_remote_counts(cis_index* ix, const int64_t* delta) {
+    CIS_REQUIRE(ix != nullptr && delta != nullptr, "NULL argument");
+    int64_t added = 0;
+    for (int64_t c = 0; c < ix->ncells; ++c) {
+        CIS_REQUIRE(delta[c] >= 0, "negative count for cell %lld", (long long)c);
+        if (ix->owns(c) || delta[c] == 0) continue;
+        ix->gcount[c] += delta[c];
+        added += delta[c];
+    }
+    ix->nb_indexed += added;
+    if (added) ix->dirty = true;
+    return CIS_OK;
+}
+
 // merge pending appends into the host CSR (stable: old items of a cell first, then new ones in
 // arrival order) and refresh the device copy
 static int index_sync(cis_index* ix) {
@@ -3232,6 +3255,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     const bool short_cells = ix->nonempty_cells > 0 && ix->n_total / ix->nonempty_cells < 8192 && M <= 8;
     const bool use3 = !ix->force_exact_scan && scan3_supported(M, K, L) && !use_all_path(ix, M, K, L, nq) &&
                       (ix->force_scan3 || (nq >= 256 && !ix->force_scan2 && (env_scan == 3 || (env_scan == 0 && short_cells))));
+    // (Splitting a shard's cells into chunks so that a cell-sharded index at world = 8 fills the chip again was measured
+    // and lost: 0.516 against 0.306 ms per partial search -- more survivors, colder bounds: profiles/r02d_shard_emulation.txt.)
     const int seg_max = use3 ? (nq >= 64 ? 65536 : 4096) : (nq >= 1024 ? (1 << 20) : (nq >= 64 ? 16384 : 4096));
     CIS_TRY(cis_launch_sqdist_both(m, xc, ct, nq, ix->w_cd.p, st));
     const size_t plan_lds = (size_t)V * sizeof(int);

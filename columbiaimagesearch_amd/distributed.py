@@ -120,6 +120,43 @@ def merge_packed_sorted(parts, off, cnt, nq, L):
     return out
 
 
+def route_codes(coarse, fine, ids, owner, V, group=None):
+    """All-to-all routing of freshly encoded codes to the ranks that own their cells.
+    coarse [n,2] uint16, fine [n,M] uint8, ids [n] int64: THIS rank's slice of the batch (host arrays).  Returns the
+    (coarse, fine, ids) this rank owns, ordered by source rank and, inside a source, in the source's order -- i.e. in
+    the order of the concatenated batch, so that the per-cell insertion order (= the reference's list order,
+    lopq/lopq/search.py:359) is the one a single index would have.  One record is 8 + 4 + M bytes; one collective for
+    the split sizes, one for the records (RCCL send/recv groups on GPUs; the same calls run on gloo)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    coarse = np.ascontiguousarray(np.asarray(coarse).reshape(-1, 2), dtype=np.uint16)
+    n = coarse.shape[0]
+    fine = np.asarray(fine)
+    M = int(fine.shape[-1]) if fine.ndim == 2 else (fine.size // n if n else 0)
+    fine = np.ascontiguousarray(fine.reshape(n, M), dtype=np.uint8)
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    rec = np.zeros((n, 12 + M), dtype=np.uint8)
+    rec[:, :8] = ids.view(np.uint8).reshape(n, 8)
+    rec[:, 8:12] = coarse.view(np.uint8).reshape(n, 4)
+    rec[:, 12:] = fine
+    dst = np.asarray(owner)[coarse[:, 0].astype(np.int64) * V + coarse[:, 1]] if n else np.zeros(0, dtype=np.int64)
+    order = np.argsort(dst, kind="stable")  # records grouped by destination, original order inside a group
+    send_counts = np.bincount(dst, minlength=world).astype(np.int64)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    sc = torch.from_numpy(send_counts).to(dev)
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = rc.cpu().numpy()
+    send = torch.from_numpy(rec[order].reshape(-1)).to(dev)
+    recv = torch.empty(int(recv_counts.sum()) * (12 + M), dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(recv, send, output_split_sizes=[int(c) * (12 + M) for c in recv_counts],
+                           input_split_sizes=[int(c) * (12 + M) for c in send_counts], group=group)
+    got = recv.cpu().numpy().reshape(-1, 12 + M)
+    return (np.ascontiguousarray(got[:, 8:12]).view(np.uint16).reshape(-1, 2), np.ascontiguousarray(got[:, 12:]),
+            np.ascontiguousarray(got[:, :8]).view(np.int64).reshape(-1))
+
+
 class ShardedSearcher(object):
     """LOPQSearcherHIP sharded by coarse cell over the ranks of a torch.distributed group."""
 
@@ -130,13 +167,77 @@ class ShardedSearcher(object):
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.local = LOPQSearcherHIP(model, shard=(self.rank, self.world, owner))
+        self._owner = None if owner is None else np.ascontiguousarray(owner, dtype=np.int32)
+        self._side = None
 
     def add_codes_array(self, coarse, fine, ids=None, dedup=True):
         """Every rank is given ALL codes (it keeps its own cells and counts the rest)."""
         return self.local.add_codes_array(coarse, fine, ids, dedup)
 
+    def add_codes_routed(self, coarse, fine, ids, dedup=True):
+        """Every rank brings ITS slice of a batch (e.g. what it encoded itself); the codes travel once, to the owner of
+        their cell (all-to-all), the owners insert them, and the accepted per-cell counts are summed over the ranks so
+        that every rank ends with the whole cell-size table.  Equivalent to add_codes_array of the concatenated batch
+        (rank 0's slice first) on every rank, at 1/world of the traffic and host work."""
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        L = _lib.lib()
+        V = self.local.model.V
+        owner = self._owner if self._owner is not None else np.arange(V * V) % self.world
+        c, f, i = route_codes(coarse, fine, ids, owner, V, self.group)
+        before = np.zeros(V * V, dtype=np.int64)
+        _lib.check(L.cis_index_cell_counts(self.local._ix, _lib.ptr(before)))
+        added = self.local.add_codes_array(c, f, i, dedup) if c.shape[0] else 0
+        after = np.zeros(V * V, dtype=np.int64)
+        _lib.check(L.cis_index_cell_counts(self.local._ix, _lib.ptr(after)))
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        delta = torch.from_numpy(after - before).to(dev)
+        dist.all_reduce(delta, group=self.group)
+        delta = np.ascontiguousarray(delta.cpu().numpy())
+        _lib.check(L.cis_index_add_remote_counts(self.local._ix, _lib.ptr(delta)))
+        self.local.nb_indexed = int(L.cis_index_size(self.local._ix))
+        return added
+
     def get_nb_indexed(self):
         return self.local.get_nb_indexed()
+
+    # -- pipelined form: the exchange + merge of batch b run on a side stream while the caller launches batch b+1 --------
+    def search_begin(self, q, quota=10, limit=None):
+        """This rank's partial search (asynchronous, current stream).  Returns a handle for search_end."""
+        import torch
+        L = self.local._dev_args(q, quota, limit)[0]
+        p = self.local.search_partial_packed_dev(q, quota=quota, limit=limit)
+        ev = torch.cuda.Event()
+        ev.record()
+        return {"p": p, "ev": ev, "nq": int(q.shape[0]), "L": L}
+
+    def search_end(self, h):
+        """Exchange + merge of a search_begin handle on the side stream; the result tensors are safe to use on the
+        current stream when this returns (it waits for the side stream's event, not for the device)."""
+        import torch
+        from .lopq.search import merge_packed_dev
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        p = h["p"]
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(h["ev"])
+            for t in (p["packed"], p["cnt"], p["visited"]):
+                t.record_stream(self._side)
+            parts, off, cnt_all = exchange_packed(p["packed"], p["cnt"], self.group)
+            if h["L"] <= 512:
+                out = merge_packed_dev(parts, off, cnt_all, h["nq"], h["L"])
+            else:
+                out = merge_packed_sorted(parts, off, cnt_all, h["nq"], h["L"])
+            done = torch.cuda.Event()
+            done.record(self._side)
+        for t in out.values():
+            if hasattr(t, "record_stream"):
+                t.record_stream(cur)
+        cur.wait_event(done)
+        out["visited"] = p["visited"]
+        return out
 
     def search_batch_dev(self, q, quota=10, limit=None, packed=True):
         """packed=True (default): only valid hits travel.  A rank owns 1/world of the cells, so its [nq, L] partial

@@ -132,6 +132,12 @@ void cis_index_destroy(cis_index* ix);
  * multisequence order and quota cut-off without communicating (search.py:128-133).
  * owner = NULL selects cell_id % world.  Must be called on an empty index. */
 int cis_index_set_shard(cis_index* ix, int rank, int world, const int32_t* owner /* [V*V] or NULL */);
+/* Routed insert into a cell-sharded index: cis_index_add is then given only the codes of
+ * the cells this rank owns; cis_index_cell_counts reads the per-cell sizes [V*V] (all shards), and
+ * cis_index_add_remote_counts adds per-cell increments [V*V] for the cells owned by OTHER ranks (entries of owned cells
+ * are ignored), so that every rank keeps the whole cell-size table the quota cut needs (lopq/lopq/search.py:128-133). */
+int cis_index_cell_counts(cis_index* ix, int64_t* counts);
+int cis_index_add_remote_counts(cis_index* ix, const int64_t* delta);
 
 /* add_codes (search.py:325-369): append items in order; with dedup != 0 an id already present in
  * the SAME cell is skipped (first occurrence wins).  *n_added = items counted (all shards). */

@@ -108,3 +108,42 @@ def test_greedy_owner_is_balanced_and_deterministic():
         assert np.array_equal(o1, o2)
         load = np.bincount(o1, weights=counts, minlength=world)
         assert load.max() <= 1.05 * load.mean()
+
+
+def _route_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from columbiaimagesearch_amd.distributed import greedy_cell_owner, route_codes
+        z, X, Q = load_golden("c2")
+        coarse, fine = z["coarse"][:9000], z["fine"][:9000]
+        n, V = coarse.shape[0], 16
+        ids = np.arange(n, dtype=np.int64) * 3 + 1
+        cell = coarse[:, 0].astype(np.int64) * V + coarse[:, 1]
+        owner = greedy_cell_owner(np.bincount(cell, minlength=V * V), world)
+        a, b = rank * n // world, (rank + 1) * n // world
+        c, f, i = route_codes(coarse[a:b], fine[a:b], ids[a:b], owner, V)
+        mine = owner[cell] == rank  # what a single pass over the concatenated batch hands this rank, in batch order
+        ok = np.array_equal(c, coarse[mine]) and np.array_equal(f, fine[mine]) and np.array_equal(i, ids[mine])
+        e = route_codes(coarse[:0], fine[:0], ids[:0], owner, V)  # an empty slice on every rank
+        ok = ok and e[0].shape == (0, 2) and e[1].shape[0] == 0 and e[2].shape == (0,)
+        ret[rank] = (bool(ok), int(mine.sum()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_routed_insert_all_to_all_three_gloo_ranks():
+    """every code travels once, to the owner of its cell, and arrives in batch order."""
+    world = 3
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_route_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert all(ret[r][0] for r in range(world))
+    assert sum(ret[r][1] for r in range(world)) == 9000

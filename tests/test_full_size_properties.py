@@ -158,3 +158,22 @@ def test_checksum_of_checksums_against_the_oracle(world):
         h_gpu.update(hashlib.sha1(np.ascontiguousarray(out["ids"][r]).tobytes()).digest())
     assert h_cpu.hexdigest() == h_gpu.hexdigest()
     assert worst <= 1e-9  # north_star asks 1e-4
+
+
+def test_routed_insert_and_pipelined_sharded_search_rccl():
+    """RCCL process group (world = the visible GPUs, at least 1): routed insert + search_begin/search_end pipeline equal
+    the plain searcher -- tests/tools/sharded_pipeline_check.py, one process per GPU."""
+    import os, subprocess, sys, torch
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = os.path.join(here, "tools", "sharded_pipeline_check.py")
+    ngpu = min(torch.cuda.device_count(), 4)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if ngpu >= 2:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpu), "--master-addr", "127.0.0.1",
+               "--master-port", "29581", script]
+    else:
+        cmd = [sys.executable, script]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-3000:]
+    assert text.count("routed insert + pipelined search ok") == 3, text[-3000:]

@@ -8,9 +8,9 @@ import bench
 from columbiaimagesearch_amd.distributed import greedy_cell_owner
 from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
 from columbiaimagesearch_amd.lopq.search import pack_hits_dev, merge_packed_dev
-model, z = bench.load_model()
+model, z = bench.load_model("c4")
 dev = torch.device("cuda", 0)
-P = bench.mixture_centers(dev)
+P = bench.mixture_centers("descriptor", dev)
 N = 10_000_000; chunk = N // 80
 cs, fs = [], []
 for c in range(80):
@@ -19,7 +19,7 @@ coarse = torch.cat(cs).cpu().numpy().view(np.uint16); fine = torch.cat(fs).cpu()
 cells = coarse[:, 0].astype(np.int64) * model.V + coarse[:, 1]
 counts = np.bincount(cells, minlength=model.V * model.V)
 q = bench.make_queries(bench.gen_chunk(P, 0, chunk, dev), 0, 8192, dev)
-for world in (1, 2, 4, 8):
+for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
     owner = greedy_cell_owner(counts, world)
     s = LOPQSearcherHIP(model, shard=(0, world, owner))
     s.add_codes_array(coarse, fine, ids=np.arange(N, dtype=np.int64), dedup=False)
