@@ -415,6 +415,7 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long c0 = S3_CLK();
+    (void)c0;
     // item_idx[] is wave-uniform (scalar registers); item fields are (re)loaded through scalar loads where they are used
     const WorkItem it0 = items[item_idx[0]];
     {
@@ -746,12 +747,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     const int* qs = n_slots_ptr + 8;  // [9] queue starts, written by the slot builder
     const int home = blockIdx.x & 7;
     const long long k0 = S3_CLK();
+    (void)k0;
     for (int a = 0; a < 8; ++a) {
         const int x = (home + a) & 7;
         const int qstart = qs[x];
         const int count = qs[x + 1] - qstart;
         while (true) {
             const long long q0 = S3_CLK();
+            (void)q0;
             int j;
             if constexpr (NW > 1) {
                 __syncthreads();  // previous slot fully written out; LDS may be reused

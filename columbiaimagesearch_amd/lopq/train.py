@@ -43,6 +43,32 @@ def assign_clusters(data, C, chunk=8192):
     return out
 
 
+ACCUM_BACKEND = "host"  # "hip": covariance accumulations and residual projections on the GPU (csrc/lopq_train.hip)
+
+
+def _group_rows(assign, groups):
+    """Stable order of the rows by group + the group offsets (what cis_train_gram / cis_train_project take)."""
+    order = np.argsort(assign, kind="stable")
+    off = np.concatenate([[0], np.cumsum(np.bincount(assign, minlength=groups))]).astype(np.int64)
+    return order, off
+
+
+def gram_hip(X, assign=None, groups=1):
+    """(G [groups,d,d], S [groups,d]): per-group sums of x x^T and of x, float64, on the GPU."""
+    from .. import _lib
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, d = X.shape
+    if assign is None:
+        off = np.array([0, n], dtype=np.int64)
+    else:
+        order, off = _group_rows(np.asarray(assign, dtype=np.int64), groups)
+        X = np.ascontiguousarray(X[order])
+    G = np.empty((groups, d, d))
+    S = np.empty((groups, d))
+    _lib.check(_lib.lib().cis_train_gram(_lib.ptr(X), n, d, _lib.ptr(off), groups, _lib.ptr(G), _lib.ptr(S)))
+    return G, S
+
+
 def local_rotations(data, C, num_buckets):
     """Per-cluster residual mean and PCA rotation with balanced variance.
     reference: lopq/lopq/model.py:74-206.  Returns (R [V,d,d], mu [V,d], assignments, residuals)."""
@@ -51,16 +77,25 @@ def local_rotations(data, C, num_buckets):
     residuals = np.asarray(data - C[assign], dtype=np.float64)
     R = np.zeros((V, d, d))
     mu = np.zeros((V, d))
+    grams = None
+    if ACCUM_BACKEND == "hip":  # all V accumulators in one launch: the reference's per-sample np.outer loop (:142-155)
+        grams, sums = gram_hip(residuals, assign, V)
+        counts = np.bincount(assign, minlength=V)
     for c in range(V):
-        r = residuals[assign == c]
-        n = r.shape[0]
-        if n > 0:
-            mu[c] = r.sum(axis=0) / n
+        if grams is None:
+            r = residuals[assign == c]
+            n = r.shape[0]
+            if n > 0:
+                mu[c] = r.sum(axis=0) / n
+        else:
+            n = int(counts[c])
+            if n > 0:
+                mu[c] = sums[c] / n
         if n < d:
             logger.warning("Fewer points (%d) than dimensions (%d) in rotation computation for cluster %d", n, d, c)
             eigvals, vecs = np.ones(d), np.eye(d)
         else:
-            A = r.T.dot(r)
+            A = r.T.dot(r) if grams is None else grams[c]
             cov = (A + A.T) / (2.0 * (n - 1)) - np.outer(mu[c], mu[c])
             eigvals, vecs = np.linalg.eigh(cov)
         R[c] = vecs[:, eigenvalue_allocation(num_buckets, eigvals)].T
@@ -69,6 +104,17 @@ def local_rotations(data, C, num_buckets):
 
 def project_to_local(residuals, assign, R, mu):
     """R[a] . (res - mu[a]) for every training residual.  reference: lopq/lopq/model.py:209-234."""
+    if ACCUM_BACKEND == "hip":
+        from .. import _lib
+        V, d = mu.shape
+        order, off = _group_rows(np.asarray(assign, dtype=np.int64), V)
+        X = np.ascontiguousarray(np.asarray(residuals, dtype=np.float64)[order])
+        Y = np.empty_like(X)
+        Rc, mc = np.ascontiguousarray(R, dtype=np.float64), np.ascontiguousarray(mu, dtype=np.float64)
+        _lib.check(_lib.lib().cis_train_project(_lib.ptr(X), X.shape[0], d, _lib.ptr(off), V, _lib.ptr(Rc), _lib.ptr(mc), _lib.ptr(Y)))
+        out = np.empty_like(Y)
+        out[order] = Y
+        return out
     out = np.zeros(residuals.shape)
     for c in np.unique(assign):
         sel = np.nonzero(assign == c)[0]
@@ -127,8 +173,13 @@ def train_pca(data, pca_dims=256, pca_subsample=None):
     n, D = data.shape
     pca_dims = min(pca_dims, D)
     X = np.asarray(data, dtype=np.float64)
-    mu = X.mean(axis=0)
-    A = X.T.dot(X) / (n - 1) - np.outer(mu, mu)
+    if ACCUM_BACKEND == "hip":  # summed_covar of the reference's per-sample loop (:263-267) as one tiled product
+        G, S = gram_hip(X)
+        mu = S[0] / n
+        A = G[0] / (n - 1) - np.outer(mu, mu)
+    else:
+        mu = X.mean(axis=0)
+        A = X.T.dot(X) / (n - 1) - np.outer(mu, mu)
     E, P = np.linalg.eigh(A)
     E, P = E[-pca_dims:], P[:, -pca_dims:]
     P = P[:, eigenvalue_allocation(2, E)]

@@ -199,6 +199,17 @@ int cis_rerank_dev(const void* d_feats, int f_dtype, int64_t n_feats, int D, con
  * (sum of squared distances, or NULL) refer to the returned centroids. */
 int cis_kmeans(const float* X, int64_t n, int d, int k, int iters, float* centroids, int32_t* assign, double* inertia);
 
+/* Training accumulations on the GPU (csrc/lopq_train.hip), float64, host pointers.  Rows of X [n][d] are sorted by group;
+ * group_off [groups+1] are the row offsets (group_off[0] = 0, group_off[groups] = n).
+ * cis_train_gram:    G[g] = sum_{r in g} x_r x_r^T [groups][d][d] and S[g] = sum x_r [groups][d] (S may be NULL): the np.outer
+ *                    accumulators of the PCA covariance (lopq/lopq/model.py:263-267, one group) and of the per-cluster
+ *                    residual covariances (:142-155).
+ * cis_train_project: Y[r] = R[g] . (x_r - mu[g]) for the rows of group g (compute_local_rotations' projection, :209-234);
+ *                    R [groups][d][d] row-major, mu [groups][d]. */
+int cis_train_gram(const double* X, int64_t n, int d, const int64_t* group_off, int groups, double* G, double* S);
+int cis_train_project(const double* X, int64_t n, int d, const int64_t* group_off, int groups, const double* R,
+                      const double* mu, double* Y);
+
 /* Counters of the last search on this handle (for bench.py's roofline):
  *   stats[0] candidates scanned (sum over queries of retrieved items on this shard)
  *   stats[1] (query, cell) work items   stats[2] ADC tables built   stats[3] scan kernel launches */

@@ -279,6 +279,8 @@ def make_pk(outdir):
             codes_dict[det_ids[i]] = [code.coarse, code.fine]
         with open(os.path.join(sub, "model_%s.pkl" % tag), "wb") as f:
             pickle.dump(m, f, protocol=2)
+        if tag == "lopq":  # the reference's .mat exchange format (lopq/lopq/model.py:712-728), written by the reference
+            m.export_mat(os.path.join(sub, "model_lopq.mat"))
         with open(os.path.join(sub, "codes_%s.pkl" % tag), "wb") as f:
             pickle.dump(codes_dict, f, protocol=2)
         s = LOPQSearcher(m)

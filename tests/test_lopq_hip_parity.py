@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 PCA_FIXTURES = ["c2", "c3", "c3b", "c4", "c3full"]
 ALL = ["tiny", "c1"] + PCA_FIXTURES
 
-_ROUTE_FREE = ("encode", "near_tie", "model_pieces", "selftest", "multisequence", "rerank", "kmeans", "select_path",
+_ROUTE_FREE = ("encode", "near_tie", "model_pieces", "selftest", "multisequence", "rerank", "kmeans", "training", "select_path",
                "large_limit", "fuzz")
 
 
@@ -656,3 +656,49 @@ def test_kmeans_hip_distortion_close_to_sklearn():
         rec = np.stack([m.reconstruct((tuple(c), tuple(f))) for c, f in zip(coarse[:500], fine[:500])])
         errs[backend] = float(((X[:500] - rec) ** 2).sum(1).mean())
     assert errs["hip"] <= 1.1 * errs["sklearn"], errs
+
+
+@pytest.mark.gpu
+def test_training_accumulations_on_gpu_match_host():
+    """SURVEY.md section 8f row 3 beyond k-means: the covariance accumulators (lopq/lopq/model.py:142-155, :263-267) and the
+    per-cluster projection (:209-234) as float64 GPU products -- against numpy (summation order is the only difference), and a
+    model whose rotations / PCA were fitted through them against the host-fitted one (same k-means seeds => same parameters up
+    to that rounding, and the same codes on almost every vector)."""
+    from columbiaimagesearch_amd.lopq import LOPQModelPCA
+    from columbiaimagesearch_amd.lopq import train as T
+    import golden_inputs as gi
+    rs = np.random.RandomState(3)
+    for n, d, groups in ((5000, 24, 1), (7000, 70, 9), (900, 130, 5)):
+        X = rs.randn(n, d) * (1.0 + np.arange(d)) ** -0.3
+        assign = rs.randint(0, groups, n) if groups > 1 else None
+        if groups > 1:
+            assign[assign == 2] = 3  # an empty group
+        G, S = T.gram_hip(X, assign, groups)
+        for g in range(groups):
+            r = X if assign is None else X[assign == g]
+            np.testing.assert_allclose(G[g], r.T.dot(r), rtol=1e-12, atol=1e-10)
+            np.testing.assert_allclose(S[g], r.sum(axis=0), rtol=1e-12, atol=1e-10)
+        if groups > 1:
+            R = rs.randn(groups, d, d)
+            mu = rs.randn(groups, d)
+            T.ACCUM_BACKEND = "hip"
+            try:
+                got = T.project_to_local(X, assign, R, mu)
+            finally:
+                T.ACCUM_BACKEND = "host"
+            np.testing.assert_allclose(got, T.project_to_local(X, assign, R, mu), rtol=1e-11, atol=1e-11)
+    X = gi.descriptor_like(20000, 48, 8, np.float64)
+    models = {}
+    for backend in ("host", "hip"):
+        T.ACCUM_BACKEND = backend
+        try:
+            m = LOPQModelPCA(V=4, M=4, subquantizer_clusters=32, renorm=True)
+            m.fit(X, pca_dims=32, n_init=1, random_state=9)
+        finally:
+            T.ACCUM_BACKEND = "host"
+        models[backend] = m
+    a, b = models["host"], models["hip"]
+    np.testing.assert_allclose(np.abs(a.pca_P), np.abs(b.pca_P), atol=1e-6)  # eigenvectors up to sign
+    ca, fa = a.predict_batch(X[:4000])
+    cb, fb = b.predict_batch(X[:4000])
+    assert (ca != cb).any(axis=1).mean() < 0.01 and (fa != fb).any(axis=1).mean() < 0.05

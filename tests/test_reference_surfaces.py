@@ -84,6 +84,31 @@ def test_oracle_matches_pickled_reference_codes(as_lopq, tag):
         assert tuple(int(v) for v in c) == tuple(coarse[i]) and tuple(int(v) for v in f) == tuple(fine[i])
 
 
+def test_mat_file_written_by_the_reference(as_lopq, tmp_path):
+    """The .mat exchange format (lopq/lopq/model.py:712-746): load_mat reads the file the REFERENCE's export_mat wrote
+    (tests/golden/pk/model_lopq.mat) into the parameters of the reference's pickled model, and export_mat writes the
+    same arrays under the same names."""
+    from scipy.io import loadmat
+    ref_path = os.path.join(PK, "model_lopq.mat")
+    m = as_lopq.LOPQModel.load_mat(ref_path)
+    want = _load("model_lopq.pkl")
+    assert (m.V, m.M, m.subquantizer_clusters) == (want.V, want.M, want.subquantizer_clusters)
+    for s in range(2):
+        np.testing.assert_array_equal(m.Cs[s], want.Cs[s])
+        np.testing.assert_array_equal(m.Rs[s], want.Rs[s])
+        np.testing.assert_array_equal(m.mus[s], want.mus[s])
+        assert len(m.subquantizers[s]) == len(want.subquantizers[s])
+        for a, b in zip(m.subquantizers[s], want.subquantizers[s]):
+            np.testing.assert_array_equal(a, b)
+    out = str(tmp_path / "ours.mat")
+    want.export_mat(out)  # `want` is OUR class (install_as_lopq) holding the reference's parameters
+    ours, ref = loadmat(out), loadmat(ref_path)
+    assert sorted(k for k in ours if not k.startswith("__")) == sorted(k for k in ref if not k.startswith("__"))
+    for k in ("Cs", "Rs", "mus", "subs", "V", "M"):
+        assert ours[k].shape == ref[k].shape and ours[k].dtype == ref[k].dtype, k
+        np.testing.assert_array_equal(ours[k], ref[k])
+
+
 def test_lmdb_searcher_hands_str_to_id_lambda():
     """the production searcher is LOPQSearcherLMDB(model, path, id_lambda=str); ids are sha1
     strings.  get_cell is host-side, so this part runs without a GPU."""
