@@ -72,11 +72,13 @@ __global__ __launch_bounds__(64) void k_plan(const CT* __restrict__ sorted, cons
                                              const int64_t* __restrict__ item_off, const int64_t* __restrict__ tab_off,
                                              WorkItem* __restrict__ items, TabDesc* __restrict__ tabs,
                                              int* __restrict__ grp_cnt /* [2V] */, const int* __restrict__ grp_base /* [2V] */,
-                                             int* __restrict__ grp_cur /* [2V] */, int* __restrict__ tab_order /* [n_tabs] */) {
+                                             int* __restrict__ grp_cur /* [2V] */, int* __restrict__ tab_order /* [n_tabs] */,
+                                             const int* __restrict__ only /* null, or [nq]: walk only the flagged queries (k_plan_par's fallback) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* t = reinterpret_cast<int*>(smem);  // [V]
     const int q = blockIdx.x;
     const int lane = threadIdx.x;
+    if (only && !only[q]) return;
     const CT* d0 = sorted + ((int64_t)q * 2 + 0) * V;
     const CT* d1 = sorted + ((int64_t)q * 2 + 1) * V;
     const uint16_t* o0 = order + ((int64_t)q * 2 + 0) * V;
@@ -170,6 +172,324 @@ __global__ __launch_bounds__(64) void k_plan(const CT* __restrict__ sorted, cons
             tabs[tbase + i] = td;
             const int g = (td.split * V + td.cluster) * GRP_SUB + (q % GRP_SUB);
             tab_order[grp_base[g] + atomicAdd(&grp_cur[g], 1)] = (int)(tbase + i);  // order inside a group does not matter
+        }
+    }
+}
+
+// The same plan for indexes with thousands of coarse clusters (the reference's release configurations use V = 2048 / 4096:
+// millions of tiny cells, hundreds to thousands of cells per query at quota 10000), where one frontier step per visited
+// cell is the whole cost of a search.  The multisequence order is the order of the sums s(i, j) = fl(d0[i] + d1[j]) (rank
+// pairs, both lists ascending): the heap of lopq/lopq/search.py:58-82 holds (s, (i, j)) keys and a cell enters it when both
+// its predecessors (i-1, j), (i, j-1) have been popped.  Those are componentwise smaller, so their keys are smaller too (s is
+// monotone in i and j, the pair breaks ties): by induction everything with a smaller key is popped before a given cell, i.e.
+// the heap's order IS the sorted order of the keys, ties included.  So, per query and with one workgroup:
+//   1. bisection on the VALUE tau (bit patterns order like the non-negative sums): count of {s <= tau} = sum over rows of a
+//      prefix length (binary search along the ascending d1), until about `target` cells are inside;
+//   2. the cells {s <= tau} are enumerated into LDS with the global sizes of their cells and sorted by (s, i, j) (bitonic);
+//   3. a prefix sum of the cell sizes in that order finds the quota cut (search.py:128-133); too few candidates inside ->
+//      target * 4 and again;
+//   4. a band that cannot be cut below what the workgroup sorts (thousands of equal sums), or more visited cells than the
+//      list holds: the query is flagged and the frontier walk above (k_plan with `only`) handles it.
+// The count pass leaves the visited (i, j) list in global memory for the emit pass.
+static const int PLAN_PAR_CAP = 4096;   // cells a workgroup enumerates and sorts
+static const int PLAN_PAR_STAGE = 4096; // d0 / d1 staged in LDS: the kernel takes V <= 4096
+
+// all of d0 / d1 is staged in LDS (V <= PLAN_PAR_STAGE); read in place (no generic pointers to the LDS arrays)
+#define PL0(i) s_d0[(i)]
+#define PL1(i) s_d1[(i)]
+
+template <typename CT, bool EMIT>
+__global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted, const uint16_t* __restrict__ order,
+                                                  const int64_t* __restrict__ gcount, const int64_t* __restrict__ loff,
+                                                  int nq, int V, int64_t quota, int seg_max, PlanOut* __restrict__ plan,
+                                                  const int64_t* __restrict__ item_off, const int64_t* __restrict__ tab_off,
+                                                  WorkItem* __restrict__ items, TabDesc* __restrict__ tabs,
+                                                  int* __restrict__ grp_cnt, const int* __restrict__ grp_base,
+                                                  int* __restrict__ grp_cur, int* __restrict__ tab_order,
+                                                  uint32_t* __restrict__ vis_list /* [nq][vis_cap] (i << 16 | j) in visit order */,
+                                                  int* __restrict__ fallback /* [nq] */, int vis_cap) {
+    __shared__ uint64_t s_key[PLAN_PAR_CAP];
+    __shared__ uint32_t s_ij[PLAN_PAR_CAP];
+    __shared__ uint32_t s_gc[PLAN_PAR_CAP];
+    __shared__ CT s_d0[PLAN_PAR_STAGE], s_d1[PLAN_PAR_STAGE];
+    __shared__ int64_t s_red[8];
+    __shared__ int s_i[8];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const CT* d0 = sorted + ((int64_t)q * 2 + 0) * V;
+    const CT* d1 = sorted + ((int64_t)q * 2 + 1) * V;
+    const uint16_t* o0 = order + ((int64_t)q * 2 + 0) * V;
+    const uint16_t* o1 = order + ((int64_t)q * 2 + 1) * V;
+    uint32_t* vl = vis_list + (int64_t)q * vis_cap;
+    auto block_sum = [&](int64_t v) -> int64_t {  // every thread gets the sum
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if (lane == 0) s_red[wv] = v;
+        __syncthreads();
+        const int64_t t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        // the same value in every lane: say so (scalar registers, uniform branches on it)
+        return ((int64_t)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t);
+    };
+    if constexpr (EMIT) {
+        if (fallback[q]) return;  // the frontier walk emits this query
+        const PlanOut pl = plan[q];
+        const int64_t ibase = item_off[q], tbase = tab_off[q];
+        // items: exclusive scan of the chunk counts of the visited cells, in visit order
+        int run = 0;
+        for (int b0 = 0; b0 < pl.visited; b0 += 256) {
+            const int idx = b0 + tid;
+            int nch = 0, bi = 0, bj = 0;
+            int64_t ls = 0, ll = 0, cell = 0;
+            if (idx < pl.visited) {
+                const uint32_t ij = vl[idx];
+                bi = (int)(ij >> 16); bj = (int)(ij & 0xffff);
+                cell = (int64_t)o0[bi] * V + o1[bj];
+                ls = loff[cell];
+                ll = loff[cell + 1] - ls;
+                nch = ll > 0 ? (int)((ll + seg_max - 1) / seg_max) : 0;
+            }
+            int x = nch;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(x, d);
+                if (lane >= d) x += y;
+            }
+            __syncthreads();
+            if (lane == 63) s_i[wv] = x;
+            __syncthreads();
+            int base = run;
+            for (int w = 0; w < wv; ++w) base += s_i[w];
+            const int pos = base + x - nch;
+            for (int ch = 0; ch < nch; ++ch) {
+                WorkItem it;
+                it.q = q; it.rank = idx;
+                it.tab0 = (int)(tbase + bi);
+                it.tab1 = (int)(tbase + pl.ntab0 + bj);
+                it.pos0 = ch * seg_max;
+                it.cell = (int)cell; it.pad = 0;
+                it.start = ls + (int64_t)ch * seg_max;
+                const int64_t rem = ll - (int64_t)ch * seg_max;
+                it.len = (int)(rem < seg_max ? rem : seg_max);
+                items[ibase + pos + ch] = it;
+            }
+            run += s_i[0] + s_i[1] + s_i[2] + s_i[3];
+        }
+        for (int i = tid; i < pl.ntab0 + pl.ntab1; i += 256) {
+            TabDesc td;
+            td.q = q; td.pad = 0;
+            if (i < pl.ntab0) { td.split = 0; td.cluster = o0[i]; }
+            else { td.split = 1; td.cluster = o1[i - pl.ntab0]; }
+            tabs[tbase + i] = td;
+            const int g = (td.split * V + td.cluster) * GRP_SUB + (q % GRP_SUB);
+            tab_order[grp_base[g] + atomicAdd(&grp_cur[g], 1)] = (int)(tbase + i);
+        }
+        return;
+    } else {
+        const int ns = V < PLAN_PAR_STAGE ? V : PLAN_PAR_STAGE;
+        for (int i = tid; i < ns; i += 256) { s_d0[i] = d0[i]; s_d1[i] = d1[i]; }
+        __syncthreads();
+        // prefix length of row i under tau: #{j : fl(d0[i] + d1[j]) <= tau}
+        auto row_prefix = [&](CT a, uint64_t tau) -> int {
+            int lo = 0, hi = V;  // first j with sum > tau
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (f2bits((CT)(a + PL1(mid))) <= tau) lo = mid + 1;
+                else hi = mid;
+            }
+            return lo;
+        };
+        auto count_le = [&](uint64_t tau) -> int64_t {
+            int64_t c = 0;
+            for (int i = tid; i < V; i += 256) {
+                const CT a = PL0(i);
+                if (f2bits((CT)(a + PL1(0))) > tau) break;  // rows are ascending too
+                c += row_prefix(a, tau);
+            }
+            return block_sum(c);
+        };
+        // Bands of increasing tau: band b holds the cells with tau_{b-1} < s <= tau_b (at most PLAN_PAR_CAP of them), is
+        // sorted on its own and appended to the visited list; the quota prefix sum carries over.
+        bool fb = false, done = false;
+        int visited = 0;
+        int64_t cum = 0, c_prev = 0, target = 256;
+        bool have_prev = false;
+        uint64_t tau_prev = 0;
+        const int64_t all_cells = (int64_t)V * V;
+        const uint64_t s_min = f2bits((CT)(PL0(0) + PL1(0)));
+        const uint64_t s_max = f2bits((CT)(s_d0[V - 1] + s_d1[V - 1]));
+        if (quota <= 0) { target = 1; }  // the test follows the first append (search.py:131-132): one cell
+        while (!done && !fb) {
+            const int64_t left = all_cells - c_prev;
+            if (left <= 0) break;  // every cell visited, quota not reached
+            const int64_t want = target < left ? target : left;
+            // tau with want <= #{tau_prev < s <= tau} <= 2 * want (or the smallest tau that reaches `want` when values repeat)
+            uint64_t lo = have_prev ? tau_prev + 1 : s_min, hi = s_max;
+            int64_t c_hi = all_cells;
+            while (c_hi - c_prev > 2 * want && lo < hi) {
+                const uint64_t mid = lo + ((hi - lo) >> 1);
+                const int64_t c = count_le(mid);
+                if (c - c_prev >= want) { hi = mid; c_hi = c; }
+                else lo = mid + 1;
+            }
+            if (c_hi - c_prev > PLAN_PAR_CAP) { fb = true; break; }
+            const int cnt = (int)(c_hi - c_prev);
+            if (visited + cnt > vis_cap) { fb = true; break; }
+            // enumerate the band.  (a) per row: cells (p_prev, p_hi]; first slot of every row in s_gc[i] (rows in order)
+            int run = 0, rows = 0;
+            for (int b0 = 0; b0 < V; b0 += 256) {
+                const int i = b0 + tid;
+                int p = 0;
+                bool act = false;
+                if (i < V) {
+                    const CT a = PL0(i);
+                    act = f2bits((CT)(a + PL1(0))) <= hi;
+                    if (act) p = row_prefix(a, hi) - (have_prev ? row_prefix(a, tau_prev) : 0);
+                }
+                int x = p;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int y = __shfl_up(x, d);
+                    if (lane >= d) x += y;
+                }
+                __syncthreads();
+                if (lane == 63) s_i[wv] = x;
+                __syncthreads();
+                int base = run;
+                for (int w = 0; w < wv; ++w) base += s_i[w];
+                if (act) s_gc[i] = (uint32_t)(base + x - p);
+                run += s_i[0] + s_i[1] + s_i[2] + s_i[3];
+                const int nact = (int)block_sum(act ? 1 : 0);
+                rows += nact;
+                if (nact < 256) break;  // the active rows are a prefix (ascending d0): this was the last block of them
+            }
+            // (b) one thread per cell: row by binary search over the row starts (the LAST row whose start is <= e is the
+            // one that holds e: empty rows share their start with the next row), then sum, rank pair and GLOBAL cell size
+            constexpr int PER = PLAN_PAR_CAP / 256;
+            uint32_t gsz[PER];
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int e = r * 256 + tid;
+                gsz[r] = 0u;
+                if (e < cnt) {
+                    int lo_ = 0, hi_ = rows;  // first row whose start is > e
+                    while (lo_ < hi_) {
+                        const int mid = (lo_ + hi_) >> 1;
+                        if ((int)s_gc[mid] <= e) lo_ = mid + 1;
+                        else hi_ = mid;
+                    }
+                    const int i = lo_ - 1;
+                    const CT a = PL0(i);
+                    const int j = e - (int)s_gc[i] + (have_prev ? row_prefix(a, tau_prev) : 0);
+                    s_key[e] = f2bits((CT)(a + PL1(j)));
+                    s_ij[e] = ((uint32_t)i << 16) | (uint32_t)j;
+                    const int64_t g = gcount[(int64_t)o0[i] * V + o1[j]];
+                    gsz[r] = g > 0x7fffffffll ? 0x7fffffffu : (uint32_t)g;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int e = r * 256 + tid;
+                if (e < cnt) s_gc[e] = gsz[r];
+            }
+            int ns2 = 256;
+            while (ns2 < cnt) ns2 <<= 1;
+            for (int x = cnt + tid; x < ns2; x += 256) { s_key[x] = ~0ull; s_ij[x] = ~0u; s_gc[x] = 0u; }
+            __syncthreads();
+            for (int k = 2; k <= ns2; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = tid; t < (ns2 >> 1); t += 256) {
+                        const int a_ = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                        const int b_ = a_ + j;
+                        const bool asc = ((a_ & k) == 0);
+                        const uint64_t ka = s_key[a_], kb = s_key[b_];
+                        const uint32_t ia = s_ij[a_], ib = s_ij[b_];
+                        const bool gt = (ka > kb) || (ka == kb && ia > ib);
+                        if (gt == asc) {
+                            s_key[a_] = kb; s_key[b_] = ka; s_ij[a_] = ib; s_ij[b_] = ia;
+                            const uint32_t ga = s_gc[a_]; s_gc[a_] = s_gc[b_]; s_gc[b_] = ga;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            // quota cut inside this band: first position whose inclusive prefix of the cell sizes reaches the quota
+            int64_t run64 = cum;
+            int cut = -1;
+            for (int b0 = 0; b0 < cnt && cut < 0; b0 += 256) {
+                const int idx = b0 + tid;
+                int64_t x = idx < cnt ? (int64_t)s_gc[idx] : 0;
+                const int64_t own = x;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int64_t y = __shfl_up(x, d);
+                    if (lane >= d) x += y;
+                }
+                __syncthreads();
+                if (lane == 63) s_red[wv] = x;
+                if (tid == 0) s_i[4] = 0x7fffffff;
+                __syncthreads();
+                int64_t base = run64;
+                for (int w = 0; w < wv; ++w) base += s_red[w];
+                const int64_t incl = base + x;
+                if (idx < cnt && incl >= quota && incl - own < quota) atomicMin(&s_i[4], idx);
+                const int64_t tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+                __syncthreads();
+                if (s_i[4] != 0x7fffffff) cut = s_i[4];
+                run64 += tot;
+                __syncthreads();
+            }
+            if (quota <= 0) cut = 0;
+            const int take = cut >= 0 ? cut + 1 : cnt;
+            for (int idx = tid; idx < take; idx += 256) vl[visited + idx] = s_ij[idx];
+            visited += take;
+            if (cut >= 0) { done = true; break; }
+            cum = run64;
+            c_prev = c_hi;
+            tau_prev = hi;
+            have_prev = true;
+            target = target * 4 < PLAN_PAR_CAP / 2 ? target * 4 : PLAN_PAR_CAP / 2;
+            __syncthreads();
+        }
+        if (tid == 0) fallback[q] = fb ? 1 : 0;
+        if (fb) return;
+        __threadfence_block();
+        __syncthreads();
+        int64_t n_items = 0, ncand = 0;
+        int max_i = -1, max_j = -1;
+        for (int idx = tid; idx < visited; idx += 256) {
+            const uint32_t ij = vl[idx];
+            const int bi = (int)(ij >> 16), bj = (int)(ij & 0xffff);
+            const int64_t cell = (int64_t)o0[bi] * V + o1[bj];
+            const int64_t ll = loff[cell + 1] - loff[cell];
+            if (ll > 0) {
+                n_items += (ll + seg_max - 1) / seg_max;
+                ncand += ll;
+                max_i = bi > max_i ? bi : max_i;
+                max_j = bj > max_j ? bj : max_j;
+            }
+        }
+        n_items = block_sum(n_items);
+        ncand = block_sum(ncand);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int a = __shfl_xor(max_i, o), b = __shfl_xor(max_j, o);
+            max_i = a > max_i ? a : max_i;
+            max_j = b > max_j ? b : max_j;
+        }
+        __syncthreads();
+        if (lane == 0) { s_i[wv] = max_i; s_i[4 + wv] = max_j; }
+        __syncthreads();
+        max_i = s_i[0]; max_j = s_i[4];
+        for (int w = 1; w < 4; ++w) { max_i = s_i[w] > max_i ? s_i[w] : max_i; max_j = s_i[4 + w] > max_j ? s_i[4 + w] : max_j; }
+        if (tid == 0) {
+            PlanOut p;
+            p.visited = visited; p.n_items = (int)n_items; p.ntab0 = max_i + 1; p.ntab1 = max_j + 1; p.ncand = ncand;
+            plan[q] = p;
+        }
+        for (int i = tid; i < max_i + 1 + max_j + 1; i += 256) {
+            const int g = i <= max_i ? (int)o0[i] : V + (int)o1[i - (max_i + 1)];
+            atomicAdd(&grp_cnt[g * GRP_SUB + (q % GRP_SUB)], 1);
         }
     }
 }
@@ -2176,6 +2496,7 @@ struct cis_index {
     int64_t n_local = 0;
     // per-batch workspace
     DevBuf w_slack;  // per work item: see k_merge_survivors
+    DevBuf w_planfb, w_vis;  // k_plan_par: per-query fallback flags, visited (i, j) lists
     DevBuf w_xp, w_cd, w_order, w_sorted, w_plan, w_off, w_items, w_tabs, w_T, w_hits, w_hitn, w_part, w_q,
         w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos, w_order2, w_px, w_T32, w_grp, w_tord;
     int64_t stats[4] = {0, 0, 0, 0};
@@ -2222,7 +2543,7 @@ extern "C" void cis_index_destroy(cis_index* ix) {
     if (ix->m) (void)hipSetDevice(ix->m->device);
     DevBuf* bufs[] = {&ix->d_codes, &ix->d_ids, &ix->d_loff, &ix->d_gcount, &ix->w_xp, &ix->w_cd, &ix->w_order,
                       &ix->w_sorted, &ix->w_plan, &ix->w_off, &ix->w_items, &ix->w_tabs, &ix->w_T, &ix->w_hits,
-                      &ix->w_hitn, &ix->w_slack, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
+                      &ix->w_hitn, &ix->w_slack, &ix->w_planfb, &ix->w_vis, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
                       &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px, &ix->w_T32, &ix->w_grp, &ix->w_tord};
     for (DevBuf* b : bufs) b->release();
     if (ix->h_totals) (void)hipHostFree(ix->h_totals);
@@ -2848,9 +3169,70 @@ __global__ __launch_bounds__(256) void k_adc_all_lds(const WorkItem* __restrict_
     if (qmin) publish_key_range(mn, mx, qmin, qmax, it.q);
 }
 
+// The same for indexes of tiny cells (thousands of coarse clusters: a query visits hundreds of cells of a few codes each):
+// one workgroup row per QUERY walks the query's candidates as one flat range; a candidate finds its work item by binary
+// search over the items' first-candidate positions (staged in LDS) and reads its table entries from global memory (the
+// query's ~100 half tables are L2-resident).  A workgroup per work item would stage 16 KB of tables for 8 candidates.
+static const int FLAT_ITEMS = 4096;  // work items of a query whose starts fit the LDS stage; above: searched in global memory
+template <int MT>
+__global__ __launch_bounds__(256) void k_adc_all_flat(const WorkItem* __restrict__ items, const int64_t* __restrict__ cand_start,
+                                                      const int64_t* __restrict__ seg, const int64_t* __restrict__ item_off,
+                                                      const double* __restrict__ T, const uint8_t* __restrict__ codes, int M, int K,
+                                                      uint64_t* __restrict__ keys, uint64_t* __restrict__ vals,
+                                                      unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax) {
+    __shared__ int s_start[FLAT_ITEMS];
+    const int q = blockIdx.x;
+    const int64_t it0 = item_off[q], it1 = item_off[q + 1];
+    const int64_t c0 = seg[q], c1 = seg[q + 1];
+    const int ni = (int)(it1 - it0);
+    const int64_t n = c1 - c0;
+    const bool staged = ni <= FLAT_ITEMS;
+    if (staged)
+        for (int i = threadIdx.x; i < ni; i += 256) s_start[i] = (int)(cand_start[it0 + i] - c0);
+    __syncthreads();
+    const int nf = M / 2;
+    uint64_t mn = ~0ull, mx = 0ull;
+    for (int64_t c = (int64_t)blockIdx.y * 256 + threadIdx.x; c < n; c += (int64_t)gridDim.y * 256) {
+        int lo = 0, hi = ni;  // first item whose start is > c; the item before it holds c (empty items never exist)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const int64_t st_ = staged ? (int64_t)s_start[mid] : cand_start[it0 + mid] - c0;
+            if (st_ <= c) lo = mid + 1;
+            else hi = mid;
+        }
+        const int i = lo - 1;
+        const WorkItem it = items[it0 + i];
+        const int p = (int)(c - (staged ? (int64_t)s_start[i] : cand_start[it0 + i] - c0));
+        const double* t0 = T + (int64_t)it.tab0 * nf * K;
+        const double* t1 = T + (int64_t)it.tab1 * nf * K;
+        double d;
+        if constexpr (MT != 0) {
+            const CodeWords<MT> cw = load_code<MT>(codes, it.start + p);
+            d = adc64_words<MT>(cw.w, K, t0, t1);
+        } else {
+            d = adc64_global(codes, it.start + p, M, K, t0, t1);
+        }
+        const uint64_t kk = (uint64_t)__double_as_longlong(d);
+        keys[c0 + c] = kk;
+        mn = kk < mn ? kk : mn;
+        mx = kk > mx ? kk : mx;
+        if (vals) vals[c0 + c] = ((uint64_t)(it0 + i) << 32) | (uint32_t)p;
+    }
+    if (qmin) publish_key_range(mn, mx, qmin, qmax, q);
+}
+
 static void launch_adc_all(int64_t n_items, hipStream_t st, const WorkItem* items, const int64_t* cand_start, const double* T,
                            const uint8_t* codes, int M, int K, uint64_t* keys, uint64_t* vals, unsigned long long* qmin,
-                           unsigned long long* qmax, const int64_t* d_totals = nullptr) {
+                           unsigned long long* qmax, const int64_t* d_totals = nullptr, const int64_t* seg = nullptr,
+                           const int64_t* item_off = nullptr, int nq = 0, bool flat = false) {
+    if (flat && seg && item_off && nq > 0 && !d_totals) {
+        const dim3 gf((unsigned)nq, 8);
+        if (K <= 256 && M == 4) hipLaunchKernelGGL(k_adc_all_flat<4>, gf, dim3(256), 0, st, items, cand_start, seg, item_off, T, codes, M, K, keys, vals, qmin, qmax);
+        else if (K <= 256 && M == 8) hipLaunchKernelGGL(k_adc_all_flat<8>, gf, dim3(256), 0, st, items, cand_start, seg, item_off, T, codes, M, K, keys, vals, qmin, qmax);
+        else if (K <= 256 && M == 16) hipLaunchKernelGGL(k_adc_all_flat<16>, gf, dim3(256), 0, st, items, cand_start, seg, item_off, T, codes, M, K, keys, vals, qmin, qmax);
+        else hipLaunchKernelGGL(k_adc_all_flat<0>, gf, dim3(256), 0, st, items, cand_start, seg, item_off, T, codes, M, K, keys, vals, qmin, qmax);
+        return;
+    }
     const dim3 g((unsigned)n_items, 8);
     const size_t lds = (size_t)M * K * sizeof(double);
     if (K <= 256 && M == 4) hipLaunchKernelGGL(k_adc_all_lds<4>, g, dim3(256), lds, st, items, cand_start, T, codes, K, keys, vals, qmin, qmax, d_totals);
@@ -3173,10 +3555,18 @@ static int small_batch_nq(int L) {
     return 512;
 }
 
+// thousands of coarse clusters: cells of a few codes each (the release configurations' V = 2048 / 4096)
+static bool index_has_tiny_cells(const cis_index* ix) {
+    return ix->nonempty_cells > 0 && ix->n_total / ix->nonempty_cells < 64;
+}
+
 static bool use_all_path(const cis_index* ix, int M, int K, int L, int nq) {
     if (L > MAX_LDS_LIMIT) return true;
     if (ix->force_exact_scan) return false;
     if (L > 440) return true;
+    // a scan workgroup per (query, cell) slot stages 16 KB of tables and a survivor list per work item: hopeless for cells of
+    // a few codes -- every candidate's exact distance + a per-query select instead (unless a test forces a scan kernel)
+    if (index_has_tiny_cells(ix) && !ix->force_prefilter_scan) return true;
     return !ix->force_prefilter_scan && nq <= small_batch_nq(L);
 }
 
@@ -3258,6 +3648,19 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     // (Splitting a shard's cells into chunks so that a cell-sharded index at world = 8 fills the chip again was measured
     // and lost: 0.516 against 0.306 ms per partial search -- more survivors, colder bounds: profiles/r02d_shard_emulation.txt.)
     const int seg_max = use3 ? (nq >= 64 ? 65536 : 4096) : (nq >= 1024 ? (1 << 20) : (nq >= 64 ? 16384 : 4096));
+    // thousands of coarse clusters (the release configurations' V = 2048 / 4096): the plan is a per-query selection + sort
+    // (k_plan_par) instead of one frontier step per visited cell; queries it cannot resolve fall back to the frontier walk
+    static const bool no_par_plan = getenv("CIS_NO_PAR_PLAN") != nullptr;
+    const bool par_plan = V >= 128 && V <= PLAN_PAR_CAP && !no_par_plan;
+    int* plan_fb = nullptr;
+    uint32_t* vis_list = nullptr;
+    const int vis_cap = (int64_t)V * V < 16384 ? V * V : 16384;  // visited cells per query the fast plan records
+    if (par_plan) {
+        CIS_TRY(ix->w_planfb.reserve((size_t)nq * sizeof(int)));
+        CIS_TRY(ix->w_vis.reserve((size_t)nq * vis_cap * sizeof(uint32_t)));
+        plan_fb = ix->w_planfb.as<int>();
+        vis_list = ix->w_vis.as<uint32_t>();
+    }
     CIS_TRY(cis_launch_sqdist_both(m, xc, ct, nq, ix->w_cd.p, st));
     const size_t plan_lds = (size_t)V * sizeof(int);
     int Vp2 = 64;
@@ -3269,9 +3672,13 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         else
             hipLaunchKernelGGL(k_rank<float>, dim3(nq, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, st, ix->w_cd.as<float>(), nq, V,
                                ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
+        if (par_plan)
+            hipLaunchKernelGGL((k_plan_par<float, false>), dim3(nq), dim3(256), 0, st, ix->w_sorted.as<float>(), ix->w_order.as<uint16_t>(),
+                               ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
+                               nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap);
         hipLaunchKernelGGL((k_plan<float, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<float>(),
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
-                           seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr);
+                           seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr, plan_fb);
     } else {
         if (V > 256 && Vp2 <= 4096)
             hipLaunchKernelGGL(k_rank_sort<double>, dim3(nq, 2), dim3(256), (size_t)Vp2 * 16, st, ix->w_cd.as<double>(), nq, V, Vp2,
@@ -3279,9 +3686,21 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         else
             hipLaunchKernelGGL(k_rank<double>, dim3(nq, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, st, ix->w_cd.as<double>(), nq,
                                V, ix->w_order.as<uint16_t>(), ix->w_sorted.as<double>(), grp_cnt);
+        if (par_plan)
+            hipLaunchKernelGGL((k_plan_par<double, false>), dim3(nq), dim3(256), 0, st, ix->w_sorted.as<double>(), ix->w_order.as<uint16_t>(),
+                               ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
+                               nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap);
         hipLaunchKernelGGL((k_plan<double, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
-                           seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr);
+                           seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr, plan_fb);
+    }
+    if (par_plan && getenv("CIS_DEBUG_PLAN")) {
+        std::vector<int> fbh(nq);
+        CIS_CHECK_HIP(hipMemcpyAsync(fbh.data(), plan_fb, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st));
+        CIS_CHECK_HIP(hipStreamSynchronize(st));
+        int nfb = 0;
+        for (int i = 0; i < nq; ++i) nfb += fbh[i] != 0;
+        fprintf(stderr, "[cis] k_plan_par: %d of %d queries fall back to the frontier walk (quota %lld)\n", nfb, nq, (long long)quota);
     }
     if (!ix->h_totals) {
         CIS_CHECK_HIP(hipHostMalloc((void**)&ix->h_totals, 4 * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
@@ -3353,6 +3772,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     CIS_TRY(ix->w_tabs.reserve((size_t)(n_tabs + 1) * sizeof(TabDesc)));
     CIS_TRY(ix->w_T.reserve((size_t)(n_tabs + 1) * nf * K * sizeof(double)));
     const bool big = use_all_path(ix, M, K, L, nq);  // ranked over all candidates' exact distances (below)
+    const bool tiny_cells = index_has_tiny_cells(ix);
     const bool fast = scan2_supported(M, K, L) && !ix->force_exact_scan;
     const Scan2Geom geom = scan2_geom(M, K, L, nq);
     const Scan3Geom geom3 = scan3_geom(M, K, L, n_items > 0 ? n_cand_all / n_items : 0);
@@ -3375,16 +3795,24 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         px_buf = ix->w_px.as<double>();
     }
     if (ct == CIS_F32) {
+        if (par_plan)
+            hipLaunchKernelGGL((k_plan_par<float, true>), dim3(nq), dim3(256), 0, st, ix->w_sorted.as<float>(), ix->w_order.as<uint16_t>(),
+                               ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota, seg_max, plan, item_off, tab_off, items,
+                               tabs, nullptr, grp_base, grp_cur, tab_order, vis_list, plan_fb, vis_cap);
         hipLaunchKernelGGL((k_plan<float, true>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<float>(),
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
-                           seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order);
+                           seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order, plan_fb);
         if (n_tabs > 0)
             launch_tables<float>(n_tabs, tab_lds, st, (const float*)xc, m->d_Cs32, m->d_Rt, m->d_mus, m->d_subs, tabs, tab_order, V, h,
                                  m->w, nf, K, D, T, m->prog_w, px_buf, d_tot);
     } else {
+        if (par_plan)
+            hipLaunchKernelGGL((k_plan_par<double, true>), dim3(nq), dim3(256), 0, st, ix->w_sorted.as<double>(), ix->w_order.as<uint16_t>(),
+                               ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota, seg_max, plan, item_off, tab_off, items,
+                               tabs, nullptr, grp_base, grp_cur, tab_order, vis_list, plan_fb, vis_cap);
         hipLaunchKernelGGL((k_plan<double, true>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
                            ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
-                           seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order);
+                           seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order, plan_fb);
         if (n_tabs > 0)
             launch_tables<double>(n_tabs, tab_lds, st, (const double*)xc, m->d_Cs64, m->d_Rt, m->d_mus, m->d_subs, tabs, tab_order, V,
                                   h, m->w, nf, K, D, T, m->prog_w, px_buf, d_tot);
@@ -3440,7 +3868,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (!sp.select) {
             uint64_t *keys_out = b1, *vals_in = b2, *vals_out = b3;
             if (n_items > 0) {
-                launch_adc_all(n_items, st, items, cand_start, T, codes, M, K, keys_in, vals_in, nullptr, nullptr);
+                launch_adc_all(n_items, st, items, cand_start, T, codes, M, K, keys_in, vals_in, nullptr, nullptr, nullptr, seg, item_off, nq, tiny_cells);
                 size_t b = tmp_bytes;
                 CIS_TRY(cis_seg_sort_u64(tmp, &b, keys_in, keys_out, vals_in, vals_out, n_cand, nq, seg, seg + 1, st));
             }
@@ -3448,7 +3876,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         } else {
             uint64_t *sel_keys = b1, *sel_vals = b2;
             if (n_items > 0)
-                launch_adc_all(n_items, st, items, cand_start, T, codes, M, K, keys_in, nullptr, qmin, qmax, d_tot);
+                launch_adc_all(n_items, st, items, cand_start, T, codes, M, K, keys_in, nullptr, qmin, qmax, d_tot, seg, item_off, nq, tiny_cells);
             if (sp.sort_lds) {
                 // fewer queries than CUs: one large workgroup per query walks its keys faster; else two 512-thread ones per CU
                 if (nq <= 256)
