@@ -2497,6 +2497,7 @@ struct cis_index {
     // per-batch workspace
     DevBuf w_slack;  // per work item: see k_merge_survivors
     DevBuf w_planfb, w_vis;  // k_plan_par: per-query fallback flags, visited (i, j) lists
+    DevBuf w_tiles;          // tile sums of the candidate layout
     DevBuf w_xp, w_cd, w_order, w_sorted, w_plan, w_off, w_items, w_tabs, w_T, w_hits, w_hitn, w_part, w_q,
         w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos, w_order2, w_px, w_T32, w_grp, w_tord;
     int64_t stats[4] = {0, 0, 0, 0};
@@ -2543,7 +2544,7 @@ extern "C" void cis_index_destroy(cis_index* ix) {
     if (ix->m) (void)hipSetDevice(ix->m->device);
     DevBuf* bufs[] = {&ix->d_codes, &ix->d_ids, &ix->d_loff, &ix->d_gcount, &ix->w_xp, &ix->w_cd, &ix->w_order,
                       &ix->w_sorted, &ix->w_plan, &ix->w_off, &ix->w_items, &ix->w_tabs, &ix->w_T, &ix->w_hits,
-                      &ix->w_hitn, &ix->w_slack, &ix->w_planfb, &ix->w_vis, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
+                      &ix->w_hitn, &ix->w_slack, &ix->w_planfb, &ix->w_vis, &ix->w_tiles, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
                       &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px, &ix->w_T32, &ix->w_grp, &ix->w_tord};
     for (DevBuf* b : bufs) b->release();
     if (ix->h_totals) (void)hipHostFree(ix->h_totals);
@@ -3033,11 +3034,78 @@ __global__ void k_item_lens(const WorkItem* __restrict__ items, int64_t n, int64
 }
 
 __global__ void k_seg_begin(const int64_t* __restrict__ cand_start, const int64_t* __restrict__ item_off, int nq, int64_t n_items,
-                            int64_t n_cand, int64_t* __restrict__ seg) {
+                            int64_t n_cand, int64_t* __restrict__ seg, unsigned long long* __restrict__ qmin,
+                            unsigned long long* __restrict__ qmax) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > nq) return;
     const int64_t it = item_off[q];
     seg[q] = (q == nq || it >= n_items) ? n_cand : cand_start[it];
+    if (qmin && q < nq) { qmin[q] = ~0ull; qmax[q] = 0ull; }
+}
+
+// candidate layout for batches of many work items (hundreds of thousands: tiny cells): exclusive scan of the items' lengths
+// over tiles of 4096 items -- tile sums, one workgroup scans them, tiles rescan with their offset -- then k_seg_begin.
+// (k_cand_layout below does it all in one workgroup: the right thing for the usual few thousand items, 2 ms for a million.)
+static const int CAND_TILE = 4096;
+__global__ __launch_bounds__(256) void k_cand_tile_sum(const WorkItem* __restrict__ items, int64_t n_items, int64_t* __restrict__ tile_sums) {
+    __shared__ int64_t s_w[4];
+    const int64_t base = (int64_t)blockIdx.x * CAND_TILE;
+    int64_t sum = 0;
+    for (int e = threadIdx.x; e < CAND_TILE; e += 256)
+        if (base + e < n_items) sum += items[base + e].len;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(1024) void k_cand_tile_scan(int64_t* __restrict__ tile_sums, int64_t ntiles) {  // in place, exclusive
+    __shared__ int64_t s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int64_t carry = 0;
+    for (int64_t b0 = 0; b0 < ntiles; b0 += 1024) {
+        const int64_t i = b0 + tid;
+        const int64_t v = i < ntiles ? tile_sums[i] : 0;
+        int64_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        __syncthreads();
+        if (lane == 63) s_w[wv] = x;
+        __syncthreads();
+        int64_t base = carry, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wv) base += s_w[w]; tot += s_w[w]; }
+        if (i < ntiles) tile_sums[i] = base + x - v;
+        carry += tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cand_tile_apply(const WorkItem* __restrict__ items, int64_t n_items,
+                                                         const int64_t* __restrict__ tile_off, int64_t* __restrict__ cand_start) {
+    __shared__ int64_t s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * CAND_TILE;
+    int64_t carry = tile_off[blockIdx.x];
+    for (int e0 = 0; e0 < CAND_TILE; e0 += 256) {
+        const int64_t i = base + e0 + tid;
+        const int64_t v = i < n_items ? items[i].len : 0;
+        int64_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        __syncthreads();
+        if (lane == 63) s_w[wv] = x;
+        __syncthreads();
+        int64_t b = carry;
+        for (int w = 0; w < wv; ++w) b += s_w[w];
+        if (i < n_items) cand_start[i] = b + x - v;
+        carry += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    }
 }
 
 // candidate layout of the all-candidates path in one launch: exclusive scan of the work items' lengths (cand_start),
@@ -3862,6 +3930,16 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         uint64_t* b3 = b2 + bl;
         uint64_t* b4 = b3 + bl;
         void* tmp = reinterpret_cast<void*>(((uintptr_t)(sp.select ? (sp.sort_lds ? b3 : b3 + 2 * bl) : b4) + 255) & ~(uintptr_t)255);
+        if (n_items > 16384 && !d_tot) {
+            const int64_t ntiles = ceil_div(n_items, CAND_TILE);
+            CIS_TRY(ix->w_tiles.reserve((size_t)(ntiles + 1) * sizeof(int64_t)));
+            int64_t* tile_sums = ix->w_tiles.as<int64_t>();
+            hipLaunchKernelGGL(k_cand_tile_sum, dim3((unsigned)ntiles), dim3(256), 0, st, items, n_items, tile_sums);
+            hipLaunchKernelGGL(k_cand_tile_scan, dim3(1), dim3(1024), 0, st, tile_sums, ntiles);
+            hipLaunchKernelGGL(k_cand_tile_apply, dim3((unsigned)ntiles), dim3(256), 0, st, items, n_items, tile_sums, cand_start);
+            hipLaunchKernelGGL(k_seg_begin, dim3((unsigned)ceil_div(nq + 1, 256)), dim3(256), 0, st, cand_start, item_off, nq, n_items, n_cand, seg,
+                               sp.select ? qmin : (unsigned long long*)nullptr, qmax);
+        } else
         hipLaunchKernelGGL(k_cand_layout, dim3(1), dim3(1024), 0, st, items, n_items, item_off, nq, n_cand, cand_start, seg,
                            sp.select ? qmin : (unsigned long long*)nullptr, qmax, d_tot);
         const uint64_t *rk = nullptr, *rv = nullptr;  // ranked pairs
