@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 PCA_FIXTURES = ["c2", "c3", "c3b", "c4", "c3full"]
 ALL = ["tiny", "c1"] + PCA_FIXTURES
 
-_ROUTE_FREE = ("encode", "near_tie", "model_pieces", "selftest", "multisequence", "rerank", "kmeans", "training", "select_path",
+_ROUTE_FREE = ("encode", "near_tie", "model_pieces", "selftest", "multisequence", "rerank", "kmeans", "training", "multisequence_plan", "select_path",
                "large_limit", "fuzz")
 
 
@@ -702,3 +702,47 @@ def test_training_accumulations_on_gpu_match_host():
     ca, fa = a.predict_batch(X[:4000])
     cb, fb = b.predict_batch(X[:4000])
     assert (ca != cb).any(axis=1).mean() < 0.01 and (fa != fb).any(axis=1).mean() < 0.05
+
+
+@pytest.mark.gpu
+def test_multisequence_plan_with_thousands_of_cells_and_tied_sums():
+    """The plan of indexes with many coarse clusters (k_plan_par: banded selection + sort instead of one frontier step per
+    cell) against the oracle's frontier walk, on a lattice model built to make the rank-pair sums d0[i] + d1[j] TIE by
+    the hundreds (integer squares: 1 + 49 == 25 + 25): the heap's order is the (sum, i, j) order, ties included.
+    Thousands of visited cells (several bands), every cell of the index (quota above its size), tiny cells throughout."""
+    from oracle import lopq_oracle as O
+    from columbiaimagesearch_amd.lopq import LOPQModel, LOPQSearcherHIP
+    V, K = 128, 4
+    c = np.arange(1, V + 1, dtype=np.float32).reshape(V, 1)
+    Cs = (c.copy(), c.copy())
+    Rs = tuple(np.ones((V, 1, 1)) for _ in range(2))
+    mus = tuple(np.zeros((V, 1)) for _ in range(2))
+    subs = tuple([np.array([[-0.3], [-0.1], [0.1], [0.3]])] for _ in range(2))
+    m = LOPQModel(parameters=(Cs, Rs, mus, subs))
+    om = O.OracleModel(list(Cs), list(Rs), list(mus), [list(subs[0]), list(subs[1])])
+    rs = np.random.RandomState(12)
+    n = 30000
+    cells = rs.randint(1, V + 1, size=(n, 2))
+    X = (cells + rs.uniform(-0.4, 0.4, size=(n, 2))).astype(np.float32)
+    coarse, fine = m.predict_batch(X)
+    np.testing.assert_array_equal(coarse, cells - 1)
+    s = LOPQSearcherHIP(m)
+    s.add_codes_array(coarse, fine)
+    oi = O.OracleCSRIndex(om, coarse, fine)
+    Q = np.array([[0.0, 0.0], [-3.0, 200.0], [140.0, -1.0], [0.0, 131.0]], dtype=np.float32)  # distinct d0 and d1, tied sums
+    sums = np.add.outer((Q[0, 0] - c[:, 0]) ** 2, (Q[0, 1] - c[:, 0]) ** 2)
+    assert len(np.unique(sums)) < sums.size // 2  # the construction does tie
+    for quota, limit in ((700, 30), (6000, 50), (40000, 60)):
+        r = s.search_batch(Q, quota=quota, limit=limit)
+        for qi in range(len(Q)):
+            ids, dists, visited = oi.search(Q[qi], quota=quota, limit=limit)
+            k = len(ids)
+            assert int(r["visited"][qi]) == visited and int(r["n_found"][qi]) == k, (quota, qi, int(r["visited"][qi]), visited)
+            np.testing.assert_array_equal(r["ids"][qi, :k], ids)
+            np.testing.assert_allclose(r["dists"][qi, :k], dists, rtol=1e-9, atol=1e-12)
+    # the visit ORDER itself (ranks are part of the ranking key): multisequence cells, tie groups included
+    from columbiaimagesearch_amd.lopq.search import multisequence_batch
+    got_cells, _ = multisequence_batch(Q, Cs, max_cells=3000)
+    for qi in range(len(Q)):
+        want = [cell for _, cell in zip(range(3000), (cc for _, cc in O.multisequence(om, Q[qi])))]
+        np.testing.assert_array_equal(got_cells[qi], np.array(want))
