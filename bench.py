@@ -235,6 +235,7 @@ def main():
         for b in range(args.steps):
             out = step(qbatches[(args.warmup + b) % len(qbatches)])
             cand += searcher.last_stats()["candidates"]
+        scan_name = searcher.last_stats()["scan_kernel"]
     else:
         # steps are independent batches: the exchange + merge of batch b (side stream, RCCL) overlap the partial search
         # of batch b+1 (compute stream)
@@ -246,6 +247,7 @@ def main():
             out = sharded.search_end(h)
             h = h2
         out = sharded.search_end(h)
+        scan_name = searcher.last_stats()["scan_kernel"]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -437,7 +439,7 @@ def main():
                        "name": args.config, "index_vectors": N, "queries_per_step": NQ, "quota": QUOTA, "limit": LIMIT,
                        "sharding": "by coarse cell over %d GPU(s)%s" % (world, ", RCCL all-gather merge" if world > 1 else ""),
                        "candidates_per_query": cand_all / float(NQ * args.steps)},
-            "roofline": {"bound": "hbm", "kernel": "k_adc_scan2", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": scan_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes / launches,
                          "avg_launch_ms": prof["scan_kernel_ms"] / launches, "launches": launches},

@@ -77,6 +77,7 @@ _PROTOS = {
     "cis_train_gram": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "cis_train_project": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "cis_index_last_stats": (c_int, [c_void_p, c_void_p]),
+    "cis_index_last_scan_kernel": (c_int, [c_void_p]),
     "cis_cnn_create": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_int]),
     "cis_cnn_destroy": (None, [c_void_p]),
     "cis_cnn_feat_dim": (c_int, [c_int]),

@@ -1691,7 +1691,7 @@ __device__ __forceinline__ void adc32_reduce(typename AdcVec<G>::type (&f)[M], f
 
 // One workgroup (NW waves) scans one cell chunk for `ng` <= G queries that all visit it.
 template <int M, int NR, int U, int G, int NW>
-__device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (&item_idx)[G], int ng,
+__device__ __forceinline__ void scan2_group(const WorkItem* __restrict__ items_all, const int (&item_idx)[G], int ng,
                                             const double* __restrict__ T, const float* __restrict__ T32,
                                             const uint8_t* __restrict__ codes,
                                             const int64_t* __restrict__ ids, int K, int L, int S, float margin,
@@ -1700,6 +1700,18 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
     // region capacity: 8 entries short of the NR*64 keys a wave can hold in registers, so that the
     // G=2 / 4-wave layout (16 KB tables + 8 regions) stays under 40 KB and four workgroups share a CU
     constexpr int R = NR * 64 - 8;
+    // item_idx[] is wave-uniform (the slot index went through readfirstlane): the work items are scalar loads and live in
+    // scalar registers instead of 10 VGPRs each (they used to spill to scratch)
+    // (field by field: a local array of the 48-byte structs was kept in scratch, 24 KB of stores per slot and workgroup)
+    int it_tab0[G], it_tab1[G], it_q[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        it_tab0[g] = items_all[item_idx[g]].tab0;
+        it_tab1[g] = items_all[item_idx[g]].tab1;
+        it_q[g] = items_all[item_idx[g]].q;
+    }
+    const int it0_len = items_all[item_idx[0]].len;
+    const int64_t it0_start = items_all[item_idx[0]].start;
     char* tab = smem;                                                              // [K][M][G] float32
     uint64_t* rk_all = reinterpret_cast<uint64_t*>(smem + (size_t)K * M * G * 4);  // [G][NW][R] (d32, pos) entries; exact keys at the end
     uint64_t* tr_all = rk_all + G * NW * R;                                        // [G][NW][64] scratch slots of the branch-free append
@@ -1712,13 +1724,6 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
     (void)clk_exact; (void)clk_final;
     int n_slow = 0, n_app = 0;
     (void)clk_begin; (void)clk_slow; (void)clk_comp; (void)n_slow; (void)n_app;
-    const double* t0[G];
-    const double* t1[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        t0[g] = T + (int64_t)it[g].tab0 * nf * K;
-        t1[g] = T + (int64_t)it[g].tab1 * nf * K;
-    }
     const float INF = __int_as_float(0x7f800000);
     {
         // LDS tables from the float32 copies ([nf][K] per (query, half)): 16-byte loads (four consecutive k of one
@@ -1732,8 +1737,8 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
             for (int g = 0; g < G; ++g) {
                 const bool on = (g < ng) && (e < nvec);  // an absent second query gets +inf tables: nothing ever passes
                 const int eg = e < nvec ? e : 0;
-                v[g][0] = reinterpret_cast<const float4*>(T32 + (int64_t)it[g].tab0 * nf * K)[eg];
-                v[g][1] = reinterpret_cast<const float4*>(T32 + (int64_t)it[g].tab1 * nf * K)[eg];
+                v[g][0] = reinterpret_cast<const float4*>(T32 + (int64_t)it_tab0[g] * nf * K)[eg];
+                v[g][1] = reinterpret_cast<const float4*>(T32 + (int64_t)it_tab1[g] * nf * K)[eg];
                 if (!on) { v[g][0] = make_float4(INF, INF, INF, INF); v[g][1] = v[g][0]; }
             }
             if (e < nvec) {
@@ -1762,7 +1767,10 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
                 // scanned by different workgroups at different times (the slot list is sorted by cell), so the
                 // later ones start with a tight bound instead of +inf.  Only the amount of work depends on timing.
 #ifndef CIS_SCAN_NO_QBOUND
-                const unsigned long long e = (g < ng) ? __hip_atomic_load(&qbound[it[g].q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                int qg = it_q[0];  // g is a thread index here: select, do not index the register array
+#pragma unroll
+                for (int gg = 1; gg < G; ++gg) qg = (g == gg) ? it_q[gg] : qg;
+                const unsigned long long e = (g < ng) ? __hip_atomic_load(&qbound[qg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                                       : 0x7ff0000000000000ull;
 #else
                 const unsigned long long e = 0x7ff0000000000000ull;
@@ -1779,9 +1787,9 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
     const RotConsts<M> rc = make_rot<M>(lane);
     const int Lw = (L + NW - 1) / NW;
     // wave-uniform by construction; tell the compiler so (scalar loop control, scalar tail test)
-    const int len = __builtin_amdgcn_readfirstlane(it[0].len);
-    const int64_t start = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it[0].start >> 32)) << 32) |
-                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)it[0].start);
+    const int len = __builtin_amdgcn_readfirstlane(it0_len);
+    const int64_t start = ((int64_t)__builtin_amdgcn_readfirstlane((int)(it0_start >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)it0_start);
     const int nit = (len + 64 * U - 1) / (64 * U);
     int cnt[G];
     constexpr double EPS32 = 2.0 * M * 5.9604644775390625e-8;  // float32 sum vs exact: |d32 - d64| <= EPS32 * d64
@@ -1935,7 +1943,8 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
                 if (c2 < 0) {
                     uint32_t dp = 0xffffffffu;
                     const long long clk_e0 = CIS_CLK();
-                    c2 = wave_compact_exact<M, NR, NW, false>(rk, rp, cnt[g], L, Lw, &sh[g], w, codes, start, K, t0[g], t1[g], dp);
+                    c2 = wave_compact_exact<M, NR, NW, false>(rk, rp, cnt[g], L, Lw, &sh[g], w, codes, start, K, T + (int64_t)it_tab0[g] * nf * K,
+                                                                  T + (int64_t)it_tab1[g] * nf * K, dp);
                     clk_exact += CIS_CLK() - clk_e0;
                     dp = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp);
                     if (dp != 0xffffffffu) {
@@ -1982,7 +1991,7 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
 #ifndef CIS_SCAN_NO_QBOUND
         if (tid == 0) {
             const uint64_t b = block_bound_u64<NW>(&sh[g]);
-            if (b < sh[g].ext) atomicMin(&qbound[it[g].q], (unsigned long long)b);
+            if (b < sh[g].ext) atomicMin(&qbound[it_q[g]], (unsigned long long)b);
         }
 #endif
     }
@@ -2025,7 +2034,7 @@ __device__ __forceinline__ void scan2_group(const WorkItem (&it)[G], const int (
 // that XCD's private L2.  A workgroup whose own queue is empty steals from the others, which removes
 // the tail caused by unequal cell sizes.
 template <int M, int NR, int U, int G, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(G == 4 ? 2 : 4, 4))) void k_adc_scan2(const WorkItem* __restrict__ items, const int* __restrict__ slots,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(G == 4 ? 2 : ((M == 16 && G == 2) ? 3 : 4), 4))) void k_adc_scan2(const WorkItem* __restrict__ items, const int* __restrict__ slots,
                                                        const int* __restrict__ n_slots_ptr, const double* __restrict__ T,
                                                        const float* __restrict__ T32,
                                                        const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids,
@@ -2046,41 +2055,40 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(G == 4 
             __syncthreads();  // previous slot fully written out; LDS may be reused
             if (threadIdx.x == 0) *s_next = atomicAdd(&queue_ctr[x], 1);
             __syncthreads();
-            const int j = *s_next;
+            const int j = __builtin_amdgcn_readfirstlane(*s_next);  // wave-uniform: the slot and its work items stay in scalar registers
             if (j >= count) break;
             const int slot = qstart + j;
-            WorkItem it[G];
             int idx[G];
             int ng = 0;
+            bool same = true;  // the items of a slot must cover the same chunk of the same cell; otherwise run them one by one
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 idx[g] = slots[slot * G + g];
-                if (idx[g] >= 0) { it[g] = items[idx[g]]; ng = g + 1; }
-                else { it[g] = it[0]; idx[g] = idx[0]; }
+                if (idx[g] >= 0) {
+                    ng = g + 1;
+                    same = same && items[idx[g]].start == items[idx[0]].start && items[idx[g]].len == items[idx[0]].len;
+                } else {
+                    idx[g] = idx[0];
+                }
             }
             if constexpr (G >= 2) {
-                // the items of a slot must cover the same chunk of the same cell; otherwise run them one by one
-                bool same = true;
-#pragma unroll
-                for (int g = 1; g < G; ++g) same = same && (g >= ng || (it[g].start == it[0].start && it[g].len == it[0].len));
                 if (!same) {
                     for (int g2 = 0; g2 < ng; ++g2) {
-                        WorkItem one[G];
                         int oi[G];
 #pragma unroll
                         for (int g = 0; g < G; ++g) {
-                            one[g] = it[0]; oi[g] = idx[0];
+                            oi[g] = idx[0];
 #pragma unroll
                             for (int gg = 1; gg < G; ++gg)
-                                if (gg == g2) { one[g] = it[gg]; oi[g] = idx[gg]; }
+                                if (gg == g2) oi[g] = idx[gg];
                         }
                         if (g2 > 0) __syncthreads();
-                        scan2_group<M, NR, U, G, NW>(one, oi, 1, T, T32, codes, ids, K, L, S, margin, item_surv, item_n, qbound, smem);
+                        scan2_group<M, NR, U, G, NW>(items, oi, 1, T, T32, codes, ids, K, L, S, margin, item_surv, item_n, qbound, smem);
                     }
                     continue;
                 }
             }
-            scan2_group<M, NR, U, G, NW>(it, idx, ng, T, T32, codes, ids, K, L, S, margin, item_surv, item_n, qbound, smem);
+            scan2_group<M, NR, U, G, NW>(items, idx, ng, T, T32, codes, ids, K, L, S, margin, item_surv, item_n, qbound, smem);
         }
     }
 }
@@ -2505,6 +2513,7 @@ struct cis_index {
     bool force_exact_scan = false;  // tests: run every item through the float64 kernel
     bool force_scan2 = false;       // scan mode 2: the float32-prefilter kernel whatever the batch size
     bool force_scan3 = false;       // scan mode 3: the 16-bit fixed-point kernel whatever the batch size
+    int last_scan_kernel = 0;       // 0 none (all-candidates path), 1 float64 scan, 2 float32 prefilter, 3 16-bit fixed-point prefilter
     bool force_prefilter_scan = false;  // tests: the float32-prefilter kernel also for small batches
     int profiling = 0;  // 0 off, 1 events around the scan kernel only, 2 events around every stage
     int64_t* h_totals = nullptr;    // pinned, device-mapped: the plan totals land here without a copy
@@ -2897,6 +2906,8 @@ extern "C" int cis_index_read_profile(cis_index* ix, double ms[5], int64_t* laun
     ix->prof_launches = 0;
     return CIS_OK;
 }
+
+extern "C" int cis_index_last_scan_kernel(cis_index* ix) { return ix ? ix->last_scan_kernel : 0; }
 
 extern "C" int cis_index_last_stats(cis_index* ix, int64_t stats[4]) {
     CIS_REQUIRE(ix != nullptr && stats != nullptr, "NULL argument");
@@ -3666,6 +3677,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                         hipStream_t st) {
     cis_model* m = ix->m;
     const int V = m->V, D = m->D, K = m->K, M = m->M, h = m->h, nf = m->nf;
+    ix->last_scan_kernel = 0;
     cis_index::ProfRec pr;
     pr.has_scan = false;
     for (int i = 0; i < 6; ++i) pr.ev[i] = nullptr;
@@ -4024,6 +4036,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                                    slots, n_slots, qstart);
             }
             CIS_TRY(mark(5));
+            ix->last_scan_kernel = use3 ? 3 : 2;
             if (use3)
                 launch_scan3(M, geom3, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, ix->w_slack.as<float>(), qbound);
             else
@@ -4031,6 +4044,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         }
         else {
             CIS_TRY(mark(5));
+            ix->last_scan_kernel = 1;
             launch_scan_exact(M, n_items, st, items, T, codes, ids, K, L, S, nullptr, hits, hitn);
         }
         ix->stats[3] += 1;

@@ -357,7 +357,9 @@ class LOPQSearcherHIP(LOPQSearcherBase):
         """Counters of the last search: candidates scanned, work items, tables, scan launches."""
         st = np.zeros(4, dtype=np.int64)
         _lib.check(_lib.lib().cis_index_last_stats(self._ix, _lib.ptr(st)))
-        return {"candidates": int(st[0]), "items": int(st[1]), "tables": int(st[2]), "scan_launches": int(st[3])}
+        kind = int(_lib.lib().cis_index_last_scan_kernel(self._ix))
+        return {"candidates": int(st[0]), "items": int(st[1]), "tables": int(st[2]), "scan_launches": int(st[3]),
+                "scan_kernel": {0: None, 1: "k_adc_scan", 2: "k_adc_scan2", 3: "k_adc_scan3"}.get(kind)}
 
 
     default_prefilter_only = False  # tests: new searchers keep the float32-prefilter kernel for every batch size

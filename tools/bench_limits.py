@@ -9,8 +9,8 @@ from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
 
 N = int(os.environ.get("CIS_BENCH_N", 10_000_000)); NCH = 10
 dev = torch.device("cuda", 0)
-model, z = B.load_model()
-P = B.mixture_centers(dev)
+model, z = B.load_model("c4")
+P = B.mixture_centers("descriptor", dev)
 co, fi = [], []
 for c in range(NCH):
     a, b = model.predict_batch_dev(B.gen_chunk(P, c, N // NCH, dev)); co.append(a); fi.append(b)

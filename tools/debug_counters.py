@@ -5,9 +5,9 @@ sys.argv = [sys.argv[0]]
 import bench
 from columbiaimagesearch_amd import _lib
 from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
-model, z = bench.load_model()
+model, z = bench.load_model("c4")
 dev = torch.device("cuda", 0)
-centers = bench.mixture_centers(dev)
+centers = bench.mixture_centers("descriptor", dev)
 N = int(os.environ.get("CIS_DBG_N", 10_000_000)); chunk = N // 80
 cs, fs = [], []
 for c in range(80):

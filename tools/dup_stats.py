@@ -4,9 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 sys.argv = [sys.argv[0]]
 import bench
-model, z = bench.load_model()
+model, z = bench.load_model("c4")
 dev = torch.device("cuda", 0)
-centers = bench.mixture_centers(dev)
+centers = bench.mixture_centers("descriptor", dev)
 n = 2_000_000
 x = bench.gen_chunk(centers, 0, n, dev)
 co, fi = model.predict_batch_dev(x)

@@ -11,7 +11,7 @@ def total(counter):
     tot, kern = 0.0, None
     for line in open("gpurun_out/%s_%s_%s_pmc.csv" % (tag, config, counter)).read().splitlines()[1:]:
         parts = line.rsplit(",", 4)
-        if len(parts) == 5 and "k_adc_scan2" in parts[0] and parts[2] == counter:
+        if len(parts) == 5 and "k_adc_scan" in parts[0] and parts[2] == counter:
             tot += float(parts[3])
             kern = parts[0]
     return tot, kern
