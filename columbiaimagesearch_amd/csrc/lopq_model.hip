@@ -205,6 +205,136 @@ __global__ __launch_bounds__(256) void k_pca_gemm(const TX* __restrict__ X, cons
     }
 }
 
+// The same product on the float64 matrix cores: v_mfma_f64_16x16x4_f64, 64 x 64 block tile, four waves of 32 x 32 (2 x 2 MFMA
+// tiles), K advances 16 per LDS stage with the next stage's operands prefetched into registers.  Operand layout: lane l gives
+// A[row = l & 15][k = l >> 4] and B[k = l >> 4][col = l & 15]; result reg r of lane l is C[row = (l >> 4) + 4 r][col = l & 15].
+// The register-tiled kernel above is LDS-bound (eight 8-byte reads per sixteen FMAs: 17-23 TFLOP/s); here a wave reads four
+// operands per four MFMAs (4 x 2048 flop).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+template <typename TX, bool SUBF32>
+__global__ __launch_bounds__(256) void k_pca_gemm_mfma(const TX* __restrict__ X, const double* __restrict__ mu,
+                                                       const double* __restrict__ P, double* __restrict__ Y,
+                                                       int64_t n, int D_in, int D) {
+    constexpr int BM = 64, BK = 32;
+    __shared__ double sA[2][BK][BM + 2];  // [stage][k][row]
+    __shared__ double sB[2][BK][64 + 2];  // [stage][k][col]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int col0 = blockIdx.y * 64;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+    // a stage is 64 rows x 32 k of X (four consecutive k per thread and fetch: one 16-byte load for float32 rows) and
+    // 32 k x 64 columns of P (two consecutive columns per thread and fetch)
+    double ra[2][4], rb[4][2];
+    const bool vec4 = (D_in % 4 == 0);
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = tid + e * 256;            // 512 quads: row = idx / 8, k quad = idx % 8
+            const int r = idx >> 3, kq = (idx & 7) * 4;
+            const bool ron = row0 + r < n;
+            float xf[4];
+            double xd[4];
+            bool on[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { on[c] = ron && k0 + kq + c < D_in; xf[c] = 0.f; xd[c] = 0.0; }
+            if constexpr (sizeof(TX) == 4) {
+                if (vec4 && on[3]) {
+                    const float4 q = *reinterpret_cast<const float4*>(X + (row0 + r) * D_in + k0 + kq);
+                    xf[0] = q.x; xf[1] = q.y; xf[2] = q.z; xf[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (on[c]) xf[c] = (float)X[(row0 + r) * D_in + k0 + kq + c];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xd[c] = (double)xf[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (on[c]) xd[c] = (double)X[(row0 + r) * D_in + k0 + kq + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double v = 0.0;
+                if (on[c]) {
+                    if constexpr (SUBF32) v = (double)(xf[c] - (float)mu[k0 + kq + c]);  // float32 - float32
+                    else v = xd[c] - mu[k0 + kq + c];
+                }
+                ra[e][c] = v;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;            // 1024 pairs: k = idx / 32, column pair = idx % 32
+            const int k = idx >> 5, c = (idx & 31) * 2;
+            rb[e][0] = 0.0; rb[e][1] = 0.0;
+            if (k0 + k < D_in) {
+                if (col0 + c + 1 < D && (D % 2 == 0)) {
+                    const double2 q = *reinterpret_cast<const double2*>(P + (int64_t)(k0 + k) * D + col0 + c);
+                    rb[e][0] = q.x; rb[e][1] = q.y;
+                } else {
+                    if (col0 + c < D) rb[e][0] = P[(int64_t)(k0 + k) * D + col0 + c];
+                    if (col0 + c + 1 < D) rb[e][1] = P[(int64_t)(k0 + k) * D + col0 + c + 1];
+                }
+            }
+        }
+    };
+    auto stash = [&](int st) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = tid + e * 256;
+            const int r = idx >> 3, kq = (idx & 7) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sA[st][kq + c][r] = ra[e][c];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            const int k = idx >> 5, c = (idx & 31) * 2;
+            sB[st][k][c] = rb[e][0];
+            sB[st][k][c + 1] = rb[e][1];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int st = 0;
+    for (int k0 = 0; k0 < D_in; k0 += BK) {
+        const bool more = k0 + BK < D_in;
+        if (more) fetch(k0 + BK);
+#pragma unroll
+        for (int k = 0; k < BK; k += 4) {
+            double a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = sA[st][k + (lane >> 4)][wm * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = sB[st][k + (lane >> 4)][wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stash(st ^ 1);
+        __syncthreads();
+        st ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+                const int c = col0 + wn * 32 + j * 16 + (lane & 15);
+                if (row < n && c < D) Y[row * D + c] = acc[i][j][r];
+            }
+}
+
 // Row L2 renormalisation (numpy: sqrt(add.reduce(y*y, axis=1)), then y / norm) and float32 cast.
 // One 64-lane wave per row would break the summation order, so each thread owns a row.
 __global__ void k_pca_finish(const double* __restrict__ Y, float* __restrict__ out, int64_t n, int D,
@@ -599,9 +729,14 @@ int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, floa
     // 64-row tiles when they fill the chip twice over, 32-row tiles otherwise
     const bool small = ceil_div(n, 64) * ceil_div(m->D, 64) < 512;
     dim3 g((unsigned)ceil_div(n, small ? 32 : 64), (unsigned)ceil_div(m->D, 64));
+    // wide inputs (the 4096-d DeepSentibank features): the float64 matrix cores; CIS_PCA_GEMM=valu keeps the register-tiled kernel
+    static const bool pca_valu = getenv("CIS_PCA_GEMM") && !strcmp(getenv("CIS_PCA_GEMM"), "valu");
+    const bool use_mfma = !pca_valu && m->D_in >= 256;
+    dim3 gm((unsigned)ceil_div(n, 64), (unsigned)ceil_div(m->D, 64));
 #define CIS_PCA_LAUNCH(TX, SUB, XP)                                                                                              \
     do {                                                                                                                          \
-        if (small) hipLaunchKernelGGL((k_pca_gemm<TX, SUB, 2>), g, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
+        if (use_mfma) hipLaunchKernelGGL((k_pca_gemm_mfma<TX, SUB>), gm, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
+        else if (small) hipLaunchKernelGGL((k_pca_gemm<TX, SUB, 2>), g, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
         else hipLaunchKernelGGL((k_pca_gemm<TX, SUB, 4>), g, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);       \
     } while (0)
     if (x_dtype == CIS_F32 && m->pca_mu_f32) CIS_PCA_LAUNCH(float, true, (const float*)dX);
