@@ -402,7 +402,7 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
                                             const double* __restrict__ T, const float* __restrict__ T32,
                                             const uint8_t* __restrict__ codes, int K, int L, int S,
                                             uint64_t* __restrict__ item_surv, int* __restrict__ item_n, float* __restrict__ item_slack,
-                                            unsigned long long* __restrict__ qbound, char* smem) {
+                                            unsigned long long* __restrict__ qbound, char* smem, bool two_pass) {
     constexpr int G = S3G;
     constexpr int R = NR * 64 - 8;
     constexpr int nf = M / 2;
@@ -455,7 +455,10 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
 #endif
             { sh[g].thr = thr; thr1[g] = (uint16_t)((g < ng) ? thr + 1u : 0u); }
             // what the merge may assume about a survivor: exact distance >= (its float32 upper bound) - slack
-            if (g < ng) item_slack[item_idx[g]] = __double2float_ru(ub * ((double)M + 0.1));
+            if (g < ng) {
+                item_slack[2 * (int64_t)item_idx[g] + 0] = __double2float_ru(ub * ((double)M + 0.1));
+                item_slack[2 * (int64_t)item_idx[g] + 1] = __double2float_ru(ub);  // the merge turns a survivor's sum s into the bound (s + M) * ub
+            }
         }
         if (tid < 8 * G) {
             const int g = tid >> 3, i = tid & 7;
@@ -522,6 +525,215 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
         const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cbase >> 32));
         const int nbytes = __builtin_amdgcn_readfirstlane(len * M);
         rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)bhi << 32) | blo), 0, nbytes, 0x00020000);
+    }
+    // ---- two-pass mode (short chunks): no running bound, no regions, no selections --------------------------------------
+    // Pass 1 adds every candidate's sum into a 512-bin histogram per query (LDS atomics; the histograms use the memory of the
+    // regions).  One wave per query then finds the first bin whose cumulative count reaches L: every candidate up to that bin's
+    // upper edge is kept -- at least L of them, so the edge is a valid bound (published for the query's other cells), and at
+    // most L plus one bin's population.  Pass 2 computes the sums again and appends what is under the fixed threshold straight
+    // to the work item's survivor list (one LDS atomic per survivor).  A chunk of a few thousand candidates spends its time in
+    // the per-wave selections of the streaming form (one when a region first fills, one at the end, per wave and query); here
+    // it pays the table gathers twice instead.  A crowd -- more candidates under the edge than the list holds (thousands of
+    // equal sums: duplicate codes) -- falls through to the streaming form below, which resolves ties exactly.
+    if (two_pass) {
+        constexpr int NB = 512, BSH = 7;  // bins of 128 sums
+        static_assert(G * NB <= G * NW * R, "the histograms live in the region memory");
+        uint32_t* hist = rk_all;          // [G][NB]
+        int* s_flag = reinterpret_cast<int*>(thr1 + 4);  // crowd flag (the 8 bytes after the packed thresholds)
+        for (int e = tid; e < G * NB; e += NW * 64) hist[e] = 0u;
+        if (tid == 0) *s_flag = 0;
+        __syncthreads();
+        auto sums_of = [&](const CodeWords<M> (&cur)[U], u32x2_t (&d)[U]) {
+            u32x2_t fbuf[2][OCT];
+            uint32_t D[2][(M + 3) / 4];
+            rot_words<M>(cur[0], rc, D[0]);
+            adc16_issue<M, OCT>(D[0], 0, tab, rc, fbuf[0]);
+#pragma unroll
+            for (int q = 0; q < U * NU; ++q) {
+                const int u = q / NU, o = q % NU;
+                if (q + 1 < U * NU) {
+                    const int u1 = (q + 1) / NU, o1 = (q + 1) % NU;
+                    if (o1 == 0) rot_words<M>(cur[u1], rc, D[u1 & 1]);
+                    adc16_issue<M, OCT>(D[u1 & 1], o1, tab, rc, fbuf[(q + 1) & 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x2_t part = adc16_sum<OCT>(fbuf[q & 1]);
+                if (o == 0) {
+                    d[u] = part;
+                } else {
+                    d[u][0] = pk_add_u16(d[u][0], part[0]);
+                    d[u][1] = pk_add_u16(d[u][1], part[1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        {   // pass 1
+            CodeWords<M> nx[U];
+            if (w < nit) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) nx[u] = load_code_buf<M>(rs, w * 64 * U + u * 64 + lane);
+            }
+            for (int iter = w; iter < nit; iter += NW) {
+                const int base = iter * 64 * U;
+                CodeWords<M> cur[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) cur[u] = nx[u];
+                if (iter + NW < nit) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) nx[u] = load_code_buf<M>(rs, (iter + NW) * 64 * U + u * 64 + lane);
+                }
+                u32x2_t d[U];
+                sums_of(cur, d);
+                const bool tail = base + 64 * U > len;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!tail || base + u * 64 + lane < len) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            const uint32_t sg = (g & 1) ? (d[u][g >> 1] >> 16) : (d[u][g >> 1] & 0xffffu);
+                            atomicAdd(&hist[g * NB + (sg >> BSH)], 1u);
+                        }
+                    }
+                }
+            }
+        }
+        S3_CTR(11, S3_CLK() - c0);
+        __syncthreads();
+        S3_CTR(12, S3_CLK() - c0);
+        // thresholds: wave w serves the queries g = w, w + NW, ...
+        for (int g = w; g < G; g += NW) {
+            uint32_t c[8];
+            int own = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { c[i] = hist[g * NB + lane * 8 + i]; own += (int)c[i]; }
+            int x = own;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const int y = __shfl_up(x, dd);
+                if (lane >= dd) x += y;
+            }
+            const unsigned long long reach = __ballot(x >= L);
+            uint32_t thr = 65534u;
+            int n_le = __builtin_amdgcn_readlane(x, 63);  // all candidates
+            bool have_bound = false;
+            if (g < ng && reach != 0ull) {
+                const int fl = __ffsll((long long)reach) - 1;
+                int cum = x - own, bin = lane * 8, cnt_le = 0;
+                bool hit = false;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    cum += (int)c[i];
+                    if (!hit && cum >= L) { hit = true; bin = lane * 8 + i; cnt_le = cum; }
+                }
+                const int bsel = __builtin_amdgcn_readlane(bin, fl);
+                n_le = __builtin_amdgcn_readlane(cnt_le, fl);
+                const uint32_t edge = ((uint32_t)(bsel + 1) << BSH) - 1u;
+                thr = edge < 65534u ? edge : 65534u;
+                have_bound = true;
+            }
+            if (lane == 0) {
+                const uint32_t t_ext = lds_ld(&sh[g].thr);  // from the query's other cells (or 0 for an absent query)
+                const uint32_t t = thr < t_ext ? thr : t_ext;
+                sh[g].thr = t;
+                thr1[g] = (uint16_t)((g < ng) ? t + 1u : 0u);
+                sh[g].wcnt[0] = 0;
+                if (g < ng && thr <= t_ext && n_le > R) *s_flag = 1;  // more survivors than ONE wave's region holds: streaming form
+                if (have_bound && thr < t_ext) {
+                    // at least L candidates of this chunk have a sum <= thr: an exact-distance bound for the whole query
+                    const uint64_t b = val_to_bound(thr, M, sh[g].ub);
+                    sh[g].wt[0] = b;
+                }
+            }
+        }
+        __syncthreads();
+        S3_CTR(13, S3_CLK() - c0);
+        if (*s_flag == 0) {
+            if (tid < G && tid < ng) {
+                const uint64_t b = sh[tid].wt[0];
+                if (b < sh[tid].ext) atomicMin(&qbound[items[item_idx[tid]].q], (unsigned long long)b);
+            }
+            // pass 2: the histograms are dead, their memory is the wave-private regions again.  At most R candidates of a query
+            // are under its threshold (checked above), so no region can overflow and nothing is ever compacted.
+            const u32x2_t tpk = *reinterpret_cast<const volatile u32x2_t*>(thr1);
+            const uint32_t s01 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tpk[0]);
+            const uint32_t s23 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tpk[1]);
+            int cnt2[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) cnt2[g] = 0;
+            CodeWords<M> nx[U];
+            if (w < nit) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) nx[u] = load_code_buf<M>(rs, w * 64 * U + u * 64 + lane);
+            }
+            for (int iter = w; iter < nit; iter += NW) {
+                const int base = iter * 64 * U;
+                CodeWords<M> cur[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) cur[u] = nx[u];
+                if (iter + NW < nit) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) nx[u] = load_code_buf<M>(rs, (iter + NW) * 64 * U + u * 64 + lane);
+                }
+                u32x2_t d[U];
+                sums_of(cur, d);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t x = pk_subsat_u16(tpk[0], d[u][0]) | pk_subsat_u16(tpk[1], d[u][1]);
+                    unsigned long long am = __ballot(x != 0u);
+                    const int n = len - base - u * 64;
+                    if (n < 64) am &= n <= 0 ? 0ull : ((1ull << n) - 1ull);
+                    if (am == 0ull) continue;  // scalar branch
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const uint32_t sg = (g & 1) ? (d[u][g >> 1] >> 16) : (d[u][g >> 1] & 0xffffu);
+                        const uint32_t t1 = (g & 1) ? ((g >> 1) ? s23 >> 16 : s01 >> 16) : ((g >> 1) ? s23 & 0xffffu : s01 & 0xffffu);
+                        const unsigned long long m = __ballot(sg < t1) & am;
+                        if (m == 0ull) continue;
+                        uint32_t* rk = rk_all + (g * NW + w) * R;
+                        const int idx = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, cnt2[g]));
+                        if (((m >> lane) & 1ull) && idx < R) rk[idx] = (sg << 16) | (uint32_t)(base + u * 64 + lane);
+                        cnt2[g] += __popcll(m);
+                    }
+                }
+            }
+            S3_CTR(14, S3_CLK() - c0);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (lane == 0 && g < ng) sh[g].wcnt[w] = cnt2[g] < R ? cnt2[g] : R;
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g >= ng) break;
+                const uint32_t* rk = rk_all + (g * NW + w) * R;
+                int off = 0, total = 0;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    const int c = sh[g].wcnt[i];
+                    off += (i < w) ? c : 0;
+                    total += c;
+                }
+                const int mine = cnt2[g] < R ? cnt2[g] : R;
+                uint64_t* out = item_surv + (int64_t)item_idx[g] * S + off;
+                for (int e = lane; e < mine; e += 64) {
+                    const uint32_t x = rk[e];
+                    out[e] = ((uint64_t)(x >> 16) << 32) | (x & 0xffffu);
+                }
+                if (tid == 0) item_n[item_idx[g]] = total;
+            }
+            S3_CTR(7, S3_CLK() - c0);
+            S3_CTR(0, 1);
+            return;
+        }
+        // crowd: the streaming form starts from the bounds of the query's other cells again
+        if (tid < G) {
+            const int g = tid;
+            const uint32_t t = (g < ng) ? bound_to_thr(sh[g].ext, sh[g].inv_up) : 0u;
+            sh[g].thr = t;
+            thr1[g] = (uint16_t)((g < ng) ? t + 1u : 0u);
+            sh[g].wt[0] = 0x7ff0000000000000ull;
+            sh[g].wcnt[0] = 0;
+        }
+        __syncthreads();
     }
     CodeWords<M> nxt[U];
     if (w < nit) {
@@ -717,13 +929,11 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
             off += (i < w) ? c : 0;
             total += c;
         }
-        // a survivor leaves as (float32 upper bound of its exact distance, rounded up) << 32 | position
-        const double ub = sh[g].ub;
+        // a survivor leaves as (16-bit sum << 32 | position); the merge turns the sum into an upper bound of the exact distance
         uint64_t* out = item_surv + (int64_t)item_idx[g] * S + off;  // S = NW * R >= total
         for (int e = lane; e < cnt[g]; e += 64) {
             const uint32_t x = rk[e];
-            const float hi = __double2float_ru((double)((x >> 16) + (uint32_t)M) * ub);
-            out[e] = ((uint64_t)__float_as_uint(hi) << 32) | (x & 0xffffu);
+            out[e] = ((uint64_t)(x >> 16) << 32) | (x & 0xffffu);
         }
         if (tid == 0) item_n[item_idx[g]] = total;
     }
@@ -739,11 +949,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     const int* __restrict__ n_slots_ptr, const double* __restrict__ T, const float* __restrict__ T32,
     const uint8_t* __restrict__ codes, int K, int L, int S, int* __restrict__ queue_ctr /* [8], zeroed */,
     uint64_t* __restrict__ item_surv, int* __restrict__ item_n, float* __restrict__ item_slack,
-    unsigned long long* __restrict__ qbound /* [nq], +inf */) {
+    unsigned long long* __restrict__ qbound /* [nq], +inf */, int two_pass) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int G = S3G;
     constexpr int R = NR * 64 - 8;
-    int* s_next = reinterpret_cast<int*>(smem + (size_t)K * M * G * 2 + (size_t)G * NW * R * 4 + G * sizeof(Scan3Shared) + 16);
+    int* s_next = reinterpret_cast<int*>(smem + (size_t)K * M * G * 2 + (size_t)G * NW * R * 4 + G * sizeof(Scan3Shared) + 32);
     const int* qs = n_slots_ptr + 8;  // [9] queue starts, written by the slot builder
     const int home = blockIdx.x & 7;
     const long long k0 = S3_CLK();
@@ -793,11 +1003,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                             if (gg == g2) oi[g] = idx[gg];
                     }
                     if (g2 > 0) __syncthreads();
-                    scan3_group<M, NR, U, NW>(items, tabs, oi, 1, T, T32, codes, K, L, S, item_surv, item_n, item_slack, qbound, smem);
+                    scan3_group<M, NR, U, NW>(items, tabs, oi, 1, T, T32, codes, K, L, S, item_surv, item_n, item_slack, qbound, smem, two_pass != 0);
                 }
                 continue;
             }
-            scan3_group<M, NR, U, NW>(items, tabs, idx, ng, T, T32, codes, K, L, S, item_surv, item_n, item_slack, qbound, smem);
+            scan3_group<M, NR, U, NW>(items, tabs, idx, ng, T, T32, codes, K, L, S, item_surv, item_n, item_slack, qbound, smem, two_pass != 0);
         }
     }
     S3_CTR(9, S3_CLK() - k0);
@@ -811,19 +1021,19 @@ bool scan3_supported(int M, int K, int L) {
 // NW = waves per workgroup: every wave of a workgroup pays one compaction per query when its region first fills and
 // one at the end of the chunk, so short chunks want few waves (less of the chunk's time goes to selection), long ones
 // four (more waves share one 16 KB table set).
-Scan3Geom scan3_geom(int M, int K, int L, int64_t avg_chunk) {
+Scan3Geom scan3_geom(int M, int K, int L, int64_t avg_chunk, int force_two_pass) {
     Scan3Geom g;
     const int NR = (L <= 184) ? 4 : 8;
     g.G = S3G;
     g.NW = 4;  // measured (profiles/r02c_scan3_nw.txt): 2 and 1 waves lose more to latency than they save in selections
     (void)avg_chunk;
-    if (const char* e = getenv("CIS_SCAN3_NW")) {
-        const int v = atoi(e);
-        if (v == 1 || v == 2 || v == 4) g.NW = v;
-    }
     g.U = 4;
+    // short chunks (a few thousand candidates): the two-pass form; CIS_SCAN3_TWOPASS=0/1 overrides (A/B runs)
+    g.two_pass = (avg_chunk > 0 && avg_chunk < 12288 && M <= 8) ? 1 : 0;
+    if (const char* e = getenv("CIS_SCAN3_TWOPASS")) g.two_pass = atoi(e) ? 1 : 0;
+    if (force_two_pass >= 0) g.two_pass = force_two_pass;  // scan modes 3 / 4 (tests)
     g.S = g.NW * (NR * 64 - 8);
-    g.lds = (size_t)K * M * g.G * 2 + (size_t)g.G * g.NW * (NR * 64 - 8) * 4 + g.G * sizeof(Scan3Shared) + 16 + 16;
+    g.lds = (size_t)K * M * g.G * 2 + (size_t)g.G * g.NW * (NR * 64 - 8) * 4 + g.G * sizeof(Scan3Shared) + 32 + 16;
     return g;
 }
 
@@ -840,18 +1050,13 @@ static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, 
     const int64_t want = (n_items + g.G - 1) / g.G + 8;
     const unsigned grid = (unsigned)(want < resident ? ((want + 7) / 8) * 8 : resident);
     hipLaunchKernelGGL((k_adc_scan3<M, NR, U, NW, WPE>), dim3(grid), dim3(NW * 64), g.lds, st, items, tabs, slots, n_slots, T, T32,
-                       codes, K, L, g.S, qctr, hits, hitn, slack, qbound);
+                       codes, K, L, g.S, qctr, hits, hitn, slack, qbound, g.two_pass);
 }
 
 void launch_scan3(int M, const Scan3Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const TabDesc* tabs,
                   const int* slots, const int* n_slots, const double* T, const float* T32, const uint8_t* codes, int K, int L,
                   int* qctr, uint64_t* hits, int* hitn, float* slack, unsigned long long* qbound) {
-#define CIS_S3_NW(MM, RR)                                                                                                                       \
-    do {                                                                                                                                        \
-        if (g.NW == 4) launch_scan3_t<MM, RR, 4>(g, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, hits, hitn, slack, qbound);      \
-        else if (g.NW == 2) launch_scan3_t<MM, RR, 2>(g, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, hits, hitn, slack, qbound); \
-        else launch_scan3_t<MM, RR, 1>(g, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, hits, hitn, slack, qbound);                \
-    } while (0)
+#define CIS_S3_NW(MM, RR) launch_scan3_t<MM, RR, 4>(g, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, hits, hitn, slack, qbound)
 #define CIS_S3(MM)                   \
     do {                             \
         if (L <= 184) CIS_S3_NW(MM, 4); \

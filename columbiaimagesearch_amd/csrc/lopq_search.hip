@@ -2269,6 +2269,8 @@ __global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restr
                 const uint64_t ent = valid[i] ? surv[(first + lst) * (int64_t)S + off] : ~0ull;
                 hi[i] = (uint32_t)(ent >> 32);
                 pp[i] = (uint32_t)ent;
+                if (item_slack && valid[i])  // k_adc_scan3 hands over the 16-bit sum: (sum + M) * ub >= the exact distance
+                    hi[i] = __float_as_uint(__double2float_ru((double)(hi[i] + (uint32_t)MT) * (double)item_slack[2 * (first + lst) + 1]));
                 mn = (valid[i] && hi[i] < mn) ? hi[i] : mn;
                 mx = (valid[i] && hi[i] > mx) ? hi[i] : mx;
             }
@@ -2284,7 +2286,7 @@ __global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restr
                 if (item_slack) {
                     vub = __uint_as_float(v);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) sl[i] = (i < n_lists) ? item_slack[first + i] : 0.f;
+                    for (int i = 0; i < 4; ++i) sl[i] = (i < n_lists) ? item_slack[2 * (first + i)] : 0.f;
                 } else {
                     const float margin = 1.0f + 3.0f * (2.0f * (float)MT * 5.9604645e-8f);
                     thr = __float_as_uint(__double2float_ru((double)__uint_as_float(v) * (double)margin));
@@ -2513,6 +2515,7 @@ struct cis_index {
     bool force_exact_scan = false;  // tests: run every item through the float64 kernel
     bool force_scan2 = false;       // scan mode 2: the float32-prefilter kernel whatever the batch size
     bool force_scan3 = false;       // scan mode 3: the 16-bit fixed-point kernel whatever the batch size
+    int force_two_pass = -1;        // scan mode 3: k_adc_scan3's streaming form, 4: its two-pass form (-1: by chunk length)
     int last_scan_kernel = 0;       // 0 none (all-candidates path), 1 float64 scan, 2 float32 prefilter, 3 16-bit fixed-point prefilter
     bool force_prefilter_scan = false;  // tests: the float32-prefilter kernel also for small batches
     int profiling = 0;  // 0 off, 1 events around the scan kernel only, 2 events around every stage
@@ -2872,11 +2875,12 @@ extern "C" int cis_multisequence(const void* X, int x_dtype, const void* C0, con
 }
 
 extern "C" int cis_index_set_scan_mode(cis_index* ix, int mode) {
-    CIS_REQUIRE(ix != nullptr && mode >= 0 && mode <= 3, "bad scan mode");
+    CIS_REQUIRE(ix != nullptr && mode >= 0 && mode <= 4, "bad scan mode");
     ix->force_exact_scan = (mode == 1);
-    ix->force_prefilter_scan = (mode == 2 || mode == 3);
+    ix->force_prefilter_scan = (mode >= 2);
     ix->force_scan2 = (mode == 2);
-    ix->force_scan3 = (mode == 3);
+    ix->force_scan3 = (mode == 3 || mode == 4);
+    ix->force_two_pass = mode == 3 ? 0 : (mode == 4 ? 1 : -1);
     return CIS_OK;
 }
 
@@ -3855,11 +3859,11 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     const bool tiny_cells = index_has_tiny_cells(ix);
     const bool fast = scan2_supported(M, K, L) && !ix->force_exact_scan;
     const Scan2Geom geom = scan2_geom(M, K, L, nq);
-    const Scan3Geom geom3 = scan3_geom(M, K, L, n_items > 0 ? n_cand_all / n_items : 0);
+    const Scan3Geom geom3 = scan3_geom(M, K, L, n_items > 0 ? n_cand_all / n_items : 0, ix->force_two_pass);
     const int S = fast ? (use3 ? geom3.S : geom.S) : L;  // hit slots per work item (fast kernels: a full region per wave)
     if (!big) CIS_TRY(ix->w_hits.reserve((size_t)(n_items + 1) * S * (fast ? sizeof(uint64_t) : sizeof(cis_hit))));
     CIS_TRY(ix->w_hitn.reserve((size_t)(n_items + 1) * 2 * sizeof(int)));
-    if (use3) CIS_TRY(ix->w_slack.reserve((size_t)(n_items + 1) * sizeof(float)));
+    if (use3) CIS_TRY(ix->w_slack.reserve((size_t)(n_items + 1) * 2 * sizeof(float)));
     WorkItem* items = ix->w_items.as<WorkItem>();
     TabDesc* tabs = ix->w_tabs.as<TabDesc>();
     CIS_TRY(ix->w_tord.reserve((size_t)(n_tabs + 1) * sizeof(int)));

@@ -230,7 +230,8 @@ int cis_index_set_profiling(cis_index* ix, int level /* 0 off, 1 only the pair o
  * survivors -- the 16-bit fixed-point kernel k_adc_scan3 for batches of >= 256 queries, the float32 kernel k_adc_scan2
  * below that; small batches take the all-candidates path instead: exact distances of every candidate, radix select;
  * exact float64 scan kernel otherwise), 1 = exact float64 scan kernel wherever it applies (limit <= 3072),
- * 2 = the float32-prefilter kernel for every batch size, 3 = the 16-bit fixed-point kernel for every batch size.
+ * 2 = the float32-prefilter kernel for every batch size, 3 / 4 = the 16-bit fixed-point kernel for every batch size in its
+ * streaming / two-pass (histogram threshold, then collection) form.
  * All routes produce identical results; the switch exists so that tests can prove it. */
 int cis_index_set_scan_mode(cis_index* ix, int mode);
 int cis_index_read_profile(cis_index* ix, double ms[5], int64_t* launches);

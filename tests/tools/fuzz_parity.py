@@ -57,7 +57,7 @@ def run(cases, seed0):
       limit = None if limit is None else int(limit)
       if limit is None and quota > 20000:
           limit = 100
-      s.set_scan_mode(mode=int(rs.choice([0, 2, 3, 3])))  # automatic routing, float32-prefilter kernel, 16-bit fixed-point kernel
+      s.set_scan_mode(mode=int(rs.choice([0, 2, 3, 4, 4])))  # automatic routing, float32-prefilter kernel, 16-bit fixed-point kernel
       r = s.search_batch(Q, quota=quota, limit=limit)
       ok = True
       for qi in range(nq):

@@ -33,4 +33,6 @@ prev = 0.0
 for i, n in enumerate(names):
     t = b[i + 1] / slots / 100.0
     print("  %-34s %7.2f us (+%.2f)" % (n, t, t - prev)); prev = t
+if b[11]:
+    print("  two-pass form: pass 1 end %.2f, barrier %.2f, thresholds %.2f, pass 2 end %.2f (same unit, from slot start)" % tuple(b[i] / slots / 100.0 for i in (11, 12, 13, 14)))
 print("  queue fetch per attempt           %7.2f us; kernel per workgroup %.1f us, slots per workgroup %.2f" % (b[8] / (slots + 8 * wgs) / 100.0, b[9] / wgs / 100.0, slots / wgs))
