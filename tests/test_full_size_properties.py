@@ -177,3 +177,12 @@ def test_routed_insert_and_pipelined_sharded_search_rccl():
     text = out.stdout.decode()
     assert out.returncode == 0, text[-3000:]
     assert text.count("routed insert + pipelined search ok") == 3, text[-3000:]
+
+
+def test_fork_before_first_use():
+    """The library initialises HIP lazily: a process that imported the package may fork (gunicorn, multiprocessing) and parent and
+    children each get their own device state -- tests/tools/fork_check.py in a fresh interpreter (this one has touched the GPU)."""
+    import os, subprocess, sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "fork_check.py")
+    out = subprocess.run([sys.executable, script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert out.returncode == 0 and "fork check ok" in out.stdout.decode(), out.stdout.decode()[-3000:]
