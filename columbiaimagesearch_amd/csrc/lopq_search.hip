@@ -4237,15 +4237,15 @@ static int merge_parts(const cis_hit* d_parts, int world, int nq, int L, int64_t
 
 // Merge of PACKED per-shard hit lists: shard w contributed parts[w*stride + off[w*nq+q] .. + cnt[w*nq+q]) for query q
 // (its valid hits only, in query order).  One wave per query; same ranking key as everywhere: (dist, visit_rank, pos).
-template <int CAPM>
-__global__ __launch_bounds__(256) void k_merge_packed(const cis_hit* __restrict__ parts, int world, int64_t stride,
+template <int CAPM, int WPB /* waves (= queries) per workgroup */>
+__global__ __launch_bounds__(WPB * 64) void k_merge_packed(const cis_hit* __restrict__ parts, int world, int64_t stride,
                                                       const int64_t* __restrict__ off, const int32_t* __restrict__ cnt, int nq,
                                                       int limit, int64_t* __restrict__ out_ids, double* __restrict__ out_dists,
                                                       int* __restrict__ out_n, int32_t* __restrict__ out_cells,
                                                       uint32_t* __restrict__ out_pos) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
-    const int q = blockIdx.x * 4 + wq;
+    const int q = blockIdx.x * WPB + wq;
     if (q >= nq) return;
     uint64_t* ka = reinterpret_cast<uint64_t*>(smem) + (size_t)wq * 3 * CAPM;
     uint64_t* kb = ka + CAPM;
@@ -4320,13 +4320,16 @@ extern "C" int cis_merge_packed_dev(const cis_hit* d_parts, int world, int64_t s
     hipStream_t st = (hipStream_t)stream;
     const dim3 g((unsigned)ceil_div(nq, 4));
     if (limit <= 128)
-        hipLaunchKernelGGL(k_merge_packed<256>, g, dim3(256), (size_t)4 * 3 * 256 * 8, st, d_parts, world, stride, d_off, d_cnt, nq, limit,
+        hipLaunchKernelGGL((k_merge_packed<256, 4>), g, dim3(256), (size_t)4 * 3 * 256 * 8, st, d_parts, world, stride, d_off, d_cnt, nq, limit,
                            d_ids, d_dists, d_n_found, d_cells, d_pos);
     else if (limit <= 512)
-        hipLaunchKernelGGL(k_merge_packed<1024>, g, dim3(256), (size_t)4 * 3 * 1024 * 8, st, d_parts, world, stride, d_off, d_cnt, nq,
+        hipLaunchKernelGGL((k_merge_packed<1024, 4>), g, dim3(256), (size_t)4 * 3 * 1024 * 8, st, d_parts, world, stride, d_off, d_cnt, nq,
                            limit, d_ids, d_dists, d_n_found, d_cells, d_pos);
+    else if (limit <= 3072)  // one wave per workgroup with 96 KB of LDS: 4096 keys per round, `limit` of them carried over
+        hipLaunchKernelGGL((k_merge_packed<4096, 1>), dim3((unsigned)nq), dim3(64), (size_t)3 * 4096 * 8, st, d_parts, world, stride, d_off,
+                           d_cnt, nq, limit, d_ids, d_dists, d_n_found, d_cells, d_pos);
     else {
-        cis_set_error("packed merge supports limit <= 512");
+        cis_set_error("packed merge supports limit <= 3072");
         return CIS_EUNSUPPORTED;
     }
     CIS_CHECK_HIP(hipGetLastError());

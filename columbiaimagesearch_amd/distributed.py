@@ -83,7 +83,7 @@ def merge_packed_sorted(parts, off, cnt, nq, L):
     visit_rank | pos << 32, id, cell), off [world, nq] int64, cnt [world, nq] int32 -> dict like merge_packed_dev.
     The ranking key (dist, visit_rank, pos) of lopq/lopq/search.py:128-133,:210 is applied as three stable device
     sorts (least significant key first), then the first L records of every query are scattered out.  Used above the
-    512 records per query that cis_merge_packed_dev ranks in one wave."""
+    3072 records per query that cis_merge_packed_dev ranks in one wave."""
     import torch
     world, stride = int(parts.shape[0]), int(parts.shape[1])
     dev = parts.device
@@ -226,7 +226,7 @@ class ShardedSearcher(object):
             for t in (p["packed"], p["cnt"], p["visited"]):
                 t.record_stream(self._side)
             parts, off, cnt_all = exchange_packed(p["packed"], p["cnt"], self.group)
-            if h["L"] <= 512:
+            if h["L"] <= 3072:
                 out = merge_packed_dev(parts, off, cnt_all, h["nq"], h["L"])
             else:
                 out = merge_packed_sorted(parts, off, cnt_all, h["nq"], h["L"])
@@ -255,8 +255,8 @@ class ShardedSearcher(object):
         nq = int(q.shape[0])
         p = self.local.search_partial_packed_dev(q, quota=quota, limit=limit)
         parts, off, cnt_all = exchange_packed(p["packed"], p["cnt"], self.group)
-        if L <= 512:
-            out = merge_packed_dev(parts, off, cnt_all, nq, L)      # one wave per query
+        if L <= 3072:
+            out = merge_packed_dev(parts, off, cnt_all, nq, L)      # one wave per query (HIP kernel)
         else:
             out = merge_packed_sorted(parts, off, cnt_all, nq, L)   # any limit: stable device sorts
         out["visited"] = p["visited"]

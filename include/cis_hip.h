@@ -181,7 +181,7 @@ int cis_merge_hits_dev(const cis_hit* d_parts, int world, int nq, int limit, int
                        uint32_t* d_pos /* or NULL */, void* stream);
 
 /* The same for PACKED partial lists (what travels over xGMI): shard w contributed its valid hits only, in query
- * order, d_parts[w*stride + d_off[w*nq + q] .. + d_cnt[w*nq + q]) for query q.  limit <= 512. */
+ * order, d_parts[w*stride + d_off[w*nq + q] .. + d_cnt[w*nq + q]) for query q.  limit <= 3072 (one wave per query; above that the caller ranks the packed lists itself: distributed.merge_packed_sorted). */
 int cis_merge_packed_dev(const cis_hit* d_parts, int world, int64_t stride, const int64_t* d_off /* [world][nq] */,
                          const int32_t* d_cnt /* [world][nq] */, int nq, int limit, int64_t* d_ids, double* d_dists,
                          int32_t* d_n_found, int32_t* d_cells /* or NULL */, uint32_t* d_pos /* or NULL */, void* stream);

@@ -176,7 +176,7 @@ def test_routed_insert_and_pipelined_sharded_search_rccl():
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     text = out.stdout.decode()
     assert out.returncode == 0, text[-3000:]
-    assert text.count("routed insert + pipelined search ok") == 3, text[-3000:]
+    assert text.count("routed insert + pipelined search ok") == 4, text[-3000:]
 
 
 def test_fork_before_first_use():

@@ -31,7 +31,7 @@ a, b = rank * n // world, (rank + 1) * n // world  # this rank's slice of the ba
 sh.add_codes_routed(coarse[a:b], fine[a:b], ids[a:b])
 assert sh.get_nb_indexed() == single.get_nb_indexed(), (sh.get_nb_indexed(), single.get_nb_indexed())
 qs = [torch.as_tensor(Q[i:i + 16]).cuda().contiguous() for i in (0, 16, 32, 48)]
-for quota, limit in [(3000, 100), (50, 20), (5000, 600)]:
+for quota, limit in [(3000, 100), (50, 20), (5000, 600), (20000, 3500)]:
     want = [single.search_batch_dev(q, quota=quota, limit=limit) for q in qs]
     got = []
     h = sh.search_begin(qs[0], quota=quota, limit=limit)
