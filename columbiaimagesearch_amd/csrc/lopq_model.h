@@ -18,6 +18,8 @@ struct cis_model {
     double* d_subs = nullptr;  // [M][K][w]
     double* d_P = nullptr;     // [D_in][D]
     double* d_pmu = nullptr;   // [D_in]
+    double* d_cnorm = nullptr; // [2][V] squared norms of the coarse centroids, then the maximum per split [2]
+    int* d_flag = nullptr;     // [2] overflow flag of the coarse prefilter (k_coarse_mfma), one per encode pass parity
 
     PwProg prog_h, prog_w, prog_D;  // numpy summation order over h, w and D elements
 

@@ -377,20 +377,26 @@ __global__ __launch_bounds__(256) void k_pca_finish8(const double* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void k_sqdist_rows(const T* __restrict__ X, int64_t ldx, int xoff,
                                                      const T* __restrict__ C, int64_t n, int ncent, int d,
-                                                     T* __restrict__ out, PwProg prog) {
-    const int c = blockIdx.y * 16 + (threadIdx.x % 16);
-    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x / 16);
-    if (r >= n || c >= ncent) return;
-    const T* x = X + r * ldx + xoff;
-    const T* cc = C + (int64_t)c * d;
-    auto elem = [&](int i) -> T { const T df = x[i] - cc[i]; return df * df; };
-    out[r * ncent + c] = pw_sum<T>(prog, elem);
+                                                     T* __restrict__ out, PwProg prog, const int* __restrict__ only_if) {
+    if (only_if && *only_if == 0) return;
+    // the grid may be smaller than the tile count (predicated launches keep it small: they normally exit at once)
+    for (int cb = blockIdx.y; cb * 16 < ncent; cb += gridDim.y)
+        for (int64_t rb = blockIdx.x; rb * 16 < n; rb += gridDim.x) {
+            const int c = cb * 16 + (threadIdx.x % 16);
+            const int64_t r = rb * 16 + (threadIdx.x / 16);
+            if (r >= n || c >= ncent) continue;
+            const T* x = X + r * ldx + xoff;
+            const T* cc = C + (int64_t)c * d;
+            auto elem = [&](int i) -> T { const T df = x[i] - cc[i]; return df * df; };
+            out[r * ncent + c] = pw_sum<T>(prog, elem);
+        }
 }
 
 // First-minimum argmin over each row (numpy argmin tie rule).
 template <typename T, typename TO>
 __global__ void k_argmin_rows(const T* __restrict__ dist, int64_t n, int ncent, TO* __restrict__ out,
-                              int ostride, int ooff) {
+                              int ostride, int ooff, const int* __restrict__ only_if) {
+    if (only_if && *only_if == 0) return;
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const T* d = dist + r * ncent;
@@ -401,6 +407,196 @@ __global__ void k_argmin_rows(const T* __restrict__ dist, int64_t n, int ncent, 
         if (v < best) { best = v; bi = c; }
     }
     out[r * ostride + ooff] = (TO)bi;
+}
+
+// Coarse assignment when there are hundreds or thousands of clusters (the release configurations: V = 2048 / 4096): computing
+// every one of the n x V distances in numpy's summation order is a 4 ms pass per 64 k vectors and split.  Here the matrix
+// cores produce dt[c] = |c|^2 - 2 x.c in float64 (v_mfma_f64_16x16x4_f64; the vectors of a wave live in registers as the A
+// operand, 64 centroids x 64 dims per LDS stage as B), a row keeps every centroid whose dt is within `2 slack` of the running
+// minimum in a wave-private LDS list (about ln(V/64)+1 entries per row), and only the listed pairs are evaluated exactly
+// as predict_cluster does (lopq/lopq/utils.py:33-53: ((x - C)**2).sum(axis=1) in the compute type, first minimum wins).
+// slack = eps_rel (|x|^2 + max_c |c|^2) bounds |dt + |x|^2 - numpy's value| for every centroid, so the numpy argmin is always in the list:
+// numpy's value d_c* <= d_c for all c  =>  dt_c* <= dt_cmin + 2 slack.  A list that overflows raises `fallback` and the exact
+// kernels (predicated on that flag) redo the pass.
+template <typename T, int KS /* h padded to 4*KS */>
+__global__ __launch_bounds__(256) void k_coarse_mfma(const T* __restrict__ X, int64_t ldx, int h, const T* __restrict__ Call,
+                                                     const double* __restrict__ cnorm /* [2][V] + [2] maxima */, int64_t n, int V,
+                                                     uint16_t* __restrict__ out, PwProg prog, double eps_rel,
+                                                     int* __restrict__ fallback) {
+    constexpr int KC = (KS * 4 < 64) ? KS * 4 : 64;  // dims per LDS stage
+    constexpr int NKC = (KS * 4) / KC;
+    constexpr int CAP = 512;
+    __shared__ double sB[2][64][KC + 2];  // [stage][centroid][k]
+    __shared__ double sCn[2][64];
+    __shared__ uint32_t sList[4][CAP];
+    __shared__ double sXn[4][16];
+    __shared__ unsigned long long sBest[4][16];
+    __shared__ uint32_t sBestC[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.y;
+    const int xoff = split * h;
+    const T* C = Call + (size_t)split * V * h;
+    const double* cn = cnorm + (size_t)split * V;
+    const double cn_max = cnorm[2 * V + split];
+    const int64_t row0 = (int64_t)blockIdx.x * 64 + wave * 16;
+    // A operand: lane holds x[row = lane & 15][k = 4 step + (lane >> 4)]
+    double a[KS];
+    {
+        const int64_t r = row0 + (lane & 15);
+        const T* x = X + r * ldx + xoff;
+        double sq = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = 4 * s + (lane >> 4);
+            a[s] = (r < n && k < h) ? (double)x[k] : 0.0;
+            sq = fma(a[s], a[s], sq);
+        }
+        sq += __shfl_xor(sq, 16);
+        sq += __shfl_xor(sq, 32);
+        if (lane < 16) {
+            sXn[wave][lane] = sq;
+            sBest[wave][lane] = ~0ull;
+            sBestC[wave][lane] = 0xffffffffu;
+        }
+    }
+    __syncthreads();
+    double slack2[4], lmin[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        slack2[r] = 2.0 * eps_rel * (sXn[wave][(lane >> 4) + 4 * r] + cn_max);
+        lmin[r] = __builtin_inf();
+    }
+    // stage fetch: 64 centroids x KC dims = 64 * KC / 4 quads of consecutive k, 256 threads
+    constexpr int QPC = KC / 4;               // quads per centroid
+    constexpr int NQ = 64 * QPC / 256;        // quads per thread (4 at KC = 64)
+    static_assert(NQ >= 1, "stage too small");
+    double rb[NQ][4];
+    double rcn = 0.0;
+    auto fetch = [&](int t, int kc) {
+#pragma unroll
+        for (int e = 0; e < NQ; ++e) {
+            const int idx = tid + e * 256;
+            const int c = t * 64 + idx / QPC, k = kc * KC + (idx % QPC) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rb[e][q] = (c < V && k + q < h) ? (double)C[(size_t)c * h + k + q] : 0.0;
+        }
+        if (kc == 0 && tid < 64) rcn = (t * 64 + tid < V) ? cn[t * 64 + tid] : __builtin_inf();
+    };
+    auto stash = [&](int st, int kc) {
+#pragma unroll
+        for (int e = 0; e < NQ; ++e) {
+            const int idx = tid + e * 256;
+            double* d = &sB[st][idx / QPC][(idx % QPC) * 4];
+            d[0] = rb[e][0]; d[1] = rb[e][1]; d[2] = rb[e][2]; d[3] = rb[e][3];
+        }
+        if (kc == 0 && tid < 64) sCn[st][tid] = rcn;
+    };
+    const int ntiles = (V + 63) / 64;
+    const int nstages = ntiles * NKC;
+    int wcnt = 0;        // entries in this wave's list (wave-uniform)
+    bool over = false;
+    f64x4 acc[4];
+    fetch(0, 0);
+    stash(0, 0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc) {
+        const int sidx = t * NKC + kc, st = sidx & 1;
+        const bool more = sidx + 1 < nstages;
+        if (more) fetch((sidx + 1) / NKC, (sidx + 1) % NKC);
+        if (kc == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[j][r] = 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) {
+            const double av = a[kc * (KC / 4) + s];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double bv = sB[st][j * 16 + (lane & 15)][4 * s + (lane >> 4)];
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[j], 0, 0, 0);
+            }
+        }
+        if (kc == NKC - 1) {
+            const int cst = (sidx - kc) & 1;  // the stage that carried this tile's norms
+            double dt[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double cnv = sCn[cst][j * 16 + (lane & 15)];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dt[j][r] = fma(-2.0, acc[j][r], cnv);
+                    lmin[r] = fmin(lmin[r], dt[j][r]);
+                }
+            }
+            unsigned mask = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double mrow = lmin[r];
+                mrow = fmin(mrow, __shfl_xor(mrow, 1));
+                mrow = fmin(mrow, __shfl_xor(mrow, 2));
+                mrow = fmin(mrow, __shfl_xor(mrow, 4));
+                mrow = fmin(mrow, __shfl_xor(mrow, 8));
+                lmin[r] = mrow;
+                const double thr = mrow + slack2[r];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (dt[j][r] <= thr) mask |= 1u << (j * 4 + r);
+            }
+            if (__ballot(mask != 0) != 0ull && !over) {
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const bool p = (mask >> b) & 1u;
+                    const unsigned long long bal = __ballot(p);
+                    if (bal == 0ull) continue;
+                    const int cnt = __popcll(bal);
+                    if (wcnt + cnt > CAP) { over = true; break; }
+                    if (p) {
+                        const int pos = wcnt + __popcll(bal & ((1ull << lane) - 1ull));
+                        const int row = (lane >> 4) + 4 * (b & 3), c = t * 64 + (b >> 2) * 16 + (lane & 15);
+                        sList[wave][pos] = ((uint32_t)row << 16) | (uint32_t)c;
+                    }
+                    wcnt += cnt;
+                }
+            }
+        }
+        if (more) stash(st ^ 1, (sidx + 1) % NKC);
+        __syncthreads();
+      }
+    }
+    if (over) {
+        if (lane == 0) atomicOr(fallback, 1);  // the exact kernels redo the pass
+        wcnt = 0;
+    }
+    // exact re-check of the listed pairs, numpy's order and type; first minimum per row
+    auto exact = [&](uint32_t e) -> double {
+        const int64_t r = row0 + (e >> 16);
+        const T* x = X + r * ldx + xoff;
+        const T* cc = C + (size_t)(e & 0xffffu) * h;
+        auto elem = [&](int i) -> T { const T df = x[i] - cc[i]; return df * df; };
+        return (double)pw_sum<T>(prog, elem);
+    };
+    for (int i = lane; i < wcnt; i += 64) {
+        const uint32_t e = sList[wave][i];
+        if (row0 + (e >> 16) >= n) continue;
+        const double v = exact(e);
+        if (v == v) atomicMin(&sBest[wave][e >> 16], (unsigned long long)__double_as_longlong(v));
+    }
+    __syncthreads();
+    for (int i = lane; i < wcnt; i += 64) {
+        const uint32_t e = sList[wave][i];
+        if (row0 + (e >> 16) >= n) continue;
+        const double v = exact(e);
+        if ((unsigned long long)__double_as_longlong(v) == sBest[wave][e >> 16]) atomicMin(&sBestC[wave][e >> 16], e & 0xffffu);
+    }
+    __syncthreads();
+    if (lane < 16 && row0 + lane < n && !over) {
+        const uint32_t c = sBestC[wave][lane];
+        out[(row0 + lane) * 2 + split] = (uint16_t)(c == 0xffffffffu ? 0u : c);
+    }
 }
 
 // Fine codes in one pass (predict_fine, lopq/lopq/model.py:575-602 -> predict_cluster, lopq/lopq/utils.py:33-53): a thread
@@ -460,46 +656,65 @@ __global__ __launch_bounds__(256) void k_group_hist(const uint16_t* __restrict__
         if (s_bins[i]) atomicAdd(&counts[i], s_bins[i]);
 }
 
-// single block: exclusive scans over the 2V (split, cluster) bins; emits the tile descriptors.
+// single block: exclusive scans over the 2V (split, cluster) bins; emits the tile descriptors.  A thread owns a contiguous
+// range of bins (row offsets restart at the second split, tile numbers run on); with more bins than threads every thread
+// emits the tiles of its own bins, with few large bins the block emits them together.
 __global__ __launch_bounds__(256) void k_group_scan(const int* __restrict__ counts, int V, int* __restrict__ offsets,
                                                     int* __restrict__ cursor, ProjTile* __restrict__ tiles, int* __restrict__ n_tiles,
                                                     int tile_rows) {
-    extern __shared__ int s_tbase[];  // [2V] first tile of every bin (V <= 1024), else single-thread emission
-    const bool par = V <= 1024;
-    if (threadIdx.x == 0) {
-        int nt = 0;
-        for (int s = 0; s < 2; ++s) {
-            int off = 0;
-            for (int c = 0; c < V; ++c) {
-                const int cnt = counts[s * V + c];
-                offsets[s * V + c] = off;
-                cursor[s * V + c] = 0;
-                if (par) {
-                    s_tbase[s * V + c] = nt;
-                    nt += (cnt + tile_rows - 1) / tile_rows;
-                } else {
-                    for (int t = 0; t < cnt; t += tile_rows) {
-                        ProjTile pt;
-                        pt.split = s; pt.cluster = c; pt.start = off + t;
-                        pt.count = (cnt - t < tile_rows) ? (cnt - t) : tile_rows;
-                        tiles[nt++] = pt;
-                    }
-                }
-                off += cnt;
-            }
-        }
-        *n_tiles = nt;
+    extern __shared__ int s_tbase[];  // [2V] first tile of every bin
+    __shared__ int s_scan[3][256];
+    const int tid = threadIdx.x;
+    const int nb = 2 * V, per = (nb + 255) / 256;
+    const int b0 = (tid * per < nb) ? tid * per : nb, b1 = (b0 + per < nb) ? b0 + per : nb;
+    int loc[3] = {0, 0, 0};  // rows of split 0, rows of split 1, tiles
+    for (int b = b0; b < b1; ++b) {
+        const int cnt = counts[b];
+        loc[b < V ? 0 : 1] += cnt;
+        loc[2] += (cnt + tile_rows - 1) / tile_rows;
     }
-    if (!par) return;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) s_scan[q][tid] = loc[q];
     __syncthreads();
-    // the tiles of a bin are written by the threads of the block together (bins one after the other)
-    for (int b = 0; b < 2 * V; ++b) {
-        const int cnt = counts[b], nb = (cnt + tile_rows - 1) / tile_rows;
-        for (int t = threadIdx.x; t < nb; t += 256) {
+    for (int d = 1; d < 256; d <<= 1) {
+        int v[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[q] = (tid >= d) ? s_scan[q][tid - d] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s_scan[q][tid] += v[q];
+        __syncthreads();
+    }
+    int off[2] = {s_scan[0][tid] - loc[0], s_scan[1][tid] - loc[1]};
+    int t = s_scan[2][tid] - loc[2];
+    if (tid == 255) *n_tiles = s_scan[2][255];
+    const bool own = nb > 256;
+    for (int b = b0; b < b1; ++b) {
+        const int cnt = counts[b], s = b < V ? 0 : 1;
+        offsets[b] = off[s];
+        cursor[b] = 0;
+        s_tbase[b] = t;
+        if (own) {
+            for (int r = 0; r < cnt; r += tile_rows) {
+                ProjTile pt;
+                pt.split = s; pt.cluster = b - s * V; pt.start = off[s] + r;
+                pt.count = (cnt - r < tile_rows) ? (cnt - r) : tile_rows;
+                tiles[t++] = pt;
+            }
+        } else {
+            t += (cnt + tile_rows - 1) / tile_rows;
+        }
+        off[s] += cnt;
+    }
+    if (own) return;
+    __syncthreads();
+    for (int b = 0; b < nb; ++b) {
+        const int cnt = counts[b], nbt = (cnt + tile_rows - 1) / tile_rows;
+        for (int i = tid; i < nbt; i += 256) {
             ProjTile pt;
-            pt.split = b / V; pt.cluster = b - pt.split * V; pt.start = offsets[b] + t * tile_rows;
-            pt.count = (cnt - t * tile_rows < tile_rows) ? (cnt - t * tile_rows) : tile_rows;
-            tiles[s_tbase[b] + t] = pt;
+            pt.split = b / V; pt.cluster = b - pt.split * V; pt.start = offsets[b] + i * tile_rows;
+            pt.count = (cnt - i * tile_rows < tile_rows) ? (cnt - i * tile_rows) : tile_rows;
+            tiles[s_tbase[b] + i] = pt;
         }
     }
 }
@@ -649,7 +864,7 @@ static int upload(T** dst, const T* src, size_t count) {
 extern "C" void cis_model_destroy(cis_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    void* ptrs[] = {m->d_Cs32, m->d_Cs64, m->d_Rs, m->d_Rt, m->d_mus, m->d_subs, m->d_P, m->d_pmu};
+    void* ptrs[] = {m->d_Cs32, m->d_Cs64, m->d_Rs, m->d_Rt, m->d_mus, m->d_subs, m->d_P, m->d_pmu, m->d_cnorm, m->d_flag};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&m->ws_xp, &m->ws_x64, &m->ws_y64, &m->ws_dist, &m->ws_proj, &m->ws_group,
@@ -698,6 +913,19 @@ extern "C" int cis_model_create(cis_model** out, int D_in, int D, int V, int M, 
         memcpy(c64.data(), Cs, nC * sizeof(double));
     }
     if ((rc = upload(&m->d_Cs64, c64.data(), nC)) != CIS_OK) return fail(rc);
+    {
+        std::vector<double> cn((size_t)2 * V + 2, 0.0);
+        for (int s = 0; s < 2; ++s)
+            for (int c = 0; c < V; ++c) {
+                double a = 0.0;
+                for (int i = 0; i < m->h; ++i) { const double v = c64[((size_t)s * V + c) * m->h + i]; a += v * v; }
+                cn[(size_t)s * V + c] = a;
+                if (a > cn[(size_t)2 * V + s]) cn[(size_t)2 * V + s] = a;
+            }
+        if ((rc = upload(&m->d_cnorm, cn.data(), cn.size())) != CIS_OK) return fail(rc);
+        const int zero[2] = {0, 0};
+        if ((rc = upload(&m->d_flag, zero, 2)) != CIS_OK) return fail(rc);
+    }
     const size_t nR = (size_t)2 * V * m->h * m->h;
     if ((rc = upload(&m->d_Rs, Rs, nR)) != CIS_OK) return fail(rc);
     {
@@ -803,10 +1031,10 @@ int cis_launch_sqdist(cis_model* m, const void* xc, int ct, int64_t n, int split
     dim3 g((unsigned)ceil_div(n, 16), (unsigned)ceil_div(m->V, 16));
     if (ct == CIS_F32)
         hipLaunchKernelGGL(k_sqdist_rows<float>, g, dim3(256), 0, st, (const float*)xc, (int64_t)m->D, split * m->h,
-                           m->d_Cs32 + (size_t)split * m->V * m->h, n, m->V, m->h, (float*)out, m->prog_h);
+                           m->d_Cs32 + (size_t)split * m->V * m->h, n, m->V, m->h, (float*)out, m->prog_h, (const int*)nullptr);
     else
         hipLaunchKernelGGL(k_sqdist_rows<double>, g, dim3(256), 0, st, (const double*)xc, (int64_t)m->D, split * m->h,
-                           m->d_Cs64 + (size_t)split * m->V * m->h, n, m->V, m->h, (double*)out, m->prog_h);
+                           m->d_Cs64 + (size_t)split * m->V * m->h, n, m->V, m->h, (double*)out, m->prog_h, (const int*)nullptr);
     CIS_CHECK_HIP(hipGetLastError());
     return CIS_OK;
 }
@@ -819,10 +1047,10 @@ int cis_launch_sqdist_generic(const void* X, int ct, int64_t ldx, int xoff, cons
     dim3 g((unsigned)ceil_div(n, 16), (unsigned)ceil_div(ncent, 16));
     if (ct == CIS_F32)
         hipLaunchKernelGGL(k_sqdist_rows<float>, g, dim3(256), 0, st, (const float*)X, ldx, xoff, (const float*)C, n, ncent, d,
-                           (float*)out, prog);
+                           (float*)out, prog, (const int*)nullptr);
     else
         hipLaunchKernelGGL(k_sqdist_rows<double>, g, dim3(256), 0, st, (const double*)X, ldx, xoff, (const double*)C, n, ncent,
-                           d, (double*)out, prog);
+                           d, (double*)out, prog, (const int*)nullptr);
     CIS_CHECK_HIP(hipGetLastError());
     return CIS_OK;
 }
@@ -858,10 +1086,10 @@ extern "C" int cis_predict_cluster(const void* X, int x_dtype, const void* C, in
     if ((rc = cis_launch_sqdist_generic(bx.p, ct, d, 0, bc.p, n, ncent, d, bd.p, nullptr)) != CIS_OK) return done(rc);
     if (ct == CIS_F32)
         hipLaunchKernelGGL((k_argmin_rows<float, uint32_t>), dim3(grid1(n, 256)), dim3(256), 0, nullptr, bd.as<float>(), n, ncent,
-                           bo.as<uint32_t>(), 1, 0);
+                           bo.as<uint32_t>(), 1, 0, (const int*)nullptr);
     else
         hipLaunchKernelGGL((k_argmin_rows<double, uint32_t>), dim3(grid1(n, 256)), dim3(256), 0, nullptr, bd.as<double>(), n,
-                           ncent, bo.as<uint32_t>(), 1, 0);
+                           ncent, bo.as<uint32_t>(), 1, 0, (const int*)nullptr);
     hipError_t e = hipMemcpy(out, bo.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost);
     if (e != hipSuccess) { cis_set_error("hipMemcpy failed: %s", hipGetErrorString(e)); return done(CIS_EHIP); }
     return done(CIS_OK);
@@ -871,20 +1099,51 @@ extern "C" int cis_predict_cluster(const void* X, int x_dtype, const void* C, in
 static int dev_predict_coarse(cis_model* m, const void* xc, int ct, int64_t n, uint16_t* d_coarse, hipStream_t st) {
     if (n == 0) return CIS_OK;
     CIS_TRY(m->ws_dist.reserve((size_t)n * (m->V > m->K ? m->V : m->K) * sizeof(double)));
+    // many clusters: matrix-core prefilter + exact re-check of the few listed pairs; the exact kernels below then only run
+    // (device-side predicate) when a candidate list overflowed
+    const int coarse_mode = getenv("CIS_COARSE") ? atoi(getenv("CIS_COARSE")) : -1;  // 0 exact kernels, 1 prefilter
+    const bool pre = (coarse_mode == 1 || (coarse_mode != 0 && m->V >= 256)) && m->h <= 128 && m->V <= 65535;
+    const int* only_if = nullptr;
+    if (pre) {
+        CIS_CHECK_HIP(hipMemsetAsync(m->d_flag, 0, sizeof(int), st));
+        const dim3 gp((unsigned)ceil_div(n, 64), 2);
+        // |dt + |x|^2 - numpy's value| <= (h + 6) u (|x| + |c|)^2 for the exact sum in the compute type (u = 2^-24 / 2^-53) plus
+        // (h + 4) 2^-53 (|x|^2 + |c|^2) for the float64 matrix-core form; (|x| + |c|)^2 <= 2 (|x|^2 + |c|^2); margin x4
+        const double u = (ct == CIS_F32) ? ldexp(1.0, -24) : ldexp(1.0, -53);
+        const double eps_rel = 4.0 * (2.0 * (m->h + 6) * u + (m->h + 4) * ldexp(1.0, -53));
+#define CIS_COARSE_LAUNCH(T, KS, C)                                                                                          \
+    hipLaunchKernelGGL((k_coarse_mfma<T, KS>), gp, dim3(256), 0, st, (const T*)xc, (int64_t)m->D, m->h, C, m->d_cnorm, n, m->V, \
+                       d_coarse, m->prog_h, eps_rel, m->d_flag)
+        if (ct == CIS_F32) {
+            if (m->h <= 32) CIS_COARSE_LAUNCH(float, 8, m->d_Cs32);
+            else if (m->h <= 64) CIS_COARSE_LAUNCH(float, 16, m->d_Cs32);
+            else CIS_COARSE_LAUNCH(float, 32, m->d_Cs32);
+        } else {
+            if (m->h <= 32) CIS_COARSE_LAUNCH(double, 8, m->d_Cs64);
+            else if (m->h <= 64) CIS_COARSE_LAUNCH(double, 16, m->d_Cs64);
+            else CIS_COARSE_LAUNCH(double, 32, m->d_Cs64);
+        }
+#undef CIS_COARSE_LAUNCH
+        only_if = m->d_flag;
+    }
     dim3 g((unsigned)ceil_div(n, 16), (unsigned)ceil_div(m->V, 16));
+    if (pre) {
+        if (g.x > 512) g.x = 512;
+        if (g.y > 8) g.y = 8;
+    }
     for (int s = 0; s < 2; ++s) {
         if (ct == CIS_F32) {
             float* dist = m->ws_dist.as<float>();
             hipLaunchKernelGGL(k_sqdist_rows<float>, g, dim3(256), 0, st, (const float*)xc, (int64_t)m->D, s * m->h,
-                               m->d_Cs32 + (size_t)s * m->V * m->h, n, m->V, m->h, dist, m->prog_h);
+                               m->d_Cs32 + (size_t)s * m->V * m->h, n, m->V, m->h, dist, m->prog_h, only_if);
             hipLaunchKernelGGL((k_argmin_rows<float, uint16_t>), dim3(grid1(n, 256)), dim3(256), 0, st, dist, n, m->V,
-                               d_coarse, 2, s);
+                               d_coarse, 2, s, only_if);
         } else {
             double* dist = m->ws_dist.as<double>();
             hipLaunchKernelGGL(k_sqdist_rows<double>, g, dim3(256), 0, st, (const double*)xc, (int64_t)m->D, s * m->h,
-                               m->d_Cs64 + (size_t)s * m->V * m->h, n, m->V, m->h, dist, m->prog_h);
+                               m->d_Cs64 + (size_t)s * m->V * m->h, n, m->V, m->h, dist, m->prog_h, only_if);
             hipLaunchKernelGGL((k_argmin_rows<double, uint16_t>), dim3(grid1(n, 256)), dim3(256), 0, st, dist, n, m->V,
-                               d_coarse, 2, s);
+                               d_coarse, 2, s, only_if);
         }
     }
     CIS_CHECK_HIP(hipGetLastError());
@@ -910,7 +1169,7 @@ static int dev_project(cis_model* m, const void* xc, int ct, int64_t n, const ui
     CIS_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)2 * V * sizeof(int), st));
     const size_t bins_lds = V <= 1024 ? (size_t)4 * V * sizeof(int) : 0;
     hipLaunchKernelGGL(k_group_hist, dim3(grid1(n, 256)), dim3(256), bins_lds, st, d_coarse, n, V, counts);
-    hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(256), V <= 1024 ? (size_t)2 * V * sizeof(int) : 0, st, counts, V, offsets, cursor, tiles,
+    hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(256), (size_t)2 * V * sizeof(int), st, counts, V, offsets, cursor, tiles,
                        n_tiles, 64);
     hipLaunchKernelGGL(k_group_scatter, dim3(grid1(n, 256)), dim3(256), bins_lds, st, d_coarse, n, V, offsets, cursor, perm);
     dim3 g((unsigned)max_tiles, (unsigned)ceil_div(m->h, 64));
@@ -943,9 +1202,9 @@ static int dev_fine_from_proj(cis_model* m, const double* d_proj, int64_t n, uin
     dim3 g((unsigned)ceil_div(n, 16), (unsigned)ceil_div(m->K, 16));
     for (int j = 0; j < m->M; ++j) {
         hipLaunchKernelGGL(k_sqdist_rows<double>, g, dim3(256), 0, st, d_proj, (int64_t)m->D, j * m->w,
-                           m->d_subs + (size_t)j * m->K * m->w, n, m->K, m->w, dist, m->prog_w);
+                           m->d_subs + (size_t)j * m->K * m->w, n, m->K, m->w, dist, m->prog_w, (const int*)nullptr);
         hipLaunchKernelGGL((k_argmin_rows<double, uint8_t>), dim3(grid1(n, 256)), dim3(256), 0, st, dist, n, m->K,
-                           d_fine, m->M, j);
+                           d_fine, m->M, j, (const int*)nullptr);
     }
     CIS_CHECK_HIP(hipGetLastError());
     return CIS_OK;
@@ -1109,7 +1368,7 @@ extern "C" int cis_subquantizer_distances(cis_model* m, const void* X, int x_dty
     dim3 g((unsigned)ceil_div(n, 16), (unsigned)ceil_div(m->K, 16));
     for (int j = 0; j < m->M; ++j) {
         hipLaunchKernelGGL(k_sqdist_rows<double>, g, dim3(256), 0, nullptr, m->ws_proj.as<double>(), (int64_t)m->D,
-                           j * m->w, m->d_subs + (size_t)j * m->K * m->w, n, m->K, m->w, dist, m->prog_w);
+                           j * m->w, m->d_subs + (size_t)j * m->K * m->w, n, m->K, m->w, dist, m->prog_w, (const int*)nullptr);
         CIS_CHECK_HIP(hipMemcpy2D(tables + (size_t)j * m->K, (size_t)m->M * m->K * sizeof(double), dist,
                                   (size_t)m->K * sizeof(double), (size_t)m->K * sizeof(double), (size_t)n,
                                   hipMemcpyDeviceToHost));

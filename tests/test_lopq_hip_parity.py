@@ -615,6 +615,80 @@ def test_wide_coarse_vocabulary_matches_oracle(V, M, K, D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("V,h,dtype", [(300, 64, np.float32), (1000, 30, np.float64), (2048, 64, np.float32), (512, 128, np.float64),
+                                       (640, 128, np.float32), (257, 7, np.float32)])
+def test_coarse_prefilter_matches_numpy_argmin(V, h, dtype):
+    """Coarse ids with many clusters: the matrix-core prefilter + exact re-check (k_coarse_mfma) against numpy's
+    ((x - C)**2).sum(axis=1).argmin() (lopq/lopq/utils.py:33-53) and against the all-pairs exact kernels, on inputs built to
+    tie: duplicated centroids (the first index must win), vectors ON centroids, midpoints of centroid pairs, zero vectors,
+    vectors far outside the centroids' range, a ragged row count."""
+    from oracle import lopq_oracle as O
+    from columbiaimagesearch_amd.lopq import LOPQModel
+    rs = np.random.RandomState(V + h)
+    D = 2 * h
+    Cs = [rs.randn(V, h).astype(dtype) * (0.3 + s) for s in range(2)]
+    for C in Cs:
+        C[V // 2] = C[3]            # exact duplicates: numpy returns the first
+        C[V - 1] = C[V // 3]
+    M = 2
+    Rs = tuple(np.broadcast_to(np.eye(h), (V, h, h)).copy() for _ in range(2))
+    mus = tuple(np.zeros((V, h)) for _ in range(2))
+    subs = tuple([rs.randn(4, h)] for _ in range(2))
+    m = LOPQModel(parameters=(tuple(Cs), Rs, mus, subs))
+    om = O.OracleModel(Cs, list(Rs), list(mus), [list(subs[0]), list(subs[1])])
+    n = 6001
+    X = np.concatenate([rs.randn(n, h) * (0.3 + s) for s in range(2)], axis=1)
+    pick = rs.randint(0, V, size=(n, 2))
+    for s in range(2):
+        sl = slice(s * h, (s + 1) * h)
+        X[0:1500, sl] = Cs[s][pick[0:1500, s]]                                      # on a centroid (some on the duplicated ones)
+        X[1500:3000, sl] = (Cs[s][pick[1500:3000, s]].astype(np.float64) + Cs[s][pick[1500:3000, 1 - s]]) / 2  # midpoints
+        X[3000:3050, sl] = 0.0
+        X[3050:3100, sl] *= 1e3
+        X[3100:3150, sl] *= 1e-6
+    X[:20, :h] = Cs[0][3]
+    X = X.astype(dtype)
+    want = O.predict_coarse(om, X)
+    got = {}
+    for mode in ("1", "0"):
+        os.environ["CIS_COARSE"] = mode
+        try:
+            got[mode] = m.predict_coarse(X)
+        finally:
+            del os.environ["CIS_COARSE"]
+    np.testing.assert_array_equal(got["0"], want)
+    np.testing.assert_array_equal(got["1"], want)
+    assert (want[:20, 0] == 3).all()
+
+
+@pytest.mark.gpu
+def test_coarse_prefilter_overflow_falls_back_to_exact_kernels():
+    """Hundreds of identical centroids put every one of them on a row's candidate list: the list overflows, the kernel raises
+    its flag and the predicated exact kernels redo the pass -- the answer is still numpy's (first index of the tie)."""
+    from oracle import lopq_oracle as O
+    from columbiaimagesearch_amd.lopq import LOPQModel
+    rs = np.random.RandomState(5)
+    V, h = 768, 16
+    Cs = [rs.randn(V, h).astype(np.float32) for _ in range(2)]
+    Cs[0][100:700] = Cs[0][100]
+    Rs = tuple(np.broadcast_to(np.eye(h), (V, h, h)).copy() for _ in range(2))
+    mus = tuple(np.zeros((V, h)) for _ in range(2))
+    subs = tuple([rs.randn(4, h)] for _ in range(2))
+    m = LOPQModel(parameters=(tuple(Cs), Rs, mus, subs))
+    om = O.OracleModel(Cs, list(Rs), list(mus), [list(subs[0]), list(subs[1])])
+    X = rs.randn(3000, 2 * h).astype(np.float32)
+    X[:1000, :h] = Cs[0][100] + rs.randn(1000, h).astype(np.float32) * 1e-3
+    os.environ["CIS_COARSE"] = "1"
+    try:
+        got = m.predict_coarse(X)
+    finally:
+        del os.environ["CIS_COARSE"]
+    want = O.predict_coarse(om, X)
+    np.testing.assert_array_equal(got, want)
+    assert (want[:1000, 0] == 100).all()
+
+
+@pytest.mark.gpu
 def test_randomised_parity_fuzz():
     """Random model shapes / duplicate-heavy data / quota and limit over all three ranking paths (tests/tools/fuzz_parity.py)."""
     import importlib.util
