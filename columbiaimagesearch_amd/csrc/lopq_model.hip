@@ -354,23 +354,26 @@ __global__ void k_pca_finish(const double* __restrict__ Y, float* __restrict__ o
 // interleaved accumulators, r[j] = a[j] + a[8+j] + a[16+j] + ..., combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).
 // Eight lanes own the eight accumulators of a row (same additions in the same order, IEEE addition is commutative),
 // so the loads and stores of a row are contiguous instead of one strided row per thread.
-__global__ __launch_bounds__(256) void k_pca_finish8(const double* __restrict__ Y, float* __restrict__ out, int64_t n, int D) {
+__global__ __launch_bounds__(64) void k_pca_finish8(const double* __restrict__ Y, float* __restrict__ out, int64_t n, int D) {
     const int j = threadIdx.x & 7;
-    const int64_t r = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int64_t r = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
     const bool on = r < n;
     const double* y = Y + (on ? r : 0) * D;
-    double v0 = y[j];
-    double acc = v0 * v0;
-    for (int i = 8; i < D; i += 8) {
-        const double v = y[i + j];
-        acc = acc + v * v;
-    }
+    double v[16];  // D <= 128: the row's values stay in registers between the norm and the division (one wave per 8 rows)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (i * 8 < D) ? y[i * 8 + j] : 0.0;
+    double acc = v[0] * v[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i)
+        if (i * 8 < D) acc = acc + v[i] * v[i];
     acc = acc + __shfl_xor(acc, 1);
     acc = acc + __shfl_xor(acc, 2);
     acc = acc + __shfl_xor(acc, 4);
     const double nrm = sqrt(acc);
     if (!on) return;
-    for (int i = 0; i < D; i += 8) out[r * D + i + j] = (float)(y[i + j] / nrm);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i * 8 < D) out[r * D + i * 8 + j] = (float)(v[i] / nrm);
 }
 
 // out[r][c] = sum_i (X[r][xoff+i] - C[c][i])^2 in numpy's order; 16 rows x 16 centroids / block.
@@ -958,8 +961,10 @@ int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, floa
     const bool small = ceil_div(n, 64) * ceil_div(m->D, 64) < 512;
     dim3 g((unsigned)ceil_div(n, small ? 32 : 64), (unsigned)ceil_div(m->D, 64));
     // wide inputs (the 4096-d DeepSentibank features): the float64 matrix cores; CIS_PCA_GEMM=valu keeps the register-tiled kernel
-    static const bool pca_valu = getenv("CIS_PCA_GEMM") && !strcmp(getenv("CIS_PCA_GEMM"), "valu");
-    const bool use_mfma = !pca_valu && m->D_in >= 256;
+    const char* pca_env = getenv("CIS_PCA_GEMM");
+    const bool pca_valu = pca_env && !strcmp(pca_env, "valu");
+    const bool pca_force = pca_env && !strcmp(pca_env, "mfma");
+    const bool use_mfma = !pca_valu && (m->D_in >= 128 || pca_force);
     dim3 gm((unsigned)ceil_div(n, 64), (unsigned)ceil_div(m->D, 64));
 #define CIS_PCA_LAUNCH(TX, SUB, XP)                                                                                              \
     do {                                                                                                                          \
@@ -972,7 +977,7 @@ int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, floa
     else CIS_PCA_LAUNCH(double, false, (const double*)dX);
 #undef CIS_PCA_LAUNCH
     if (m->renorm && m->D >= 8 && m->D <= 128 && m->D % 8 == 0)
-        hipLaunchKernelGGL(k_pca_finish8, dim3((unsigned)ceil_div(n, 32)), dim3(256), 0, st, Y, d_out, n, m->D);
+        hipLaunchKernelGGL(k_pca_finish8, dim3((unsigned)ceil_div(n, 8)), dim3(64), 0, st, Y, d_out, n, m->D);
     else
         hipLaunchKernelGGL(k_pca_finish, dim3(grid1(n, 64)), dim3(64), 0, st, Y, d_out, n, m->D, m->renorm ? 1 : 0, m->prog_D);
     CIS_CHECK_HIP(hipGetLastError());

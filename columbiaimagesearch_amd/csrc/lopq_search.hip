@@ -2516,6 +2516,9 @@ struct cis_index {
     bool force_scan2 = false;       // scan mode 2: the float32-prefilter kernel whatever the batch size
     bool force_scan3 = false;       // scan mode 3: the 16-bit fixed-point kernel whatever the batch size
     int force_two_pass = -1;        // scan mode 3: k_adc_scan3's streaming form, 4: its two-pass form (-1: by chunk length)
+    int batch_hint = 0;             // sub-batch size that fitted the workspace budget after a retry (search_all)
+    int64_t batch_hint_quota = -1;
+    double retry_fraction = 0.5;
     int last_scan_kernel = 0;       // 0 none (all-candidates path), 1 float64 scan, 2 float32 prefilter, 3 16-bit fixed-point prefilter
     bool force_prefilter_scan = false;  // tests: the float32-prefilter kernel also for small batches
     int profiling = 0;  // 0 off, 1 events around the scan kernel only, 2 events around every stage
@@ -3738,7 +3741,13 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     const bool par_plan = V >= 128 && V <= PLAN_PAR_CAP && !no_par_plan;
     int* plan_fb = nullptr;
     uint32_t* vis_list = nullptr;
-    const int vis_cap = (int64_t)V * V < 16384 ? V * V : 16384;  // visited cells per query the fast plan records
+    // visited cells per query the fast plan records: 2 GB of visit lists per batch (an outlier query far from the data walks
+    // tens of thousands of empty cells at V = 4096; past the cap the query goes to the serial frontier walk, ~3 us per cell)
+    int64_t vis_cap64 = ((int64_t)1 << 31) / ((int64_t)(nq > 0 ? nq : 1) * 4);
+    if (vis_cap64 < 16384) vis_cap64 = 16384;
+    if (vis_cap64 > (1 << 20)) vis_cap64 = 1 << 20;
+    if (vis_cap64 > (int64_t)V * V) vis_cap64 = (int64_t)V * V;
+    const int vis_cap = (int)vis_cap64;
     if (par_plan) {
         CIS_TRY(ix->w_planfb.reserve((size_t)nq * sizeof(int)));
         CIS_TRY(ix->w_vis.reserve((size_t)nq * vis_cap * sizeof(uint32_t)));
@@ -3832,9 +3841,6 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         }
         n_items = h_tot[0]; n_tabs = h_tot[1]; n_cand_all = h_tot[2];
         ix->stats_pending_seq = 0;
-        ix->stats[0] += n_cand_all;
-        ix->stats[1] += n_items;
-        ix->stats[2] += n_tabs;
     }
     CIS_REQUIRE(n_items < ((int64_t)1 << 31) && n_tabs < ((int64_t)1 << 31), "query batch too large");
     {
@@ -3848,7 +3854,17 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             need = (sp_.select ? 8.0 * (double)n_cand_all + (sp_.sort_lds ? 16.0 : 32.0) * (double)nq * (double)sp_.stride : 32.0 * (double)n_cand_all) +
                    (double)n_tabs * nf * K * sizeof(double);
         }
-        if (need > 4.0e9 && nq > 1) return CIS_RETRY_SMALLER;
+        // default 24 GB of the 288 GB: thousands of coarse clusters need ~1.6 MB of tables per query (V = 2048, quota 10000)
+        const double budget = (getenv("CIS_WORKSPACE_GB") ? atof(getenv("CIS_WORKSPACE_GB")) : 24.0) * 1.0e9;
+        if (need > budget && nq > 1) {
+            ix->retry_fraction = 0.9 * budget / need;  // the caller plans again with this share of the batch
+            return CIS_RETRY_SMALLER;
+        }
+    }
+    if (!d_tot) {
+        ix->stats[0] += n_cand_all;
+        ix->stats[1] += n_items;
+        ix->stats[2] += n_tabs;
     }
     // 3. emit items + table list
     CIS_TRY(mark(1));  // the plan read-back above is part of the front end
@@ -4125,7 +4141,9 @@ static int search_all(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_
     CIS_CHECK_HIP(hipSetDevice(ix->m->device));
     for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
     ix->stats_pending_seq = 0;
-    int batch = QUERY_BATCH;
+    // a batch that did not fit the workspace is planned again smaller; the size that fitted is remembered for the next
+    // call with the same quota (the plan of a rejected batch is wasted front-end time)
+    int batch = (ix->batch_hint > 0 && ix->batch_hint_quota == quota) ? ix->batch_hint : QUERY_BATCH;
     for (int a = 0; a < nq;) {
         const int bn = (nq - a < batch) ? (nq - a) : batch;
         const char* q = (const char*)dQ + (size_t)a * ix->m->D_in * q_dtype;
@@ -4140,7 +4158,12 @@ static int search_all(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_
             rc = search_batch(ix, q, q_dtype, bn, quota, 1, o, st);
         }
         if (rc == CIS_RETRY_SMALLER) {
-            batch = bn > 1 ? bn / 2 : 1;
+            int nb = (int)((double)bn * ix->retry_fraction);
+            if (nb > bn / 2 && bn / 2 >= 64) nb = nb / 64 * 64;
+            if (nb >= bn) nb = bn / 2;
+            batch = nb > 1 ? nb : 1;
+            ix->batch_hint = batch;
+            ix->batch_hint_quota = quota;
             continue;
         }
         CIS_TRY(rc);

@@ -390,8 +390,16 @@ def test_exhaustive_quota_splits_batches_and_matches_oracle():
     rs = np.random.RandomState(5)
     Qb = np.concatenate([Q, X[rs.choice(len(X), 4096 - len(Q), replace=False)]])  # 4096 queries x 256 cells
     quota = len(z["coarse"]) + 1  # can never be filled: every one of the V*V cells is visited
-    r = s.search_batch(Qb, quota=quota, limit=100)
+    os.environ["CIS_WORKSPACE_GB"] = "2"  # the default budget (24 GB) would take this batch whole
+    try:
+        r = s.search_batch(Qb, quota=quota, limit=100)
+        r2 = s.search_batch(Qb[:3000], quota=quota, limit=100)  # starts from the remembered sub-batch size
+    finally:
+        del os.environ["CIS_WORKSPACE_GB"]
     assert (r["visited"] == m.V * m.V).all() and (r["n_found"] == 100).all()
+    np.testing.assert_array_equal(r2["ids"], r["ids"][:3000])
+    whole = s.search_batch(Qb[:512], quota=quota, limit=100)
+    np.testing.assert_array_equal(whole["ids"], r["ids"][:512])
     om = O.OracleModel.from_npz(z)
     oi = O.OracleCSRIndex(om, z["coarse"], z["fine"])
     for qi in list(range(8)) + [2000, 4095]:
