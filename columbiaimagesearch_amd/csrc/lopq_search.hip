@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64) void k_plan(const CT* __restrict__ sorted, cons
 //   4. a band that cannot be cut below what the workgroup sorts (thousands of equal sums), or more visited cells than the
 //      list holds: the query is flagged and the frontier walk above (k_plan with `only`) handles it.
 // The count pass leaves the visited (i, j) list in global memory for the emit pass.
-static const int PLAN_PAR_CAP = 4096;   // cells a workgroup enumerates and sorts
+static const int PLAN_PAR_CAP = 2048;   // cells a workgroup enumerates and sorts per band
 static const int PLAN_PAR_STAGE = 4096; // d0 / d1 staged in LDS: the kernel takes V <= 4096
 
 // all of d0 / d1 is staged in LDS (V <= PLAN_PAR_STAGE); read in place (no generic pointers to the LDS arrays)
@@ -210,8 +210,10 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
                                                   int* __restrict__ fallback /* [nq] */, int vis_cap) {
     __shared__ uint64_t s_key[PLAN_PAR_CAP];
     __shared__ uint32_t s_ij[PLAN_PAR_CAP];
-    __shared__ uint32_t s_gc[PLAN_PAR_CAP];
-    __shared__ CT s_d0[PLAN_PAR_STAGE], s_d1[PLAN_PAR_STAGE];
+    __shared__ uint32_t s_gc[PLAN_PAR_STAGE];  // row starts of the band (one per active row, <= V), then the cells' sizes (<= PLAN_PAR_CAP)
+    extern __shared__ __align__(16) unsigned char s_plan_dyn[];  // d0, d1: 2 V values (count pass; two workgroups per CU at V = 2048)
+    CT* s_d0 = reinterpret_cast<CT*>(s_plan_dyn);
+    CT* s_d1 = s_d0 + V;
     __shared__ int64_t s_red[8];
     __shared__ int s_i[8];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -3307,6 +3309,111 @@ __global__ __launch_bounds__(256) void k_adc_all_flat(const WorkItem* __restrict
     if (qmin) publish_key_range(mn, mx, qmin, qmax, q);
 }
 
+// Tiny cells, direct form: no distance tables at all.  With thousands of coarse clusters a query touches ~100 (split, cluster)
+// pairs per 10 k candidates -- more table entries (100 x nf x K) than lookups (10 k x M), 8 KB of float64 per table written and
+// gathered back at random (10 GB per 8192 queries at V = 2048).  Here a candidate's entry j is computed where it is needed:
+// e_j = sum_i (px[tab][j w + i] - sub[j][code_j][i])^2 in predict_cluster's order -- the expression, operands and summation of
+// k_tables_from_px, so the same bits -- with the sub-quantizers of a PHASE (JP of them, <= 128 KB of float64) resident in LDS and
+// the projected residuals px (512 B per (query, cluster)) read through L2.  The running sum of search.py:173 crosses the phases
+// through the key array: phase p adds its entries, left to right, to what phase p - 1 left.
+template <int MT, int W, int JP>
+__global__ __launch_bounds__(1024) void k_adc_direct(const WorkItem* __restrict__ items, const int64_t* __restrict__ cand_start,
+                                                     const int64_t* __restrict__ seg, const int64_t* __restrict__ item_off,
+                                                     const double* __restrict__ px, const double* __restrict__ subs,
+                                                     const uint8_t* __restrict__ codes, int K, int h, int phase, int nq,
+                                                     uint64_t* __restrict__ keys, uint64_t* __restrict__ vals,
+                                                     unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax) {
+    extern __shared__ __align__(16) double s_sub[];  // [JP][K][W], then the item starts of the current query
+    int* s_start = reinterpret_cast<int*>(s_sub + (size_t)JP * K * W);
+    constexpr int nf = MT / 2;
+    constexpr int NPH = MT / JP;
+    const int j0 = phase * JP;
+    {
+        const double2* src = reinterpret_cast<const double2*>(subs + (size_t)j0 * K * W);
+        double2* dst = reinterpret_cast<double2*>(s_sub);
+        for (int i = threadIdx.x; i < JP * K * W / 2; i += 1024) dst[i] = src[i];
+    }
+    const bool last = phase == NPH - 1;
+    for (int q = blockIdx.x; q < nq; q += gridDim.x) {
+        const int64_t it0 = item_off[q], it1 = item_off[q + 1];
+        const int64_t c0 = seg[q], c1 = seg[q + 1];
+        const int ni = (int)(it1 - it0);
+        const int64_t n = c1 - c0;
+        const bool staged = ni <= FLAT_ITEMS;
+        __syncthreads();  // the previous query's starts are no longer read (and the sub-quantizers are in place)
+        if (staged)
+            for (int i = threadIdx.x; i < ni; i += 1024) s_start[i] = (int)(cand_start[it0 + i] - c0);
+        __syncthreads();
+        uint64_t mn = ~0ull, mx = 0ull;
+        for (int64_t c = threadIdx.x; c < n; c += 1024) {
+            int lo = 0, hi = ni;  // first item whose start is > c; the item before it holds c
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const int64_t st_ = staged ? (int64_t)s_start[mid] : cand_start[it0 + mid] - c0;
+                if (st_ <= c) lo = mid + 1;
+                else hi = mid;
+            }
+            const int i = lo - 1;
+            const WorkItem it = items[it0 + i];
+            const int p = (int)(c - (staged ? (int64_t)s_start[i] : cand_start[it0 + i] - c0));
+            const CodeWords<MT> cw = load_code<MT>(codes, it.start + p);
+            double d = phase == 0 ? 0.0 : __longlong_as_double((long long)keys[c0 + c]);
+#pragma unroll
+            for (int jj = 0; jj < JP; ++jj) {
+                const int j = j0 + jj;
+                const bool second = j >= nf;
+                const double* f = px + (int64_t)(second ? it.tab1 : it.tab0) * h + (second ? j - nf : j) * W;
+                const uint32_t code = (cw.w[j >> 2] >> (8 * (j & 3))) & 255u;
+                const double* sc = s_sub + ((size_t)jj * K + code) * W;
+                auto elem = [&](int e) -> double { const double df = f[e] - sc[e]; return df * df; };
+                const double v = pw_leaf<double>(elem, 0, W);
+                d = (phase == 0 && jj == 0) ? v : d + v;
+            }
+            const uint64_t kk = (uint64_t)__double_as_longlong(d);
+            keys[c0 + c] = kk;
+            if (last) {
+                mn = kk < mn ? kk : mn;
+                mx = kk > mx ? kk : mx;
+                if (vals) vals[c0 + c] = ((uint64_t)(it0 + i) << 32) | (uint32_t)p;
+            }
+        }
+        if (last && qmin) publish_key_range(mn, mx, qmin, qmax, q);
+    }
+}
+
+// sub-quantizers per phase of the direct form: the largest divisor of M whose float64 centroids fit 128 KB of LDS; 0 = not served
+static int direct_jp(int M, int K, int w) {
+    if (!(M == 4 || M == 8 || M == 16) || K > 256 || K % 2 != 0 || !(w == 4 || w == 8 || w == 16 || w == 32)) return 0;
+    return M < 64 / w ? M : 64 / w;  // sized for K = 256 (the instantiated set below)
+}
+
+template <int MT, int W, int JP>
+static void launch_adc_direct_t(hipStream_t st, const WorkItem* items, const int64_t* cand_start, const int64_t* seg,
+                                const int64_t* item_off, const double* px, const double* subs, const uint8_t* codes, int K, int h,
+                                int nq, uint64_t* keys, uint64_t* vals, unsigned long long* qmin, unsigned long long* qmax) {
+    const size_t lds = (size_t)JP * K * W * sizeof(double) + (size_t)FLAT_ITEMS * sizeof(int);
+    const unsigned grid = (unsigned)(nq < 256 ? nq : 256);
+    for (int ph = 0; ph < MT / JP; ++ph)
+        hipLaunchKernelGGL((k_adc_direct<MT, W, JP>), dim3(grid), dim3(1024), lds, st, items, cand_start, seg, item_off, px, subs, codes, K, h,
+                           ph, nq, keys, vals, qmin, qmax);
+}
+
+static bool launch_adc_direct(int M, int K, int w, hipStream_t st, const WorkItem* items, const int64_t* cand_start, const int64_t* seg,
+                              const int64_t* item_off, const double* px, const double* subs, const uint8_t* codes, int h, int nq,
+                              uint64_t* keys, uint64_t* vals, unsigned long long* qmin, unsigned long long* qmax) {
+    const int jp = direct_jp(M, K, w);
+#define CIS_DIRECT(MT, W, JP)                                                                                                     \
+    if (M == MT && w == W && jp == JP) {                                                                                          \
+        launch_adc_direct_t<MT, W, JP>(st, items, cand_start, seg, item_off, px, subs, codes, K, h, nq, keys, vals, qmin, qmax);  \
+        return true;                                                                                                              \
+    }
+    // K = 256: 128 KB hold 64 / w sub-quantizers
+    CIS_DIRECT(8, 16, 4) CIS_DIRECT(16, 16, 4) CIS_DIRECT(4, 16, 4) CIS_DIRECT(8, 8, 8) CIS_DIRECT(16, 8, 8) CIS_DIRECT(4, 8, 4)
+    CIS_DIRECT(4, 32, 2) CIS_DIRECT(8, 32, 2) CIS_DIRECT(16, 32, 2) CIS_DIRECT(4, 4, 4) CIS_DIRECT(8, 4, 8) CIS_DIRECT(16, 4, 16)
+#undef CIS_DIRECT
+    return false;
+}
+
 static void launch_adc_all(int64_t n_items, hipStream_t st, const WorkItem* items, const int64_t* cand_start, const double* T,
                            const uint8_t* codes, int M, int K, uint64_t* keys, uint64_t* vals, unsigned long long* qmin,
                            unsigned long long* qmax, const int64_t* d_totals = nullptr, const int64_t* seg = nullptr,
@@ -3738,7 +3845,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     // thousands of coarse clusters (the release configurations' V = 2048 / 4096): the plan is a per-query selection + sort
     // (k_plan_par) instead of one frontier step per visited cell; queries it cannot resolve fall back to the frontier walk
     static const bool no_par_plan = getenv("CIS_NO_PAR_PLAN") != nullptr;
-    const bool par_plan = V >= 128 && V <= PLAN_PAR_CAP && !no_par_plan;
+    const bool par_plan = V >= 128 && V <= PLAN_PAR_STAGE && !no_par_plan;
     int* plan_fb = nullptr;
     uint32_t* vis_list = nullptr;
     // visited cells per query the fast plan records: 2 GB of visit lists per batch (an outlier query far from the data walks
@@ -3766,7 +3873,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             hipLaunchKernelGGL(k_rank<float>, dim3(nq, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, st, ix->w_cd.as<float>(), nq, V,
                                ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
         if (par_plan)
-            hipLaunchKernelGGL((k_plan_par<float, false>), dim3(nq), dim3(256), 0, st, ix->w_sorted.as<float>(), ix->w_order.as<uint16_t>(),
+            hipLaunchKernelGGL((k_plan_par<float, false>), dim3(nq), dim3(256), (size_t)2 * V * sizeof(float), st, ix->w_sorted.as<float>(), ix->w_order.as<uint16_t>(),
                                ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
                                nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap);
         hipLaunchKernelGGL((k_plan<float, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<float>(),
@@ -3780,7 +3887,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             hipLaunchKernelGGL(k_rank<double>, dim3(nq, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, st, ix->w_cd.as<double>(), nq,
                                V, ix->w_order.as<uint16_t>(), ix->w_sorted.as<double>(), grp_cnt);
         if (par_plan)
-            hipLaunchKernelGGL((k_plan_par<double, false>), dim3(nq), dim3(256), 0, st, ix->w_sorted.as<double>(), ix->w_order.as<uint16_t>(),
+            hipLaunchKernelGGL((k_plan_par<double, false>), dim3(nq), dim3(256), (size_t)2 * V * sizeof(double), st, ix->w_sorted.as<double>(), ix->w_order.as<uint16_t>(),
                                ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
                                nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap);
         hipLaunchKernelGGL((k_plan<double, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
@@ -3843,6 +3950,9 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         ix->stats_pending_seq = 0;
     }
     CIS_REQUIRE(n_items < ((int64_t)1 << 31) && n_tabs < ((int64_t)1 << 31), "query batch too large");
+    // tiny cells on the all-candidates path: entries computed per candidate from px (k_adc_direct), no tables
+    const bool direct_elig = !d_tot && use_all_path(ix, M, K, L, nq) && index_has_tiny_cells(ix) && h <= 256 && direct_jp(M, K, m->w) > 0 &&
+                             !getenv("CIS_TABLES_UNGROUPED") && !getenv("CIS_NO_DIRECT");
     {
         // workspace budget: per-item hit lists and the float64 tables.  A batch that would need more (e.g. an
         // exhaustive quota: every query visits every cell) is split by the caller and planned again.
@@ -3852,7 +3962,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (use_all_path(ix, M, K, L, nq)) {  // every candidate's key, plus the selected pairs or the full sort's buffers
             const SelectPlan sp_ = select_plan(L, nq, n_cand_all);
             need = (sp_.select ? 8.0 * (double)n_cand_all + (sp_.sort_lds ? 16.0 : 32.0) * (double)nq * (double)sp_.stride : 32.0 * (double)n_cand_all) +
-                   (double)n_tabs * nf * K * sizeof(double);
+                   (direct_elig ? (double)n_tabs * h * sizeof(double) : (double)n_tabs * nf * K * sizeof(double));
         }
         // default 24 GB of the 288 GB: thousands of coarse clusters need ~1.6 MB of tables per query (V = 2048, quota 10000)
         const double budget = (getenv("CIS_WORKSPACE_GB") ? atof(getenv("CIS_WORKSPACE_GB")) : 24.0) * 1.0e9;
@@ -3870,7 +3980,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     CIS_TRY(mark(1));  // the plan read-back above is part of the front end
     CIS_TRY(ix->w_items.reserve((size_t)(n_items + 1) * sizeof(WorkItem)));
     CIS_TRY(ix->w_tabs.reserve((size_t)(n_tabs + 1) * sizeof(TabDesc)));
-    CIS_TRY(ix->w_T.reserve((size_t)(n_tabs + 1) * nf * K * sizeof(double)));
+    CIS_TRY(ix->w_T.reserve(direct_elig ? 256 : (size_t)(n_tabs + 1) * nf * K * sizeof(double)));
     const bool big = use_all_path(ix, M, K, L, nq);  // ranked over all candidates' exact distances (below)
     const bool tiny_cells = index_has_tiny_cells(ix);
     const bool fast = scan2_supported(M, K, L) && !ix->force_exact_scan;
@@ -3885,7 +3995,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     CIS_TRY(ix->w_tord.reserve((size_t)(n_tabs + 1) * sizeof(int)));
     int* tab_order = ix->w_tord.as<int>();  // table indices grouped by (split, cluster)
     double* T = ix->w_T.as<double>();
-    CIS_TRY(ix->w_T32.reserve((size_t)(n_tabs + 1) * nf * K * sizeof(float)));
+    CIS_TRY(ix->w_T32.reserve(direct_elig ? 256 : (size_t)(n_tabs + 1) * nf * K * sizeof(float)));
     float* T32 = ix->w_T32.as<float>();
     const size_t tab_lds = (size_t)(2 * h + (h < 256 ? 256 : 0)) * sizeof(double);
     const bool split_tables = (m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) && K <= 256;
@@ -3917,7 +4027,9 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             launch_tables<double>(n_tabs, tab_lds, st, (const double*)xc, m->d_Cs64, m->d_Rt, m->d_mus, m->d_subs, tabs, tab_order, V,
                                   h, m->w, nf, K, D, T, m->prog_w, px_buf, d_tot);
     }
-    if (split_tables && n_tabs > 0) {
+    const bool direct = direct_elig;
+    if (direct) {
+    } else if (split_tables && n_tabs > 0) {
         dim3 g((unsigned)ceil_div(n_tabs, 64), (unsigned)nf, 2);
         switch (m->w) {
             case 4: hipLaunchKernelGGL(k_tables_from_px<4>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32, d_tot); break;
@@ -3978,14 +4090,15 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (!sp.select) {
             uint64_t *keys_out = b1, *vals_in = b2, *vals_out = b3;
             if (n_items > 0) {
-                launch_adc_all(n_items, st, items, cand_start, T, codes, M, K, keys_in, vals_in, nullptr, nullptr, nullptr, seg, item_off, nq, tiny_cells);
+                if (!(direct && launch_adc_direct(M, K, m->w, st, items, cand_start, seg, item_off, px_buf, m->d_subs, codes, h, nq, keys_in, vals_in, nullptr, nullptr)))
+                    launch_adc_all(n_items, st, items, cand_start, T, codes, M, K, keys_in, vals_in, nullptr, nullptr, nullptr, seg, item_off, nq, tiny_cells);
                 size_t b = tmp_bytes;
                 CIS_TRY(cis_seg_sort_u64(tmp, &b, keys_in, keys_out, vals_in, vals_out, n_cand, nq, seg, seg + 1, st));
             }
             rk = keys_out; rv = vals_out;
         } else {
             uint64_t *sel_keys = b1, *sel_vals = b2;
-            if (n_items > 0)
+            if (n_items > 0 && !(direct && launch_adc_direct(M, K, m->w, st, items, cand_start, seg, item_off, px_buf, m->d_subs, codes, h, nq, keys_in, nullptr, qmin, qmax)))
                 launch_adc_all(n_items, st, items, cand_start, T, codes, M, K, keys_in, nullptr, qmin, qmax, d_tot, seg, item_off, nq, tiny_cells);
             if (sp.sort_lds) {
                 // fewer queries than CUs: one large workgroup per query walks its keys faster; else two 512-thread ones per CU
