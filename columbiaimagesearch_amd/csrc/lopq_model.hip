@@ -211,11 +211,14 @@ __global__ __launch_bounds__(256) void k_pca_gemm(const TX* __restrict__ X, cons
 // The register-tiled kernel above is LDS-bound (eight 8-byte reads per sixteen FMAs: 17-23 TFLOP/s); here a wave reads four
 // operands per four MFMAs (4 x 2048 flop).
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-template <typename TX, bool SUBF32>
+template <typename TX, bool SUBF32, int BK>
 __global__ __launch_bounds__(256) void k_pca_gemm_mfma(const TX* __restrict__ X, const double* __restrict__ mu,
                                                        const double* __restrict__ P, double* __restrict__ Y,
                                                        int64_t n, int D_in, int D) {
-    constexpr int BM = 64, BK = 32;
+    constexpr int BM = 64;
+    constexpr int QK = BK / 4;            // quads of consecutive k per row and stage
+    constexpr int NA = 64 * QK / 256;     // X quads per thread and stage (2 at BK = 32, 1 at BK = 16)
+    constexpr int NB = BK * 32 / 256;     // P column pairs per thread and stage
     __shared__ double sA[2][BK][BM + 2];  // [stage][k][row]
     __shared__ double sB[2][BK][64 + 2];  // [stage][k][col]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -231,13 +234,13 @@ __global__ __launch_bounds__(256) void k_pca_gemm_mfma(const TX* __restrict__ X,
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
     // a stage is 64 rows x 32 k of X (four consecutive k per thread and fetch: one 16-byte load for float32 rows) and
     // 32 k x 64 columns of P (two consecutive columns per thread and fetch)
-    double ra[2][4], rb[4][2];
+    double ra[NA][4], rb[NB][2];
     const bool vec4 = (D_in % 4 == 0);
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int idx = tid + e * 256;            // 512 quads: row = idx / 8, k quad = idx % 8
-            const int r = idx >> 3, kq = (idx & 7) * 4;
+        for (int e = 0; e < NA; ++e) {
+            const int idx = tid + e * 256;            // 64 * QK quads: row = idx / QK, k quad = idx % QK
+            const int r = idx / QK, kq = (idx % QK) * 4;
             const bool ron = row0 + r < n;
             float xf[4];
             double xd[4];
@@ -269,8 +272,8 @@ __global__ __launch_bounds__(256) void k_pca_gemm_mfma(const TX* __restrict__ X,
             }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = tid + e * 256;            // 1024 pairs: k = idx / 32, column pair = idx % 32
+        for (int e = 0; e < NB; ++e) {
+            const int idx = tid + e * 256;            // BK * 32 pairs: k = idx / 32, column pair = idx % 32
             const int k = idx >> 5, c = (idx & 31) * 2;
             rb[e][0] = 0.0; rb[e][1] = 0.0;
             if (k0 + k < D_in) {
@@ -286,14 +289,14 @@ __global__ __launch_bounds__(256) void k_pca_gemm_mfma(const TX* __restrict__ X,
     };
     auto stash = [&](int st) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < NA; ++e) {
             const int idx = tid + e * 256;
-            const int r = idx >> 3, kq = (idx & 7) * 4;
+            const int r = idx / QK, kq = (idx % QK) * 4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) sA[st][kq + c][r] = ra[e][c];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < NB; ++e) {
             const int idx = tid + e * 256;
             const int k = idx >> 5, c = (idx & 31) * 2;
             sB[st][k][c] = rb[e][0];
@@ -966,9 +969,13 @@ int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, floa
     const bool pca_force = pca_env && !strcmp(pca_env, "mfma");
     const bool use_mfma = !pca_valu && (m->D_in >= 128 || pca_force);
     dim3 gm((unsigned)ceil_div(n, 64), (unsigned)ceil_div(m->D, 64));
+    // K 16 per stage = four workgroups per CU: pays once the grid is more than one round of the 32-per-stage form (measured on
+    // the 4096 -> 256 product: 12500 rows 7.5 -> 8.3 M vectors/s of encode, 8192 rows 0.61 -> 0.64 ms)
+    const bool bk16 = getenv("CIS_PCA_BK") ? atoi(getenv("CIS_PCA_BK")) == 16 : (int64_t)gm.x * gm.y > 640;
 #define CIS_PCA_LAUNCH(TX, SUB, XP)                                                                                              \
     do {                                                                                                                          \
-        if (use_mfma) hipLaunchKernelGGL((k_pca_gemm_mfma<TX, SUB>), gm, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
+        if (use_mfma && bk16) hipLaunchKernelGGL((k_pca_gemm_mfma<TX, SUB, 16>), gm, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
+        else if (use_mfma) hipLaunchKernelGGL((k_pca_gemm_mfma<TX, SUB, 32>), gm, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
         else if (small) hipLaunchKernelGGL((k_pca_gemm<TX, SUB, 2>), g, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
         else hipLaunchKernelGGL((k_pca_gemm<TX, SUB, 4>), g, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);       \
     } while (0)
