@@ -605,6 +605,191 @@ __global__ __launch_bounds__(256) void k_coarse_mfma(const T* __restrict__ X, in
     }
 }
 
+// The same for the float32 compute type (float32 vectors and centroids: what the reference's k-means returns for float32
+// training data) on the float32 matrix cores, v_mfma_f32_32x32x2_f32: twice the float64 rate, half the LDS bytes.  numpy's
+// value is itself a float32 sum here, so the slack is of the order of 2^-17 (|x|^2 + |c|^2) whatever produces dt; a wave
+// owns 32 vectors (A operand: lane l holds x[row = l & 31][k = 2 s + (l >> 5)]), a stage is 64 centroids x 64 dims stored
+// [centroid][k parity][k / 2] with a row stride of 65 words (conflict-free operand reads), the result register r of lane l is
+// row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int KS /* h padded to 2*KS, a multiple of 32 */>
+__global__ __launch_bounds__(256) void k_coarse_mfma32(const float* __restrict__ X, int64_t ldx, int h, const float* __restrict__ Call,
+                                                       const double* __restrict__ cnorm, int64_t n, int V,
+                                                       uint16_t* __restrict__ out, PwProg prog, double eps_rel,
+                                                       int* __restrict__ fallback) {
+    constexpr int KC = 64;             // dims per LDS stage
+    constexpr int NKC = (2 * KS) / KC;
+    constexpr int CAP = 1024;
+    __shared__ float sB[2][64][65];
+    __shared__ float sCn[2][64];
+    __shared__ uint32_t sList[4][CAP];
+    __shared__ float sXn[4][32];
+    __shared__ unsigned long long sBest[4][32];
+    __shared__ uint32_t sBestC[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.y;
+    const int xoff = split * h;
+    const float* C = Call + (size_t)split * V * h;
+    const double* cn = cnorm + (size_t)split * V;
+    const double cn_max = cnorm[2 * V + split];
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    float a[KS];
+    {
+        const int64_t r = row0 + (lane & 31);
+        const float* x = X + r * ldx + xoff;
+        double sq = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = 2 * s + (lane >> 5);
+            a[s] = (r < n && k < h) ? x[k] : 0.f;
+            sq = fma((double)a[s], (double)a[s], sq);
+        }
+        sq += __shfl_xor(sq, 32);
+        if (lane < 32) {
+            sXn[wave][lane] = (float)(2.0 * eps_rel * (sq + cn_max) * 1.0000002);  // the row's 2 x slack, rounded up
+            sBest[wave][lane] = ~0ull;
+            sBestC[wave][lane] = 0xffffffffu;
+        }
+    }
+    __syncthreads();
+    float slack2[16], lmin[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        slack2[r] = sXn[wave][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+        lmin[r] = __builtin_inff();
+    }
+    // stage fetch: 64 centroids x 16 quads of consecutive k = 1024 quads, four per thread
+    float rb[4][4];
+    float rcn = 0.f;
+    auto fetch = [&](int t, int kc) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            const int c = t * 64 + (idx >> 4), k = kc * KC + (idx & 15) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rb[e][q] = (c < V && k + q < h) ? C[(size_t)c * h + k + q] : 0.f;
+        }
+        if (kc == 0 && tid < 64) rcn = (t * 64 + tid < V) ? (float)cn[t * 64 + tid] : __builtin_inff();
+    };
+    auto stash = [&](int st, int kc) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            float* d = &sB[st][idx >> 4][0];
+            const int s0 = (idx & 15) * 2;  // k = 4 (idx & 15) + q  ->  parity q & 1, index s0 + (q >> 1)
+            d[s0] = rb[e][0]; d[32 + s0] = rb[e][1]; d[s0 + 1] = rb[e][2]; d[32 + s0 + 1] = rb[e][3];
+        }
+        if (kc == 0 && tid < 64) sCn[st][tid] = rcn;
+    };
+    const int ntiles = (V + 63) / 64;
+    const int nstages = ntiles * NKC;
+    int wcnt = 0;
+    bool over = false;
+    f32x16 acc[2];
+    fetch(0, 0);
+    stash(0, 0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc) {
+        const int sidx = t * NKC + kc, st = sidx & 1;
+        const bool more = sidx + 1 < nstages;
+        if (more) fetch((sidx + 1) / NKC, (sidx + 1) % NKC);
+        if (kc == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            const float av = a[kc * (KC / 2) + s];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float bv = sB[st][j * 32 + (lane & 31)][(lane >> 5) * 32 + s];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+            }
+        }
+        if (kc == NKC - 1) {
+            const int cst = (sidx - kc) & 1;
+            float dt[2][16];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float cnv = sCn[cst][j * 32 + (lane & 31)];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    dt[j][r] = fmaf(-2.f, acc[j][r], cnv);
+                    lmin[r] = fminf(lmin[r], dt[j][r]);
+                }
+            }
+            unsigned mask = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float mrow = lmin[r];
+                mrow = fminf(mrow, __shfl_xor(mrow, 1));
+                mrow = fminf(mrow, __shfl_xor(mrow, 2));
+                mrow = fminf(mrow, __shfl_xor(mrow, 4));
+                mrow = fminf(mrow, __shfl_xor(mrow, 8));
+                mrow = fminf(mrow, __shfl_xor(mrow, 16));
+                lmin[r] = mrow;
+                const float thr = mrow + slack2[r];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (dt[j][r] <= thr) mask |= 1u << (j * 16 + r);
+            }
+            if (__ballot(mask != 0) != 0ull && !over) {
+#pragma unroll
+                for (int b = 0; b < 32; ++b) {
+                    const bool p = (mask >> b) & 1u;
+                    const unsigned long long bal = __ballot(p);
+                    if (bal == 0ull) continue;
+                    const int cnt = __popcll(bal);
+                    if (wcnt + cnt > CAP) { over = true; break; }
+                    if (p) {
+                        const int pos = wcnt + __popcll(bal & ((1ull << lane) - 1ull));
+                        const int r = b & 15;
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), c = t * 64 + (b >> 4) * 32 + (lane & 31);
+                        sList[wave][pos] = ((uint32_t)row << 16) | (uint32_t)c;
+                    }
+                    wcnt += cnt;
+                }
+            }
+        }
+        if (more) stash(st ^ 1, (sidx + 1) % NKC);
+        __syncthreads();
+      }
+    }
+    if (over) {
+        if (lane == 0) atomicOr(fallback, 1);  // the exact kernels redo the pass
+        wcnt = 0;
+    }
+    auto exact = [&](uint32_t e) -> double {
+        const int64_t r = row0 + (e >> 16);
+        const float* x = X + r * ldx + xoff;
+        const float* cc = C + (size_t)(e & 0xffffu) * h;
+        auto elem = [&](int i) -> float { const float df = x[i] - cc[i]; return df * df; };
+        return (double)pw_sum<float>(prog, elem);
+    };
+    for (int i = lane; i < wcnt; i += 64) {
+        const uint32_t e = sList[wave][i];
+        if (row0 + (e >> 16) >= n) continue;
+        const double v = exact(e);
+        if (v == v) atomicMin(&sBest[wave][e >> 16], (unsigned long long)__double_as_longlong(v));
+    }
+    __syncthreads();
+    for (int i = lane; i < wcnt; i += 64) {
+        const uint32_t e = sList[wave][i];
+        if (row0 + (e >> 16) >= n) continue;
+        const double v = exact(e);
+        if ((unsigned long long)__double_as_longlong(v) == sBest[wave][e >> 16]) atomicMin(&sBestC[wave][e >> 16], e & 0xffffu);
+    }
+    __syncthreads();
+    if (lane < 32 && row0 + lane < n && !over) {
+        const uint32_t c = sBestC[wave][lane];
+        out[(row0 + lane) * 2 + split] = (uint16_t)(c == 0xffffffffu ? 0u : c);
+    }
+}
+
 // Fine codes in one pass (predict_fine, lopq/lopq/model.py:575-602 -> predict_cluster, lopq/lopq/utils.py:33-53): a thread
 // owns one (vector, sub-quantizer), keeps its w projected values in registers, walks the K sub-centroids staged in LDS
 // (every lane reads the same address: broadcast) and keeps the first minimum.  Every distance is summed exactly as numpy
@@ -1114,7 +1299,7 @@ static int dev_predict_coarse(cis_model* m, const void* xc, int ct, int64_t n, u
     // many clusters: matrix-core prefilter + exact re-check of the few listed pairs; the exact kernels below then only run
     // (device-side predicate) when a candidate list overflowed
     const int coarse_mode = getenv("CIS_COARSE") ? atoi(getenv("CIS_COARSE")) : -1;  // 0 exact kernels, 1 prefilter
-    const bool pre = (coarse_mode == 1 || (coarse_mode != 0 && m->V >= 256)) && m->h <= 128 && m->V <= 65535;
+    const bool pre = (coarse_mode >= 1 || (coarse_mode != 0 && m->V >= 256)) && m->h <= 128 && m->V <= 65535;  // 2: float64 cores for float32 too
     const int* only_if = nullptr;
     if (pre) {
         CIS_CHECK_HIP(hipMemsetAsync(m->d_flag, 0, sizeof(int), st));
@@ -1126,7 +1311,17 @@ static int dev_predict_coarse(cis_model* m, const void* xc, int ct, int64_t n, u
 #define CIS_COARSE_LAUNCH(T, KS, C)                                                                                          \
     hipLaunchKernelGGL((k_coarse_mfma<T, KS>), gp, dim3(256), 0, st, (const T*)xc, (int64_t)m->D, m->h, C, m->d_cnorm, n, m->V, \
                        d_coarse, m->prog_h, eps_rel, m->d_flag)
-        if (ct == CIS_F32) {
+        if (ct == CIS_F32 && coarse_mode != 2) {
+            // float32 matrix cores; the slack adds the float32 product's own error, (h + 4) 2^-24 (|x|^2 + |c|^2)
+            const double eps32 = 4.0 * (2.0 * (m->h + 6) + (m->h + 4)) * ldexp(1.0, -24);
+            const dim3 gp32((unsigned)ceil_div(n, 128), 2);
+            if (m->h <= 64)
+                hipLaunchKernelGGL((k_coarse_mfma32<32>), gp32, dim3(256), 0, st, (const float*)xc, (int64_t)m->D, m->h, m->d_Cs32, m->d_cnorm, n,
+                                   m->V, d_coarse, m->prog_h, eps32, m->d_flag);
+            else
+                hipLaunchKernelGGL((k_coarse_mfma32<64>), gp32, dim3(256), 0, st, (const float*)xc, (int64_t)m->D, m->h, m->d_Cs32, m->d_cnorm, n,
+                                   m->V, d_coarse, m->prog_h, eps32, m->d_flag);
+        } else if (ct == CIS_F32) {
             if (m->h <= 32) CIS_COARSE_LAUNCH(float, 8, m->d_Cs32);
             else if (m->h <= 64) CIS_COARSE_LAUNCH(float, 16, m->d_Cs32);
             else CIS_COARSE_LAUNCH(float, 32, m->d_Cs32);
