@@ -2036,7 +2036,7 @@ __device__ __forceinline__ void scan2_group(const WorkItem* __restrict__ items_a
 // that XCD's private L2.  A workgroup whose own queue is empty steals from the others, which removes
 // the tail caused by unequal cell sizes.
 template <int M, int NR, int U, int G, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(G == 4 ? 2 : ((M == 16 && G == 2) ? 3 : 4), 4))) void k_adc_scan2(const WorkItem* __restrict__ items, const int* __restrict__ slots,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NR == 16 ? 2 : (G == 4 ? 2 : ((M == 16 && G == 2) ? 3 : 4)), 4))) void k_adc_scan2(const WorkItem* __restrict__ items, const int* __restrict__ slots,
                                                        const int* __restrict__ n_slots_ptr, const double* __restrict__ T,
                                                        const float* __restrict__ T32,
                                                        const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids,
@@ -2964,9 +2964,11 @@ static void launch_scan_exact(int M, int64_t n_items, hipStream_t st, const Work
     else launch_scan_m<4096, 4>(M, n_items, st, items, T, codes, ids, K, L, S, flag, hits, hitn);
 }
 
-// float32-prefilter kernel (v2): M in {4, 8, 16}, K <= 256, L <= 440 (a wave region holds L + 64 entries)
+// float32-prefilter kernel (v2): M in {4, 8, 16}, K <= 256, L <= 952 (a wave region of NR * 64 - 8 entries holds L + 64; 16 registers
+// per lane above 440, one query per workgroup there: 43-51 KB of LDS, three workgroups per CU)
+static const int SCAN2_MAX_LIMIT = 952;
 static bool scan2_supported(int M, int K, int L) {
-    return (M == 4 || M == 8 || M == 16) && K <= 256 && K % 4 == 0 && L >= 1 && L <= 440;
+    return (M == 4 || M == 8 || M == 16) && K <= 256 && K % 4 == 0 && L >= 1 && L <= SCAN2_MAX_LIMIT;
 }
 
 struct Scan2Geom { int G, NW, U, S; size_t lds; };
@@ -2975,13 +2977,13 @@ struct Scan2Geom { int G, NW, U, S; size_t lds; };
 // large enough to find pairs; G = 1 with 4 waves for small batches (latency mode).
 static Scan2Geom scan2_geom(int M, int K, int L, int nq) {
     Scan2Geom g;
-    const int NR = (L <= 184) ? 4 : 8;
-    g.G = (nq >= 64) ? 2 : 1;  // pairs of queries per workgroup when the batch is large enough to find pairs
+    const int NR = (L <= 184) ? 4 : (L <= 440 ? 8 : 16);
+    g.G = (nq >= 64 && NR < 16) ? 2 : 1;  // pairs of queries per workgroup when the batch is large enough to find pairs
     g.NW = 4;
     g.U = (g.G == 2) ? 4 : 2;
     if (const char* e = getenv("CIS_SCAN_GEOM")) {  // experiments: "G,NW,U" out of the instantiated set
         int a = 0, b = 0, c = 0;
-        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && ((a == 1 && b == 4) || (a == 2 && b == 4) || (a == 2 && b == 8 && c == 2) || (a == 2 && (b == 1 || b == 2) && c == 4) || (a == 4 && b == 4 && c == 4 && NR == 4)) && (c == 2 || c == 4)) {
+        if (NR < 16 && sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && ((a == 1 && b == 4) || (a == 2 && b == 4) || (a == 2 && b == 8 && c == 2) || (a == 2 && (b == 1 || b == 2) && c == 4) || (a == 4 && b == 4 && c == 4 && NR == 4)) && (c == 2 || c == 4)) {
             g.G = a; g.NW = b; g.U = c;
         }
     }
@@ -3013,13 +3015,15 @@ static void launch_scan2_mr(const Scan2Geom& g, int64_t n_items, hipStream_t st,
         launch_scan2_t<M, NR, GG, WW, UU>(n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, g.S, g.lds, qctr, hits, hitn, qbound); \
         return;                                                                                                       \
     }
-    CIS_SCAN2_CASE(1, 4, 4)
     CIS_SCAN2_CASE(1, 4, 2)
-    CIS_SCAN2_CASE(2, 4, 4)
-    CIS_SCAN2_CASE(2, 4, 2)
-    CIS_SCAN2_CASE(2, 8, 2)
-    CIS_SCAN2_CASE(2, 1, 4)
-    CIS_SCAN2_CASE(2, 2, 4)
+    if constexpr (NR != 16) {  // limit 441 ... 952 (NR = 16): one query per workgroup only
+        CIS_SCAN2_CASE(1, 4, 4)
+        CIS_SCAN2_CASE(2, 4, 4)
+        CIS_SCAN2_CASE(2, 4, 2)
+        CIS_SCAN2_CASE(2, 8, 2)
+        CIS_SCAN2_CASE(2, 1, 4)
+        CIS_SCAN2_CASE(2, 2, 4)
+    }
     if constexpr (NR == 4) { CIS_SCAN2_CASE(4, 4, 4) }  // four queries per workgroup: measured slower (72 KB of LDS -> 2 workgroups per CU)
 #undef CIS_SCAN2_CASE
 }
@@ -3029,7 +3033,8 @@ static void launch_scan2_m(const Scan2Geom& g, int64_t n_items, hipStream_t st, 
                            const int* n_slots, const double* T, const float* T32, const uint8_t* codes, const int64_t* ids, int K, int L,
                            int* qctr, uint64_t* hits, int* hitn, unsigned long long* qbound) {
     if (L <= 184) launch_scan2_mr<M, 4>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
-    else launch_scan2_mr<M, 8>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
+    else if (L <= 440) launch_scan2_mr<M, 8>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
+    else launch_scan2_mr<M, 16>(g, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, hits, hitn, qbound);
 }
 
 static void launch_scan2(int M, const Scan2Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const int* slots,
@@ -3756,7 +3761,7 @@ static bool index_has_tiny_cells(const cis_index* ix) {
 static bool use_all_path(const cis_index* ix, int M, int K, int L, int nq) {
     if (L > MAX_LDS_LIMIT) return true;
     if (ix->force_exact_scan) return false;
-    if (L > 440) return true;
+    if (L > SCAN2_MAX_LIMIT) return true;
     // a scan workgroup per (query, cell) slot stages 16 KB of tables and a survivor list per work item: hopeless for cells of
     // a few codes -- every candidate's exact distance + a per-query select instead (unless a test forces a scan kernel)
     if (index_has_tiny_cells(ix) && !ix->force_prefilter_scan) return true;
@@ -4211,7 +4216,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     } while (0)
             if (L <= 128) CIS_MERGE_SURV_M(256);
             else if (L <= 256) CIS_MERGE_SURV_M(512);
-            else CIS_MERGE_SURV_M(1024);
+            else if (L <= 440) CIS_MERGE_SURV_M(1024);
+            else CIS_MERGE_SURV_M(2048);
 #undef CIS_MERGE_SURV_M
 #undef CIS_MERGE_SURV
         } else if (L <= 512)

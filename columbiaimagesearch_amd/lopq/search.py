@@ -366,7 +366,7 @@ class LOPQSearcherHIP(LOPQSearcherBase):
     default_scan_mode = 0           # tests: 3 = new searchers run the 16-bit fixed-point kernel for every batch size
 
     def set_scan_mode(self, exact_only=False, prefilter_only=None, mode=None):
-        """Routing of limit <= 440 (tests; results are identical on every route): exact_only forces the float64 scan
+        """Routing of limit <= 952 (tests; results are identical on every route): exact_only forces the float64 scan
         kernel, prefilter_only the float32-prefilter kernel for every batch size (small batches otherwise take the
         all-candidates path: shorter kernel chain at low occupancy; large ones the 16-bit fixed-point kernel);
         mode = the raw cis_index_set_scan_mode value (3: the 16-bit fixed-point kernel for every batch size)."""

@@ -226,9 +226,9 @@ int cis_index_last_scan_kernel(cis_index* ix);
  *   ms[4] the ADC scan kernel alone (events right before and after its launch)
  *   *launches = number of scan kernel launches accumulated. */
 int cis_index_set_profiling(cis_index* ix, int level /* 0 off, 1 only the pair of events around the scan kernel (ms[4]), 2 every stage */);
-/* Ranking route selection: 0 = automatic (limit <= 440: a prefilter scan kernel with exact float64 re-scoring of its
+/* Ranking route selection: 0 = automatic (limit <= 952: a prefilter scan kernel with exact float64 re-scoring of its
  * survivors -- the 16-bit fixed-point kernel k_adc_scan3 for batches of >= 256 queries over short cells (< 8192 codes on
- * average, M <= 8), the float32 kernel k_adc_scan2 otherwise; small batches, limit > 440 and indexes of tiny cells
+ * average, M <= 8, limit <= 440), the float32 kernel k_adc_scan2 otherwise; small batches, limit > 952 and indexes of tiny cells
  * (thousands of coarse clusters) take the all-candidates path instead: exact distances of every candidate, radix select;
  * exact float64 scan kernel otherwise), 1 = exact float64 scan kernel wherever it applies (limit <= 3072),
  * 2 = the float32-prefilter kernel for every batch size, 3 / 4 = the 16-bit fixed-point kernel for every batch size in its

@@ -334,6 +334,37 @@ def test_fast_and_exact_scan_kernels_agree(name):
         np.testing.assert_array_equal(a["dists"].view(np.uint64), b["dists"].view(np.uint64))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c2", "c3", "c4"])
+def test_prefilter_scan_with_16_register_regions_matches_exact_kernel_and_oracle(name):
+    """limit 441 ... 952: the float32-prefilter kernel with 16 region registers per lane (one query per workgroup) and the
+    2048-key survivor merge, against the float64 scan kernel (bit-identical) and the oracle; 953 is back on the all-candidates
+    path.  M = 8 and 16."""
+    from oracle import lopq_oracle as O
+    z, X, Q = load_golden(name)
+    m = hip_model(z)
+    s = _build_searcher(name, z, X, m)
+    om = O.OracleModel.from_npz(z)
+    oi = O.OracleCSRIndex(om, z["coarse"], z["fine"])
+    for quota, limit in [(5000, 441), (100000, 700), (100000, 952), (100000, 953)]:
+        s.set_scan_mode(prefilter_only=True)
+        a = s.search_batch(Q, quota=quota, limit=limit)
+        kern = s.last_stats()["scan_kernel"]
+        assert kern == ("k_adc_scan2" if limit <= 952 else None), (limit, kern)
+        s.set_scan_mode(exact_only=True)
+        b = s.search_batch(Q, quota=quota, limit=limit)
+        s.set_scan_mode(exact_only=False)
+        for k in ("ids", "n_found", "visited"):
+            np.testing.assert_array_equal(a[k], b[k])
+        np.testing.assert_array_equal(a["dists"].view(np.uint64), b["dists"].view(np.uint64))
+        for qi in range(0, len(Q), max(1, len(Q) // 6)):
+            ids, dists, visited = oi.search(Q[qi], quota=quota, limit=limit)
+            n = len(ids)
+            assert a["n_found"][qi] == n and a["visited"][qi] == visited
+            np.testing.assert_array_equal(a["ids"][qi, :n], ids)
+            np.testing.assert_allclose(a["dists"][qi, :n], dists, rtol=1e-9, atol=1e-12)
+
+
 def test_many_exact_ties_fall_back_to_exact_kernel():
     """Thousands of identical codes in one cell tie exactly in float32 and float64: the fast kernel
     must hand those work items to the exact kernel, and ties come back in insertion order."""

@@ -22,7 +22,7 @@ q = B.make_queries(x0, 0, nq, dev)
 host = os.environ.get("HOST") == "1"  # host-pointer entry point (cis_index_search): PCIe copies in and out included
 qh = q.cpu().numpy()
 run = (lambda limit: s.search_batch(qh, quota=10000, limit=limit)) if host else (lambda limit: s.search_batch_dev(q, quota=10000, limit=limit))
-for limit in [int(v) for v in os.environ.get("LIMITS", "10,100,440,441,1000,3072,3073,10000").split(",")]:
+for limit in [int(v) for v in os.environ.get("LIMITS", "10,100,440,441,952,953,3072,3073,10000").split(",")]:
     for _ in range(2):
         run(limit)
     torch.cuda.synchronize(); t = time.perf_counter()
