@@ -14,9 +14,10 @@ def run(cases, seed0):
   bad = 0
   for case in range(cases):
       rs = np.random.RandomState(seed0 * 1000 + case)
+      t_case = time.time()
       M = int(rs.choice(MS))
       K = int(rs.choice(KS))
-      V = int(rs.choice([2, 4, 16, 40]))
+      V = int(rs.choice([2, 4, 16, 40, 40, 300, 1024]))  # >= 256: matrix-core coarse prefilter, tiny cells (k_plan_par, k_adc_direct)
       w = int(rs.choice([2, 4, 8]))
       D = M * w
       h, nf = D // 2, M // 2
@@ -38,10 +39,12 @@ def run(cases, seed0):
           D_in = D
           m = LOPQModel(parameters=(tuple(Cs), tuple(Rs), tuple(mus), tuple(subs)))
           om = O.OracleModel(Cs, Rs, mus, subs)
-      n = int(rs.choice([300, 5000, 60000]))
+      n = int(rs.choice([300, 5000, 60000])) if V < 300 else (int(rs.choice([5000, 60000])) if V < 1024 else 60000)
       base = rs.randn(max(n // int(rs.choice([1, 3, 50])), 1), D_in)  # few distinct points -> many duplicate codes
       X = (base[rs.randint(0, len(base), n)] + rs.choice([0.0, 1e-3, 0.3]) * rs.randn(n, D_in)).astype(dt)
-      nq = int(rs.choice([24, 96, 300]))  # >= 64: two queries per workgroup in the scan
+      nq = int(rs.choice([24, 96, 300, 600]))  # >= 64: two queries per workgroup in the scan; 600: past every small-batch threshold
+      if V >= 300:
+          nq = min(nq, 96)  # the oracle's heap walks thousands of cells per query there
       Q = (X[rs.randint(0, n, nq)] + 0.05 * rs.randn(nq, D_in)).astype(dt)
       coarse, fine = m.predict_batch(X)
       oc, of = O.compute_codes(om, X[:3000])  # encode parity: bit-exact codes (numpy summation order, first minimum)
@@ -53,7 +56,9 @@ def run(cases, seed0):
       s.add_codes_array(coarse, fine, dedup=False)
       oi = O.OracleCSRIndex(om, coarse, fine)
       quota = int(rs.choice([1, 10, 100, 1000, 10000]))
-      limit = rs.choice([None, 1, 7, 100, 184, 185, 300, 440, 441, 1000, 4000])
+      if V >= 300:
+          quota = max(1, min(quota, 1000, n // 8))  # a quota the index cannot fill walks all V * V cells in the oracle's Python heap
+      limit = rs.choice([None, 1, 7, 100, 184, 185, 300, 440, 441, 600, 952, 953, 1000, 4000])
       limit = None if limit is None else int(limit)
       if limit is None and quota > 20000:
           limit = 100
@@ -69,7 +74,7 @@ def run(cases, seed0):
               print("MISMATCH case %d query %d: M=%d K=%d V=%d w=%d n=%d quota=%d limit=%s dtype=%s found %d/%d" % (
                   case, qi, M, K, V, w, n, quota, limit, np.dtype(dt).name, r["n_found"][qi], k))
               break
-      if ok and limit is not None and limit <= 512 and rs.rand() < 0.3:
+      if ok and limit is not None and limit <= 3072 and rs.rand() < 0.3:
           # the same index cut into three cell shards: packed partial lists merged == the single index
           import torch
           from columbiaimagesearch_amd.lopq.search import merge_packed_dev
@@ -98,6 +103,8 @@ def run(cases, seed0):
               print("SHARDED MISMATCH case %d: M=%d K=%d V=%d n=%d quota=%d limit=%s" % (case, M, K, V, n, quota, limit))
       bad += 0 if ok else 1
       s.close()
+      if os.environ.get("FUZZ_VERBOSE"):
+          print("case %d ok=%s M=%d K=%d V=%d w=%d n=%d nq=%d quota=%d limit=%s %.1fs" % (case, ok, M, K, V, w, n, nq, quota, limit, time.time() - t_case), flush=True)
   return bad
 
 
