@@ -734,7 +734,11 @@ def test_randomised_parity_fuzz():
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "tools", "fuzz_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    mod.VS = [2, 4, 16, 40]
     assert mod.run(60, 11) == 0
+    mod.VS = [300]  # uint16 coarse ids: matrix-core coarse prefilter, tiny cells (parallel plan, direct ADC); the tool's CLI adds 1024
+    assert mod.run(6, 13) == 0
+    mod.VS = [2, 4, 16, 40]
     # shapes outside the specialised kernels (M not in {4, 8, 16}, K not a multiple of 4 / not a power of two): the float64
     # scan kernel and the global-table distance kernel of the all-candidates path
     mod.MS, mod.KS = [2, 6, 12, 32], [10, 100, 256]

@@ -9,6 +9,8 @@ from columbiaimagesearch_amd.lopq import LOPQModel, LOPQModelPCA, LOPQSearcherHI
 # FUZZ_M / FUZZ_K: other shapes, e.g. FUZZ_M=2,6,12,32 FUZZ_K=10,100,256 (the generic kernels: float64 scan, global-table distances)
 MS = [int(v) for v in os.environ.get("FUZZ_M", "4,8,16").split(",")]
 KS = [int(v) for v in os.environ.get("FUZZ_K", "16,64,256").split(",")]
+# >= 256: matrix-core coarse prefilter, tiny cells (k_plan_par, k_adc_direct); slow in the oracle (Python heap over V * V cells)
+VS = [int(v) for v in os.environ.get("FUZZ_V", "2,4,16,40,40,300,1024").split(",")]
 
 def run(cases, seed0):
   bad = 0
@@ -17,7 +19,7 @@ def run(cases, seed0):
       t_case = time.time()
       M = int(rs.choice(MS))
       K = int(rs.choice(KS))
-      V = int(rs.choice([2, 4, 16, 40, 40, 300, 1024]))  # >= 256: matrix-core coarse prefilter, tiny cells (k_plan_par, k_adc_direct)
+      V = int(rs.choice(VS))
       w = int(rs.choice([2, 4, 8]))
       D = M * w
       h, nf = D // 2, M // 2
