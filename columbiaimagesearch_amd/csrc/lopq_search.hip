@@ -2216,7 +2216,11 @@ static __device__ __forceinline__ void wave_bitonic_lds(uint64_t* ka, uint64_t* 
 }
 
 template <int CAPM, int MT /* 4, 8, 16, or 0 = any M */, int NEMAX /* 4 or 8: survivors per lane the fast path may hold */>
-__global__ __launch_bounds__(256) void k_merge_survivors(const uint64_t* __restrict__ surv /* [n_items][S] */,
+#ifndef CIS_MERGE_WPE
+#define CIS_MERGE_WPE 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MT == 16 || MT == 0) ? 2 : CIS_MERGE_WPE, 8)))
+void k_merge_survivors(const uint64_t* __restrict__ surv /* [n_items][S] */,
                                                          const int* __restrict__ item_n, const int64_t* __restrict__ item_off,
                                                          const WorkItem* __restrict__ items, const double* __restrict__ T,
                                                          const uint8_t* __restrict__ codes, const int64_t* __restrict__ ids,
