@@ -19,6 +19,9 @@
  *  - the library never keeps caller pointers after a call returns; handles own device memory;
  *  - HIP is initialised lazily on first use, so a process may fork before touching the library
  *    (gunicorn / multiprocessing callers); handles must not be shared across processes;
+ *  - a handle (model, index, CNN) owns ONE set of device workspaces: calls on the same handle must not overlap -- neither from
+ *    two threads nor on two streams (a `*_dev` call returns while its kernels are still queued: issue the next call on the
+ *    same stream, or wait for the first).  An index also uses its model's workspaces.  Different handles are independent;
  *  - dtype arguments: CIS_F32 = 4, CIS_F64 = 8 (bytes per element).
  */
 #ifndef CIS_HIP_H
