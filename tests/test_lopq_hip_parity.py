@@ -619,9 +619,10 @@ def _random_model(V, M, K, D, seed, dtype=np.float32):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("V,M,K,D", [(300, 8, 64, 32), (1024, 4, 256, 16), (4096, 4, 16, 16)])
+@pytest.mark.parametrize("V,M,K,D", [(300, 8, 64, 32), (1024, 4, 256, 16), (4096, 4, 16, 16), (300, 8, 256, 128), (300, 4, 256, 128), (300, 16, 64, 128)])
 def test_wide_coarse_vocabulary_matches_oracle(V, M, K, D):
-    """V > 256 (uint16 coarse codes, V*V up to a million cells, mostly empty): encode and search parity."""
+    """V > 256 (uint16 coarse codes, V*V up to a million cells, mostly empty): encode and search parity.  The 128-d shapes put
+    w = 16 / 32 / 8 (sub-quantizer phases of 4 / 2 / 8 in k_adc_direct) and h = 64 (one full stage of the coarse prefilter) under test."""
     from oracle import lopq_oracle as O
     from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
     m, om = _random_model(V, M, K, D, seed=V)
