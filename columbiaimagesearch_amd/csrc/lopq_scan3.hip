@@ -632,17 +632,27 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
                 have_bound = true;
             }
             if (lane == 0) {
+                // L candidates have a sum <= thr, i.e. an exact distance below (thr + M)(1 + eps) / qinv -- and a candidate with an
+                // exact distance below THAT can carry any sum up to thr + M + 1 (a sum brackets its distance only to within M
+                // units: s <= d qinv (1 + 2^-23), d qinv < (s + M)(1 + 2^-22)).  So the collection threshold is thr + M + 1, not
+                // thr: with the edge itself the last ranks of a query could go to a candidate a few units further out (found by
+                // the parity fuzz: one query in ~20 k, rank `limit` only).  M + 1 < one bin: the count under the collection
+                // threshold is at most the next bin's population more.
+                uint32_t keep = thr, n_keep = (uint32_t)n_le;
+                if (have_bound && thr < 65534u) {
+                    keep = thr + (uint32_t)M + 1u;
+                    keep = keep < 65534u ? keep : 65534u;
+                    const uint32_t nb = (thr + 1u) >> BSH;  // the bin right after the edge
+                    if (nb < (uint32_t)NB) n_keep += hist[g * NB + nb];
+                }
                 const uint32_t t_ext = lds_ld(&sh[g].thr);  // from the query's other cells (or 0 for an absent query)
-                const uint32_t t = thr < t_ext ? thr : t_ext;
+                const uint32_t t = keep < t_ext ? keep : t_ext;
                 sh[g].thr = t;
                 thr1[g] = (uint16_t)((g < ng) ? t + 1u : 0u);
                 sh[g].wcnt[0] = 0;
-                if (g < ng && thr <= t_ext && n_le > R) *s_flag = 1;  // more survivors than ONE wave's region holds: streaming form
-                if (have_bound && thr < t_ext) {
-                    // at least L candidates of this chunk have a sum <= thr: an exact-distance bound for the whole query
-                    const uint64_t b = val_to_bound(thr, M, sh[g].ub);
-                    sh[g].wt[0] = b;
-                }
+                if (g < ng && n_keep > (uint32_t)R) *s_flag = 1;  // possibly more survivors than ONE wave's region holds: streaming form
+                // at least L candidates of this chunk have a sum <= thr: an exact-distance bound for the whole query
+                sh[g].wt[0] = have_bound ? val_to_bound(thr, M, sh[g].ub) : 0x7ff0000000000000ull;
             }
         }
         __syncthreads();

@@ -737,6 +737,14 @@ def test_randomised_parity_fuzz():
     spec.loader.exec_module(mod)
     mod.VS = [2, 4, 16, 40]
     assert mod.run(60, 11) == 0
+    # regression: the two-pass fixed-point scan must collect up to M + 1 units past its histogram edge (a sum brackets the exact
+    # distance only to within M units); these two cases lost the candidate of rank `limit` before the fix
+    os.environ["FUZZ_ONLY"], os.environ["FUZZ_MODE"] = "2,58", "4"
+    try:
+        mod.VS = [2, 4, 16, 40, 40, 300, 1024]  # the stream that found it
+        assert mod.run(60, 24) == 0
+    finally:
+        del os.environ["FUZZ_ONLY"], os.environ["FUZZ_MODE"]
     mod.VS = [300]  # uint16 coarse ids: matrix-core coarse prefilter, tiny cells (parallel plan, direct ADC); the tool's CLI adds 1024
     assert mod.run(6, 13) == 0
     mod.VS = [2, 4, 16, 40]

@@ -14,7 +14,10 @@ VS = [int(v) for v in os.environ.get("FUZZ_V", "2,4,16,40,40,300,1024").split(",
 
 def run(cases, seed0):
   bad = 0
+  only = [int(v) for v in os.environ["FUZZ_ONLY"].split(",")] if os.environ.get("FUZZ_ONLY") else None
   for case in range(cases):
+      if only is not None and case not in only:
+          continue
       rs = np.random.RandomState(seed0 * 1000 + case)
       t_case = time.time()
       M = int(rs.choice(MS))
@@ -64,7 +67,26 @@ def run(cases, seed0):
       limit = None if limit is None else int(limit)
       if limit is None and quota > 20000:
           limit = 100
-      s.set_scan_mode(mode=int(rs.choice([0, 2, 3, 4, 4])))  # automatic routing, float32-prefilter kernel, 16-bit fixed-point kernel
+      mode = int(rs.choice([0, 2, 3, 4, 4]))  # automatic routing, float32-prefilter kernel, 16-bit fixed-point kernel (streaming / two-pass)
+      if os.environ.get("FUZZ_ALL_MODES"):  # diagnosis: every route on this case
+          for md in (0, 1, 2, 3, 4):
+              s.set_scan_mode(mode=md)
+              rr = s.search_batch(Q, quota=quota, limit=limit)
+              nbad = 0
+              for qi in range(nq):
+                  ids, dists, visited = oi.search(Q[qi], quota=quota, limit=limit)
+                  k = len(ids)
+                  if not (rr["n_found"][qi] == k and np.array_equal(rr["ids"][qi, :k], ids)):
+                      if nbad == 0:
+                          d = np.nonzero(rr["ids"][qi, :k] != ids)[0]
+                          print("  mode %d query %d: first diff at rank %d of %d (%d differ); got id %d dist %.17g, want id %d dist %.17g; kernel %s" % (
+                              md, qi, d[0] if len(d) else -1, k, len(d), rr["ids"][qi, d[0]] if len(d) else -1, rr["dists"][qi, d[0]] if len(d) else 0,
+                              ids[d[0]] if len(d) else -1, dists[d[0]] if len(d) else 0, s.last_stats()["scan_kernel"]))
+                      nbad += 1
+              print("  mode %d: %d of %d queries differ" % (md, nbad, nq), flush=True)
+      if os.environ.get("FUZZ_MODE"):
+          mode = int(os.environ["FUZZ_MODE"])
+      s.set_scan_mode(mode=mode)
       r = s.search_batch(Q, quota=quota, limit=limit)
       ok = True
       for qi in range(nq):
@@ -73,8 +95,8 @@ def run(cases, seed0):
           if not (r["n_found"][qi] == k and r["visited"][qi] == visited and np.array_equal(r["ids"][qi, :k], ids)
                   and np.allclose(r["dists"][qi, :k], dists, rtol=1e-9, atol=0)):
               ok = False
-              print("MISMATCH case %d query %d: M=%d K=%d V=%d w=%d n=%d quota=%d limit=%s dtype=%s found %d/%d" % (
-                  case, qi, M, K, V, w, n, quota, limit, np.dtype(dt).name, r["n_found"][qi], k))
+              print("MISMATCH case %d query %d: M=%d K=%d V=%d w=%d n=%d nq=%d quota=%d limit=%s dtype=%s mode=%d found %d/%d" % (
+                  case, qi, M, K, V, w, n, nq, quota, limit, np.dtype(dt).name, mode, r["n_found"][qi], k))
               break
       if ok and limit is not None and limit <= 3072 and rs.rand() < 0.3:
           # the same index cut into three cell shards: packed partial lists merged == the single index
