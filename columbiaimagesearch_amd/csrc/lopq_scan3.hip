@@ -645,6 +645,9 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
                     const uint32_t nb = (thr + 1u) >> BSH;  // the bin right after the edge
                     if (nb < (uint32_t)NB) n_keep += hist[g * NB + nb];
                 }
+#ifdef CIS_S3_OLD_EDGE  // test-sensitivity builds only: the collection threshold before the fix
+                keep = thr;
+#endif
                 const uint32_t t_ext = lds_ld(&sh[g].thr);  // from the query's other cells (or 0 for an absent query)
                 const uint32_t t = keep < t_ext ? keep : t_ext;
                 sh[g].thr = t;

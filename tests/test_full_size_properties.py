@@ -92,6 +92,36 @@ def test_search_properties_at_full_size(world):
     assert (big["dists"][:, 0] <= o1["dists"][:512, 0]).all()
 
 
+def test_every_scan_route_agrees_at_full_size(world):
+    """Whole 8192-query batches through every ranking route -- automatic, float32 prefilter, 16-bit fixed-point prefilter in its
+    streaming and its two-pass form, float64 scan -- bit for bit: on the 10M index (39 k-candidate cells) and on an index of its
+    first million vectors (3.9 k-candidate cells: the shape at which automatic routing takes the two-pass form).  A route
+    that drops one candidate in twenty thousand queries shows up here (the two-pass form once did, at rank `limit`)."""
+    import torch
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    B, dev = world["B"], world["dev"]
+    small = LOPQSearcherHIP(world["model"])
+    n1 = 1_000_000
+    small.add_codes_array(world["coarse"][:n1], world["fine"][:n1], ids=np.arange(n1, dtype=np.int64), dedup=False)
+    try:
+        for s, batches in ((world["searcher"], (0, 5)), (small, (1, 2, 3, 6))):
+            for b in batches:
+                q = B.make_queries(world["x0"], b, NQ, dev)
+                for limit in (LIMIT, 37, 185):
+                    s.set_scan_mode(mode=1)
+                    want = _np(s.search_batch_dev(q, quota=QUOTA, limit=limit))
+                    for mode in (0, 2, 3, 4):
+                        s.set_scan_mode(mode=mode)
+                        got = _np(s.search_batch_dev(q, quota=QUOTA, limit=limit))
+                        for k in ("ids", "n_found", "visited"):
+                            np.testing.assert_array_equal(got[k], want[k], err_msg="mode %d batch %d limit %d %s" % (mode, b, limit, k))
+                        np.testing.assert_array_equal(got["dists"].view(np.uint64), want["dists"].view(np.uint64))
+                    s.set_scan_mode(mode=0)
+    finally:
+        world["searcher"].set_scan_mode(mode=0)
+        small.close()
+
+
 def test_database_vectors_find_themselves(world):
     import torch
     s, x0 = world["searcher"], world["x0"]
