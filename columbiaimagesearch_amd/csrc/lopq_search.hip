@@ -3853,7 +3853,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     const int seg_max = use3 ? (nq >= 64 ? 65536 : 4096) : (nq >= 1024 ? (1 << 20) : (nq >= 64 ? 16384 : 4096));
     // thousands of coarse clusters (the release configurations' V = 2048 / 4096): the plan is a per-query selection + sort
     // (k_plan_par) instead of one frontier step per visited cell; queries it cannot resolve fall back to the frontier walk
-    static const bool no_par_plan = getenv("CIS_NO_PAR_PLAN") != nullptr;
+    const bool no_par_plan = getenv("CIS_NO_PAR_PLAN") != nullptr;
     const bool par_plan = V >= 128 && V <= PLAN_PAR_STAGE && !no_par_plan;
     int* plan_fb = nullptr;
     uint32_t* vis_list = nullptr;

@@ -77,3 +77,19 @@ for qi in range(4):
     eid, ed, ev_ = oi.search(qh[qi], quota=10000, limit=100)
     ok = ok and np.array_equal(ids[qi, :len(eid)], eid) and ev_ == vis[qi] and np.allclose(dd[qi, :len(ed)], ed, rtol=1e-9)
 print("parity (4 queries vs oracle, quota 10000): %s" % ok)
+# every query of the batch, bit for bit, across the library's own routes: direct ADC (default) / float64 tables + flat lookups /
+# the float64 scan kernel per work item
+ref = {k: out[k].cpu().numpy() for k in ("ids", "dists", "n_found", "visited")}
+same = {}
+for name, env, mode in (("tables", {"CIS_NO_DIRECT": "1"}, 0), ("serial_plan", {"CIS_NO_PAR_PLAN": "1"}, 0), ("exact_scan", {}, 1)):
+    os.environ.update(env)
+    s.set_scan_mode(mode=mode)
+    nqc = NQ if name != "exact_scan" else min(NQ, 256)
+    o2 = s.search_batch_dev(q[:nqc].contiguous(), quota=10000, limit=100)
+    torch.cuda.synchronize()
+    for k in env:
+        del os.environ[k]
+    s.set_scan_mode(mode=0)
+    same[name] = all(np.array_equal(o2[k].cpu().numpy().view(np.uint64) if k == "dists" else o2[k].cpu().numpy(),
+                                    ref[k][:nqc].view(np.uint64) if k == "dists" else ref[k][:nqc]) for k in ref)
+print("routes agree on the whole batch (ids, float64 distance bits, counts): %s" % same)
