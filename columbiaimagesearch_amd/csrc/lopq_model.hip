@@ -1210,8 +1210,67 @@ __global__ __launch_bounds__(256) void k_sqdist_rows2(const T* __restrict__ X, i
     out[((int64_t)s * n + r) * ncent + c] = pw_sum<T>(prog, elem);
 }
 
+// The same for many centroids (V >= 64, h = 32 or 64: one summation leaf): a thread keeps its row in registers, a
+// workgroup of 256 rows walks 64 centroids staged in LDS (every lane reads the same address: broadcast), four results
+// leave as one 16-byte store.  The element order is pw_leaf's, so the values are the ones of the kernel above -- which
+// reads both operands through strided 4-byte global loads (1.2 ms per 8192 queries at V = 2048).
+template <typename T, int H>
+__global__ __launch_bounds__(256) void k_sqdist_rows2_reg(const T* __restrict__ X, int64_t ldx, const T* __restrict__ C,
+                                                          int64_t n, int ncent, T* __restrict__ out) {
+    constexpr int CT = 64;
+    __shared__ __align__(16) T sC[CT][H];
+    const int s = blockIdx.z;
+    const int c0 = blockIdx.y * CT;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int nc = (ncent - c0 < CT) ? (ncent - c0) : CT;
+    {
+        const T* src = C + ((int64_t)s * ncent + c0) * H;
+        for (int e = threadIdx.x; e < nc * H; e += 256) (&sC[0][0])[e] = src[e];
+    }
+    T x[H];
+    {
+        const T* xr = X + (r < n ? r : 0) * ldx + s * H;
+#pragma unroll
+        for (int i = 0; i < H; ++i) x[i] = xr[i];
+    }
+    __syncthreads();
+    if (r >= n) return;
+    T* o = out + ((int64_t)s * n + r) * ncent + c0;
+    const bool vec = (ncent % 4 == 0) && sizeof(T) == 4;
+    for (int cq = 0; cq < nc; cq += 4) {
+        T v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = (cq + k < nc) ? cq + k : nc - 1;
+            const T* cc = sC[c];
+            auto elem = [&](int i) -> T { const T df = x[i] - cc[i]; return df * df; };
+            v[k] = pw_leaf<T>(elem, 0, H);
+        }
+        if (vec && cq + 3 < nc) {
+            *reinterpret_cast<float4*>(o + cq) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (cq + k < nc) o[cq + k] = v[k];
+        }
+    }
+}
+
 int cis_launch_sqdist_both(cis_model* m, const void* xc, int ct, int64_t n, void* out, hipStream_t st) {
     if (n == 0) return CIS_OK;
+    // (the row must fit the register file next to eight accumulators: float32 up to h = 64, float64 up to h = 32)
+    if (m->V >= 64 && ((ct == CIS_F32 && (m->h == 32 || m->h == 64)) || (ct != CIS_F32 && m->h == 32)) && !getenv("CIS_SQDIST_PLAIN")) {
+        const dim3 gr((unsigned)ceil_div(n, 256), (unsigned)ceil_div(m->V, 64), 2);
+#define CIS_SQ_REG(T, H, CP) hipLaunchKernelGGL((k_sqdist_rows2_reg<T, H>), gr, dim3(256), 0, st, (const T*)xc, (int64_t)m->D, CP, n, m->V, (T*)out)
+        if (ct == CIS_F32) {
+            if (m->h == 32) CIS_SQ_REG(float, 32, m->d_Cs32); else CIS_SQ_REG(float, 64, m->d_Cs32);
+        } else {
+            CIS_SQ_REG(double, 32, m->d_Cs64);
+        }
+#undef CIS_SQ_REG
+        CIS_CHECK_HIP(hipGetLastError());
+        return CIS_OK;
+    }
     dim3 g((unsigned)ceil_div(n, 16), (unsigned)ceil_div(m->V, 16), 2);
     if (ct == CIS_F32)
         hipLaunchKernelGGL(k_sqdist_rows2<float>, g, dim3(256), 0, st, (const float*)xc, (int64_t)m->D, m->h, m->d_Cs32, n, m->V,
