@@ -1043,6 +1043,28 @@ __global__ __launch_bounds__(256) void k_rank_sort(const CT* __restrict__ dist /
     if (q == 0 && s == 0)
         for (int i = threadIdx.x; i < 4 * V * GRP_SUB; i += blockDim.x) grp[i] = 0;
     const CT* d = dist + ((int64_t)s * nq + q) * V;
+    if constexpr (sizeof(CT) == 4) {
+        // float32 distances: (distance bits, index) is ONE 64-bit key -- half the LDS traffic of the pair sort below
+        for (int v = threadIdx.x; v < Vp2; v += 256) ka[v] = v < V ? ((f2bits(d[v]) << 32) | (uint64_t)v) : ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= Vp2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = threadIdx.x; t < (Vp2 >> 1); t += 256) {
+                    const int a_ = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int b_ = a_ + j;
+                    const uint64_t x = ka[a_], y = ka[b_];
+                    if ((x > y) == ((a_ & k) == 0)) { ka[a_] = y; ka[b_] = x; }
+                }
+                __syncthreads();
+            }
+        }
+        for (int r = threadIdx.x; r < V; r += 256) {
+            const int v = (int)(uint32_t)ka[r];
+            order[((int64_t)q * 2 + s) * V + r] = (uint16_t)v;
+            sorted[((int64_t)q * 2 + s) * V + r] = d[v];
+        }
+        return;
+    }
     for (int v = threadIdx.x; v < Vp2; v += 256) {
         ka[v] = v < V ? f2bits(d[v]) : ~0ull;
         kb[v] = v < V ? (uint64_t)v : ~0ull;
