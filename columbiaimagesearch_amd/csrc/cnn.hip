@@ -15,6 +15,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvDesc {
     int N, H, W, C;          // input: images, height, width, total channels
@@ -233,6 +234,215 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
             }
         }
     }
+}
+
+// s_waitcnt vmcnt(n) for a compile-time n that is only known after unrolling (the immediate must be a literal)
+static __device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Direct 3x3 / stride 1 / pad 1 convolution with C input = C output channels on a channels-last activation (the residual
+// branches of the dlib net at 35x35x32 and 17x17x64: half of its multiply-adds).  The implicit GEMM above gathers every
+// input pixel nine times from global memory, once per tap, and transposes it into LDS each time.  Here the input of a
+// workgroup's output range reaches LDS ONCE and the nine taps are nine shifted views of it:
+//   positions are numbered on a grid with one shared zero column per row and one shared zero row per image,
+//   q = (img*(H+1) + r)*(W+1) + c, so that the input of output q for tap (ky, kx) is position q + (ky-1)*(W+1) + (kx-1)
+//   for EVERY q (the borders read the zero column / zero row) -- a pure shift of the flattened index.  The grid exists
+//   only inside the kernel: the fill decodes q and reads the ordinary NHWC activation, the epilogue writes valid q only.
+// LDS: A window [BM + 2(W+2)][C+2] floats (pitch 2*odd: the 32 positions of a ds_read_b64 lane group fall on 32 distinct
+// bank pairs), weights of one tap [C/2][C][2] double-buffered (a lane's two k values adjacent).  One ds_read_b64 feeds two
+// v_mfma_f32_32x32x2_f32: lane half h holds k = kk+2h and kk+2h+1 of a 4-deep k step, A and B paired alike.
+// Accumulation order per output: taps in (ky, kx) order, channels ascending in 4-deep steps -- the same for every pixel,
+// batch size and tile position.
+template <int C, int H, int W, int WM, int NWM, int NWN>
+__global__ __launch_bounds__(NWM * NWN * 64) void k_conv3x3_direct(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int N,
+                                                           const float* __restrict__ res, int resC, int relu) {
+    constexpr int P = W + 1, IMGQ = (H + 1) * P, HALO = P + 1;
+    constexpr int NW = NWM * NWN, BM = NWM * WM * 32, NPOS = BM + 2 * HALO, LDC = C + 2, WN = C / 32 / NWN, NT = NW * 64;
+    static_assert(WN * NWN * 32 == C, "output channels split evenly over the waves");
+    constexpr int C4 = C / 4;
+    extern __shared__ float smem[];
+    float* As = smem;                    // [NPOS][LDC]
+    float* Bs = smem + NPOS * LDC;       // [2][C/2][C][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int wm = wave / NWN, wn = wave % NWN;  // wave tile: WM*32 positions x WN*32 output channels
+    const int64_t Qtot = (int64_t)N * IMGQ;
+    const int64_t q0 = (int64_t)blockIdx.x * BM;
+    // ---- the first WD taps of weights -> registers; Wp holds the paired layout [tap][C/2][C][2] ----
+    constexpr int WQ = C * C / 4;                          // float4 per tap
+    constexpr int WIT = (WQ + NT - 1) / NT;
+    // The fetch is inline assembly: as a C++ load the compiler sinks it below the tap's MFMAs, next to the LDS write that
+    // consumes it, and every tap then waits out a global-memory round trip.  The matching wait is wait_vmcnt().
+    constexpr int WD = 3;  // taps of weights in flight: one tap of MFMAs (0.4 - 1.7 us) does not cover a loaded L2 round trip
+    f32x4 wr[WD][WIT];
+#define CIS_WFETCH(tap_)                                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < WIT; ++i_) {                                                               \
+        const int idx_ = tid + NT * i_;                                                                                \
+        if (WQ % NT == 0 || idx_ < WQ)                                                                                 \
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wr[(tap_) % WD][i_]) : "v"(Wp + (int64_t)(tap_) * C * C + idx_ * 4) : "memory"); \
+    }
+#define CIS_WSTASH(tap_)                                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < WIT; ++i_) {                                                               \
+        const int idx_ = tid + NT * i_;                                                                                \
+        if (WQ % NT == 0 || idx_ < WQ) *reinterpret_cast<f32x4*>(Bs + ((tap_) & 1) * (C * C) + idx_ * 4) = wr[(tap_) % WD][i_]; \
+    }
+#pragma unroll
+    for (int t = 0; t < WD; ++t) { CIS_WFETCH(t) }
+    // ---- A window: positions q0 - HALO ... q0 + BM + HALO; every load of the thread in flight before the first LDS write ----
+    constexpr int AIT = (NPOS * C4 + NT - 1) / NT;
+    {
+        float4 v[AIT];
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            const int idx = tid + NT * i;
+            const int j = idx / C4, f = idx % C4;
+            const int64_t q = q0 - HALO + j;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NPOS * C4 && q >= 0 && q < Qtot) {
+                const int img = (int)(q / IMGQ), rem = (int)(q - (int64_t)img * IMGQ);
+                const int r = rem / P, c = rem - r * P;
+                if (r < H && c < W) v[i] = *reinterpret_cast<const float4*>(in + (((int64_t)img * H + r) * W + c) * C + f * 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            const int idx = tid + NT * i;
+            if (idx < NPOS * C4) {
+                const int j = idx / C4, f = idx % C4;
+                float2* dst = reinterpret_cast<float2*>(As + j * LDC + f * 4);
+                dst[0] = make_float2(v[i].x, v[i].y);
+                dst[1] = make_float2(v[i].z, v[i].w);
+            }
+        }
+    }
+    wait_vmcnt(0);
+    CIS_WSTASH(0)
+    __syncthreads();
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float* Abase = As + (HALO + wm * WM * 32 + l31) * LDC + 2 * h;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap + WD < 9) { CIS_WFETCH(tap + WD) }  // its ring slot held this tap's weights, already in LDS
+        __builtin_amdgcn_sched_barrier(0);
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const float* At = Abase + ((ky - 1) * P + (kx - 1)) * LDC;
+        const float* Bt = Bs + (tap & 1) * (C * C) + (h * C + wn * WN * 32 + l31) * 2;
+        float2 a[2][WM], b[2][WN];
+        auto operands = [&](int kk, float2(&av)[WM], float2(&bw)[WN]) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) av[i] = *reinterpret_cast<const float2*>(At + i * 32 * LDC + kk);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bw[j] = *reinterpret_cast<const float2*>(Bt + ((kk / 2) * C + j * 32) * 2);
+        };
+        operands(0, a[0], b[0]);
+#pragma unroll
+        for (int s = 0; s < C / 4; ++s) {
+            if (s + 1 < C / 4) operands((s + 1) * 4, a[(s + 1) & 1], b[(s + 1) & 1]);  // next step's reads before this step's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][i].x, b[s & 1][j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][i].y, b[s & 1][j].y, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap + 1 < 9) {
+            // loads return in order: tap + 1 has landed once only the younger taps' loads are outstanding
+            wait_vmcnt(WIT * ((tap + WD < 8 ? tap + WD : 8) - (tap + 1)));
+            CIS_WSTASH(tap + 1)  // the other buffer: its readers finished before the previous barrier
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: col = lane&31 (oc), row = (r&3) + 8*(r>>2) + 4*h (position); residual loads issued together ----
+    float bv[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bv[j] = bias[(wn * WN + j) * 32 + l31];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        int64_t pp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int64_t q = q0 + (wm * WM + i) * 32 + row;
+            pp[r] = -1;
+            if (q < Qtot) {
+                const int img = (int)(q / IMGQ), rem = (int)(q - (int64_t)img * IMGQ);
+                const int y = rem / P, x = rem - y * P;
+                if (y < H && x < W) pp[r] = ((int64_t)img * H + y) * W + x;
+            }
+        }
+        if (res) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int oc = (wn * WN + j) * 32 + l31;
+                if (oc < resC) {
+                    float rv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = pp[r] >= 0 ? res[pp[r] * resC + oc] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += bv[j] + rv[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += bv[j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += bv[j];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (pp[r] < 0) continue;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                float v = acc[i][j][r];
+                if (relu) v = v > 0.f ? v : 0.f;
+                out[pp[r] * C + (wn * WN + j) * 32 + l31] = v;
+            }
+        }
+    }
+}
+
+#undef CIS_WFETCH
+#undef CIS_WSTASH
+
+template <int C, int H, int W, int WM, int NWM, int NWN>
+static int launch_conv3x3_direct(const float* in, const float* w, const float* b, float* out, int N, const float* res, int resC,
+                                 int relu, hipStream_t st) {
+    constexpr int P = W + 1, BM = NWM * WM * 32, NPOS = BM + 2 * (P + 1);
+    constexpr size_t lds = ((size_t)NPOS * (C + 2) + 2 * C * C) * sizeof(float);
+    static bool attr_set = false;
+    auto kern = k_conv3x3_direct<C, H, W, WM, NWM, NWN>;
+    if (!attr_set) {
+        CIS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int64_t Qtot = (int64_t)N * (H + 1) * P;
+    hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(Qtot, BM)), dim3(NWM * NWN * 64), lds, st, in, w, b, out, N, res, resC, relu);
+    return CIS_OK;
 }
 
 // max pooling 3x3 stride 2 on NHWC, caffe output size ceil((H-3)/2)+1, windows clipped to the input
@@ -454,6 +664,7 @@ __global__ void k_global_avgpool(const float* __restrict__ in, float* __restrict
 struct LayerW {
     float* d_w = nullptr;  // packed [g][K][OCg]
     float* d_b = nullptr;
+    float* d_w2 = nullptr; // 3x3 layers with IC == OC == C served by k_conv3x3_direct: [tap][C/2][C][2] (a k pair adjacent)
 };
 
 struct cis_cnn {
@@ -481,7 +692,7 @@ extern "C" void cis_cnn_destroy(cis_cnn* c) {
     (void)hipSetDevice(c->device);
     for (auto& l : c->conv) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
     for (auto& l : c->fc) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
-    for (auto& l : c->dl) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
+    for (auto& l : c->dl) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_w2) (void)hipFree(l.d_w2); }
     c->act0.release(); c->act1.release(); c->act2.release(); c->act3.release(); c->part.release(); c->in_buf.release(); c->out_buf.release();
     delete c;
 }
@@ -508,6 +719,14 @@ static int pack_conv_affine(LayerW* L, const float* w, const float* b, const flo
     }
     CIS_TRY(upload_f(&L->d_w, packed.data(), packed.size()));
     CIS_TRY(upload_f(&L->d_b, bias.data(), bias.size()));
+    if (k == 3 && IC == OC && ICp == IC && (OC == 32 || OC == 64)) {
+        std::vector<float> paired(packed.size());
+        for (int t = 0; t < 9; ++t)
+            for (int ic = 0; ic < IC; ++ic)
+                for (int o = 0; o < OC; ++o)
+                    paired[(((size_t)t * (IC / 2) + ic / 2) * OC + o) * 2 + (ic & 1)] = packed[((size_t)t * IC + ic) * OC + o];
+        CIS_TRY(upload_f(&L->d_w2, paired.data(), paired.size()));
+    }
     return CIS_OK;
 }
 
@@ -672,8 +891,29 @@ static ConvDesc nhwc_conv(int n, int H, int W, int C, int OC, int k, int stride,
 // A convolution whose output has too few tiles to fill the chip (the deep, spatially small layers of the dlib net: 16-256
 // workgroups walking K = 1152 ... 2304 serially) splits K over blockIdx.z and adds the partial sums in a fixed order,
 // together with bias, residual branch and ReLU (k_splitk_reduce).
-static int conv_fill_chip(cis_cnn* c, ConvDesc d, const float* in, const float* w, const float* b, float* out, hipStream_t st) {
+static int conv_fill_chip(cis_cnn* c, ConvDesc d, const float* in, const LayerW& L, float* out, hipStream_t st) {
+    const float* w = L.d_w;
+    const float* b = L.d_b;
     const int64_t npix = (int64_t)d.N * d.OH * d.OW;
+    // the 3x3 / stride 1 / pad 1 layers with as many output as input channels at the two large spatial sizes: direct kernel
+    const bool no_direct = getenv("CIS_CNN_NO_DIRECT") != nullptr;  // read per call: A/B runs in one process
+    if (!no_direct && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.groups == 1 && d.C == d.OC && d.sC == 1 && b != nullptr && L.d_w2 != nullptr &&
+        d.runq == 0 && d.splitk == 1) {
+        const char* cfg_s = getenv("CIS_CNN_DIRECT_CFG");  // tile sweep (tools/check_dlib_direct.py)
+        const int cfg = cfg_s ? atoi(cfg_s) : 0;
+#define CIS_DIRECT(C_, H_, W_, WM_, NWM_, NWN_) return launch_conv3x3_direct<C_, H_, W_, WM_, NWM_, NWN_>(in, L.d_w2, b, out, d.N, d.res, d.resC, d.relu, st)
+        if (d.C == 32 && d.H == 35 && d.W == 35) {
+            if (cfg == 1) CIS_DIRECT(32, 35, 35, 1, 8, 1);
+            if (cfg == 2) CIS_DIRECT(32, 35, 35, 2, 4, 1);
+            CIS_DIRECT(32, 35, 35, 1, 4, 1);
+        }
+        if (d.C == 64 && d.H == 17 && d.W == 17) {
+            if (cfg == 1) CIS_DIRECT(64, 17, 17, 1, 2, 2);
+            if (cfg == 2) CIS_DIRECT(64, 17, 17, 1, 4, 1);
+            CIS_DIRECT(64, 17, 17, 1, 4, 2);
+        }
+#undef CIS_DIRECT
+    }
     const bool vec = d.sC == 1 && d.ICg % 16 == 0 && d.C % 4 == 0 && d.groups == 1 && d.OC % 4 == 0 && d.runq == 0;
     const int64_t tiles = npix <= 2048 ? ceil_div(npix, 32) * ceil_div((int64_t)d.OCg, 128) : ceil_div(npix, 64) * ceil_div((int64_t)d.OCg, 64);
     const int nkt = d.K / 16;
@@ -725,7 +965,7 @@ static int cnn_forward_dlib(cis_cnn* c, const float* d_in, int n, float* d_feats
         const DlibBlock& b = kDlibBlocks[i];
         const int s = b.down ? 2 : 1, p = b.down ? 0 : 1;
         ConvDesc da = nhwc_conv(n, H, W, C, b.cout, 3, s, p, 1);
-        CIS_TRY(conv_fill_chip(c, da, x, c->dl[1 + 2 * i].d_w, c->dl[1 + 2 * i].d_b, T1, st));
+        CIS_TRY(conv_fill_chip(c, da, x, c->dl[1 + 2 * i], T1, st));
         ConvDesc db = nhwc_conv(n, da.OH, da.OW, b.cout, b.cout, 3, 1, 1, 0);
         int SH = H, SW = W, SC = C;
         if (b.down) { SH = (H - 2) / 2 + 1; SW = (W - 2) / 2 + 1; }
@@ -743,9 +983,9 @@ static int cnn_forward_dlib(cis_cnn* c, const float* d_in, int n, float* d_feats
         }
         if (fuse) {
             db.res = skip; db.resC = SC; db.relu = 1;
-            CIS_TRY(conv_fill_chip(c, db, T1, c->dl[2 + 2 * i].d_w, c->dl[2 + 2 * i].d_b, other, st));
+            CIS_TRY(conv_fill_chip(c, db, T1, c->dl[2 + 2 * i], other, st));
         } else {
-            CIS_TRY(conv_fill_chip(c, db, T1, c->dl[2 + 2 * i].d_w, c->dl[2 + 2 * i].d_b, T2, st));
+            CIS_TRY(conv_fill_chip(c, db, T1, c->dl[2 + 2 * i], T2, st));
             if (b.down) {
                 hipLaunchKernelGGL(k_avgpool2_nhwc, grid((int64_t)n * SH * SW * C), dim3(256), 0, st, x, T1, n, H, W, C, SH, SW);
                 skip = T1;  // T1 is free again: conv b has consumed it (same stream)

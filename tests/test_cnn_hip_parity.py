@@ -115,6 +115,28 @@ def test_dlib_resnet_matches_torch_cpu(tmp_path):
     np.testing.assert_array_equal(d, got[:2].astype(np.float64))
 
 
+def test_dlib_direct_3x3_kernel_agrees_with_implicit_gemm(monkeypatch):
+    """The direct 3x3 kernel (k_conv3x3_direct: the 35x35x32 and 17x17x64 residual branches) against the implicit-GEMM route
+    of the same layers (CIS_CNN_NO_DIRECT), on batches whose tiles straddle image borders, and for every tile shape."""
+    from oracle import dlib_oracle as D
+    from columbiaimagesearch_amd.featurizer import DLibFaceNet
+    net = DLibFaceNet(D.synthetic_weights(3))
+    for n, seed in ((1, 7), (7, 8), (70, 9)):
+        chips = D.synthetic_chips(n, seed=seed)
+        monkeypatch.setenv("CIS_CNN_NO_DIRECT", "1")
+        ref = net.forward(chips)
+        monkeypatch.delenv("CIS_CNN_NO_DIRECT")
+        tol = 3e-5 * np.abs(ref).max()  # same products, different float32 summation order
+        for cfg in ("0", "1", "2"):
+            monkeypatch.setenv("CIS_CNN_DIRECT_CFG", cfg)
+            got = net.forward(chips)
+            assert np.isfinite(got).all()
+            np.testing.assert_allclose(got, ref, rtol=0, atol=tol)
+            # a face's descriptor does not depend on its place in the batch: same accumulation order at every position
+            np.testing.assert_array_equal(net.forward(chips[n - 1:n])[0], got[n - 1]) if n <= 7 else None
+        monkeypatch.delenv("CIS_CNN_DIRECT_CFG")
+
+
 def test_batch_ingest_matches_per_item_chain():
     """CNN -> L2 normalise -> LOPQ encode -> insert on the GPU == the same chain item by item through the host surfaces."""
     import torch
