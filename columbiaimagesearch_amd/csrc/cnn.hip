@@ -920,6 +920,14 @@ static int conv_fill_chip(cis_cnn* c, ConvDesc d, const float* in, const LayerW&
     int splitk = 1;
     static const bool off = getenv("CIS_CNN_NO_SPLITK") != nullptr;
     while (!off && vec && d.OCg > 32 && tiles * splitk < 512 && splitk < 32 && nkt / (splitk * 2) >= 6) splitk *= 2;
+    // the 128- and 256-channel maps (8x8 ... 3x3 per chip): 128 x 128 tiles (the kernel's most efficient shape) with K split until
+    // the chip is full, instead of 64 x 64 tiles: 70 -> 66 us and 74 -> 64 us per layer at batch 256 (CIS_CNN_NO_BIGTILE: old choice)
+    if (!off && vec && !getenv("CIS_CNN_NO_BIGTILE") && d.OCg >= 128 && d.OCg % 128 == 0 && npix > 2048) {
+        const int64_t t128 = ceil_div(npix, 128) * (d.OCg / 128);
+        int s = 1;
+        while (t128 * s < 512 && s < 32 && nkt / (s * 2) >= 6) s *= 2;
+        if (t128 * s >= 512) splitk = s;
+    }
     if (splitk == 1) {
         launch_conv(d, in, w, b, out, st);
         return CIS_OK;
