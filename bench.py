@@ -412,6 +412,14 @@ def main():
                 "value": world * B / dt, "unit": "descriptors/s", "n_gpus": world, "parallelism": "replicas, no collective", "ms_per_batch": dt * 1e3, "dtype": "f32",
                 "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": flop / dt / (F32_MFMA_PEAK_TFLOPS * 1e12), "flop_per_image": 2 * 270854144}}
+        # the same forward at 1024 chips per call: a launch of the 256-chip batch lasts 60-80 us, of which the ramp and the tail
+        # of the workgroup rounds are a fifth -- reported next to the BASELINE batch, not instead of it
+        del xb
+        B4 = 1024
+        xb = (torch.rand((B4, 150, 150, 3), generator=gcn, device=device) * 255).contiguous()
+        dt4 = time_net(net, xb, torch.empty((B4, 128), device=device), reps=4)
+        dlib["batch_1024"] = {"value": world * B4 / dt4, "unit": "descriptors/s", "ms_per_batch": dt4 * 1e3,
+                              "frac": 2.0 * 270854144 * B4 / dt4 / (F32_MFMA_PEAK_TFLOPS * 1e12)}
         net.close()
 
     if rank == 0:
