@@ -667,11 +667,24 @@ struct LayerW {
     float* d_w2 = nullptr; // 3x3 layers with IC == OC == C served by k_conv3x3_direct: [tap][C/2][C][2] (a k pair adjacent)
 };
 
+// activations and split-K partial sums of one forward in flight
+struct CnnWs {
+    DevBuf act0, act1, act2, act3, part;
+    void release() { act0.release(); act1.release(); act2.release(); act3.release(); part.release(); }
+};
+static const int kMaxParts = 4;
+
 struct cis_cnn {
     int arch = 0, device = 0;
     LayerW conv[5], fc[2];        // DeepSentibank
     std::vector<LayerW> dl;       // dlib ResNet: conv0, then (a, b) per block, then fc (bias-free); affine layers folded in
-    DevBuf act0, act1, act2, act3, part, in_buf, out_buf;
+    // A batch is cut into up to kMaxParts contiguous parts that run the whole forward concurrently on the handle's own streams,
+    // each with its own workspace: a launch of the 256-item batch lasts 60-80 us and spends a fifth of it in the ramp and tail of
+    // its workgroup rounds, which the other part's launches fill (dlib, batch 256: 2.16 -> 2.03 ms with two parts).
+    CnnWs ws[kMaxParts];
+    hipStream_t ps[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_in = nullptr, ev_done[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
+    DevBuf in_buf, out_buf;
 };
 
 // dlib anet_type block plan: (in channels, out channels, down-sampling block)
@@ -693,7 +706,11 @@ extern "C" void cis_cnn_destroy(cis_cnn* c) {
     for (auto& l : c->conv) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
     for (auto& l : c->fc) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
     for (auto& l : c->dl) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_w2) (void)hipFree(l.d_w2); }
-    c->act0.release(); c->act1.release(); c->act2.release(); c->act3.release(); c->part.release(); c->in_buf.release(); c->out_buf.release();
+    for (auto& w : c->ws) w.release();
+    for (auto& s : c->ps) if (s) (void)hipStreamDestroy(s);
+    for (auto& e : c->ev_done) if (e) (void)hipEventDestroy(e);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    c->in_buf.release(); c->out_buf.release();
     delete c;
 }
 
@@ -891,7 +908,7 @@ static ConvDesc nhwc_conv(int n, int H, int W, int C, int OC, int k, int stride,
 // A convolution whose output has too few tiles to fill the chip (the deep, spatially small layers of the dlib net: 16-256
 // workgroups walking K = 1152 ... 2304 serially) splits K over blockIdx.z and adds the partial sums in a fixed order,
 // together with bias, residual branch and ReLU (k_splitk_reduce).
-static int conv_fill_chip(cis_cnn* c, ConvDesc d, const float* in, const LayerW& L, float* out, hipStream_t st) {
+static int conv_fill_chip(CnnWs* ws, ConvDesc d, const float* in, const LayerW& L, float* out, hipStream_t st) {
     const float* w = L.d_w;
     const float* b = L.d_b;
     const int64_t npix = (int64_t)d.N * d.OH * d.OW;
@@ -932,8 +949,8 @@ static int conv_fill_chip(cis_cnn* c, ConvDesc d, const float* in, const LayerW&
         launch_conv(d, in, w, b, out, st);
         return CIS_OK;
     }
-    CIS_TRY(c->part.reserve((size_t)splitk * npix * d.OC * sizeof(float)));
-    float* part = c->part.as<float>();
+    CIS_TRY(ws->part.reserve((size_t)splitk * npix * d.OC * sizeof(float)));
+    float* part = ws->part.as<float>();
     ConvDesc dp = d;
     dp.splitk = splitk;
     dp.part_stride = npix * d.OC;
@@ -946,16 +963,16 @@ static int conv_fill_chip(cis_cnn* c, ConvDesc d, const float* in, const LayerW&
 }
 
 // dlib face ResNet: d_in = [n][150][150][3] float32 RGB 0..255 (aligned chips), d_feats = [n][128]
-static int cnn_forward_dlib(cis_cnn* c, const float* d_in, int n, float* d_feats, hipStream_t st) {
+static int cnn_forward_dlib(cis_cnn* c, CnnWs* ws, const float* d_in, int n, float* d_feats, hipStream_t st) {
     const size_t big = (size_t)n * 72 * 72 * 32;  // largest activation: first convolution's output
-    CIS_TRY(c->act0.reserve(big * sizeof(float)));
-    CIS_TRY(c->act1.reserve(big * sizeof(float)));
-    CIS_TRY(c->act2.reserve(big * sizeof(float)));
-    CIS_TRY(c->act3.reserve(big * sizeof(float)));
-    float* A = c->act0.as<float>();
-    float* B = c->act1.as<float>();
-    float* T1 = c->act2.as<float>();
-    float* T2 = c->act3.as<float>();
+    CIS_TRY(ws->act0.reserve(big * sizeof(float)));
+    CIS_TRY(ws->act1.reserve(big * sizeof(float)));
+    CIS_TRY(ws->act2.reserve(big * sizeof(float)));
+    CIS_TRY(ws->act3.reserve(big * sizeof(float)));
+    float* A = ws->act0.as<float>();
+    float* B = ws->act1.as<float>();
+    float* T1 = ws->act2.as<float>();
+    float* T2 = ws->act3.as<float>();
     auto grid = [](int64_t total) { return dim3((unsigned)ceil_div(total, 256)); };
     hipLaunchKernelGGL(k_normalize_rgb4, grid((int64_t)n * 150 * 150), dim3(256), 0, st, d_in, A, (int64_t)n * 150 * 150, 122.782f,
                        117.001f, 104.298f);
@@ -973,7 +990,7 @@ static int cnn_forward_dlib(cis_cnn* c, const float* d_in, int n, float* d_feats
         const DlibBlock& b = kDlibBlocks[i];
         const int s = b.down ? 2 : 1, p = b.down ? 0 : 1;
         ConvDesc da = nhwc_conv(n, H, W, C, b.cout, 3, s, p, 1);
-        CIS_TRY(conv_fill_chip(c, da, x, c->dl[1 + 2 * i], T1, st));
+        CIS_TRY(conv_fill_chip(ws, da, x, c->dl[1 + 2 * i], T1, st));
         ConvDesc db = nhwc_conv(n, da.OH, da.OW, b.cout, b.cout, 3, 1, 1, 0);
         int SH = H, SW = W, SC = C;
         if (b.down) { SH = (H - 2) / 2 + 1; SW = (W - 2) / 2 + 1; }
@@ -991,9 +1008,9 @@ static int cnn_forward_dlib(cis_cnn* c, const float* d_in, int n, float* d_feats
         }
         if (fuse) {
             db.res = skip; db.resC = SC; db.relu = 1;
-            CIS_TRY(conv_fill_chip(c, db, T1, c->dl[2 + 2 * i], other, st));
+            CIS_TRY(conv_fill_chip(ws, db, T1, c->dl[2 + 2 * i], other, st));
         } else {
-            CIS_TRY(conv_fill_chip(c, db, T1, c->dl[2 + 2 * i], T2, st));
+            CIS_TRY(conv_fill_chip(ws, db, T1, c->dl[2 + 2 * i], T2, st));
             if (b.down) {
                 hipLaunchKernelGGL(k_avgpool2_nhwc, grid((int64_t)n * SH * SW * C), dim3(256), 0, st, x, T1, n, H, W, C, SH, SW);
                 skip = T1;  // T1 is free again: conv b has consumed it (same stream)
@@ -1011,19 +1028,52 @@ static int cnn_forward_dlib(cis_cnn* c, const float* d_in, int n, float* d_feats
     return CIS_OK;
 }
 
+static int cnn_forward_sentibank(cis_cnn* c, CnnWs* ws, const float* d_nchw, int n, float* d_feats, hipStream_t st);
+
 extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float* d_feats, void* stream) {
     CIS_REQUIRE(c != nullptr, "cnn is NULL");
     CIS_REQUIRE(n >= 0, "n must be >= 0");
     if (n == 0) return CIS_OK;
     CIS_CHECK_HIP(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
-    if (c->arch == 2) return cnn_forward_dlib(c, d_nchw, n, d_feats, st);
+    // parts of the batch in flight together (CIS_CNN_PARTS=1: one launch chain on the caller's stream)
+    // measured (dlib): two parts at 256 chips 2.16 -> 2.03 ms; four parts lose (the host enqueues the parts' ~50 launches one part after
+    // the other, so the last part starts late); 1024 chips: launches are long enough alone; DeepSentibank: +2 %, left alone
+    int parts = (c->arch == 2 && n >= 128 && n <= 512) ? 2 : 1;
+    if (const char* e = getenv("CIS_CNN_PARTS")) parts = atoi(e);
+    if (parts > kMaxParts) parts = kMaxParts;
+    if (parts > n) parts = n;
+    const size_t in_item = c->arch == 2 ? (size_t)150 * 150 * 3 : (size_t)3 * 227 * 227, out_item = c->arch == 2 ? 128 : 4096;
+    if (parts <= 1)
+        return c->arch == 2 ? cnn_forward_dlib(c, &c->ws[0], d_nchw, n, d_feats, st) : cnn_forward_sentibank(c, &c->ws[0], d_nchw, n, d_feats, st);
+    if (!c->ev_in) {
+        CIS_CHECK_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+        for (int p = 0; p < kMaxParts; ++p) {
+            CIS_CHECK_HIP(hipStreamCreateWithFlags(&c->ps[p], hipStreamNonBlocking));
+            CIS_CHECK_HIP(hipEventCreateWithFlags(&c->ev_done[p], hipEventDisableTiming));
+        }
+    }
+    CIS_CHECK_HIP(hipEventRecord(c->ev_in, st));  // the parts start after the caller's earlier work ...
+    int rc = CIS_OK;
+    for (int p = 0; p < parts; ++p) {
+        const int lo = (int)((int64_t)n * p / parts), hi = (int)((int64_t)n * (p + 1) / parts);
+        CIS_CHECK_HIP(hipStreamWaitEvent(c->ps[p], c->ev_in, 0));
+        const int r = c->arch == 2 ? cnn_forward_dlib(c, &c->ws[p], d_nchw + lo * in_item, hi - lo, d_feats + lo * out_item, c->ps[p])
+                                   : cnn_forward_sentibank(c, &c->ws[p], d_nchw + lo * in_item, hi - lo, d_feats + lo * out_item, c->ps[p]);
+        if (r != CIS_OK) rc = r;
+        CIS_CHECK_HIP(hipEventRecord(c->ev_done[p], c->ps[p]));
+        CIS_CHECK_HIP(hipStreamWaitEvent(st, c->ev_done[p], 0));  // ... and the caller's later work waits for every part
+    }
+    return rc;
+}
+
+static int cnn_forward_sentibank(cis_cnn* c, CnnWs* ws, const float* d_nchw, int n, float* d_feats, hipStream_t st) {
     // largest activation: conv1 output n x 55 x 55 x 96
     const size_t act_elems = (size_t)n * 55 * 55 * 96;
-    CIS_TRY(c->act0.reserve(act_elems * sizeof(float)));
-    CIS_TRY(c->act1.reserve(act_elems * sizeof(float)));
-    CIS_TRY(c->act2.reserve((size_t)4 * n * 4096 * sizeof(float)));  // split-K partial sums of the fc layers
-    float* bufs[2] = {c->act0.as<float>(), c->act1.as<float>()};
+    CIS_TRY(ws->act0.reserve(act_elems * sizeof(float)));
+    CIS_TRY(ws->act1.reserve(act_elems * sizeof(float)));
+    CIS_TRY(ws->act2.reserve((size_t)4 * n * 4096 * sizeof(float)));  // split-K partial sums of the fc layers
+    float* bufs[2] = {ws->act0.as<float>(), ws->act1.as<float>()};
     const float* cur = d_nchw;
     int which = 0;
     int C = 3, H = 227, W = 227;
@@ -1045,8 +1095,8 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
             // first layer: the NCHW batch is re-laid as NHWC rows (pitch 684 floats) once, then every (pixel, kernel row)
             // is a run of 33 contiguous floats gathered with aligned 16-byte loads instead of 363 scalar loads per pixel
             const int pitch = ((W * 3 + 3) / 4) * 4;
-            CIS_TRY(c->act3.reserve(((size_t)n * H * pitch + 16) * sizeof(float)));
-            float* xt = c->act3.as<float>();
+            CIS_TRY(ws->act3.reserve(((size_t)n * H * pitch + 16) * sizeof(float)));
+            float* xt = ws->act3.as<float>();
             hipLaunchKernelGGL(k_nchw3_to_nhwc, dim3((unsigned)ceil_div((int64_t)n * H * W, 256)), dim3(256), 0, st, cur, xt,
                                (int64_t)n * H, H, W, pitch);
             d.sN = (int64_t)H * pitch; d.sC = 1; d.sH = pitch; d.sW = 3;
@@ -1101,7 +1151,7 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
         if (splitk > 1) {
             d.splitk = splitk;
             d.part_stride = (int64_t)n * 4096;
-            float* part = c->act2.as<float>();
+            float* part = ws->act2.as<float>();
             launch_conv(d, cur, c->fc[l].d_w, nullptr, part, st);
             const int64_t n4 = (int64_t)n * 4096 / 4;
             hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, part, splitk, d.part_stride,
