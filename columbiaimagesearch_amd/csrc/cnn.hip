@@ -12,6 +12,7 @@
 // LDS, never materialised.  Activations are kept channels-last (NHWC) between layers so that the K
 // axis of the gather and the across-channel LRN window are contiguous.  Bias + ReLU are fused into the
 // GEMM epilogue; pooling uses caffe's ceil-mode output size with windows clipped to the input.
+#include <atomic>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -434,11 +435,16 @@ static int launch_conv3x3_direct(const float* in, const float* w, const float* b
                                  int relu, hipStream_t st) {
     constexpr int P = W + 1, BM = NWM * WM * 32, NPOS = BM + 2 * (P + 1);
     constexpr size_t lds = ((size_t)NPOS * (C + 2) + 2 * C * C) * sizeof(float);
-    static bool attr_set = false;
+    // the dynamic-LDS attribute is a per-device property of the function: one bit per device, set by whichever thread launches there
+    // first (setting it twice is harmless, so the race of two first launches needs no lock)
+    static std::atomic<uint64_t> attr_set{0};
     auto kern = k_conv3x3_direct<C, H, W, WM, NWM, NWN>;
-    if (!attr_set) {
+    int dev = 0;
+    CIS_CHECK_HIP(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
         CIS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
     const int64_t Qtot = (int64_t)N * (H + 1) * P;
     hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(Qtot, BM)), dim3(NWM * NWN * 64), lds, st, in, w, b, out, N, res, resC, relu);
@@ -1054,17 +1060,26 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
         }
     }
     CIS_CHECK_HIP(hipEventRecord(c->ev_in, st));  // the parts start after the caller's earlier work ...
+    // A failure inside the loop must not leave parts that are already running unfenced: every part that was started is still
+    // recorded and waited for on the caller's stream, then the first error is returned.
     int rc = CIS_OK;
-    for (int p = 0; p < parts; ++p) {
+    hipError_t herr = hipSuccess;
+    for (int p = 0; p < parts && rc == CIS_OK && herr == hipSuccess; ++p) {
         const int lo = (int)((int64_t)n * p / parts), hi = (int)((int64_t)n * (p + 1) / parts);
-        CIS_CHECK_HIP(hipStreamWaitEvent(c->ps[p], c->ev_in, 0));
-        const int r = c->arch == 2 ? cnn_forward_dlib(c, &c->ws[p], d_nchw + lo * in_item, hi - lo, d_feats + lo * out_item, c->ps[p])
-                                   : cnn_forward_sentibank(c, &c->ws[p], d_nchw + lo * in_item, hi - lo, d_feats + lo * out_item, c->ps[p]);
-        if (r != CIS_OK) rc = r;
-        CIS_CHECK_HIP(hipEventRecord(c->ev_done[p], c->ps[p]));
-        CIS_CHECK_HIP(hipStreamWaitEvent(st, c->ev_done[p], 0));  // ... and the caller's later work waits for every part
+        herr = hipStreamWaitEvent(c->ps[p], c->ev_in, 0);
+        if (herr != hipSuccess) break;  // nothing of this part was enqueued
+        rc = c->arch == 2 ? cnn_forward_dlib(c, &c->ws[p], d_nchw + lo * in_item, hi - lo, d_feats + lo * out_item, c->ps[p])
+                          : cnn_forward_sentibank(c, &c->ws[p], d_nchw + lo * in_item, hi - lo, d_feats + lo * out_item, c->ps[p]);
+        hipError_t e = hipEventRecord(c->ev_done[p], c->ps[p]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, c->ev_done[p], 0);  // ... and the caller's later work waits for every part
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(c->ps[p]);  // the fence could not be placed: drain the part before reporting
+            herr = e;
+        }
     }
-    return rc;
+    if (rc != CIS_OK) return rc;
+    CIS_CHECK_HIP(herr);
+    return CIS_OK;
 }
 
 static int cnn_forward_sentibank(cis_cnn* c, CnnWs* ws, const float* d_nchw, int n, float* d_feats, hipStream_t st) {

@@ -28,6 +28,9 @@
 // Survivors leave as (float(s) << 32 | pos) 8-byte pairs, the format k_merge_survivors reads; their high words are
 // only ordered inside one work item (each item has its own scale), so the merge re-scores all of them (cut = 0).
 #include "scan_common.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 
@@ -962,7 +965,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     const int* __restrict__ n_slots_ptr, const double* __restrict__ T, const float* __restrict__ T32,
     const uint8_t* __restrict__ codes, int K, int L, int S, int* __restrict__ queue_ctr /* [8], zeroed */,
     uint64_t* __restrict__ item_surv, int* __restrict__ item_n, float* __restrict__ item_slack,
-    unsigned long long* __restrict__ qbound /* [nq], +inf */, int two_pass) {
+    unsigned long long* __restrict__ qbound /* [nq], +inf */, int two_pass, int single_queue /* queue 0 holds everything: [qs[0], qs[1]) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int G = S3G;
     constexpr int R = NR * 64 - 8;
@@ -974,7 +977,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     for (int a = 0; a < 8; ++a) {
         const int x = (home + a) & 7;
         const int qstart = qs[x];
-        const int count = qs[x + 1] - qstart;
+        const int count = single_queue ? (x == 0 ? qs[1] - qstart : 0) : qs[x + 1] - qstart;
         while (true) {
             const long long q0 = S3_CLK();
             (void)q0;
@@ -1027,6 +1030,501 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     S3_CTR(10, 1);
 }
 
+// ---- sampled single-pass form (scan mode 5; automatic for short chunks at M <= 8, limit <= 128) ---------------------------
+// On short chunks (BASELINE config C2: 1M vectors, 3.9 k candidates per cell, ~3 cells per query) the forms above spend their
+// time around the table gathers, not in them (profiles/r03a_c2_probes.txt: 0.183 of 0.271 ms remain with the loops removed;
+// every phase of a slot is a few microseconds of latency and the SIMDs are ~1/3 busy): at 128 registers and 37 KB of LDS a CU
+// holds four workgroups, too few to hide a slot's chain of dependent loads and its barriers, and the two-pass form gathers every
+// candidate twice.  This form is built for occupancy -- 80 registers, 25 KB of LDS: six workgroups = 24 waves per CU -- and does
+// less per slot:
+//   * its slots are known in advance (static schedule: runs of 32 consecutive slots -- about one cell -- round-robin over the
+//     XCDs, a workgroup takes every LW-th slot of its XCD): one lane per slot resolves the descriptor chain slot -> items ->
+//     table descriptors for eight of the workgroup's slots at once, into LDS;
+//   * the collection threshold comes from a SAMPLE of <= 16 rows of 64 candidates spread over the chunk: the waves write the
+//     sample's sums to LDS, wave g takes query g's k_s-th smallest by ballot bisection in registers (no histogram, no LDS
+//     atomics); k_s - 4 sqrt(k_s) >= limit x sampled fraction, so that the whole chunk holds >= limit candidates under that
+//     value tau but for a ~1e-4 tail.  A query whose other cells already published a bound (qbound) at least as tight skips
+//     the sample's verdict: that bound is valid by itself;
+//   * every candidate is gathered ONCE; sums up to tau + M + 1 are appended to one list per query (one 4-lane LDS atomic per
+//     row of 64 candidates reserves the places of all four queries);
+//   * what the sample only made likely is VERIFIED: wave g loads query g's list (<= 504 entries, eight registers per lane),
+//     counts the sums <= tau -- fewer than `limit`, or a list that overflowed, puts the slot on the fall-back list, which
+//     k_adc_scan3's two-pass form (-> streaming form for crowds of equal sums) works off right after this kernel; the result
+//     therefore never depends on the sample -- and cuts the list to the exact limit-th smallest sum + M + 1 (the bracket
+//     argument of the two-pass form) before it leaves the CU, so the merge sees ~limit survivors per item.
+// Measured on C2 (profiles/r03f..h): 0.268 -> 0.205 ms per 8192 queries; sample of 8 rows with 376-entry lists and k - 3 sqrt(k):
+// the same time but ~60 of 6289 slots through the fall-back; here none.  Probes of this kernel: nothing passing 0.146, no main
+// pass 0.135, no sample pass either 0.120 ms -- what is left is staging 32 KB of float32 tables per slot (201 MB per batch).
+// (A second attempt inside the kernel -- exact two-level histogram threshold -- and a dynamic share of slots were built and
+// measured slower, 0.22 - 0.24 ms: the extra code costs the common path more than the fall-back launch costs.)
+struct Slot4 {  // one slot's descriptor chain, resolved once (LDS)
+    int item[S3G], tab0[S3G], tab1[S3G], q[S3G];
+    float qinv[S3G];
+    int start_lo, start_hi, len, ng;  // ng < 0: the slot's items do not cover one chunk (-> fall-back list)
+};
+struct Scan4Shared {  // per query
+    double inv_up, ub;
+    uint64_t ext;
+    uint32_t tau;     // >= limit candidates are expected (sample) to have a sum <= tau
+    int verify;       // the collection threshold rests on the sample: count before trusting it
+    int cnt;          // entries in the query's list
+    int q;
+};
+
+// sums of UU rows of 64 candidates (software pipelined: the table reads of unit q+1 are issued before the adds of unit q)
+template <int M, int UU, int OCT = (M >= 8 ? 8 : 4)>
+__device__ __forceinline__ void adc16_rows(const CodeWords<M> (&cur)[UU], const char* __restrict__ tab, const RotConsts<M>& rc,
+                                           u32x2_t (&d)[UU]) {
+    constexpr int NU = M / OCT;
+    u32x2_t fbuf[2][OCT];
+    uint32_t D[2][(M + 3) / 4];
+    rot_words<M>(cur[0], rc, D[0]);
+    adc16_issue<M, OCT>(D[0], 0, tab, rc, fbuf[0]);
+#pragma unroll
+    for (int q = 0; q < UU * NU; ++q) {
+        const int u = q / NU, o = q % NU;
+        if (q + 1 < UU * NU) {
+            const int u1 = (q + 1) / NU, o1 = (q + 1) % NU;
+            if (o1 == 0) rot_words<M>(cur[u1], rc, D[u1 & 1]);
+            adc16_issue<M, OCT>(D[u1 & 1], o1, tab, rc, fbuf[(q + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x2_t part = adc16_sum<OCT>(fbuf[q & 1]);
+        if (o == 0) {
+            d[u] = part;
+        } else {
+            d[u][0] = pk_add_u16(d[u][0], part[0]);
+            d[u][1] = pk_add_u16(d[u][1], part[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// A barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence on every address space (s_waitcnt
+// vmcnt(0) before s_barrier: it also waits for every global load and store in flight).  Inside a slot the waves of a
+// workgroup exchange data through LDS only, so lgkmcnt(0) is the whole fence.
+static __device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#ifndef CIS_S4_U
+#define CIS_S4_U 2
+#endif
+#ifndef CIS_S4_OCT
+#define CIS_S4_OCT 4
+#endif
+#ifndef CIS_S4_WPE
+#define CIS_S4_WPE 6
+#endif
+static const int S4_OCT = CIS_S4_OCT;  // table reads per pipeline unit of the main pass (4: 16 registers of reads in flight)
+#ifndef CIS_S4_LCAP
+#define CIS_S4_LCAP 504
+#endif
+#ifndef CIS_S4_NS
+#define CIS_S4_NS 16
+#endif
+#ifndef CIS_S4_Z
+#define CIS_S4_Z 4.0f
+#endif
+static const int S4_DS = 8;              // slot descriptors resolved per round
+static const int S4_LCAP = CIS_S4_LCAP;  // entries of a query's list
+static const int S4_NS = CIS_S4_NS;      // sample rows per chunk (64 sums per query each)
+
+static size_t scan4_lds(int M, int K) {
+    const size_t lists = (size_t)S3G * S4_LCAP * 4, samp = (size_t)S3G * S4_NS * 64 * 2;
+    return (size_t)K * M * S3G * 2 + (lists > samp ? lists : samp) + S3G * sizeof(Scan4Shared) + 32 + S4_DS * sizeof(Slot4);
+}
+
+template <int M, int U, int NW, int WPE>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_adc_scan4(
+    const WorkItem* __restrict__ items, const TabDesc* __restrict__ tabs, const int* __restrict__ slots,
+    const int* __restrict__ n_slots_ptr, const float* __restrict__ T32, const uint8_t* __restrict__ codes, int K, int L, int S,
+    int* __restrict__ dbg /* [2]: slots, fallbacks */, int* __restrict__ fhdr /* fall-back list: [17] = count (queue 0 of a scan3 header) */,
+    int* __restrict__ fslots, uint64_t* __restrict__ item_surv, int* __restrict__ item_n, float* __restrict__ item_slack,
+    unsigned long long* __restrict__ qbound) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int G = S3G;
+    static_assert(NW == G, "one wave per query in the threshold and verification phases");
+    static_assert(M == 4 || M == 8, "one float4 of every half table per thread");
+    constexpr int nf = M / 2;
+    constexpr uint32_t CAP = 65535u / M;
+    constexpr int LCAP = S4_LCAP, NS = S4_NS, NRV = (LCAP + 63) / 64;
+    constexpr size_t LIST_B = (size_t)G * LCAP * 4 > (size_t)G * NS * 64 * 2 ? (size_t)G * LCAP * 4 : (size_t)G * NS * 64 * 2;
+    char* tab = smem;                                                            // [K][M][G] uint16
+    uint32_t* lists = reinterpret_cast<uint32_t*>(smem + (size_t)K * M * G * 2);  // [G][LCAP] (sum << 16 | position)
+    uint16_t* samp = reinterpret_cast<uint16_t*>(lists);                         // [G][NS * 64] the sample's sums (before the main pass)
+    Scan4Shared* sh = reinterpret_cast<Scan4Shared*>(reinterpret_cast<char*>(lists) + LIST_B);
+    uint16_t* thr1 = reinterpret_cast<uint16_t*>(sh + G);  // [G] collection thresholds + 1, packed like the sums
+    int* s_flag = reinterpret_cast<int*>(thr1 + 4);
+    int* s_cnt = s_flag + 1;                               // [G] list cursors (the 4-lane atomic of the main pass)
+    Slot4* sd = reinterpret_cast<Slot4*>(reinterpret_cast<char*>(thr1) + 32);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = n_slots_ptr[0];
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, LW = gridDim.x >> 3;
+    // the workgroup's k-th slot: local index li = lb + k * LW on its XCD -> run (li / 32) * 8 + xcd, place li % 32
+    auto slot_of = [&](int k) -> int {
+        const int li = lb + k * LW;
+        const int j = (((li >> 5) * 8 + xcd) << 5) | (li & 31);
+        return j < total ? j : -1;
+    };
+    const RotConsts<M> rc = make_rot<M>(lane);
+    const int nvec = (nf * K) >> 2;  // float4 per half table (<= 256 = threads)
+    const long long k0 = S3_CLK();
+    (void)k0;
+    for (int kb = 0;; kb += S4_DS) {
+        if (slot_of(kb) < 0) break;  // wave-uniform
+        __syncthreads();             // the previous round's descriptors and lists are dead
+        if (tid < S4_DS) {           // one lane per slot walks the chain slot -> items -> table descriptors
+            Slot4 d;
+            const int j = slot_of(kb + tid);
+            d.ng = 0; d.len = 0; d.start_lo = d.start_hi = 0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) { d.item[g] = 0; d.tab0[g] = 0; d.tab1[g] = 0; d.q[g] = 0; d.qinv[g] = 0.f; }
+            if (j >= 0) {
+                int idx[G];
+                int ng = 0;
+                bool same = true;
+#pragma unroll
+                for (int g = 0; g < G; ++g) idx[g] = slots[j * G + g];
+                const int64_t st0 = items[idx[0]].start;
+                const int len0 = items[idx[0]].len;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (idx[g] >= 0) ng = g + 1;
+                    else idx[g] = idx[0];
+                    const WorkItem* it = &items[idx[g]];
+                    same = same && it->start == st0 && it->len == len0;
+                    const int t0 = it->tab0, t1 = it->tab1;
+                    d.item[g] = idx[g]; d.tab0[g] = t0; d.tab1[g] = t1; d.q[g] = it->q;
+                    float mxT = fmaxf(__int_as_float(tabs[t0].pad), __int_as_float(tabs[t1].pad));
+                    mxT = fmaxf(mxT, 1e-30f);
+                    float qi = ((float)CAP / mxT) * (1.0f - 9.5367431640625e-7f);  // as scan3_group: T32 * qinv stays below cap
+                    qi = (mxT < 3.0e38f) ? qi : 0.0f;
+                    qi = (qi < 3.0e38f) ? qi : 3.0e38f;
+                    d.qinv[g] = qi;
+                }
+                d.start_lo = (int)(uint32_t)st0; d.start_hi = (int)(st0 >> 32); d.len = len0;
+                d.ng = same ? ng : -ng;
+            }
+            sd[tid] = d;
+        }
+        __syncthreads();
+        for (int kk = 0; kk < S4_DS; ++kk) {
+            const Slot4* d = &sd[kk];
+            const int ngs = __builtin_amdgcn_readfirstlane(d->ng);
+            if (ngs == 0) break;  // no more slots
+            const long long c0 = S3_CLK();
+            (void)c0;
+            const int ng = ngs < 0 ? -ngs : ngs;
+            bool fail = ngs < 0;  // items of different chunks in one slot: the streaming form runs them one by one
+            if (!fail) {
+                float qinv[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    qinv[g] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, d->qinv[g])));
+                const int len = __builtin_amdgcn_readfirstlane(d->len);
+                const int64_t start = ((int64_t)__builtin_amdgcn_readfirstlane(d->start_hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(d->start_lo);
+                // ---- tables -> 16-bit entries -> LDS (scan3_group's arithmetic) --------------------------------------------------
+                if (tid < nvec) {
+                    float4 pv[G][2];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int t0 = __builtin_amdgcn_readfirstlane(d->tab0[g]), t1 = __builtin_amdgcn_readfirstlane(d->tab1[g]);
+                        pv[g][0] = reinterpret_cast<const float4*>(T32 + (int64_t)t0 * nf * K)[tid];
+                        pv[g][1] = reinterpret_cast<const float4*>(T32 + (int64_t)t1 * nf * K)[tid];
+                    }
+                    uint32_t* tw = reinterpret_cast<uint32_t*>(tab);
+                    const int j = (4 * tid) / K, k0 = 4 * tid - j * K;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            uint32_t qv[G];
+#pragma unroll
+                            for (int g = 0; g < G; ++g) {
+                                const float4 q = pv[g][s2];
+                                const float x = c == 0 ? q.x : (c == 1 ? q.y : (c == 2 ? q.z : q.w));
+                                qv[g] = (g < ng) ? (uint32_t)(x * qinv[g]) : CAP;  // truncation: a lower bound of x * qinv
+                                qv[g] = qv[g] > CAP ? CAP : qv[g];
+                            }
+                            u32x2_t pk;
+                            pk[0] = qv[0] | (qv[1] << 16);
+                            pk[1] = qv[2] | (qv[3] << 16);
+                            *reinterpret_cast<u32x2_t*>(tw + (((k0 + c) * M + s2 * nf + j) << 1)) = pk;
+                        }
+                    }
+                }
+                if (tid >= 64 && tid < 64 + G) {
+                    const int g = tid - 64;
+                    float qi = qinv[0];
+#pragma unroll
+                    for (int gg = 1; gg < G; ++gg) qi = (g == gg) ? qinv[gg] : qi;
+                    const double inv_up = (double)qi * (1.0 + 2.384185791015625e-7);
+                    const double ub = qi > 0.0f ? (1.0 + 4.76837158203125e-7) / (double)qi : __longlong_as_double(0x7ff0000000000000LL);
+                    const int item = d->item[g];
+                    const int q = d->q[g];
+                    sh[g].inv_up = inv_up;
+                    sh[g].ub = ub;
+                    sh[g].q = q;
+                    sh[g].ext = (g < ng) ? __hip_atomic_load(&qbound[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7ff0000000000000ull;
+                    sh[g].cnt = 0;
+                    s_cnt[g] = 0;
+                    if (g < ng) {
+                        item_slack[2 * (int64_t)item + 0] = __double2float_ru(ub * ((double)M + 0.1));
+                        item_slack[2 * (int64_t)item + 1] = __double2float_ru(ub);
+                    }
+                }
+                if (tid == 0) *s_flag = 0;
+                __amdgpu_buffer_rsrc_t rs;
+                {
+                    const uint64_t cbase = (uint64_t)(uintptr_t)(codes + start * M);
+                    const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cbase);
+                    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cbase >> 32));
+                    rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)bhi << 32) | blo), 0, len * M, 0x00020000);
+                }
+                const int nrows = (len + 63) >> 6;
+                // sample rows: t * nrows / ns for t < ns = min(nrows, NS) (all rows when the chunk has <= NS of them)
+                const int ns = nrows < NS ? nrows : NS;
+                // the sample's code rows travel while the tables are staged
+                constexpr int SPW = NS / NW;  // sample rows per wave
+                static_assert(NS % (2 * NW) == 0, "sample rows come in pairs per wave");
+                CodeWords<M> sc[SPW];
+                int srow[SPW];
+#pragma unroll
+                for (int i = 0; i < SPW; ++i) {
+                    const int t = SPW * w + i;
+                    srow[i] = t < ns ? (int)(((int64_t)t * nrows) / ns) : nrows;
+                    sc[i] = load_code_buf<M>(rs, srow[i] * 64 + lane);  // rows past the chunk read zeros (masked below)
+                }
+                S3_CTR(11, S3_CLK() - c0);
+                lds_barrier();  // B1: tables and scales visible
+                S3_CTR(2, S3_CLK() - c0);
+                // ---- sample pass: wave w computes sample rows 2w, 2w+1; an absent sample leaves 0xffff -------------------------------
+                {
+                    u32x2_t dd[SPW];
+#if defined(CIS_S4_PROBE) && CIS_S4_PROBE >= 3
+                    for (int u = 0; u < SPW; ++u) { dd[u][0] = 0xffffffffu; dd[u][1] = 0xffffffffu; }  // probe: no sample pass
+#else
+                    adc16_rows<M, SPW, S4_OCT>(sc, tab, rc, dd);
+#endif
+#pragma unroll
+                    for (int u = 0; u < SPW; ++u) {
+                        const int t = SPW * w + u;
+                        const bool ok = (t < ns) && (srow[u] * 64 + lane < len);
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            const uint32_t sg = (g & 1) ? (dd[u][g >> 1] >> 16) : (dd[u][g >> 1] & 0xffffu);
+#if defined(CIS_S4_PROBE) && CIS_S4_PROBE >= 3
+                            samp[g * (NS * 64) + t * 64 + lane] = (uint16_t)0xffffu;
+#else
+                            samp[g * (NS * 64) + t * 64 + lane] = (uint16_t)(ok ? sg : 0xffffu);
+#endif
+                        }
+                    }
+                }
+                lds_barrier();  // B2
+                S3_CTR(3, S3_CLK() - c0);
+                // ---- thresholds: wave g serves query g ---------------------------------------------------------------------------------
+                {
+                    const int g = w;
+                    uint32_t sv[NS];
+                    int nsam = 0;
+#pragma unroll
+                    for (int r = 0; r < NS; ++r) {
+                        sv[r] = samp[g * (NS * 64) + r * 64 + lane];
+                        nsam += __popcll(__ballot(sv[r] != 0xffffu));
+                    }
+                    // sample rank: k - z sqrt(k) >= L * nsam / len (all rows sampled: the L-th smallest itself, exact)
+                    const bool exact = ns == nrows;
+                    int ksv = L;
+                    if (!exact) {
+                        const float need = (float)L * (float)nsam / (float)len;
+                        const float hz = 0.5f * CIS_S4_Z;
+                        const float rt = hz + sqrtf(hz * hz + need);  // root of k - z sqrt(k) = need
+                        ksv = (int)(rt * rt) + 1;
+                    }
+                    uint32_t tau = 65534u;
+                    bool have_bound = false;
+                    if (g < ng && nsam >= ksv) {  // wave-uniform
+                        uint32_t lo = 0u, hi = 65534u;
+                        while (lo < hi) {
+                            const uint32_t p = lo + ((hi - lo) >> 1);
+                            int c = 0;
+#pragma unroll
+                            for (int r = 0; r < NS; ++r) c += __popcll(__ballot(sv[r] <= p));  // (absent samples are 0xffff > p)
+                            if (c >= ksv) hi = p;
+                            else lo = p + 1;
+                        }
+                        tau = lo;
+                        have_bound = tau < 65534u;
+                    }
+                    if (lane == 0) {
+                        uint32_t keep = 65534u;
+                        if (have_bound) {
+                            keep = tau + (uint32_t)M + 1u;  // a sum brackets its distance to within M units (two-pass form above)
+                            keep = keep < 65534u ? keep : 65534u;
+                        }
+                        const uint32_t t_ext = (g < ng) ? bound_to_thr(sh[g].ext, sh[g].inv_up) : 0u;
+                        const uint32_t t = keep < t_ext ? keep : t_ext;
+                        thr1[g] = (uint16_t)((g < ng) ? t + 1u : 0u);
+#if defined(CIS_S4_PROBE) && CIS_S4_PROBE == 1
+                        thr1[g] = 0;  // probe: nothing passes
+#endif
+                        sh[g].tau = tau;
+                        // keep < t_ext: the threshold rests on the sample (exact when every row was sampled, else to be verified)
+                        sh[g].verify = (have_bound && keep < t_ext && !exact) ? 1 : 0;
+#if defined(CIS_S4_PROBE)
+                        sh[g].verify = 0;
+#endif
+                    }
+                }
+                lds_barrier();  // B3: thresholds set, the sample is dead (its memory is the lists from here on)
+                S3_CTR(4, S3_CLK() - c0);
+                // ---- main pass: every candidate once ------------------------------------------------------------------------------------
+                {
+                    const u32x2_t tpk = *reinterpret_cast<const volatile u32x2_t*>(thr1);
+                    const uint32_t s01 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tpk[0]);
+                    const uint32_t s23 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tpk[1]);
+#if defined(CIS_S4_PROBE) && CIS_S4_PROBE >= 2
+                    const int nit = 0;  // probe: no main pass
+#else
+                    const int nit = (len + 64 * U - 1) / (64 * U);
+#endif
+                    CodeWords<M> nx[U];
+                    if (w < nit) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) nx[u] = load_code_buf<M>(rs, w * 64 * U + u * 64 + lane);
+                    }
+                    for (int iter = w; iter < nit; iter += NW) {
+                        const int base = iter * 64 * U;
+                        CodeWords<M> cur[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) cur[u] = nx[u];
+                        if (iter + NW < nit) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) nx[u] = load_code_buf<M>(rs, (iter + NW) * 64 * U + u * 64 + lane);
+                        }
+                        u32x2_t dd[U];
+                        adc16_rows<M, U, S4_OCT>(cur, tab, rc, dd);
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const uint32_t xx = pk_subsat_u16(tpk[0], dd[u][0]) | pk_subsat_u16(tpk[1], dd[u][1]);
+                            unsigned long long am = __ballot(xx != 0u);
+                            const int n = len - base - u * 64;
+                            if (n < 64) am &= n <= 0 ? 0ull : ((1ull << n) - 1ull);
+                            if (am == 0ull) continue;  // scalar branch
+                            unsigned long long m[G];
+                            int mine = 0;  // lane g: the places query g needs
+#pragma unroll
+                            for (int g = 0; g < G; ++g) {
+                                const uint32_t sg = (g & 1) ? (dd[u][g >> 1] >> 16) : (dd[u][g >> 1] & 0xffffu);
+                                const uint32_t t1 = (g & 1) ? ((g >> 1) ? s23 >> 16 : s01 >> 16) : ((g >> 1) ? s23 & 0xffffu : s01 & 0xffffu);
+                                m[g] = __ballot(sg < t1) & am;
+                                mine = (lane == g) ? __popcll(m[g]) : mine;
+                            }
+                            int got = 0;
+                            if (lane < G) got = atomicAdd(&s_cnt[lane], mine);  // one LDS atomic reserves the places of all four queries
+#pragma unroll
+                            for (int g = 0; g < G; ++g) {
+                                if (m[g] == 0ull) continue;
+                                const int b0 = __builtin_amdgcn_readlane(got, g);
+                                const uint32_t sg = (g & 1) ? (dd[u][g >> 1] >> 16) : (dd[u][g >> 1] & 0xffffu);
+                                const int idx = __builtin_amdgcn_mbcnt_hi((unsigned)(m[g] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[g], b0));
+                                if (((m[g] >> lane) & 1ull) && idx < LCAP) lists[g * LCAP + idx] = (sg << 16) | (uint32_t)(base + u * 64 + lane);
+                            }
+                        }
+                    }
+                }
+                S3_CTR(12, S3_CLK() - c0);
+                lds_barrier();  // B4: lists complete
+                S3_CTR(5, S3_CLK() - c0);
+                // ---- verification + cut + write-out: wave g serves query g ------------------------------------------------------------
+                bool bad = false;
+                if (w < ng) {
+                    const int g = w;
+                    const int tot = s_cnt[g];
+                    bad = tot > LCAP;  // the list overflowed (a crowd of equal sums, or a threshold far too loose)
+                    if (!bad) {
+                        uint32_t ent[NRV];
+                        bool val[NRV];
+#pragma unroll
+                        for (int r = 0; r < NRV; ++r) {
+                            val[r] = r * 64 + lane < tot;
+                            ent[r] = val[r] ? lists[g * LCAP + r * 64 + lane] : 0xffffffffu;
+                        }
+                        const uint32_t tau = sh[g].tau;
+                        if (sh[g].verify) {
+                            int nle = 0;
+#pragma unroll
+                            for (int r = 0; r < NRV; ++r) nle += __popcll(__ballot(val[r] && (ent[r] >> 16) <= tau));
+                            bad = nle < L;
+                        }
+                        if (!bad) {
+                            uint32_t cut = 65535u;
+                            if (tot >= L) {
+                                // v = the L-th smallest collected sum = the chunk's L-th smallest (everything up to the collection
+                                // threshold is in the list); sums above v + M + 1 are strictly worse than L candidates
+                                uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+                                for (int r = 0; r < NRV; ++r) {
+                                    const uint32_t s = ent[r] >> 16;
+                                    mn = (val[r] && s < mn) ? s : mn;
+                                    mx = (val[r] && s > mx) ? s : mx;
+                                }
+                                wave_minmax_step<1>(mn, mx); wave_minmax_step<2>(mn, mx); wave_minmax_step<4>(mn, mx);
+                                wave_minmax_step<8>(mn, mx); wave_minmax_step<16>(mn, mx); wave_minmax_step<32>(mn, mx);
+                                uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)mn), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
+                                while (lo < hi) {  // wave-uniform bisection on the 16-bit value
+                                    const uint32_t p = lo + ((hi - lo) >> 1);
+                                    int c = 0;
+#pragma unroll
+                                    for (int r = 0; r < NRV; ++r) c += __popcll(__ballot(val[r] && (ent[r] >> 16) <= p));
+                                    if (c >= L) hi = p;
+                                    else lo = p + 1;
+                                }
+                                cut = lo + (uint32_t)M + 1u;
+                                const uint64_t b = val_to_bound(lo, M, sh[g].ub);  // >= L candidates of this chunk do not exceed it
+                                if (lane == 0 && b < sh[g].ext) atomicMin(&qbound[sh[g].q], (unsigned long long)b);
+                            }
+                            const int item = __builtin_amdgcn_readfirstlane(d->item[g]);
+                            uint64_t* out = item_surv + (int64_t)item * S;
+                            int kept = 0;
+#pragma unroll
+                            for (int r = 0; r < NRV; ++r) {
+                                const bool kp = val[r] && (ent[r] >> 16) <= cut;
+                                const unsigned long long mk = __ballot(kp);
+                                const int idx = kept + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
+                                if (kp) out[idx] = ((uint64_t)(ent[r] >> 16) << 32) | (ent[r] & 0xffffu);
+                                kept += __popcll(mk);
+                            }
+                            if (lane == 0) item_n[item] = kept;
+                        }
+                    }
+                    if (bad && lane == 0) *s_flag = 1;
+                }
+                lds_barrier();  // B5: the lists have been read, the verdict is in
+                S3_CTR(6, S3_CLK() - c0);
+                fail = *s_flag != 0;
+            }
+            S3_CTR(0, 1);
+            if (tid == 0) {
+                atomicAdd(&dbg[0], 1);
+                if (fail) {
+                    // the sample misjudged the chunk, a crowd of equal sums, or items of different chunks: the slot goes to the forms that
+                    // need no sample (their output replaces whatever this slot wrote)
+                    atomicAdd(&dbg[1], 1);
+                    const int f = atomicAdd(&fhdr[17], 1);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) fslots[f * G + g] = g < ng ? d->item[g] : -1;
+                }
+            }
+        }
+    }
+    S3_CTR(9, S3_CLK() - k0);
+    S3_CTR(10, 1);
+}
+
 bool scan3_supported(int M, int K, int L) {
     return (M == 4 || M == 8 || M == 16) && K <= 256 && K % 4 == 0 && L >= 1 && L <= 440;
 }
@@ -1042,9 +1540,15 @@ Scan3Geom scan3_geom(int M, int K, int L, int64_t avg_chunk, int force_two_pass)
     (void)avg_chunk;
     g.U = 4;
     // short chunks (a few thousand candidates): the two-pass form; CIS_SCAN3_TWOPASS=0/1 overrides (A/B runs)
+    // 2 = the sampled single-pass form (k_adc_scan4), 1 = the two-pass form; CIS_SCAN3_TWOPASS=0/1/2 overrides (A/B runs)
     g.two_pass = (avg_chunk > 0 && avg_chunk < 12288 && M <= 8) ? 1 : 0;
-    if (const char* e = getenv("CIS_SCAN3_TWOPASS")) g.two_pass = atoi(e) ? 1 : 0;
-    if (force_two_pass >= 0) g.two_pass = force_two_pass;  // scan modes 3 / 4 (tests)
+    // the sampled form's lists hold 376 sums per query: chunks of a few thousand candidates at limit <= 128 (a looser sample
+    // threshold overflows them and the slot is scanned again by the two-pass form)
+    if (g.two_pass == 1 && L <= 128 && avg_chunk < 6144) g.two_pass = 2;
+    if (const char* e = getenv("CIS_SCAN3_TWOPASS")) g.two_pass = atoi(e);
+    if (force_two_pass >= 0) g.two_pass = force_two_pass;  // scan modes 3 / 4 / 5 (tests)
+    if (g.two_pass == 2 && M > 8) g.two_pass = 1;
+    if (g.two_pass < 0 || g.two_pass > 2) g.two_pass = 0;
     g.S = g.NW * (NR * 64 - 8);
     g.lds = (size_t)K * M * g.G * 2 + (size_t)g.G * g.NW * (NR * 64 - 8) * 4 + g.G * sizeof(Scan3Shared) + 32 + 16;
     return g;
@@ -1053,7 +1557,7 @@ Scan3Geom scan3_geom(int M, int K, int L, int64_t avg_chunk, int force_two_pass)
 template <int M, int NR, int NW>
 static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const TabDesc* tabs,
                            const int* slots, const int* n_slots, const double* T, const float* T32, const uint8_t* codes, int K,
-                           int L, int* qctr, uint64_t* hits, int* hitn, float* slack, unsigned long long* qbound) {
+                           int L, int* qctr, uint64_t* hits, int* hitn, float* slack, unsigned long long* qbound, int* fhdr, int* fslots) {
     // waves per SIMD the kernel is compiled for (register budget): what the LDS footprint lets a CU hold anyway
     constexpr int U = 4;  // (U = 2 at 5 waves per SIMD measured slower: 0.535 against 0.497 ms on c4)
     constexpr int WPE = M == 16 ? (NW == 4 ? 3 : 2) : (NW == 4 ? 4 : (NW == 2 ? 3 : 2));
@@ -1062,14 +1566,36 @@ static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, 
     const int64_t resident = 256 * (per_cu < 1 ? 1 : per_cu);  // persistent grid: what the chip can hold
     const int64_t want = (n_items + g.G - 1) / g.G + 8;
     const unsigned grid = (unsigned)(want < resident ? ((want + 7) / 8) * 8 : resident);
+    if constexpr (M <= 8 && NW == 4) {
+        if (g.two_pass == 2) {
+            // k_adc_scan4, then the slots it could not settle (normally none) through this kernel's two-pass form: the fall-back
+            // list is a second slot header (fhdr: queue counters [0..7], queue starts [16..24] of which only [17] = count is used)
+            constexpr int WPE4 = CIS_S4_WPE;
+            const size_t lds4 = scan4_lds(M, K);
+            const int by_lds4 = (int)(163840 / lds4);
+            const int per_cu4 = by_lds4 < WPE4 ? by_lds4 : WPE4;
+            const int64_t resident4 = 256 * (per_cu4 < 1 ? 1 : per_cu4);
+            const unsigned grid4 = (unsigned)(want < resident4 ? ((want + 7) / 8) * 8 : resident4);
+            hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_U, NW, WPE4>), dim3(grid4), dim3(NW * 64), lds4, st, items, tabs, slots, n_slots, T32, codes,
+                               K, L, g.S, qctr + 9, fhdr, fslots, hits, hitn, slack, qbound);
+            if (getenv("CIS_SCAN4_DEBUG")) {  // diagnosis: how many slots the sample misjudged (blocks)
+                int h[2] = {0, 0};
+                if (hipMemcpyAsync(h, qctr + 9, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+                    fprintf(stderr, "[cis] k_adc_scan4: %d slots, %d to the fall-back list\n", h[0], h[1]);
+            }
+            hipLaunchKernelGGL((k_adc_scan3<M, NR, U, NW, WPE>), dim3(256), dim3(NW * 64), g.lds, st, items, tabs, fslots, fhdr + 8, T, T32,
+                               codes, K, L, g.S, fhdr, hits, hitn, slack, qbound, 1, 1);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_adc_scan3<M, NR, U, NW, WPE>), dim3(grid), dim3(NW * 64), g.lds, st, items, tabs, slots, n_slots, T, T32,
-                       codes, K, L, g.S, qctr, hits, hitn, slack, qbound, g.two_pass);
+                       codes, K, L, g.S, qctr, hits, hitn, slack, qbound, g.two_pass, 0);
 }
 
 void launch_scan3(int M, const Scan3Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const TabDesc* tabs,
                   const int* slots, const int* n_slots, const double* T, const float* T32, const uint8_t* codes, int K, int L,
-                  int* qctr, uint64_t* hits, int* hitn, float* slack, unsigned long long* qbound) {
-#define CIS_S3_NW(MM, RR) launch_scan3_t<MM, RR, 4>(g, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, hits, hitn, slack, qbound)
+                  int* qctr, uint64_t* hits, int* hitn, float* slack, unsigned long long* qbound, int* fhdr, int* fslots) {
+#define CIS_S3_NW(MM, RR) launch_scan3_t<MM, RR, 4>(g, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, hits, hitn, slack, qbound, fhdr, fslots)
 #define CIS_S3(MM)                   \
     do {                             \
         if (L <= 184) CIS_S3_NW(MM, 4); \

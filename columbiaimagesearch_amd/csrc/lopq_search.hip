@@ -658,7 +658,7 @@ __global__ __launch_bounds__(1024) void k_plan_scan(const PlanOut* __restrict__ 
 __global__ void k_slots_init(int* __restrict__ qctr16, int* __restrict__ cell_cnt, int ncells, int* __restrict__ slots,
                              int64_t n_slot_entries) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 16) qctr16[i] = 0;
+    if (i < 64) qctr16[i] = 0;  // queue counters, slot counts, debug counters, the fall-back header of the sampled scan
     if (i < ncells) cell_cnt[i] = 0;
     if (i < n_slot_entries) slots[i] = -1;
 }
@@ -2906,12 +2906,12 @@ extern "C" int cis_multisequence(const void* X, int x_dtype, const void* C0, con
 }
 
 extern "C" int cis_index_set_scan_mode(cis_index* ix, int mode) {
-    CIS_REQUIRE(ix != nullptr && mode >= 0 && mode <= 4, "bad scan mode");
+    CIS_REQUIRE(ix != nullptr && mode >= 0 && mode <= 5, "bad scan mode");
     ix->force_exact_scan = (mode == 1);
     ix->force_prefilter_scan = (mode >= 2);
     ix->force_scan2 = (mode == 2);
-    ix->force_scan3 = (mode == 3 || mode == 4);
-    ix->force_two_pass = mode == 3 ? 0 : (mode == 4 ? 1 : -1);
+    ix->force_scan3 = (mode == 3 || mode == 4 || mode == 5);
+    ix->force_two_pass = mode == 3 ? 0 : (mode == 4 ? 1 : (mode == 5 ? 2 : -1));
     return CIS_OK;
 }
 
@@ -4178,13 +4178,15 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             const int G = use3 ? geom3.G : geom.G;
             const int64_t nkeys = 2 * ix->ncells;
             const int64_t max_slots = sort_items ? (n_items + nkeys) / G + nkeys + 2 : n_items;
-            CIS_TRY(ix->w_order2.reserve((size_t)(32 + 2 * nkeys + max_slots * G) * sizeof(int)));
-            int* qctr = ix->w_order2.as<int>();  // [8] queue counters, [8] n_slots (first), [9] queue starts
+            CIS_TRY(ix->w_order2.reserve((size_t)(64 + 2 * nkeys + 2 * max_slots * G) * sizeof(int)));
+            int* qctr = ix->w_order2.as<int>();  // [8] queue counters, [8] n_slots (first), [9] queue starts, [32] fall-back header (scan3)
             int* n_slots = qctr + 8;
             int* qstart = qctr + 16;
-            int* cell_cnt = qctr + 32;
+            int* fhdr = qctr + 32;
+            int* cell_cnt = qctr + 64;
             int* slot_off = cell_cnt + nkeys;
             int* slots = slot_off + nkeys;
+            int* fslots = slots + max_slots * G;
             if (sort_items) {
                 const int64_t ninit = max_slots * G > nkeys ? max_slots * G : nkeys;
                 hipLaunchKernelGGL(k_slots_init, dim3((unsigned)ceil_div(ninit < 16 ? 16 : ninit, 256)), dim3(256), 0, st, qctr,
@@ -4195,14 +4197,14 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                 hipLaunchKernelGGL(k_item_scatter, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items,
                                    slot_off, cell_cnt, G, slots, (int)ix->ncells);
             } else {
-                CIS_CHECK_HIP(hipMemsetAsync(qctr, 0, 16 * sizeof(int), st));
+                CIS_CHECK_HIP(hipMemsetAsync(qctr, 0, 64 * sizeof(int), st));
                 hipLaunchKernelGGL(k_identity_slots, dim3((unsigned)ceil_div(n_items < 9 ? 9 : n_items, 256)), dim3(256), 0, st, n_items, G,
                                    slots, n_slots, qstart);
             }
             CIS_TRY(mark(5));
             ix->last_scan_kernel = use3 ? 3 : 2;
             if (use3)
-                launch_scan3(M, geom3, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, ix->w_slack.as<float>(), qbound);
+                launch_scan3(M, geom3, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, ix->w_slack.as<float>(), qbound, fhdr, fslots);
             else
                 launch_scan2(M, geom, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, qbound);
         }

@@ -234,4 +234,5 @@ Scan3Geom scan3_geom(int M, int K, int L, int64_t avg_chunk /* candidates per wo
                      int force_two_pass /* -1: by chunk length, 0: streaming form, 1: two-pass form */);
 void launch_scan3(int M, const Scan3Geom& g, int64_t n_items, hipStream_t st, const WorkItem* items, const TabDesc* tabs,
                   const int* slots, const int* n_slots, const double* T, const float* T32, const uint8_t* codes, int K, int L,
-                  int* qctr, uint64_t* hits, int* hitn, float* slack, unsigned long long* qbound);
+                  int* qctr, uint64_t* hits, int* hitn, float* slack, unsigned long long* qbound,
+                  int* fhdr /* [32] zeroed: fall-back slot header of the sampled form */, int* fslots /* [n_slots * G] */);

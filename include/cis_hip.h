@@ -235,7 +235,8 @@ int cis_index_set_profiling(cis_index* ix, int level /* 0 off, 1 only the pair o
  * (thousands of coarse clusters) take the all-candidates path instead: exact distances of every candidate, radix select;
  * exact float64 scan kernel otherwise), 1 = exact float64 scan kernel wherever it applies (limit <= 3072),
  * 2 = the float32-prefilter kernel for every batch size, 3 / 4 = the 16-bit fixed-point kernel for every batch size in its
- * streaming / two-pass (histogram threshold, then collection) form.
+ * streaming / two-pass (histogram threshold, then collection) form, 5 = the same kernel family's sampled single-pass form
+ * (threshold from a sample of the chunk, verified after the pass; what large batches over short cells take by default).
  * All routes produce identical results; the switch exists so that tests can prove it. */
 int cis_index_set_scan_mode(cis_index* ix, int mode);
 int cis_index_read_profile(cis_index* ix, double ms[5], int64_t* launches);

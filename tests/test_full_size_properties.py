@@ -94,7 +94,7 @@ def test_search_properties_at_full_size(world):
 
 def test_every_scan_route_agrees_at_full_size(world):
     """Whole 8192-query batches through every ranking route -- automatic, float32 prefilter, 16-bit fixed-point prefilter in its
-    streaming and its two-pass form, float64 scan -- bit for bit: on the 10M index (39 k-candidate cells) and on an index of its
+    streaming, its two-pass and its sampled single-pass form, float64 scan -- bit for bit: on the 10M index (39 k-candidate cells) and on an index of its
     first million vectors (3.9 k-candidate cells: the shape at which automatic routing takes the two-pass form).  A route
     that drops one candidate in twenty thousand queries shows up here (the two-pass form once did, at rank `limit`)."""
     import torch
@@ -110,7 +110,7 @@ def test_every_scan_route_agrees_at_full_size(world):
                 for limit in (LIMIT, 37, 185):
                     s.set_scan_mode(mode=1)
                     want = _np(s.search_batch_dev(q, quota=QUOTA, limit=limit))
-                    for mode in (0, 2, 3, 4):
+                    for mode in (0, 2, 3, 4, 5):
                         s.set_scan_mode(mode=mode)
                         got = _np(s.search_batch_dev(q, quota=QUOTA, limit=limit))
                         for k in ("ids", "n_found", "visited"):

@@ -18,17 +18,18 @@ _ROUTE_FREE = ("encode", "near_tie", "model_pieces", "selftest", "multisequence"
                "large_limit", "fuzz")
 
 
-@pytest.fixture(autouse=True, params=["auto", "prefilter", "scan3", "scan4"])
+@pytest.fixture(autouse=True, params=["auto", "prefilter", "scan3", "scan4", "scan5"])
 def route(request):
     """Every search test runs on the three routes of limit <= 440: "auto" (small batches -- what most fixtures are -- take
     the all-candidates path: exact distances + radix select), "prefilter" (the float32-prefilter scan kernel k_adc_scan2
     whatever the batch size), "scan3" / "scan4" (the 16-bit fixed-point kernel k_adc_scan3 whatever the batch size, in its
-    streaming and in its two-pass form: what large batches over short cells run)."""
+    streaming and in its two-pass form), "scan5" (the sampled single-pass form k_adc_scan4: what large batches over short
+    cells run)."""
     from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
     if request.param != "auto" and any(k in request.node.name for k in _ROUTE_FREE):
         pytest.skip("does not depend on the search route")
     LOPQSearcherHIP.default_prefilter_only = request.param == "prefilter"
-    LOPQSearcherHIP.default_scan_mode = {"scan3": 3, "scan4": 4}.get(request.param, 0)
+    LOPQSearcherHIP.default_scan_mode = {"scan3": 3, "scan4": 4, "scan5": 5}.get(request.param, 0)
     yield request.param
     LOPQSearcherHIP.default_prefilter_only = False
     LOPQSearcherHIP.default_scan_mode = 0
@@ -390,8 +391,8 @@ def test_many_exact_ties_fall_back_to_exact_kernel():
     b = s.search_batch(q, quota=50000, limit=100)
     np.testing.assert_array_equal(a["ids"], b["ids"])
     np.testing.assert_array_equal(a["dists"].view(np.uint64), b["dists"].view(np.uint64))
-    for mode in (3, 4):  # 16-bit fixed-point kernel: the crowd of equal sums goes through the exact compaction (4: via the two-pass
-        s.set_scan_mode(mode=mode)  # form's crowd fall-through)
+    for mode in (3, 4, 5):  # 16-bit fixed-point kernel: the crowd of equal sums goes through the exact compaction (4: via the two-pass
+        s.set_scan_mode(mode=mode)  # form's crowd fall-through; 5: the sampled form's list overflow -> two-pass -> streaming)
         for qq in (q, np.concatenate([q, X[1:8]])):  # alone in its slot, and sharing slots with other queries
             d = s.search_batch(qq, quota=50000, limit=100)
             np.testing.assert_array_equal(a["ids"][0], d["ids"][0])

@@ -67,9 +67,9 @@ def run(cases, seed0):
       limit = None if limit is None else int(limit)
       if limit is None and quota > 20000:
           limit = 100
-      mode = int(rs.choice([0, 2, 3, 4, 4]))  # automatic routing, float32-prefilter kernel, 16-bit fixed-point kernel (streaming / two-pass)
+      mode = int(rs.choice([0, 2, 3, 4, 5, 5]))  # automatic routing, float32-prefilter kernel, 16-bit fixed-point kernel (streaming / two-pass / sampled)
       if os.environ.get("FUZZ_ALL_MODES"):  # diagnosis: every route on this case
-          for md in (0, 1, 2, 3, 4):
+          for md in (0, 1, 2, 3, 4, 5):
               s.set_scan_mode(mode=md)
               rr = s.search_batch(Q, quota=quota, limit=limit)
               nbad = 0
