@@ -58,6 +58,14 @@ _PROTOS = {
     "cis_index_add_remote_counts": (c_int, [c_void_p, c_void_p]),
     "cis_index_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(c_int64)]),
     "cis_index_size": (c_int64, [c_void_p]),
+    "cis_index_add_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(c_int64), POINTER(c_int64),
+                                  c_void_p, c_void_p]),
+    "cis_l2_normalize_dev": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "cis_index_cell_counts_dev": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "cis_index_add_remote_counts_dev": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "cis_index_route_pack_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "cis_index_add_records_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int, POINTER(c_int64), POINTER(c_int64), c_void_p,
+                                          c_void_p]),
     "cis_index_get_cell": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, POINTER(c_int64)]),
     "cis_index_get_codes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "cis_index_search": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,

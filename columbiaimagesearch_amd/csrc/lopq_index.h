@@ -1,0 +1,87 @@
+// Internal view of the LOPQ index handle, shared by lopq_index.hip (storage: device-side insert) and lopq_search.hip
+// (search pipeline).
+//
+// The index lives in HBM and only there.  Inserts -- from host arrays (cis_index_add) or from device arrays
+// (cis_index_add_dev) -- are merged into the cell-contiguous arrays by kernels (lopq_index.hip); the host keeps no copy
+// of codes or ids and no (cell, id) set.
+#pragma once
+#include "lopq_model.h"
+
+// One cell-contiguous store: items of a cell in insertion order (= the reference's per-cell list order,
+// lopq/lopq/search.py:359).  Two generations of every array: a merge reads the current one and writes the other.
+struct CellStore {
+    DevBuf codes[2];  // [n][M] uint8 (not allocated for the id-only store)
+    DevBuf ids[2];    // [n] int64
+    DevBuf loff[2];   // [ncells + 1] int64
+    DevBuf cmax;      // [ncells] int64: largest id stored in the cell (-1: empty) -- an id above it cannot be a duplicate
+    int cur = 0;
+    int64_t n = 0;
+    bool with_codes = true;
+    bool init = false;
+    void release() {
+        for (int i = 0; i < 2; ++i) { codes[i].release(); ids[i].release(); loff[i].release(); }
+        cmax.release();
+    }
+};
+
+struct cis_index {
+    cis_model* m = nullptr;
+    int V = 0, M = 0;
+    int64_t ncells = 0;
+    int rank = 0, world = 1;
+    std::vector<int32_t> owner;  // empty: cell % world
+    DevBuf d_owner;              // [ncells] int32 when `owner` is set
+    // HBM-resident index of THIS shard
+    CellStore own;     // codes + ids of the cells this shard owns
+    CellStore ghost;   // ids only, cells owned by OTHER shards: exists only when a sharded index is handed every item
+                       // with dedup (cis_index_add on all ranks instead of the routed insert) -- what the duplicate
+                       // test of those cells needs
+    DevBuf d_gcount;   // [ncells] int64, all shards
+    bool had_plain_remote = false;  // items of other shards' cells were counted without (cell, id) bookkeeping
+    int64_t nb_indexed = 0;
+    // views the search pipeline reads (current generation of `own`)
+    const uint8_t* codes_ptr() const { return own.codes[own.cur].as<uint8_t>(); }
+    const int64_t* ids_ptr() const { return own.ids[own.cur].as<int64_t>(); }
+    const int64_t* loff_ptr() const { return own.loff[own.cur].as<int64_t>(); }
+    int64_t n_local = 0;
+    // insert workspace
+    DevBuf wi_key[2], wi_val[2], wi_hist, wi_sid, wi_acc, wi_apre, wi_tmp, wi_in_ids, wi_in_coarse, wi_in_fine, wi_scan;
+    DevBuf d_stats;              // statistics words of the last merge (see lopq_index.hip)
+    int64_t* h_ins = nullptr;    // pinned host copy of them
+    // per-batch workspace
+    DevBuf w_slack;  // per work item: see k_merge_survivors
+    DevBuf w_planfb, w_vis;  // k_plan_par: per-query fallback flags, visited (i, j) lists
+    DevBuf w_tiles;          // tile sums of the candidate layout
+    DevBuf w_xp, w_cd, w_order, w_sorted, w_plan, w_off, w_items, w_tabs, w_T, w_hits, w_hitn, w_part, w_q,
+        w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos, w_order2, w_px, w_T32, w_grp, w_tord;
+    int64_t stats[4] = {0, 0, 0, 0};
+    // optional stage timing (hipEvents on the launch stream)
+    bool force_exact_scan = false;  // tests: run every item through the float64 kernel
+    bool force_scan2 = false;       // scan mode 2: the float32-prefilter kernel whatever the batch size
+    bool force_scan3 = false;       // scan mode 3: the 16-bit fixed-point kernel whatever the batch size
+    int force_two_pass = -1;        // scan mode 3: k_adc_scan3's streaming form, 4: its two-pass form (-1: by chunk length)
+    int batch_hint = 0;             // sub-batch size that fitted the workspace budget after a retry (search_all)
+    int64_t batch_hint_quota = -1;
+    double retry_fraction = 0.5;
+    int last_scan_kernel = 0;       // 0 none (all-candidates path), 1 float64 scan, 2 float32 prefilter, 3 16-bit fixed-point prefilter
+    bool force_prefilter_scan = false;  // tests: the float32-prefilter kernel also for small batches
+    int profiling = 0;  // 0 off, 1 events around the scan kernel only, 2 events around every stage
+    int64_t* h_totals = nullptr;    // pinned, device-mapped: the plan totals land here without a copy
+    int64_t* d_h_totals = nullptr;
+    int64_t plan_seq = 0;           // sequence number of the last plan whose totals were requested
+    int64_t stats_pending_seq = 0;  // != 0: the last batch did not read its totals back; last_stats waits for this plan
+    int64_t n_total = 0, max_cell = 0, nonempty_cells = 0;  // over all shards (gcount): bounds for such batches
+    struct ProfRec { hipEvent_t ev[6]; bool has_scan; };  // ev[5]: just before the scan kernel (after slot building)
+    std::vector<ProfRec> prof;
+    double prof_ms[5] = {0, 0, 0, 0, 0};
+    int64_t prof_launches = 0;
+
+    bool owns(int64_t cell) const {
+        if (world <= 1) return true;
+        if (!owner.empty()) return owner[cell] == rank;
+        return (int)(cell % world) == rank;
+    }
+};
+
+// Makes the device arrays exist (empty index: offsets all zero) -- called at the head of every search.
+int cis_index_ready(cis_index* ix);

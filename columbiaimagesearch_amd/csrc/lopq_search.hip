@@ -17,9 +17,8 @@
 //   top-k -> per-query merge -> ids/dists.
 #include <chrono>
 #include <algorithm>
-#include <unordered_set>
 
-#include "lopq_model.h"
+#include "lopq_index.h"
 #include "scan_common.h"
 
 // ================================================================================================
@@ -2499,285 +2498,8 @@ __global__ void k_copy_visited(const PlanOut* __restrict__ plan, int nq, int32_t
 }
 
 // ================================================================================================
-// host: index object
+// host: index object -- storage, insert and the get_cell / get_codes readers are in lopq_index.hip
 // ================================================================================================
-struct PairHash {
-    size_t operator()(const std::pair<int64_t, int64_t>& p) const {
-        uint64_t x = (uint64_t)p.first * 0x9E3779B97F4A7C15ull ^ ((uint64_t)p.second + 0x7F4A7C15ull);
-        x ^= x >> 31;
-        x *= 0xBF58476D1CE4E5B9ull;
-        x ^= x >> 29;
-        return (size_t)x;
-    }
-};
-
-struct cis_index {
-    cis_model* m = nullptr;
-    int V = 0, M = 0;
-    int64_t ncells = 0;
-    int rank = 0, world = 1;
-    std::vector<int32_t> owner;  // empty: cell % world
-    // host storage of THIS shard: CSR + pending appends (arrival order)
-    std::vector<int64_t> csr_off;  // [ncells+1]
-    std::vector<int64_t> csr_ids;
-    std::vector<uint8_t> csr_fine;
-    std::vector<int64_t> pend_ids;
-    std::vector<int64_t> pend_cell;
-    std::vector<uint8_t> pend_fine;
-    std::vector<int64_t> gcount;  // [ncells] all shards
-    std::unordered_set<std::pair<int64_t, int64_t>, PairHash> seen;  // (cell, id) of every dedup add
-    bool had_plain_add = false;  // items were added without (cell, id) bookkeeping
-    int64_t nb_indexed = 0;
-    bool dirty = true;
-    // device copy
-    DevBuf d_codes, d_ids, d_loff, d_gcount;
-    int64_t n_local = 0;
-    // per-batch workspace
-    DevBuf w_slack;  // per work item: see k_merge_survivors
-    DevBuf w_planfb, w_vis;  // k_plan_par: per-query fallback flags, visited (i, j) lists
-    DevBuf w_tiles;          // tile sums of the candidate layout
-    DevBuf w_xp, w_cd, w_order, w_sorted, w_plan, w_off, w_items, w_tabs, w_T, w_hits, w_hitn, w_part, w_q,
-        w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos, w_order2, w_px, w_T32, w_grp, w_tord;
-    int64_t stats[4] = {0, 0, 0, 0};
-    // optional stage timing (hipEvents on the launch stream)
-    bool force_exact_scan = false;  // tests: run every item through the float64 kernel
-    bool force_scan2 = false;       // scan mode 2: the float32-prefilter kernel whatever the batch size
-    bool force_scan3 = false;       // scan mode 3: the 16-bit fixed-point kernel whatever the batch size
-    int force_two_pass = -1;        // scan mode 3: k_adc_scan3's streaming form, 4: its two-pass form (-1: by chunk length)
-    int batch_hint = 0;             // sub-batch size that fitted the workspace budget after a retry (search_all)
-    int64_t batch_hint_quota = -1;
-    double retry_fraction = 0.5;
-    int last_scan_kernel = 0;       // 0 none (all-candidates path), 1 float64 scan, 2 float32 prefilter, 3 16-bit fixed-point prefilter
-    bool force_prefilter_scan = false;  // tests: the float32-prefilter kernel also for small batches
-    int profiling = 0;  // 0 off, 1 events around the scan kernel only, 2 events around every stage
-    int64_t* h_totals = nullptr;    // pinned, device-mapped: the plan totals land here without a copy
-    int64_t* d_h_totals = nullptr;
-    int64_t plan_seq = 0;           // sequence number of the last plan whose totals were requested
-    int64_t stats_pending_seq = 0;  // != 0: the last batch did not read its totals back; last_stats waits for this plan
-    int64_t n_total = 0, max_cell = 0, nonempty_cells = 0;  // over all shards (gcount): bounds for such batches
-    struct ProfRec { hipEvent_t ev[6]; bool has_scan; };  // ev[5]: just before the scan kernel (after slot building)
-    std::vector<ProfRec> prof;
-    double prof_ms[5] = {0, 0, 0, 0, 0};
-    int64_t prof_launches = 0;
-
-    bool owns(int64_t cell) const {
-        if (world <= 1) return true;
-        if (!owner.empty()) return owner[cell] == rank;
-        return (int)(cell % world) == rank;
-    }
-};
-
-extern "C" int cis_index_create(cis_index** out, cis_model* m) {
-    CIS_REQUIRE(out != nullptr, "out is NULL");
-    *out = nullptr;
-    CIS_REQUIRE(m != nullptr, "model is NULL");
-    cis_index* ix = new cis_index();
-    ix->m = m;
-    ix->V = m->V;
-    ix->M = m->M;
-    ix->ncells = (int64_t)m->V * m->V;
-    ix->csr_off.assign(ix->ncells + 1, 0);
-    ix->gcount.assign(ix->ncells, 0);
-    *out = ix;
-    return CIS_OK;
-}
-
-extern "C" void cis_index_destroy(cis_index* ix) {
-    if (!ix) return;
-    if (ix->m) (void)hipSetDevice(ix->m->device);
-    DevBuf* bufs[] = {&ix->d_codes, &ix->d_ids, &ix->d_loff, &ix->d_gcount, &ix->w_xp, &ix->w_cd, &ix->w_order,
-                      &ix->w_sorted, &ix->w_plan, &ix->w_off, &ix->w_items, &ix->w_tabs, &ix->w_T, &ix->w_hits,
-                      &ix->w_hitn, &ix->w_slack, &ix->w_planfb, &ix->w_vis, &ix->w_tiles, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
-                      &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px, &ix->w_T32, &ix->w_grp, &ix->w_tord};
-    for (DevBuf* b : bufs) b->release();
-    if (ix->h_totals) (void)hipHostFree(ix->h_totals);
-    delete ix;
-}
-
-extern "C" int cis_index_set_shard(cis_index* ix, int rank, int world, const int32_t* owner) {
-    CIS_REQUIRE(ix != nullptr, "index is NULL");
-    CIS_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad shard %d of %d", rank, world);
-    CIS_REQUIRE(ix->nb_indexed == 0, "set_shard must be called on an empty index");
-    ix->rank = rank;
-    ix->world = world;
-    ix->owner.clear();
-    if (owner) {
-        ix->owner.assign(owner, owner + ix->ncells);
-        for (int64_t c = 0; c < ix->ncells; ++c)
-            CIS_REQUIRE(owner[c] >= 0 && owner[c] < world, "owner[%lld]=%d out of range", (long long)c, owner[c]);
-    }
-    return CIS_OK;
-}
-
-extern "C" int64_t cis_index_size(cis_index* ix) { return ix ? ix->nb_indexed : 0; }
-
-extern "C" int cis_index_add(cis_index* ix, const int64_t* ids, const uint16_t* coarse, const uint8_t* fine,
-                             int64_t n, int dedup, int64_t* n_added) {
-    CIS_REQUIRE(ix != nullptr, "index is NULL");
-    CIS_REQUIRE(n >= 0 && (n == 0 || (ids && coarse && fine)), "NULL buffer");
-    const int V = ix->V, M = ix->M, K = ix->m->K;
-    for (int64_t i = 0; i < n; ++i)
-        CIS_REQUIRE(coarse[2 * i] < V && coarse[2 * i + 1] < V, "item %lld: coarse code out of range (V=%d)",
-                    (long long)i, V);
-    if (K < 256)
-        for (int64_t i = 0; i < n * M; ++i)
-            CIS_REQUIRE(fine[i] < K, "fine code %d out of range (K=%d)", (int)fine[i], K);
-    if (dedup && ix->had_plain_add) {
-        cis_set_error("dedup add after plain (dedup=0) adds on the same index is not supported");
-        return CIS_EUNSUPPORTED;
-    }
-    int64_t added = 0;
-    try {
-        for (int64_t i = 0; i < n; ++i) {
-            const int64_t cell = (int64_t)coarse[2 * i] * V + coarse[2 * i + 1];
-            if (dedup) {
-                if (!ix->seen.insert(std::make_pair(cell, ids[i])).second) continue;
-            }
-            ix->gcount[cell] += 1;
-            ++added;
-            if (ix->owns(cell)) {
-                ix->pend_ids.push_back(ids[i]);
-                ix->pend_cell.push_back(cell);
-                ix->pend_fine.insert(ix->pend_fine.end(), fine + i * M, fine + (i + 1) * M);
-            }
-        }
-    } catch (const std::bad_alloc&) {
-        cis_set_error("out of host memory while adding codes");
-        return CIS_ENOMEM;
-    }
-    if (!dedup && n > 0) ix->had_plain_add = true;
-    ix->nb_indexed += added;
-    if (added) ix->dirty = true;
-    if (n_added) *n_added = added;
-    return CIS_OK;
-}
-
-// Cell-sharded insert with routed codes (columbiaimagesearch_amd/distributed.py:add_codes_routed): a rank is handed only
-// the codes of the cells it owns; the sizes of the other cells -- which drive the quota cut of every query on every
-// rank (search.py:128-133) -- arrive as per-cell increments summed over the owners.
-extern "C" int cis_index_cell_counts(cis_index* ix, int64_t* counts) {
-    CIS_REQUIRE(ix != nullptr && counts != nullptr, "NULL argument");
-    for (int64_t c = 0; c < ix->ncells; ++c) counts[c] = ix->gcount[c];
-    return CIS_OK;
-}
-
-extern "C" int cis_index_add_remote_counts(cis_index* ix, const int64_t* delta) {
-    CIS_REQUIRE(ix != nullptr && delta != nullptr, "NULL argument");
-    int64_t added = 0;
-    for (int64_t c = 0; c < ix->ncells; ++c) {
-        CIS_REQUIRE(delta[c] >= 0, "negative count for cell %lld", (long long)c);
-        if (ix->owns(c) || delta[c] == 0) continue;
-        ix->gcount[c] += delta[c];
-        added += delta[c];
-    }
-    ix->nb_indexed += added;
-    if (added) ix->dirty = true;
-    return CIS_OK;
-}
-
-// merge pending appends into the host CSR (stable: old items of a cell first, then new ones in
-// arrival order) and refresh the device copy
-static int index_sync(cis_index* ix) {
-    if (!ix->dirty) return CIS_OK;
-    CIS_TRY(cis_lazy_init());
-    CIS_CHECK_HIP(hipSetDevice(ix->m->device));
-    const int M = ix->M;
-    const int64_t nc = ix->ncells;
-    const int64_t np = (int64_t)ix->pend_ids.size();
-    try {
-        if (np > 0) {
-            std::vector<int64_t> add(nc + 1, 0);
-            for (int64_t i = 0; i < np; ++i) add[ix->pend_cell[i] + 1] += 1;
-            std::vector<int64_t> noff(nc + 1, 0);
-            for (int64_t c = 0; c < nc; ++c) noff[c + 1] = noff[c] + (ix->csr_off[c + 1] - ix->csr_off[c]) + add[c + 1];
-            const int64_t ntot = noff[nc];
-            std::vector<int64_t> nids((size_t)ntot);
-            std::vector<uint8_t> nfine((size_t)ntot * M);
-            std::vector<int64_t> cur(nc);
-            for (int64_t c = 0; c < nc; ++c) {
-                const int64_t a = ix->csr_off[c], b = ix->csr_off[c + 1];
-                if (b > a) {
-                    memcpy(&nids[noff[c]], &ix->csr_ids[a], (size_t)(b - a) * sizeof(int64_t));
-                    memcpy(&nfine[(size_t)noff[c] * M], &ix->csr_fine[(size_t)a * M], (size_t)(b - a) * M);
-                }
-                cur[c] = noff[c] + (b - a);
-            }
-            for (int64_t i = 0; i < np; ++i) {
-                const int64_t p = cur[ix->pend_cell[i]]++;
-                nids[p] = ix->pend_ids[i];
-                memcpy(&nfine[(size_t)p * M], &ix->pend_fine[(size_t)i * M], M);
-            }
-            ix->csr_off.swap(noff);
-            ix->csr_ids.swap(nids);
-            ix->csr_fine.swap(nfine);
-            std::vector<int64_t>().swap(ix->pend_ids);
-            std::vector<int64_t>().swap(ix->pend_cell);
-            std::vector<uint8_t>().swap(ix->pend_fine);
-        }
-    } catch (const std::bad_alloc&) {
-        cis_set_error("out of host memory while building the cell index");
-        return CIS_ENOMEM;
-    }
-    const int64_t nl = ix->csr_off[nc];
-    ix->n_local = nl;
-    CIS_TRY(ix->d_codes.reserve((size_t)(nl > 0 ? nl : 1) * M + 64));
-    CIS_TRY(ix->d_ids.reserve((size_t)(nl > 0 ? nl : 1) * sizeof(int64_t)));
-    CIS_TRY(ix->d_loff.reserve((size_t)(nc + 1) * sizeof(int64_t)));
-    CIS_TRY(ix->d_gcount.reserve((size_t)nc * sizeof(int64_t)));
-    if (nl > 0) {
-        CIS_CHECK_HIP(hipMemcpy(ix->d_codes.p, ix->csr_fine.data(), (size_t)nl * M, hipMemcpyHostToDevice));
-        CIS_CHECK_HIP(hipMemcpy(ix->d_ids.p, ix->csr_ids.data(), (size_t)nl * sizeof(int64_t), hipMemcpyHostToDevice));
-    }
-    CIS_CHECK_HIP(hipMemcpy(ix->d_loff.p, ix->csr_off.data(), (size_t)(nc + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    CIS_CHECK_HIP(hipMemcpy(ix->d_gcount.p, ix->gcount.data(), (size_t)nc * sizeof(int64_t), hipMemcpyHostToDevice));
-    ix->n_total = 0; ix->max_cell = 0; ix->nonempty_cells = 0;
-    for (int64_t c = 0; c < nc; ++c) {
-        const int64_t g = ix->gcount[c];
-        ix->n_total += g;
-        ix->max_cell = g > ix->max_cell ? g : ix->max_cell;
-        ix->nonempty_cells += g > 0;
-    }
-    ix->dirty = false;
-    return CIS_OK;
-}
-
-extern "C" int cis_index_get_cell(cis_index* ix, int c0, int c1, int64_t cap, int64_t* ids, uint8_t* fine, int64_t* n) {
-    CIS_REQUIRE(ix != nullptr && n != nullptr, "NULL argument");
-    CIS_REQUIRE(c0 >= 0 && c0 < ix->V && c1 >= 0 && c1 < ix->V, "cell (%d,%d) out of range", c0, c1);
-    const int64_t cell = (int64_t)c0 * ix->V + c1;
-    *n = ix->gcount[cell];
-    if (cap <= 0 || !ix->owns(cell)) return CIS_OK;
-    // host-only merge is enough here; the device copy is refreshed by the next search
-    const int M = ix->M;
-    std::vector<int64_t> tmp_ids;
-    std::vector<uint8_t> tmp_fine;
-    const int64_t a = ix->csr_off[cell], b = ix->csr_off[cell + 1];
-    int64_t k = 0;
-    for (int64_t p = a; p < b && k < cap; ++p, ++k) {
-        if (ids) ids[k] = ix->csr_ids[p];
-        if (fine) memcpy(fine + k * M, &ix->csr_fine[(size_t)p * M], M);
-    }
-    for (size_t i = 0; i < ix->pend_ids.size() && k < cap; ++i) {
-        if (ix->pend_cell[i] != cell) continue;
-        if (ids) ids[k] = ix->pend_ids[i];
-        if (fine) memcpy(fine + k * M, &ix->pend_fine[i * M], M);
-        ++k;
-    }
-    return CIS_OK;
-}
-
-extern "C" int cis_index_get_codes(cis_index* ix, const int32_t* cells, const uint32_t* pos, int64_t n, uint8_t* fine) {
-    CIS_REQUIRE(ix != nullptr && (n == 0 || (cells && pos && fine)), "NULL argument");
-    CIS_REQUIRE(ix->pend_ids.empty(), "index has unsynchronised adds; search first");
-    const int M = ix->M;
-    for (int64_t i = 0; i < n; ++i) {
-        CIS_REQUIRE(cells[i] >= 0 && cells[i] < ix->ncells, "cell %d out of range", cells[i]);
-        const int64_t a = ix->csr_off[cells[i]], b = ix->csr_off[cells[i] + 1];
-        CIS_REQUIRE((int64_t)pos[i] < b - a, "item (%d, %u) is not stored on this shard", cells[i], pos[i]);
-        memcpy(fine + i * M, &ix->csr_fine[(size_t)(a + pos[i]) * M], M);
-    }
-    return CIS_OK;
-}
 
 extern "C" int cis_index_set_profiling(cis_index* ix, int enable) {
     CIS_REQUIRE(ix != nullptr, "index is NULL");
@@ -3905,10 +3627,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                                ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
         if (par_plan)
             hipLaunchKernelGGL((k_plan_par<float, false>), dim3(nq), dim3(256), (size_t)2 * V * sizeof(float), st, ix->w_sorted.as<float>(), ix->w_order.as<uint16_t>(),
-                               ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
+                               ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
                                nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap);
         hipLaunchKernelGGL((k_plan<float, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<float>(),
-                           ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
+                           ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota,
                            seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr, plan_fb);
     } else {
         if (V > 256 && Vp2 <= 4096)
@@ -3919,10 +3641,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                                V, ix->w_order.as<uint16_t>(), ix->w_sorted.as<double>(), grp_cnt);
         if (par_plan)
             hipLaunchKernelGGL((k_plan_par<double, false>), dim3(nq), dim3(256), (size_t)2 * V * sizeof(double), st, ix->w_sorted.as<double>(), ix->w_order.as<uint16_t>(),
-                               ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
+                               ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
                                nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap);
         hipLaunchKernelGGL((k_plan<double, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
-                           ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
+                           ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota,
                            seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr, plan_fb);
     }
     if (par_plan && getenv("CIS_DEBUG_PLAN")) {
@@ -4038,10 +3760,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     if (ct == CIS_F32) {
         if (par_plan)
             hipLaunchKernelGGL((k_plan_par<float, true>), dim3(nq), dim3(256), 0, st, ix->w_sorted.as<float>(), ix->w_order.as<uint16_t>(),
-                               ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota, seg_max, plan, item_off, tab_off, items,
+                               ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota, seg_max, plan, item_off, tab_off, items,
                                tabs, nullptr, grp_base, grp_cur, tab_order, vis_list, plan_fb, vis_cap);
         hipLaunchKernelGGL((k_plan<float, true>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<float>(),
-                           ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
+                           ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota,
                            seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order, plan_fb);
         if (n_tabs > 0)
             launch_tables<float>(n_tabs, tab_lds, st, (const float*)xc, m->d_Cs32, m->d_Rt, m->d_mus, m->d_subs, tabs, tab_order, V, h,
@@ -4049,10 +3771,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     } else {
         if (par_plan)
             hipLaunchKernelGGL((k_plan_par<double, true>), dim3(nq), dim3(256), 0, st, ix->w_sorted.as<double>(), ix->w_order.as<uint16_t>(),
-                               ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota, seg_max, plan, item_off, tab_off, items,
+                               ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota, seg_max, plan, item_off, tab_off, items,
                                tabs, nullptr, grp_base, grp_cur, tab_order, vis_list, plan_fb, vis_cap);
         hipLaunchKernelGGL((k_plan<double, true>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
-                           ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->d_loff.as<int64_t>(), nq, V, quota,
+                           ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota,
                            seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order, plan_fb);
         if (n_tabs > 0)
             launch_tables<double>(n_tabs, tab_lds, st, (const double*)xc, m->d_Cs64, m->d_Rt, m->d_mus, m->d_subs, tabs, tab_order, V,
@@ -4079,8 +3801,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         CIS_TRY(mark(2));
         const int64_t n_cand = n_cand_all;
         CIS_REQUIRE(n_cand < ((int64_t)1 << 32), "query batch too large for the sorted path");
-        const uint8_t* codes = ix->d_codes.as<uint8_t>();
-        const int64_t* ids = ix->d_ids.as<int64_t>();
+        const uint8_t* codes = ix->codes_ptr();
+        const int64_t* ids = ix->ids_ptr();
         const SelectPlan sp = select_plan(L, nq, n_cand);
         const int64_t n_sel = sp.select ? (int64_t)nq * sp.stride : 0;
         size_t sort_tmp = 0;
@@ -4168,8 +3890,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     CIS_TRY(mark(2));
     if (n_items > 0) {
         pr.has_scan = true;
-        const uint8_t* codes = ix->d_codes.as<uint8_t>();
-        const int64_t* ids = ix->d_ids.as<int64_t>();
+        const uint8_t* codes = ix->codes_ptr();
+        const int64_t* ids = ix->ids_ptr();
         cis_hit* hits = ix->w_hits.as<cis_hit>();
         int* hitn = ix->w_hitn.as<int>();
         if (fast) {
@@ -4223,8 +3945,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (fast) {
             // survivors of the float32 scan: exact re-scoring + ranking (limit <= 440 here)
             const uint64_t* surv = ix->w_hits.as<uint64_t>();
-            const uint8_t* codes = ix->d_codes.as<uint8_t>();
-            const int64_t* ids = ix->d_ids.as<int64_t>();
+            const uint8_t* codes = ix->codes_ptr();
+            const int64_t* ids = ix->ids_ptr();
             // several lists per query (short cells): the variant whose fast path holds 512 survivors per query
             const bool many = n_items > nq + nq / 4;
 #define CIS_MERGE_SURV(CAP, MT)                                                                                              \
@@ -4284,7 +4006,7 @@ static int search_all(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_
     CIS_REQUIRE(ix != nullptr, "index is NULL");
     CIS_REQUIRE(q_dtype == CIS_F32 || q_dtype == CIS_F64, "q_dtype must be 4 or 8");
     CIS_REQUIRE(nq >= 0, "nq must be >= 0");
-    CIS_TRY(index_sync(ix));
+    CIS_TRY(cis_index_ready(ix));
     CIS_CHECK_HIP(hipSetDevice(ix->m->device));
     for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
     ix->stats_pending_seq = 0;

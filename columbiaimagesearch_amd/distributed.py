@@ -120,7 +120,7 @@ def merge_packed_sorted(parts, off, cnt, nq, L):
     return out
 
 
-def route_codes(coarse, fine, ids, owner, V, group=None):
+def route_codes(coarse, fine, ids, owner, V, group=None, M=None):
     """All-to-all routing of freshly encoded codes to the ranks that own their cells.
     coarse [n,2] uint16, fine [n,M] uint8, ids [n] int64: THIS rank's slice of the batch (host arrays).  Returns the
     (coarse, fine, ids) this rank owns, ordered by source rank and, inside a source, in the source's order -- i.e. in
@@ -133,7 +133,10 @@ def route_codes(coarse, fine, ids, owner, V, group=None):
     coarse = np.ascontiguousarray(np.asarray(coarse).reshape(-1, 2), dtype=np.uint16)
     n = coarse.shape[0]
     fine = np.asarray(fine)
-    M = int(fine.shape[-1]) if fine.ndim == 2 else (fine.size // n if n else 0)
+    if M is None:  # the record width must be the same on every rank: callers with possibly empty slices pass the model's M
+        M = int(fine.shape[-1]) if fine.ndim == 2 else (fine.size // n if n else 0)
+    if fine.size != n * M:
+        raise ValueError("fine must hold %d x %d codes" % (n, M))
     fine = np.ascontiguousarray(fine.reshape(n, M), dtype=np.uint8)
     ids = np.ascontiguousarray(ids, dtype=np.int64)
     rec = np.zeros((n, 12 + M), dtype=np.uint8)
@@ -185,7 +188,7 @@ class ShardedSearcher(object):
         L = _lib.lib()
         V = self.local.model.V
         owner = self._owner if self._owner is not None else np.arange(V * V) % self.world
-        c, f, i = route_codes(coarse, fine, ids, owner, V, self.group)
+        c, f, i = route_codes(coarse, fine, ids, owner, V, self.group, M=self.local._M)
         before = np.zeros(V * V, dtype=np.int64)
         _lib.check(L.cis_index_cell_counts(self.local._ix, _lib.ptr(before)))
         added = self.local.add_codes_array(c, f, i, dedup) if c.shape[0] else 0
@@ -198,6 +201,65 @@ class ShardedSearcher(object):
         _lib.check(L.cis_index_add_remote_counts(self.local._ix, _lib.ptr(delta)))
         self.local.nb_indexed = int(L.cis_index_size(self.local._ix))
         return added
+
+    def add_codes_routed_dev(self, coarse, fine, ids, dedup=True):
+        """add_codes_routed on tensors in HBM (this rank's freshly encoded slice: coarse [n,2] 16-bit, fine [n,M] uint8,
+        ids [n] int64).  The records are grouped by owner on the device (cis_index_route_pack_dev), travel once in ONE
+        all-to-all of device buffers (RCCL over xGMI; only the world split sizes are read by the host, which the collective's
+        interface needs), are merged into the owner's HBM index by kernels (cis_index_add_records_dev), and the per-cell
+        accepted counts are all-reduced on the device.  Returns the number of items this rank accepted."""
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        L = _lib.lib()
+        ix = self.local._ix
+        M, V = self.local._M, self.local.model.V
+        n = int(coarse.shape[0])
+        if tuple(fine.shape) != (n, M) or tuple(ids.shape) != (n,) or tuple(coarse.shape) != (n, 2):
+            raise ValueError("coarse [n,2], fine [n,%d] and ids [n] expected" % M)
+        dev = coarse.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rec_b = 12 + M
+        send = torch.empty(max(n, 1) * rec_b, dtype=torch.uint8, device=dev)
+        sc = torch.empty(self.world, dtype=torch.int64, device=dev)
+        _lib.check(L.cis_index_route_pack_dev(ix, ids.data_ptr(), coarse.data_ptr(), fine.data_ptr(), n, send.data_ptr(),
+                                              sc.data_ptr(), stream))
+        staged = dist.get_backend(self.group) != "nccl"  # gloo has no all-to-all on device buffers: stage the collectives
+        rc = torch.empty_like(sc)
+        if staged:
+            sc_h = sc.cpu()
+            rc_h = torch.empty_like(sc_h)
+            dist.all_to_all_single(rc_h, sc_h, group=self.group)
+        else:
+            dist.all_to_all_single(rc, sc, group=self.group)
+            sc_h, rc_h = sc.cpu(), rc.cpu()
+        in_split = [int(c) * rec_b for c in sc_h.tolist()]
+        out_split = [int(c) * rec_b for c in rc_h.tolist()]
+        n_recv = sum(out_split) // rec_b
+        recv = torch.empty(max(n_recv, 1) * rec_b, dtype=torch.uint8, device=dev)
+        if staged:
+            recv_h = torch.empty(n_recv * rec_b, dtype=torch.uint8)
+            dist.all_to_all_single(recv_h, send[:n * rec_b].cpu(), output_split_sizes=out_split, input_split_sizes=in_split,
+                                   group=self.group)
+            recv[:n_recv * rec_b].copy_(recv_h)
+        else:
+            dist.all_to_all_single(recv[:n_recv * rec_b], send[:n * rec_b], output_split_sizes=out_split,
+                                   input_split_sizes=in_split, group=self.group)
+        delta = torch.empty(V * V, dtype=torch.int64, device=dev)
+        added, bad = _lib.c_int64(0), _lib.c_int64(0)
+        _lib.check(L.cis_index_add_records_dev(ix, recv.data_ptr(), n_recv, 1 if dedup else 0, _lib.ctypes.byref(added),
+                                               _lib.ctypes.byref(bad), delta.data_ptr(), stream))
+        if staged:
+            d_h = delta.cpu()
+            dist.all_reduce(d_h, group=self.group)
+            delta.copy_(d_h)
+        else:
+            dist.all_reduce(delta, group=self.group)
+        _lib.check(L.cis_index_add_remote_counts_dev(ix, delta.data_ptr(), stream))
+        self.local.nb_indexed = int(L.cis_index_size(ix))
+        if bad.value:
+            print("Could not push {} codes (out of range for this model, or negative ids).".format(bad.value))
+        return int(added.value)
 
     def get_nb_indexed(self):
         return self.local.get_nb_indexed()

@@ -5,8 +5,8 @@ Counterpart of the per-image chain of the reference, with the same per-element s
   L2 normalisation     cufacesearch/cufacesearch/featurizer/featsio.py:13-22 (feat / np.linalg.norm(feat), in the feature dtype)
   compute_codes        cufacesearch/cufacesearch/searcher/searcher_lopqhbase.py:482-524 (model.predict per feature)
   add_codes_from_dict  lopq/lopq/search.py:275-283
-Only the (coarse, fine) codes -- 4 + M bytes per descriptor -- leave the GPU; images come in as preprocessed batches
-(decoding / resizing stays host code).
+Nothing leaves the GPU: the codes are merged into the HBM-resident index by kernels (csrc/lopq_index.hip); images come in
+as preprocessed batches (decoding / resizing stays host code).
 """
 import numpy as np
 
@@ -14,10 +14,17 @@ from . import _lib
 
 
 def l2_normalize_dev(feats):
-    """Row-wise feat / ||feat|| in the tensor's dtype (zero rows stay zero: the reference would emit NaNs for them)."""
+    """Row-wise feat / ||feat|| in the tensor's dtype, in place on a contiguous tensor (cis_l2_normalize_dev: one wave per
+    row; zero rows stay zero: the reference would emit NaNs for them).  Returns the tensor."""
     import torch
-    nrm = torch.linalg.vector_norm(feats, dim=1, keepdim=True)
-    return feats / torch.where(nrm > 0, nrm, torch.ones_like(nrm))
+    if not (feats.is_cuda and feats.dim() == 2 and feats.dtype in (torch.float32, torch.float64)):
+        raise ValueError("feats must be a float32 / float64 [n, d] tensor on the GPU")
+    if not feats.is_contiguous():
+        feats = feats.contiguous()
+    _lib.check(_lib.lib().cis_l2_normalize_dev(feats.data_ptr(), _lib.CIS_F32 if feats.dtype == torch.float32 else _lib.CIS_F64,
+                                               int(feats.shape[0]), int(feats.shape[1]),
+                                               torch.cuda.current_stream(feats.device).cuda_stream))
+    return feats
 
 
 class BatchIngest(object):
@@ -37,11 +44,19 @@ class BatchIngest(object):
         return self.model.predict_batch_dev(l2_normalize_dev(feats).contiguous())
 
     def ingest_batch(self, x, ids=None):
-        """Encode one batch and insert it; ids default to consecutive integers.  Returns the number of new items."""
+        """Encode one batch and insert it; ids default to consecutive integers.  Returns the number of new items.
+        Codes and ids stay in HBM: the insert is the device-side merge of csrc/lopq_index.hip (through the all-to-all of
+        distributed.ShardedSearcher.add_codes_routed_dev when the searcher is sharded)."""
+        import torch
         coarse, fine = self.encode_batch_dev(x)
         n = int(coarse.shape[0])
         if ids is None:
-            ids = np.arange(self.nb_ingested, self.nb_ingested + n, dtype=np.int64)
-        added = self.searcher.add_codes_array(coarse.cpu().numpy().view(np.uint16), fine.cpu().numpy(), ids)
+            ids = torch.arange(self.nb_ingested, self.nb_ingested + n, dtype=torch.int64, device=coarse.device)
+        elif not hasattr(ids, "is_cuda"):
+            ids = torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int64)).to(coarse.device)
+        if hasattr(self.searcher, "add_codes_routed_dev"):
+            added = self.searcher.add_codes_routed_dev(coarse, fine, ids)
+        else:
+            added = self.searcher.add_codes_dev(coarse, fine, ids)[0]
         self.nb_ingested += n
         return added

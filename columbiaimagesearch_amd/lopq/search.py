@@ -195,6 +195,31 @@ class LOPQSearcherHIP(LOPQSearcherBase):
         self.nb_indexed = int(_lib.lib().cis_index_size(self._ix))
         return int(added.value)
 
+    def add_codes_dev(self, coarse, fine, ids, dedup=True, cell_delta=None):
+        """add_codes_array on tensors that are already in HBM (what predict_batch_dev returned): coarse [n,2] int16/uint16
+        bits, fine [n,M] uint8, ids [n] int64 >= 0.  The insert is a stable merge by kernels on the current stream
+        (csrc/lopq_index.hip); nothing travels through the host but the accepted count.  Returns (added, skipped):
+        items with out-of-range codes or negative ids are skipped and counted ("Could not push code", :365-367).
+        cell_delta: optional int64 [V*V] tensor that receives the per-cell accepted counts of this call."""
+        import torch
+        n = int(coarse.shape[0])
+        if not (coarse.is_cuda and fine.is_cuda and ids.is_cuda and coarse.is_contiguous() and fine.is_contiguous()
+                and ids.is_contiguous()):
+            raise ValueError("coarse, fine and ids must be contiguous tensors on the GPU")
+        if coarse.dtype not in (torch.int16, torch.uint16) or tuple(coarse.shape) != (n, 2):
+            raise ValueError("coarse must be a [n, 2] tensor of 16-bit codes")
+        if fine.dtype != torch.uint8 or tuple(fine.shape) != (n, self._M) or ids.dtype != torch.int64 or tuple(ids.shape) != (n,):
+            raise ValueError("fine must be uint8 [n, %d] and ids int64 [n]" % self._M)
+        added, bad = _lib.c_int64(0), _lib.c_int64(0)
+        _lib.check(_lib.lib().cis_index_add_dev(self._ix, ids.data_ptr(), coarse.data_ptr(), fine.data_ptr(), n, 1 if dedup else 0,
+                                                _lib.ctypes.byref(added), _lib.ctypes.byref(bad),
+                                                None if cell_delta is None else cell_delta.data_ptr(),
+                                                torch.cuda.current_stream(coarse.device).cuda_stream))
+        self.nb_indexed = int(_lib.lib().cis_index_size(self._ix))
+        if bad.value:
+            print("Could not push {} codes (out of range for this model, or negative ids).".format(bad.value))
+        return int(added.value), int(bad.value)
+
     def add_codes(self, codes, ids=None):
         """reference: lopq/lopq/search.py:325-369.  codes: iterable of (coarse, fine) tuples.  Items
         that cannot be pushed are reported and skipped, like the reference does (:365-367)."""

@@ -141,11 +141,34 @@ int cis_index_set_shard(cis_index* ix, int rank, int world, const int32_t* owner
  * are ignored), so that every rank keeps the whole cell-size table the quota cut needs (lopq/lopq/search.py:128-133). */
 int cis_index_cell_counts(cis_index* ix, int64_t* counts);
 int cis_index_add_remote_counts(cis_index* ix, const int64_t* delta);
+/* The same on device arrays (the all-reduce of the increments runs over RCCL on them): d_counts / d_delta [V*V]. */
+int cis_index_cell_counts_dev(cis_index* ix, int64_t* d_counts, void* stream);
+int cis_index_add_remote_counts_dev(cis_index* ix, const int64_t* d_delta, void* stream);
+/* Routed insert without a host copy.  cis_index_route_pack_dev groups this rank's n freshly encoded items by the rank
+ * that owns their cell (arrival order inside a group, so that the per-cell insertion order after the exchange is that of
+ * a single index, search.py:359): d_records [n][12 + M] = id (8 B, little endian) | coarse (2 x uint16) | fine (M B),
+ * d_counts [world] int64 = records per destination.  cis_index_add_records_dev inserts records received from the
+ * all-to-all (same semantics and outputs as cis_index_add_dev). */
+int cis_index_route_pack_dev(cis_index* ix, const int64_t* d_ids, const uint16_t* d_coarse, const uint8_t* d_fine,
+                             int64_t n, uint8_t* d_records, int64_t* d_counts, void* stream);
+int cis_index_add_records_dev(cis_index* ix, const uint8_t* d_records, int64_t n, int dedup, int64_t* n_added,
+                              int64_t* n_invalid, int64_t* d_cell_delta, void* stream);
 
 /* add_codes (search.py:325-369): append items in order; with dedup != 0 an id already present in
  * the SAME cell is skipped (first occurrence wins).  *n_added = items counted (all shards). */
 int cis_index_add(cis_index* ix, const int64_t* ids, const uint16_t* coarse, const uint8_t* fine,
                   int64_t n, int dedup, int64_t* n_added);
+/* The same insert on arrays that are already in HBM (the codes cis_encode_dev just produced: the refresh loop of
+ * searcher_lopqhbase.py:743-758 without the round trip through the host).  The index lives in HBM only; an insert is a
+ * stable merge by kernels on `stream` (csrc/lopq_index.hip), and the call returns after the stream has drained (the
+ * accepted count is read back).  Items with out-of-range codes or negative ids are skipped and counted in *n_invalid
+ * ("could not push code", search.py:365-367) -- the host entry point above rejects the whole call instead. */
+int cis_index_add_dev(cis_index* ix, const int64_t* d_ids, const uint16_t* d_coarse, const uint8_t* d_fine, int64_t n,
+                      int dedup, int64_t* n_added, int64_t* n_invalid, int64_t* d_cell_delta /* [V*V] accepted per cell, or NULL */,
+                      void* stream);
+/* featsio.normfeatB64encode's normalisation (cufacesearch/cufacesearch/featurizer/featsio.py:13-22) on n device rows of d
+ * values, in place, in the rows' dtype; zero rows stay zero. */
+int cis_l2_normalize_dev(void* d_x, int dtype, int64_t n, int d, void* stream);
 /* get_nb_indexed (search.py:91-92): items over all shards. */
 int64_t cis_index_size(cis_index* ix);
 /* get_cell (search.py:372-382): items of one cell in insertion order.  Returns the cell's size in
