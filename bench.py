@@ -175,6 +175,10 @@ def main():
     t_build = time.time()
     my_chunks = [c for c in range(N_CHUNKS) if c * world // N_CHUNKS == rank]
     coarse_l, fine_l, ev = [], [], []
+    # encode parity at full size: rows sampled from EVERY chunk are kept (host copies) and their codes are checked against
+    # the oracle's compute_codes after the timed region (the oracle index of the search spot check is built from HIP codes)
+    n_sample = max(4096 // N_CHUNKS + 1, 1)
+    sample_x, sample_pos = [], []
     for c in my_chunks:
         x = gen_chunk(centers, c, chunk_n, device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -184,29 +188,43 @@ def main():
         ev.append((e0, e1))
         coarse_l.append(co)
         fine_l.append(fi)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            sel = torch.as_tensor(np.random.RandomState(4242 + c).choice(chunk_n, n_sample, replace=False), device=device)
+            sample_x.append(x[sel].cpu().numpy())
+            sample_pos.append(sel.cpu().numpy() + (c - my_chunks[0]) * chunk_n)
     coarse = torch.cat(coarse_l)
     fine = torch.cat(fine_l)
+    del coarse_l, fine_l
     torch.cuda.synchronize()
     encode_s = sum(a.elapsed_time(b) for a, b in ev) / 1e3  # without the synthetic data generation
-    coarse_h = coarse.cpu().numpy().view(np.uint16)
-    fine_h = fine.cpu().numpy()
     V = model.V
     # this rank encoded chunks [first, first + len(my_chunks)): ids are positions in the whole database
-    my_ids = np.arange(my_chunks[0] * chunk_n, (my_chunks[-1] + 1) * chunk_n, dtype=np.int64)
-    cell = coarse_h[:, 0].astype(np.int64) * V + coarse_h[:, 1]
-    counts = np.bincount(cell, minlength=V * V)
+    ids_dev = torch.arange(my_chunks[0] * chunk_n, (my_chunks[-1] + 1) * chunk_n, dtype=torch.int64, device=device)
+    t_ins = time.perf_counter()
     if use_dist:
         # cells -> ranks by greedy balance of the cell populations: the table must be identical on every rank, so the
-        # per-cell counts are summed over the ranks first (V*V int64); then every code travels ONCE, to its owner
-        ct_all = torch.from_numpy(counts).to(device if backend == "nccl" else "cpu")
+        # per-cell counts are summed over the ranks first (V*V int64); then every code travels ONCE, to its owner -- device
+        # buffers in, RCCL all-to-all, device-side merge into the owner's index (no host copy of the codes)
+        cell = coarse[:, 0].to(torch.int64).bitwise_and_(0xFFFF) * V + coarse[:, 1].to(torch.int64).bitwise_and_(0xFFFF)
+        ct_all = torch.bincount(cell, minlength=V * V)
+        del cell
+        if backend != "nccl":
+            ct_all = ct_all.cpu()
         dist.all_reduce(ct_all)
         sharded = ShardedSearcher(model, owner=greedy_cell_owner(ct_all.cpu().numpy(), world))
         searcher = sharded.local
-        sharded.add_codes_routed(coarse_h, fine_h, my_ids, dedup=False)
+        sharded.add_codes_routed_dev(coarse, fine, ids_dev, dedup=False)
     else:
         sharded = None
         searcher = LOPQSearcherHIP(model)
-        searcher.add_codes_array(coarse_h, fine_h, ids=my_ids, dedup=False)
+        searcher.add_codes_dev(coarse, fine, ids_dev, dedup=False)  # device-side merge (csrc/lopq_index.hip)
+    torch.cuda.synchronize()
+    insert_s = time.perf_counter() - t_ins
+    coarse_h = fine_h = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # host copies only for the oracle legs
+        coarse_h = coarse.cpu().numpy().view(np.uint16)
+        fine_h = fine.cpu().numpy()
+    del coarse, fine, ids_dev
     build_s = time.time() - t_build
 
     # ---- queries (resident in HBM before the timed region) --------------------------------------
@@ -230,20 +248,24 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     cand = 0
+    cand_items = 0
     out = None
     if sharded is None:
         for b in range(args.steps):
             out = step(qbatches[(args.warmup + b) % len(qbatches)])
             cand += searcher.last_stats()["candidates"]
+            cand_items += searcher.last_stats()["items"]
         scan_name = searcher.last_stats()["scan_kernel"]
     else:
         # steps are independent batches: the exchange + merge of batch b (side stream, RCCL) overlap the partial search
         # of batch b+1 (compute stream)
         h = sharded.search_begin(qbatches[args.warmup % len(qbatches)], quota=QUOTA, limit=LIMIT)
         cand += searcher.last_stats()["candidates"]
+        cand_items += searcher.last_stats()["items"]
         for b in range(1, args.steps):
             h2 = sharded.search_begin(qbatches[(args.warmup + b) % len(qbatches)], quota=QUOTA, limit=LIMIT)
             cand += searcher.last_stats()["candidates"]
+            cand_items += searcher.last_stats()["items"]
             out = sharded.search_end(h)
             h = h2
         out = sharded.search_end(h)
@@ -305,6 +327,13 @@ def main():
         from oracle import cpu_bench
         from oracle import lopq_oracle as O
         om = O.OracleModel.from_npz(z)
+        # encode parity at full size: the sampled rows of every chunk through the oracle's compute_codes
+        sx = np.concatenate(sample_x)
+        sp = np.concatenate(sample_pos)
+        oc, of = O.compute_codes(om, sx)
+        enc_ok = bool((oc == coarse_h[sp]).all() and (of == fine_h[sp]).all())
+        enc_checked = int(sp.shape[0])
+        del sample_x
         oix = O.OracleCSRIndex(om, coarse_h, fine_h)
         qh = qr.cpu().numpy()
         gi, gd = res["ids"].cpu().numpy(), res["dists"].cpu().numpy()
@@ -361,7 +390,27 @@ def main():
                           "vectors per-vector loop on 1 core, %d vectors over the workers (4 s); DeepSentibank torch-CPU: %d "
                           "images batch 1 over the workers (5 s), one batch of 256 on %d threads"
                           % (n_vec, n_sa, cores, n_el, n_ea, n_c1, cores)}
-        parity = {"queries_checked": max(n_loop, n_vec), "ids_bit_exact": ok, "max_rel_dist_err": max_rel}
+        parity = {"queries_checked": max(n_loop, n_vec), "ids_bit_exact": ok, "max_rel_dist_err": max_rel,
+                  "encode_rows_checked": enc_checked, "encode_rows_from_chunks": N_CHUNKS, "encode_codes_bit_exact": enc_ok}
+        # the loop restatement against the reference's own wall time on C1 (the reference ran in the build
+        # container when the fixture was made: tests/golden/c1.npz:ref_encode_vec_per_s; this host is a different machine)
+        try:
+            sys.path.insert(0, os.path.join(REPO, "tests"))
+            import golden_inputs as gi
+            z1 = np.load(os.path.join(REPO, "tests", "golden", "c1.npz"))
+            om1 = O.OracleModel.from_npz(z1)
+            x1 = gi.c1_inputs()[0][:4096]
+            if "ref_encode_vec_per_s" in z1:
+                n1, t1s = 0, time.perf_counter()
+                while time.perf_counter() - t1s < 3.0 and n1 < len(x1):
+                    O.compute_codes_loop(om1, x1[n1:n1 + 64])
+                    n1 += 64
+                loop1 = n1 / (time.perf_counter() - t1s)
+                cpu["c1_encode_loop_vps_this_host"] = loop1
+                cpu["c1_encode_reference_vps_build_container"] = float(z1["ref_encode_vec_per_s"])
+                cpu["c1_loop_over_reference"] = loop1 / float(z1["ref_encode_vec_per_s"])
+        except Exception as e:  # a timing note must never cost the bench line
+            cpu["c1_loop_over_reference_error"] = repr(e)
 
     # ---- second half of the BASELINE metric: CNN descriptors/s (batch 256, synthetic weights) ------------
     cnn = None
@@ -422,18 +471,83 @@ def main():
                               "frac": 2.0 * 270854144 * B4 / dt4 / (F32_MFMA_PEAK_TFLOPS * 1e12)}
         net.close()
 
+    # ---- BASELINE config C5 leg: batched CNN extract (batch 256) -> L2 normalise -> LOPQ encode -> insert into the resident index ----
+    ingest = None
+    if not args.no_cnn and sharded is None:
+        from columbiaimagesearch_amd.featurizer.synthetic import dlib_weights, sentibank_weights
+        from columbiaimagesearch_amd.featurizer import DLibFaceNet, SentiBankNet
+        from columbiaimagesearch_amd.ingest import BatchIngest, l2_normalize_dev
+        torch.cuda.empty_cache()
+        B = 256
+        g5 = torch.Generator(device=device)
+        g5.manual_seed(55)
+        if cfg["d_in"] == 4096:
+            net5, net_name = SentiBankNet(sentibank_weights(0)), "DeepSentibank fc7 (4096-d float32)"
+            xb5 = (torch.randn((B, 3, 227, 227), generator=g5, device=device) * 50.0).contiguous()
+            fdt = None
+        else:
+            net5, net_name = DLibFaceNet(dlib_weights(0)), "dlib face ResNet (128-d, cast to float64 like the reference's descriptors)"
+            xb5 = (torch.rand((B, 150, 150, 3), generator=g5, device=device) * 255).contiguous()
+            fdt = torch.float64
+        ing = BatchIngest(net5, model, searcher, feat_dtype=fdt)
+        n_before = searcher.get_nb_indexed()
+        ing.nb_ingested = 1 << 40  # fresh ids: nothing is a duplicate of the resident items
+        n_ing = 12
+        for _ in range(2):
+            ing.ingest_batch(xb5)
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        for _ in range(n_ing):
+            ing.ingest_batch(xb5)   # forward -> normalise -> encode -> device-side merge incl. refreshed cell statistics
+        torch.cuda.synchronize()
+        dt5 = (time.perf_counter() - t5) / n_ing
+        t5 = time.perf_counter()
+        for _ in range(n_ing):
+            ing.encode_batch_dev(xb5)
+        torch.cuda.synchronize()
+        de5 = (time.perf_counter() - t5) / n_ing
+        r5 = searcher.search_batch_dev(qbatches[0][:64].contiguous(), quota=QUOTA, limit=LIMIT)  # the grown index still answers
+        torch.cuda.synchronize()
+        ingest = {"metric": "descriptors/s end to end: CNN forward (batch 256) -> L2 normalise -> LOPQ encode -> insert with dedup into the "
+                            "resident index (BASELINE config C5 chain on this config's model)",
+                  "value": B / dt5, "unit": "descriptors/s", "ms_per_batch": dt5 * 1e3, "net": net_name,
+                  "extract_encode_ms": de5 * 1e3, "insert_ms": (dt5 - de5) * 1e3, "resident_items_before": int(n_before),
+                  "resident_items_after": int(searcher.get_nb_indexed()), "batches": n_ing,
+                  "insert": "cis_index_add_dev: device-side stable merge, one read + one write of the index per batch; no host copy of codes",
+                  "searched_after": int((r5["n_found"] > 0).sum().item())}
+        net5.close()
+        del xb5
+
     if rank == 0:
         M = model.M
         launches = max(prof["scan_launches"], 1)
         scan_s = prof["scan_kernel_ms"] / 1e3  # HIP events right around the scan kernel launches, on their stream
-        algo_bytes = cand * M  # this rank's scan kernel
+        algo_bytes = cand * M  # this rank's scan kernel, SURVEY.md 8(d): every (candidate, query) pair counts M code bytes
         achieved = algo_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
-        # HBM traffic comes from rocprofv3 --pmc passes of this command (tools/gpu_round_profile.sh), not from this run
-        traffic, traffic_src = None, None
-        tpath = os.path.join(REPO, "profiles", "scan_traffic_%s.json" % args.config)
-        if os.path.exists(tpath) and world == 1:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            traffic_src = "from_profile: profiles/scan_traffic_%s.json (separate rocprofv3 --pmc passes of this command)" % args.config
+        # What binds the kernel: the accounting above re-counts a code for every query although the G queries
+        # of a workgroup share one load and the index streams through L2 / Infinity Cache -- it can exceed the HBM peak (C3),
+        # so `frac` is capped at 1 and the bounds the kernel really runs against are reported next to it, from the same
+        # launch time: bytes its memory instructions move, LDS table-gather cycles, VALU issue slots of its minimal loop.
+        G = {"k_adc_scan2": 2, "k_adc_scan3": 4}.get(scan_name, 1)
+        K = 256
+        pairs_rows = cand / float(G) / 64.0                 # wave-rows: 64 candidates x G queries
+        items = cand_items
+        moved = cand * M / float(G) + items * M * K * 4 + items * LIMIT * 8   # codes once per workgroup + float32 tables staged + survivors
+        lds_cycles = pairs_rows * M * 2.0                   # one ds_read_b64 per sub-quantizer and row, 2 LDS cycles when conflict-free
+        valu_instr = pairs_rows * ((2 * M + 4) if G == 2 else (3 * M + 4))  # address + packed add(s) per sub-quantizer, unpack + compare
+        clk, n_cu = 2.4e9, 256
+        t_lds = lds_cycles / (n_cu * clk)
+        t_valu = valu_instr * 4.0 / (4 * n_cu * clk)        # a wave64 VALU instruction occupies its SIMD for 4 cycles
+        t_mem = moved / (HBM_PEAK_GBS * 1e9)
+        binding = {"unit": "fraction of the launch time each resource's minimum accounts for (1.0 = bound by it)",
+                   "hbm_moved_bytes": {"bytes_per_launch": moved / launches, "frac": t_mem / scan_s if scan_s > 0 else None,
+                                       "note": "cand*M/G + float32 tables staged + survivors, against 8 TB/s (mostly L2 / Infinity Cache hits)"},
+                   "lds_gather": {"wave_reads_per_launch": pairs_rows * M / launches, "frac": t_lds / scan_s if scan_s > 0 else None,
+                                  "note": "ds_read_b64 per (row of 64 candidates x G queries, sub-quantizer), 2 cycles each, 256 CUs at 2.4 GHz"},
+                   "valu_issue": {"wave_instr_per_launch": valu_instr / launches, "frac": t_valu / scan_s if scan_s > 0 else None,
+                                  "note": "minimal gather-and-add loop only (no selection / append), 4 cycles per wave64 instruction, 1024 SIMDs"},
+                   "queries_per_workgroup": G}
+        binding["binds"] = max(("hbm_moved_bytes", "lds_gather", "valu_issue"), key=lambda k: binding[k]["frac"] or 0.0)
         line = {
             "metric": "queries/sec @ recall@10 on 10M LOPQ index",
             "value": NQ * args.steps / elapsed,
@@ -457,9 +571,10 @@ def main():
                        "sharding": "by coarse cell over %d GPU(s)%s" % (world, ", RCCL all-gather merge" if world > 1 else ""),
                        "candidates_per_query": cand_all / float(NQ * args.steps)},
             "roofline": {"bound": "hbm", "kernel": scan_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "unit": "GB/s", "frac": min(achieved / HBM_PEAK_GBS, 1.0), "accounting_frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "traffic_note": "PMC passes are separate rocprofv3 runs: profiles/scan_traffic_%s.json" % args.config,
                          "algorithmic_bytes_per_launch": algo_bytes / launches,
-                         "avg_launch_ms": prof["scan_kernel_ms"] / launches, "launches": launches},
+                         "avg_launch_ms": prof["scan_kernel_ms"] / launches, "launches": launches, "binding": binding},
             "stage_ms_per_step": {k: stage_prof[k] / n_stage for k in ("front_ms", "tables_ms", "scan_ms", "merge_ms", "scan_kernel_ms")},
             "encode": {"value": len(my_chunks) * chunk_n / encode_s, "unit": "vectors/s", "vectors": len(my_chunks) * chunk_n,
                        "note": "cis_encode_dev on this rank's share of the index build, HIP events around the encode calls"},
@@ -468,7 +583,9 @@ def main():
             "dlib": dlib,
             "cpu_baseline": cpu,
             "parity": parity,
-            "build": {"encode_s": encode_s, "total_s": build_s},
+            "ingest": ingest,
+            "build": {"encode_s": encode_s, "insert_s": insert_s, "total_s": build_s,
+                      "insert": "device-side merge of %d codes into the HBM index (cis_index_add_dev%s)" % (len(my_chunks) * chunk_n, " after the RCCL all-to-all" if use_dist else "")},
         }
     if use_dist:
         dist.barrier()

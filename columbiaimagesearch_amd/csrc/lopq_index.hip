@@ -799,9 +799,12 @@ extern "C" int cis_index_get_cell(cis_index* ix, int c0, int c1, int64_t cap, in
     int64_t g = 0, ab[2] = {0, 0};
     CIS_CHECK_HIP(hipMemcpy(&g, ix->d_gcount.as<int64_t>() + cell, sizeof(int64_t), hipMemcpyDeviceToHost));
     *n = g;
-    if (cap <= 0 || !ix->owns(cell)) return CIS_OK;
+    if (cap <= 0) return CIS_OK;
+    *n = 0;  // with a buffer: the number of items copied (a cell of another shard has none here)
+    if (!ix->owns(cell)) return CIS_OK;
     CIS_CHECK_HIP(hipMemcpy(ab, ix->loff_ptr() + cell, 2 * sizeof(int64_t), hipMemcpyDeviceToHost));
     const int64_t k = std::min(cap, ab[1] - ab[0]);
+    *n = k;
     if (k > 0) {
         if (ids) CIS_CHECK_HIP(hipMemcpy(ids, ix->ids_ptr() + ab[0], (size_t)k * sizeof(int64_t), hipMemcpyDeviceToHost));
         if (fine) CIS_CHECK_HIP(hipMemcpy(fine, ix->codes_ptr() + ab[0] * ix->M, (size_t)k * ix->M, hipMemcpyDeviceToHost));

@@ -255,6 +255,7 @@ class LOPQSearcherHIP(LOPQSearcherBase):
         ids = np.empty(cap, dtype=np.int64)
         fine = np.empty((cap, self._M), dtype=np.uint8)
         _lib.check(L.cis_index_get_cell(self._ix, c0, c1, cap, _lib.ptr(ids), _lib.ptr(fine), _lib.ctypes.byref(n)))
+        ids, fine = ids[:int(n.value)], fine[:int(n.value)]  # a cell of another shard holds nothing here
         ct = _code_dtype(self.model.V)
         coarse = (ct(c0), ct(c1))
         return [(self._caller_id(i), LOPQCode(coarse, tuple(f))) for i, f in zip(ids, fine)]

@@ -171,8 +171,9 @@ int cis_index_add_dev(cis_index* ix, const int64_t* d_ids, const uint16_t* d_coa
 int cis_l2_normalize_dev(void* d_x, int dtype, int64_t n, int d, void* stream);
 /* get_nb_indexed (search.py:91-92): items over all shards. */
 int64_t cis_index_size(cis_index* ix);
-/* get_cell (search.py:372-382): items of one cell in insertion order.  Returns the cell's size in
- * *n; copies at most cap items.  In sharded mode non-owned cells report their size but copy 0. */
+/* get_cell (search.py:372-382): items of one cell in insertion order.  cap <= 0: *n = the cell's size (all
+ * shards), nothing is copied.  cap > 0: copies at most cap items, *n = the number copied (0 for a cell that
+ * another shard owns). */
 int cis_index_get_cell(cis_index* ix, int c0, int c1, int64_t cap, int64_t* ids, uint8_t* fine, int64_t* n);
 
 /* LOPQSearcherBase.search over nq queries (search.py:179-224): Q [nq][D_in] of q_dtype.

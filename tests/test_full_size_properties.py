@@ -33,10 +33,14 @@ def world():
         a, b = model.predict_batch_dev(B.gen_chunk(P, c, chunk_n, dev))
         co.append(a)
         fi.append(b)
-    coarse = torch.cat(co).cpu().numpy().view(np.uint16)
-    fine = torch.cat(fi).cpu().numpy()
+    cd, fd = torch.cat(co), torch.cat(fi)
+    coarse = cd.cpu().numpy().view(np.uint16)
+    fine = fd.cpu().numpy()
     s = LOPQSearcherHIP(model)
-    s.add_codes_array(coarse, fine, ids=np.arange(N, dtype=np.int64), dedup=False)
+    # the device-side insert (csrc/lopq_index.hip): codes go from the encoder to the index without leaving HBM
+    added, bad = s.add_codes_dev(cd, fd, torch.arange(N, dtype=torch.int64, device=dev), dedup=False)
+    assert (added, bad) == (N, 0)
+    del cd, fd, co, fi
     x0 = B.gen_chunk(P, 0, chunk_n, dev)
     q = B.make_queries(x0, 0, NQ, dev)
     return dict(model=model, z=z, P=P, chunk_n=chunk_n, coarse=coarse, fine=fine, searcher=s, x0=x0, q=q, B=B, dev=dev)
@@ -58,6 +62,33 @@ def test_encode_is_independent_of_batch_composition(world):
         np.testing.assert_array_equal(f.cpu().numpy(), ref_f[a:b])
     c, f = m.predict_batch_dev(x0[:0].contiguous())  # empty input
     assert c.shape[0] == 0 and f.shape[0] == 0
+
+
+def test_encode_matches_oracle_on_rows_sampled_from_every_chunk(world):
+    """4160 rows drawn from all 10 chunks of the 10M build against the oracle's compute_codes, bit for bit (the oracle index
+    of the search checks below is built from the HIP codes: this is what makes that sound)."""
+    from oracle import lopq_oracle as O
+    B, P, chunk_n, dev = world["B"], world["P"], world["chunk_n"], world["dev"]
+    om = O.OracleModel.from_npz(world["z"])
+    import torch
+    for c in range(N_CHUNKS):
+        sel = np.random.RandomState(900 + c).choice(chunk_n, 416, replace=False)
+        x = B.gen_chunk(P, c, chunk_n, dev)[torch.as_tensor(sel, device=dev)].cpu().numpy()
+        oc, of = O.compute_codes(om, x)
+        np.testing.assert_array_equal(oc, world["coarse"][c * chunk_n + sel])
+        np.testing.assert_array_equal(of, world["fine"][c * chunk_n + sel])
+
+
+def test_index_built_on_device_equals_host_built_cells(world):
+    """Cells of the 10M index read back (get_cell) == a numpy grouping of the codes by cell in arrival order."""
+    s, coarse, fine = world["searcher"], world["coarse"], world["fine"]
+    V = world["model"].V
+    cell = coarse[:, 0].astype(np.int64) * V + coarse[:, 1]
+    for c in (0, 77, V * V - 1):
+        idx = np.nonzero(cell == c)[0]
+        got = s.get_cell((c // V, c % V))
+        np.testing.assert_array_equal(np.array([i for i, _ in got], dtype=np.int64), idx)
+        np.testing.assert_array_equal(np.array([code.fine for _, code in got], dtype=np.uint8), fine[idx])
 
 
 def test_search_properties_at_full_size(world):
@@ -207,6 +238,42 @@ def test_routed_insert_and_pipelined_sharded_search_rccl():
     text = out.stdout.decode()
     assert out.returncode == 0, text[-3000:]
     assert text.count("routed insert + pipelined search ok") == 4, text[-3000:]
+
+
+def test_routed_device_insert_with_two_ranks_on_one_gpu():
+    """World 2 over gloo on ONE device: the routed insert really exchanges records between ranks (RCCL has only ever run
+    at world 1 on this pool); the collectives are staged through the host for gloo, everything else is the device path."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = os.path.join(here, "tools", "sharded_pipeline_check.py")
+    env = dict(os.environ, CIS_CHECK_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29583", script]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-3000:]
+    assert "world 2: routed device insert == routed host insert" in text, text[-3000:]
+    assert text.count("routed insert + pipelined search ok") == 4, text[-3000:]
+
+
+def test_bench_multi_rank_protocol_with_two_ranks_on_one_gpu():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), here over gloo with both
+    ranks on the one GPU of the box: device-side routed build, pipelined sharded search, max-over-ranks timing, ONE JSON line
+    from rank 0 whose recall matches the single-GPU run of the same index size."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CIS_BENCH_BACKEND="gloo", CIS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CIS_BENCH_N="400000")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29585", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "c2",
+           "--no-cnn", "--no-cpu-baseline", "--no-pcie"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, cwd=repo)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-3000:]
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, text[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["recall_at_10"] >= 0.9
+    assert line["config"]["index_vectors"] == 400000 and line["roofline"]["frac"] <= 1.0
 
 
 def test_fork_before_first_use():

@@ -15,25 +15,53 @@ from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 local = int(os.environ.get("LOCAL_RANK", 0))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29578")
+backend = os.environ.get("CIS_CHECK_BACKEND", "nccl")  # "gloo": several ranks on ONE GPU (RCCL refuses shared devices): the staged collectives
+if backend != "nccl":
+    local = 0
 torch.cuda.set_device(local)
 _lib.check(_lib.lib().cis_set_device(local))
-dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local) if backend == "nccl" else None)
 z, X, Q = load_golden("c2")
 m = hip_model(z)
 coarse, fine = z["coarse"], z["fine"]
 n = coarse.shape[0]
 ids = np.arange(n, dtype=np.int64) + 7
-single = LOPQSearcherHIP(m); single.add_codes_array(coarse, fine, ids)
+# the single index sees the items in the order the sharded one does: two batches, each the concatenation of the ranks'
+# slices (rank 0's first) -- per-cell insertion order decides between equal distances (duplicate codes are common here)
+single = LOPQSearcherHIP(m)
+bounds = [(r * n // world, (r + 1) * n // world) for r in range(world)]
+for part in (0, 1):
+    sel = np.concatenate([np.arange(a_, a_ + (b_ - a_) // 2 + 50) if part == 0 else np.arange(a_ + (b_ - a_) // 2, b_) for a_, b_ in bounds])
+    single.add_codes_array(coarse[sel], fine[sel], ids[sel])
 V = m.V
 counts = np.bincount(coarse[:, 0].astype(np.int64) * V + coarse[:, 1], minlength=V * V)
 sh = ShardedSearcher(m, owner=greedy_cell_owner(counts, world))
 a, b = rank * n // world, (rank + 1) * n // world  # this rank's slice of the batch, as if it had encoded it
-sh.add_codes_routed(coarse[a:b], fine[a:b], ids[a:b])
+h1 = (b - a) // 2  # two batches, the second one repeating 50 items of the first (recognised as duplicates by their owners)
+sh.add_codes_routed(coarse[a:a + h1 + 50], fine[a:a + h1 + 50], ids[a:a + h1 + 50])
+sh.add_codes_routed(coarse[a + h1:b], fine[a + h1:b], ids[a + h1:b])
 assert sh.get_nb_indexed() == single.get_nb_indexed(), (sh.get_nb_indexed(), single.get_nb_indexed())
+# the same insert without a host copy: records packed on the device, one all-to-all of device buffers, device-side merge;
+# the same two batches
+sh_dev = ShardedSearcher(m, owner=greedy_cell_owner(counts, world))
+cd, fd, idd = (torch.as_tensor(coarse[a:b].view(np.int16)).cuda(), torch.as_tensor(fine[a:b]).cuda(), torch.as_tensor(ids[a:b]).cuda())
+sh_dev.add_codes_routed_dev(cd[:h1 + 50].contiguous(), fd[:h1 + 50].contiguous(), idd[:h1 + 50].contiguous())
+sh_dev.add_codes_routed_dev(cd[h1:].contiguous(), fd[h1:].contiguous(), idd[h1:].contiguous())
+assert sh_dev.get_nb_indexed() == single.get_nb_indexed(), (sh_dev.get_nb_indexed(), single.get_nb_indexed())
+cc_a, cc_b = np.zeros(V * V, dtype=np.int64), np.zeros(V * V, dtype=np.int64)
+_lib.check(_lib.lib().cis_index_cell_counts(sh.local._ix, _lib.ptr(cc_a)))
+_lib.check(_lib.lib().cis_index_cell_counts(sh_dev.local._ix, _lib.ptr(cc_b)))
+assert (cc_a == cc_b).all() and (cc_a == counts).all()
+for c in range(0, V * V, 37):  # cells of this rank: same items in the same order whichever way they were inserted
+    ga, gb = sh.local.get_cell((c // V, c % V)), sh_dev.local.get_cell((c // V, c % V))
+    assert [i for i, _ in ga] == [i for i, _ in gb] and [x.fine for _, x in ga] == [x.fine for _, x in gb], c
+if rank == 0:
+    print("world %d: routed device insert == routed host insert" % world)
 qs = [torch.as_tensor(Q[i:i + 16]).cuda().contiguous() for i in (0, 16, 32, 48)]
 for quota, limit in [(3000, 100), (50, 20), (5000, 600), (20000, 3500)]:
     want = [single.search_batch_dev(q, quota=quota, limit=limit) for q in qs]
     got = []
+    sh = sh_dev if limit == 20 else sh
     h = sh.search_begin(qs[0], quota=quota, limit=limit)
     for q in qs[1:]:
         h2 = sh.search_begin(q, quota=quota, limit=limit)
