@@ -353,6 +353,8 @@ def main():
             ok = ok and bool((gi[n_vec, :len(ids)] == ids).all())
             n_vec += 1
         cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+        from columbiaimagesearch_amd.extractor.preprocess_pool import cpu_allowance
+        allowance = cpu_allowance()  # the container's cgroup CPU time (16 cores on the GPU boxes seen so far, of 256 visible)
         # encode, reference-shaped per-vector loop (lopq/lopq/utils.py:203-218), 1 core
         enc_x = gen_chunk(centers, 1, 8192, device).cpu().numpy()
         n_el, t0 = 0, time.perf_counter()
@@ -383,7 +385,7 @@ def main():
                "sample": "%d queries of the timed workload (quota=%d, limit=%d, %d-vector index) through the oracle's "
                          "reference-shaped per-candidate loop (search.py:166-175)" % (n_loop, QUOTA, LIMIT, N),
                "search_vectorised_1core_qps": n_vec / t_vec,
-               "search_vectorised_allcore_qps": srch_all, "allcore_workers": cores,
+               "search_vectorised_allcore_qps": srch_all, "allcore_workers": cores, "cgroup_cpu_allowance_cores": allowance,
                "encode_loop_1core_vps": enc_loop, "encode_vectorised_allcore_vps": enc_all,
                "cnn_torch_cpu_batch1_x_cores_ips": cnn1_all, "cnn_torch_cpu_batch256_ips": cnn256,
                "samples": "vectorised search: %d queries on 1 core, %d queries over %d single-threaded workers (6 s); encode: %d "

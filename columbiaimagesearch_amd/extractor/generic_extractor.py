@@ -36,9 +36,23 @@ def build_extr_str_failed(featurizer_type, detector_type, input_type):
     return build_extr_str(featurizer_type, detector_type, input_type) + "_" + EXTR_STR_FAILED
 
 
+PY2_FLOAT_STR = True  # column names as the reference's Python 2 wrote them (HBase rows written by it stay addressable)
+
+
+def _py2_str(v):
+    """What "{}".format(v) gave under the reference's Python 2 for a float: str(float) = 12 significant digits
+    ('%.12g', with '.0' appended to integral values) where Python 3 prints the 17-digit repr.  Other types unchanged."""
+    if PY2_FLOAT_STR and isinstance(v, float):
+        s = "%.12g" % v
+        if "." not in s and "e" not in s and "n" not in s:  # integral value (not inf / nan)
+            s += ".0"
+        return s
+    return "{}".format(v)
+
+
 def get_bbox_str(bbox):
     """left_top_right_bottom_score (reference: detector/utils.py:114-123)"""
-    return "_".join(["{}"] * 5).format(bbox["left"], bbox["top"], bbox["right"], bbox["bottom"], bbox["score"])
+    return "_".join(_py2_str(bbox[k]) for k in ("left", "top", "right", "bottom", "score"))
 
 
 class DLibHOGDetector(object):
@@ -101,21 +115,28 @@ class GenericExtractor(object):
         return self.process_batch([img_buffer], _raise=True)[0]
 
     def _process_batch_dets(self, img_buffers, _raise):
-        """Detector branch (:236-247) for a list of images: detections of ALL images are featurized in one GPU batch
-        (`featurizer.featurize_dets(img, dets)` when the featurizer has it, else one `featurize(img, det)` each).
-        An image without detections keeps ``processed = "0"`` like the reference's init_out_dict (:201-210)."""
+        """Detector branch (:236-247) for a list of images.  With a featurizer that separates alignment from the network
+        (`_chip` + `featurize_chips`: the dlib face featurizer) the aligned chips of ALL images' detections are gathered and
+        go through the network in GPU batches of up to `chip_batch` chips; otherwise one `featurize(img, det)` per detection
+        like the reference.  An image without detections keeps ``processed = "0"`` like init_out_dict (:201-210)."""
+        import numpy as np
         out = [None] * len(img_buffers)
         dtype = get_feat_dtype(self.featurizer_type)
+        batched = hasattr(self.featurizer, "_chip") and hasattr(self.featurizer, "featurize_chips")
+        chips, owner = [], []  # aligned chips of every image, (image index, detection) each
         for i, buf in enumerate(img_buffers):
             try:
                 img, dets = self.detector.detect_from_buffer_noinfos(buf, up_sample=1)
                 row = self.init_out_dict()
-                if dets:
-                    if hasattr(self.featurizer, "featurize_dets"):
-                        feats = self.featurizer.featurize_dets(img, dets)
-                    else:
-                        feats = [self.featurizer.featurize(img, d) for d in dets]
-                    for det, feat in zip(dets, feats):
+                if dets and batched:
+                    if len(img.shape) == 2:
+                        img = np.stack([img] * 3, axis=-1)  # dlib_featurizer.py:97-99 gray2rgb
+                    mine = [np.asarray(self.featurizer._chip(img, d)) for d in dets]  # any failure fails the image, not the batch
+                    chips.extend(mine)
+                    owner.extend((i, d) for d in dets)
+                elif dets:
+                    for det in dets:
+                        feat = self.featurizer.featurize(img, det)
                         row[self.extr_str_processed] = str(1)
                         row[self.extr_str + "_" + get_bbox_str(det)] = normfeatB64encode(feat.astype(dtype))  # :241-247
                 out[i] = row
@@ -123,15 +144,43 @@ class GenericExtractor(object):
                 if _raise:
                     raise
                 out[i] = self.failed_out_dict()
+        for a in range(0, len(chips), self.chip_batch):
+            feats = self.featurizer.featurize_chips(np.stack(chips[a:a + self.chip_batch]))
+            for (i, det), feat in zip(owner[a:a + self.chip_batch], feats):
+                out[i][self.extr_str_processed] = str(1)
+                out[i][self.extr_str + "_" + get_bbox_str(det)] = normfeatB64encode(feat.astype(dtype))  # :241-247
         return out
 
-    def process_batch(self, img_buffers, _raise=False):
+    chip_batch = 256  # chips per forward pass of the detector branch (BASELINE batch)
+
+    def process_batch(self, img_buffers, _raise=False, pool=None):
         """One GPU forward for the whole list.  Images that cannot be decoded get the reference's failure row
-        (DaemonBatchExtractor.run reports failed_out_dict on any exception, :109-127) and do not poison the batch."""
+        (DaemonBatchExtractor.run reports failed_out_dict on any exception, :109-127) and do not poison the batch.
+        pool: an extractor.preprocess_pool.PreprocessPool of worker processes that decode / resize in parallel into a
+        page-locked ring (rows are identical to the serial path: the workers run the featurizer's own preprocessing)."""
         if self.detector is not None:
             return self._process_batch_dets(img_buffers, _raise)
-        good, tensors = [], []
+        import numpy as np
         out = [None] * len(img_buffers)
+        if pool is not None:
+            # two halves of the ring alternate: the workers decode batch b + 1 while the GPU runs batch b and the rows of
+            # batch b are encoded here
+            import torch
+            half = max(pool.slots // 2, 1)
+            starts = list(range(0, len(img_buffers), half))
+            nxt = pool.start(img_buffers[0:half], 0) if starts else None
+            for bi, a in enumerate(starts):
+                ring, ok = pool.finish(nxt)
+                if bi + 1 < len(starts):
+                    b0 = starts[bi + 1]
+                    nxt = pool.start(img_buffers[b0:b0 + half], ((bi + 1) % 2) * half)
+                if ok.any():
+                    x = torch.from_numpy(ring).cuda(non_blocking=True)  # slots of failed images hold stale data: computed, ignored
+                    feats = self.featurizer.net.forward_dev(x).cpu().numpy()
+                for k in range(len(ok)):
+                    out[a + k] = self._row(feats[k]) if ok[k] else self.failed_out_dict()
+            return out
+        good, tensors = [], []
         for i, buf in enumerate(img_buffers):
             try:
                 tensors.append(self.featurizer.preprocess_img(buf))
@@ -139,7 +188,6 @@ class GenericExtractor(object):
             except Exception:
                 out[i] = self.failed_out_dict()
         if good:
-            import numpy as np
             feats = self.featurizer.net.forward(np.stack(tensors))
             for i, f in zip(good, feats):
                 out[i] = self._row(f)

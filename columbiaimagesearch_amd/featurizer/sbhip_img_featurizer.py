@@ -23,6 +23,57 @@ INPUT_HW = 227
 FEAT_DIM = 4096
 
 
+def bytescale(data, low=0, high=255, cmin=None, cmax=None):
+    """scipy.misc.bytescale as imresize -> toimage applies it to the float image caffe.io.load_image returns:
+    the image's own min..max is stretched to 0..255 before the resize (so a low-contrast image is NOT resized
+    as its uint8 self).  float32 arithmetic like the reference's (float32 image, python-float scale)."""
+    if cmin is None:
+        cmin = data.min()
+    if cmax is None:
+        cmax = data.max()
+    cscale = cmax - cmin
+    if cscale == 0:
+        cscale = 1
+    scale = float(high - low) / cscale
+    bytedata = (data - cmin) * data.dtype.type(scale) + data.dtype.type(low)
+    return (bytedata.clip(low, high) + data.dtype.type(0.5)).astype(np.uint8)
+
+
+_U8_AS_FLOAT = (np.arange(256, dtype=np.uint8) / 255.0).astype(np.float32)  # img_as_float of every possible pixel value
+
+
+def load_and_bytescale(a8):
+    """uint8 RGB image -> what bytescale((a8 / 255.0).astype(float32)) returns, through a 256-entry table: the chain is a
+    function of the pixel value and of the image's min / max only (the float conversion is monotone, so the float min / max
+    are the conversions of the uint8 min / max), and the table is computed by the very same numpy expressions on the 256
+    possible values -- identical bytes at a fraction of the passes over the image."""
+    lut = bytescale(_U8_AS_FLOAT, cmin=_U8_AS_FLOAT[a8.min()], cmax=_U8_AS_FLOAT[a8.max()])
+    return lut[a8]
+
+
+def sentibank_preprocess(img_buffer, mu, w_boff, w_eoff, h_boff, h_eoff, target_size=(256, 256, 3), out=None):
+    """host-side restatement of reference :113-134 with PIL: caffe.io.load_image -> RGB float32 in [0,1]
+    (skimage.img_as_float(...).astype(float32)); scipy.misc.imresize = toimage (bytescale: min..max -> 0..255,
+    uint8) + PIL LANCZOS resize to 256x256; centre crop 227; HWC->CHW; RGB->BGR; subtract the cropped mean.
+    A plain function of picklable arguments, so that worker processes run exactly what featurize() runs."""
+    from PIL import Image
+    if isinstance(img_buffer, (bytes, bytearray)):
+        img_buffer = io.BytesIO(img_buffer)
+    im = Image.open(img_buffer)
+    if getattr(im, "n_frames", 1) > 1:
+        im.seek(1)  # reference takes image[1] of a GIF (:123-125)
+    rgb = im.convert("RGB")
+    ext = rgb.getextrema()  # per band (min, max): the table needs the image's own range
+    lut = bytescale(_U8_AS_FLOAT, cmin=_U8_AS_FLOAT[min(e[0] for e in ext)], cmax=_U8_AS_FLOAT[max(e[1] for e in ext)])
+    im = rgb.point(lut.tolist() * 3).resize((target_size[1], target_size[0]), Image.LANCZOS)  # load_and_bytescale, in PIL's C loop
+    a = np.asarray(im, dtype=np.uint8)[w_boff:w_eoff, h_boff:h_eoff, :]
+    chw = a.transpose(2, 0, 1)[::-1].astype(np.float32)  # channel swap (2,1,0): RGB -> BGR
+    if out is not None:
+        np.subtract(chw, mu, out=out)
+        return out
+    return chw - mu
+
+
 class SentiBankNet(object):
     """The network alone: float32 NCHW batch in, fc7 (post-ReLU) out.  Owns a cis_cnn handle."""
 
@@ -94,34 +145,16 @@ class SentiBankHIPImgFeaturizer(GenericFeaturizer):
         from .caffemodel import sentibank_weights
         return sentibank_weights(path)  # the reference's file: a serialised caffe NetParameter
 
-    @staticmethod
-    def bytescale(data, low=0, high=255):
-        """scipy.misc.bytescale as imresize -> toimage applies it to the float image caffe.io.load_image returns:
-        the image's own min..max is stretched to 0..255 before the resize (so a low-contrast image is NOT resized
-        as its uint8 self).  float32 arithmetic like the reference's (float32 image, python-float scale)."""
-        cmin, cmax = data.min(), data.max()
-        cscale = cmax - cmin
-        if cscale == 0:
-            cscale = 1
-        scale = float(high - low) / cscale
-        bytedata = (data - cmin) * data.dtype.type(scale) + data.dtype.type(low)
-        return (bytedata.clip(low, high) + data.dtype.type(0.5)).astype(np.uint8)
+    bytescale = staticmethod(lambda data, low=0, high=255: bytescale(data, low, high))
+
+    def preprocess_spec(self):
+        """What a worker process needs to run this featurizer's preprocessing without the GPU object (picklable):
+        (function, constant arguments) -- extractor/preprocess_pool.py."""
+        return sentibank_preprocess, (self.mu, self.w_boff, self.w_eoff, self.h_boff, self.h_eoff, self.target_size)
 
     def preprocess_img(self, img_buffer):
-        """host-side restatement of reference :113-134 with PIL: caffe.io.load_image -> RGB float32 in [0,1]
-        (skimage.img_as_float(...).astype(float32)); scipy.misc.imresize = toimage (bytescale: min..max -> 0..255,
-        uint8) + PIL LANCZOS resize to 256x256; centre crop 227; HWC->CHW; RGB->BGR; subtract the cropped mean."""
-        from PIL import Image
-        if isinstance(img_buffer, (bytes, bytearray)):
-            img_buffer = io.BytesIO(img_buffer)
-        im = Image.open(img_buffer)
-        if getattr(im, "n_frames", 1) > 1:
-            im.seek(1)  # reference takes image[1] of a GIF (:123-125)
-        img = (np.asarray(im.convert("RGB"), dtype=np.uint8) / 255.0).astype(np.float32)
-        im = Image.fromarray(self.bytescale(img), mode="RGB").resize((self.target_size[1], self.target_size[0]), Image.LANCZOS)
-        a = np.asarray(im, dtype=np.uint8)[self.w_boff:self.w_eoff, self.h_boff:self.h_eoff, :]
-        chw = a.transpose(2, 0, 1)[::-1].astype(np.float32)  # channel swap (2,1,0): RGB -> BGR
-        return chw - self.mu
+        """host-side restatement of reference :113-134 (sentibank_preprocess below)"""
+        return sentibank_preprocess(img_buffer, self.mu, self.w_boff, self.w_eoff, self.h_boff, self.h_eoff, self.target_size)
 
     def featurize(self, img, bbox=None, img_type="buffer"):
         """reference :137-154 -> np.ndarray (4096,) float32; `bbox` is ignored there too"""

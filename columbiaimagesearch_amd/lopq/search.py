@@ -106,6 +106,35 @@ class LOPQSearcherBase(object):
     def get_cell(self, cell):
         raise NotImplementedError()
 
+    # -- the two public hooks of the base class (cufacesearch never calls them; third-party code may) ----------------------
+    def get_result_quota(self, x, quota=10):
+        """reference: lopq/lopq/search.py:110-135 -> (retrieved items, cells visited).  x is in LOPQ space (the
+        reference applies no PCA here either); cells come from the GPU multisequence, items from get_cell."""
+        retrieved = []
+        visited = 0
+        for _, cell in multisequence(x, self.model.Cs):
+            retrieved += self.get_cell(cell)
+            visited += 1
+            if len(retrieved) >= quota:
+                break
+        return retrieved, visited
+
+    def compute_distances(self, x, items):
+        """reference: lopq/lopq/search.py:137-177 -> [(dist, item)]: ADC tables (model.get_subquantizer_distances, HIP)
+        memoised per coarse cluster, the M entries of an item summed left to right in float64 like the reference's sum()."""
+        memo = [{}, {}]
+        results = []
+        for item in items:
+            coarse, fine = item[1]
+            c0, c1 = int(coarse[0]), int(coarse[1])
+            if c0 not in memo[0]:
+                memo[0][c0] = self.model.get_subquantizer_distances(x, (c0, c1), coarse_split=0)
+            if c1 not in memo[1]:
+                memo[1][c1] = self.model.get_subquantizer_distances(x, (c0, c1), coarse_split=1)
+            tables = memo[0][c0] + memo[1][c1]
+            results.append((sum([tables[i][fc] for i, fc in enumerate(fine)]), item))
+        return results
+
 
 class LOPQSearcherHIP(LOPQSearcherBase):
     def __init__(self, model, shard=None):

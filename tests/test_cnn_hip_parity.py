@@ -95,6 +95,36 @@ def test_batched_extractor_rows_match_single_image_rows(tmp_path, net_and_weight
         assert f.shape == (4096,) and abs(np.linalg.norm(f) - 1.0) < 1e-5
 
 
+def test_preprocess_pool_rows_equal_process_buffer_rows(tmp_path, net_and_weights):
+    """Worker processes decode / resize into the shared ring, one forward for the batch: rows identical (same strings)
+    to the per-image entry point; an undecodable buffer gets the failure row."""
+    import io
+    from PIL import Image
+    from columbiaimagesearch_amd.extractor import GenericExtractor
+    from columbiaimagesearch_amd.extractor.preprocess_pool import PreprocessPool
+    _, w = net_and_weights
+    np.savez(tmp_path / "w.npz", **w)
+    np.save(tmp_path / "mean.npy", np.zeros((3, 256, 256)) + 110.0)
+    conf = {"EX_sbcaffe_path": str(tmp_path / "w.npz"), "EX_imgmean_path": str(tmp_path / "mean.npy")}
+    ex = GenericExtractor("full", "sbpycaffe", "image", "ext", "EX_", conf)
+    rs = np.random.RandomState(4)
+    bufs = []
+    for i in range(7):
+        b = io.BytesIO()
+        Image.fromarray(rs.randint(0, 255, (200 + 17 * i, 300 - 11 * i, 3), dtype=np.uint8)).save(b, format="JPEG" if i % 2 else "PNG")
+        bufs.append(b.getvalue())
+    bufs.insert(3, b"garbage")
+    pool = PreprocessPool(ex.featurizer, workers=3, slots=5)  # fewer slots than images: two rounds
+    try:
+        rows = ex.process_batch(bufs, pool=pool)
+    finally:
+        pool.close()
+    assert rows[3] == ex.failed_out_dict()
+    for k, b in enumerate(bufs):
+        if k != 3:
+            assert rows[k] == ex.process_buffer(b), k
+
+
 def test_dlib_resnet_matches_torch_cpu(tmp_path):
     """dlib face ResNet (29 convolutions, residual adds with zero padding) vs the CPU restatement, synthetic weights."""
     from oracle import dlib_oracle as D
@@ -135,6 +165,60 @@ def test_dlib_direct_3x3_kernel_agrees_with_implicit_gemm(monkeypatch):
             # a face's descriptor does not depend on its place in the batch: same accumulation order at every position
             np.testing.assert_array_equal(net.forward(chips[n - 1:n])[0], got[n - 1]) if n <= 7 else None
         monkeypatch.delenv("CIS_CNN_DIRECT_CFG")
+
+
+@pytest.mark.parametrize("n", [128, 257, 512])
+def test_dlib_batch_in_concurrent_parts_equals_the_single_chain(monkeypatch, n):
+    """A batch of 128-512 chips runs as two parts on the handle's own streams (own workspaces, event fences on the caller's
+    stream).  Part p of the default forward must equal, bit for bit, the single-chain forward (CIS_CNN_PARTS=1) of the same
+    chips as their own batch (same batch size -> same tile / split-K choices); through the host entry point (NULL stream,
+    copy right behind the fences), through forward_dev on a side torch stream, and with 3 and 4 parts."""
+    import torch
+    from oracle import dlib_oracle as D
+    from columbiaimagesearch_amd.featurizer import DLibFaceNet
+    net = DLibFaceNet(D.synthetic_weights(1))
+    chips = D.synthetic_chips(n, seed=n)
+
+    def single_chain(lo, hi):
+        monkeypatch.setenv("CIS_CNN_PARTS", "1")
+        out = net.forward(chips[lo:hi])
+        monkeypatch.delenv("CIS_CNN_PARTS")
+        return out
+
+    for parts in (2, 3, 4):
+        want = np.concatenate([single_chain(n * p // parts, n * (p + 1) // parts) for p in range(parts)])
+        if parts == 2:
+            monkeypatch.delenv("CIS_CNN_PARTS", raising=False)  # the default route of this batch size
+        else:
+            monkeypatch.setenv("CIS_CNN_PARTS", str(parts))
+        got_host = net.forward(chips)
+        np.testing.assert_array_equal(got_host, want)
+        side = torch.cuda.Stream()
+        x = torch.as_tensor(chips).cuda()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            y = x * 1.0                       # earlier work on the caller's stream that the parts must wait for
+            out = net.forward_dev(y)
+            out2 = out + 0.0                  # later work on the caller's stream that must wait for every part
+        side.synchronize()
+        np.testing.assert_array_equal(out2.cpu().numpy(), want)
+        monkeypatch.delenv("CIS_CNN_PARTS", raising=False)
+    # against the single chain of the whole batch: same products, float32 summation order of the other tile choice
+    whole = single_chain(0, n)
+    np.testing.assert_allclose(got_host, whole, rtol=0, atol=3e-5 * np.abs(whole).max())
+    net.close()
+
+
+def test_sentibank_batch_in_concurrent_parts_equals_the_single_chain(monkeypatch, net_and_weights):
+    net, w = net_and_weights
+    from oracle import cnn_oracle as C
+    x = C.synthetic_images(9, seed=11)
+    for parts in (2, 3):
+        monkeypatch.setenv("CIS_CNN_PARTS", "1")
+        want = np.concatenate([net.forward(x[9 * p // parts: 9 * (p + 1) // parts]) for p in range(parts)])
+        monkeypatch.setenv("CIS_CNN_PARTS", str(parts))
+        np.testing.assert_array_equal(net.forward(x), want)
+    monkeypatch.delenv("CIS_CNN_PARTS")
 
 
 def test_batch_ingest_matches_per_item_chain():

@@ -197,6 +197,29 @@ def test_tiny_cells_ids_and_errors():
         s4.search_batch(np.zeros((1, 5)), quota=1)
 
 
+def test_public_hooks_get_result_quota_and_compute_distances():
+    """search.py:110-177 as callable hooks on the HIP searcher: same retrieved items / visited count / distances as the
+    oracle's dict index, and search() == sorted(compute_distances(get_result_quota()))[:limit]."""
+    from oracle import lopq_oracle as O
+    z, X, Q = load_golden("c1")
+    m = hip_model(z)
+    s = _build_searcher("c1", z, X, m)
+    oi = O.OracleIndex(O.OracleModel.from_npz(z))
+    coarse, fine = m.predict_batch(X)
+    oi.add_codes_arrays(coarse, fine)
+    for qi in range(3):
+        x = Q[qi]
+        items, visited = s.get_result_quota(x, quota=300)
+        want_items, want_visited = oi.get_result_quota(x, quota=300)
+        assert visited == want_visited and [i for i, _ in items] == [i for i, _ in want_items]
+        scored = s.compute_distances(x, items)
+        want = oi.compute_distances(x, want_items)
+        np.testing.assert_allclose([d for d, _ in scored], [d for d, _ in want], rtol=1e-9)
+        res, vis = s.search(x, quota=300, limit=20, with_dists=True)
+        top = sorted(scored, key=lambda t: t[0])[:20]
+        assert vis == visited and [r.id for r in res] == [it[0] for _, it in top]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("name", ["tiny", "c2"])
 def test_cell_sharded_search_equals_single(name, world):

@@ -296,3 +296,11 @@ def test_extractor_detector_rows(tmp_path):
         assert got.dtype == np.float64 and got.shape == (128,)
         np.testing.assert_allclose(got, ref, atol=2e-4)
     assert ex.process_buffer(bufs[0]) == rows[0]  # the reference's per-image entry point
+    # the chips of many images go through the network together (3 images x 2 detections in batches of 4 chips): same rows
+    ex.chip_batch = 4
+    many = ex.process_batch([bufs[0], bufs[1], bufs[0], b"x", bufs[0]])
+    assert many[0] == rows[0] and many[2] == rows[0] and many[4] == rows[0] and many[1] == rows[1] and many[3] == rows[2]
+    # Python-2 column names: the reference's "{}".format(score) printed 12 significant digits
+    from columbiaimagesearch_amd.extractor.generic_extractor import get_bbox_str
+    assert get_bbox_str({"left": 1, "top": 2, "right": 3, "bottom": 4, "score": 0.1 + 0.2}) == "1_2_3_4_0.3"
+    assert get_bbox_str({"left": 1, "top": 2, "right": 3, "bottom": 4, "score": 2.0}) == "1_2_3_4_2.0"
