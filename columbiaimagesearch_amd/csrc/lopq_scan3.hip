@@ -42,6 +42,11 @@ static __device__ __forceinline__ uint32_t pk_subsat_u16(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
 }
 
+// per 16-bit half: min(a, b)
+static __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
+
 static const int S3G = 4;  // queries per workgroup
 
 #ifdef CIS_S3_COUNTERS
@@ -1060,7 +1065,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 struct Slot4 {  // one slot's descriptor chain, resolved once (LDS)
     int item[S3G], tab0[S3G], tab1[S3G], q[S3G];
     float qinv[S3G];
-    int start_lo, start_hi, len, ng;  // ng < 0: the slot's items do not cover one chunk (-> fall-back list)
+    int start_lo, start_hi, len, ng;  // ng < 0: the slot's items do not cover one chunk: they run chunk by chunk (sub-slots)
+    int ist_lo[S3G], ist_hi[S3G], ilen[S3G];  // every item's own chunk (read for such slots only)
 };
 struct Scan4Shared {  // per query
     double inv_up, ub;
@@ -1130,25 +1136,28 @@ static const int S4_DS = 8;              // slot descriptors resolved per round
 static const int S4_LCAP = CIS_S4_LCAP;  // entries of a query's list
 static const int S4_NS = CIS_S4_NS;      // sample rows per chunk (64 sums per query each)
 
-static size_t scan4_lds(int M, int K) {
-    const size_t lists = (size_t)S3G * S4_LCAP * 4, samp = (size_t)S3G * S4_NS * 64 * 2;
-    return (size_t)K * M * S3G * 2 + (lists > samp ? lists : samp) + S3G * sizeof(Scan4Shared) + 32 + S4_DS * sizeof(Slot4);
+static const int S4_LCAP_LONG = 1016;    // list entries per query for long chunks (sixteen registers per lane in the verification)
+
+static size_t scan4_lds(int M, int K, int lcap) {
+    const size_t lists = (size_t)S3G * lcap * 4, samp = (size_t)S3G * S4_NS * 64 * 2;
+    return (size_t)K * M * S3G * 2 + (lists > samp ? lists : samp) + S3G * sizeof(Scan4Shared) + 96 + (S4_DS + 1) * sizeof(Slot4);
 }
 
-template <int M, int U, int NW, int WPE>
+template <int M, int U, int NW, int WPE, int LCAPT>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_adc_scan4(
     const WorkItem* __restrict__ items, const TabDesc* __restrict__ tabs, const int* __restrict__ slots,
     const int* __restrict__ n_slots_ptr, const float* __restrict__ T32, const uint8_t* __restrict__ codes, int K, int L, int S,
     int* __restrict__ dbg /* [2]: slots, fallbacks */, int* __restrict__ fhdr /* fall-back list: [17] = count (queue 0 of a scan3 header) */,
     int* __restrict__ fslots, uint64_t* __restrict__ item_surv, int* __restrict__ item_n, float* __restrict__ item_slack,
-    unsigned long long* __restrict__ qbound) {
+    unsigned long long* __restrict__ qbound, float zq /* sample rank margin: k - zq sqrt(k) */, int frac_den /* sample one row in frac_den */,
+    int nsx /* most sample rows per chunk */, int dyn /* slots from a counter instead of the static schedule */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int G = S3G;
     static_assert(NW == G, "one wave per query in the threshold and verification phases");
     static_assert(M == 4 || M == 8, "one float4 of every half table per thread");
     constexpr int nf = M / 2;
     constexpr uint32_t CAP = 65535u / M;
-    constexpr int LCAP = S4_LCAP, NS = S4_NS, NRV = (LCAP + 63) / 64;
+    constexpr int LCAP = LCAPT, NS = S4_NS, NRV = (LCAP + 63) / 64;
     constexpr size_t LIST_B = (size_t)G * LCAP * 4 > (size_t)G * NS * 64 * 2 ? (size_t)G * LCAP * 4 : (size_t)G * NS * 64 * 2;
     char* tab = smem;                                                            // [K][M][G] uint16
     uint32_t* lists = reinterpret_cast<uint32_t*>(smem + (size_t)K * M * G * 2);  // [G][LCAP] (sum << 16 | position)
@@ -1157,7 +1166,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     uint16_t* thr1 = reinterpret_cast<uint16_t*>(sh + G);  // [G] collection thresholds + 1, packed like the sums
     int* s_flag = reinterpret_cast<int*>(thr1 + 4);
     int* s_cnt = s_flag + 1;                               // [G] list cursors (the 4-lane atomic of the main pass)
-    Slot4* sd = reinterpret_cast<Slot4*>(reinterpret_cast<char*>(thr1) + 32);
+    int* wcnt = reinterpret_cast<int*>(reinterpret_cast<char*>(thr1) + 32);  // [G][NW] entries of the wave-private lists (long chunks)
+    Slot4* sd = reinterpret_cast<Slot4*>(reinterpret_cast<char*>(thr1) + 96);
+    constexpr bool WLISTS = LCAPT > 504;  // long chunks: every wave appends to its own quarter of a query's list (no LDS atomic in the loop)
+    constexpr int WCAP = LCAPT / NW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int total = n_slots_ptr[0];
@@ -1173,14 +1185,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     const long long k0 = S3_CLK();
     (void)k0;
     for (int kb = 0;; kb += S4_DS) {
-        if (slot_of(kb) < 0) break;  // wave-uniform
+        int dyn_j = -1;
+        if (WLISTS && dyn) {
+            // long chunks: a slot lasts ~100 us and slots differ (cells longer than a chunk run twice): the next slot comes from
+            // a counter instead of the static schedule, one per round
+            __syncthreads();
+            if (tid == 0) *s_flag = atomicAdd(&dbg[6], 1);
+            __syncthreads();
+            dyn_j = *s_flag;
+            if (dyn_j >= total) break;
+        } else {
+            if (slot_of(kb) < 0) break;  // wave-uniform
+        }
         __syncthreads();             // the previous round's descriptors and lists are dead
         if (tid < S4_DS) {           // one lane per slot walks the chain slot -> items -> table descriptors
             Slot4 d;
-            const int j = slot_of(kb + tid);
+            const int j = (WLISTS && dyn) ? (tid == 0 ? dyn_j : -1) : slot_of(kb + tid);
             d.ng = 0; d.len = 0; d.start_lo = d.start_hi = 0;
 #pragma unroll
-            for (int g = 0; g < G; ++g) { d.item[g] = 0; d.tab0[g] = 0; d.tab1[g] = 0; d.q[g] = 0; d.qinv[g] = 0.f; }
+            for (int g = 0; g < G; ++g) { d.item[g] = 0; d.tab0[g] = 0; d.tab1[g] = 0; d.q[g] = 0; d.qinv[g] = 0.f; d.ist_lo[g] = d.ist_hi[g] = d.ilen[g] = 0; }
             if (j >= 0) {
                 int idx[G];
                 int ng = 0;
@@ -1197,6 +1220,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     same = same && it->start == st0 && it->len == len0;
                     const int t0 = it->tab0, t1 = it->tab1;
                     d.item[g] = idx[g]; d.tab0[g] = t0; d.tab1[g] = t1; d.q[g] = it->q;
+                    d.ist_lo[g] = (int)(uint32_t)it->start; d.ist_hi[g] = (int)(it->start >> 32); d.ilen[g] = it->len;
                     float mxT = fmaxf(__int_as_float(tabs[t0].pad), __int_as_float(tabs[t1].pad));
                     mxT = fmaxf(mxT, 1e-30f);
                     float qi = ((float)CAP / mxT) * (1.0f - 9.5367431640625e-7f);  // as scan3_group: T32 * qinv stays below cap
@@ -1212,12 +1236,43 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         __syncthreads();
         for (int kk = 0; kk < S4_DS; ++kk) {
             const Slot4* d = &sd[kk];
+            const int ngs0 = __builtin_amdgcn_readfirstlane(d->ng);
+            if (ngs0 == 0) break;  // no more slots
+            // Items of different chunks in one slot (a cell longer than a chunk: its chunks share the slot key): the slot runs as
+            // sub-slots, one per chunk, each with the items of that chunk moved to the front of a scratch descriptor.
+            int remaining = ngs0 < 0 ? ((1 << (-ngs0)) - 1) : 0;
+            do {
+            if (ngs0 < 0) {
+                Slot4* ds = &sd[S4_DS];
+                if (tid == 0) {
+                    const Slot4* src = &sd[kk];
+                    int g0 = 0;
+                    while (!((remaining >> g0) & 1)) ++g0;
+                    int n = 0, rest = remaining;
+                    for (int h = g0; h < G; ++h) {
+                        if (((remaining >> h) & 1) && src->ist_lo[h] == src->ist_lo[g0] && src->ist_hi[h] == src->ist_hi[g0] && src->ilen[h] == src->ilen[g0]) {
+                            ds->item[n] = src->item[h]; ds->tab0[n] = src->tab0[h]; ds->tab1[n] = src->tab1[h]; ds->q[n] = src->q[h];
+                            ds->qinv[n] = src->qinv[h];
+                            ++n;
+                            rest &= ~(1 << h);
+                        }
+                    }
+                    for (int h = n; h < G; ++h) {
+                        ds->item[h] = ds->item[0]; ds->tab0[h] = ds->tab0[0]; ds->tab1[h] = ds->tab1[0]; ds->q[h] = ds->q[0]; ds->qinv[h] = ds->qinv[0];
+                    }
+                    ds->start_lo = src->ist_lo[g0]; ds->start_hi = src->ist_hi[g0]; ds->len = src->ilen[g0];
+                    ds->ng = n;
+                    ds->ist_lo[0] = rest;  // what is left for the next sub-slot
+                }
+                lds_barrier();
+                d = ds;
+                remaining = __builtin_amdgcn_readfirstlane(ds->ist_lo[0]);
+            }
             const int ngs = __builtin_amdgcn_readfirstlane(d->ng);
-            if (ngs == 0) break;  // no more slots
             const long long c0 = S3_CLK();
             (void)c0;
-            const int ng = ngs < 0 ? -ngs : ngs;
-            bool fail = ngs < 0;  // items of different chunks in one slot: the streaming form runs them one by one
+            const int ng = ngs;
+            bool fail = false;
             if (!fail) {
                 float qinv[G];
 #pragma unroll
@@ -1284,99 +1339,225 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)bhi << 32) | blo), 0, len * M, 0x00020000);
                 }
                 const int nrows = (len + 63) >> 6;
-                // sample rows: t * nrows / ns for t < ns = min(nrows, NS) (all rows when the chunk has <= NS of them)
-                const int ns = nrows < NS ? nrows : NS;
-                // the sample's code rows travel while the tables are staged
-                constexpr int SPW = NS / NW;  // sample rows per wave
-                static_assert(NS % (2 * NW) == 0, "sample rows come in pairs per wave");
-                CodeWords<M> sc[SPW];
-                int srow[SPW];
+                constexpr bool MULTI = LCAPT > 504;  // long chunks: a tenth of the rows as the sample, bucket minima instead of the sums
+                if constexpr (!MULTI) {
+                    // sample rows: t * nrows / ns for t < ns = min(nrows, NS) (all rows when the chunk has <= NS of them)
+                    const int ns = nrows < NS ? nrows : NS;
+                    // the sample's code rows travel while the tables are staged
+                    constexpr int SPW = NS / NW;  // sample rows per wave
+                    static_assert(NS % (2 * NW) == 0, "sample rows come in pairs per wave");
+                    CodeWords<M> sc[SPW];
+                    int srow[SPW];
 #pragma unroll
-                for (int i = 0; i < SPW; ++i) {
-                    const int t = SPW * w + i;
-                    srow[i] = t < ns ? (int)(((int64_t)t * nrows) / ns) : nrows;
-                    sc[i] = load_code_buf<M>(rs, srow[i] * 64 + lane);  // rows past the chunk read zeros (masked below)
-                }
-                S3_CTR(11, S3_CLK() - c0);
-                lds_barrier();  // B1: tables and scales visible
-                S3_CTR(2, S3_CLK() - c0);
-                // ---- sample pass: wave w computes sample rows 2w, 2w+1; an absent sample leaves 0xffff -------------------------------
-                {
-                    u32x2_t dd[SPW];
+                    for (int i = 0; i < SPW; ++i) {
+                        const int t = SPW * w + i;
+                        srow[i] = t < ns ? (int)(((int64_t)t * nrows) / ns) : nrows;
+                        sc[i] = load_code_buf<M>(rs, srow[i] * 64 + lane);  // rows past the chunk read zeros (masked below)
+                    }
+                    S3_CTR(11, S3_CLK() - c0);
+                    lds_barrier();  // B1: tables and scales visible
+                    S3_CTR(2, S3_CLK() - c0);
+                    // ---- sample pass: wave w computes sample rows 2w, 2w+1; an absent sample leaves 0xffff -------------------------------
+                    {
+                        u32x2_t dd[SPW];
 #if defined(CIS_S4_PROBE) && CIS_S4_PROBE >= 3
-                    for (int u = 0; u < SPW; ++u) { dd[u][0] = 0xffffffffu; dd[u][1] = 0xffffffffu; }  // probe: no sample pass
+                        for (int u = 0; u < SPW; ++u) { dd[u][0] = 0xffffffffu; dd[u][1] = 0xffffffffu; }  // probe: no sample pass
 #else
-                    adc16_rows<M, SPW, S4_OCT>(sc, tab, rc, dd);
+                        adc16_rows<M, SPW, S4_OCT>(sc, tab, rc, dd);
 #endif
 #pragma unroll
-                    for (int u = 0; u < SPW; ++u) {
-                        const int t = SPW * w + u;
-                        const bool ok = (t < ns) && (srow[u] * 64 + lane < len);
+                        for (int u = 0; u < SPW; ++u) {
+                            const int t = SPW * w + u;
+                            const bool ok = (t < ns) && (srow[u] * 64 + lane < len);
 #pragma unroll
-                        for (int g = 0; g < G; ++g) {
-                            const uint32_t sg = (g & 1) ? (dd[u][g >> 1] >> 16) : (dd[u][g >> 1] & 0xffffu);
+                            for (int g = 0; g < G; ++g) {
+                                const uint32_t sg = (g & 1) ? (dd[u][g >> 1] >> 16) : (dd[u][g >> 1] & 0xffffu);
 #if defined(CIS_S4_PROBE) && CIS_S4_PROBE >= 3
-                            samp[g * (NS * 64) + t * 64 + lane] = (uint16_t)0xffffu;
+                                samp[g * (NS * 64) + t * 64 + lane] = (uint16_t)0xffffu;
 #else
-                            samp[g * (NS * 64) + t * 64 + lane] = (uint16_t)(ok ? sg : 0xffffu);
+                                samp[g * (NS * 64) + t * 64 + lane] = (uint16_t)(ok ? sg : 0xffffu);
 #endif
+                            }
                         }
                     }
-                }
-                lds_barrier();  // B2
-                S3_CTR(3, S3_CLK() - c0);
-                // ---- thresholds: wave g serves query g ---------------------------------------------------------------------------------
-                {
-                    const int g = w;
-                    uint32_t sv[NS];
-                    int nsam = 0;
+                    lds_barrier();  // B2
+                    S3_CTR(3, S3_CLK() - c0);
+                    // ---- thresholds: wave g serves query g ---------------------------------------------------------------------------------
+                    {
+                        const int g = w;
+                        uint32_t sv[NS];
+                        int nsam = 0;
 #pragma unroll
-                    for (int r = 0; r < NS; ++r) {
-                        sv[r] = samp[g * (NS * 64) + r * 64 + lane];
-                        nsam += __popcll(__ballot(sv[r] != 0xffffu));
-                    }
-                    // sample rank: k - z sqrt(k) >= L * nsam / len (all rows sampled: the L-th smallest itself, exact)
-                    const bool exact = ns == nrows;
-                    int ksv = L;
-                    if (!exact) {
-                        const float need = (float)L * (float)nsam / (float)len;
-                        const float hz = 0.5f * CIS_S4_Z;
-                        const float rt = hz + sqrtf(hz * hz + need);  // root of k - z sqrt(k) = need
-                        ksv = (int)(rt * rt) + 1;
-                    }
-                    uint32_t tau = 65534u;
-                    bool have_bound = false;
-                    if (g < ng && nsam >= ksv) {  // wave-uniform
-                        uint32_t lo = 0u, hi = 65534u;
-                        while (lo < hi) {
-                            const uint32_t p = lo + ((hi - lo) >> 1);
-                            int c = 0;
+                        for (int r = 0; r < NS; ++r) {
+                            sv[r] = samp[g * (NS * 64) + r * 64 + lane];
+                            nsam += __popcll(__ballot(sv[r] != 0xffffu));
+                        }
+                        // sample rank: k - z sqrt(k) >= L * nsam / len (all rows sampled: the L-th smallest itself, exact)
+                        const bool exact = ns == nrows;
+                        int ksv = L;
+                        if (!exact) {
+                            const float need = (float)L * (float)nsam / (float)len;
+                            const float hz = 0.5f * zq;
+                            const float rt = hz + sqrtf(hz * hz + need);  // root of k - z sqrt(k) = need
+                            ksv = (int)(rt * rt) + 1;
+                        }
+                        uint32_t tau = 65534u;
+                        bool have_bound = false;
+                        if (g < ng && nsam >= ksv) {  // wave-uniform
+                            uint32_t lo = 0u, hi = 65534u;
+                            while (lo < hi) {
+                                const uint32_t p = lo + ((hi - lo) >> 1);
+                                int c = 0;
 #pragma unroll
-                            for (int r = 0; r < NS; ++r) c += __popcll(__ballot(sv[r] <= p));  // (absent samples are 0xffff > p)
-                            if (c >= ksv) hi = p;
-                            else lo = p + 1;
+                                for (int r = 0; r < NS; ++r) c += __popcll(__ballot(sv[r] <= p));  // (absent samples are 0xffff > p)
+                                if (c >= ksv) hi = p;
+                                else lo = p + 1;
+                            }
+                            tau = lo;
+                            have_bound = tau < 65534u;
                         }
-                        tau = lo;
-                        have_bound = tau < 65534u;
-                    }
-                    if (lane == 0) {
-                        uint32_t keep = 65534u;
-                        if (have_bound) {
-                            keep = tau + (uint32_t)M + 1u;  // a sum brackets its distance to within M units (two-pass form above)
-                            keep = keep < 65534u ? keep : 65534u;
-                        }
-                        const uint32_t t_ext = (g < ng) ? bound_to_thr(sh[g].ext, sh[g].inv_up) : 0u;
-                        const uint32_t t = keep < t_ext ? keep : t_ext;
-                        thr1[g] = (uint16_t)((g < ng) ? t + 1u : 0u);
+                        if (lane == 0) {
+                            uint32_t keep = 65534u;
+                            if (have_bound) {
+                                keep = tau + (uint32_t)M + 1u;  // a sum brackets its distance to within M units (two-pass form above)
+                                keep = keep < 65534u ? keep : 65534u;
+                            }
+                            const uint32_t t_ext = (g < ng) ? bound_to_thr(sh[g].ext, sh[g].inv_up) : 0u;
+                            const uint32_t t = keep < t_ext ? keep : t_ext;
+                            thr1[g] = (uint16_t)((g < ng) ? t + 1u : 0u);
 #if defined(CIS_S4_PROBE) && CIS_S4_PROBE == 1
-                        thr1[g] = 0;  // probe: nothing passes
+                            thr1[g] = 0;  // probe: nothing passes
 #endif
-                        sh[g].tau = tau;
-                        // keep < t_ext: the threshold rests on the sample (exact when every row was sampled, else to be verified)
-                        sh[g].verify = (have_bound && keep < t_ext && !exact) ? 1 : 0;
+                            sh[g].tau = tau;
+                            // keep < t_ext: the threshold rests on the sample (exact when every row was sampled, else to be verified)
+                            sh[g].verify = (have_bound && keep < t_ext && !exact) ? 1 : 0;
 #if defined(CIS_S4_PROBE)
-                        sh[g].verify = 0;
+                            sh[g].verify = 0;
 #endif
+                        }
+                    }
+                } else {
+                    // Sample rows: t * nrows / ns for t < ns; ns = about one row in frac_den, at least NS and at most S4_NSX rows, all
+                    // rows when the chunk has no more than that.  The waves keep, per lane and query, the MINIMUM of the sample sums
+                    // they computed: 4 x 64 bucket minima per query instead of the sums themselves.  count(buckets <= v) <=
+                    // count(samples <= v), so the k-th smallest bucket minimum is an upper bound of the k-th smallest sample sum:
+                    // a threshold taken from the buckets is never tighter than the one the whole sample would give, costs one packed
+                    // min per row and a bisection over four registers, and needs 2 KB of LDS whatever the sample size.
+                    int ns = nrows / frac_den;
+                    ns = ns < NS ? NS : ns;
+                    ns = ns > nsx ? nsx : ns;
+                    ns = ns < nrows ? ns : nrows;
+                    constexpr int SPW = 4;  // sample rows per wave and round
+                    const int rounds = (ns + NW * SPW - 1) / (NW * SPW);
+                    // the first round's code rows travel while the tables are staged
+                    CodeWords<M> sc[SPW];
+                    int srow[SPW];
+#pragma unroll
+                    for (int i = 0; i < SPW; ++i) {
+                        const int t = SPW * w + i;
+                        srow[i] = t < ns ? (int)(((int64_t)t * nrows) / ns) : nrows;
+                        sc[i] = load_code_buf<M>(rs, srow[i] * 64 + lane);  // rows past the chunk read zeros (masked below)
+                    }
+                    S3_CTR(11, S3_CLK() - c0);
+                    lds_barrier();  // B1: tables and scales visible
+                    S3_CTR(2, S3_CLK() - c0);
+                    // ---- sample pass --------------------------------------------------------------------------------------------------------
+                    {
+                        uint32_t bm0 = 0xffffffffu, bm1 = 0xffffffffu;
+#pragma unroll 1
+                        for (int r = 0; r < rounds; ++r) {
+                            CodeWords<M> nsc[SPW];
+                            int nrow[SPW];
+                            if constexpr (MULTI) {
+                                if (r + 1 < rounds) {
+#pragma unroll
+                                    for (int i = 0; i < SPW; ++i) {
+                                        const int t = ((r + 1) * NW + w) * SPW + i;
+                                        nrow[i] = t < ns ? (int)(((int64_t)t * nrows) / ns) : nrows;
+                                        nsc[i] = load_code_buf<M>(rs, nrow[i] * 64 + lane);
+                                    }
+                                }
+                            }
+                            u32x2_t dd[SPW];
+#if defined(CIS_S4_PROBE) && CIS_S4_PROBE >= 3
+                            for (int u = 0; u < SPW; ++u) { dd[u][0] = 0xffffffffu; dd[u][1] = 0xffffffffu; }  // probe: no sample pass
+#else
+                            adc16_rows<M, SPW, S4_OCT>(sc, tab, rc, dd);
+#endif
+#pragma unroll
+                            for (int u = 0; u < SPW; ++u) {
+                                const bool ok = srow[u] < nrows && (srow[u] * 64 + lane < len);
+                                bm0 = pk_min_u16(bm0, ok ? dd[u][0] : 0xffffffffu);
+                                bm1 = pk_min_u16(bm1, ok ? dd[u][1] : 0xffffffffu);
+                            }
+                            if constexpr (MULTI) {
+                                if (r + 1 < rounds) {
+#pragma unroll
+                                    for (int i = 0; i < SPW; ++i) { sc[i] = nsc[i]; srow[i] = nrow[i]; }
+                                }
+                            }
+                        }
+                        u32x2_t bm;
+                        bm[0] = bm0; bm[1] = bm1;
+                        reinterpret_cast<u32x2_t*>(samp)[w * 64 + lane] = bm;  // [NW][64] x four queries
+                    }
+                    lds_barrier();  // B2
+                    S3_CTR(3, S3_CLK() - c0);
+                    // ---- thresholds: wave g serves query g ---------------------------------------------------------------------------------
+                    {
+                        const int g = w;
+                        uint32_t sv[NW];
+#pragma unroll
+                        for (int r = 0; r < NW; ++r) {
+                            const u32x2_t x = reinterpret_cast<const volatile u32x2_t*>(samp)[r * 64 + lane];
+                            const uint32_t xw = (g >> 1) ? x[1] : x[0];
+                            sv[r] = (g & 1) ? (xw >> 16) : (xw & 0xffffu);
+                        }
+                        // every sampled row is full but the chunk's last one, which is sampled only when all rows are
+                        const bool all = ns == nrows;
+                        const int nsam = all ? len : ns * 64;
+                        // sample rank: k - z sqrt(k) >= L * nsam / len (all rows sampled: the L-th smallest bucket is a valid bound)
+                        int ksv = L;
+                        if (!all) {
+                            const float need = (float)L * (float)nsam / (float)len;
+                            const float hz = 0.5f * zq;
+                            const float rt = hz + sqrtf(hz * hz + need);  // root of k - z sqrt(k) = need
+                            ksv = (int)(rt * rt) + 1;
+                        }
+                        uint32_t tau = 65534u;
+                        bool have_bound = false;
+                        if (g < ng && nsam >= ksv) {  // wave-uniform
+                            uint32_t lo = 0u, hi = 65534u;
+                            while (lo < hi) {
+                                const uint32_t p = lo + ((hi - lo) >> 1);
+                                int c = 0;
+#pragma unroll
+                                for (int r = 0; r < NW; ++r) c += __popcll(__ballot(sv[r] <= p));  // (empty buckets are 0xffff > p)
+                                if (c >= ksv) hi = p;
+                                else lo = p + 1;
+                            }
+                            tau = lo;
+                            have_bound = tau < 65534u;
+                        }
+                        if (lane == 0) {
+                            uint32_t keep = 65534u;
+                            if (have_bound) {
+                                keep = tau + (uint32_t)M + 1u;  // a sum brackets its distance to within M units (two-pass form above)
+                                keep = keep < 65534u ? keep : 65534u;
+                            }
+                            const uint32_t t_ext = (g < ng) ? bound_to_thr(sh[g].ext, sh[g].inv_up) : 0u;
+                            const uint32_t t = keep < t_ext ? keep : t_ext;
+                            thr1[g] = (uint16_t)((g < ng) ? t + 1u : 0u);
+#if defined(CIS_S4_PROBE) && CIS_S4_PROBE == 1
+                            thr1[g] = 0;  // probe: nothing passes
+#endif
+                            sh[g].tau = tau;
+                            // keep < t_ext: the threshold rests on the sample (valid by itself when every row was sampled, else to be verified)
+                            sh[g].verify = (have_bound && keep < t_ext && !all) ? 1 : 0;
+#if defined(CIS_S4_PROBE)
+                            sh[g].verify = 0;
+#endif
+                        }
                     }
                 }
                 lds_barrier();  // B3: thresholds set, the sample is dead (its memory is the lists from here on)
@@ -1396,6 +1577,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
                         for (int u = 0; u < U; ++u) nx[u] = load_code_buf<M>(rs, w * 64 * U + u * 64 + lane);
                     }
+                    int wcur[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) wcur[g] = 0;
                     for (int iter = w; iter < nit; iter += NW) {
                         const int base = iter * 64 * U;
                         CodeWords<M> cur[U];
@@ -1414,6 +1598,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                             const int n = len - base - u * 64;
                             if (n < 64) am &= n <= 0 ? 0ull : ((1ull << n) - 1ull);
                             if (am == 0ull) continue;  // scalar branch
+                            if constexpr (WLISTS) {
+#pragma unroll
+                                for (int g = 0; g < G; ++g) {
+                                    const uint32_t sg = (g & 1) ? (dd[u][g >> 1] >> 16) : (dd[u][g >> 1] & 0xffffu);
+                                    const uint32_t t1 = (g & 1) ? ((g >> 1) ? s23 >> 16 : s01 >> 16) : ((g >> 1) ? s23 & 0xffffu : s01 & 0xffffu);
+                                    const unsigned long long mg = __ballot(sg < t1) & am;
+                                    if (mg == 0ull) continue;
+                                    const int idx = __builtin_amdgcn_mbcnt_hi((unsigned)(mg >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mg, wcur[g]));
+                                    if (((mg >> lane) & 1ull) && idx < WCAP) lists[(g * NW + w) * WCAP + idx] = (sg << 16) | (uint32_t)(base + u * 64 + lane);
+                                    wcur[g] += __popcll(mg);
+                                }
+                                continue;
+                            }
                             unsigned long long m[G];
                             int mine = 0;  // lane g: the places query g needs
 #pragma unroll
@@ -1435,6 +1632,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                             }
                         }
                     }
+                    if constexpr (WLISTS) {
+                        if (lane < G) {
+                            int c = wcur[0];
+#pragma unroll
+                            for (int g = 1; g < G; ++g) c = (lane == g) ? wcur[g] : c;
+                            wcnt[lane * NW + w] = c;
+                        }
+                    }
                 }
                 S3_CTR(12, S3_CLK() - c0);
                 lds_barrier();  // B4: lists complete
@@ -1443,15 +1648,34 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                 bool bad = false;
                 if (w < ng) {
                     const int g = w;
-                    const int tot = s_cnt[g];
-                    bad = tot > LCAP;  // the list overflowed (a crowd of equal sums, or a threshold far too loose)
+                    int tot = 0;
+                    int wtot[NW];
+                    if constexpr (WLISTS) {
+#pragma unroll
+                        for (int r = 0; r < NW; ++r) {
+                            wtot[r] = wcnt[g * NW + r];
+                            bad = bad || wtot[r] > WCAP;  // a wave's quarter overflowed
+                            tot += wtot[r];
+                        }
+                    } else {
+                        tot = s_cnt[g];
+                        bad = tot > LCAP;  // the list overflowed (a crowd of equal sums, or a threshold far too loose)
+                    }
+                    if (bad && lane == 0) atomicAdd(&dbg[2], 1);
                     if (!bad) {
                         uint32_t ent[NRV];
                         bool val[NRV];
 #pragma unroll
                         for (int r = 0; r < NRV; ++r) {
-                            val[r] = r * 64 + lane < tot;
-                            ent[r] = val[r] ? lists[g * LCAP + r * 64 + lane] : 0xffffffffu;
+                            if constexpr (WLISTS) {
+                                constexpr int RW = NRV / NW;  // registers per wave quarter
+                                const int e = (r % RW) * 64 + lane;
+                                val[r] = e < wtot[r / RW];
+                                ent[r] = val[r] ? lists[(g * NW + r / RW) * WCAP + e] : 0xffffffffu;
+                            } else {
+                                val[r] = r * 64 + lane < tot;
+                                ent[r] = val[r] ? lists[g * LCAP + r * 64 + lane] : 0xffffffffu;
+                            }
                         }
                         const uint32_t tau = sh[g].tau;
                         if (sh[g].verify) {
@@ -1459,6 +1683,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
                             for (int r = 0; r < NRV; ++r) nle += __popcll(__ballot(val[r] && (ent[r] >> 16) <= tau));
                             bad = nle < L;
+                            if (bad && lane == 0) atomicAdd(&dbg[3], 1);
                         }
                         if (!bad) {
                             uint32_t cut = 65535u;
@@ -1489,16 +1714,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                             }
                             const int item = __builtin_amdgcn_readfirstlane(d->item[g]);
                             uint64_t* out = item_surv + (int64_t)item * S;
-                            int kept = 0;
+                            if constexpr (LCAP > 504) {  // an item's survivor row holds S entries: a crowd of sums at the cut goes to the forms that handle crowds
+                                int nk = 0;
 #pragma unroll
-                            for (int r = 0; r < NRV; ++r) {
-                                const bool kp = val[r] && (ent[r] >> 16) <= cut;
-                                const unsigned long long mk = __ballot(kp);
-                                const int idx = kept + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
-                                if (kp) out[idx] = ((uint64_t)(ent[r] >> 16) << 32) | (ent[r] & 0xffffu);
-                                kept += __popcll(mk);
+                                for (int r = 0; r < NRV; ++r) nk += __popcll(__ballot(val[r] && (ent[r] >> 16) <= cut));
+                                bad = nk > S;
+                                if (bad && lane == 0) atomicAdd(&dbg[4], 1);
                             }
-                            if (lane == 0) item_n[item] = kept;
+                            if (!bad) {
+                                int kept = 0;
+#pragma unroll
+                                for (int r = 0; r < NRV; ++r) {
+                                    const bool kp = val[r] && (ent[r] >> 16) <= cut;
+                                    const unsigned long long mk = __ballot(kp);
+                                    const int idx = kept + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
+                                    if (kp) out[idx] = ((uint64_t)(ent[r] >> 16) << 32) | (ent[r] & 0xffffu);
+                                    kept += __popcll(mk);
+                                }
+                                if (lane == 0) item_n[item] = kept;
+                            }
                         }
                     }
                     if (bad && lane == 0) *s_flag = 1;
@@ -1510,15 +1744,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
             S3_CTR(0, 1);
             if (tid == 0) {
                 atomicAdd(&dbg[0], 1);
+                if (ngs0 < 0) atomicAdd(&dbg[5], 1);
                 if (fail) {
-                    // the sample misjudged the chunk, a crowd of equal sums, or items of different chunks: the slot goes to the forms that
-                    // need no sample (their output replaces whatever this slot wrote)
+                    // the sample misjudged the chunk, or a crowd of equal sums: the (sub-)slot goes to the forms that need no sample
+                    // (their output replaces whatever this slot wrote)
                     atomicAdd(&dbg[1], 1);
                     const int f = atomicAdd(&fhdr[17], 1);
 #pragma unroll
                     for (int g = 0; g < G; ++g) fslots[f * G + g] = g < ng ? d->item[g] : -1;
                 }
             }
+            } while (remaining != 0);
         }
     }
     S3_CTR(9, S3_CLK() - k0);
@@ -1545,9 +1781,15 @@ Scan3Geom scan3_geom(int M, int K, int L, int64_t avg_chunk, int force_two_pass)
     // the sampled form's lists hold 376 sums per query: chunks of a few thousand candidates at limit <= 128 (a looser sample
     // threshold overflows them and the slot is scanned again by the two-pass form)
     if (g.two_pass == 1 && L <= 128 && avg_chunk < 6144) g.two_pass = 2;
+    // long chunks (tens of thousands of candidates): the sampled form as well, with a tenth of the rows as the sample, lists
+    // of 1016 entries (the sample threshold lets ~4 L candidates through) and a wider rank margin (a list that fails its
+    // verification costs a whole streaming-form slot in the fall-back launch)
+    g.long_chunks = avg_chunk >= 6144 ? 1 : 0;
+    if (g.two_pass == 0 && g.long_chunks && M <= 8 && L <= 128) g.two_pass = 2;
     if (const char* e = getenv("CIS_SCAN3_TWOPASS")) g.two_pass = atoi(e);
     if (force_two_pass >= 0) g.two_pass = force_two_pass;  // scan modes 3 / 4 / 5 (tests)
-    if (g.two_pass == 2 && M > 8) g.two_pass = 1;
+    if (g.two_pass == 2 && M > 8) g.two_pass = g.long_chunks ? 0 : 1;
+    if (g.two_pass == 1 && g.long_chunks && force_two_pass < 0) g.two_pass = 0;  // the histogram atomics of the two-pass form contend on long chunks
     if (g.two_pass < 0 || g.two_pass > 2) g.two_pass = 0;
     g.S = g.NW * (NR * 64 - 8);
     g.lds = (size_t)K * M * g.G * 2 + (size_t)g.G * g.NW * (NR * 64 - 8) * 4 + g.G * sizeof(Scan3Shared) + 32 + 16;
@@ -1570,21 +1812,44 @@ static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, 
         if (g.two_pass == 2) {
             // k_adc_scan4, then the slots it could not settle (normally none) through this kernel's two-pass form: the fall-back
             // list is a second slot header (fhdr: queue counters [0..7], queue starts [16..24] of which only [17] = count is used)
-            constexpr int WPE4 = CIS_S4_WPE;
-            const size_t lds4 = scan4_lds(M, K);
-            const int by_lds4 = (int)(163840 / lds4);
-            const int per_cu4 = by_lds4 < WPE4 ? by_lds4 : WPE4;
-            const int64_t resident4 = 256 * (per_cu4 < 1 ? 1 : per_cu4);
-            const unsigned grid4 = (unsigned)(want < resident4 ? ((want + 7) / 8) * 8 : resident4);
-            hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_U, NW, WPE4>), dim3(grid4), dim3(NW * 64), lds4, st, items, tabs, slots, n_slots, T32, codes,
-                               K, L, g.S, qctr + 9, fhdr, fslots, hits, hitn, slack, qbound);
-            if (getenv("CIS_SCAN4_DEBUG")) {  // diagnosis: how many slots the sample misjudged (blocks)
-                int h[2] = {0, 0};
-                if (hipMemcpyAsync(h, qctr + 9, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
-                    fprintf(stderr, "[cis] k_adc_scan4: %d slots, %d to the fall-back list\n", h[0], h[1]);
+            // read per call (A/B runs and the fall-back tests set them between calls)
+            const float z_short = getenv("CIS_S4_ZS") ? (float)atof(getenv("CIS_S4_ZS")) : CIS_S4_Z;
+            // long chunks, measured on C4 (profiles/r03m_scan_long.txt): z 4 / 4.5 / 5 -> 0.326 / 0.332 / 0.335 ms, no verification
+            // failure in 100 k lists at z = 4; static schedule 0.301 against 0.326 ms with slots from a counter; one row in 8 / 10 /
+            // 16 as the sample -> 0.321 / 0.326 / 0.45 ms; at most 128 sample rows (64: the 65536-candidate chunks overflow their lists)
+            const float z_long = getenv("CIS_S4_ZL") ? (float)atof(getenv("CIS_S4_ZL")) : 4.5f;
+            const int frac_long = getenv("CIS_S4_FRAC") ? atoi(getenv("CIS_S4_FRAC")) : 8;
+            const int nsx_long = getenv("CIS_S4_NSX") ? atoi(getenv("CIS_S4_NSX")) : 128;
+            const int dyn_long = getenv("CIS_S4_DYN") ? atoi(getenv("CIS_S4_DYN")) : 0;
+            int* dbg4 = qctr + 9;
+            if (!g.long_chunks) {
+                constexpr int WPE4 = CIS_S4_WPE;
+                const size_t lds4 = scan4_lds(M, K, S4_LCAP);
+                const int by_lds4 = (int)(163840 / lds4);
+                const int per_cu4 = by_lds4 < WPE4 ? by_lds4 : WPE4;
+                const int64_t resident4 = 256 * (per_cu4 < 1 ? 1 : per_cu4);
+                const unsigned grid4 = (unsigned)(want < resident4 ? ((want + 7) / 8) * 8 : resident4);
+                hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_U, NW, WPE4, S4_LCAP>), dim3(grid4), dim3(NW * 64), lds4, st, items, tabs, slots, n_slots,
+                                   T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_short, 1 << 20, S4_NS, 0);
+            } else {
+                constexpr int WPE4 = 4;
+                const size_t lds4 = scan4_lds(M, K, S4_LCAP_LONG);
+                const int by_lds4 = (int)(163840 / lds4);
+                const int per_cu4 = by_lds4 < WPE4 ? by_lds4 : WPE4;
+                const int64_t resident4 = 256 * (per_cu4 < 1 ? 1 : per_cu4);
+                const unsigned grid4 = (unsigned)(want < resident4 ? ((want + 7) / 8) * 8 : resident4);
+                hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_U, NW, WPE4, S4_LCAP_LONG>), dim3(grid4), dim3(NW * 64), lds4, st, items, tabs, slots,
+                                   n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_long, frac_long, nsx_long, dyn_long);
             }
+            if (getenv("CIS_SCAN4_DEBUG")) {  // diagnosis: how many slots the sample misjudged (blocks)
+                int h[6] = {0, 0, 0, 0, 0, 0};
+                if (hipMemcpyAsync(h, qctr + 9, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+                    fprintf(stderr, "[cis] k_adc_scan4: %d slots, %d to the fall-back list (lists: %d overflowed, %d failed the verification, %d crowds at the cut; %d slots with items of different chunks)\n",
+                            h[0], h[1], h[2], h[3], h[4], h[5]);
+            }
+            // the slots it could not settle: the two-pass form for short chunks, the streaming form for long ones
             hipLaunchKernelGGL((k_adc_scan3<M, NR, U, NW, WPE>), dim3(256), dim3(NW * 64), g.lds, st, items, tabs, fslots, fhdr + 8, T, T32,
-                               codes, K, L, g.S, fhdr, hits, hitn, slack, qbound, 1, 1);
+                               codes, K, L, g.S, fhdr, hits, hitn, slack, qbound, g.long_chunks ? 0 : 1, 1);
             return;
         }
     }

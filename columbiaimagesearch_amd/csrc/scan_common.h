@@ -228,7 +228,7 @@ __device__ __forceinline__ CodeWords<M> load_code_buf(__amdgpu_buffer_rsrc_t rs,
 }
 
 // ---- ADC scan v3 (lopq_scan3.hip): 16-bit fixed-point tables, four queries per workgroup ---------------------------
-struct Scan3Geom { int G, NW, U, S, two_pass; size_t lds; };
+struct Scan3Geom { int G, NW, U, S, two_pass, long_chunks; size_t lds; };
 bool scan3_supported(int M, int K, int L);
 Scan3Geom scan3_geom(int M, int K, int L, int64_t avg_chunk /* candidates per work item of the batch */,
                      int force_two_pass /* -1: by chunk length, 0: streaming form, 1: two-pass form */);

@@ -11,12 +11,14 @@ Item ids may be any hashable (the reference uses ``sha1[_bbox]`` strings,
 cufacesearch/indexer/hbase_indexer_minimal.py:816): integers travel to the device as they are,
 everything else is mapped to an integer slot here.
 """
+import os
 from collections import namedtuple
 from itertools import count
 
 import numpy as np
 
 from .. import _lib
+from . import kvlog
 from .model import LOPQCode, LOPQModel, LOPQModelPCA, _code_dtype
 
 _SLOT_BASE = 1 << 62  # device ids >= this are slots of non-integer caller ids
@@ -510,9 +512,10 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
     ``array('H')`` :425-427) followed by ``bytes(id)`` (:462, the py2 ``str`` of the id); ``put`` REPLACES an existing
     key (:465, last write wins -- the dict searcher keeps the first); ``get_cell`` walks the keys in byte order
     (:482-499), so items of a cell -- and therefore results with equal distances -- come in key order; ids come back
-    through ``id_lambda``.  The key/value store lives on the host (a dict; mirrored into LMDB at ``lmdb_path`` when the
-    ``lmdb`` module is importable, which it is not in the build image, so persistence is untested); the device index is
-    rebuilt in key order before the first search after an insert."""
+    through ``id_lambda``.  The key/value store lives on the host (a dict) and is PERSISTENT at ``lmdb_path``: in LMDB when
+    the ``lmdb`` module is importable (the reference's own files), otherwise in an append-only log of the same key / value
+    bytes (lopq/kvlog.py) -- a restart re-opens the index (cold start tested in tests/test_reference_surfaces.py); the
+    device index is rebuilt in key order before the first search after an insert."""
 
     def __init__(self, model, lmdb_path=None, id_lambda=int):
         super(LOPQSearcherLMDB, self).__init__()
@@ -523,18 +526,39 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
         self._dev = None   # LOPQSearcherHIP over the key-ordered arrays
         self._suffix_of_slot = []
         self.env = None
+        self._log = None   # kvlog.KVLog: the persistent form when the lmdb module is not installed
         if lmdb_path is not None:
             try:
                 import lmdb
             except ImportError:
                 lmdb = None
-            if lmdb is not None:
+            if lmdb is not None and not os.path.exists(os.path.join(str(lmdb_path), kvlog.FILE_NAME)):
                 self.env = lmdb.open(self.lmdb_path, map_size=1024 * 1000000 * 32, max_dbs=1)  # :416
                 self.index_db = self.env.open_db(b"index")
                 with self.env.begin(db=self.index_db) as txn:
                     for key, value in txn.cursor():
                         self._store.setdefault(self.decode_cell(key[:4]), {})[bytes(key[4:])] = self.decode_fine_codes(value)
+            else:
+                # cold start from the log: same keys, same values, later records replace earlier ones (put semantics)
+                self._log = kvlog.KVLog(str(lmdb_path))
+                for key, value in self._log.load():
+                    self._store.setdefault(self.decode_cell(key[:4]), {})[bytes(key[4:])] = self.decode_fine_codes(value)
         self.nb_indexed = sum(len(v) for v in self._store.values())
+
+    def close(self):
+        """Flush and release the persistent store (a log with many replaced keys is compacted first)."""
+        if self._log is not None:
+            live = self.get_nb_indexed()
+            if self._log.records > 2 * max(live, 1):
+                self._log.compact((self.encode_cell(c) + k, self.encode_fine_codes(f))
+                                  for c in sorted(self._store) for k, f in sorted(self._store[c].items()))
+            self._log = None
+        if self.env is not None:
+            self.env.close()
+            self.env = None
+        if self._dev is not None:
+            self._dev.close()
+            self._dev = None
 
     @staticmethod
     def encode_cell(cell):
@@ -573,6 +597,7 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
     def add_codes(self, codes, ids=None):
         id_iter = count() if ids is None else iter(ids)
         txn = self.env.begin(db=self.index_db, write=True) if self.env is not None else None
+        logged = [] if self._log is not None else None
         try:
             for item_id, code in zip(id_iter, codes):
                 cell = (int(code[0][0]), int(code[0][1]))
@@ -581,10 +606,14 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
                 self._store.setdefault(cell, {})[suffix] = fine  # put(): an existing key is overwritten
                 if txn is not None:
                     txn.put(self.encode_cell(cell) + suffix, self.encode_fine_codes(fine))
+                if logged is not None:
+                    logged.append((self.encode_cell(cell) + suffix, self.encode_fine_codes(fine)))
         finally:
             if txn is not None:
                 txn.commit()
                 self.env.sync()
+            if logged:
+                self._log.append(logged)  # one write + fsync per add_codes call (the reference: env.sync(), :468)
         self._dev = None
         self.get_nb_indexed()
 

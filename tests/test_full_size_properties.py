@@ -153,6 +153,29 @@ def test_every_scan_route_agrees_at_full_size(world):
         small.close()
 
 
+def test_sampled_scan_fall_back_on_long_chunks(world, monkeypatch):
+    """The sampled single-pass form on 39 k-candidate chunks with a sample margin so small (z = 0.3) that many lists fail
+    their verification, and with lists too short for their chunks (a 16-row sample at most): the slots concerned are scanned
+    again by the streaming form, the result is the float64 kernel's, bit for bit."""
+    B, dev, s = world["B"], world["dev"], world["searcher"]
+    q = B.make_queries(world["x0"], 7, 2048, dev)
+    try:
+        s.set_scan_mode(mode=1)
+        want = _np(s.search_batch_dev(q, quota=QUOTA, limit=LIMIT))
+        s.set_scan_mode(mode=5)
+        for env in ({"CIS_S4_ZL": "0.3"}, {"CIS_S4_NSX": "16", "CIS_S4_FRAC": "64"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got = _np(s.search_batch_dev(q, quota=QUOTA, limit=LIMIT))
+            for k in env:
+                monkeypatch.delenv(k)
+            for k in ("ids", "n_found", "visited"):
+                np.testing.assert_array_equal(got[k], want[k], err_msg=str(env))
+            np.testing.assert_array_equal(got["dists"].view(np.uint64), want["dists"].view(np.uint64))
+    finally:
+        s.set_scan_mode(mode=0)
+
+
 def test_database_vectors_find_themselves(world):
     import torch
     s, x0 = world["searcher"], world["x0"]

@@ -304,3 +304,76 @@ def test_extractor_detector_rows(tmp_path):
     from columbiaimagesearch_amd.extractor.generic_extractor import get_bbox_str
     assert get_bbox_str({"left": 1, "top": 2, "right": 3, "bottom": 4, "score": 0.1 + 0.2}) == "1_2_3_4_0.3"
     assert get_bbox_str({"left": 1, "top": 2, "right": 3, "bottom": 4, "score": 2.0}) == "1_2_3_4_2.0"
+
+
+def _lmdb_fixture():
+    from test_lopq_hip_parity import hip_model
+    from conftest import load_golden
+    z, X, Q = load_golden("c2")
+    return hip_model(z), z, Q
+
+
+def test_lmdb_order_index_survives_a_restart(tmp_path):
+    """LOPQSearcherLMDB(lmdb_path=...) re-opens what an earlier process stored (lopq/lopq/search.py:416-417, :445-470): same
+    keys (cell as 2 x uint16 + bytes(id)), same values, put = last write wins, cells read back in key order.  Host logic
+    only (no GPU): get_cell / nb_indexed before == after a reopen; a torn tail record is dropped; compaction keeps the content."""
+    from columbiaimagesearch_amd.lopq import LOPQSearcherLMDB
+    from columbiaimagesearch_amd.lopq import kvlog
+    m, z, Q = _lmdb_fixture()
+    n = 1500
+    coarse, fine = z["coarse"][:n], z["fine"][:n]
+    codes = [((int(c[0]), int(c[1])), tuple(int(v) for v in f)) for c, f in zip(coarse, fine)]
+    ids = ["sha1_%05d" % (i * 7919 % n) for i in range(n)]  # production ids are strings; byte order != insertion order
+    path = str(tmp_path / "lmdb_index")
+    s = LOPQSearcherLMDB(m, path, id_lambda=str)
+    s.add_codes(codes[:1000], ids[:1000])
+    s.add_codes(codes[1000:], ids[1000:])
+    s.add_codes([codes[5]], [ids[3]])            # an existing key gets a new value (last write wins) -- in the same cell or not
+    cells = sorted({c for c, _ in codes})
+    before = {c: s.get_cell(c) for c in cells}
+    nb = s.get_nb_indexed()
+    assert s._log is not None and os.path.exists(os.path.join(path, kvlog.FILE_NAME))
+    key0 = s.encode_cell(codes[0][0]) + ids[0].encode()
+    raw = open(os.path.join(path, kvlog.FILE_NAME), "rb").read()
+    assert key0 in raw and s.encode_fine_codes(codes[0][1]) in raw   # the reference's key / value bytes, verbatim
+    s.close()
+    s2 = LOPQSearcherLMDB(m, path, id_lambda=str)
+    assert s2.get_nb_indexed() == nb
+    assert {c: s2.get_cell(c) for c in cells} == before
+    for c in cells[:5]:
+        assert [i for i, _ in before[c]] == sorted(i for i, _ in before[c])  # key (byte) order inside a cell
+    s2.close()
+    # a crash in the middle of an append leaves a torn record: it is cut off, everything before it is kept
+    with open(os.path.join(path, kvlog.FILE_NAME), "ab") as f:
+        f.write(b"\x10\x00\x00\x00\x08\x00\x00\x00partial")
+    s3 = LOPQSearcherLMDB(m, path, id_lambda=str)
+    assert s3.get_nb_indexed() == nb and {c: s3.get_cell(c) for c in cells} == before
+    # many overwrites -> close() compacts the log to one record per live key
+    for _ in range(3):
+        s3.add_codes(codes[:1000], ids[:1000])
+    size_before = os.path.getsize(os.path.join(path, kvlog.FILE_NAME))
+    s3.close()
+    assert os.path.getsize(os.path.join(path, kvlog.FILE_NAME)) < size_before / 2
+    s4 = LOPQSearcherLMDB(m, path, id_lambda=str)
+    assert s4.get_nb_indexed() == nb and {c: s4.get_cell(c) for c in cells} == before
+    s4.close()
+
+
+@gpu
+def test_lmdb_order_index_cold_start_answers_like_the_live_one(tmp_path):
+    from columbiaimagesearch_amd.lopq import LOPQSearcherLMDB
+    m, z, Q = _lmdb_fixture()
+    n = 3000
+    codes = [((int(c[0]), int(c[1])), tuple(int(v) for v in f)) for c, f in zip(z["coarse"][:n], z["fine"][:n])]
+    ids = ["%040x" % (i * 2654435761 % (1 << 61)) for i in range(n)]
+    path = str(tmp_path / "ix")
+    live = LOPQSearcherLMDB(m, path, id_lambda=str)
+    live.add_codes(codes, ids)
+    want = [live.search(Q[i], quota=200, limit=30, with_dists=True) for i in range(5)]
+    live.close()
+    cold = LOPQSearcherLMDB(m, path, id_lambda=str)   # a new process would do exactly this
+    assert cold.get_nb_indexed() == n
+    for i in range(5):
+        res, visited = cold.search(Q[i], quota=200, limit=30, with_dists=True)
+        assert visited == want[i][1] and [(r.id, r.code, r.dist) for r in res] == [(r.id, r.code, r.dist) for r in want[i][0]]
+    cold.close()
