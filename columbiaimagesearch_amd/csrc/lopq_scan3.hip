@@ -1116,6 +1116,9 @@ static __device__ __forceinline__ void lds_barrier() {
 #ifndef CIS_S4_U
 #define CIS_S4_U 2
 #endif
+#ifndef CIS_S4_UL
+#define CIS_S4_UL 2  // rows per iteration of the long-chunk form
+#endif
 #ifndef CIS_S4_OCT
 #define CIS_S4_OCT 4
 #endif
@@ -1599,6 +1602,28 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                             if (n < 64) am &= n <= 0 ? 0ull : ((1ull << n) - 1ull);
                             if (am == 0ull) continue;  // scalar branch
                             if constexpr (WLISTS) {
+#ifdef CIS_S4_SCALAR_APPEND  // measured on C4: 0.341 ms against 0.307 ms for the ballot form below (the scalar chain serialises)
+                                // A row that gets here carries one passing lane as a rule (the threshold lets ~1 % through): the lanes
+                                // are taken one by one on the scalar unit -- two readlanes, four scalar compares, a uniform LDS store per
+                                // pass -- instead of four ballots and prefix counts over the whole wave.
+                                while (am != 0ull) {
+                                    const int l = __builtin_ctzll(am);
+                                    am &= am - 1ull;
+                                    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)dd[u][0], l);
+                                    const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)dd[u][1], l);
+                                    const uint32_t pos = (uint32_t)(base + u * 64 + l);
+#pragma unroll
+                                    for (int g = 0; g < G; ++g) {
+                                        const uint32_t dw = (g >> 1) ? d1 : d0;
+                                        const uint32_t sg = (g & 1) ? (dw >> 16) : (dw & 0xffffu);
+                                        const uint32_t t1 = (g & 1) ? ((g >> 1) ? s23 >> 16 : s01 >> 16) : ((g >> 1) ? s23 & 0xffffu : s01 & 0xffffu);
+                                        if (sg < t1) {  // scalar
+                                            if (wcur[g] < WCAP) lists[(g * NW + w) * WCAP + wcur[g]] = (sg << 16) | pos;  // every lane stores the same word
+                                            wcur[g] += 1;
+                                        }
+                                    }
+                                }
+#else
 #pragma unroll
                                 for (int g = 0; g < G; ++g) {
                                     const uint32_t sg = (g & 1) ? (dd[u][g >> 1] >> 16) : (dd[u][g >> 1] & 0xffffu);
@@ -1609,6 +1634,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                                     if (((mg >> lane) & 1ull) && idx < WCAP) lists[(g * NW + w) * WCAP + idx] = (sg << 16) | (uint32_t)(base + u * 64 + lane);
                                     wcur[g] += __popcll(mg);
                                 }
+#endif
                                 continue;
                             }
                             unsigned long long m[G];
@@ -1838,7 +1864,7 @@ static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, 
                 const int per_cu4 = by_lds4 < WPE4 ? by_lds4 : WPE4;
                 const int64_t resident4 = 256 * (per_cu4 < 1 ? 1 : per_cu4);
                 const unsigned grid4 = (unsigned)(want < resident4 ? ((want + 7) / 8) * 8 : resident4);
-                hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_U, NW, WPE4, S4_LCAP_LONG>), dim3(grid4), dim3(NW * 64), lds4, st, items, tabs, slots,
+                hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_UL, NW, WPE4, S4_LCAP_LONG>), dim3(grid4), dim3(NW * 64), lds4, st, items, tabs, slots,
                                    n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_long, frac_long, nsx_long, dyn_long);
             }
             if (getenv("CIS_SCAN4_DEBUG")) {  // diagnosis: how many slots the sample misjudged (blocks)
