@@ -549,6 +549,14 @@ def main():
                    "valu_issue": {"wave_instr_per_launch": valu_instr / launches, "frac": t_valu / scan_s if scan_s > 0 else None,
                                   "note": "minimal gather-and-add loop only (no selection / append), 4 cycles per wave64 instruction, 1024 SIMDs"},
                    "queries_per_workgroup": G}
+        # encode: SURVEY.md 8(d)'s algorithmic flop per vector -- 2 D_in D (PCA) + 3 V D (coarse) + 4 h^2 (rotation) + 3 K D (fine) --
+        # against the float64 peak (AMD's MI355X figure, 78.6 TFLOP/s vector = matrix; the arithmetic that decides a code is
+        # float64 / numpy-ordered, the fine and large-V coarse stages prefilter on the float32 matrix cores and re-check exactly)
+        Dm, hm = model.dim, model.dim // 2
+        enc_flop = 2.0 * cfg["d_in"] * Dm + 3.0 * model.V * Dm + 4.0 * hm * hm + 3.0 * 256 * Dm
+        enc_rate = len(my_chunks) * chunk_n / encode_s
+        encode_roofline = {"bound": "mfma", "achieved": enc_rate * enc_flop / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                           "frac": enc_rate * enc_flop / 78.6e12, "flop_per_vector": enc_flop, "dtype": "f64"}
         binding["binds"] = max(("hbm_moved_bytes", "lds_gather", "valu_issue"), key=lambda k: binding[k]["frac"] or 0.0)
         line = {
             "metric": "queries/sec @ recall@10 on 10M LOPQ index",
@@ -579,7 +587,8 @@ def main():
                          "avg_launch_ms": prof["scan_kernel_ms"] / launches, "launches": launches, "binding": binding},
             "stage_ms_per_step": {k: stage_prof[k] / n_stage for k in ("front_ms", "tables_ms", "scan_ms", "merge_ms", "scan_kernel_ms")},
             "encode": {"value": len(my_chunks) * chunk_n / encode_s, "unit": "vectors/s", "vectors": len(my_chunks) * chunk_n,
-                       "note": "cis_encode_dev on this rank's share of the index build, HIP events around the encode calls"},
+                       "note": "cis_encode_dev on this rank's share of the index build, HIP events around the encode calls",
+                       "roofline": encode_roofline},
             "pcie_inclusive": pcie,
             "cnn": cnn,
             "dlib": dlib,

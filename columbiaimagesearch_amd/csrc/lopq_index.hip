@@ -19,7 +19,8 @@
 //   k_ins_offsets   new CSR offsets = old + accepted items of smaller cells (binary search in the sorted keys),
 //                   global cell sizes += accepted
 //   k_ins_move      old items to their new places (a cell moves as a block)
-//   k_ins_scatter   accepted items behind the old items of their cell, in arrival order
+//   k_ins_scatter   accepted items behind the old items of their cell, in arrival order: place = old offset of the next cell +
+//                   accepted items before it
 // The two generations of the arrays swap.  Cost: one read + one write of the shard's index (24 B per item at M = 16)
 // plus O(n) for the batch -- 10M items x M = 8: ~0.1 ms; the host does nothing per item and keeps no (cell, id) set.
 //
@@ -320,23 +321,37 @@ __global__ void k_ins_move_cells(const int64_t* __restrict__ loff, const int64_t
     }
 }
 
+// Place of accepted item j (sorted by cell, then arrival): behind every old item of the cells up to its own and behind the
+// accepted items before it -- loff_old[c + 1] + apre[j].  The cell's largest id: one atomic per run of equal cells in a wave
+// (the items are sorted by cell: a wave usually holds one cell, and 10M items hammering 256 addresses one by one took 22 ms).
 __global__ void k_ins_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ perm, const int64_t* __restrict__ sid,
                               const uint32_t* __restrict__ acc, const uint32_t* __restrict__ apre, int64_t n,
-                              const int64_t* __restrict__ loff, const int64_t* __restrict__ noff, const uint8_t* __restrict__ fine, int M,
+                              const int64_t* __restrict__ loff, const uint8_t* __restrict__ fine, int M,
                               int64_t* __restrict__ ids_new, uint8_t* __restrict__ codes_new, unsigned long long* __restrict__ cmaxp) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n || !acc[j]) return;
-    const uint32_t c = key[j];
-    const int64_t lb = lower_bound_u32(key, n, c);
-    const int64_t rank = (int64_t)apre[j] - (int64_t)apre[lb];
-    const int64_t dst = noff[c] + (loff[c + 1] - loff[c]) + rank;
-    const int64_t id = sid[j];
-    ids_new[dst] = id;
-    if (codes_new) {
-        const int64_t i = perm[j];
-        for (int b = 0; b < M; ++b) codes_new[dst * M + b] = fine[i * M + b];
+    const bool on = j < n && acc[j];
+    const uint32_t c = on ? key[j] : 0xffffffffu;
+    unsigned long long v = 0ull;
+    if (on) {
+        const int64_t dst = loff[c + 1] + (int64_t)apre[j];
+        const int64_t id = sid[j];
+        ids_new[dst] = id;
+        if (codes_new) {
+            const int64_t i = perm[j];
+            for (int b = 0; b < M; ++b) codes_new[dst * M + b] = fine[i * M + b];
+        }
+        v = (unsigned long long)id + 1ull;
     }
-    atomicMax(&cmaxp[c], (unsigned long long)id + 1ull);
+    // segmented maximum over runs of equal cells inside the wave (keys are sorted, so runs are contiguous lanes)
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long u = __shfl_up(v, o);
+        const uint32_t cu = __shfl_up(c, o);
+        if (lane >= o && cu == c && u > v) v = u;
+    }
+    const uint32_t cn = __shfl_down(c, 1);
+    if (on && (lane == 63 || cn != c)) atomicMax(&cmaxp[c], v);  // the last lane of a run holds the run's maximum
 }
 
 // statistics of the global cell-size table: total, largest cell, non-empty cells (atomics into zeroed words)
@@ -617,7 +632,7 @@ static int store_merge(cis_index* ix, CellStore& s, int sel, const int64_t* d_id
         }
     }
     hipLaunchKernelGGL(k_ins_scatter, dim3(grid_for(n, 256)), dim3(256), 0, st, skey, perm, (const int64_t*)sid, (const uint32_t*)acc,
-                       (const uint32_t*)apre, n, loff, (const int64_t*)noff, d_fine, M, s.ids[nxt].as<int64_t>(), ncodes, cmaxp);
+                       (const uint32_t*)apre, n, loff, d_fine, M, s.ids[nxt].as<int64_t>(), ncodes, cmaxp);
     CIS_CHECK_HIP(hipGetLastError());
     // the host learns the accepted count when the stream is synchronised (caller); the generation swaps now
     s.cur = nxt;

@@ -821,6 +821,200 @@ __global__ __launch_bounds__(256) void k_fine_codes(const double* __restrict__ p
     fine[r * M + j] = (uint8_t)bi;
 }
 
+// Fine codes on the float32 matrix cores with an exact re-check (round 3; the scheme of k_coarse_mfma32).
+// dt[k] = |c_k|^2 - 2 x.c_k for the K sub-centroids of sub-quantizer j comes from v_mfma_f32_32x32x2_f32 with the CENTROIDS as
+// the A operand (rows) and the wave's 32 vectors as the B operand (columns): lane l ends up with 16 of the 32 centroids of a
+// tile for vector l & 31, so the minimum over centroids is in-lane plus one exchange with lane l ^ 32.  |dt + |x|^2 - d| <=
+// slack = (W + 8) 2^-24 (|x|^2 + max|c|^2) bounds the float32 path (inputs rounded to float32, W-term float32 dot product,
+// the final fma) against numpy's float64 value d of predict_cluster (lopq/lopq/utils.py:33-53), so every centroid within
+// 2 x slack of the row's minimum (a first pass of the same products) is listed -- numpy's argmin always is.  A row with ONE
+// listed centroid is done; rows with several (near-ties, duplicate centroids) are evaluated exactly: float64, numpy's pairwise
+// order (pw_leaf), first minimum wins.
+// A wave whose list overflows (hundreds of identical sub-centroids) evaluates its 32 rows against all centroids itself.
+template <int W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fine_mfma(
+                                                   const double* __restrict__ proj /* [n][D] */, int D,
+                                                   const double* __restrict__ subs /* [M][K][W] */, int64_t n, int K, int M,
+                                                   uint8_t* __restrict__ fine /* [n][M] */, int reps) {
+    // score[k] = x.c_k - |c_k|^2 / 2 = -dt[k] / 2: the norm rides in the product as one more k-step (A = |c|^2 / 2, B = -1), so the
+    // vector work per tile is sixteen max / compare instructions and nothing else
+    constexpr int KS = W / 2 + 1;  // MFMA steps (two dims each; the last one carries the norm)
+    constexpr int PITCH = W + 3;   // odd: the 32 centroid rows of an operand read fall on 32 banks
+    constexpr int CAP = 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int KP = (K + 31) & ~31;
+    float* sA = reinterpret_cast<float*>(smem);              // [KP][PITCH] float32 sub-centroids, |c|^2 / 2, 0 (rows >= K: zeros, 3e38)
+    uint32_t* sList = reinterpret_cast<uint32_t*>(sA + (size_t)KP * PITCH); // [4][CAP] (row << 16 | centroid)
+    unsigned long long* sBest = reinterpret_cast<unsigned long long*>(sList + 4 * CAP);  // [4][32]
+    uint32_t* sBestC = reinterpret_cast<uint32_t*>(sBest + 4 * 32);                       // [4][32]
+    uint32_t* sCnt = sBestC + 4 * 32;                                                     // [4][32] listed candidates per row
+    float* sCmax = reinterpret_cast<float*>(sCnt + 4 * 32);                               // [4] partial maxima of |c|^2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = blockIdx.y;
+    const double* src = subs + (size_t)j * K * W;
+    float cmx = 0.f;
+    for (int k = tid; k < KP; k += 256) {
+        double sq = 0.0;
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const double v = k < K ? src[(size_t)k * W + i] : 0.0;
+            sA[k * PITCH + i] = (float)v;
+            sq = fma(v, v, sq);
+        }
+        sA[k * PITCH + W] = k < K ? 0.5f * (float)sq : 3.0e38f;
+        sA[k * PITCH + W + 1] = 0.f;
+        cmx = fmaxf(cmx, k < K ? (float)sq : 0.f);
+    }
+    for (int o = 32; o > 0; o >>= 1) cmx = fmaxf(cmx, __shfl_xor(cmx, o));
+    if (lane == 0) sCmax[wave] = cmx;
+    __syncthreads();
+    const float cmax = fmaxf(fmaxf(sCmax[0], sCmax[1]), fmaxf(sCmax[2], sCmax[3]));
+    // the staged codebook serves `reps` groups of 128 vectors (staging it costs as much as one group's matrix products)
+    for (int rep = 0; rep < reps; ++rep) {
+    const int64_t row0 = ((int64_t)blockIdx.x * reps + rep) * 128 + wave * 32;
+    if (row0 >= n) break;
+    const int64_t r = row0 + (lane & 31);
+    float a[KS];
+    double xsq = 0.0;
+    {
+        const double* x = proj + r * D + j * W;
+#pragma unroll
+        for (int s2 = 0; s2 < KS - 1; ++s2) {
+            const double v = r < n ? x[2 * s2 + (lane >> 5)] : 0.0;
+            a[s2] = (float)v;
+            xsq = fma(v, v, xsq);
+        }
+        a[KS - 1] = (lane >> 5) ? 0.f : -1.f;
+        xsq += __shfl_xor(xsq, 32);
+    }
+    if (lane < 32) {
+        sBest[wave * 32 + lane] = ~0ull;
+        sBestC[wave * 32 + lane] = 0xffffffffu;
+        sCnt[wave * 32 + lane] = 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // |score + (d - |x|^2) / 2| <= slack / 2, slack = (W + 8) 2^-24 (|x|^2 + max |c|^2): inputs rounded to float32 (2 x 2^-24 per
+    // product), W + 1 float32 additions of the accumulation (2^-24 of the partial sums each), |c|^2 rounded
+    const float slack1 = (float)((double)(W + 8) * 5.9604644775390625e-8 * (xsq + (double)cmax) * 1.0000002);  // = 2 x slack / 2
+    int wcnt = 0;
+    bool over = false;
+    const int ntiles = KP / 32;
+    // the matrix products of tile t + 1 are issued before the vector work on tile t: the matrix pipe runs under it
+    auto tile_products = [&](int t) -> f32x16 {
+        f32x16 c;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c[q] = 0.f;
+        const float* arow = sA + (size_t)(t * 32 + (lane & 31)) * PITCH + (lane >> 5);
+        float av[KS];
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) av[s2] = arow[2 * s2];
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], a[s2], c, 0, 0, 0);
+        return c;
+    };
+    // pass 1: the row's best score over all sub-centroids
+    float rmax = -__builtin_inff();
+    f32x16 acc_next = tile_products(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const f32x16 acc = acc_next;
+        if (t + 1 < ntiles) acc_next = tile_products(t + 1);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rmax = fmaxf(rmax, acc[q]);
+    }
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
+    // pass 2: the same products again (bit-identical), every centroid within 2 x slack of the best is listed -- one per row
+    // as a rule, and a row with a single candidate needs no exact evaluation at all
+    const float thr = rmax - slack1;
+    acc_next = tile_products(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const f32x16 acc = acc_next;
+        if (t + 1 < ntiles) acc_next = tile_products(t + 1);
+        unsigned mask = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (acc[q] >= thr) mask |= 1u << q;
+        // lanes with candidates append them one bit at a time (one iteration as a rule)
+        while (!over) {
+            const bool p = mask != 0u;
+            const unsigned long long bal = __ballot(p);
+            if (bal == 0ull) break;
+            const int cnt = __popcll(bal);
+            if (wcnt + cnt > CAP) { over = true; break; }
+            if (p) {
+                const int q = __builtin_ctz(mask);
+                mask &= mask - 1u;
+                const int pos = wcnt + __popcll(bal & ((1ull << lane) - 1ull));
+                const int c = t * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                sList[wave * CAP + pos] = ((uint32_t)(lane & 31) << 16) | (uint32_t)c;
+                atomicAdd(&sCnt[wave * 32 + (lane & 31)], 1u);
+            }
+            wcnt += cnt;
+        }
+    }
+    auto exact = [&](int row, int c) -> double {
+        const double* x = proj + (row0 + row) * D + j * W;
+        const double* cc = src + (size_t)c * W;
+        auto elem = [&](int i) -> double { const double df = x[i] - cc[i]; return df * df; };
+        return pw_leaf<double>(elem, 0, W);
+    };
+    if (over) {
+        // every centroid for the wave's rows: lane l takes row l & 31 and the centroids of its half, in index order
+        double best = 0.0;
+        int bi = -1;
+        if (row0 + (lane & 31) < n) {
+            const int half = (K + 1) / 2, k0 = (lane >> 5) * half, k1 = (k0 + half < K) ? k0 + half : K;
+            for (int k = k0; k < k1; ++k) {
+                const double dd = exact(lane & 31, k);
+                if (bi < 0 || dd < best) { best = dd; bi = k; }
+            }
+        }
+        const double ob = __shfl_xor(best, 32);
+        const int obi = __shfl_xor(bi, 32);
+        if (lane < 32 && row0 + lane < n) {
+            // the upper half's centroid wins only with a strictly smaller distance (first minimum)
+            const int code = (obi >= 0 && (bi < 0 || ob < best)) ? obi : bi;
+            fine[(row0 + lane) * M + j] = (uint8_t)code;
+        }
+        continue;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // rows with ONE listed centroid are done; the others (near-ties, duplicate centroids) are evaluated exactly: float64,
+    // numpy's order, first minimum
+    for (int i = lane; i < wcnt; i += 64) {
+        const uint32_t e = sList[wave * CAP + i];
+        if (sCnt[wave * 32 + (e >> 16)] == 1u) sBestC[wave * 32 + (e >> 16)] = e & 0xffffu;
+    }
+    bool any_multi = false;
+    for (int i = lane; i < wcnt; i += 64) any_multi = any_multi || sCnt[wave * 32 + (sList[wave * CAP + i] >> 16)] > 1u;
+    if (__ballot(any_multi) != 0ull) {
+        for (int i = lane; i < wcnt; i += 64) {
+            const uint32_t e = sList[wave * CAP + i];
+            if (row0 + (e >> 16) >= n || sCnt[wave * 32 + (e >> 16)] <= 1u) continue;
+            const double v = exact((int)(e >> 16), (int)(e & 0xffffu));
+            atomicMin(&sBest[wave * 32 + (e >> 16)], (unsigned long long)__double_as_longlong(v));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < wcnt; i += 64) {
+            const uint32_t e = sList[wave * CAP + i];
+            if (row0 + (e >> 16) >= n || sCnt[wave * 32 + (e >> 16)] <= 1u) continue;
+            const double v = exact((int)(e >> 16), (int)(e & 0xffffu));
+            if ((unsigned long long)__double_as_longlong(v) == sBest[wave * 32 + (e >> 16)]) atomicMin(&sBestC[wave * 32 + (e >> 16)], e & 0xffffu);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32 && row0 + lane < n) {
+        const uint32_t c = sBestC[wave * 32 + lane];
+        fine[(row0 + lane) * M + j] = (uint8_t)(c == 0xffffffffu ? 0u : c);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- grouping rows by coarse cluster so that a tile of 64 vectors shares one rotation ----------
 struct ProjTile { int split, cluster, start, count; };
 
@@ -1351,6 +1545,41 @@ extern "C" int cis_predict_cluster(const void* X, int x_dtype, const void* C, in
     return done(CIS_OK);
 }
 
+// Coarse assignment for a few clusters (V < 256: no matrix-core prefilter): a thread keeps its row half in registers, walks
+// the V centroids of the split staged in LDS (broadcast reads) and keeps the first minimum -- distances in numpy's order
+// (pw_leaf: h <= 128 is one summation leaf) and compute type, exactly as k_sqdist_rows + k_argmin_rows produce them, without
+// the n x V distance matrix and the second launch (2 x 38 + 2 x 5 us per 65536 vectors at V = 16 -> one launch).
+template <typename T, int H>
+__global__ __launch_bounds__(256) void k_coarse_assign_reg(const T* __restrict__ X, int64_t ldx, const T* __restrict__ C,
+                                                           int64_t n, int ncent, uint16_t* __restrict__ out /* [n][2] */) {
+    constexpr int CT = 64;
+    __shared__ __align__(16) T sC[CT][H];
+    const int s = blockIdx.y;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    T x[H];
+    {
+        const T* xr = X + (r < n ? r : 0) * ldx + s * H;
+#pragma unroll
+        for (int i = 0; i < H; ++i) x[i] = xr[i];
+    }
+    T best = (T)0;
+    int bi = -1;
+    for (int c0 = 0; c0 < ncent; c0 += CT) {
+        const int nc = (ncent - c0 < CT) ? (ncent - c0) : CT;
+        __syncthreads();
+        const T* src = C + ((int64_t)s * ncent + c0) * H;
+        for (int e = threadIdx.x; e < nc * H; e += 256) (&sC[0][0])[e] = src[e];
+        __syncthreads();
+        for (int c = 0; c < nc; ++c) {
+            const T* cc = sC[c];
+            auto elem = [&](int i) -> T { const T df = x[i] - cc[i]; return df * df; };
+            const T v = pw_leaf<T>(elem, 0, H);
+            if (bi < 0 || v < best) { best = v; bi = c0 + c; }
+        }
+    }
+    if (r < n) out[r * 2 + s] = (uint16_t)bi;
+}
+
 // coarse ids of n LOPQ-space vectors (already in compute type ct) -> d_coarse [n][2]
 static int dev_predict_coarse(cis_model* m, const void* xc, int ct, int64_t n, uint16_t* d_coarse, hipStream_t st) {
     if (n == 0) return CIS_OK;
@@ -1360,6 +1589,17 @@ static int dev_predict_coarse(cis_model* m, const void* xc, int ct, int64_t n, u
     const int coarse_mode = getenv("CIS_COARSE") ? atoi(getenv("CIS_COARSE")) : -1;  // 0 exact kernels, 1 prefilter
     const bool pre = (coarse_mode >= 1 || (coarse_mode != 0 && m->V >= 256)) && m->h <= 128 && m->V <= 65535;  // 2: float64 cores for float32 too
     const int* only_if = nullptr;
+    if (!pre && m->V <= 1024 && ((ct == CIS_F32 && (m->h == 32 || m->h == 64)) || (ct != CIS_F32 && m->h == 32)) && !getenv("CIS_SQDIST_PLAIN")) {
+        const dim3 gr((unsigned)ceil_div(n, 256), 2);
+        if (ct == CIS_F32) {
+            if (m->h == 32) hipLaunchKernelGGL((k_coarse_assign_reg<float, 32>), gr, dim3(256), 0, st, (const float*)xc, (int64_t)m->D, m->d_Cs32, n, m->V, d_coarse);
+            else hipLaunchKernelGGL((k_coarse_assign_reg<float, 64>), gr, dim3(256), 0, st, (const float*)xc, (int64_t)m->D, m->d_Cs32, n, m->V, d_coarse);
+        } else {
+            hipLaunchKernelGGL((k_coarse_assign_reg<double, 32>), gr, dim3(256), 0, st, (const double*)xc, (int64_t)m->D, m->d_Cs64, n, m->V, d_coarse);
+        }
+        CIS_CHECK_HIP(hipGetLastError());
+        return CIS_OK;
+    }
     if (pre) {
         CIS_CHECK_HIP(hipMemsetAsync(m->d_flag, 0, sizeof(int), st));
         const dim3 gp((unsigned)ceil_div(n, 64), 2);
@@ -1451,6 +1691,25 @@ static int dev_project(cis_model* m, const void* xc, int ct, int64_t n, const ui
 
 static int dev_fine_from_proj(cis_model* m, const double* d_proj, int64_t n, uint8_t* d_fine, hipStream_t st) {
     if (n == 0) return CIS_OK;
+    // CIS_FINE=0: every (vector, sub-centroid) pair exactly on the VALU (k_fine_codes, rounds 1-2); default: matrix-core
+    // prefilter + exact re-check of the listed pairs
+    const bool fine_mfma = !(getenv("CIS_FINE") && atoi(getenv("CIS_FINE")) == 0);
+    if (fine_mfma && m->K <= 256 && (m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) && !getenv("CIS_ENCODE_TWO_KERNEL")) {
+        // groups of 128 vectors per workgroup: as many as keep >= ~4 workgroups per CU in the launch
+        int reps = (int)(ceil_div(n, 128) * m->M / 1024);
+        reps = reps < 1 ? 1 : (reps > 8 ? 8 : reps);
+        const dim3 gf((unsigned)ceil_div(n, (int64_t)128 * reps), (unsigned)m->M);
+        const int KP = (m->K + 31) & ~31;
+        const size_t lds = (size_t)KP * (m->w + 3) * 4 + 4 * 512 * 4 + 4 * 32 * 8 + 2 * 4 * 32 * 4 + 16;
+        switch (m->w) {
+            case 4: hipLaunchKernelGGL(k_fine_mfma<4>, gf, dim3(256), lds, st, d_proj, m->D, m->d_subs, n, m->K, m->M, d_fine, reps); break;
+            case 8: hipLaunchKernelGGL(k_fine_mfma<8>, gf, dim3(256), lds, st, d_proj, m->D, m->d_subs, n, m->K, m->M, d_fine, reps); break;
+            case 16: hipLaunchKernelGGL(k_fine_mfma<16>, gf, dim3(256), lds, st, d_proj, m->D, m->d_subs, n, m->K, m->M, d_fine, reps); break;
+            default: hipLaunchKernelGGL(k_fine_mfma<32>, gf, dim3(256), lds, st, d_proj, m->D, m->d_subs, n, m->K, m->M, d_fine, reps); break;
+        }
+        CIS_CHECK_HIP(hipGetLastError());
+        return CIS_OK;
+    }
     if (m->K <= 256 && (m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) && !getenv("CIS_ENCODE_TWO_KERNEL")) {
         const dim3 gf((unsigned)ceil_div(n, 256), (unsigned)m->M);
         const size_t lds = (size_t)m->K * m->w * sizeof(double);

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 PCA_FIXTURES = ["c2", "c3", "c3b", "c4", "c3full"]
 ALL = ["tiny", "c1"] + PCA_FIXTURES
 
-_ROUTE_FREE = ("encode", "near_tie", "model_pieces", "selftest", "multisequence", "rerank", "kmeans", "training", "multisequence_plan", "select_path",
+_ROUTE_FREE = ("encode", "near_tie", "fine_codes", "hooks", "model_pieces", "selftest", "multisequence", "rerank", "kmeans", "training", "multisequence_plan", "select_path",
                "large_limit", "fuzz")
 
 
@@ -71,6 +71,44 @@ def test_encode_bit_exact(name):
     one = m.predict(X[3])  # the reference's per-vector entry point
     assert tuple(int(c) for c in one.coarse) == tuple(int(c) for c in coarse[3])
     assert tuple(int(f) for f in one.fine) == tuple(int(f) for f in fine[3])
+
+
+def test_fine_codes_prefilter_adversarial(monkeypatch):
+    """Fine codes on the matrix cores (k_fine_mfma: float32 prefilter + exact re-check) against the oracle and against the
+    all-pairs VALU kernel (CIS_FINE=0) on inputs built to stress the prefilter: many identical sub-centroids (the wave's list
+    overflows -> all-pairs path, first index wins), vectors whose projected residual sits ON a sub-centroid or next to the
+    midpoint of two (near-ties far below the float32 prefilter's resolution), huge and tiny scales, ragged counts, K not a multiple of 32,
+    w = 32, 16, 8, 4."""
+    from oracle import lopq_oracle as O
+    from columbiaimagesearch_amd.lopq import LOPQModel
+    rs = np.random.RandomState(11)
+    for (V, M, K, D, scale) in [(4, 8, 256, 128, 1.0), (4, 4, 256, 128, 1e-3), (3, 16, 200, 128, 1e3), (4, 8, 40, 32, 1.0), (4, 32, 256, 128, 1.0)]:
+        h, w, nf = D // 2, D // M, M // 2
+        Cs = [rs.randn(V, h) * scale for _ in range(2)]
+        Rs = [np.stack([np.linalg.qr(rs.randn(h, h))[0] for _ in range(V)]) for _ in range(2)]
+        mus = [rs.randn(V, h) * 0.05 * scale for _ in range(2)]
+        subs = [[rs.randn(K, w) * 0.6 * scale for _ in range(nf)] for _ in range(2)]
+        subs[0][0][K // 2:] = subs[0][0][3]          # half of one codebook is ONE centroid: hundreds of candidates per vector
+        subs[1][nf - 1][7] = subs[1][nf - 1][2]      # an exact duplicate pair
+        m = LOPQModel(parameters=(tuple(Cs), tuple(Rs), tuple(mus), tuple(tuple(x) for x in subs)))
+        om = O.OracleModel(Cs, Rs, mus, subs)
+        n = 777
+        X = rs.randn(n, D) * scale
+        for i in range(300):  # projection R[c] ((x - C[c]) - mu[c]) == target  <=>  x = C[c] + mu[c] + R[c]^T target
+            for s_ in range(2):
+                c = i % V
+                # (midpoints of two sub-centroids would be ties that the rounding of the ROTATION decides -- BLAS order in the
+                # reference, k-ascending fma chains here, DESIGN.md section 3 -- so they are 1 % off the midpoint)
+                tgt = np.concatenate([subs[s_][j][(i + j) % K] if i % 2 == 0 else 0.505 * subs[s_][j][i % K] + 0.495 * subs[s_][j][(i * 7 + 1) % K]
+                                      for j in range(nf)])
+                X[i, s_ * h:(s_ + 1) * h] = Cs[s_][c] + mus[s_][c] + Rs[s_][c].T @ tgt
+        oc, of = O.compute_codes(om, X)
+        for route in ("1", "0"):
+            monkeypatch.setenv("CIS_FINE", route)
+            coarse, fine = m.predict_batch(X)
+            np.testing.assert_array_equal(coarse, oc)
+            np.testing.assert_array_equal(fine, of, err_msg="CIS_FINE=%s shape %r" % (route, (V, M, K, D, scale)))
+        monkeypatch.delenv("CIS_FINE")
 
 
 @pytest.mark.parametrize("name", ["c1"] + PCA_FIXTURES)
