@@ -626,6 +626,84 @@ __global__ void k_normalize_rgb4(const float* __restrict__ in, float* __restrict
     *reinterpret_cast<float4*>(out + i * 4) = make_float4((r - m0) * (1.0f / 256.0f), (g - m1) * (1.0f / 256.0f), (b - m2) * (1.0f / 256.0f), 0.f);
 }
 
+// The dlib net's first layer as a direct convolution (round 3): 7 x 7, stride 2, 150 x 150 x 3 -> 72 x 72 x 32, normalisation of the
+// raw RGB chip, bias (dlib's affine layer is folded into the weights) and ReLU in the same kernel.
+//   * GEMM view: M = 32 consecutive output pixels of one image (p = oy * 72 + ox; 72 * 72 = 162 tiles exactly), N = the 32 output
+//     channels, K = 7 * 7 * 3 = 147 (+1 zero) = 74 steps of v_mfma_f32_32x32x2_f32.
+//   * The WEIGHTS are the B operand and stay in registers for the whole kernel: lane l holds W[k = 2 s + (l >> 5)][oc = l & 31] for
+//     every step s -- 74 registers, loaded once.
+//   * A workgroup (four waves = four tiles = 128 pixels) stages the input rows its pixels touch -- at most 11 rows of 150 x 3 floats,
+//     normalised on the way in ((px - mean) / 256) -- in LDS as they are in memory ([row][x][c]: 450 floats per row).  The A operand of
+//     lane (pixel m, k half) for step s is window[base_m + (k / 21) * 450 + k % 21], k = 2 s + half: base_m is one register, the
+//     rest an immediate offset of the ds_read (the odd k of a pair sits one float further, 430 further where a kernel row ends).
+//     Pixels are 6 floats apart (stride 2 x 3 channels): the 32 lanes of a read group fall on 16 banks, a 2-way conflict, against 64
+//     cycles of matrix pipe per step.
+// k_conv_igemm ran this layer on (R, G, B, 0) pixels with K = 196 in 254 us per 256 chips (0.31 of the f32 MFMA peak counting the real
+// 147-term products) behind a 25 us normalisation pass.
+__global__ __launch_bounds__(256) void k_conv7x7s2_direct(const float* __restrict__ in /* [n][150][150][3] raw RGB */,
+                                                          const float* __restrict__ wpk /* [196][32]: k = ky * 28 + kx * 4 + c */,
+                                                          const float* __restrict__ bias /* [32] */, float* __restrict__ out /* [n][72][72][32] */,
+                                                          int n, float m0, float m1, float m2) {
+    constexpr int IW = 150, OW = 72, ROWF = IW * 3, NT = OW * OW / 32;  // 162 tiles per image
+    constexpr int KSTEPS = 74;
+    __shared__ float win[11 * ROWF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int img = blockIdx.x / 41, grp = blockIdx.x % 41;  // 41 groups of four tiles per image (the last one holds two)
+    const int tile0 = grp * 4;
+    const int ntile = (NT - tile0 < 4) ? (NT - tile0) : 4;
+    const int p0 = tile0 * 32, p1 = p0 + ntile * 32 - 1;
+    const int oy0 = p0 / OW, oy1 = p1 / OW;
+    const int nrows = 2 * (oy1 - oy0) + 7;  // input rows 2 oy0 .. 2 oy1 + 6
+    // weights -> registers (B operand)
+    float w[KSTEPS];
+    {
+        const int oc = lane & 31, kh = lane >> 5;
+#pragma unroll
+        for (int s2 = 0; s2 < KSTEPS; ++s2) {
+            const int k = 2 * s2 + kh;             // (ky, kx, c) = (k / 21, (k % 21) / 3, k % 3)
+            const int ky = k / 21, rem = k - ky * 21, kx = rem / 3, cc = rem - kx * 3;
+            w[s2] = k < 147 ? wpk[(ky * 28 + kx * 4 + cc) * 32 + oc] : 0.f;
+        }
+    }
+    // window: rows 2 oy0 ... of the raw chip, normalised
+    {
+        const float* src = in + ((int64_t)img * IW + 2 * oy0) * ROWF;
+        const int tot = nrows * ROWF;
+        for (int e = tid; e < tot; e += 256) {
+            const int cc = e % 3;
+            const float mean = cc == 0 ? m0 : (cc == 1 ? m1 : m2);
+            win[e] = (src[e] - mean) * (1.0f / 256.0f);
+        }
+    }
+    __syncthreads();
+    if (wave >= ntile) return;
+    const int p = p0 + wave * 32 + (lane & 31);
+    const int oy = p / OW, ox = p - oy * OW;
+    const float* a0 = win + (2 * (oy - oy0)) * ROWF + 6 * ox + (lane >> 5);
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < KSTEPS; ++s2) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int k = 2 * s2;
+        const int off = (k / 21) * ROWF + (k % 21);            // folds to an immediate
+        const bool row_end = (k % 21) == 20;                   // the odd element of the pair starts the next kernel row
+        const float av = row_end ? a0[off + (lane >> 5) * (ROWF - 21)] : a0[off];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w[s2], acc, 0, 0, 0);
+    }
+    // epilogue: bias + ReLU; register q of lane l is pixel (q & 3) + 8 (q >> 2) + 4 (l >> 5), channel l & 31
+    const float bv = bias[lane & 31];
+    float* o = out + ((int64_t)img * OW * OW + p0 + wave * 32) * 32 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        const float v = acc[q] + bv;
+        o[row * 32] = v > 0.f ? v : 0.f;
+    }
+}
+
 // avg_pool<2,2,2,2>, no padding, output floor((H-2)/2)+1
 __global__ void k_avgpool2_nhwc(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C, int OH, int OW) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -980,14 +1058,20 @@ static int cnn_forward_dlib(cis_cnn* c, CnnWs* ws, const float* d_in, int n, flo
     float* T1 = ws->act2.as<float>();
     float* T2 = ws->act3.as<float>();
     auto grid = [](int64_t total) { return dim3((unsigned)ceil_div(total, 256)); };
-    hipLaunchKernelGGL(k_normalize_rgb4, grid((int64_t)n * 150 * 150), dim3(256), 0, st, d_in, A, (int64_t)n * 150 * 150, 122.782f,
-                       117.001f, 104.298f);
-    ConvDesc d0 = nhwc_conv(n, 150, 150, 3, 32, 7, 2, 0, 1);
-    // (R, G, B, 0) pixels: a kernel row is a run of 7 aligned float4, k = ky * 28 + kx * 4 + c (weights packed to match)
-    d0.sN = (int64_t)150 * 150 * 4; d0.sH = 150 * 4; d0.sW = 4;
-    d0.runq = 7;
-    d0.K = 7 * 28;
-    launch_conv(d0, A, c->dl[0].d_w, c->dl[0].d_b, B, st);  // 72 x 72 x 32, affine folded, relu
+    if (!getenv("CIS_CNN_NO_DIRECT7")) {
+        // first layer: direct 7 x 7 / 2 convolution, normalisation + bias + ReLU fused (k_conv7x7s2_direct)
+        hipLaunchKernelGGL(k_conv7x7s2_direct, dim3((unsigned)n * 41), dim3(256), 0, st, d_in, (const float*)c->dl[0].d_w,
+                           (const float*)c->dl[0].d_b, B, n, 122.782f, 117.001f, 104.298f);
+    } else {
+        hipLaunchKernelGGL(k_normalize_rgb4, grid((int64_t)n * 150 * 150), dim3(256), 0, st, d_in, A, (int64_t)n * 150 * 150, 122.782f,
+                           117.001f, 104.298f);
+        ConvDesc d0 = nhwc_conv(n, 150, 150, 3, 32, 7, 2, 0, 1);
+        // (R, G, B, 0) pixels: a kernel row is a run of 7 aligned float4, k = ky * 28 + kx * 4 + c (weights packed to match)
+        d0.sN = (int64_t)150 * 150 * 4; d0.sH = 150 * 4; d0.sW = 4;
+        d0.runq = 7;
+        d0.K = 7 * 28;
+        launch_conv(d0, A, c->dl[0].d_w, c->dl[0].d_b, B, st);  // 72 x 72 x 32, affine folded, relu
+    }
     int H = (72 - 3) / 2 + 1, W = H, C = 32;                  // max_pool<3,3,2,2>: 35
     hipLaunchKernelGGL(k_maxpool_nhwc_v4, grid((int64_t)n * H * W * C / 4), dim3(256), 0, st, B, A, n, 72, 72, C, H, W);
     float* x = A;      // current activation

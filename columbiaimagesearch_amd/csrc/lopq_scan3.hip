@@ -983,6 +983,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         const int x = (home + a) & 7;
         const int qstart = qs[x];
         const int count = single_queue ? (x == 0 ? qs[1] - qstart : 0) : qs[x + 1] - qstart;
+        if (count <= 0) continue;  // an empty queue costs no atomic and no barrier (the fall-back launch usually finds nothing at all)
         while (true) {
             const long long q0 = S3_CLK();
             (void)q0;
@@ -1192,11 +1193,28 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         if (WLISTS && dyn) {
             // long chunks: a slot lasts ~100 us and slots differ (cells longer than a chunk run twice): the next slot comes from
             // a counter instead of the static schedule, one per round
+            // (dyn == 1: one counter for all; dyn == 2: one queue per XCD holding the runs of 32 slots -- about one cell -- that the
+            // static schedule gives that XCD, so that a cell still streams through ONE L2; an XCD whose queue is empty steals)
             __syncthreads();
-            if (tid == 0) *s_flag = atomicAdd(&dbg[6], 1);
+            if (tid == 0) {
+                int jn = -1;
+                if (dyn == 1) {
+                    jn = atomicAdd(&dbg[6], 1);
+                    jn = jn < total ? jn : -1;
+                } else {
+                    int* qx = dbg - 9;  // the slot header's eight queue counters (zeroed with it; the streaming kernels' own use of them is another launch)
+                    for (int a2 = 0; a2 < 8 && jn < 0; ++a2) {
+                        const int x = (xcd + a2) & 7;
+                        const int li = atomicAdd(&qx[x], 1);
+                        const int jj = (((li >> 5) * 8 + x) << 5) | (li & 31);
+                        if (jj < total) jn = jj;
+                    }
+                }
+                *s_flag = jn;
+            }
             __syncthreads();
             dyn_j = *s_flag;
-            if (dyn_j >= total) break;
+            if (dyn_j < 0) break;
         } else {
             if (slot_of(kb) < 0) break;  // wave-uniform
         }

@@ -190,7 +190,7 @@ def make_c1(outdir):
     np.savez_compressed(os.path.join(outdir, "c1.npz"), **d)
 
 
-def make_pca_fixture(outdir, name, V, M, pca_dims, n_index, n_train, nq, inputs, settings, pca_subsample=None):
+def make_pca_fixture(outdir, name, V, M, pca_dims, n_index, n_train, nq, inputs, settings, pca_subsample=None, train_X=None):
     from lopq import LOPQModelPCA, LOPQSearcher
     from lopq.utils import compute_codes_notparallel
     X, Q = inputs
@@ -198,7 +198,7 @@ def make_pca_fixture(outdir, name, V, M, pca_dims, n_index, n_train, nq, inputs,
     t = time.time()
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
-        m.fit(X[:n_train], pca_dims=pca_dims, n_init=1, random_state=4321, pca_subsample=pca_subsample)
+        m.fit(X[:n_train] if train_X is None else train_X, pca_dims=pca_dims, n_init=1, random_state=4321, pca_subsample=pca_subsample)
     print("%s fit %.1fs  Cs %s Rs %s" % (name, time.time() - t, m.Cs[0].dtype, m.Rs[0].dtype))
     Xi = X[:n_index]
     with contextlib.redirect_stdout(io.StringIO()):
@@ -248,9 +248,10 @@ def make_c3b(outdir):
 def make_c3full(outdir):
     """C3 at its TRUE shape: float32 non-negative 4096-d features, PCA 4096 -> 256 (pca_dims of
     conf/conf_search_sbpycaffe_release.json:12), V=16, M=16 (h=128, w=16).  The reference fits everything
-    (PCA on the first 2500 training vectors: its per-sample np.outer loop costs 0.1 s per 4096-d sample)."""
+    (PCA on 2500 of the training vectors: its per-sample np.outer loop costs 0.1 s per 4096-d sample; the LOPQ stages on all
+    20000 training vectors of golden_inputs.c3full_train -- every local rotation has more points than dimensions)."""
     make_pca_fixture(outdir, "c3full", 16, 16, 256, 4000, 6000, 32, gi.c3full_inputs(),
-                     [(10, 10), (1000, 100), (10000, 100)], pca_subsample=2500)
+                     [(10, 10), (1000, 100), (10000, 100)], pca_subsample=2500, train_X=gi.c3full_train())
 
 
 def make_pk(outdir):

@@ -90,6 +90,12 @@ def c3full_inputs():
     return X, Q
 
 
+def c3full_train():
+    """Training set of the c3full model: 20000 vectors of the same mixture (round 3: the first fit used the 6000 index
+    vectors, which left 21 of the 32 local rotations with fewer points than dimensions and the index degenerate)."""
+    return gmm_unit(20000, 4096, 64, 6, np.float32, nonneg=True)
+
+
 def pk_inputs():
     """Inputs of the pickled-model fixtures (tests/golden/pk): 3000 x 24 float64, 8 queries."""
     rs = np.random.RandomState(5150)

@@ -167,6 +167,28 @@ def test_dlib_direct_3x3_kernel_agrees_with_implicit_gemm(monkeypatch):
         monkeypatch.delenv("CIS_CNN_DIRECT_CFG")
 
 
+def test_dlib_direct_first_layer_agrees_with_implicit_gemm(monkeypatch):
+    """k_conv7x7s2_direct (first layer: raw chip in, normalisation + bias + ReLU fused, weights resident in registers) against the
+    implicit-GEMM route of the same layer behind the separate normalisation pass (CIS_CNN_NO_DIRECT7), and against the CPU
+    restatement; tiles that wrap output rows, the two-tile group at the end of an image, several batch sizes."""
+    from oracle import dlib_oracle as D
+    from columbiaimagesearch_amd.featurizer import DLibFaceNet
+    w = D.synthetic_weights(5)
+    net = DLibFaceNet(w)
+    for n, seed in ((1, 1), (3, 2), (33, 3)):
+        chips = D.synthetic_chips(n, seed=seed)
+        monkeypatch.setenv("CIS_CNN_NO_DIRECT7", "1")
+        ref = net.forward(chips)
+        monkeypatch.delenv("CIS_CNN_NO_DIRECT7")
+        got = net.forward(chips)
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=3e-5 * np.abs(ref).max())  # same products, another float32 summation order
+        if n <= 3:
+            cpu = D.forward_torch(chips, w)
+            np.testing.assert_allclose(got, cpu, rtol=0, atol=3e-4 * np.abs(cpu).max())
+    net.close()
+
+
 @pytest.mark.parametrize("n", [128, 257, 512])
 def test_dlib_batch_in_concurrent_parts_equals_the_single_chain(monkeypatch, n):
     """A batch of 128-512 chips runs as two parts on the handle's own streams (own workspaces, event fences on the caller's

@@ -40,5 +40,5 @@ for _ in range(steps):
     ing.encode_batch_dev(x)
 torch.cuda.synchronize()
 de = (time.perf_counter() - t) / steps
-print("batch %d: CNN + normalise + encode %.3f ms (%.0f descriptors/s); with host insert %.3f ms (%.0f descriptors/s); indexed %d" % (
+print("batch %d: CNN + normalise + encode %.3f ms (%.0f descriptors/s); with device-side insert %.3f ms (%.0f descriptors/s); indexed %d" % (
     B, de * 1e3, B / de, dt * 1e3, B / dt, s.get_nb_indexed()))

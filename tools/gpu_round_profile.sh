@@ -15,5 +15,5 @@ timeout 600 tools/gpu_pmc_cnn.sh ${tag} > /dev/null 2>&1
 { for net in cnn dlib; do echo "== tools/bench_$net.py =="; python tools/mfma_pmc_summary.py gpurun_out/${tag}_${net}_mfma_pmc.csv; done; } > gpurun_out/${tag}_mfma_utilisation.txt 2>&1
 { for a in "2048 10000000 1024" "2048 10000000 8192" "4096 10000000 8192"; do echo "== tools/bench_prodv.py $a =="; timeout 600 python tools/bench_prodv.py $a 2>&1 | grep -v amdgpu | grep "V=\|quota\|parity\|routes"; done; } > gpurun_out/${tag}_prodv.txt
 timeout 400 python tools/emulate_shard.py 2>&1 | grep world > gpurun_out/${tag}_shards.txt
-timeout 300 python tools/bench_ingest.py 2>&1 | grep -v amdgpu | tail -3 > gpurun_out/${tag}_ingest.txt
+{ timeout 300 python tools/bench_ingest.py 2>&1 | grep -v amdgpu | tail -3; timeout 300 python tools/bench_ingest_buffers.py 8192 2>&1 | grep "stages\|buffers"; } > gpurun_out/${tag}_ingest.txt
 cat gpurun_out/${tag}_pytest_gpu.txt; for c in c4 c2 c3; do head -4 gpurun_out/${tag}_${c}_profile.txt; done; cat gpurun_out/${tag}_mfma_utilisation.txt gpurun_out/${tag}_cnn.txt gpurun_out/${tag}_prodv.txt gpurun_out/${tag}_shards.txt gpurun_out/${tag}_ingest.txt; tail -20 gpurun_out/${tag}_limits.txt
