@@ -640,17 +640,21 @@ __global__ void k_normalize_rgb4(const float* __restrict__ in, float* __restrict
 //     cycles of matrix pipe per step.
 // k_conv_igemm ran this layer on (R, G, B, 0) pixels with K = 196 in 254 us per 256 chips (0.31 of the f32 MFMA peak counting the real
 // 147-term products) behind a 25 us normalisation pass.
+template <int TPW /* tiles per wave: the staged window and the weight registers serve 4 TPW tiles */>
 __global__ __launch_bounds__(256) void k_conv7x7s2_direct(const float* __restrict__ in /* [n][150][150][3] raw RGB */,
                                                           const float* __restrict__ wpk /* [196][32]: k = ky * 28 + kx * 4 + c */,
                                                           const float* __restrict__ bias /* [32] */, float* __restrict__ out /* [n][72][72][32] */,
                                                           int n, float m0, float m1, float m2) {
     constexpr int IW = 150, OW = 72, ROWF = IW * 3, NT = OW * OW / 32;  // 162 tiles per image
     constexpr int KSTEPS = 74;
-    __shared__ float win[11 * ROWF];
+    constexpr int GT = 4 * TPW;                                  // tiles per workgroup
+    constexpr int GROUPS = (NT + GT - 1) / GT;                   // workgroups per image
+    constexpr int MAXROWS = 2 * ((GT * 32 + OW - 1) / OW) + 7;   // input rows a group's pixels can touch
+    __shared__ float win[MAXROWS * ROWF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int img = blockIdx.x / 41, grp = blockIdx.x % 41;  // 41 groups of four tiles per image (the last one holds two)
-    const int tile0 = grp * 4;
-    const int ntile = (NT - tile0 < 4) ? (NT - tile0) : 4;
+    const int img = blockIdx.x / GROUPS, grp = blockIdx.x % GROUPS;
+    const int tile0 = grp * GT;
+    const int ntile = (NT - tile0 < GT) ? (NT - tile0) : GT;
     const int p0 = tile0 * 32, p1 = p0 + ntile * 32 - 1;
     const int oy0 = p0 / OW, oy1 = p1 / OW;
     const int nrows = 2 * (oy1 - oy0) + 7;  // input rows 2 oy0 .. 2 oy1 + 6
@@ -676,31 +680,31 @@ __global__ __launch_bounds__(256) void k_conv7x7s2_direct(const float* __restric
         }
     }
     __syncthreads();
-    if (wave >= ntile) return;
-    const int p = p0 + wave * 32 + (lane & 31);
-    const int oy = p / OW, ox = p - oy * OW;
-    const float* a0 = win + (2 * (oy - oy0)) * ROWF + 6 * ox + (lane >> 5);
-    f32x16 acc;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll
-    for (int s2 = 0; s2 < KSTEPS; ++s2) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int k = 2 * s2;
-        const int off = (k / 21) * ROWF + (k % 21);            // folds to an immediate
-        const bool row_end = (k % 21) == 20;                   // the odd element of the pair starts the next kernel row
-        const float av = row_end ? a0[off + (lane >> 5) * (ROWF - 21)] : a0[off];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w[s2], acc, 0, 0, 0);
-    }
-    // epilogue: bias + ReLU; register q of lane l is pixel (q & 3) + 8 (q >> 2) + 4 (l >> 5), channel l & 31
     const float bv = bias[lane & 31];
-    float* o = out + ((int64_t)img * OW * OW + p0 + wave * 32) * 32 + (lane & 31);
+    for (int tw = wave; tw < ntile; tw += 4) {
+        const int p = p0 + tw * 32 + (lane & 31);
+        const int oy = p / OW, ox = p - oy * OW;
+        const float* a0 = win + (2 * (oy - oy0)) * ROWF + 6 * ox + (lane >> 5);
+        f32x16 acc;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        const float v = acc[q] + bv;
-        o[row * 32] = v > 0.f ? v : 0.f;
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < KSTEPS; ++s2) {
+            const int k = 2 * s2;
+            const int off = (k / 21) * ROWF + (k % 21);            // folds to an immediate
+            const bool row_end = (k % 21) == 20;                   // the odd element of the pair starts the next kernel row
+            float av = row_end ? a0[off + (lane >> 5) * (ROWF - 21)] : a0[off];
+            if (k + 1 >= 147) av = (lane >> 5) ? 0.f : av;        // the padding term: its address is past the window (0 x garbage may be NaN)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w[s2], acc, 0, 0, 0);
+        }
+        // epilogue: bias + ReLU; register q of lane l is pixel (q & 3) + 8 (q >> 2) + 4 (l >> 5), channel l & 31
+        float* o = out + ((int64_t)img * OW * OW + p0 + tw * 32) * 32 + (lane & 31);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            const float v = acc[q] + bv;
+            o[row * 32] = v > 0.f ? v : 0.f;
+        }
     }
 }
 
@@ -1060,8 +1064,17 @@ static int cnn_forward_dlib(cis_cnn* c, CnnWs* ws, const float* d_in, int n, flo
     auto grid = [](int64_t total) { return dim3((unsigned)ceil_div(total, 256)); };
     if (!getenv("CIS_CNN_NO_DIRECT7")) {
         // first layer: direct 7 x 7 / 2 convolution, normalisation + bias + ReLU fused (k_conv7x7s2_direct)
-        hipLaunchKernelGGL(k_conv7x7s2_direct, dim3((unsigned)n * 41), dim3(256), 0, st, d_in, (const float*)c->dl[0].d_w,
-                           (const float*)c->dl[0].d_b, B, n, 122.782f, 117.001f, 104.298f);
+        // tiles per wave (the staged window and the weight registers serve 4 x that many tiles): 1 / 2 / 4 -> 161 / 141 / 133 us per 256 chips, forward 1.97 / 1.92 / 1.90 ms (profiles/r03r_dlib_first_layer.txt)
+        const int tpw = getenv("CIS_CNN_D7_TPW") ? atoi(getenv("CIS_CNN_D7_TPW")) : 4;
+        if (tpw == 1)
+            hipLaunchKernelGGL(k_conv7x7s2_direct<1>, dim3((unsigned)n * 41), dim3(256), 0, st, d_in, (const float*)c->dl[0].d_w,
+                               (const float*)c->dl[0].d_b, B, n, 122.782f, 117.001f, 104.298f);
+        else if (tpw == 4)
+            hipLaunchKernelGGL(k_conv7x7s2_direct<4>, dim3((unsigned)n * 11), dim3(256), 0, st, d_in, (const float*)c->dl[0].d_w,
+                               (const float*)c->dl[0].d_b, B, n, 122.782f, 117.001f, 104.298f);
+        else
+            hipLaunchKernelGGL(k_conv7x7s2_direct<2>, dim3((unsigned)n * 21), dim3(256), 0, st, d_in, (const float*)c->dl[0].d_w,
+                               (const float*)c->dl[0].d_b, B, n, 122.782f, 117.001f, 104.298f);
     } else {
         hipLaunchKernelGGL(k_normalize_rgb4, grid((int64_t)n * 150 * 150), dim3(256), 0, st, d_in, A, (int64_t)n * 150 * 150, 122.782f,
                            117.001f, 104.298f);

@@ -6,7 +6,7 @@ python - <<PY
 import csv, re
 rows=list(csv.DictReader(open("/tmp/dl/r_kernel_trace.csv")))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-idx=[i for i,r in enumerate(rows) if "normalize" in r["Kernel_Name"]]
+idx=[i for i,r in enumerate(rows) if "normalize" in r["Kernel_Name"] or "conv7x7" in r["Kernel_Name"]]
 tot=0
 for r in rows[idx[-1]:]:
     d=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3; tot+=d
