@@ -1172,7 +1172,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     int* s_cnt = s_flag + 1;                               // [G] list cursors (the 4-lane atomic of the main pass)
     int* wcnt = reinterpret_cast<int*>(reinterpret_cast<char*>(thr1) + 32);  // [G][NW] entries of the wave-private lists (long chunks)
     Slot4* sd = reinterpret_cast<Slot4*>(reinterpret_cast<char*>(thr1) + 96);
-    constexpr bool WLISTS = LCAPT > 504;  // long chunks: every wave appends to its own quarter of a query's list (no LDS atomic in the loop)
+#ifdef CIS_S4_SHARED_LISTS  // short chunks with one list per query and an LDS atomic per row: 0.176 against 0.172 ms on C2
+    constexpr bool WLISTS = LCAPT > 504;
+#else
+    constexpr bool WLISTS = true;  // every wave appends to its own quarter of a query's list (no LDS atomic in the loop)
+#endif
     constexpr int WCAP = LCAPT / NW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1190,7 +1194,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     (void)k0;
     for (int kb = 0;; kb += S4_DS) {
         int dyn_j = -1;
-        if (WLISTS && dyn) {
+        if (LCAPT > 504 && dyn) {
             // long chunks: a slot lasts ~100 us and slots differ (cells longer than a chunk run twice): the next slot comes from
             // a counter instead of the static schedule, one per round
             // (dyn == 1: one counter for all; dyn == 2: one queue per XCD holding the runs of 32 slots -- about one cell -- that the
@@ -1221,7 +1225,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         __syncthreads();             // the previous round's descriptors and lists are dead
         if (tid < S4_DS) {           // one lane per slot walks the chain slot -> items -> table descriptors
             Slot4 d;
-            const int j = (WLISTS && dyn) ? (tid == 0 ? dyn_j : -1) : slot_of(kb + tid);
+            const int j = (LCAPT > 504 && dyn) ? (tid == 0 ? dyn_j : -1) : slot_of(kb + tid);
             d.ng = 0; d.len = 0; d.start_lo = d.start_hi = 0;
 #pragma unroll
             for (int g = 0; g < G; ++g) { d.item[g] = 0; d.tab0[g] = 0; d.tab1[g] = 0; d.q[g] = 0; d.qinv[g] = 0.f; d.ist_lo[g] = d.ist_hi[g] = d.ilen[g] = 0; }
@@ -1303,15 +1307,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                 const int64_t start = ((int64_t)__builtin_amdgcn_readfirstlane(d->start_hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(d->start_lo);
                 // ---- tables -> 16-bit entries -> LDS (scan3_group's arithmetic) --------------------------------------------------
                 if (tid < nvec) {
+                    // thread -> (sub-quantizer j = tid % nf, four consecutive k): the lanes of a store group spread over the nf
+                    // sub-quantizers (a run of consecutive k per lane group put all sixteen lanes on one bank pair: the entry
+                    // stride of k is M * 8 bytes)
+                    const int j = tid & (nf - 1), kq = tid / nf, k0 = 4 * kq;
+                    const int vidx = j * (K >> 2) + kq;  // float4 index inside a half table [nf][K]
                     float4 pv[G][2];
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const int t0 = __builtin_amdgcn_readfirstlane(d->tab0[g]), t1 = __builtin_amdgcn_readfirstlane(d->tab1[g]);
-                        pv[g][0] = reinterpret_cast<const float4*>(T32 + (int64_t)t0 * nf * K)[tid];
-                        pv[g][1] = reinterpret_cast<const float4*>(T32 + (int64_t)t1 * nf * K)[tid];
+                        pv[g][0] = reinterpret_cast<const float4*>(T32 + (int64_t)t0 * nf * K)[vidx];
+                        pv[g][1] = reinterpret_cast<const float4*>(T32 + (int64_t)t1 * nf * K)[vidx];
                     }
                     uint32_t* tw = reinterpret_cast<uint32_t*>(tab);
-                    const int j = (4 * tid) / K, k0 = 4 * tid - j * K;
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll

@@ -67,9 +67,10 @@ __global__ __launch_bounds__(256) void k_gram_groups(const double* __restrict__ 
 // grid (tiles of 64 outputs, ceil(max rows of a group / 64), groups): y[r][o] = sum_k (x[r][k] - mu[g][k]) * R[g][o][k]
 __global__ __launch_bounds__(256) void k_project_groups(const double* __restrict__ X, const int64_t* __restrict__ goff, int d,
                                                         const double* __restrict__ R /* [groups][d][d] */,
-                                                        const double* __restrict__ mu /* [groups][d] */, double* __restrict__ Y) {
+                                                        const double* __restrict__ mu /* [groups][d] */, double* __restrict__ Y,
+                                                        int64_t tile_base /* first row tile of this launch (groups above 4M rows take several) */) {
     const int g = blockIdx.z, o0 = blockIdx.x * 64;
-    const int64_t r0 = goff[g] + (int64_t)blockIdx.y * 64, r1 = goff[g + 1];
+    const int64_t r0 = goff[g] + (tile_base + (int64_t)blockIdx.y) * 64, r1 = goff[g + 1];
     if (r0 >= r1) return;
     __shared__ double sx[16][64 + 1], sr[16][64 + 1];  // [k][row], [k][output]
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -162,11 +163,13 @@ extern "C" int cis_train_project(const double* X, int64_t n, int d, const int64_
     int64_t max_rows = 0;
     for (int g = 0; g < groups; ++g) max_rows = group_off[g + 1] - group_off[g] > max_rows ? group_off[g + 1] - group_off[g] : max_rows;
     const int64_t row_tiles = ceil_div(max_rows, 64);
-    CIS_REQUIRE(row_tiles <= 65535, "a group of more than 4M rows: split the call");
     for (int g0 = 0; g0 < groups; g0 += 32768) {
         const int ng = groups - g0 < 32768 ? groups - g0 : 32768;
-        hipLaunchKernelGGL(k_project_groups, dim3((unsigned)ceil_div(d, 64), (unsigned)row_tiles, (unsigned)ng), dim3(256), 0, nullptr,
-                           b.dX, b.dOff + g0, d, b.dR + (int64_t)g0 * d * d, b.dM + (int64_t)g0 * d, b.dY);
+        for (int64_t t0 = 0; t0 < row_tiles; t0 += 65535) {  // the grid's y extent holds 65535 tiles = 4M rows of a group
+            const int64_t nt = row_tiles - t0 < 65535 ? row_tiles - t0 : 65535;
+            hipLaunchKernelGGL(k_project_groups, dim3((unsigned)ceil_div(d, 64), (unsigned)nt, (unsigned)ng), dim3(256), 0, nullptr,
+                               b.dX, b.dOff + g0, d, b.dR + (int64_t)g0 * d * d, b.dM + (int64_t)g0 * d, b.dY, t0);
+        }
     }
     CIS_CHECK_HIP(hipGetLastError());
     CIS_CHECK_HIP(hipMemcpy(Y, b.dY, (size_t)n * d * sizeof(double), hipMemcpyDeviceToHost));
