@@ -128,6 +128,15 @@ def _route_worker(rank, world, port, ret):
         ok = np.array_equal(c, coarse[mine]) and np.array_equal(f, fine[mine]) and np.array_equal(i, ids[mine])
         e = route_codes(coarse[:0], fine[:0], ids[:0], owner, V)  # an empty slice on every rank
         ok = ok and e[0].shape == (0, 2) and e[1].shape[0] == 0 and e[2].shape == (0,)
+        # ONE rank with nothing to bring, handed as a 1-D empty array: the record width comes from the model's M, not from
+        # the local array (a rank that derived M = 0 would announce 12-byte records to peers sending 12 + M)
+        M = fine.shape[1]
+        if rank == 1:
+            c2, f2, i2 = route_codes(np.zeros((0, 2), np.uint16), np.zeros(0, np.uint8), np.zeros(0, np.int64), owner, V, M=M)
+        else:
+            c2, f2, i2 = route_codes(coarse[a:b], fine[a:b], ids[a:b], owner, V, M=M)
+        keep = mine & ~((np.arange(n) >= n // world) & (np.arange(n) < 2 * n // world))  # rank 1's slice is missing
+        ok = ok and np.array_equal(c2, coarse[keep]) and np.array_equal(f2, fine[keep]) and np.array_equal(i2, ids[keep])
         ret[rank] = (bool(ok), int(mine.sum()))
     finally:
         dist.destroy_process_group()
