@@ -522,7 +522,13 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
         self.model = model
         self.lmdb_path = lmdb_path
         self.id_lambda = id_lambda
-        self._store = {}   # cell (c0, c1) -> {key suffix bytes: fine tuple}
+        # row store: one row per live key, in first-insertion order; a put of an existing key rewrites its row
+        self._row_of = {}           # full key bytes (cell + suffix) -> row
+        self._suffixes = []         # row -> key suffix bytes
+        self._rows_of_cell = {}     # cell (c0, c1) -> [rows]
+        self._cap = 0
+        self._cells_arr = np.zeros((0, 2), dtype=np.uint16)      # row -> cell
+        self._fine_arr = np.zeros((0, model.M), dtype=np.uint8)  # row -> fine codes
         self._dev = None   # LOPQSearcherHIP over the key-ordered arrays
         self._suffix_of_slot = []
         self.env = None
@@ -537,21 +543,36 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
                 self.index_db = self.env.open_db(b"index")
                 with self.env.begin(db=self.index_db) as txn:
                     for key, value in txn.cursor():
-                        self._store.setdefault(self.decode_cell(key[:4]), {})[bytes(key[4:])] = self.decode_fine_codes(value)
+                        self._put(bytes(key), self.decode_fine_codes(value))
             else:
                 # cold start from the log: same keys, same values, later records replace earlier ones (put semantics)
                 self._log = kvlog.KVLog(str(lmdb_path))
                 for key, value in self._log.load():
-                    self._store.setdefault(self.decode_cell(key[:4]), {})[bytes(key[4:])] = self.decode_fine_codes(value)
-        self.nb_indexed = sum(len(v) for v in self._store.values())
+                    self._put(bytes(key), self.decode_fine_codes(value))
+        self.nb_indexed = len(self._suffixes)
+
+    def _put(self, key, fine):
+        """put(): a new key takes the next row, an existing key has its value replaced (last write wins, :465)."""
+        row = self._row_of.get(key)
+        if row is None:
+            row = len(self._suffixes)
+            if row >= self._cap:  # grow the row arrays geometrically
+                self._cap = max(1024, 2 * self._cap)
+                self._cells_arr = np.concatenate([self._cells_arr, np.zeros((self._cap - self._cells_arr.shape[0], 2), dtype=np.uint16)])
+                self._fine_arr = np.concatenate([self._fine_arr, np.zeros((self._cap - self._fine_arr.shape[0], self._fine_arr.shape[1]), dtype=np.uint8)])
+            self._row_of[key] = row
+            self._suffixes.append(key[4:])
+            cell = self.decode_cell(key[:4])
+            self._cells_arr[row] = cell
+            self._rows_of_cell.setdefault(cell, []).append(row)
+        self._fine_arr[row] = fine
 
     def close(self):
         """Flush and release the persistent store (a log with many replaced keys is compacted first)."""
         if self._log is not None:
             live = self.get_nb_indexed()
             if self._log.records > 2 * max(live, 1):
-                self._log.compact((self.encode_cell(c) + k, self.encode_fine_codes(f))
-                                  for c in sorted(self._store) for k, f in sorted(self._store[c].items()))
+                self._log.compact((key, self.encode_fine_codes(self._fine_arr[row])) for key, row in sorted(self._row_of.items()))
             self._log = None
         if self.env is not None:
             self.env.close()
@@ -591,7 +612,7 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
         return self.id_lambda(suffix.decode("latin1"))
 
     def get_nb_indexed(self):
-        self.nb_indexed = sum(len(v) for v in self._store.values())
+        self.nb_indexed = len(self._suffixes)
         return self.nb_indexed
 
     def add_codes(self, codes, ids=None):
@@ -603,7 +624,7 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
                 cell = (int(code[0][0]), int(code[0][1]))
                 fine = tuple(int(v) for v in code[1])
                 suffix = self._key_suffix(item_id)
-                self._store.setdefault(cell, {})[suffix] = fine  # put(): an existing key is overwritten
+                self._put(self.encode_cell(cell) + suffix, fine)  # put(): an existing key is overwritten
                 if txn is not None:
                     txn.put(self.encode_cell(cell) + suffix, self.encode_fine_codes(fine))
                 if logged is not None:
@@ -614,7 +635,9 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
                 self.env.sync()
             if logged:
                 self._log.append(logged)  # one write + fsync per add_codes call (the reference: env.sync(), :468)
-        self._dev = None
+        if self._dev is not None:  # the key-ordered GPU index is rebuilt before the next search
+            self._dev.close()
+            self._dev = None
         self.get_nb_indexed()
 
     def add_codes_array(self, coarse, fine, ids=None, dedup=True):
@@ -625,27 +648,26 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
     def get_cell(self, cell):
         ct = _code_dtype(self.model.V)
         c = (int(cell[0]), int(cell[1]))
-        items = self._store.get(c, {})
-        return [(self._id_of_suffix(k), LOPQCode((ct(c[0]), ct(c[1])), items[k])) for k in sorted(items)]
+        rows = sorted(self._rows_of_cell.get(c, ()), key=lambda r: self._suffixes[r])  # the cursor's order: key bytes
+        return [(self._id_of_suffix(self._suffixes[r]), LOPQCode((ct(c[0]), ct(c[1])), tuple(int(v) for v in self._fine_arr[r])))
+                for r in rows]
 
     def _device_index(self):
+        """The GPU index in key order: one lexicographic sort of (cell, key suffix) over the row arrays (numpy, no Python loop
+        over the items) and one device-side bulk insert -- rounds 1-2 re-sorted a dict of dicts item by item on every refresh."""
         if self._dev is None:
-            cells = sorted(self._store)
-            n = sum(len(self._store[c]) for c in cells)
-            coarse = np.empty((n, 2), dtype=np.uint16)
-            fine = np.empty((n, self.model.M), dtype=np.uint8)
-            self._suffix_of_slot = []
-            i = 0
-            for c in cells:
-                items = self._store[c]
-                for k in sorted(items):  # byte order of the keys inside the cell = the cursor's order
-                    coarse[i] = c
-                    fine[i] = items[k]
-                    self._suffix_of_slot.append(k)
-                    i += 1
+            n = len(self._suffixes)
             self._dev = LOPQSearcherHIP(self.model)
             if n:
-                self._dev.add_codes_array(coarse, fine, ids=np.arange(n, dtype=np.int64), dedup=False)
+                cells = self._cells_arr[:n]
+                cell_id = cells[:, 0].astype(np.int64) * 65536 + cells[:, 1]
+                # fixed-width byte strings compare like the keys do (a shorter key sorts first; ids hold no NUL bytes)
+                order = np.lexsort((np.array(self._suffixes, dtype="S"), cell_id))
+                self._suffix_of_slot = [self._suffixes[r] for r in order]
+                self._dev.add_codes_array(np.ascontiguousarray(cells[order]), np.ascontiguousarray(self._fine_arr[:n][order]),
+                                          ids=np.arange(n, dtype=np.int64), dedup=False)
+            else:
+                self._suffix_of_slot = []
         return self._dev
 
     def search_batch(self, X, quota=10, limit=None, with_codes=False):
