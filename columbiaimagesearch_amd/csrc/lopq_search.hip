@@ -4216,6 +4216,65 @@ __global__ __launch_bounds__(WPB * 64) void k_merge_packed(const cis_hit* __rest
     if (lane == 0 && out_n) out_n[q] = nv;
 }
 
+// Any limit (above the 3072 records a wave ranks in LDS): every shard's list arrives ranked by (dist, visit_rank, pos), and the
+// keys of different shards never tie (a cell lives on one shard), so a record's place in the merged ranking is its index in its
+// own list plus, for every other list, the number of records with a smaller key -- binary searches, no sort.  One workgroup per
+// query; records past `limit` are dropped, unused slots padded like every other route (-1 / NaN).
+__global__ __launch_bounds__(256) void k_merge_packed_ranked(const cis_hit* __restrict__ parts, int world, int64_t stride,
+                                                             const int64_t* __restrict__ off, const int32_t* __restrict__ cnt, int nq, int limit,
+                                                             int64_t* __restrict__ out_ids, double* __restrict__ out_dists, int32_t* __restrict__ out_n,
+                                                             int32_t* __restrict__ out_cells, uint32_t* __restrict__ out_pos) {
+    const int q = blockIdx.x;
+    __shared__ int s_tot;
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < world; ++w) t += cnt[(int64_t)w * nq + q];
+        s_tot = t;
+    }
+    __syncthreads();
+    const int total = s_tot;
+    const int64_t o = (int64_t)q * limit;
+    auto less = [](const cis_hit& a, const cis_hit& b) -> bool {
+        const uint64_t da = (uint64_t)__double_as_longlong(a.dist), db = (uint64_t)__double_as_longlong(b.dist);
+        if (da != db) return da < db;  // non-negative doubles order like their bit patterns
+        if (a.visit_rank != b.visit_rank) return a.visit_rank < b.visit_rank;
+        return a.pos < b.pos;
+    };
+    for (int w = 0; w < world; ++w) {
+        const cis_hit* lst = parts + (int64_t)w * stride + off[(int64_t)w * nq + q];
+        const int n = cnt[(int64_t)w * nq + q];
+        for (int a = threadIdx.x; a < n; a += blockDim.x) {
+            const cis_hit e = lst[a];
+            int64_t rank = a;
+            for (int w2 = 0; w2 < world && rank < limit; ++w2) {
+                if (w2 == w) continue;
+                const cis_hit* l2 = parts + (int64_t)w2 * stride + off[(int64_t)w2 * nq + q];
+                int lo = 0, hi = cnt[(int64_t)w2 * nq + q];
+                while (lo < hi) {  // records of list w2 with a smaller key
+                    const int mid = (lo + hi) >> 1;
+                    if (less(l2[mid], e)) lo = mid + 1;
+                    else hi = mid;
+                }
+                rank += lo;
+            }
+            if (rank < limit) {
+                out_ids[o + rank] = e.id;
+                out_dists[o + rank] = e.dist;
+                if (out_cells) out_cells[o + rank] = e.cell;
+                if (out_pos) out_pos[o + rank] = e.pos;
+            }
+        }
+    }
+    const int nv = total < limit ? total : limit;
+    for (int x = nv + threadIdx.x; x < limit; x += blockDim.x) {
+        out_ids[o + x] = -1;
+        out_dists[o + x] = __longlong_as_double(0x7ff8000000000000LL);
+        if (out_cells) out_cells[o + x] = -1;
+        if (out_pos) out_pos[o + x] = 0xffffffffu;
+    }
+    if (threadIdx.x == 0 && out_n) out_n[q] = nv;
+}
+
 extern "C" int cis_merge_packed_dev(const cis_hit* d_parts, int world, int64_t stride, const int64_t* d_off,
                                     const int32_t* d_cnt, int nq, int limit, int64_t* d_ids, double* d_dists,
                                     int32_t* d_n_found, int32_t* d_cells, uint32_t* d_pos, void* stream) {
@@ -4234,10 +4293,9 @@ extern "C" int cis_merge_packed_dev(const cis_hit* d_parts, int world, int64_t s
     else if (limit <= 3072)  // one wave per workgroup with 96 KB of LDS: 4096 keys per round, `limit` of them carried over
         hipLaunchKernelGGL((k_merge_packed<4096, 1>), dim3((unsigned)nq), dim3(64), (size_t)3 * 4096 * 8, st, d_parts, world, stride, d_off,
                            d_cnt, nq, limit, d_ids, d_dists, d_n_found, d_cells, d_pos);
-    else {
-        cis_set_error("packed merge supports limit <= 3072");
-        return CIS_EUNSUPPORTED;
-    }
+    else  // any limit: places by binary search in the other shards' ranked lists
+        hipLaunchKernelGGL(k_merge_packed_ranked, dim3((unsigned)nq), dim3(256), 0, st, d_parts, world, stride, d_off, d_cnt, nq, limit,
+                           d_ids, d_dists, d_n_found, d_cells, d_pos);
     CIS_CHECK_HIP(hipGetLastError());
     return CIS_OK;
 }

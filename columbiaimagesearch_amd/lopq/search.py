@@ -469,16 +469,6 @@ def merge_hits_dev(parts, with_codes=False):
     return out
 
 
-def pack_hits_dev(hits):
-    """Valid hits of a partial result [nq, L, 32] (uint8) packed in query order: (packed [total, 4] int64, cnt [nq] int32).
-    Valid hits are a prefix of every row (id >= 0).  The boolean indexing synchronises with the device."""
-    import torch
-    nq, L = int(hits.shape[0]), int(hits.shape[1])
-    hv = hits.view(torch.int64).view(nq, L, 4)
-    valid = hv[:, :, 2] >= 0
-    return hv[valid], valid.sum(dim=1, dtype=torch.int32)
-
-
 def merge_packed_dev(parts, off, cnt, nq, L, with_codes=False):
     """Merge packed per-shard hit lists: parts [world, stride, 4] int64 (cis_hit records), off [world, nq] int64,
     cnt [world, nq] int32 -> dict like search_batch_dev.  This is what follows the all-gather over xGMI: only valid
@@ -687,4 +677,4 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
 LOPQSearcher = LOPQSearcherHIP
 
 __all__ = ["LOPQSearcherBase", "LOPQSearcherHIP", "LOPQSearcher", "LOPQSearcherLMDB", "LOPQModel", "LOPQModelPCA", "LOPQCode",
-           "multisequence", "multisequence_batch", "merge_hits_dev", "merge_packed_dev", "pack_hits_dev"]
+           "multisequence", "multisequence_batch", "merge_hits_dev", "merge_packed_dev"]

@@ -61,7 +61,7 @@ def _worker(rank, world, port, name, quota, limit, ret):
                 ref_lst = parts[w, qi][parts[w, qi]["id"] >= 0]
                 ok = ok and np.array_equal(lst, ref_lst)
         # the any-limit merge of the packed lists (stable sorts by pos/visit_rank, dist, query) reproduces the single index
-        from columbiaimagesearch_amd.distributed import merge_packed_sorted
+        from ref_merge import merge_packed_sorted
         mo = merge_packed_sorted(pparts, off, cnt_all, nq, limit)
         for qi in range(nq):
             ids, dists, _ = ix.search(Q[qi], quota=quota, limit=limit)

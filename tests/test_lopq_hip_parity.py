@@ -300,7 +300,8 @@ def test_cell_sharded_search_equals_single(name, world):
         np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
         np.testing.assert_array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
         # the packed exchange format (what ShardedSearcher sends over RCCL): valid hits only, padded to the largest shard
-        from columbiaimagesearch_amd.lopq.search import merge_packed_dev, pack_hits_dev
+        from columbiaimagesearch_amd.lopq.search import merge_packed_dev
+        from ref_merge import pack_hits_dev
         packed = [pack_hits_dev(h) for h in parts]
         stride = max(max(int(pk.shape[0]) for pk, _ in packed), 1)
         buf = torch.zeros((world, stride, 4), dtype=torch.int64, device="cuda")
@@ -326,9 +327,9 @@ def test_cell_sharded_search_equals_single(name, world):
 @pytest.mark.gpu
 def test_sharded_any_limit_merge_equals_single():
     """limit above the 512 records per query of the one-wave merge kernel (and above the 3072 of the dense one): the
-    shards' packed lists are merged by stable device sorts (distributed.merge_packed_sorted) -- same result as one index."""
+    shards' packed lists are merged by cis_merge_packed_dev at any limit -- same result as one index."""
     import torch
-    from columbiaimagesearch_amd.distributed import merge_packed_sorted
+    from ref_merge import merge_packed_sorted
     from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
     z, X, Q = load_golden("c2")
     m = hip_model(z)
@@ -352,12 +353,15 @@ def test_sharded_any_limit_merge_equals_single():
             buf[r, :t] = p["packed"][:t]
         cnt = torch.stack([p["cnt"] for p in pp]).contiguous()
         off = torch.stack([p["off"] for p in pp]).contiguous()
-        out = merge_packed_sorted(buf, off, cnt, 9, L)
-        np.testing.assert_array_equal(out["ids"].cpu().numpy(), ref["ids"])
-        np.testing.assert_array_equal(out["n_found"].cpu().numpy(), ref["n_found"])
-        a, b = out["dists"].cpu().numpy(), ref["dists"]
-        np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
-        np.testing.assert_array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+        from columbiaimagesearch_amd.lopq.search import merge_packed_dev
+        # the product merge (HIP: one wave per query up to 3072 records, places by binary search above) and the test-side
+        # restatement with three stable torch sorts, both against the single index
+        for out in (merge_packed_dev(buf, off, cnt, 9, L, with_codes=True), merge_packed_sorted(buf, off, cnt, 9, L)):
+            np.testing.assert_array_equal(out["ids"].cpu().numpy(), ref["ids"])
+            np.testing.assert_array_equal(out["n_found"].cpu().numpy(), ref["n_found"])
+            a, b = out["dists"].cpu().numpy(), ref["dists"]
+            np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+            np.testing.assert_array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
 
 
 def test_device_entry_points_match_host_entry_points():

@@ -7,7 +7,9 @@ sys.argv = [sys.argv[0]]
 import bench
 from columbiaimagesearch_amd.distributed import greedy_cell_owner
 from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
-from columbiaimagesearch_amd.lopq.search import pack_hits_dev, merge_packed_dev
+from columbiaimagesearch_amd.lopq.search import merge_packed_dev
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from ref_merge import pack_hits_dev
 model, z = bench.load_model("c4")
 dev = torch.device("cuda", 0)
 P = bench.mixture_centers("descriptor", dev)
