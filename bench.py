@@ -179,8 +179,20 @@ def main():
     # the oracle's compute_codes after the timed region (the oracle index of the search spot check is built from HIP codes)
     n_sample = max(4096 // N_CHUNKS + 1, 1)
     sample_x, sample_pos = [], []
-    for c in my_chunks:
-        x = gen_chunk(centers, c, chunk_n, device)
+    # the generator's chunks are encoded in groups of about 65536 vectors, the library's own pass size (one call per 12500-row
+    # chunk of the 1M configurations leaves the chip half empty: c2 75 -> ~150 M, c3 8.7 -> ~10 M vectors/s)
+    group = max(1, 65536 // chunk_n)
+    for g0 in range(0, len(my_chunks), group):
+        xs = []
+        for c in my_chunks[g0:g0 + group]:
+            x = gen_chunk(centers, c, chunk_n, device)
+            xs.append(x)
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                sel = torch.as_tensor(np.random.RandomState(4242 + c).choice(chunk_n, n_sample, replace=False), device=device)
+                sample_x.append(x[sel].cpu().numpy())
+                sample_pos.append(sel.cpu().numpy() + (c - my_chunks[0]) * chunk_n)
+        x = xs[0] if len(xs) == 1 else torch.cat(xs)
+        del xs
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()  # predict_batch_dev launches on torch's current stream: these events bracket the encode kernels only
         co, fi = model.predict_batch_dev(x)
@@ -188,10 +200,7 @@ def main():
         ev.append((e0, e1))
         coarse_l.append(co)
         fine_l.append(fi)
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            sel = torch.as_tensor(np.random.RandomState(4242 + c).choice(chunk_n, n_sample, replace=False), device=device)
-            sample_x.append(x[sel].cpu().numpy())
-            sample_pos.append(sel.cpu().numpy() + (c - my_chunks[0]) * chunk_n)
+        del x
     coarse = torch.cat(coarse_l)
     fine = torch.cat(fine_l)
     del coarse_l, fine_l

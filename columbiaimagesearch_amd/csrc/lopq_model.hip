@@ -338,6 +338,132 @@ __global__ __launch_bounds__(256) void k_pca_gemm_mfma(const TX* __restrict__ X,
             }
 }
 
+// The same product with 128 x 128 block tiles for passes that fill the chip (the encode's 65536-row passes at 4096 input dims:
+// 137 GFLOP each): a wave owns 64 x 64 = 4 x 4 MFMA tiles, so a k-step of four reads eight operands for sixteen MFMAs (the 64 x 64
+// form: four for four) and every staged element of X and P feeds twice as many products.  Same instruction and the same k order per
+// output element as the form above -- bit-identical results.
+template <typename TX, bool SUBF32>
+__global__ __launch_bounds__(256) void k_pca_gemm_mfma128(const TX* __restrict__ X, const double* __restrict__ mu,
+                                                          const double* __restrict__ P, double* __restrict__ Y,
+                                                          int64_t n, int D_in, int D) {
+    constexpr int BK = 16, BM = 128, BN = 128;
+    __shared__ double sA[2][BK][BM + 2];  // [stage][k][row]
+    __shared__ double sB[2][BK][BN + 2];  // [stage][k][col]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int col0 = blockIdx.y * BN;
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+    double ra[2][4], rb[4][2];
+    const bool vec4 = (D_in % 4 == 0);
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = tid + e * 256;            // 128 rows x 4 quads of consecutive k
+            const int r = idx >> 2, kq = (idx & 3) * 4;
+            const bool ron = row0 + r < n;
+            float xf[4];
+            double xd[4];
+            bool on[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { on[c] = ron && k0 + kq + c < D_in; xf[c] = 0.f; xd[c] = 0.0; }
+            if constexpr (sizeof(TX) == 4) {
+                if (vec4 && on[3]) {
+                    const float4 q = *reinterpret_cast<const float4*>(X + (row0 + r) * D_in + k0 + kq);
+                    xf[0] = q.x; xf[1] = q.y; xf[2] = q.z; xf[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (on[c]) xf[c] = (float)X[(row0 + r) * D_in + k0 + kq + c];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xd[c] = (double)xf[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (on[c]) xd[c] = (double)X[(row0 + r) * D_in + k0 + kq + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double v = 0.0;
+                if (on[c]) {
+                    if constexpr (SUBF32) v = (double)(xf[c] - (float)mu[k0 + kq + c]);  // float32 - float32
+                    else v = xd[c] - mu[k0 + kq + c];
+                }
+                ra[e][c] = v;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;            // 16 k x 64 column pairs
+            const int k = idx >> 6, c = (idx & 63) * 2;
+            rb[e][0] = 0.0; rb[e][1] = 0.0;
+            if (k0 + k < D_in) {
+                if (col0 + c + 1 < D && (D % 2 == 0)) {
+                    const double2 q = *reinterpret_cast<const double2*>(P + (int64_t)(k0 + k) * D + col0 + c);
+                    rb[e][0] = q.x; rb[e][1] = q.y;
+                } else {
+                    if (col0 + c < D) rb[e][0] = P[(int64_t)(k0 + k) * D + col0 + c];
+                    if (col0 + c + 1 < D) rb[e][1] = P[(int64_t)(k0 + k) * D + col0 + c + 1];
+                }
+            }
+        }
+    };
+    auto stash = [&](int st) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = tid + e * 256;
+            const int r = idx >> 2, kq = (idx & 3) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sA[st][kq + c][r] = ra[e][c];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            const int k = idx >> 6, c = (idx & 63) * 2;
+            sB[st][k][c] = rb[e][0];
+            sB[st][k][c + 1] = rb[e][1];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int st = 0;
+    for (int k0 = 0; k0 < D_in; k0 += BK) {
+        const bool more = k0 + BK < D_in;
+        if (more) fetch(k0 + BK);
+#pragma unroll
+        for (int k = 0; k < BK; k += 4) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = sA[st][k + (lane >> 4)][wm * 64 + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = sB[st][k + (lane >> 4)][wn * 64 + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stash(st ^ 1);
+        __syncthreads();
+        st ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + wm * 64 + i * 16 + (lane >> 4) + 4 * r;
+                const int c = col0 + wn * 64 + j * 16 + (lane & 15);
+                if (row < n && c < D) Y[row * D + c] = acc[i][j][r];
+            }
+}
+
 // Row L2 renormalisation (numpy: sqrt(add.reduce(y*y, axis=1)), then y / norm) and float32 cast.
 // One 64-lane wave per row would break the summation order, so each thread owns a row.
 __global__ void k_pca_finish(const double* __restrict__ Y, float* __restrict__ out, int64_t n, int D,
@@ -1351,9 +1477,14 @@ int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, floa
     // K 16 per stage = four workgroups per CU: pays once the grid is more than one round of the 32-per-stage form (measured on
     // the 4096 -> 256 product: 12500 rows 7.5 -> 8.3 M vectors/s of encode, 8192 rows 0.61 -> 0.64 ms)
     const bool bk16 = getenv("CIS_PCA_BK") ? atoi(getenv("CIS_PCA_BK")) == 16 : (int64_t)gm.x * gm.y > 640;
+    // 128 x 128 tiles once they fill the chip twice over (CIS_PCA_TILE=64 keeps the 64 x 64 form)
+    const dim3 gm128((unsigned)ceil_div(n, 128), (unsigned)ceil_div(m->D, 128));
+    const int tile_env = getenv("CIS_PCA_TILE") ? atoi(getenv("CIS_PCA_TILE")) : 0;
+    const bool big_tiles = use_mfma && m->D >= 128 && tile_env != 64 && ((int64_t)gm128.x * gm128.y >= 512 || tile_env == 128);
 #define CIS_PCA_LAUNCH(TX, SUB, XP)                                                                                              \
     do {                                                                                                                          \
-        if (use_mfma && bk16) hipLaunchKernelGGL((k_pca_gemm_mfma<TX, SUB, 16>), gm, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
+        if (big_tiles) hipLaunchKernelGGL((k_pca_gemm_mfma128<TX, SUB>), gm128, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
+        else if (use_mfma && bk16) hipLaunchKernelGGL((k_pca_gemm_mfma<TX, SUB, 16>), gm, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
         else if (use_mfma) hipLaunchKernelGGL((k_pca_gemm_mfma<TX, SUB, 32>), gm, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
         else if (small) hipLaunchKernelGGL((k_pca_gemm<TX, SUB, 2>), g, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
         else hipLaunchKernelGGL((k_pca_gemm<TX, SUB, 4>), g, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D);       \
