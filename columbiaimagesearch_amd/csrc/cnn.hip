@@ -13,6 +13,7 @@
 // axis of the gather and the across-channel LRN window are contiguous.  Bias + ReLU are fused into the
 // GEMM epilogue; pooling uses caffe's ceil-mode output size with windows clipped to the input.
 #include <atomic>
+#include <thread>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1161,6 +1162,34 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
     // recorded and waited for on the caller's stream, then the first error is returned.
     int rc = CIS_OK;
     hipError_t herr = hipSuccess;
+    // CIS_CNN_THREADS=1: every part is enqueued from its own host thread (a part is ~50 launches: enqueued one part after the other,
+    // the last part starts late); default off, measured in profiles/r03y_cnn_parts.txt
+    static const bool threaded = getenv("CIS_CNN_THREADS") && atoi(getenv("CIS_CNN_THREADS")) != 0;
+    if (threaded) {
+        int rcs[kMaxParts] = {0, 0, 0, 0};
+        for (int p = 0; p < parts && herr == hipSuccess; ++p) herr = hipStreamWaitEvent(c->ps[p], c->ev_in, 0);
+        if (herr == hipSuccess) {
+            auto run = [&](int p) {
+                (void)hipSetDevice(c->device);
+                const int lo = (int)((int64_t)n * p / parts), hi = (int)((int64_t)n * (p + 1) / parts);
+                rcs[p] = c->arch == 2 ? cnn_forward_dlib(c, &c->ws[p], d_nchw + lo * in_item, hi - lo, d_feats + lo * out_item, c->ps[p])
+                                      : cnn_forward_sentibank(c, &c->ws[p], d_nchw + lo * in_item, hi - lo, d_feats + lo * out_item, c->ps[p]);
+            };
+            std::thread th[kMaxParts];
+            for (int p = 1; p < parts; ++p) th[p] = std::thread(run, p);
+            run(0);
+            for (int p = 1; p < parts; ++p) th[p].join();
+            for (int p = 0; p < parts; ++p) {
+                if (rcs[p] != CIS_OK && rc == CIS_OK) rc = rcs[p];
+                hipError_t e = hipEventRecord(c->ev_done[p], c->ps[p]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(st, c->ev_done[p], 0);
+                if (e != hipSuccess) { (void)hipStreamSynchronize(c->ps[p]); herr = e; }
+            }
+            if (rc != CIS_OK) { cis_set_error("a part of the CNN forward failed (code %d)", rc); return rc; }
+        }
+        CIS_CHECK_HIP(herr);
+        return CIS_OK;
+    }
     for (int p = 0; p < parts && rc == CIS_OK && herr == hipSuccess; ++p) {
         const int lo = (int)((int64_t)n * p / parts), hi = (int)((int64_t)n * (p + 1) / parts);
         herr = hipStreamWaitEvent(c->ps[p], c->ev_in, 0);
