@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int G = S3G;
     static_assert(NW == G, "one wave per query in the threshold and verification phases");
-    static_assert(M == 4 || M == 8, "one float4 of every half table per thread");
+    static_assert(M == 4 || M == 8 || M == 16, "float4s of the half tables are dealt to the threads in rounds of 256");
     constexpr int nf = M / 2;
     constexpr uint32_t CAP = 65535u / M;
     constexpr int LCAP = LCAPT, NS = S4_NS, NRV = (LCAP + 63) / 64;
@@ -1306,11 +1306,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                 const int len = __builtin_amdgcn_readfirstlane(d->len);
                 const int64_t start = ((int64_t)__builtin_amdgcn_readfirstlane(d->start_hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(d->start_lo);
                 // ---- tables -> 16-bit entries -> LDS (scan3_group's arithmetic) --------------------------------------------------
-                if (tid < nvec) {
-                    // thread -> (sub-quantizer j = tid % nf, four consecutive k): the lanes of a store group spread over the nf
+                for (int vt = tid; vt < nvec; vt += NW * 64) {
+                    // thread -> (sub-quantizer j = vt % nf, four consecutive k): the lanes of a store group spread over the nf
                     // sub-quantizers (a run of consecutive k per lane group put all sixteen lanes on one bank pair: the entry
                     // stride of k is M * 8 bytes)
-                    const int j = tid & (nf - 1), kq = tid / nf, k0 = 4 * kq;
+                    const int j = vt & (nf - 1), kq = vt / nf, k0 = 4 * kq;
                     const int vidx = j * (K >> 2) + kq;  // float4 index inside a half table [nf][K]
                     float4 pv[G][2];
 #pragma unroll
@@ -1837,10 +1837,14 @@ Scan3Geom scan3_geom(int M, int K, int L, int64_t avg_chunk, int force_two_pass)
     // of 1016 entries (the sample threshold lets ~4 L candidates through) and a wider rank margin (a list that fails its
     // verification costs a whole streaming-form slot in the fall-back launch)
     g.long_chunks = avg_chunk >= 6144 ? 1 : 0;
-    if (g.two_pass == 0 && g.long_chunks && M <= 8 && L <= 128) g.two_pass = 2;
+    // the sampled form at M = 16 (CIS_S4_M16=1, off): built and measured on C3 -- with 12-bit entries the + M + 1 slack is ~17 % of the
+    // cut, 84 % of the 1016-entry lists overflow and the slots go to the fall-back (8.99 against 0.60 ms for k_adc_scan2); it needs
+    // 17-bit sums (or a per-query scale that saturates far entries with a flag) first
+    static const int s4_m16 = getenv("CIS_S4_M16") ? atoi(getenv("CIS_S4_M16")) : 0;
+    if (g.two_pass == 0 && g.long_chunks && (M <= 8 || s4_m16) && L <= 128) g.two_pass = 2;
     if (const char* e = getenv("CIS_SCAN3_TWOPASS")) g.two_pass = atoi(e);
     if (force_two_pass >= 0) g.two_pass = force_two_pass;  // scan modes 3 / 4 / 5 (tests)
-    if (g.two_pass == 2 && M > 8) g.two_pass = g.long_chunks ? 0 : 1;
+    if (g.two_pass == 2 && M > 8 && !s4_m16 && force_two_pass != 2) g.two_pass = g.long_chunks ? 0 : 1;
     if (g.two_pass == 1 && g.long_chunks && force_two_pass < 0) g.two_pass = 0;  // the histogram atomics of the two-pass form contend on long chunks
     if (g.two_pass < 0 || g.two_pass > 2) g.two_pass = 0;
     g.S = g.NW * (NR * 64 - 8);
@@ -1860,7 +1864,7 @@ static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, 
     const int64_t resident = 256 * (per_cu < 1 ? 1 : per_cu);  // persistent grid: what the chip can hold
     const int64_t want = (n_items + g.G - 1) / g.G + 8;
     const unsigned grid = (unsigned)(want < resident ? ((want + 7) / 8) * 8 : resident);
-    if constexpr (M <= 8 && NW == 4) {
+    if constexpr (NW == 4) {
         if (g.two_pass == 2) {
             // k_adc_scan4, then the slots it could not settle (normally none) through this kernel's two-pass form: the fall-back
             // list is a second slot header (fhdr: queue counters [0..7], queue starts [16..24] of which only [17] = count is used)
@@ -1875,7 +1879,7 @@ static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, 
             const int dyn_long = getenv("CIS_S4_DYN") ? atoi(getenv("CIS_S4_DYN")) : 0;
             int* dbg4 = qctr + 9;
             if (!g.long_chunks) {
-                constexpr int WPE4 = CIS_S4_WPE;
+                constexpr int WPE4 = (M == 16) ? 4 : CIS_S4_WPE;  // (M = 16: 41 KB of LDS hold three workgroups per CU anyway)
                 const size_t lds4 = scan4_lds(M, K, S4_LCAP);
                 const int by_lds4 = (int)(163840 / lds4);
                 const int per_cu4 = by_lds4 < WPE4 ? by_lds4 : WPE4;
@@ -1884,7 +1888,7 @@ static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, 
                 hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_U, NW, WPE4, S4_LCAP>), dim3(grid4), dim3(NW * 64), lds4, st, items, tabs, slots, n_slots,
                                    T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_short, 1 << 20, S4_NS, 0);
             } else {
-                constexpr int WPE4 = 4;
+                constexpr int WPE4 = (M == 16) ? 3 : 4;  // (M = 16: 49 KB of LDS = three workgroups per CU, 168 registers)
                 const size_t lds4 = scan4_lds(M, K, S4_LCAP_LONG);
                 const int by_lds4 = (int)(163840 / lds4);
                 const int per_cu4 = by_lds4 < WPE4 ? by_lds4 : WPE4;

@@ -3603,7 +3603,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     // ... and long cells at M <= 8, limit <= 128 through its sampled single-pass form (k_adc_scan4 with a tenth of the rows as
     // the sample: profiles/r03m_*); CIS_SCAN_LONG=0 keeps them on k_adc_scan2
     static const int env_long = getenv("CIS_SCAN_LONG") ? atoi(getenv("CIS_SCAN_LONG")) : 1;
-    const bool long_cells = env_long != 0 && !short_cells && M <= 8 && L <= 128 && ix->ncells <= 65536;
+    static const int env_m16 = getenv("CIS_S4_M16") ? atoi(getenv("CIS_S4_M16")) : 0;
+    const bool long_cells = env_long != 0 && !short_cells && (M <= 8 || env_m16) && L <= 128 && ix->ncells <= 65536;
     const bool use3 = !ix->force_exact_scan && scan3_supported(M, K, L) && !use_all_path(ix, M, K, L, nq) &&
                       (ix->force_scan3 || (nq >= 256 && !ix->force_scan2 && (env_scan == 3 || (env_scan == 0 && (short_cells || long_cells)))));
     // (Splitting a shard's cells into chunks so that a cell-sharded index at world = 8 fills the chip again was measured
