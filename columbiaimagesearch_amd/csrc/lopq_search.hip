@@ -3609,7 +3609,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                       (ix->force_scan3 || (nq >= 256 && !ix->force_scan2 && (env_scan == 3 || (env_scan == 0 && (short_cells || long_cells)))));
     // (Splitting a shard's cells into chunks so that a cell-sharded index at world = 8 fills the chip again was measured
     // and lost: 0.516 against 0.306 ms per partial search -- more survivors, colder bounds: profiles/r02d_shard_emulation.txt.)
-    const int seg_max = use3 ? (nq >= 64 ? 65536 : 4096) : (nq >= 1024 ? (1 << 20) : (nq >= 64 ? 16384 : 4096));
+    int seg_max = use3 ? (nq >= 64 ? 65536 : 4096) : (nq >= 1024 ? (1 << 20) : (nq >= 64 ? 16384 : 4096));
+    if (const char* e = getenv("CIS_SEG_MAX")) seg_max = atoi(e) > 0 ? atoi(e) : seg_max;  // A/B runs (tools/emulate_shard.py)
     // thousands of coarse clusters (the release configurations' V = 2048 / 4096): the plan is a per-query selection + sort
     // (k_plan_par) instead of one frontier step per visited cell; queries it cannot resolve fall back to the frontier walk
     const bool no_par_plan = getenv("CIS_NO_PAR_PLAN") != nullptr;
