@@ -667,21 +667,25 @@ __global__ void k_slots_init(int* __restrict__ qctr16, int* __restrict__ cell_cn
 // first cell usually holds the best candidates, so by the time the other cells of a query are scanned its bound
 // (qbound) is already tight and they run the hot loop only.
 static __device__ __forceinline__ int q8_begin(int x, int ncells) { return (int)(((int64_t)x * ncells + 7) / 8); }
-static __device__ __forceinline__ int slot_key(const WorkItem& it, int ncells) {
+// CH keys per (cell, first / other): the chunks of a cell longer than one chunk get their own slots (round 3; with one key per cell
+// such items shared slots and ran as sub-slots, one chunk after the other, inside one workgroup)
+static __device__ __forceinline__ int slot_key(const WorkItem& it, int ncells, int CH, int seg_max) {
     const int x = (int)(((int64_t)it.cell * 8) / ncells);
     const int b = q8_begin(x, ncells), sz = q8_begin(x + 1, ncells) - b;
-    return 2 * b + (it.rank > 0 ? sz : 0) + (it.cell - b);
+    int ch = CH > 1 ? it.pos0 / seg_max : 0;
+    ch = ch < CH ? ch : CH - 1;
+    return (2 * b + (it.rank > 0 ? sz : 0) + (it.cell - b)) * CH + ch;
 }
 
-__global__ void k_item_hist(const WorkItem* __restrict__ items, int64_t n, int* __restrict__ cell_cnt, int ncells) {
+__global__ void k_item_hist(const WorkItem* __restrict__ items, int64_t n, int* __restrict__ cell_cnt, int ncells, int CH, int seg_max) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&cell_cnt[slot_key(items[i], ncells)], 1);
+    if (i < n) atomicAdd(&cell_cnt[slot_key(items[i], ncells, CH, seg_max)], 1);
 }
 
 // counts -> exclusive SLOT offsets per cell (a slot holds up to G items of one cell); the counts are
 // reset to zero so that the scatter can reuse them as cursors.  *n_slots = total number of slots.
 __global__ void k_cell_scan(int* __restrict__ cell_cnt, int* __restrict__ slot_off, int nkeys, int G,
-                            int* __restrict__ n_slots, int* __restrict__ qstart /* [9] first slot of every queue */) {
+                            int* __restrict__ n_slots, int* __restrict__ qstart /* [9] first slot of every queue */, int CH) {
     __shared__ int part[256];
     const int tid = threadIdx.x;
     const int ncells = nkeys;  // (keys, two per cell)
@@ -706,7 +710,7 @@ __global__ void k_cell_scan(int* __restrict__ cell_cnt, int* __restrict__ slot_o
     }
     __syncthreads();
     if (tid < 8) {  // queue x starts at the first key of its cell range
-        const int k0 = 2 * q8_begin(tid, nkeys / 2);
+        const int k0 = 2 * q8_begin(tid, nkeys / (2 * CH)) * CH;
         qstart[tid] = k0 < nkeys ? slot_off[k0] : *n_slots;
     }
     if (tid == 8) qstart[8] = *n_slots;
@@ -714,10 +718,10 @@ __global__ void k_cell_scan(int* __restrict__ cell_cnt, int* __restrict__ slot_o
 
 // slots[(slot_off[cell] + r / G) * G + r % G] = item, r = arrival rank of the item inside its cell
 __global__ void k_item_scatter(const WorkItem* __restrict__ items, int64_t n, const int* __restrict__ slot_off,
-                               int* __restrict__ cursor, int G, int* __restrict__ slots, int ncells) {
+                               int* __restrict__ cursor, int G, int* __restrict__ slots, int ncells, int CH, int seg_max) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int c = slot_key(items[i], ncells);
+    const int c = slot_key(items[i], ncells, CH, seg_max);
     const int r = atomicAdd(&cursor[c], 1);
     slots[(slot_off[c] + r / G) * G + (r % G)] = (int)i;
 }
@@ -3914,7 +3918,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             // slot list: work items grouped by coarse cell (counting sort; skipped for huge V), G per slot
             const bool sort_items = ix->ncells <= 65536;
             const int G = use3 ? geom3.G : geom.G;
-            const int64_t nkeys = 2 * ix->ncells;
+            // chunks per cell that get their own slot keys: what the largest cell needs (all shards' sizes bound this shard's)
+            int64_t CH = use3 ? ceil_div(ix->max_cell > 0 ? ix->max_cell : 1, (int64_t)seg_max) : 1;
+            CH = CH < 1 ? 1 : (CH > 16 ? 16 : CH);
+            const int64_t nkeys = 2 * ix->ncells * CH;
             const int64_t max_slots = sort_items ? (n_items + nkeys) / G + nkeys + 2 : n_items;
             CIS_TRY(ix->w_order2.reserve((size_t)(64 + 2 * nkeys + 2 * max_slots * G) * sizeof(int)));
             int* qctr = ix->w_order2.as<int>();  // [8] queue counters, [8] n_slots (first), [9] queue starts, [32] fall-back header (scan3)
@@ -3930,10 +3937,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                 hipLaunchKernelGGL(k_slots_init, dim3((unsigned)ceil_div(ninit < 16 ? 16 : ninit, 256)), dim3(256), 0, st, qctr,
                                    cell_cnt, (int)nkeys, slots, max_slots * G);
                 hipLaunchKernelGGL(k_item_hist, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, cell_cnt,
-                                   (int)ix->ncells);
-                hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(256), 0, st, cell_cnt, slot_off, (int)nkeys, G, n_slots, qstart);
+                                   (int)ix->ncells, (int)CH, seg_max);
+                hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(256), 0, st, cell_cnt, slot_off, (int)nkeys, G, n_slots, qstart, (int)CH);
                 hipLaunchKernelGGL(k_item_scatter, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items,
-                                   slot_off, cell_cnt, G, slots, (int)ix->ncells);
+                                   slot_off, cell_cnt, G, slots, (int)ix->ncells, (int)CH, seg_max);
             } else {
                 CIS_CHECK_HIP(hipMemsetAsync(qctr, 0, 64 * sizeof(int), st));
                 hipLaunchKernelGGL(k_identity_slots, dim3((unsigned)ceil_div(n_items < 9 ? 9 : n_items, 256)), dim3(256), 0, st, n_items, G,
