@@ -3614,6 +3614,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     // (Splitting a shard's cells into chunks so that a cell-sharded index at world = 8 fills the chip again was measured
     // and lost: 0.516 against 0.306 ms per partial search -- more survivors, colder bounds: profiles/r02d_shard_emulation.txt.)
     int seg_max = use3 ? (nq >= 64 ? 65536 : 4096) : (nq >= 1024 ? (1 << 20) : (nq >= 64 ? 16384 : 4096));
+    // a shard of four or more holds few work items per batch (a rank owns 1 / world of the cells): its long cells are cut into chunks
+    // of 20480 candidates, each with its own slots, so that they spread over the chip -- emulated rank 0 of world 8: scan 0.169 -> 0.126
+    // ms, partial search 0.343 -> 0.307 ms (10240: 0.445 ms; on one GPU whole cells win: profiles/r03zb_chunk_keys.txt)
+    if (use3 && ix->world >= 4 && nq >= 64) seg_max = 20480;
     if (const char* e = getenv("CIS_SEG_MAX")) seg_max = atoi(e) > 0 ? atoi(e) : seg_max;  // A/B runs (tools/emulate_shard.py)
     // thousands of coarse clusters (the release configurations' V = 2048 / 4096): the plan is a per-query selection + sort
     // (k_plan_par) instead of one frontier step per visited cell; queries it cannot resolve fall back to the frontier walk

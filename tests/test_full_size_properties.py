@@ -193,22 +193,27 @@ def test_database_vectors_find_themselves(world):
     assert (out["dists"][r, c] >= first[r]).all()
 
 
-def test_two_cell_shards_merge_to_the_single_index(world):
+@pytest.mark.parametrize("nshards", [2, 4])
+def test_cell_shards_merge_to_the_single_index(world, nshards):
+    """Partition invariance at full size: 2 and 4 cell shards scanned separately and merged == the single index (from four
+    shards on a shard's long cells are scanned in chunks of 20480 candidates, each with its own slots, so that the few work
+    items of a shard still spread over the chip)."""
     import torch
     from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
     from columbiaimagesearch_amd.lopq.search import merge_packed_dev
     s, q = world["searcher"], world["q"][:2048].contiguous()
     ref = _np(s.search_batch_dev(q, quota=QUOTA, limit=LIMIT))
     parts = []
-    for r in range(2):
-        sh = LOPQSearcherHIP(world["model"], shard=(r, 2))
+    for r in range(nshards):
+        sh = LOPQSearcherHIP(world["model"], shard=(r, nshards))
         sh.add_codes_array(world["coarse"], world["fine"], ids=np.arange(N, dtype=np.int64), dedup=False)
         pp = sh.search_partial_packed_dev(q, quota=QUOTA, limit=LIMIT)
         torch.cuda.synchronize()
         parts.append({k: v.clone() for k, v in pp.items() if hasattr(v, "clone")})
+        sh.close()
         del sh
     stride = max(int(p["total"].item()) for p in parts)
-    buf = torch.zeros((2, stride, 4), dtype=torch.int64, device=world["dev"])
+    buf = torch.zeros((nshards, stride, 4), dtype=torch.int64, device=world["dev"])
     for r, p in enumerate(parts):
         t = int(p["total"].item())
         buf[r, :t] = p["packed"][:t]
