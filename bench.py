@@ -130,7 +130,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(CONFIGS), default=os.environ.get("CIS_BENCH_CONFIG", "c4"))
     ap.add_argument("--n", type=int, default=int(os.environ.get("CIS_BENCH_N", 0)), help="index vectors (default: the config's)")
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="of the INDEX size with --gpus (weak: n vectors per GPU); the query load always grows with the query groups")
+    ap.add_argument("--cell-shards", type=int, default=int(os.environ.get("CIS_BENCH_CELL_SHARDS", 0)),
+                    help="S of the R x S grid (R = gpus / S query groups, each one copy of the index sharded by cell over S "
+                         "GPUs).  Default: 2 when --gpus is even, --gpus otherwise; S = gpus is the pure cell-sharded layout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cnn", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-pointer leg (profiling runs)")
@@ -150,7 +154,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from columbiaimagesearch_amd import _lib
-    from columbiaimagesearch_amd.distributed import ShardedSearcher, greedy_cell_owner
+    from columbiaimagesearch_amd.distributed import GridSearcher, greedy_cell_owner
     from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
     _lib.check(_lib.lib().cis_set_device(local_rank))
     # CIS_BENCH_FORCE_DIST=1 runs the sharded code path (process group, all-gather, merge) even with one
@@ -173,7 +177,13 @@ def main():
 
     # ---- build: data-parallel encode on the GPUs, codes all-gathered, index sharded by cell -----
     t_build = time.time()
-    my_chunks = [c for c in range(N_CHUNKS) if c * world // N_CHUNKS == rank]
+    S = args.cell_shards if args.cell_shards > 0 else (2 if world % 2 == 0 else world)
+    if world % S:
+        raise SystemExit("--cell-shards %d does not divide --gpus %d" % (S, world))
+    R = world // S                      # query groups
+    g_q, s_c = rank // S, rank % S      # this rank: cell shard s_c of query group g_q
+    my_slice = s_c * R + g_q            # GridSearcher.slice_number: keeps the cells in the order of a single index
+    my_chunks = [c for c in range(N_CHUNKS) if c * world // N_CHUNKS == my_slice]
     coarse_l, fine_l, ev = [], [], []
     # encode parity at full size: rows sampled from EVERY chunk are kept (host copies) and their codes are checked against
     # the oracle's compute_codes after the timed region (the oracle index of the search spot check is built from HIP codes)
@@ -211,18 +221,21 @@ def main():
     ids_dev = torch.arange(my_chunks[0] * chunk_n, (my_chunks[-1] + 1) * chunk_n, dtype=torch.int64, device=device)
     t_ins = time.perf_counter()
     if use_dist:
-        # cells -> ranks by greedy balance of the cell populations: the table must be identical on every rank, so the
-        # per-cell counts are summed over the ranks first (V*V int64); then every code travels ONCE, to its owner -- device
-        # buffers in, RCCL all-to-all, device-side merge into the owner's index (no host copy of the codes)
+        # R x S grid (distributed.GridSearcher): R query groups, each holding one copy of the index sharded by cell over S ranks.
+        # cells -> shards by greedy balance of the cell populations: the table must be identical on every rank, so the
+        # per-cell counts are summed over the ranks first (V*V int64); then every code travels once per copy, to its owner --
+        # device buffers in, RCCL all-gather along the column + all-to-all inside the row, device-side merge into the owner's
+        # index (no host copy of the codes)
         cell = coarse[:, 0].to(torch.int64).bitwise_and_(0xFFFF) * V + coarse[:, 1].to(torch.int64).bitwise_and_(0xFFFF)
         ct_all = torch.bincount(cell, minlength=V * V)
         del cell
         if backend != "nccl":
             ct_all = ct_all.cpu()
         dist.all_reduce(ct_all)
-        sharded = ShardedSearcher(model, owner=greedy_cell_owner(ct_all.cpu().numpy(), world))
+        sharded = GridSearcher(model, S, owner=greedy_cell_owner(ct_all.cpu().numpy(), S) if S > 1 else None)
+        assert sharded.slice_number == my_slice
         searcher = sharded.local
-        sharded.add_codes_routed_dev(coarse, fine, ids_dev, dedup=False)
+        sharded.add_codes_dev(coarse, fine, ids_dev, dedup=False)  # column all-gather, then routed inside the query group
     else:
         sharded = None
         searcher = LOPQSearcherHIP(model)
@@ -246,8 +259,11 @@ def main():
             return searcher.search_batch_dev(q, quota=QUOTA, limit=LIMIT)
         return sharded.search_batch_dev(q, quota=QUOTA, limit=LIMIT)  # partial scan -> RCCL all-gather -> merge
 
+    def qb(b):  # a step = one batch of NQ queries PER QUERY GROUP: group g answers its own batches, the S ranks of a group the same
+        return qbatches[(b * R + g_q) % len(qbatches)]
+
     for b in range(args.warmup):
-        step(qbatches[b % len(qbatches)])
+        step(qb(b))
     # timed region: only the pair of HIP events around the scan kernel (roofline); the per-stage events are small bubbles
     # between kernels, so the stage breakdown is taken from a few extra steps after the timed region
     searcher.set_profiling(True, scan_only=True)
@@ -261,18 +277,18 @@ def main():
     out = None
     if sharded is None:
         for b in range(args.steps):
-            out = step(qbatches[(args.warmup + b) % len(qbatches)])
+            out = step(qb(args.warmup + b))
             cand += searcher.last_stats()["candidates"]
             cand_items += searcher.last_stats()["items"]
         scan_name = searcher.last_stats()["scan_kernel"]
     else:
         # steps are independent batches: the exchange + merge of batch b (side stream, RCCL) overlap the partial search
         # of batch b+1 (compute stream)
-        h = sharded.search_begin(qbatches[args.warmup % len(qbatches)], quota=QUOTA, limit=LIMIT)
+        h = sharded.search_begin(qb(args.warmup), quota=QUOTA, limit=LIMIT)
         cand += searcher.last_stats()["candidates"]
         cand_items += searcher.last_stats()["items"]
         for b in range(1, args.steps):
-            h2 = sharded.search_begin(qbatches[(args.warmup + b) % len(qbatches)], quota=QUOTA, limit=LIMIT)
+            h2 = sharded.search_begin(qb(args.warmup + b), quota=QUOTA, limit=LIMIT)
             cand += searcher.last_stats()["candidates"]
             cand_items += searcher.last_stats()["items"]
             out = sharded.search_end(h)
@@ -287,7 +303,7 @@ def main():
     searcher.set_profiling(True)
     n_stage = min(args.steps, 5)
     for b in range(n_stage):
-        step(qbatches[b % len(qbatches)])
+        step(qb(b))
     torch.cuda.synchronize()
     stage_prof = searcher.read_profile()
     searcher.set_profiling(False)
@@ -569,14 +585,14 @@ def main():
         binding["binds"] = max(("hbm_moved_bytes", "lds_gather", "valu_issue"), key=lambda k: binding[k]["frac"] or 0.0)
         line = {
             "metric": "queries/sec @ recall@10 on 10M LOPQ index",
-            "value": NQ * args.steps / elapsed,
+            "value": R * NQ * args.steps / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -587,8 +603,11 @@ def main():
                                       "post-ReLU-like 64-component mixture" if cfg["gen"] == "relu_mixture" else "descriptor-like anisotropic mixture",
                                       cfg["d_in"], model.dim, model.V, M, cfg["fixture"], NQ, QUOTA, LIMIT),
                        "name": args.config, "index_vectors": N, "queries_per_step": NQ, "quota": QUOTA, "limit": LIMIT,
-                       "sharding": "by coarse cell over %d GPU(s)%s" % (world, ", RCCL all-gather merge" if world > 1 else ""),
-                       "candidates_per_query": cand_all / float(NQ * args.steps)},
+                       "sharding": "%d query group(s) x %d cell shard(s): each group holds the whole index sharded by coarse cell over %d GPU(s)%s "
+                                   "and answers its own %d queries per step" % (R, S, S, ", RCCL all-gather merge inside the group" if S > 1 else "", NQ),
+                       "parallelism": "grid %dx%d" % (R, S), "query_groups": R, "cell_shards": S, "queries_per_step_all_groups": R * NQ,
+                       "index_scaling": args.scaling,
+                       "candidates_per_query": cand_all / float(R * NQ * args.steps)},
             "roofline": {"bound": "hbm", "kernel": scan_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": min(achieved / HBM_PEAK_GBS, 1.0), "accounting_frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "traffic_note": "PMC passes are separate rocprofv3 runs: profiles/scan_traffic_%s.json" % args.config,

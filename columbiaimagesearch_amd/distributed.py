@@ -275,3 +275,115 @@ class ShardedSearcher(object):
         out = merge_packed_dev(parts, off, cnt_all, nq, L)  # HIP: one wave per query up to 3072 records, ranked places above
         out["visited"] = p["visited"]
         return out
+
+
+def all_gather_rows(x, group=None):
+    """All-gather tensors that differ in their first dimension only -> the concatenation in group-rank order (same device).
+    The row counts travel first (one small all-gather); the payload is padded to the largest count because neither RCCL nor
+    gloo gathers ragged buffers.  gloo cannot gather device buffers: staged through the host there."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1:
+        return x
+    staged = dist.get_backend(group) != "nccl"
+    dev = x.device
+    work = x.cpu() if staged else x
+    cnt = torch.tensor([x.shape[0]], dtype=torch.int64, device=work.device)
+    cnts = all_gather_stack(cnt, group).reshape(-1).tolist()
+    n_max = max(cnts)
+    if x.shape[0] < n_max:
+        pad = torch.zeros((n_max - x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=work.device)
+        work = torch.cat([work, pad])
+    parts = all_gather_stack(work.contiguous(), group)  # [world, n_max, ...]
+    if all(c == n_max for c in cnts):
+        out = parts.reshape((world * n_max,) + tuple(x.shape[1:]))
+    else:
+        out = torch.cat([parts[r, :cnts[r]] for r in range(world)])
+    return out.to(dev) if staged else out
+
+
+def grid_groups(cell_shards):
+    """Process groups of the 2-D layout: world = R query groups x S cell shards, world rank = g * S + s.
+    Row group g = the S ranks that hold one whole copy of the index, sharded by cell (the all-gather merge runs inside
+    it); column group s = the R ranks that hold the SAME cells in different copies.  Every rank must call this (the
+    groups are created collectively, in the same order everywhere).  Returns (g, s, R, S, row_group, col_group); the
+    groups are None where they are the whole world or a single rank."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    S = int(cell_shards)
+    if S < 1 or world % S:
+        raise ValueError("cell_shards=%d does not divide the world size %d" % (S, world))
+    R = world // S
+    g, s = rank // S, rank % S
+    if S == 1 or R == 1:  # whole copies only (a row is one rank, the column the world), or one copy over the whole world
+        return g, s, R, S, None, None
+    rows = [dist.new_group(ranks=[gg * S + ss for ss in range(S)]) for gg in range(R)]
+    cols = [dist.new_group(ranks=[gg * S + ss for gg in range(R)]) for ss in range(S)]
+    return g, s, R, S, rows[g], cols[s]
+
+
+class GridSearcher(object):
+    """Queries sharded as well as cells: `world` ranks = R query groups x S cell shards.
+
+    A query group is one ShardedSearcher (the index sharded by coarse cell over S ranks, partial search -> packed RCCL
+    all-gather inside the group -> merge); the R groups hold identical copies and answer DIFFERENT queries, with no
+    collective between them on the search path.  S is a capacity choice (the smallest S whose shard fits a GPU: a
+    10M x M=8 index is 160 MB, so S=1 fits 288 GB thousands of times over), R = world / S is throughput: the front end
+    (projection, cell ranking, tables), which cell sharding replicates on every rank, is divided by R.
+
+    Build: every rank brings the slice it encoded; the slices are all-gathered along the column (the ranks that own the
+    same cells in the other copies), then routed inside the row to the cell owners (ShardedSearcher.add_codes_routed_dev).
+    Inside a cell the items arrive ordered by (row rank s of the source, column rank g, position in the slice): to get the
+    order of a single index built from the whole data, give rank (g, s) the slice number s * R + g.
+    """
+
+    def __init__(self, model, cell_shards, owner=None):
+        import torch.distributed as dist
+        from .lopq.search import LOPQSearcherHIP
+        self.g, self.s, self.R, self.S, row, col = grid_groups(cell_shards)
+        self.world = dist.get_world_size()
+        self._col = col if self.S > 1 else None     # S == 1: the column is the whole world (group None)
+        if self.S > 1:
+            self.row = ShardedSearcher(model, owner=owner, group=row)  # row None when R == 1: the world
+            self.local = self.row.local
+        else:
+            self.row = None
+            self.local = LOPQSearcherHIP(model)
+
+    @property
+    def slice_number(self):
+        """Which of the `world` consecutive slices of the data this rank should encode (see the class comment)."""
+        return self.s * self.R + self.g
+
+    def query_group(self):
+        return self.g, self.R
+
+    def add_codes_dev(self, coarse, fine, ids, dedup=True):
+        """This rank's encoded slice (tensors in HBM) into every copy of the index.  Returns what this rank accepted."""
+        if self.R > 1:
+            coarse = all_gather_rows(coarse, self._col)
+            fine = all_gather_rows(fine, self._col)
+            ids = all_gather_rows(ids, self._col)
+        if self.row is not None:
+            return self.row.add_codes_routed_dev(coarse, fine, ids, dedup=dedup)
+        return self.local.add_codes_dev(coarse, fine, ids, dedup=dedup)[0]
+
+    def get_nb_indexed(self):
+        return self.local.get_nb_indexed()
+
+    def search_begin(self, q, quota=10, limit=None):
+        """q: the queries of THIS rank's query group (identical on the S ranks of the group)."""
+        if self.row is not None:
+            return self.row.search_begin(q, quota=quota, limit=limit)
+        return {"out": self.local.search_batch_dev(q, quota=quota, limit=limit)}
+
+    def search_end(self, h):
+        if self.row is not None:
+            return self.row.search_end(h)
+        return h["out"]
+
+    def search_batch_dev(self, q, quota=10, limit=None):
+        if self.row is not None:
+            return self.row.search_batch_dev(q, quota=quota, limit=limit)
+        return self.local.search_batch_dev(q, quota=quota, limit=limit)

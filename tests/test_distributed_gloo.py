@@ -156,3 +156,57 @@ def test_routed_insert_all_to_all_three_gloo_ranks():
         assert p.exitcode == 0
     assert all(ret[r][0] for r in range(world))
     assert sum(ret[r][1] for r in range(world)) == 9000
+
+
+def _grid_worker(rank, world, port, S, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from columbiaimagesearch_amd.distributed import all_gather_rows, greedy_cell_owner, grid_groups, route_codes
+        z, X, Q = load_golden("c2")
+        coarse, fine = z["coarse"][:9000], z["fine"][:9000]
+        n, V = coarse.shape[0], 16
+        ids = np.arange(n, dtype=np.int64) * 3 + 1
+        cell = coarse[:, 0].astype(np.int64) * V + coarse[:, 1]
+        g, s, R, S_, row, col = grid_groups(S)
+        ok = (g, s, R, S_) == (rank // S, rank % S, world // S, S)
+        owner = greedy_cell_owner(np.bincount(cell, minlength=V * V), S)
+        k = s * R + g  # GridSearcher.slice_number
+        cuts = [0] + [(j + 1) * n // world + 13 * (j + 1) - 40 for j in range(world - 1)] + [n]  # ragged slices
+        a, b = cuts[k], cuts[k + 1]
+        # column: the ranks holding the same cells in the other copies (the whole world when S == 1)
+        cg = col if S > 1 else None
+        if R > 1:
+            c = all_gather_rows(torch.from_numpy(coarse[a:b].view(np.int16).copy()), cg).numpy().view(np.uint16)
+            f = all_gather_rows(torch.from_numpy(fine[a:b].copy()), cg).numpy()
+            i = all_gather_rows(torch.from_numpy(ids[a:b].copy()), cg).numpy()
+        else:
+            c, f, i = coarse[a:b], fine[a:b], ids[a:b]
+        # after the column gather rank (g, s) holds slices s*R .. s*R+R-1: a contiguous range of the data
+        ok = ok and np.array_equal(i, ids[cuts[s * R]:cuts[s * R + R]]) and np.array_equal(c, coarse[cuts[s * R]:cuts[s * R + R]])
+        if S > 1:  # row: the S ranks of one copy
+            c, f, i = route_codes(c, f, i, owner, V, group=row if R > 1 else None, M=fine.shape[1])
+        mine = owner[cell] == s
+        ok = ok and np.array_equal(c, coarse[mine]) and np.array_equal(f, fine[mine]) and np.array_equal(i, ids[mine])
+        ret[rank] = (bool(ok), int(mine.sum()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("S", [1, 2, 4])
+def test_grid_build_four_gloo_ranks(S):
+    """R query groups x S cell shards at world 4: after the ragged column all-gather and the routed insert inside the row,
+    every copy's shard s holds exactly the items of its cells in the order of the whole data (GridSearcher's build)."""
+    world = 4
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_grid_worker, args=(r, world, port, S, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert all(ret[r][0] for r in range(world))
+    assert sum(ret[r][1] for r in range(world)) == 9000 * (world // S)

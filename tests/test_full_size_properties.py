@@ -284,15 +284,30 @@ def test_routed_device_insert_with_two_ranks_on_one_gpu():
     assert text.count("routed insert + pipelined search ok") == 4, text[-3000:]
 
 
-def test_bench_multi_rank_protocol_with_two_ranks_on_one_gpu():
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), here over gloo with both
-    ranks on the one GPU of the box: device-side routed build, pipelined sharded search, max-over-ranks timing, ONE JSON line
-    from rank 0 whose recall matches the single-GPU run of the same index size."""
+def test_query_groups_times_cell_shards_with_four_ranks_on_one_gpu():
+    """World 4 over gloo on one device: the R x S layouts 4x1 (whole copies, no search collective), 2x2 (the bench's default
+    shape at 4 GPUs) and 1x4 (cells only), built from ragged per-rank slices, answer like the single index -- tests/tools/grid_check.py."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, CIS_CHECK_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", "29587", os.path.join(here, "tools", "grid_check.py")]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-3000:]
+    for shape in ("4 x 1", "2 x 2", "1 x 4"):
+        assert "world 4 grid %s: build and search equal the single index" % shape in text, text[-3000:]
+
+
+@pytest.mark.parametrize("gpus,shards,groups", [(2, 0, 1), (4, 0, 2), (2, 1, 2)])
+def test_bench_multi_rank_protocol_on_one_gpu(gpus, shards, groups):
+    """`bench.py --gpus N` with query groups (default grid and whole copies): value counts every group's queries."""
     import json, os, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CIS_BENCH_BACKEND="gloo", CIS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CIS_BENCH_N="400000")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29585", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "c2",
+    env = dict(os.environ, CIS_BENCH_BACKEND="gloo", CIS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CIS_BENCH_N="400000",
+               CIS_BENCH_CELL_SHARDS=str(shards))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", "29589", os.path.join(repo, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--config", "c2",
            "--no-cnn", "--no-cpu-baseline", "--no-pcie"]
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, cwd=repo)
     text = out.stdout.decode()
@@ -300,7 +315,8 @@ def test_bench_multi_rank_protocol_with_two_ranks_on_one_gpu():
     lines = [l for l in text.splitlines() if l.startswith("{")]
     assert len(lines) == 1, text[-3000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["recall_at_10"] >= 0.9
+    assert line["n_gpus"] == gpus and line["config"]["query_groups"] == groups and line["recall_at_10"] >= 0.9
+    assert abs(line["value"] - groups * line["config"]["queries_per_step"] * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
     assert line["config"]["index_vectors"] == 400000 and line["roofline"]["frac"] <= 1.0
 
 
