@@ -3326,7 +3326,9 @@ __global__ __launch_bounds__(NT) void k_select_topl(const uint64_t* __restrict__
                                                               const unsigned long long* __restrict__ qmax, int64_t n_items, int L, int P2,
                                                               int64_t stride, uint64_t* __restrict__ sel_keys,
                                                               uint64_t* __restrict__ sel_vals, int* __restrict__ nsel,
-                                                              int64_t* __restrict__ seg_b, int64_t* __restrict__ seg_e) {
+                                                              int64_t* __restrict__ seg_b, int64_t* __restrict__ seg_e,
+                                                              const int* __restrict__ only = nullptr /* ranked: flagged queries only */) {
+    if (only && !only[blockIdx.x]) return;
     extern __shared__ __align__(16) unsigned char sel_lds[];
     // LDS: [okey P2][oidx P2] (SORT_LDS) | union { hist 2048 u32 ; ckey 1024 u64 + cidx 1024 u32 } | SelShared
     uint64_t* okey = reinterpret_cast<uint64_t*>(sel_lds);
@@ -3528,6 +3530,494 @@ static bool use_all_path(const cis_index* ix, int M, int K, int L, int nq) {
     // a few codes -- every candidate's exact distance + a per-query select instead (unless a test forces a scan kernel)
     if (index_has_tiny_cells(ix) && !ix->force_prefilter_scan) return true;
     return !ix->force_prefilter_scan && nq <= small_batch_nq(L);
+}
+
+// ---- tiny cells, prefiltered (round 3): the release operating point (V = 2048 / 4096: a query visits hundreds of cells of a
+// few codes each, ~10 k candidates for the 100 it returns) -----------------------------------------------------------------
+// k_adc_direct computes the exact float64 distance of EVERY candidate (128 subtract-square-adds on operands gathered from LDS
+// and L2: 5.8 of the 11.4 ms of an 8192-query batch) and k_select_topl then reads all keys back.  Here one workgroup per query
+//   1. lays the query's candidates out (owner work item of every candidate, in LDS);
+//   2. estimates a cap on the limit-th best distance from 256 sampled candidates (their float64 distances);
+//   3. builds the query's distance tables as BYTES in LDS -- entry = min(255, floor(e / step)), step = cap / 256, e computed in
+//      float32 from the projected residuals px (the operands of k_adc_direct) -- one split and at most `tch` tables at a time,
+//      and adds every candidate's table bytes up (a lower bound of its distance in steps: floor and min only round down);
+//   4. histograms the sums: s* = the smallest sum that `limit` candidates reach; a candidate whose sum is <= 254 has no clamped
+//      entry, so its distance is below (sum + M) steps, hence the limit-th best distance T < (s* + M) steps, and a candidate
+//      can only be among the best `limit` if sum <= s* + M (+ 1 bin for the float32 rounding of e, which the cap test below
+//      keeps under a sixteenth of a step per entry);
+//   5. computes the exact float64 keys of those survivors only -- the expression, operands and summation order of
+//      k_adc_direct, so the same bits -- ranks them by (key, retrieval position) in LDS and writes the best `limit` in the
+//      format of k_select_topl<true>.
+// A query for which no bound comes out (fewer than `limit` candidates under the cap, survivors beyond the LDS list, more
+// candidates than the layout holds, a cap too small for float32) gets every candidate's exact key written to the global key
+// array and a flag; k_select_topl runs afterwards on the flagged queries alone.  Results are those of the exact path, bit for bit.
+static const int TINY_NS = 128;     // sampled candidates per query (eight threads each)
+static const int TINY_SMAX = 1024;  // survivors ranked in LDS
+static const int TINY_NCMAX = 16384;
+static const int TINY_TCH = 128;    // tables per chunk at most
+
+struct TinyShared {
+    int cnt, sstar, fb;
+    unsigned int cap_bits, amax_bits, cen_bits;
+    int wsum[16];
+};
+
+template <int MT, int W>
+__device__ __noinline__ void tiny_exact_all(const WorkItem* __restrict__ items, const int64_t* __restrict__ cand_start,
+                                            const double* __restrict__ px, const double* __restrict__ subs,
+                                            const uint8_t* __restrict__ codes, int h, int64_t it0, int ni, int64_t c0, int64_t n64,
+                                            uint64_t* __restrict__ keys_fb,
+                                            unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax, int q) {
+    constexpr int NF = MT / 2, K = 256;
+    uint64_t mn = ~0ull, mx = 0ull;
+    for (int64_t c = threadIdx.x; c < n64; c += 1024) {
+        int lo = 0, hi = ni;  // the item that holds candidate c
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cand_start[it0 + mid] - c0 <= c) lo = mid + 1; else hi = mid;
+        }
+        const int i = lo - 1;
+        const WorkItem it = items[it0 + i];
+        const int p = (int)(c - (cand_start[it0 + i] - c0));
+        const CodeWords<MT> cw = load_code<MT>(codes, it.start + p);
+        double d = 0.0;
+        for (int j = 0; j < MT; ++j) {
+            const bool second = j >= NF;
+            const double* f = px + (int64_t)(second ? it.tab1 : it.tab0) * h + (second ? j - NF : j) * W;
+            const uint32_t code = (cw.w[j >> 2] >> (8 * (j & 3))) & 255u;
+            const double* sc = subs + ((size_t)j * K + code) * W;
+            auto elem = [&](int e) -> double { const double df = f[e] - sc[e]; return df * df; };
+            const double v = pw_leaf<double>(elem, 0, W);
+            d = j == 0 ? v : d + v;
+        }
+        const uint64_t kk = (uint64_t)__double_as_longlong(d);
+        keys_fb[c0 + c] = kk;
+        mn = kk < mn ? kk : mn;
+        mx = kk > mx ? kk : mx;
+    }
+    publish_key_range(mn, mx, qmin, qmax, q);
+}
+
+// Two rows of W float32 at wave-uniform addresses, through the scalar cache into SGPRs: one wait for both (the compiler keeps
+// uniform loads of a kernel that also writes global memory on the vector path -- 1 KB of identical lanes per instruction)
+typedef int tiny_i16v __attribute__((ext_vector_type(16)));
+typedef int tiny_i8v __attribute__((ext_vector_type(8)));
+typedef int tiny_i4v __attribute__((ext_vector_type(4)));
+// rows per wait: a wave's table loop is bound by the latency of these loads (L2: the rows were just written), not by arithmetic
+template <int W> struct TinyRows { static constexpr int U = W <= 16 ? 4 : 2; };
+template <int W>
+__device__ __forceinline__ void tiny_sload_rows(const float* const (&p)[TinyRows<W>::U], float (&f)[TinyRows<W>::U][W]) {
+    if constexpr (W == 4) {
+        tiny_i4v a, b, c, d;
+        asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %5, 0x0\n\ts_load_dwordx4 %2, %6, 0x0\n\ts_load_dwordx4 %3, %7, 0x0\n\t"
+                     "s_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d) : "s"(p[0]), "s"(p[1]), "s"(p[2]), "s"(p[3]) : "memory");
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[0][e] = __int_as_float(a[e]); f[1][e] = __int_as_float(b[e]); f[2][e] = __int_as_float(c[e]); f[3][e] = __int_as_float(d[e]); }
+    } else if constexpr (W == 8) {
+        tiny_i8v a, b, c, d;
+        asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %5, 0x0\n\ts_load_dwordx8 %2, %6, 0x0\n\ts_load_dwordx8 %3, %7, 0x0\n\t"
+                     "s_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d) : "s"(p[0]), "s"(p[1]), "s"(p[2]), "s"(p[3]) : "memory");
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { f[0][e] = __int_as_float(a[e]); f[1][e] = __int_as_float(b[e]); f[2][e] = __int_as_float(c[e]); f[3][e] = __int_as_float(d[e]); }
+    } else if constexpr (W == 16) {
+        tiny_i16v a, b, c, d;
+        asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %5, 0x0\n\ts_load_dwordx16 %2, %6, 0x0\n\ts_load_dwordx16 %3, %7, 0x0\n\t"
+                     "s_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d) : "s"(p[0]), "s"(p[1]), "s"(p[2]), "s"(p[3]) : "memory");
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { f[0][e] = __int_as_float(a[e]); f[1][e] = __int_as_float(b[e]); f[2][e] = __int_as_float(c[e]); f[3][e] = __int_as_float(d[e]); }
+    } else {
+        tiny_i16v a, b, c, d;
+        asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx16 %2, %5, 0x0\n\ts_load_dwordx16 %3, %5, 0x40\n\t"
+                     "s_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d) : "s"(p[0]), "s"(p[1]) : "memory");
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            f[0][e] = __int_as_float(a[e]); f[0][16 + e] = __int_as_float(b[e]);
+            f[1][e] = __int_as_float(c[e]); f[1][16 + e] = __int_as_float(d[e]);
+        }
+    }
+}
+
+struct TinyItem {       // a work item of the current query, staged in LDS
+    uint32_t start;     // first candidate (position in codes/ids): the index holds fewer than 2^32 items, or the query is flagged
+    uint16_t rel, len;  // first candidate inside the query's candidate range, candidates
+    uint16_t t0, t1;    // the two half tables, counted from the query's first table of that split
+};
+
+template <int MT, int W>
+__global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict__ items, const int64_t* __restrict__ cand_start,
+                                                      const int64_t* __restrict__ seg, const int64_t* __restrict__ item_off,
+                                                      const int64_t* __restrict__ tab_off, const PlanOut* __restrict__ plan,
+                                                      const double* __restrict__ px, const double* __restrict__ subs,
+                                                      const uint8_t* __restrict__ codes, int h, int nq, int L, int ncmax, int pool_bytes,
+                                                      int64_t stride, uint64_t* __restrict__ sel_keys, uint64_t* __restrict__ sel_vals,
+                                                      int* __restrict__ nsel, uint64_t* __restrict__ keys_fb,
+                                                      unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax,
+                                                      int* __restrict__ fbflag, float* __restrict__ px32_ws /* [grid][TINY_TCH][h] */,
+                                                      unsigned int* __restrict__ dbg) {
+    constexpr int NF = MT / 2, K = 256;
+    constexpr int PAIRS = NF * K;
+    constexpr int PPT = (PAIRS + 1023) / 1024;
+    constexpr int NR = TINY_NCMAX / 1024;  // candidates per thread at most
+    constexpr int CW = NF >= 4 ? NF / 4 : 1;
+    extern __shared__ __align__(16) unsigned char tiny_lds[];
+    uint16_t* own = reinterpret_cast<uint16_t*>(tiny_lds);
+    uint16_t* sum = own + ncmax;
+    unsigned char* pool = tiny_lds + (size_t)4 * ncmax;    // items | tables + px of a chunk, later the survivors' exact entries
+    TinyItem* s_items = reinterpret_cast<TinyItem*>(pool);
+    unsigned int* hist = reinterpret_cast<unsigned int*>(pool + pool_bytes);  // 512 bins
+    float* samp = reinterpret_cast<float*>(hist + 512);                    // TINY_NS
+    uint64_t* skey = reinterpret_cast<uint64_t*>(samp + TINY_NS);          // TINY_SMAX
+    uint32_t* sidx = reinterpret_cast<uint32_t*>(skey + TINY_SMAX);        // TINY_SMAX
+    TinyShared* sh = reinterpret_cast<TinyShared*>(sidx + TINY_SMAX);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    long long t_last = dbg ? wall_clock64() : 0;
+#define TINY_T(k_) do { if (dbg && tid == 0) { const long long now_ = wall_clock64(); atomicAdd(&dbg[4 + (k_)], (unsigned int)(now_ - t_last)); t_last = now_; } } while (0)
+    // largest centroid component (float32 rounding bound), once per workgroup
+    if (tid == 0) sh->cen_bits = 0u;
+    __syncthreads();
+    {
+        float a = 0.f;
+        for (int i = tid; i < MT * K * W; i += 1024) a = fmaxf(a, fabsf((float)subs[i]));
+        atomicMax(&sh->cen_bits, __float_as_uint(a));
+    }
+    for (int q = blockIdx.x; q < nq; q += gridDim.x) {
+        const int64_t it0 = item_off[q];
+        const int ni = (int)(item_off[q + 1] - it0);
+        const int64_t c0 = seg[q];
+        const int64_t n64 = seg[q + 1] - c0;
+        const int nv = n64 < (int64_t)L ? (int)n64 : L;
+        const int64_t ob = (int64_t)q * stride;
+        __syncthreads();  // the previous query's lists are no longer read
+        TINY_T(0);
+        if (n64 <= 0) {
+            if (tid == 0) { nsel[q] = 0; fbflag[q] = 0; }
+            continue;
+        }
+        // this query's share of the pool: its items first, the rest for tables (or the survivors' entries)
+        const int items_bytes = (ni * (int)sizeof(TinyItem) + 15) & ~15;
+        const int rest = pool_bytes - items_bytes;
+        int tch = rest > 0 ? rest / (NF * K) : 0;
+        tch = tch < TINY_TCH ? tch : TINY_TCH;
+        int smax = rest > 0 ? rest / (8 * MT) : 0;
+        smax = smax < TINY_SMAX ? smax : TINY_SMAX;
+        uint8_t* s_tab = pool + items_bytes;
+        float* ws = px32_ws + (size_t)blockIdx.x * TINY_TCH * h;  // float32 copy of the current chunk's px rows (global: scalar loads)
+        double* e_lds = reinterpret_cast<double*>(pool + items_bytes);
+        bool fall = n64 > (int64_t)ncmax || ni > 65535 || tch < 4 || L > smax;
+        const int n = (int)n64;
+        const bool all_in = !fall && n <= smax && n <= (2 * L > 256 ? 2 * L : 256);  // few candidates: every one is ranked exactly
+        int nsurv = 0;
+        if (!fall) {
+            if (tid == 0) { sh->cnt = 0; sh->sstar = 1 << 20; sh->amax_bits = 0u; sh->cap_bits = 0u; sh->fb = 0; }
+            for (int b = tid; b < 512; b += 1024) hist[b] = 0u;
+            // 1. the items, then the owner item of every candidate
+            const int64_t tbase = tab_off[q];
+            const int nt0 = plan[q].ntab0;
+            for (int i = tid; i < ni; i += 1024) {
+                const WorkItem it = items[it0 + i];
+                TinyItem ti;
+                ti.start = (uint32_t)it.start;
+                ti.rel = (uint16_t)(cand_start[it0 + i] - c0);
+                ti.len = (uint16_t)it.len;
+                ti.t0 = (uint16_t)(it.tab0 - tbase);
+                ti.t1 = (uint16_t)(it.tab1 - tbase - nt0);
+                s_items[i] = ti;
+                if (it.start + it.len > (int64_t)0xffffffffll || it.len > 65535) sh->fb = 1;
+            }
+            for (int c = tid; c < n; c += 1024) sum[c] = 0;
+            __syncthreads();
+            for (int i = wv; i < ni; i += 16) {
+                const TinyItem ti = s_items[i];
+                for (int p = lane; p < (int)ti.len; p += 64) own[(int)ti.rel + p] = (uint16_t)i;
+            }
+            __syncthreads();
+            if (sh->fb) fall = true;
+            TINY_T(1);
+        }
+        if (!fall && !all_in) {
+            const int64_t tbase = tab_off[q];
+            const int nt0 = plan[q].ntab0, nt1 = plan[q].ntab1;
+            // 2. cap from the sample: the r-th smallest of TINY_NS sampled distances (float32 arithmetic: the cap is a heuristic,
+            //    the bounds below hold for any value), r / TINY_NS ~ three times limit / n
+            {
+                const int s = tid >> 3, sub = tid & 7;
+                const int c = (int)(((int64_t)s * n + (n >> 1)) / TINY_NS);
+                const TinyItem ti = s_items[own[c]];
+                const CodeWords<MT> cw = load_code<MT>(codes, (int64_t)ti.start + (c - (int)ti.rel));
+                float acc = 0.f;
+                for (int j = sub; j < MT; j += 8) {
+                    const bool second = j >= NF;
+                    const double* f = reinterpret_cast<const double*>(__builtin_assume_aligned(
+                        px + (tbase + (second ? nt0 + (int)ti.t1 : (int)ti.t0)) * h + (second ? j - NF : j) * W, 16));
+                    const uint32_t code = (cw.w[j >> 2] >> (8 * (j & 3))) & 255u;
+                    const double* sc = reinterpret_cast<const double*>(__builtin_assume_aligned(subs + ((size_t)j * K + code) * W, 16));
+#pragma unroll
+                    for (int e = 0; e < W; ++e) { const float df = (float)f[e] - (float)sc[e]; acc = fmaf(df, df, acc); }
+                }
+                acc += __shfl_xor(acc, 1);
+                acc += __shfl_xor(acc, 2);
+                acc += __shfl_xor(acc, 4);
+                if (sub == 0) samp[s] = acc;
+            }
+            __syncthreads();
+            {
+                const int s = tid >> 3, sub = tid & 7;
+                const float v = samp[s];
+                int less = 0;
+                for (int k2 = sub * (TINY_NS / 8); k2 < (sub + 1) * (TINY_NS / 8); ++k2) {
+                    const float u = samp[k2];
+                    less += (u < v || (u == v && k2 < s)) ? 1 : 0;
+                }
+                less += __shfl_xor(less, 1);
+                less += __shfl_xor(less, 2);
+                less += __shfl_xor(less, 4);
+                int r = (int)((3.0 * TINY_NS * (double)L) / (double)n) + 3;
+                r = r > TINY_NS ? TINY_NS : r;
+                if (sub == 0 && less == r - 1) sh->cap_bits = __float_as_uint(v);
+            }
+            __syncthreads();
+            TINY_T(2);
+            const float cap = __uint_as_float(sh->cap_bits);
+            const float inv_step = cap > 0.f ? 256.0f / cap : 0.f;
+            // 3. byte tables of a split, at most tch at a time; every candidate adds its entries up.  An entry is
+            //    sum (px - c)^2 in float32: the thread keeps its (sub-quantizer, centroid) in registers, the px row of a table
+            //    arrives through scalar loads (uniform over the wave) from a float32 copy of the chunk's rows that a pre-pass
+            //    leaves in this workgroup's global scratch
+            for (int s = 0; s < 2; ++s) {
+                const int nts = s ? nt1 : nt0;
+                const int64_t tb = tbase + (s ? nt0 : 0);
+                for (int tlo = 0; tlo < nts; tlo += tch) {
+                    const int tc = nts - tlo < tch ? nts - tlo : tch;
+                    __syncthreads();  // the previous chunk's tables and rows are no longer read
+                    TINY_T(3);
+                    {
+                        float a = 0.f;
+                        const double* src = px + (tb + tlo) * h;
+#pragma unroll 4
+                        for (int i = tid; i < tc * h; i += 1024) {
+                            const float v = (float)src[i];
+                            ws[i] = v;
+                            a = fmaxf(a, fabsf(v));
+                        }
+                        atomicMax(&sh->amax_bits, __float_as_uint(a));
+                    }
+                    __syncthreads();  // (waits for the stores: they are in L2)
+                    __builtin_amdgcn_s_dcache_inv();  // the scalar cache may hold the previous chunk's rows
+                    TINY_T(4);
+#pragma unroll
+                    for (int pp = 0; pp < PPT; ++pp) {
+                        const int pr = tid + pp * 1024;
+                        if (pr < PAIRS) {
+                            const int jj = __builtin_amdgcn_readfirstlane(pr / K), k = pr % K;  // a wave shares its sub-quantizer
+                            float cen[W];
+                            const double* sc = subs + ((size_t)(s * NF + jj) * K + k) * W;
+#pragma unroll
+                            for (int e = 0; e < W; ++e) cen[e] = (float)sc[e];
+                            const float* frow = ws + jj * W;
+                            uint8_t* trow = s_tab + jj * K + k;
+                            constexpr int U = TinyRows<W>::U;
+                            typedef float tiny_f2 __attribute__((ext_vector_type(2)));
+                            for (int t = 0; t < tc; t += U) {
+                                const float* rp[U];
+                                int tu[U];
+#pragma unroll
+                                for (int u = 0; u < U; ++u) { tu[u] = t + u < tc ? t + u : tc - 1; rp[u] = frow + tu[u] * h; }
+                                float f[U][W];
+                                tiny_sload_rows<W>(rp, f);
+#pragma unroll
+                                for (int u = 0; u < U; ++u) {
+                                    tiny_f2 acc = {0.f, 0.f};  // packed float32 math: even and odd components apart
+#pragma unroll
+                                    for (int e = 0; e < W; e += 2) {
+                                        const tiny_f2 c2 = {cen[e], cen[e + 1]};
+                                        const tiny_f2 x = {f[u][e], f[u][e + 1]};
+                                        const tiny_f2 d = x - c2;
+                                        acc = __builtin_elementwise_fma(d, d, acc);
+                                    }
+                                    trow[tu[u] * NF * K] = (uint8_t)(int)fminf((acc.x + acc.y) * inv_step, 255.0f);
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    TINY_T(5);
+                    for (int cb = tid; cb < n; cb += 4096) {  // four candidates per thread and round: their code loads overlap
+                        int tl4[4];
+                        uint32_t cw4[4][CW];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = cb + r * 1024;
+                            tl4[r] = -1;
+                            if (c < n) {
+                                const TinyItem ti = s_items[own[c]];
+                                const int tl = (s ? (int)ti.t1 : (int)ti.t0) - tlo;
+                                if ((unsigned)tl < (unsigned)tc) {
+                                    tl4[r] = tl;
+                                    const uint8_t* cp = codes + ((int64_t)ti.start + (c - (int)ti.rel)) * MT;
+                                    if constexpr (NF == 2) cw4[r][0] = *reinterpret_cast<const uint32_t*>(cp) >> (16 * s);
+                                    else {
+#pragma unroll
+                                        for (int u = 0; u < CW; ++u) cw4[r][u] = reinterpret_cast<const uint32_t*>(cp + s * NF)[u];
+                                    }
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (tl4[r] >= 0) {
+                                const int c = cb + r * 1024;
+                                unsigned int acc = 0;
+#pragma unroll
+                                for (int jj = 0; jj < NF; ++jj)
+                                    acc += s_tab[(tl4[r] * NF + jj) * K + ((cw4[r][jj >> 2] >> (8 * (jj & 3))) & 255u)];
+                                sum[c] = (uint16_t)(sum[c] + acc);
+                            }
+                    }
+                }
+            }
+            __syncthreads();
+            TINY_T(6);
+            // 4. histogram of the sums, s*, the survivors' bound
+            for (int c = tid; c < n; c += 1024) {
+                const int sv = sum[c];
+                atomicAdd(&hist[sv < 511 ? sv : 511], 1u);
+            }
+            __syncthreads();
+            {
+                const int v = tid < 512 ? (int)hist[tid] : 0;
+                int tot;
+                const int ex = sel_block_excl_scan(v, sh->wsum, &tot);
+                if (tid < 512) {
+                    hist[tid] = (unsigned int)(ex + v);  // inclusive counts (each thread rewrites its own bin)
+                    if (ex < L && L <= ex + v) sh->sstar = tid;
+                }
+            }
+            __syncthreads();
+            const int sstar = sh->sstar;
+            const float amax = __uint_as_float(sh->amax_bits);
+            // float32: a component difference carries an absolute error of 2^-23 amax_ (amax_ = the largest |px| or |c| component),
+            // an entry e < cap at most 2 sqrt(W cap) 2^-23 amax_: under step / 16 = cap / 4096 when cap >= W amax_^2 / 2^20
+            const float cmax_ = __uint_as_float(sh->cen_bits);
+            const float amax_ = fmaxf(amax, cmax_);
+            if (sstar > 254 || !(cap >= (float)W * amax_ * amax_ * (1.0f / 1048576.0f))) fall = true;
+            else {
+                const int thr = sstar + MT + 1;
+                nsurv = (int)hist[thr < 511 ? thr : 511];
+                if (thr >= 511 || nsurv > smax) fall = true;
+                else {
+                    for (int c = tid; c < n; c += 1024)
+                        if ((int)sum[c] <= thr) sidx[atomicAdd(&sh->cnt, 1)] = (uint32_t)c;
+                }
+            }
+            if (dbg && tid == 0) {
+                atomicAdd(&dbg[0], 1u);
+                atomicAdd(&dbg[1], fall ? 1u : 0u);
+                atomicAdd(&dbg[2], (unsigned int)nsurv);
+                atomicAdd(&dbg[3], (unsigned int)(sstar > 254 ? 255 : sstar));
+            }
+            __syncthreads();
+        } else if (all_in) {
+            nsurv = n;
+            for (int c = tid; c < n; c += 1024) sidx[c] = (uint32_t)c;
+            __syncthreads();
+        }
+        if (fall) {
+            // every candidate's exact key to the global key array; k_select_topl ranks this query
+            tiny_exact_all<MT, W>(items, cand_start, px, subs, codes, h, it0, ni, c0, n64, keys_fb, qmin, qmax, q);
+            if (tid == 0) fbflag[q] = 1;
+            continue;
+        }
+        TINY_T(7);
+        // 5. exact entries of the survivors, one thread per (survivor, sub-quantizer); then the running sum of search.py:173
+        {
+            const int64_t tbase = tab_off[q];
+            const int nt0 = plan[q].ntab0;
+            for (int pr = tid; pr < nsurv * MT; pr += 1024) {
+                const int sv = pr / MT, j = pr % MT;
+                const int c = (int)sidx[sv];
+                const TinyItem ti = s_items[own[c]];
+                const uint32_t code = codes[((int64_t)ti.start + (c - (int)ti.rel)) * MT + j];
+                const bool second = j >= NF;
+                const double* f = reinterpret_cast<const double*>(__builtin_assume_aligned(
+                    px + (tbase + (second ? nt0 + (int)ti.t1 : (int)ti.t0)) * h + (second ? j - NF : j) * W, 16));
+                const double* sc = reinterpret_cast<const double*>(__builtin_assume_aligned(subs + ((size_t)j * K + code) * W, 16));
+                auto elem = [&](int e) -> double { const double df = f[e] - sc[e]; return df * df; };
+                e_lds[pr] = pw_leaf<double>(elem, 0, W);
+            }
+        }
+        __syncthreads();
+        TINY_T(8);
+        int n2 = 64;
+        while (n2 < nsurv) n2 <<= 1;
+        for (int sv = tid; sv < n2; sv += 1024) {
+            if (sv < nsurv) {
+                double d = e_lds[sv * MT];
+#pragma unroll
+                for (int j = 1; j < MT; ++j) d = d + e_lds[sv * MT + j];
+                skey[sv] = (uint64_t)__double_as_longlong(d);
+            } else {
+                skey[sv] = ~0ull;
+                sidx[sv] = 0xffffffffu;
+            }
+        }
+        sel_block_bitonic(skey, sidx, n2);
+        TINY_T(9);
+        for (int j = tid; j < nv; j += 1024) {
+            const int c = (int)sidx[j];
+            const int i = own[c];
+            sel_keys[ob + j] = skey[j];
+            sel_vals[ob + j] = ((uint64_t)(it0 + i) << 32) | (uint32_t)(c - (int)s_items[i].rel);
+        }
+        if (tid == 0) { nsel[q] = nv; fbflag[q] = 0; }
+        TINY_T(10);
+    }
+#undef TINY_T
+}
+
+static size_t tiny_lds_bytes(int ncmax, int pool_bytes) {
+    return (size_t)4 * ncmax + (size_t)pool_bytes + 512 * 4 + TINY_NS * 4 + (size_t)TINY_SMAX * 12 + sizeof(TinyShared) + 16;
+}
+
+// bytes of the per-query pool (items, tables or survivors) next to the candidate layout; 0: the kernel does not serve this shape
+static int tiny_pool(int M, int K, int w, int h, int L, int64_t ncmax_need, int* ncmax_out) {
+    if (!(M == 4 || M == 8 || M == 16) || K != 256 || !(w == 4 || w == 8 || w == 16 || w == 32) || h != (M / 2) * w || h > 256) return 0;
+    if (ncmax_need > TINY_NCMAX) return 0;
+    int ncmax = 4096;
+    while (ncmax < ncmax_need) ncmax += 2048;
+    const size_t fixed = tiny_lds_bytes(ncmax, 0);
+    const size_t budget = 160 * 1024 - 512;  // the static LDS of the helpers (key range, scans) comes on top
+    if (fixed + 32768 > budget) return 0;
+    const int pool = (int)((budget - fixed) & ~(size_t)15);
+    // a query with a few hundred items must keep room for 2 * limit survivors' exact entries and a useful number of tables
+    if ((pool - 8192) / (8 * M) < 2 * L || (pool - 8192) / ((M / 2) * 256) < 8) return 0;
+    *ncmax_out = ncmax;
+    return pool;
+}
+
+template <int MT, int W>
+static void launch_tiny_t(hipStream_t st, const WorkItem* items, const int64_t* cand_start, const int64_t* seg, const int64_t* item_off,
+                          const int64_t* tab_off, const PlanOut* plan, const double* px, const double* subs, const uint8_t* codes, int h, int nq,
+                          int L, int ncmax, int tch, int64_t stride, uint64_t* sel_keys, uint64_t* sel_vals, int* nsel, uint64_t* keys_fb,
+                          unsigned long long* qmin, unsigned long long* qmax, int* fbflag, float* px32_ws, unsigned int* dbg) {
+    const size_t lds = tiny_lds_bytes(ncmax, tch);
+    const unsigned grid = (unsigned)(nq < 256 ? nq : 256);
+    hipLaunchKernelGGL((k_tiny_select<MT, W>), dim3(grid), dim3(1024), lds, st, items, cand_start, seg, item_off, tab_off, plan, px, subs, codes,
+                       h, nq, L, ncmax, tch, stride, sel_keys, sel_vals, nsel, keys_fb, qmin, qmax, fbflag, px32_ws, dbg);
+}
+
+static bool launch_tiny(int M, int w, hipStream_t st, const WorkItem* items, const int64_t* cand_start, const int64_t* seg,
+                        const int64_t* item_off, const int64_t* tab_off, const PlanOut* plan, const double* px, const double* subs,
+                        const uint8_t* codes, int h, int nq, int L, int ncmax, int tch, int64_t stride, uint64_t* sel_keys, uint64_t* sel_vals,
+                        int* nsel, uint64_t* keys_fb, unsigned long long* qmin, unsigned long long* qmax, int* fbflag, float* px32_ws, unsigned int* dbg) {
+#define CIS_TINY(MT, W)                                                                                                            \
+    if (M == MT && w == W) {                                                                                                       \
+        launch_tiny_t<MT, W>(st, items, cand_start, seg, item_off, tab_off, plan, px, subs, codes, h, nq, L, ncmax, tch, stride,   \
+                             sel_keys, sel_vals, nsel, keys_fb, qmin, qmax, fbflag, px32_ws, dbg);                                 \
+        return true;                                                                                                               \
+    }
+    CIS_TINY(8, 16) CIS_TINY(16, 8) CIS_TINY(4, 32) CIS_TINY(16, 16) CIS_TINY(8, 32) CIS_TINY(8, 8) CIS_TINY(4, 16) CIS_TINY(16, 4)
+#undef CIS_TINY
+    return false;
 }
 
 // one sub-batch of queries (device pointers); writes ranked partial hits [nq][L] and visited [nq]
@@ -3875,25 +4365,64 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             rk = keys_out; rv = vals_out;
         } else {
             uint64_t *sel_keys = b1, *sel_vals = b2;
+            // tiny cells, limit a small share of the quota: byte-table prefilter + exact keys of the survivors in ONE kernel per
+            // query (k_tiny_select); the queries it flags go through the exact kernels below
+            int* fbflag = nullptr;
+            // (measured at V = 2048, 8192 queries, limit 100: quota 10000 5.16 against 6.35 ms for the exact kernels, quota 1000 2.19 against
+            // 1.36 -- the sample, the row copies and the sort are fixed costs per query: from 8192 candidates on)
+            const int64_t tiny_min_quota = getenv("CIS_TINY_MIN_QUOTA") ? atoll(getenv("CIS_TINY_MIN_QUOTA")) : 8192;
+            if (direct && sp.sort_lds && n_items > 0 && (int64_t)L * 8 <= (int64_t)quota && (int64_t)quota >= tiny_min_quota && !getenv("CIS_NO_TINY")) {
+                int ncmax = 0;
+                const int tch = tiny_pool(M, K, m->w, h, L, (int64_t)quota + ix->max_cell, &ncmax);  // bytes of the per-query pool
+                if (tch > 0) {
+                    fbflag = nsel + (nq + 2);
+                    static const bool tiny_dbg = getenv("CIS_TINY_DEBUG") != nullptr;
+                    unsigned int* dbg = nullptr;
+                    if (tiny_dbg) {
+                        CIS_TRY(ix->w_slack.reserve(64));
+                        dbg = ix->w_slack.as<unsigned int>();
+                        CIS_CHECK_HIP(hipMemsetAsync(dbg, 0, 64, st));
+                    }
+                    CIS_TRY(ix->w_T32.reserve((size_t)256 * TINY_TCH * h * sizeof(float)));  // per-workgroup float32 rows (tables are not used here)
+                    if (!launch_tiny(M, m->w, st, items, cand_start, seg, item_off, tab_off, plan, px_buf, m->d_subs, codes, h, nq, L, ncmax, tch,
+                                     sp.stride, sel_keys, sel_vals, nsel, keys_in, qmin, qmax, fbflag, ix->w_T32.as<float>(), dbg))
+                        fbflag = nullptr;
+                    else if (tiny_dbg) {
+                        unsigned int hd[16];
+                        CIS_CHECK_HIP(hipMemcpyAsync(hd, dbg, 64, hipMemcpyDeviceToHost, st));
+                        CIS_CHECK_HIP(hipStreamSynchronize(st));
+                        fprintf(stderr, "[tiny] queries %u  flagged %u  survivors/query %.1f  mean s* %.1f  (pool %d B, ncmax %d; tables/query %.1f, items/query %.1f)\n", hd[0], hd[1],
+                                hd[0] ? (double)hd[2] / hd[0] : 0.0, hd[0] ? (double)hd[3] / hd[0] : 0.0, tch, ncmax, (double)n_tabs / nq, (double)n_items / nq);
+                        // 100 MHz ticks of thread 0 per phase, summed over all queries: us per query
+                        fprintf(stderr, "[tiny] us/query: top %.1f layout %.1f sample %.1f lookups %.1f rows %.1f tables %.1f last lookups %.1f hist+gather %.1f exact %.1f sums+sort %.1f out %.1f\n",
+                                hd[4] / 100.0 / nq, hd[5] / 100.0 / nq, hd[6] / 100.0 / nq, hd[7] / 100.0 / nq, hd[8] / 100.0 / nq, hd[9] / 100.0 / nq,
+                                hd[10] / 100.0 / nq, hd[11] / 100.0 / nq, hd[12] / 100.0 / nq, hd[13] / 100.0 / nq, hd[14] / 100.0 / nq);
+                    }
+                }
+            }
+            if (fbflag) {
+            } else
             if (n_items > 0 && !(direct && launch_adc_direct(M, K, m->w, st, items, cand_start, seg, item_off, px_buf, m->d_subs, codes, h, nq, keys_in, nullptr, qmin, qmax)))
                 launch_adc_all(n_items, st, items, cand_start, T, codes, M, K, keys_in, nullptr, qmin, qmax, d_tot, seg, item_off, nq, tiny_cells);
             if (sp.sort_lds) {
                 // fewer queries than CUs: one large workgroup per query walks its keys faster; else two 512-thread ones per CU
                 if (nq <= 256)
                     hipLaunchKernelGGL((k_select_topl<true, 1024>), dim3((unsigned)nq), dim3(1024), sp.lds, st, keys_in, seg, cand_start, item_off,
-                                       qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, (int64_t*)nullptr, (int64_t*)nullptr);
+                                       qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, (int64_t*)nullptr, (int64_t*)nullptr,
+                                       (const int*)fbflag);
                 else
                     hipLaunchKernelGGL((k_select_topl<true, 512>), dim3((unsigned)nq), dim3(512), sp.lds, st, keys_in, seg, cand_start, item_off,
-                                       qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, (int64_t*)nullptr, (int64_t*)nullptr);
+                                       qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, (int64_t*)nullptr, (int64_t*)nullptr,
+                                       (const int*)fbflag);
                 rk = sel_keys; rv = sel_vals;
             } else {
                 uint64_t *srt_keys = b3, *srt_vals = b3 + bl;
                 if (nq <= 256)
                     hipLaunchKernelGGL((k_select_topl<false, 1024>), dim3((unsigned)nq), dim3(1024), sp.lds, st, keys_in, seg, cand_start, item_off,
-                                       qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, seg_b, seg_e);
+                                       qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, seg_b, seg_e, (const int*)nullptr);
                 else
                     hipLaunchKernelGGL((k_select_topl<false, 512>), dim3((unsigned)nq), dim3(512), sp.lds, st, keys_in, seg, cand_start, item_off,
-                                       qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, seg_b, seg_e);
+                                       qmin, qmax, n_items, L, sp.p2, sp.stride, sel_keys, sel_vals, nsel, seg_b, seg_e, (const int*)nullptr);
                 size_t b = tmp_bytes;
                 CIS_TRY(cis_seg_sort_u64(tmp, &b, sel_keys, srt_keys, sel_vals, srt_vals, n_sel, nq, seg_b, seg_e, st));
                 rk = srt_keys; rv = srt_vals;

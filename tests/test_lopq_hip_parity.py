@@ -939,3 +939,44 @@ def test_multisequence_plan_with_thousands_of_cells_and_tied_sums():
     for qi in range(len(Q)):
         want = [cell for _, cell in zip(range(3000), (cc for _, cc in O.multisequence(om, Q[qi])))]
         np.testing.assert_array_equal(got_cells[qi], np.array(want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,M,D,dup", [(96, 8, 128, 0), (96, 4, 128, 0), (96, 16, 128, 0), (64, 8, 64, 0), (96, 16, 256, 0), (96, 8, 128, 5000)])
+def test_tiny_cells_prefilter_equals_exact_kernels(V, M, D, dup, monkeypatch):
+    """k_tiny_select (byte-table prefilter + exact keys of the survivors, one workgroup per query) against the exact kernels it
+    replaces (k_adc_direct + k_select_topl, CIS_NO_TINY=1) and against the oracle: ids, float64 distance bits, counts, visited --
+    on indexes of tiny cells (thousands of cells of a few codes) for every sub-quantizer shape the kernel is built for, with a
+    block of identical codes (`dup`: more exact ties at the cut than the survivor list holds, so those queries take the
+    flagged route) and with quotas on both sides of the candidate layout's size."""
+    import torch
+    from oracle import lopq_oracle as O
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    K = 256
+    m, om = _random_model(V, M, K, D, seed=V + M)
+    rs = np.random.RandomState(M)
+    n = 150_000
+    X = rs.randn(n, D).astype(np.float32)
+    if dup:
+        X[1000:1000 + dup] = X[1000]
+    coarse, fine = m.predict_batch(X)
+    Q = np.concatenate([X[1000:1003] + 1e-3 * rs.randn(3, D).astype(np.float32), rs.randn(61, D).astype(np.float32)])
+    s = LOPQSearcherHIP(m)
+    s.add_codes_array(coarse, fine, ids=np.arange(n, dtype=np.int64), dedup=False)
+    q = torch.as_tensor(Q).cuda()
+    monkeypatch.setenv("CIS_TINY_MIN_QUOTA", "0")
+    oi = O.OracleCSRIndex(om, coarse, fine)
+    for quota, limit in [(4000, 100), (9000, 37), (2500, 300), (20000, 100)]:
+        monkeypatch.setenv("CIS_NO_TINY", "1")
+        want = {k: v.cpu().numpy() for k, v in s.search_batch_dev(q, quota=quota, limit=limit).items() if hasattr(v, "cpu")}
+        monkeypatch.delenv("CIS_NO_TINY")
+        got = {k: v.cpu().numpy() for k, v in s.search_batch_dev(q, quota=quota, limit=limit).items() if hasattr(v, "cpu")}
+        for k in ("ids", "n_found", "visited"):
+            np.testing.assert_array_equal(got[k], want[k], err_msg="quota %d limit %d %s" % (quota, limit, k))
+        np.testing.assert_array_equal(got["dists"].view(np.uint64), want["dists"].view(np.uint64))
+        for qi in (0, 5):
+            ids, dists, visited = oi.search(Q[qi], quota, limit)
+            assert visited == got["visited"][qi]
+            np.testing.assert_array_equal(np.asarray(ids, np.int64), got["ids"][qi][:len(ids)])
+            np.testing.assert_allclose(got["dists"][qi][:len(ids)], np.asarray(dists), rtol=1e-9)
+    s.close()
