@@ -831,7 +831,8 @@ __global__ __launch_bounds__(256) void k_tables_group(const CT* __restrict__ X, 
                                                       const double* __restrict__ Rt, const double* __restrict__ mus,
                                                       const TabDesc* __restrict__ tabs, const int* __restrict__ tab_order,
                                                       int n_tabs, int V, int h, int D, double* __restrict__ px_out,
-                                                      const int64_t* __restrict__ d_totals /* null, or the plan totals: n_tabs is a bound */) {
+                                                      const int64_t* __restrict__ d_totals /* null, or the plan totals: n_tabs is a bound */,
+                                                      float* __restrict__ px32_out /* null, or a float32 copy of px (k_tiny_select's prefilter) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (d_totals) {
         n_tabs = (int)d_totals[1];
@@ -914,19 +915,21 @@ __global__ __launch_bounds__(256) void k_tables_group(const CT* __restrict__ X, 
         double acc = psum[t * h + ii];
         for (int q = 1; q < parts; ++q) acc = acc + psum[(q * TB + t) * h + ii];
         px_out[(int64_t)s_tab[t] * h + ii] = acc;
+        if (px32_out) px32_out[(int64_t)s_tab[t] * h + ii] = (float)acc;
     }
 }
 
 template <typename CT>
 static void launch_tables(int64_t n_tabs, size_t tab_lds, hipStream_t st, const CT* X, const CT* Cs, const double* Rt,
                           const double* mus, const double* subs, const TabDesc* tabs, const int* tab_order, int V, int h, int w,
-                          int nf, int K, int D, double* T, PwProg prog_w, double* px_out, const int64_t* d_totals = nullptr) {
+                          int nf, int K, int D, double* T, PwProg prog_w, double* px_out, const int64_t* d_totals = nullptr,
+                          float* px32_out = nullptr) {
     constexpr int TB = 8;
     if (px_out && h <= 256 && 256 / h >= 1 && !getenv("CIS_TABLES_UNGROUPED")) {
         const int parts = 256 / h;
         const size_t lds = (size_t)(TB * h + parts * TB * h) * sizeof(double);
         hipLaunchKernelGGL((k_tables_group<CT, TB>), dim3((unsigned)ceil_div(n_tabs, TB)), dim3(256), lds, st, X, Cs, Rt, mus, tabs,
-                           tab_order, (int)n_tabs, V, h, D, px_out, d_totals);
+                           tab_order, (int)n_tabs, V, h, D, px_out, d_totals, px32_out);
     } else {
         hipLaunchKernelGGL(k_tables<CT>, dim3((unsigned)n_tabs), dim3(256), tab_lds, st, X, Cs, Rt, mus, subs, tabs, V, h, w, nf, K, D, T,
                            prog_w, px_out, (const int*)nullptr, 0);
@@ -3652,12 +3655,11 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
                                                       int64_t stride, uint64_t* __restrict__ sel_keys, uint64_t* __restrict__ sel_vals,
                                                       int* __restrict__ nsel, uint64_t* __restrict__ keys_fb,
                                                       unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax,
-                                                      int* __restrict__ fbflag, float* __restrict__ px32_ws /* [grid][TINY_TCH][h] */,
+                                                      int* __restrict__ fbflag, const float* __restrict__ px32 /* [ntab][h]: float32 copy of px */,
                                                       unsigned int* __restrict__ dbg) {
     constexpr int NF = MT / 2, K = 256;
     constexpr int PAIRS = NF * K;
     constexpr int PPT = (PAIRS + 1023) / 1024;
-    constexpr int NR = TINY_NCMAX / 1024;  // candidates per thread at most
     constexpr int CW = NF >= 4 ? NF / 4 : 1;
     extern __shared__ __align__(16) unsigned char tiny_lds[];
     uint16_t* own = reinterpret_cast<uint16_t*>(tiny_lds);
@@ -3670,6 +3672,7 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
     uint32_t* sidx = reinterpret_cast<uint32_t*>(skey + TINY_SMAX);        // TINY_SMAX
     TinyShared* sh = reinterpret_cast<TinyShared*>(sidx + TINY_SMAX);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __builtin_amdgcn_s_dcache_inv();  // the scalar cache may hold rows of an earlier batch at the addresses of px32
     long long t_last = dbg ? wall_clock64() : 0;
 #define TINY_T(k_) do { if (dbg && tid == 0) { const long long now_ = wall_clock64(); atomicAdd(&dbg[4 + (k_)], (unsigned int)(now_ - t_last)); t_last = now_; } } while (0)
     // largest centroid component (float32 rounding bound), once per workgroup
@@ -3701,7 +3704,6 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
         int smax = rest > 0 ? rest / (8 * MT) : 0;
         smax = smax < TINY_SMAX ? smax : TINY_SMAX;
         uint8_t* s_tab = pool + items_bytes;
-        float* ws = px32_ws + (size_t)blockIdx.x * TINY_TCH * h;  // float32 copy of the current chunk's px rows (global: scalar loads)
         double* e_lds = reinterpret_cast<double*>(pool + items_bytes);
         bool fall = n64 > (int64_t)ncmax || ni > 65535 || tch < 4 || L > smax;
         const int n = (int)n64;
@@ -3781,28 +3783,14 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
             const float inv_step = cap > 0.f ? 256.0f / cap : 0.f;
             // 3. byte tables of a split, at most tch at a time; every candidate adds its entries up.  An entry is
             //    sum (px - c)^2 in float32: the thread keeps its (sub-quantizer, centroid) in registers, the px row of a table
-            //    arrives through scalar loads (uniform over the wave) from a float32 copy of the chunk's rows that a pre-pass
-            //    leaves in this workgroup's global scratch
+            //    arrives through scalar loads (uniform over the wave) from the float32 copy of px that k_tables_group wrote
             for (int s = 0; s < 2; ++s) {
                 const int nts = s ? nt1 : nt0;
                 const int64_t tb = tbase + (s ? nt0 : 0);
                 for (int tlo = 0; tlo < nts; tlo += tch) {
                     const int tc = nts - tlo < tch ? nts - tlo : tch;
-                    __syncthreads();  // the previous chunk's tables and rows are no longer read
+                    __syncthreads();  // the previous chunk's tables are no longer read
                     TINY_T(3);
-                    {
-                        float a = 0.f;
-                        const double* src = px + (tb + tlo) * h;
-#pragma unroll 4
-                        for (int i = tid; i < tc * h; i += 1024) {
-                            const float v = (float)src[i];
-                            ws[i] = v;
-                            a = fmaxf(a, fabsf(v));
-                        }
-                        atomicMax(&sh->amax_bits, __float_as_uint(a));
-                    }
-                    __syncthreads();  // (waits for the stores: they are in L2)
-                    __builtin_amdgcn_s_dcache_inv();  // the scalar cache may hold the previous chunk's rows
                     TINY_T(4);
 #pragma unroll
                     for (int pp = 0; pp < PPT; ++pp) {
@@ -3813,7 +3801,7 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
                             const double* sc = subs + ((size_t)(s * NF + jj) * K + k) * W;
 #pragma unroll
                             for (int e = 0; e < W; ++e) cen[e] = (float)sc[e];
-                            const float* frow = ws + jj * W;
+                            const float* frow = px32 + (tb + tlo) * h + jj * W;
                             uint8_t* trow = s_tab + jj * K + k;
                             constexpr int U = TinyRows<W>::U;
                             typedef float tiny_f2 __attribute__((ext_vector_type(2)));
@@ -3894,11 +3882,11 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
             }
             __syncthreads();
             const int sstar = sh->sstar;
-            const float amax = __uint_as_float(sh->amax_bits);
-            // float32: a component difference carries an absolute error of 2^-23 amax_ (amax_ = the largest |px| or |c| component),
-            // an entry e < cap at most 2 sqrt(W cap) 2^-23 amax_: under step / 16 = cap / 4096 when cap >= W amax_^2 / 2^20
+            // float32: a component difference carries an absolute error of 2^-23 amax_, amax_ = the largest operand -- |c| <= cmax_, and
+            // where the entry is below the cap |px| < cmax_ + sqrt(cap) (a clamped entry only needs the RELATIVE accuracy it has);
+            // an entry e < cap is off by at most 2 sqrt(W cap) 2^-23 amax_: under step / 16 = cap / 4096 when cap >= W amax_^2 / 2^20
             const float cmax_ = __uint_as_float(sh->cen_bits);
-            const float amax_ = fmaxf(amax, cmax_);
+            const float amax_ = cmax_ + sqrtf(cap);
             if (sstar > 254 || !(cap >= (float)W * amax_ * amax_ * (1.0f / 1048576.0f))) fall = true;
             else {
                 const int thr = sstar + MT + 1;
@@ -4262,7 +4250,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     CIS_TRY(ix->w_tord.reserve((size_t)(n_tabs + 1) * sizeof(int)));
     int* tab_order = ix->w_tord.as<int>();  // table indices grouped by (split, cluster)
     double* T = ix->w_T.as<double>();
-    CIS_TRY(ix->w_T32.reserve(direct_elig ? 256 : (size_t)(n_tabs + 1) * nf * K * sizeof(float)));
+    // tiny cells: the float32 copy of px for k_tiny_select lives here (no tables on that path)
+    CIS_TRY(ix->w_T32.reserve(direct_elig ? (size_t)(n_tabs + 1) * h * sizeof(float) : (size_t)(n_tabs + 1) * nf * K * sizeof(float)));
     float* T32 = ix->w_T32.as<float>();
     const size_t tab_lds = (size_t)(2 * h + (h < 256 ? 256 : 0)) * sizeof(double);
     const bool split_tables = (m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) && K <= 256;
@@ -4281,7 +4270,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                            seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order, plan_fb);
         if (n_tabs > 0)
             launch_tables<float>(n_tabs, tab_lds, st, (const float*)xc, m->d_Cs32, m->d_Rt, m->d_mus, m->d_subs, tabs, tab_order, V, h,
-                                 m->w, nf, K, D, T, m->prog_w, px_buf, d_tot);
+                                 m->w, nf, K, D, T, m->prog_w, px_buf, d_tot, direct_elig ? T32 : nullptr);
     } else {
         if (par_plan)
             hipLaunchKernelGGL((k_plan_par<double, true>), dim3(nq), dim3(256), 0, st, ix->w_sorted.as<double>(), ix->w_order.as<uint16_t>(),
@@ -4292,7 +4281,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                            seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order, plan_fb);
         if (n_tabs > 0)
             launch_tables<double>(n_tabs, tab_lds, st, (const double*)xc, m->d_Cs64, m->d_Rt, m->d_mus, m->d_subs, tabs, tab_order, V,
-                                  h, m->w, nf, K, D, T, m->prog_w, px_buf, d_tot);
+                                  h, m->w, nf, K, D, T, m->prog_w, px_buf, d_tot, direct_elig ? T32 : nullptr);
     }
     const bool direct = direct_elig;
     if (direct) {
@@ -4383,9 +4372,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                         dbg = ix->w_slack.as<unsigned int>();
                         CIS_CHECK_HIP(hipMemsetAsync(dbg, 0, 64, st));
                     }
-                    CIS_TRY(ix->w_T32.reserve((size_t)256 * TINY_TCH * h * sizeof(float)));  // per-workgroup float32 rows (tables are not used here)
                     if (!launch_tiny(M, m->w, st, items, cand_start, seg, item_off, tab_off, plan, px_buf, m->d_subs, codes, h, nq, L, ncmax, tch,
-                                     sp.stride, sel_keys, sel_vals, nsel, keys_in, qmin, qmax, fbflag, ix->w_T32.as<float>(), dbg))
+                                     sp.stride, sel_keys, sel_vals, nsel, keys_in, qmin, qmax, fbflag, T32, dbg))
                         fbflag = nullptr;
                     else if (tiny_dbg) {
                         unsigned int hd[16];
