@@ -3935,26 +3935,34 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
         }
         __syncthreads();
         TINY_T(8);
-        int n2 = 64;
-        while (n2 < nsurv) n2 <<= 1;
-        for (int sv = tid; sv < n2; sv += 1024) {
-            if (sv < nsurv) {
-                double d = e_lds[sv * MT];
+        for (int sv = tid; sv < nsurv; sv += 1024) {
+            double d = e_lds[sv * MT];
 #pragma unroll
-                for (int j = 1; j < MT; ++j) d = d + e_lds[sv * MT + j];
-                skey[sv] = (uint64_t)__double_as_longlong(d);
-            } else {
-                skey[sv] = ~0ull;
-                sidx[sv] = 0xffffffffu;
-            }
+            for (int j = 1; j < MT; ++j) d = d + e_lds[sv * MT + j];
+            skey[sv] = (uint64_t)__double_as_longlong(d);
         }
-        sel_block_bitonic(skey, sidx, n2);
+        __syncthreads();
         TINY_T(9);
-        for (int j = tid; j < nv; j += 1024) {
-            const int c = (int)sidx[j];
-            const int i = own[c];
-            sel_keys[ob + j] = skey[j];
-            sel_vals[ob + j] = ((uint64_t)(it0 + i) << 32) | (uint32_t)(c - (int)s_items[i].rel);
+        // rank by counting: a survivor's place is the number of survivors before it in (key, retrieval position) order -- all lanes
+        // read the same pair at a time (LDS broadcast), no barrier; the first `limit` places are the result
+        for (int sv0 = 0; sv0 < nsurv; sv0 += 128) {  // eight threads per survivor, an eighth of the list each
+            const int sv = sv0 + (tid >> 3), part = tid & 7;
+            const bool on = sv < nsurv;
+            const uint64_t kk = on ? skey[sv] : 0ull;
+            const uint32_t cc = on ? sidx[sv] : 0u;
+            const int per = (nsurv + 7) >> 3;
+            const int j0 = part * per, j1 = j0 + per < nsurv ? j0 + per : nsurv;
+            int place = 0;
+#pragma unroll 4
+            for (int j = j0; j < j1; ++j) place += sel_pair_less(skey[j], sidx[j], kk, cc) ? 1 : 0;
+            place += __shfl_xor(place, 1);
+            place += __shfl_xor(place, 2);
+            place += __shfl_xor(place, 4);
+            if (on && part == 0 && place < nv) {
+                const int i = own[cc];
+                sel_keys[ob + place] = kk;
+                sel_vals[ob + place] = ((uint64_t)(it0 + i) << 32) | (uint32_t)((int)cc - (int)s_items[i].rel);
+            }
         }
         if (tid == 0) { nsel[q] = nv; fbflag[q] = 0; }
         TINY_T(10);
