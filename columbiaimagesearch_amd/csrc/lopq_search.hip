@@ -3560,7 +3560,7 @@ static const int TINY_NCMAX = 16384;
 static const int TINY_TCH = 128;    // tables per chunk at most
 
 struct TinyShared {
-    int cnt, sstar, fb;
+    int cnt, sstar, fb, nused[2];
     unsigned int cap_bits, amax_bits, cen_bits;
     int wsum[16];
 };
@@ -3697,7 +3697,10 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
             continue;
         }
         // this query's share of the pool: its items first, the rest for tables (or the survivors' entries)
-        const int items_bytes = (ni * (int)sizeof(TinyItem) + 15) & ~15;
+        const int ntt = plan[q].ntab0 + plan[q].ntab1;
+        const int list_off = (ni * (int)sizeof(TinyItem) + 15) & ~15;           // uint16 used[ntt]: the half tables that have a candidate
+        const int items_bytes = list_off + ((ntt * 2 + 15) & ~15);               // (items + lists: what stays for the whole query)
+        uint16_t* used = reinterpret_cast<uint16_t*>(pool + list_off);          // split 0's list, then split 1's at used + nt0
         const int rest = pool_bytes - items_bytes;
         int tch = rest > 0 ? rest / (NF * K) : 0;
         tch = tch < TINY_TCH ? tch : TINY_TCH;
@@ -3705,16 +3708,21 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
         smax = smax < TINY_SMAX ? smax : TINY_SMAX;
         uint8_t* s_tab = pool + items_bytes;
         double* e_lds = reinterpret_cast<double*>(pool + items_bytes);
-        bool fall = n64 > (int64_t)ncmax || ni > 65535 || tch < 4 || L > smax;
+        bool fall = n64 > (int64_t)ncmax || ni > 65535 || ntt > 4096 || tch < 4 || L > smax;
         const int n = (int)n64;
         const bool all_in = !fall && n <= smax && n <= (2 * L > 256 ? 2 * L : 256);  // few candidates: every one is ranked exactly
         int nsurv = 0;
         if (!fall) {
             if (tid == 0) { sh->cnt = 0; sh->sstar = 1 << 20; sh->amax_bits = 0u; sh->cap_bits = 0u; sh->fb = 0; }
             for (int b = tid; b < 512; b += 1024) hist[b] = 0u;
-            // 1. the items, then the owner item of every candidate
+            // 1. the items, the half tables that have a candidate at all (155 of 198 at V = 2048: the multisequence visits empty
+            //    cells too) numbered densely per split, then the owner item of every candidate
             const int64_t tbase = tab_off[q];
             const int nt0 = plan[q].ntab0;
+            uint16_t* slot_of = reinterpret_cast<uint16_t*>(skey);  // [ntt], free until the survivors are ranked
+            for (int i = tid; i < ntt; i += 1024) slot_of[i] = 0;
+            for (int c = tid; c < n; c += 1024) sum[c] = 0;
+            __syncthreads();
             for (int i = tid; i < ni; i += 1024) {
                 const WorkItem it = items[it0 + i];
                 TinyItem ti;
@@ -3724,9 +3732,36 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
                 ti.t0 = (uint16_t)(it.tab0 - tbase);
                 ti.t1 = (uint16_t)(it.tab1 - tbase - nt0);
                 s_items[i] = ti;
+                slot_of[ti.t0] = 1;
+                slot_of[nt0 + ti.t1] = 1;
                 if (it.start + it.len > (int64_t)0xffffffffll || it.len > 65535) sh->fb = 1;
             }
-            for (int c = tid; c < n; c += 1024) sum[c] = 0;
+            __syncthreads();
+            for (int s = 0; s < 2; ++s) {  // dense numbers: four entries per thread, one workgroup scan per split
+                const int base = s ? nt0 : 0, nts = s ? ntt - nt0 : nt0;
+                int fl[4], cnt = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = tid * 4 + u; fl[u] = i < nts ? (int)slot_of[base + i] : 0; cnt += fl[u]; }
+                int tot;
+                int run = sel_block_excl_scan(cnt, sh->wsum, &tot);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = tid * 4 + u;
+                    if (i < nts) {
+                        slot_of[base + i] = fl[u] ? (uint16_t)run : (uint16_t)0xffff;
+                        if (fl[u]) used[base + run] = (uint16_t)i;
+                        run += fl[u];
+                    }
+                }
+                if (tid == 0) sh->nused[s] = tot;
+                __syncthreads();
+            }
+            for (int i = tid; i < ni; i += 1024) {
+                TinyItem ti = s_items[i];
+                ti.t0 = slot_of[ti.t0];
+                ti.t1 = slot_of[nt0 + ti.t1];
+                s_items[i] = ti;
+            }
             __syncthreads();
             for (int i = wv; i < ni; i += 16) {
                 const TinyItem ti = s_items[i];
@@ -3734,11 +3769,12 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
             }
             __syncthreads();
             if (sh->fb) fall = true;
+            if (dbg && tid == 0) atomicAdd(&dbg[15], (unsigned int)(sh->nused[0] + sh->nused[1]));
             TINY_T(1);
         }
         if (!fall && !all_in) {
             const int64_t tbase = tab_off[q];
-            const int nt0 = plan[q].ntab0, nt1 = plan[q].ntab1;
+            const int nt0 = plan[q].ntab0;
             // 2. cap from the sample: the r-th smallest of TINY_NS sampled distances (float32 arithmetic: the cap is a heuristic,
             //    the bounds below hold for any value), r / TINY_NS ~ three times limit / n
             {
@@ -3750,7 +3786,7 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
                 for (int j = sub; j < MT; j += 8) {
                     const bool second = j >= NF;
                     const double* f = reinterpret_cast<const double*>(__builtin_assume_aligned(
-                        px + (tbase + (second ? nt0 + (int)ti.t1 : (int)ti.t0)) * h + (second ? j - NF : j) * W, 16));
+                        px + (tbase + (second ? nt0 + (int)used[nt0 + ti.t1] : (int)used[ti.t0])) * h + (second ? j - NF : j) * W, 16));
                     const uint32_t code = (cw.w[j >> 2] >> (8 * (j & 3))) & 255u;
                     const double* sc = reinterpret_cast<const double*>(__builtin_assume_aligned(subs + ((size_t)j * K + code) * W, 16));
 #pragma unroll
@@ -3785,8 +3821,9 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
             //    sum (px - c)^2 in float32: the thread keeps its (sub-quantizer, centroid) in registers, the px row of a table
             //    arrives through scalar loads (uniform over the wave) from the float32 copy of px that k_tables_group wrote
             for (int s = 0; s < 2; ++s) {
-                const int nts = s ? nt1 : nt0;
+                const int nts = sh->nused[s];            // tables of this split that have a candidate
                 const int64_t tb = tbase + (s ? nt0 : 0);
+                const uint16_t* lst = used + (s ? nt0 : 0);
                 for (int tlo = 0; tlo < nts; tlo += tch) {
                     const int tc = nts - tlo < tch ? nts - tlo : tch;
                     __syncthreads();  // the previous chunk's tables are no longer read
@@ -3801,7 +3838,7 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
                             const double* sc = subs + ((size_t)(s * NF + jj) * K + k) * W;
 #pragma unroll
                             for (int e = 0; e < W; ++e) cen[e] = (float)sc[e];
-                            const float* frow = px32 + (tb + tlo) * h + jj * W;
+                            const float* frow = px32 + tb * h + jj * W;
                             uint8_t* trow = s_tab + jj * K + k;
                             constexpr int U = TinyRows<W>::U;
                             typedef float tiny_f2 __attribute__((ext_vector_type(2)));
@@ -3809,7 +3846,7 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
                                 const float* rp[U];
                                 int tu[U];
 #pragma unroll
-                                for (int u = 0; u < U; ++u) { tu[u] = t + u < tc ? t + u : tc - 1; rp[u] = frow + tu[u] * h; }
+                                for (int u = 0; u < U; ++u) { tu[u] = t + u < tc ? t + u : tc - 1; rp[u] = frow + (int)lst[tlo + tu[u]] * h; }
                                 float f[U][W];
                                 tiny_sload_rows<W>(rp, f);
 #pragma unroll
@@ -3927,7 +3964,7 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
                 const uint32_t code = codes[((int64_t)ti.start + (c - (int)ti.rel)) * MT + j];
                 const bool second = j >= NF;
                 const double* f = reinterpret_cast<const double*>(__builtin_assume_aligned(
-                    px + (tbase + (second ? nt0 + (int)ti.t1 : (int)ti.t0)) * h + (second ? j - NF : j) * W, 16));
+                    px + (tbase + (second ? nt0 + (int)used[nt0 + ti.t1] : (int)used[ti.t0])) * h + (second ? j - NF : j) * W, 16));
                 const double* sc = reinterpret_cast<const double*>(__builtin_assume_aligned(subs + ((size_t)j * K + code) * W, 16));
                 auto elem = [&](int e) -> double { const double df = f[e] - sc[e]; return df * df; };
                 e_lds[pr] = pw_leaf<double>(elem, 0, W);
@@ -4393,6 +4430,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                         fprintf(stderr, "[tiny] us/query: top %.1f layout %.1f sample %.1f lookups %.1f rows %.1f tables %.1f last lookups %.1f hist+gather %.1f exact %.1f sums+sort %.1f out %.1f\n",
                                 hd[4] / 100.0 / nq, hd[5] / 100.0 / nq, hd[6] / 100.0 / nq, hd[7] / 100.0 / nq, hd[8] / 100.0 / nq, hd[9] / 100.0 / nq,
                                 hd[10] / 100.0 / nq, hd[11] / 100.0 / nq, hd[12] / 100.0 / nq, hd[13] / 100.0 / nq, hd[14] / 100.0 / nq);
+                        fprintf(stderr, "[tiny] half tables with a candidate: %.1f per query\n", (double)hd[15] / nq);
                     }
                 }
             }
