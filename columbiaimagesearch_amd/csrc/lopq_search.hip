@@ -3838,17 +3838,27 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
                             const double* sc = subs + ((size_t)(s * NF + jj) * K + k) * W;
 #pragma unroll
                             for (int e = 0; e < W; ++e) cen[e] = (float)sc[e];
+                            if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TINY_T(12); }
                             const float* frow = px32 + tb * h + jj * W;
                             uint8_t* trow = s_tab + jj * K + k;
                             constexpr int U = TinyRows<W>::U;
                             typedef float tiny_f2 __attribute__((ext_vector_type(2)));
+                            int cur[U];  // table numbers of the next U rows: read from LDS one iteration ahead (under the scalar loads' wait)
+#pragma unroll
+                            for (int u = 0; u < U; ++u) cur[u] = __builtin_amdgcn_readfirstlane((int)lst[tlo + (u < tc ? u : tc - 1)]);
                             for (int t = 0; t < tc; t += U) {
                                 const float* rp[U];
-                                int tu[U];
+                                int tu[U], nxt[U];
 #pragma unroll
-                                for (int u = 0; u < U; ++u) { tu[u] = t + u < tc ? t + u : tc - 1; rp[u] = frow + (int)lst[tlo + tu[u]] * h; }
+                                for (int u = 0; u < U; ++u) {
+                                    tu[u] = t + u < tc ? t + u : tc - 1;
+                                    rp[u] = frow + cur[u] * h;
+                                    nxt[u] = (int)lst[tlo + (t + U + u < tc ? t + U + u : tc - 1)];
+                                }
                                 float f[U][W];
                                 tiny_sload_rows<W>(rp, f);
+#pragma unroll
+                                for (int u = 0; u < U; ++u) cur[u] = __builtin_amdgcn_readfirstlane(nxt[u]);
 #pragma unroll
                                 for (int u = 0; u < U; ++u) {
                                     tiny_f2 acc = {0.f, 0.f};  // packed float32 math: even and odd components apart
@@ -4413,16 +4423,16 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                     static const bool tiny_dbg = getenv("CIS_TINY_DEBUG") != nullptr;
                     unsigned int* dbg = nullptr;
                     if (tiny_dbg) {
-                        CIS_TRY(ix->w_slack.reserve(64));
+                        CIS_TRY(ix->w_slack.reserve(128));
                         dbg = ix->w_slack.as<unsigned int>();
-                        CIS_CHECK_HIP(hipMemsetAsync(dbg, 0, 64, st));
+                        CIS_CHECK_HIP(hipMemsetAsync(dbg, 0, 96, st));
                     }
                     if (!launch_tiny(M, m->w, st, items, cand_start, seg, item_off, tab_off, plan, px_buf, m->d_subs, codes, h, nq, L, ncmax, tch,
                                      sp.stride, sel_keys, sel_vals, nsel, keys_in, qmin, qmax, fbflag, T32, dbg))
                         fbflag = nullptr;
                     else if (tiny_dbg) {
-                        unsigned int hd[16];
-                        CIS_CHECK_HIP(hipMemcpyAsync(hd, dbg, 64, hipMemcpyDeviceToHost, st));
+                        unsigned int hd[24];
+                        CIS_CHECK_HIP(hipMemcpyAsync(hd, dbg, 96, hipMemcpyDeviceToHost, st));
                         CIS_CHECK_HIP(hipStreamSynchronize(st));
                         fprintf(stderr, "[tiny] queries %u  flagged %u  survivors/query %.1f  mean s* %.1f  (pool %d B, ncmax %d; tables/query %.1f, items/query %.1f)\n", hd[0], hd[1],
                                 hd[0] ? (double)hd[2] / hd[0] : 0.0, hd[0] ? (double)hd[3] / hd[0] : 0.0, tch, ncmax, (double)n_tabs / nq, (double)n_items / nq);
@@ -4430,7 +4440,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                         fprintf(stderr, "[tiny] us/query: top %.1f layout %.1f sample %.1f lookups %.1f rows %.1f tables %.1f last lookups %.1f hist+gather %.1f exact %.1f sums+sort %.1f out %.1f\n",
                                 hd[4] / 100.0 / nq, hd[5] / 100.0 / nq, hd[6] / 100.0 / nq, hd[7] / 100.0 / nq, hd[8] / 100.0 / nq, hd[9] / 100.0 / nq,
                                 hd[10] / 100.0 / nq, hd[11] / 100.0 / nq, hd[12] / 100.0 / nq, hd[13] / 100.0 / nq, hd[14] / 100.0 / nq);
-                        fprintf(stderr, "[tiny] half tables with a candidate: %.1f per query\n", (double)hd[15] / nq);
+                        fprintf(stderr, "[tiny] half tables with a candidate: %.1f per query; centroid loads %.1f us/query\n", (double)hd[15] / nq, hd[16] / 100.0 / nq);
                     }
                 }
             }
