@@ -979,4 +979,20 @@ def test_tiny_cells_prefilter_equals_exact_kernels(V, M, D, dup, monkeypatch):
             assert visited == got["visited"][qi]
             np.testing.assert_array_equal(np.asarray(ids, np.int64), got["ids"][qi][:len(ids)])
             np.testing.assert_allclose(got["dists"][qi][:len(ids)], np.asarray(dists), rtol=1e-9)
+    # two cell shards on this device: each rank's partial search takes the prefilter on ITS candidates (fewer than the quota,
+    # some queries with fewer than `limit`), the merged lists equal the single index's
+    from columbiaimagesearch_amd.lopq.search import merge_hits_dev
+    quota, limit = 9000, 100
+    want = s.search_batch_dev(q, quota=quota, limit=limit)
+    parts = []
+    for r in range(2):
+        sh = LOPQSearcherHIP(m, shard=(r, 2))
+        sh.add_codes_array(coarse, fine, ids=np.arange(n, dtype=np.int64), dedup=False)
+        h, v = sh.search_partial_dev(q, quota=quota, limit=limit)
+        np.testing.assert_array_equal(v.cpu().numpy(), want["visited"].cpu().numpy())
+        parts.append(h)
+        sh.close()
+    out = merge_hits_dev(torch.stack(parts).contiguous())
+    np.testing.assert_array_equal(out["ids"].cpu().numpy(), want["ids"].cpu().numpy())
+    np.testing.assert_array_equal(out["dists"].cpu().numpy().view(np.uint64), want["dists"].cpu().numpy().view(np.uint64))
     s.close()
