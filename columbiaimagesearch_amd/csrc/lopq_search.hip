@@ -3683,6 +3683,21 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
         for (int i = tid; i < MT * K * W; i += 1024) a = fmaxf(a, fabsf((float)subs[i]));
         atomicMax(&sh->cen_bits, __float_as_uint(a));
     }
+    // the thread's (sub-quantizer, centroid) of BOTH splits stays in registers over the persistent loop when that is 32 floats or fewer
+    // (M = 8, w = 16: the release shape; loading them per chunk cost 9 us of a 105 us query)
+    constexpr bool KEEP = PPT * W <= 16;
+    float cenk[2][KEEP ? PPT : 1][KEEP ? W : 1];
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int pp = 0; pp < PPT; ++pp) {
+                const int pr = tid + pp * 1024;
+                const double* sc = subs + ((size_t)(s2 * NF + (pr < PAIRS ? pr / K : 0)) * K + pr % K) * W;
+#pragma unroll
+                for (int e = 0; e < W; ++e) cenk[s2][pp][e] = (float)sc[e];
+            }
+    }
     for (int q = blockIdx.x; q < nq; q += gridDim.x) {
         const int64_t it0 = item_off[q];
         const int ni = (int)(item_off[q + 1] - it0);
@@ -3820,6 +3835,7 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
             // 3. byte tables of a split, at most tch at a time; every candidate adds its entries up.  An entry is
             //    sum (px - c)^2 in float32: the thread keeps its (sub-quantizer, centroid) in registers, the px row of a table
             //    arrives through scalar loads (uniform over the wave) from the float32 copy of px that k_tables_group wrote
+#pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int nts = sh->nused[s];            // tables of this split that have a candidate
                 const int64_t tb = tbase + (s ? nt0 : 0);
@@ -3835,9 +3851,14 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
                         if (pr < PAIRS) {
                             const int jj = __builtin_amdgcn_readfirstlane(pr / K), k = pr % K;  // a wave shares its sub-quantizer
                             float cen[W];
-                            const double* sc = subs + ((size_t)(s * NF + jj) * K + k) * W;
+                            if constexpr (KEEP) {
 #pragma unroll
-                            for (int e = 0; e < W; ++e) cen[e] = (float)sc[e];
+                                for (int e = 0; e < W; ++e) cen[e] = cenk[s][pp][e];
+                            } else {
+                                const double* sc = subs + ((size_t)(s * NF + jj) * K + k) * W;
+#pragma unroll
+                                for (int e = 0; e < W; ++e) cen[e] = (float)sc[e];
+                            }
                             if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TINY_T(12); }
                             const float* frow = px32 + tb * h + jj * W;
                             uint8_t* trow = s_tab + jj * K + k;
