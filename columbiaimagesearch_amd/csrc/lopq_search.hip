@@ -3539,17 +3539,19 @@ static bool use_all_path(const cis_index* ix, int M, int K, int L, int nq) {
 // few codes each, ~10 k candidates for the 100 it returns) -----------------------------------------------------------------
 // k_adc_direct computes the exact float64 distance of EVERY candidate (128 subtract-square-adds on operands gathered from LDS
 // and L2: 5.8 of the 11.4 ms of an 8192-query batch) and k_select_topl then reads all keys back.  Here one workgroup per query
-//   1. lays the query's candidates out (owner work item of every candidate, in LDS);
-//   2. estimates a cap on the limit-th best distance from 256 sampled candidates (their float64 distances);
+//   1. lays the query's candidates out in LDS (its work items, the owner item of every candidate, the half tables that have a
+//      candidate at all, numbered densely);
+//   2. estimates a cap on the limit-th best distance from 128 sampled candidates;
 //   3. builds the query's distance tables as BYTES in LDS -- entry = min(255, floor(e / step)), step = cap / 256, e computed in
-//      float32 from the projected residuals px (the operands of k_adc_direct) -- one split and at most `tch` tables at a time,
-//      and adds every candidate's table bytes up (a lower bound of its distance in steps: floor and min only round down);
+//      float32 from the projected residuals px (k_tables_group leaves a float32 copy; rows arrive through scalar loads) -- one
+//      split and at most `tch` tables at a time, and adds every candidate's table bytes up (a lower bound of its distance in
+//      steps: floor and min only round down);
 //   4. histograms the sums: s* = the smallest sum that `limit` candidates reach; a candidate whose sum is <= 254 has no clamped
 //      entry, so its distance is below (sum + M) steps, hence the limit-th best distance T < (s* + M) steps, and a candidate
 //      can only be among the best `limit` if sum <= s* + M (+ 1 bin for the float32 rounding of e, which the cap test below
 //      keeps under a sixteenth of a step per entry);
 //   5. computes the exact float64 keys of those survivors only -- the expression, operands and summation order of
-//      k_adc_direct, so the same bits -- ranks them by (key, retrieval position) in LDS and writes the best `limit` in the
+//      k_adc_direct, so the same bits -- ranks them by (key, retrieval position) by counting and writes the best `limit` in the
 //      format of k_select_topl<true>.
 // A query for which no bound comes out (fewer than `limit` candidates under the cap, survivors beyond the LDS list, more
 // candidates than the layout holds, a cap too small for float32) gets every candidate's exact key written to the global key
