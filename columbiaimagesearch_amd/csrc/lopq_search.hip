@@ -3642,6 +3642,16 @@ __device__ __forceinline__ void tiny_sload_rows(const float* const (&p)[TinyRows
     }
 }
 
+// Touch the first dword of four rows (no wait): the lines are in the scalar cache when tiny_sload_rows asks for them an iteration
+// later.  The destination registers stay reserved until then -- the loads land asynchronously -- by passing through tiny_keep.
+__device__ __forceinline__ void tiny_prefetch4(const float* p0, const float* p1, const float* p2, const float* p3, int (&pf)[4]) {
+    asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0"
+                 : "=&s"(pf[0]), "=&s"(pf[1]), "=&s"(pf[2]), "=&s"(pf[3]) : "s"(p0), "s"(p1), "s"(p2), "s"(p3) : "memory");
+}
+__device__ __forceinline__ void tiny_keep(int (&pf)[4]) {  // placed right after the next wait: until here the registers are taken
+    asm volatile("" : "+s"(pf[0]), "+s"(pf[1]), "+s"(pf[2]), "+s"(pf[3]));
+}
+
 struct TinyItem {       // a work item of the current query, staged in LDS
     uint32_t start;     // first candidate (position in codes/ids): the index holds fewer than 2^32 items, or the query is flagged
     uint16_t rel, len;  // first candidate inside the query's candidate range, candidates
@@ -3869,6 +3879,7 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
                             int cur[U];  // table numbers of the next U rows: read from LDS one iteration ahead (under the scalar loads' wait)
 #pragma unroll
                             for (int u = 0; u < U; ++u) cur[u] = __builtin_amdgcn_readfirstlane((int)lst[tlo + (u < tc ? u : tc - 1)]);
+                            int pf[4] = {0, 0, 0, 0};
                             for (int t = 0; t < tc; t += U) {
                                 const float* rp[U];
                                 int tu[U], nxt[U];
@@ -3880,8 +3891,10 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
                                 }
                                 float f[U][W];
                                 tiny_sload_rows<W>(rp, f);
+                                if constexpr (U == 4) tiny_keep(pf);
 #pragma unroll
                                 for (int u = 0; u < U; ++u) cur[u] = __builtin_amdgcn_readfirstlane(nxt[u]);
+                                if constexpr (U == 4) tiny_prefetch4(frow + cur[0] * h, frow + cur[1] * h, frow + cur[2] * h, frow + cur[3] * h, pf);
 #pragma unroll
                                 for (int u = 0; u < U; ++u) {
                                     tiny_f2 acc = {0.f, 0.f};  // packed float32 math: even and odd components apart
@@ -3895,6 +3908,7 @@ __global__ __launch_bounds__(1024) void k_tiny_select(const WorkItem* __restrict
                                     trow[tu[u] * NF * K] = (uint8_t)(int)fminf((acc.x + acc.y) * inv_step, 255.0f);
                                 }
                             }
+                            if constexpr (U == 4) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tiny_keep(pf); }
                         }
                     }
                     __syncthreads();
