@@ -942,7 +942,7 @@ def test_multisequence_plan_with_thousands_of_cells_and_tied_sums():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("V,M,D,dup", [(96, 8, 128, 0), (96, 4, 128, 0), (96, 16, 128, 0), (64, 8, 64, 0), (96, 16, 256, 0), (96, 8, 128, 5000)])
+@pytest.mark.parametrize("V,M,D,dup", [(96, 8, 128, 0), (96, 4, 128, 0), (96, 16, 128, 0), (64, 8, 64, 0), (64, 16, 64, 0), (64, 4, 64, 0), (96, 16, 256, 0), (96, 8, 256, 0), (96, 8, 128, 5000)])
 def test_tiny_cells_prefilter_equals_exact_kernels(V, M, D, dup, monkeypatch):
     """k_tiny_select (byte-table prefilter + exact keys of the survivors, one workgroup per query) against the exact kernels it
     replaces (k_adc_direct + k_select_topl, CIS_NO_TINY=1) and against the oracle: ids, float64 distance bits, counts, visited --
