@@ -10,28 +10,36 @@ already resident in HBM: PCA -> coarse ranking -> multisequence plan -> ADC tabl
 top-k -> merge (-> RCCL all-gather + merge when the index is sharded by coarse cell over N GPUs).
 Operating point of the reference API: quota=10000, limit=100 (cufacesearch/searcher/searcher_lopqhbase.py:833-838).
 
---config selects the BASELINE.json workload (default c4 = the one the metric is quoted on):
+--config selects the BASELINE.json workload of the HEADLINE line (default c4 = the one the metric is quoted on):
   c4  10M x 128-d float64, LOPQModelPCA V=16 M=8 renorm (model fitted by the reference: tests/golden/c4.npz);
       descriptor-like data (anisotropic mixture with a decaying spectrum, codes almost all distinct)
   c2  the same generator and model at 1M vectors (dlib-descriptor shape)
   c3  1M x 4096-d float32 >= 0 (post-ReLU-like), LOPQModelPCA 4096 -> 256, V=16 M=16 renorm (model fitted by the
       reference on this generator: tests/golden/c3full.npz)
+Without --config, at N = 1, the line also carries "configs": {"c2", "c3", "c5"} -- short runs of the other single-GPU
+BASELINE configurations (their own ms/step, scan roofline, parity flag against the oracle) and the C5 chain at its true
+shapes (DeepSentibank batch 256 -> L2 normalise -> PCA 4096 -> 256, V=16 M=16 encode -> insert into the resident c3 index).
 
-N > 1 is strong scaling by default: the same index is sharded by coarse cell, every rank sees the whole
-query batch, scans its own cells and the per-shard top-`limit` lists are all-gathered over RCCL
-(--scaling weak: every rank brings its own --n vectors, the index grows with N).
+N > 1: the HEADLINE is BASELINE config C4's layout -- the same 10M index sharded by coarse cell over all N GPUs (S = N cell
+shards, one query group), every rank sees the whole query batch, scans its own cells, the per-shard top-`limit` lists are
+all-gathered over RCCL and merged: "scaling": "strong" (--scaling weak: every rank brings its own --n vectors).  A second
+object "grid" in the same line carries the R x S layout (R query groups, each one copy of the index sharded over S GPUs;
+--cell-shards, default 2 from 4 GPUs on, whole copies at 2): its value counts every group's queries (weak in the query load).
 
 Extra objects in the JSON line: "roofline" for the ADC scan kernel (algorithmic bytes = candidates x M, time from
-HIP events recorded on the launch stream inside the library); "cpu_baseline" = the oracle (numpy restatement of the
+HIP events recorded on the launch stream inside the library; `frac` is SURVEY.md 8(d)'s accounting and can exceed 1 -- see
+`binding` for what the kernel is bound by); "cpu_baseline" = the oracle (numpy restatement of the
 reference) timed on this host on bounded samples of the same workload, rank 0 at N=1 only: `value` is the
 reference-shaped per-candidate loop on 1 core, the other fields are the all-core vectorised search, encode
 (1 core loop / all cores) and the torch-CPU DeepSentibank forward (batch 1 x cores, batch 256); "cnn" / "dlib" =
 the descriptor networks (MFMA roofline); "pcie_inclusive" = the same step through the host-pointer entry point.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -46,6 +54,7 @@ QUOTA, LIMIT = 10000, 100
 N_CHUNKS = 80      # the database is generated in 80 equal chunks with per-chunk seeds
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 F32_MFMA_PEAK_TFLOPS = 157.3
+SENTIBANK_MAC, DLIB_MAC = 720310816, 270854144  # multiply-accumulates per image / face (oracle/cnn_oracle.py, oracle/dlib_oracle.py)
 
 CONFIGS = {
     "c4": {"n": 10_000_000, "fixture": "c4", "gen": "descriptor", "d_in": 128, "label": "C4"},
@@ -123,63 +132,105 @@ def exact_nn(queries, centers_dev, n_total, chunk_n, device, pca=None):
     return arg
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default=os.environ.get("CIS_BENCH_CONFIG", "c4"))
-    ap.add_argument("--n", type=int, default=int(os.environ.get("CIS_BENCH_N", 0)), help="index vectors (default: the config's)")
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
-                    help="of the INDEX size with --gpus (weak: n vectors per GPU); the query load always grows with the query groups")
-    ap.add_argument("--cell-shards", type=int, default=int(os.environ.get("CIS_BENCH_CELL_SHARDS", 0)),
-                    help="S of the R x S grid (R = gpus / S query groups, each one copy of the index sharded by cell over S "
-                         "GPUs).  Default: 2 when --gpus is even, --gpus otherwise; S = gpus is the pure cell-sharded layout")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-cnn", action="store_true")
-    ap.add_argument("--no-pcie", action="store_true", help="skip the host-pointer leg (profiling runs)")
-    args = ap.parse_args()
-    cfg = CONFIGS[args.config]
-    if args.n <= 0:
-        args.n = cfg["n"]
+# ---- a phase that hangs (a collective whose peer never arrives) must say which one it was -------------------------------------
+class Watchdog(object):
+    """`with wd.phase("all-gather of the packed hits", 120): ...` -- a phase that outlives its allowance prints its name on
+    stderr and ends the process (exit code 3) instead of hanging the node until the driver's limit."""
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if os.environ.get("CIS_BENCH_ONE_DEVICE") == "1":
-        local_rank = 0  # functional test of the N > 1 protocol on a 1-GPU box (with CIS_BENCH_BACKEND=gloo: RCCL refuses shared devices)
-    backend = os.environ.get("CIS_BENCH_BACKEND", "nccl")
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    from columbiaimagesearch_amd import _lib
+    def __init__(self, rank):
+        self.rank = rank
+        self._lock = threading.Lock()
+        self._name, self._deadline = None, None
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def _run(self):
+        while True:
+            time.sleep(1.0)
+            with self._lock:
+                name, dl = self._name, self._deadline
+            if name is not None and time.monotonic() > dl:
+                sys.stderr.write("[bench rank %d] phase '%s' did not finish within its allowance -- a rank is missing from a "
+                                 "collective or a kernel hangs; giving up\n" % (self.rank, name))
+                sys.stderr.flush()
+                os._exit(3)
+
+    @contextlib.contextmanager
+    def phase(self, name, seconds):
+        with self._lock:
+            prev = (self._name, self._deadline)
+            self._name, self._deadline = name, time.monotonic() + seconds
+        try:
+            yield
+        finally:
+            with self._lock:
+                self._name, self._deadline = prev
+
+
+class Ctx(object):
+    pass
+
+
+def scan_binding(cfg_name, scan_name, cand, cand_items, M, scan_s, launches):
+    """What binds the scan kernel.  `model`: the share of the launch time that each resource's MINIMUM accounts for (conflict-free
+    LDS, the bare gather-and-add loop) -- a lower bound per resource.  `measured`: the SQ counters of the same kernel on the same
+    workload from this round's rocprofv3 --pmc passes (profiles/scan_binding_<config>.json, made by tools/scan_binding.py: VALU
+    busy, LDS busy incl. bank conflicts) -- PMC counters need their own passes and cannot be read inside a timed run."""
+    G = {"k_adc_scan2": 2, "k_adc_scan3": 4, "k_adc_scan4": 4}.get(scan_name, 1)
+    K = 256
+    pairs_rows = cand / float(G) / 64.0                 # wave-rows: 64 candidates x G queries
+    moved = cand * M / float(G) + cand_items * M * K * 4 + cand_items * LIMIT * 8   # codes once per workgroup + float32 tables staged + survivors
+    lds_cycles = pairs_rows * M * 2.0                   # one ds_read_b64 per sub-quantizer and row, 2 LDS cycles when conflict-free
+    valu_instr = pairs_rows * ((2 * M + 4) if G == 2 else (3 * M + 4))  # address + packed add(s) per sub-quantizer, unpack + compare
+    clk, n_cu = 2.4e9, 256
+    t_lds = lds_cycles / (n_cu * clk)
+    t_valu = valu_instr * 4.0 / (4 * n_cu * clk)        # a wave64 VALU instruction occupies its SIMD for 4 cycles
+    t_mem = moved / (HBM_PEAK_GBS * 1e9)
+    fr = (lambda t: t / scan_s) if scan_s > 0 else (lambda t: None)
+    model = {"unit": "fraction of the launch time each resource's minimum accounts for (1.0 = bound by it)",
+             "hbm_moved_bytes": {"bytes_per_launch": moved / launches, "frac": fr(t_mem),
+                                 "note": "cand*M/G + float32 tables staged + survivors, against 8 TB/s (mostly L2 / Infinity Cache hits)"},
+             "lds_gather": {"wave_reads_per_launch": pairs_rows * M / launches, "frac": fr(t_lds),
+                            "note": "CONFLICT-FREE model: ds_read_b64 per (row of 64 candidates x G queries, sub-quantizer), 2 cycles each, 256 CUs at 2.4 GHz"},
+             "valu_issue": {"wave_instr_per_launch": valu_instr / launches, "frac": fr(t_valu),
+                            "note": "minimal gather-and-add loop only (no selection / append), 4 cycles per wave64 instruction, 1024 SIMDs"}}
+    out = {"queries_per_workgroup": G, "model": model, "measured": None}
+    p = os.path.join(REPO, "profiles", "scan_binding_%s.json" % cfg_name)
+    if os.path.exists(p):
+        try:
+            out["measured"] = json.load(open(p))
+            out["measured"]["source_file"] = "profiles/scan_binding_%s.json" % cfg_name
+        except Exception as e:
+            out["measured"] = {"error": repr(e)}
+    fracs = {k: model[k]["frac"] or 0.0 for k in ("hbm_moved_bytes", "lds_gather", "valu_issue")}
+    if out["measured"] and "valu_busy_frac" in out["measured"]:
+        fracs = {"valu_issue": out["measured"]["valu_busy_frac"], "lds_gather": out["measured"].get("lds_busy_frac", 0.0),
+                 "hbm_moved_bytes": out["measured"].get("hbm_frac", fracs["hbm_moved_bytes"])}
+        out["binds_source"] = "measured"
+    else:
+        out["binds_source"] = "model"
+    out["binds"] = max(fracs, key=lambda k: fracs[k] or 0.0)
+    return out
+
+
+def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows):
+    """Build the index of one configuration (encode on the GPUs, device-side insert, R x S layout with S cell shards) and time
+    `steps` query batches.  Returns (result dict (rank 0's view), state for the follow-up legs)."""
+    import torch.distributed as dist
     from columbiaimagesearch_amd.distributed import GridSearcher, greedy_cell_owner
     from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
-    _lib.check(_lib.lib().cis_set_device(local_rank))
-    # CIS_BENCH_FORCE_DIST=1 runs the sharded code path (process group, all-gather, merge) even with one
-    # rank -- a smoke test of the N > 1 path on a 1-GPU box
-    use_dist = world > 1 or os.environ.get("CIS_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        import torch.distributed as dist
-        if "RANK" not in os.environ:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group(backend, rank=0, world_size=1, device_id=device if backend == "nccl" else None)
-        else:
-            dist.init_process_group(backend, device_id=device if backend == "nccl" else None)  # nccl == RCCL on ROCm
-
+    cfg = CONFIGS[cfg_name]
+    device, rank, world, wd = ctx.device, ctx.rank, ctx.world, ctx.wd
     model, z = load_model(cfg["fixture"])
-    N = args.n * (world if args.scaling == "weak" else 1)
+    N = n_vectors * (world if scaling == "weak" else 1)
     N -= N % (N_CHUNKS * world)
     chunk_n = N // N_CHUNKS
     centers = mixture_centers(cfg["gen"], device)
+    st = Ctx()
+    st.cfg_name, st.cfg, st.model, st.z, st.N, st.chunk_n, st.centers = cfg_name, cfg, model, z, N, chunk_n, centers
 
-    # ---- build: data-parallel encode on the GPUs, codes all-gathered, index sharded by cell -----
+    # ---- build: data-parallel encode on the GPUs, codes routed to the owners of their cells -----
     t_build = time.time()
-    S = args.cell_shards if args.cell_shards > 0 else (2 if world % 2 == 0 else world)
-    if world % S:
-        raise SystemExit("--cell-shards %d does not divide --gpus %d" % (S, world))
     R = world // S                      # query groups
     g_q, s_c = rank // S, rank % S      # this rank: cell shard s_c of query group g_q
     my_slice = s_c * R + g_q            # GridSearcher.slice_number: keeps the cells in the order of a single index
@@ -187,40 +238,41 @@ def main():
     coarse_l, fine_l, ev = [], [], []
     # encode parity at full size: rows sampled from EVERY chunk are kept (host copies) and their codes are checked against
     # the oracle's compute_codes after the timed region (the oracle index of the search spot check is built from HIP codes)
-    n_sample = max(4096 // N_CHUNKS + 1, 1)
+    n_sample = max(oracle_rows // N_CHUNKS + 1, 1) if oracle_rows else 0
     sample_x, sample_pos = [], []
     # the generator's chunks are encoded in groups of about 65536 vectors, the library's own pass size (one call per 12500-row
     # chunk of the 1M configurations leaves the chip half empty: c2 75 -> ~150 M, c3 8.7 -> ~10 M vectors/s)
     group = max(1, 65536 // chunk_n)
-    for g0 in range(0, len(my_chunks), group):
-        xs = []
-        for c in my_chunks[g0:g0 + group]:
-            x = gen_chunk(centers, c, chunk_n, device)
-            xs.append(x)
-            if rank == 0 and world == 1 and not args.no_cpu_baseline:
-                sel = torch.as_tensor(np.random.RandomState(4242 + c).choice(chunk_n, n_sample, replace=False), device=device)
-                sample_x.append(x[sel].cpu().numpy())
-                sample_pos.append(sel.cpu().numpy() + (c - my_chunks[0]) * chunk_n)
-        x = xs[0] if len(xs) == 1 else torch.cat(xs)
-        del xs
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()  # predict_batch_dev launches on torch's current stream: these events bracket the encode kernels only
-        co, fi = model.predict_batch_dev(x)
-        e1.record()
-        ev.append((e0, e1))
-        coarse_l.append(co)
-        fine_l.append(fi)
-        del x
-    coarse = torch.cat(coarse_l)
-    fine = torch.cat(fine_l)
-    del coarse_l, fine_l
-    torch.cuda.synchronize()
+    with wd.phase("%s: encode of the index build" % cfg_name, 600):
+        for g0 in range(0, len(my_chunks), group):
+            xs = []
+            for c in my_chunks[g0:g0 + group]:
+                x = gen_chunk(centers, c, chunk_n, device)
+                xs.append(x)
+                if n_sample:
+                    sel = torch.as_tensor(np.random.RandomState(4242 + c).choice(chunk_n, n_sample, replace=False), device=device)
+                    sample_x.append(x[sel].cpu().numpy())
+                    sample_pos.append(sel.cpu().numpy() + (c - my_chunks[0]) * chunk_n)
+            x = xs[0] if len(xs) == 1 else torch.cat(xs)
+            del xs
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()  # predict_batch_dev launches on torch's current stream: these events bracket the encode kernels only
+            co, fi = model.predict_batch_dev(x)
+            e1.record()
+            ev.append((e0, e1))
+            coarse_l.append(co)
+            fine_l.append(fi)
+            del x
+        coarse = torch.cat(coarse_l)
+        fine = torch.cat(fine_l)
+        del coarse_l, fine_l
+        torch.cuda.synchronize()
     encode_s = sum(a.elapsed_time(b) for a, b in ev) / 1e3  # without the synthetic data generation
     V = model.V
     # this rank encoded chunks [first, first + len(my_chunks)): ids are positions in the whole database
     ids_dev = torch.arange(my_chunks[0] * chunk_n, (my_chunks[-1] + 1) * chunk_n, dtype=torch.int64, device=device)
     t_ins = time.perf_counter()
-    if use_dist:
+    if ctx.use_dist:
         # R x S grid (distributed.GridSearcher): R query groups, each holding one copy of the index sharded by cell over S ranks.
         # cells -> shards by greedy balance of the cell populations: the table must be identical on every rank, so the
         # per-cell counts are summed over the ranks first (V*V int64); then every code travels once per copy, to its owner --
@@ -229,99 +281,114 @@ def main():
         cell = coarse[:, 0].to(torch.int64).bitwise_and_(0xFFFF) * V + coarse[:, 1].to(torch.int64).bitwise_and_(0xFFFF)
         ct_all = torch.bincount(cell, minlength=V * V)
         del cell
-        if backend != "nccl":
+        if ctx.backend != "nccl":
             ct_all = ct_all.cpu()
-        dist.all_reduce(ct_all)
-        sharded = GridSearcher(model, S, owner=greedy_cell_owner(ct_all.cpu().numpy(), S) if S > 1 else None)
+        with wd.phase("%s: all-reduce of the per-cell counts (V*V int64)" % cfg_name, 180):
+            dist.all_reduce(ct_all)
+        with wd.phase("%s: process groups of the %d x %d grid (dist.new_group)" % (cfg_name, R, S), 180):
+            sharded = GridSearcher(model, S, owner=greedy_cell_owner(ct_all.cpu().numpy(), S) if S > 1 else None)
         assert sharded.slice_number == my_slice
         searcher = sharded.local
-        sharded.add_codes_dev(coarse, fine, ids_dev, dedup=False)  # column all-gather, then routed inside the query group
+        with wd.phase("%s: routed insert (column all-gather + all-to-all of the code records)" % cfg_name, 300):
+            sharded.add_codes_dev(coarse, fine, ids_dev, dedup=False)  # column all-gather, then routed inside the query group
+            torch.cuda.synchronize()
     else:
         sharded = None
         searcher = LOPQSearcherHIP(model)
         searcher.add_codes_dev(coarse, fine, ids_dev, dedup=False)  # device-side merge (csrc/lopq_index.hip)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     insert_s = time.perf_counter() - t_ins
-    coarse_h = fine_h = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # host copies only for the oracle legs
-        coarse_h = coarse.cpu().numpy().view(np.uint16)
-        fine_h = fine.cpu().numpy()
+    st.coarse_h = st.fine_h = None
+    if oracle_rows:  # host copies only for the oracle legs
+        st.coarse_h = coarse.cpu().numpy().view(np.uint16)
+        st.fine_h = fine.cpu().numpy()
     del coarse, fine, ids_dev
     build_s = time.time() - t_build
+    st.sample_x, st.sample_pos, st.searcher, st.sharded = sample_x, sample_pos, searcher, sharded
 
     # ---- queries (resident in HBM before the timed region) --------------------------------------
     x0 = gen_chunk(centers, 0, chunk_n, device)
-    n_batches = args.warmup + args.steps
+    n_batches = warmup + steps
     qbatches = [make_queries(x0, b, NQ, device) for b in range(min(n_batches, 8))]
+    del x0
+    st.qbatches = qbatches
 
     def step(q):
         if sharded is None:
             return searcher.search_batch_dev(q, quota=QUOTA, limit=LIMIT)
         return sharded.search_batch_dev(q, quota=QUOTA, limit=LIMIT)  # partial scan -> RCCL all-gather -> merge
+    st.step = step
 
     def qb(b):  # a step = one batch of NQ queries PER QUERY GROUP: group g answers its own batches, the S ranks of a group the same
         return qbatches[(b * R + g_q) % len(qbatches)]
 
-    for b in range(args.warmup):
-        step(qb(b))
+    with wd.phase("%s: warm-up steps (first collectives of the search path)" % cfg_name, 300):
+        for b in range(warmup):
+            step(qb(b))
+        torch.cuda.synchronize()
     # timed region: only the pair of HIP events around the scan kernel (roofline); the per-stage events are small bubbles
     # between kernels, so the stage breakdown is taken from a few extra steps after the timed region
     searcher.set_profiling(True, scan_only=True)
     searcher.read_profile()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    cand = 0
-    cand_items = 0
-    out = None
-    if sharded is None:
-        for b in range(args.steps):
-            out = step(qb(args.warmup + b))
+    with wd.phase("%s: timed steps" % cfg_name, 600):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cand = 0
+        cand_items = 0
+        if sharded is None:
+            for b in range(steps):
+                step(qb(warmup + b))
+                cand += searcher.last_stats()["candidates"]
+                cand_items += searcher.last_stats()["items"]
+        else:
+            # steps are independent batches: the exchange + merge of batch b (side stream, RCCL) overlap the partial search
+            # of batch b+1 (compute stream)
+            h = sharded.search_begin(qb(warmup), quota=QUOTA, limit=LIMIT)
             cand += searcher.last_stats()["candidates"]
             cand_items += searcher.last_stats()["items"]
+            for b in range(1, steps):
+                h2 = sharded.search_begin(qb(warmup + b), quota=QUOTA, limit=LIMIT)
+                cand += searcher.last_stats()["candidates"]
+                cand_items += searcher.last_stats()["items"]
+                sharded.search_end(h)
+                h = h2
+            sharded.search_end(h)
         scan_name = searcher.last_stats()["scan_kernel"]
-    else:
-        # steps are independent batches: the exchange + merge of batch b (side stream, RCCL) overlap the partial search
-        # of batch b+1 (compute stream)
-        h = sharded.search_begin(qb(args.warmup), quota=QUOTA, limit=LIMIT)
-        cand += searcher.last_stats()["candidates"]
-        cand_items += searcher.last_stats()["items"]
-        for b in range(1, args.steps):
-            h2 = sharded.search_begin(qb(args.warmup + b), quota=QUOTA, limit=LIMIT)
-            cand += searcher.last_stats()["candidates"]
-            cand_items += searcher.last_stats()["items"]
-            out = sharded.search_end(h)
-            h = h2
-        out = sharded.search_end(h)
-        scan_name = searcher.last_stats()["scan_kernel"]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
     prof = searcher.read_profile()
     searcher.set_profiling(True)
-    n_stage = min(args.steps, 5)
-    for b in range(n_stage):
-        step(qb(b))
-    torch.cuda.synchronize()
+    n_stage = min(steps, 5)
+    with wd.phase("%s: stage-profile steps" % cfg_name, 300):
+        for b in range(n_stage):
+            step(qb(b))
+        torch.cuda.synchronize()
     stage_prof = searcher.read_profile()
     searcher.set_profiling(False)
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        ct = torch.tensor([cand], device=device, dtype=torch.int64)
-        dist.all_reduce(ct)
-        cand_all = int(ct.item())
+        with wd.phase("%s: all-reduce of the step time / candidate counts" % cfg_name, 120):
+            tdev = device if ctx.backend == "nccl" else "cpu"
+            tt = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+            ct = torch.tensor([cand], device=tdev, dtype=torch.int64)
+            dist.all_reduce(ct)
+            cand_all = int(ct.item())
     else:
         cand_all = cand
 
     # ---- recall@10 (lopq/lopq/eval.py:92-143 semantics), untimed, rank 0 -----------------------
     recall10 = None
     qr = qbatches[0][:1024].contiguous()
-    res = step(qr)
+    with wd.phase("%s: recall batch" % cfg_name, 300):
+        res = step(qr)
+        torch.cuda.synchronize()
+    st.qr, st.res = qr, res
     if rank == 0:
         pca = None
         if cfg["gen"] == "relu_mixture":  # the 4096 -> 256 PCA changes the metric: neighbours are defined after it
@@ -330,164 +397,236 @@ def main():
         nn = exact_nn(qr, centers, N, chunk_n, device, pca)
         recall10 = float((res["ids"][:, :10] == nn[:, None]).any(dim=1).float().mean().item())
 
-    # ---- the same step through the host-pointer entry point (PCIe in and out), untimed for `value` ----------
-    pcie = None
-    if rank == 0 and world == 1 and not args.no_pcie:
-        qh_all = qbatches[0].cpu().numpy()
-        searcher.search_batch(qh_all, quota=QUOTA, limit=LIMIT)
-        tp = time.perf_counter()
-        reps = 5
+    M = model.M
+    launches = max(prof["scan_launches"], 1)
+    scan_s = prof["scan_kernel_ms"] / 1e3  # HIP events right around the scan kernel launches, on their stream
+    algo_bytes = cand * M  # this rank's scan kernel, SURVEY.md 8(d): every (candidate, query) pair counts M code bytes
+    achieved = algo_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+    # SURVEY.md 8(d)'s accounting re-counts a code for every query although the G queries of a workgroup share one load and the
+    # index streams through L2 / Infinity Cache: `frac` = achieved / peak as the contract defines it, it can exceed 1 and is not a
+    # physical bound; `binding` says what the kernel runs against and `traffic` what really moved (PMC, from profiles/)
+    traffic, traffic_note = None, "PMC passes are separate rocprofv3 runs: none committed for this config"
+    tp = os.path.join(REPO, "profiles", "scan_traffic_%s.json" % cfg_name)
+    if os.path.exists(tp):
+        try:
+            traffic = float(json.load(open(tp))["hbm_bytes_per_launch"])
+            traffic_note = "from profiles/scan_traffic_%s.json (separate rocprofv3 --pmc passes of the same command, gfx950 corrections applied), per full launch" % cfg_name
+        except Exception as e:
+            traffic_note = "profiles/scan_traffic_%s.json unreadable: %r" % (cfg_name, e)
+    Dm, hm = model.dim, model.dim // 2
+    # encode: SURVEY.md 8(d)'s algorithmic flop per vector -- 2 D_in D (PCA) + 3 V D (coarse) + 4 h^2 (rotation) + 3 K D (fine) --
+    # against the float64 peak (AMD's MI355X figure, 78.6 TFLOP/s vector = matrix; the arithmetic that decides a code is
+    # float64 / numpy-ordered, the fine and large-V coarse stages prefilter on the float32 matrix cores and re-check exactly)
+    enc_flop = 2.0 * cfg["d_in"] * Dm + 3.0 * model.V * Dm + 4.0 * hm * hm + 3.0 * 256 * Dm
+    enc_rate = len(my_chunks) * chunk_n / encode_s
+    result = {
+        "value": R * NQ * steps / elapsed,
+        "unit": "queries/s",
+        "ms_per_step": elapsed / steps * 1e3,
+        "steps": steps,
+        "recall_at_10": recall10,
+        "config": {"workload": "%s: %d x %d-d %s unit vectors (%s), LOPQModelPCA %d -> %d V=%d M=%d renorm (fitted by the "
+                               "reference, tests/golden/%s.npz), %d queries/step, quota=%d limit=%d"
+                               % (cfg["label"], N, cfg["d_in"], "float32 >= 0" if cfg["gen"] == "relu_mixture" else "float64",
+                                  "post-ReLU-like 64-component mixture" if cfg["gen"] == "relu_mixture" else "descriptor-like anisotropic mixture",
+                                  cfg["d_in"], model.dim, model.V, M, cfg["fixture"], NQ, QUOTA, LIMIT),
+                   "name": cfg_name, "index_vectors": N, "queries_per_step": NQ, "quota": QUOTA, "limit": LIMIT,
+                   "sharding": "%d query group(s) x %d cell shard(s): each group holds the whole index sharded by coarse cell over %d GPU(s)%s "
+                               "and answers its own %d queries per step" % (R, S, S, ", RCCL all-gather merge inside the group" if S > 1 else "", NQ),
+                   "parallelism": "grid %dx%d" % (R, S), "query_groups": R, "cell_shards": S, "queries_per_step_all_groups": R * NQ,
+                   "index_scaling": scaling, "query_load_scaling": "weak (x%d query groups)" % R if R > 1 else "fixed",
+                   "candidates_per_query": cand_all / float(R * NQ * steps)},
+        "roofline": {"bound": "hbm", "kernel": scan_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "accounting_frac": achieved / HBM_PEAK_GBS,
+                     "frac_note": "SURVEY.md 8(d) accounting (every (candidate, query) pair = M bytes) over the HIP-event time of the scan "
+                                  "launches; > 1 means the accounting is not a physical bound (codes are shared by the queries of a workgroup "
+                                  "and served from L2 / Infinity Cache): see `binding` and `traffic`",
+                     "traffic": traffic, "traffic_note": traffic_note,
+                     "algorithmic_bytes_per_launch": algo_bytes / launches,
+                     "avg_launch_ms": prof["scan_kernel_ms"] / launches, "launches": launches,
+                     "binding": scan_binding(cfg_name, scan_name, cand, cand_items, M, scan_s, launches)},
+        "stage_ms_per_step": {k: stage_prof[k] / n_stage for k in ("front_ms", "tables_ms", "scan_ms", "merge_ms", "scan_kernel_ms")},
+        "encode": {"value": enc_rate, "unit": "vectors/s", "vectors": len(my_chunks) * chunk_n,
+                   "note": "cis_encode_dev on this rank's share of the index build, HIP events around the encode calls",
+                   "roofline": {"bound": "mfma", "achieved": enc_rate * enc_flop / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                                "frac": enc_rate * enc_flop / 78.6e12, "flop_per_vector": enc_flop, "dtype": "f64"}},
+        "build": {"encode_s": encode_s, "insert_s": insert_s, "total_s": build_s,
+                  "insert": "device-side merge of %d codes into the HBM index (cis_index_add_dev%s)"
+                            % (len(my_chunks) * chunk_n, " after the RCCL all-to-all" if ctx.use_dist else "")},
+    }
+    st.R = R
+    return result, st
+
+
+def oracle_parity(st, t_loop_budget, n_loop_max, t_vec_budget, n_vec_max):
+    """Parity spot check of the timed workload against the oracle (numpy restatement of the reference, pinned to golden vectors):
+    the sampled rows' codes and the first queries' ranked ids / distances.  Also times the oracle (cpu_baseline).  Rank 0, N = 1."""
+    from oracle import lopq_oracle as O
+    om = O.OracleModel.from_npz(st.z)
+    sx = np.concatenate(st.sample_x)
+    sp = np.concatenate(st.sample_pos)
+    oc, of = O.compute_codes(om, sx)
+    enc_ok = bool((oc == st.coarse_h[sp]).all() and (of == st.fine_h[sp]).all())
+    oix = O.OracleCSRIndex(om, st.coarse_h, st.fine_h)
+    qh = st.qr.cpu().numpy()
+    gi, gd = st.res["ids"].cpu().numpy(), st.res["dists"].cpu().numpy()
+    n_loop, t_loop, ok, max_rel = 0, 0.0, True, 0.0
+    while t_loop < t_loop_budget and n_loop < n_loop_max:
+        tq = time.perf_counter()
+        ids, dd, _ = oix.search_loop(qh[n_loop], quota=QUOTA, limit=LIMIT)
+        t_loop += time.perf_counter() - tq
+        ok = ok and bool((gi[n_loop, :len(ids)] == ids).all())
+        max_rel = max(max_rel, float(np.max(np.abs(gd[n_loop, :len(ids)] - dd) / np.maximum(dd, 1e-300))))
+        n_loop += 1
+    n_vec, t_vec = 0, 0.0
+    while t_vec < t_vec_budget and n_vec < n_vec_max:
+        tq = time.perf_counter()
+        ids, dd, _ = oix.search(qh[n_vec], quota=QUOTA, limit=LIMIT)
+        t_vec += time.perf_counter() - tq
+        ok = ok and bool((gi[n_vec, :len(ids)] == ids).all())
+        max_rel = max(max_rel, float(np.max(np.abs(gd[n_vec, :len(ids)] - dd) / np.maximum(dd, 1e-300)))) if len(ids) else max_rel
+        n_vec += 1
+    parity = {"queries_checked": max(n_loop, n_vec), "ids_bit_exact": ok, "max_rel_dist_err": max_rel,
+              "encode_rows_checked": int(sp.shape[0]), "encode_rows_from_chunks": N_CHUNKS, "encode_codes_bit_exact": enc_ok}
+    return parity, dict(om=om, oix=oix, qh=qh, n_loop=n_loop, t_loop=t_loop, n_vec=n_vec, t_vec=t_vec)
+
+
+def cpu_baseline_leg(ctx, st, orc, with_cnn):
+    """The oracle timed on this host's cores on bounded samples of the headline workload."""
+    import shutil
+    import tempfile
+    from oracle import cpu_bench
+    from oracle import lopq_oracle as O
+    om, oix, qh = orc["om"], orc["oix"], orc["qh"]
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    from columbiaimagesearch_amd.extractor.preprocess_pool import cpu_allowance
+    allowance = cpu_allowance()  # the container's cgroup CPU time (16 cores on the GPU boxes seen so far, of 256 visible)
+    # encode, reference-shaped per-vector loop (lopq/lopq/utils.py:203-218), 1 core
+    enc_x = gen_chunk(st.centers, 1, 8192, ctx.device).cpu().numpy()
+    n_el, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 4.0 and n_el < len(enc_x):
+        O.compute_codes_loop(om, enc_x[n_el:n_el + 16])
+        n_el += 16
+    enc_loop = n_el / (time.perf_counter() - t0)
+    # all cores: one single-threaded worker per core (the reference deploys N single-threaded processes)
+    workdir = tempfile.mkdtemp(prefix="cis_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        cpu_bench.export_index(workdir, oix, qh, os.path.join(REPO, "tests", "golden", st.cfg["fixture"] + ".npz"), enc_x)
+        srch_all, n_sa, _ = cpu_bench.run_pool("search", workdir, 6.0, cores)
+        enc_all, n_ea, _ = cpu_bench.run_pool("encode", workdir, 4.0, cores)
+        cnn1_all, n_c1, _ = (None, 0, 0) if not with_cnn else cpu_bench.run_pool("cnn1", workdir, 5.0, cores)
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+    cnn256 = None
+    if with_cnn:
+        from oracle import cnn_oracle as C
+        wts = C.synthetic_weights(0)
+        xi = C.synthetic_images(256, seed=2)
+        torch.set_num_threads(cores)
+        C.forward_torch(xi[:32], wts)
+        t0 = time.perf_counter()
+        C.forward_torch(xi, wts)
+        cnn256 = 256 / (time.perf_counter() - t0)
+    cpu = {"value": orc["n_loop"] / orc["t_loop"], "unit": "queries/s", "cores": 1, "kind": "port",
+           "sample": "%d queries of the timed workload (quota=%d, limit=%d, %d-vector index) through the oracle's "
+                     "reference-shaped per-candidate loop (search.py:166-175)" % (orc["n_loop"], QUOTA, LIMIT, st.N),
+           "search_vectorised_1core_qps": orc["n_vec"] / orc["t_vec"],
+           "search_vectorised_allcore_qps": srch_all, "allcore_workers": cores, "cgroup_cpu_allowance_cores": allowance,
+           "encode_loop_1core_vps": enc_loop, "encode_vectorised_allcore_vps": enc_all,
+           "cnn_torch_cpu_batch1_x_cores_ips": cnn1_all, "cnn_torch_cpu_batch256_ips": cnn256,
+           "samples": "vectorised search: %d queries on 1 core, %d queries over %d single-threaded workers (6 s); encode: %d "
+                      "vectors per-vector loop on 1 core, %d vectors over the workers (4 s); DeepSentibank torch-CPU: %d "
+                      "images batch 1 over the workers (5 s), one batch of 256 on %d threads"
+                      % (orc["n_vec"], n_sa, cores, n_el, n_ea, n_c1, cores)}
+    # SURVEY.md 8(d): the loop restatement against the reference's own wall time on C1 (the reference ran in the build
+    # container when the fixture was made: tests/golden/c1.npz:ref_encode_vec_per_s; this host is a different machine, so the
+    # ratio is a note, not the +-20 % validation -- that one is `tools/validate_loop_restatement.py`, run in the build container)
+    try:
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        import golden_inputs as gi
+        z1 = np.load(os.path.join(REPO, "tests", "golden", "c1.npz"))
+        om1 = O.OracleModel.from_npz(z1)
+        x1 = gi.c1_inputs()[0][:4096]
+        if "ref_encode_vec_per_s" in z1:
+            n1, t1s = 0, time.perf_counter()
+            while time.perf_counter() - t1s < 3.0 and n1 < len(x1):
+                O.compute_codes_loop(om1, x1[n1:n1 + 64])
+                n1 += 64
+            loop1 = n1 / (time.perf_counter() - t1s)
+            cpu["c1_encode_loop_vps_this_host"] = loop1
+            cpu["c1_encode_reference_vps_build_container"] = float(z1["ref_encode_vec_per_s"])
+            cpu["c1_loop_over_reference"] = loop1 / float(z1["ref_encode_vec_per_s"])
+            vp = os.path.join(REPO, "profiles", "loop_restatement_validation.json")
+            if os.path.exists(vp):
+                cpu["c1_like_for_like"] = json.load(open(vp))
+    except Exception as e:  # a timing note must never cost the bench line
+        cpu["c1_loop_over_reference_error"] = repr(e)
+    return cpu
+
+
+def pcie_leg(st):
+    """The same step through the host-pointer entry point (PCIe in and out), never `value`."""
+    qh_all = st.qbatches[0].cpu().numpy()
+    st.searcher.search_batch(qh_all, quota=QUOTA, limit=LIMIT)
+    tp = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        st.searcher.search_batch(qh_all, quota=QUOTA, limit=LIMIT)
+    dtp = (time.perf_counter() - tp) / reps
+    return {"value": NQ / dtp, "unit": "queries/s", "ms_per_step": dtp * 1e3,
+            "note": "cis_index_search: host query matrix in, host ids/dists/counts out, pageable memory"}
+
+
+def cnn_legs(ctx):
+    """Second half of the BASELINE metric: CNN descriptors/s (batch 256, synthetic weights).  Every rank runs the forward on its own
+    GPU (replicas: weights replicated, no collective); the legs are bracketed by a barrier, the time is the
+    slowest rank's and the value the whole job's."""
+    import torch.distributed as dist
+    from columbiaimagesearch_amd.featurizer.synthetic import dlib_weights, sentibank_weights  # seeded (trained weights are not in the tree)
+    from columbiaimagesearch_amd.featurizer import DLibFaceNet, SentiBankNet
+    device, world = ctx.device, ctx.world
+    torch.cuda.empty_cache()
+    B = 256
+    gcn = torch.Generator(device=device)
+    gcn.manual_seed(5)
+
+    def time_net(net, xb, ob, reps=8):
+        for _ in range(2):
+            net.forward_dev(xb, ob)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tc = time.perf_counter()
         for _ in range(reps):
-            searcher.search_batch(qh_all, quota=QUOTA, limit=LIMIT)
-        dtp = (time.perf_counter() - tp) / reps
-        pcie = {"value": NQ / dtp, "unit": "queries/s", "ms_per_step": dtp * 1e3,
-                "note": "cis_index_search: host query matrix in, host ids/dists/counts out, pageable memory"}
+            net.forward_dev(xb, ob)
+        torch.cuda.synchronize()
+        dt_ = (time.perf_counter() - tc) / reps
+        if world > 1:
+            tt_ = torch.tensor([dt_], device=device if ctx.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            dt_ = float(tt_.item())
+        return dt_
 
-    # ---- CPU baseline + parity spot check: oracle on bounded samples (rank 0, N=1) ----------------
-    cpu = None
-    parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import shutil
-        import tempfile
-        from oracle import cpu_bench
-        from oracle import lopq_oracle as O
-        om = O.OracleModel.from_npz(z)
-        # encode parity at full size: the sampled rows of every chunk through the oracle's compute_codes
-        sx = np.concatenate(sample_x)
-        sp = np.concatenate(sample_pos)
-        oc, of = O.compute_codes(om, sx)
-        enc_ok = bool((oc == coarse_h[sp]).all() and (of == fine_h[sp]).all())
-        enc_checked = int(sp.shape[0])
-        del sample_x
-        oix = O.OracleCSRIndex(om, coarse_h, fine_h)
-        qh = qr.cpu().numpy()
-        gi, gd = res["ids"].cpu().numpy(), res["dists"].cpu().numpy()
-        n_loop, t_loop, ok, max_rel = 0, 0.0, True, 0.0
-        while t_loop < 10.0 and n_loop < 256:
-            tq = time.perf_counter()
-            ids, dd, _ = oix.search_loop(qh[n_loop], quota=QUOTA, limit=LIMIT)
-            t_loop += time.perf_counter() - tq
-            ok = ok and bool((gi[n_loop, :len(ids)] == ids).all())
-            max_rel = max(max_rel, float(np.max(np.abs(gd[n_loop, :len(ids)] - dd) / np.maximum(dd, 1e-300))))
-            n_loop += 1
-        n_vec, t_vec = 0, 0.0
-        while t_vec < 4.0 and n_vec < 1024:
-            tq = time.perf_counter()
-            ids, dd, _ = oix.search(qh[n_vec], quota=QUOTA, limit=LIMIT)
-            t_vec += time.perf_counter() - tq
-            ok = ok and bool((gi[n_vec, :len(ids)] == ids).all())
-            n_vec += 1
-        cores = max(1, min(len(os.sched_getaffinity(0)), 64))
-        from columbiaimagesearch_amd.extractor.preprocess_pool import cpu_allowance
-        allowance = cpu_allowance()  # the container's cgroup CPU time (16 cores on the GPU boxes seen so far, of 256 visible)
-        # encode, reference-shaped per-vector loop (lopq/lopq/utils.py:203-218), 1 core
-        enc_x = gen_chunk(centers, 1, 8192, device).cpu().numpy()
-        n_el, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 4.0 and n_el < len(enc_x):
-            O.compute_codes_loop(om, enc_x[n_el:n_el + 16])
-            n_el += 16
-        enc_loop = n_el / (time.perf_counter() - t0)
-        # all cores: one single-threaded worker per core (the reference deploys N single-threaded processes)
-        workdir = tempfile.mkdtemp(prefix="cis_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-        try:
-            cpu_bench.export_index(workdir, oix, qh, os.path.join(REPO, "tests", "golden", cfg["fixture"] + ".npz"), enc_x)
-            srch_all, n_sa, _ = cpu_bench.run_pool("search", workdir, 6.0, cores)
-            enc_all, n_ea, _ = cpu_bench.run_pool("encode", workdir, 4.0, cores)
-            cnn1_all, n_c1, _ = (None, 0, 0) if args.no_cnn else cpu_bench.run_pool("cnn1", workdir, 5.0, cores)
-        finally:
-            shutil.rmtree(workdir, ignore_errors=True)
-        cnn256 = None
-        if not args.no_cnn:
-            from oracle import cnn_oracle as C
-            wts = C.synthetic_weights(0)
-            xi = C.synthetic_images(256, seed=2)
-            torch.set_num_threads(cores)
-            C.forward_torch(xi[:32], wts)
-            t0 = time.perf_counter()
-            C.forward_torch(xi, wts)
-            cnn256 = 256 / (time.perf_counter() - t0)
-        cpu = {"value": n_loop / t_loop, "unit": "queries/s", "cores": 1, "kind": "port",
-               "sample": "%d queries of the timed workload (quota=%d, limit=%d, %d-vector index) through the oracle's "
-                         "reference-shaped per-candidate loop (search.py:166-175)" % (n_loop, QUOTA, LIMIT, N),
-               "search_vectorised_1core_qps": n_vec / t_vec,
-               "search_vectorised_allcore_qps": srch_all, "allcore_workers": cores, "cgroup_cpu_allowance_cores": allowance,
-               "encode_loop_1core_vps": enc_loop, "encode_vectorised_allcore_vps": enc_all,
-               "cnn_torch_cpu_batch1_x_cores_ips": cnn1_all, "cnn_torch_cpu_batch256_ips": cnn256,
-               "samples": "vectorised search: %d queries on 1 core, %d queries over %d single-threaded workers (6 s); encode: %d "
-                          "vectors per-vector loop on 1 core, %d vectors over the workers (4 s); DeepSentibank torch-CPU: %d "
-                          "images batch 1 over the workers (5 s), one batch of 256 on %d threads"
-                          % (n_vec, n_sa, cores, n_el, n_ea, n_c1, cores)}
-        parity = {"queries_checked": max(n_loop, n_vec), "ids_bit_exact": ok, "max_rel_dist_err": max_rel,
-                  "encode_rows_checked": enc_checked, "encode_rows_from_chunks": N_CHUNKS, "encode_codes_bit_exact": enc_ok}
-        # the loop restatement against the reference's own wall time on C1 (the reference ran in the build
-        # container when the fixture was made: tests/golden/c1.npz:ref_encode_vec_per_s; this host is a different machine)
-        try:
-            sys.path.insert(0, os.path.join(REPO, "tests"))
-            import golden_inputs as gi
-            z1 = np.load(os.path.join(REPO, "tests", "golden", "c1.npz"))
-            om1 = O.OracleModel.from_npz(z1)
-            x1 = gi.c1_inputs()[0][:4096]
-            if "ref_encode_vec_per_s" in z1:
-                n1, t1s = 0, time.perf_counter()
-                while time.perf_counter() - t1s < 3.0 and n1 < len(x1):
-                    O.compute_codes_loop(om1, x1[n1:n1 + 64])
-                    n1 += 64
-                loop1 = n1 / (time.perf_counter() - t1s)
-                cpu["c1_encode_loop_vps_this_host"] = loop1
-                cpu["c1_encode_reference_vps_build_container"] = float(z1["ref_encode_vec_per_s"])
-                cpu["c1_loop_over_reference"] = loop1 / float(z1["ref_encode_vec_per_s"])
-        except Exception as e:  # a timing note must never cost the bench line
-            cpu["c1_loop_over_reference_error"] = repr(e)
+    def roof(mac, b, dt):
+        flop = 2.0 * mac * b
+        return {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": flop / dt / (F32_MFMA_PEAK_TFLOPS * 1e12), "flop_per_image": 2 * mac}
 
-    # ---- second half of the BASELINE metric: CNN descriptors/s (batch 256, synthetic weights) ------------
-    cnn = None
-    dlib = None
-    if not args.no_cnn:
-        # every rank runs the forward on its own GPU (replicas: weights replicated, no collective); the legs are
-        # bracketed by a barrier, the time is the slowest rank's and the value the whole job's
-        from columbiaimagesearch_amd.featurizer.synthetic import dlib_weights, sentibank_weights  # seeded (trained weights are not in the tree)
-        from columbiaimagesearch_amd.featurizer import DLibFaceNet, SentiBankNet
-        del x0
-        torch.cuda.empty_cache()
-        B = 256
-        gcn = torch.Generator(device=device)
-        gcn.manual_seed(5)
-
-        def time_net(net, xb, ob, reps=8):
-            for _ in range(2):
-                net.forward_dev(xb, ob)
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            tc = time.perf_counter()
-            for _ in range(reps):
-                net.forward_dev(xb, ob)
-            torch.cuda.synchronize()
-            dt_ = (time.perf_counter() - tc) / reps
-            if world > 1:
-                tt_ = torch.tensor([dt_], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
-                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
-                dt_ = float(tt_.item())
-            return dt_
-
+    with ctx.wd.phase("CNN legs (replicas, barrier + all-reduce of the time)", 600):
         net = SentiBankNet(sentibank_weights(0))
         xb = (torch.randn((B, 3, 227, 227), generator=gcn, device=device) * 50.0).contiguous()
         dt = time_net(net, xb, torch.empty((B, 4096), device=device))
-        flop = 2.0 * 720310816 * B
         cnn = {"metric": "CNN descriptors/sec (DeepSentibank forward to fc7, batch 256 per GPU, synthetic weights)",
-               "value": world * B / dt, "unit": "descriptors/s", "n_gpus": world, "parallelism": "replicas, no collective", "ms_per_batch": dt * 1e3, "dtype": "f32",
-               "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": flop / dt / (F32_MFMA_PEAK_TFLOPS * 1e12), "flop_per_image": 2 * 720310816}}
+               "value": world * B / dt, "unit": "descriptors/s", "n_gpus": world, "parallelism": "replicas, no collective",
+               "ms_per_batch": dt * 1e3, "dtype": "f32", "roofline": roof(SENTIBANK_MAC, B, dt)}
         net.close()
         del xb
         net = DLibFaceNet(dlib_weights(0))
         xb = (torch.rand((B, 150, 150, 3), generator=gcn, device=device) * 255).contiguous()
         dt = time_net(net, xb, torch.empty((B, 128), device=device))
-        flop = 2.0 * 270854144 * B  # multiply-accumulates per face: oracle/dlib_oracle.py:mac_per_face
         dlib = {"metric": "CNN descriptors/sec (dlib face ResNet forward, batch 256 aligned chips per GPU, synthetic weights)",
-                "value": world * B / dt, "unit": "descriptors/s", "n_gpus": world, "parallelism": "replicas, no collective", "ms_per_batch": dt * 1e3, "dtype": "f32",
-                "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": flop / dt / (F32_MFMA_PEAK_TFLOPS * 1e12), "flop_per_image": 2 * 270854144}}
+                "value": world * B / dt, "unit": "descriptors/s", "n_gpus": world, "parallelism": "replicas, no collective",
+                "ms_per_batch": dt * 1e3, "dtype": "f32", "roofline": roof(DLIB_MAC, B, dt)}
         # the same forward at 1024 chips per call: a launch of the 256-chip batch lasts 60-80 us, of which the ramp and the tail
         # of the workgroup rounds are a fifth (DESIGN.md 7) -- reported next to the BASELINE batch, not instead of it
         del xb
@@ -495,139 +634,241 @@ def main():
         xb = (torch.rand((B4, 150, 150, 3), generator=gcn, device=device) * 255).contiguous()
         dt4 = time_net(net, xb, torch.empty((B4, 128), device=device), reps=4)
         dlib["batch_1024"] = {"value": world * B4 / dt4, "unit": "descriptors/s", "ms_per_batch": dt4 * 1e3,
-                              "frac": 2.0 * 270854144 * B4 / dt4 / (F32_MFMA_PEAK_TFLOPS * 1e12)}
+                              "frac": 2.0 * DLIB_MAC * B4 / dt4 / (F32_MFMA_PEAK_TFLOPS * 1e12)}
         net.close()
+        del xb
+    torch.cuda.empty_cache()
+    return cnn, dlib
 
-    # ---- BASELINE config C5 leg: batched CNN extract (batch 256) -> L2 normalise -> LOPQ encode -> insert into the resident index ----
+
+def ingest_leg(ctx, st, net_kind, n_ing=12):
+    """BASELINE config C5 chain: batched CNN extract (batch 256) -> L2 normalise -> LOPQ encode -> insert with dedup into the
+    resident index of `st`.  net_kind "sentibank" (4096-d float32 -> the PCA model: C5's true shapes) or "dlib" (128-d)."""
+    from columbiaimagesearch_amd.featurizer.synthetic import dlib_weights, sentibank_weights
+    from columbiaimagesearch_amd.featurizer import DLibFaceNet, SentiBankNet
+    from columbiaimagesearch_amd.ingest import BatchIngest
+    device, searcher = ctx.device, st.searcher
+    torch.cuda.empty_cache()
+    B = 256
+    g5 = torch.Generator(device=device)
+    g5.manual_seed(55)
+    if net_kind == "sentibank":
+        net5, net_name, mac = SentiBankNet(sentibank_weights(0)), "DeepSentibank fc7 (4096-d float32)", SENTIBANK_MAC
+        xb5 = (torch.randn((B, 3, 227, 227), generator=g5, device=device) * 50.0).contiguous()
+        fdt = None
+    else:
+        net5, net_name, mac = DLibFaceNet(dlib_weights(0)), "dlib face ResNet (128-d, cast to float64 like the reference's descriptors)", DLIB_MAC
+        xb5 = (torch.rand((B, 150, 150, 3), generator=g5, device=device) * 255).contiguous()
+        fdt = torch.float64
+    ing = BatchIngest(net5, st.model, searcher, feat_dtype=fdt)
+    n_before = searcher.get_nb_indexed()
+    ing.nb_ingested = 1 << 40  # fresh ids above every stored one: the dedup lookup is answered by the per-cell maximum
+    for _ in range(2):
+        ing.ingest_batch(xb5)
+    torch.cuda.synchronize()
+    t5 = time.perf_counter()
+    for _ in range(n_ing):
+        ing.ingest_batch(xb5)   # forward -> normalise -> encode -> device-side merge incl. refreshed cell statistics
+    torch.cuda.synchronize()
+    dt5 = (time.perf_counter() - t5) / n_ing
+    t5 = time.perf_counter()
+    for _ in range(n_ing):
+        ing.encode_batch_dev(xb5)
+    torch.cuda.synchronize()
+    de5 = (time.perf_counter() - t5) / n_ing
+    # ids BELOW the stored maximum: the dedup lookup really walks / probes the cell (ADVICE r3: the best case alone is not the figure)
+    ing.nb_ingested = st.N // 2 + 1
+    t5 = time.perf_counter()
+    n_low = 4
+    for _ in range(n_low):
+        ing.ingest_batch(xb5)
+    torch.cuda.synchronize()
+    dl5 = (time.perf_counter() - t5) / n_low
+    r5 = searcher.search_batch_dev(st.qbatches[0][:64].contiguous(), quota=QUOTA, limit=LIMIT)  # the grown index still answers
+    torch.cuda.synchronize()
+    flop = 2.0 * mac * B
+    out = {"metric": "descriptors/s end to end: CNN forward (batch 256) -> L2 normalise -> LOPQ encode -> insert with dedup into the "
+                     "resident index (BASELINE config C5 chain)",
+           "value": B / dt5, "unit": "descriptors/s", "ms_per_batch": dt5 * 1e3, "net": net_name,
+           "model": "LOPQModelPCA %d -> %d V=%d M=%d" % (st.cfg["d_in"], st.model.dim, st.model.V, st.model.M),
+           "extract_encode_ms": de5 * 1e3, "insert_ms": (dt5 - de5) * 1e3,
+           "insert_ms_ids_below_cell_maximum": (dl5 - de5) * 1e3,
+           "resident_items_before": int(n_before), "resident_items_after": int(searcher.get_nb_indexed()), "batches": n_ing,
+           "insert": "cis_index_add_dev: device-side insert, no host copy of codes",
+           "searched_after": int((r5["n_found"] > 0).sum().item()),
+           "roofline": {"bound": "mfma", "achieved": flop / dt5 / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flop / dt5 / (F32_MFMA_PEAK_TFLOPS * 1e12),
+                        "note": "CNN forward flop over the time of the WHOLE chain (forward + normalise + encode + insert)"}}
+    net5.close()
+    del xb5
+    torch.cuda.empty_cache()
+    return out
+
+
+def release_state(st):
+    try:
+        st.searcher.close()
+    except Exception:
+        pass
+    for k in list(vars(st)):
+        setattr(st, k, None)
+    torch.cuda.empty_cache()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=os.environ.get("CIS_BENCH_CONFIG") or None,
+                    help="headline workload (default c4 + short c2 / c3 / c5 sub-runs under `configs`)")
+    ap.add_argument("--n", type=int, default=int(os.environ.get("CIS_BENCH_N", 0)), help="index vectors (default: the config's)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="of the INDEX size with --gpus (weak: n vectors per GPU)")
+    ap.add_argument("--cell-shards", type=int, default=int(os.environ.get("CIS_BENCH_CELL_SHARDS", 0)),
+                    help="S of the second (`grid`) layout at N > 1: R = gpus / S query groups, each one copy of the index sharded by "
+                         "cell over S GPUs.  Default: 2 from 4 GPUs on, 1 (whole copies) at 2.  The headline is always S = gpus")
+    ap.add_argument("--no-grid", action="store_true", help="N > 1: skip the second layout")
+    ap.add_argument("--no-configs", action="store_true", help="skip the c2 / c3 / c5 sub-runs of the default line")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cnn", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-pointer leg (profiling runs)")
+    args = ap.parse_args()
+    explicit_config = args.config is not None
+    cfg_name = args.config or "c4"
+    cfg = CONFIGS[cfg_name]
+    if args.n <= 0:
+        args.n = cfg["n"]
+
+    ctx = Ctx()
+    rank = ctx.rank = int(os.environ.get("RANK", 0))
+    world = ctx.world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if os.environ.get("CIS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0  # functional test of the N > 1 protocol on a 1-GPU box (with CIS_BENCH_BACKEND=gloo: RCCL refuses shared devices)
+    backend = ctx.backend = os.environ.get("CIS_BENCH_BACKEND", "nccl")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = ctx.device = torch.device("cuda", local_rank)
+    wd = ctx.wd = Watchdog(rank)
+    from columbiaimagesearch_amd import _lib
+    _lib.check(_lib.lib().cis_set_device(local_rank))
+    # CIS_BENCH_FORCE_DIST=1 runs the sharded code path (process group, all-gather, merge) even with one
+    # rank -- a smoke test of the N > 1 path on a 1-GPU box
+    ctx.use_dist = world > 1 or os.environ.get("CIS_BENCH_FORCE_DIST") == "1"
+    if ctx.use_dist:
+        import datetime
+        import torch.distributed as dist
+        with wd.phase("init_process_group (%s, world %d)" % (backend, world), 300):
+            kw = dict(timeout=datetime.timedelta(seconds=300))
+            if "RANK" not in os.environ:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29533")
+                dist.init_process_group(backend, rank=0, world_size=1, device_id=device if backend == "nccl" else None, **kw)
+            else:
+                dist.init_process_group(backend, device_id=device if backend == "nccl" else None, **kw)  # nccl == RCCL on ROCm
+
+    solo = rank == 0 and world == 1
+    want_oracle = solo and not args.no_cpu_baseline
+    # ---- headline: BASELINE C4's layout -- ONE copy of the index sharded by coarse cell over all N GPUs ---------------------------
+    head, st = search_leg(ctx, cfg_name, args.n, world, args.steps, args.warmup, args.scaling, 4096 if want_oracle else 0)
+
+    pcie = pcie_leg(st) if solo and not args.no_pcie else None
+    cpu = parity = None
+    if want_oracle:
+        parity, orc = oracle_parity(st, 10.0, 256, 4.0, 1024)
+        cpu = cpu_baseline_leg(ctx, st, orc, not args.no_cnn)
+        del orc
     ingest = None
-    if not args.no_cnn and sharded is None:
-        from columbiaimagesearch_amd.featurizer.synthetic import dlib_weights, sentibank_weights
-        from columbiaimagesearch_amd.featurizer import DLibFaceNet, SentiBankNet
-        from columbiaimagesearch_amd.ingest import BatchIngest, l2_normalize_dev
-        torch.cuda.empty_cache()
-        B = 256
-        g5 = torch.Generator(device=device)
-        g5.manual_seed(55)
-        if cfg["d_in"] == 4096:
-            net5, net_name = SentiBankNet(sentibank_weights(0)), "DeepSentibank fc7 (4096-d float32)"
-            xb5 = (torch.randn((B, 3, 227, 227), generator=g5, device=device) * 50.0).contiguous()
-            fdt = None
-        else:
-            net5, net_name = DLibFaceNet(dlib_weights(0)), "dlib face ResNet (128-d, cast to float64 like the reference's descriptors)"
-            xb5 = (torch.rand((B, 150, 150, 3), generator=g5, device=device) * 255).contiguous()
-            fdt = torch.float64
-        ing = BatchIngest(net5, model, searcher, feat_dtype=fdt)
-        n_before = searcher.get_nb_indexed()
-        ing.nb_ingested = 1 << 40  # fresh ids: nothing is a duplicate of the resident items
-        n_ing = 12
-        for _ in range(2):
-            ing.ingest_batch(xb5)
-        torch.cuda.synchronize()
-        t5 = time.perf_counter()
-        for _ in range(n_ing):
-            ing.ingest_batch(xb5)   # forward -> normalise -> encode -> device-side merge incl. refreshed cell statistics
-        torch.cuda.synchronize()
-        dt5 = (time.perf_counter() - t5) / n_ing
-        t5 = time.perf_counter()
-        for _ in range(n_ing):
-            ing.encode_batch_dev(xb5)
-        torch.cuda.synchronize()
-        de5 = (time.perf_counter() - t5) / n_ing
-        r5 = searcher.search_batch_dev(qbatches[0][:64].contiguous(), quota=QUOTA, limit=LIMIT)  # the grown index still answers
-        torch.cuda.synchronize()
-        ingest = {"metric": "descriptors/s end to end: CNN forward (batch 256) -> L2 normalise -> LOPQ encode -> insert with dedup into the "
-                            "resident index (BASELINE config C5 chain on this config's model)",
-                  "value": B / dt5, "unit": "descriptors/s", "ms_per_batch": dt5 * 1e3, "net": net_name,
-                  "extract_encode_ms": de5 * 1e3, "insert_ms": (dt5 - de5) * 1e3, "resident_items_before": int(n_before),
-                  "resident_items_after": int(searcher.get_nb_indexed()), "batches": n_ing,
-                  "insert": "cis_index_add_dev: device-side stable merge, one read + one write of the index per batch; no host copy of codes",
-                  "searched_after": int((r5["n_found"] > 0).sum().item())}
-        net5.close()
-        del xb5
+    if not args.no_cnn and st.sharded is None:
+        ingest = ingest_leg(ctx, st, "sentibank" if cfg["d_in"] == 4096 else "dlib")
+        if cfg["d_in"] != 4096:
+            ingest["note"] = "dlib 128-d descriptors on this config's model; C5 at its true shapes (DeepSentibank 4096-d -> PCA 256, M=16) is configs.c5"
+    release_state(st)
+
+    # ---- N > 1: the R x S grid as a second object (never the headline) -----------------------------------------------------------
+    grid = None
+    if world > 1 and not args.no_grid:
+        S2 = args.cell_shards if args.cell_shards > 0 else (2 if world >= 4 and world % 2 == 0 else 1)
+        if world % S2 == 0 and S2 != world:
+            try:
+                g, gst = search_leg(ctx, cfg_name, args.n, S2, args.steps, args.warmup, args.scaling, 0)
+                grid = {"metric": "queries/sec over R query groups x S cell shards (every group holds one whole copy of the index and "
+                                  "answers its own 8192 queries per step: the query load grows with R)",
+                        "value": g["value"], "unit": "queries/s", "ms_per_step": g["ms_per_step"], "scaling": "weak",
+                        "recall_at_10": g["recall_at_10"], "config": g["config"], "roofline": g["roofline"],
+                        "stage_ms_per_step": g["stage_ms_per_step"]}
+                release_state(gst)
+            except Exception as e:  # e.g. dist.new_group unavailable: the headline (S = N) stands on its own
+                grid = {"error": repr(e), "layout": "%d x %d" % (world // S2, S2)}
+                sys.stderr.write("[bench rank %d] grid layout failed: %r\n" % (rank, e))
+
+    # ---- the other single-GPU BASELINE configurations, short (default line only) -------------------------------------------------
+    configs = None
+    if solo and not explicit_config and not args.no_configs:
+        configs = {}
+        sub_steps = max(5, min(args.steps, 10))
+        for name in ("c2", "c3"):
+            try:
+                r, sst = search_leg(ctx, name, CONFIGS[name]["n"], 1, sub_steps, 2, "strong", 1024 if want_oracle else 0)
+                sub = {"value": r["value"], "unit": "queries/s", "ms_per_step": r["ms_per_step"], "steps": sub_steps,
+                       "recall_at_10": r["recall_at_10"], "config": r["config"], "roofline": r["roofline"],
+                       "stage_ms_per_step": r["stage_ms_per_step"], "encode": r["encode"]}
+                if want_oracle:
+                    p, _ = oracle_parity(sst, 2.0, 8, 3.0, 64)
+                    sub["parity"] = p
+                    sub["parity_green"] = bool(p["ids_bit_exact"] and p["encode_codes_bit_exact"] and p["max_rel_dist_err"] < 1e-9)
+                configs[name] = sub
+                if name == "c3" and not args.no_cnn:
+                    c5 = ingest_leg(ctx, sst, "sentibank", n_ing=8)
+                    c5["config"] = {"workload": "C5 chain at its true shapes on one GPU: 256 x 3 x 227 x 227 float32 batches (randn * 50), seeded "
+                                                "synthetic DeepSentibank weights -> fc7 4096-d -> L2 normalise -> LOPQModelPCA 4096 -> 256 V=16 M=16 "
+                                                "(tests/golden/c3full.npz) -> insert with dedup into the resident %d-vector c3 index" % sst.N}
+                    configs["c5"] = c5
+                release_state(sst)
+            except Exception as e:  # a sub-run must never cost the headline line
+                configs[name] = {"error": repr(e)}
+                sys.stderr.write("[bench] sub-config %s failed: %r\n" % (name, e))
+                torch.cuda.empty_cache()
+
+    cnn = dlib = None
+    if not args.no_cnn:
+        cnn, dlib = cnn_legs(ctx)
 
     if rank == 0:
-        M = model.M
-        launches = max(prof["scan_launches"], 1)
-        scan_s = prof["scan_kernel_ms"] / 1e3  # HIP events right around the scan kernel launches, on their stream
-        algo_bytes = cand * M  # this rank's scan kernel, SURVEY.md 8(d): every (candidate, query) pair counts M code bytes
-        achieved = algo_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
-        # What binds the kernel: the accounting above re-counts a code for every query although the G queries
-        # of a workgroup share one load and the index streams through L2 / Infinity Cache -- it can exceed the HBM peak (C3),
-        # so `frac` is capped at 1 and the bounds the kernel really runs against are reported next to it, from the same
-        # launch time: bytes its memory instructions move, LDS table-gather cycles, VALU issue slots of its minimal loop.
-        G = {"k_adc_scan2": 2, "k_adc_scan3": 4}.get(scan_name, 1)
-        K = 256
-        pairs_rows = cand / float(G) / 64.0                 # wave-rows: 64 candidates x G queries
-        items = cand_items
-        moved = cand * M / float(G) + items * M * K * 4 + items * LIMIT * 8   # codes once per workgroup + float32 tables staged + survivors
-        lds_cycles = pairs_rows * M * 2.0                   # one ds_read_b64 per sub-quantizer and row, 2 LDS cycles when conflict-free
-        valu_instr = pairs_rows * ((2 * M + 4) if G == 2 else (3 * M + 4))  # address + packed add(s) per sub-quantizer, unpack + compare
-        clk, n_cu = 2.4e9, 256
-        t_lds = lds_cycles / (n_cu * clk)
-        t_valu = valu_instr * 4.0 / (4 * n_cu * clk)        # a wave64 VALU instruction occupies its SIMD for 4 cycles
-        t_mem = moved / (HBM_PEAK_GBS * 1e9)
-        binding = {"unit": "fraction of the launch time each resource's minimum accounts for (1.0 = bound by it)",
-                   "hbm_moved_bytes": {"bytes_per_launch": moved / launches, "frac": t_mem / scan_s if scan_s > 0 else None,
-                                       "note": "cand*M/G + float32 tables staged + survivors, against 8 TB/s (mostly L2 / Infinity Cache hits)"},
-                   "lds_gather": {"wave_reads_per_launch": pairs_rows * M / launches, "frac": t_lds / scan_s if scan_s > 0 else None,
-                                  "note": "ds_read_b64 per (row of 64 candidates x G queries, sub-quantizer), 2 cycles each, 256 CUs at 2.4 GHz"},
-                   "valu_issue": {"wave_instr_per_launch": valu_instr / launches, "frac": t_valu / scan_s if scan_s > 0 else None,
-                                  "note": "minimal gather-and-add loop only (no selection / append), 4 cycles per wave64 instruction, 1024 SIMDs"},
-                   "queries_per_workgroup": G}
-        # encode: SURVEY.md 8(d)'s algorithmic flop per vector -- 2 D_in D (PCA) + 3 V D (coarse) + 4 h^2 (rotation) + 3 K D (fine) --
-        # against the float64 peak (AMD's MI355X figure, 78.6 TFLOP/s vector = matrix; the arithmetic that decides a code is
-        # float64 / numpy-ordered, the fine and large-V coarse stages prefilter on the float32 matrix cores and re-check exactly)
-        Dm, hm = model.dim, model.dim // 2
-        enc_flop = 2.0 * cfg["d_in"] * Dm + 3.0 * model.V * Dm + 4.0 * hm * hm + 3.0 * 256 * Dm
-        enc_rate = len(my_chunks) * chunk_n / encode_s
-        encode_roofline = {"bound": "mfma", "achieved": enc_rate * enc_flop / 1e12, "peak": 78.6, "unit": "TFLOP/s",
-                           "frac": enc_rate * enc_flop / 78.6e12, "flop_per_vector": enc_flop, "dtype": "f64"}
-        binding["binds"] = max(("hbm_moved_bytes", "lds_gather", "valu_issue"), key=lambda k: binding[k]["frac"] or 0.0)
         line = {
             "metric": "queries/sec @ recall@10 on 10M LOPQ index",
-            "value": R * NQ * args.steps / elapsed,
+            "value": head["value"],
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "recall_at_10": recall10,
-            "config": {"workload": "%s: %d x %d-d %s unit vectors (%s), LOPQModelPCA %d -> %d V=%d M=%d renorm (fitted by the "
-                                   "reference, tests/golden/%s.npz), %d queries/step, quota=%d limit=%d"
-                                   % (cfg["label"], N, cfg["d_in"], "float32 >= 0" if cfg["gen"] == "relu_mixture" else "float64",
-                                      "post-ReLU-like 64-component mixture" if cfg["gen"] == "relu_mixture" else "descriptor-like anisotropic mixture",
-                                      cfg["d_in"], model.dim, model.V, M, cfg["fixture"], NQ, QUOTA, LIMIT),
-                       "name": args.config, "index_vectors": N, "queries_per_step": NQ, "quota": QUOTA, "limit": LIMIT,
-                       "sharding": "%d query group(s) x %d cell shard(s): each group holds the whole index sharded by coarse cell over %d GPU(s)%s "
-                                   "and answers its own %d queries per step" % (R, S, S, ", RCCL all-gather merge inside the group" if S > 1 else "", NQ),
-                       "parallelism": "grid %dx%d" % (R, S), "query_groups": R, "cell_shards": S, "queries_per_step_all_groups": R * NQ,
-                       "index_scaling": args.scaling,
-                       "candidates_per_query": cand_all / float(R * NQ * args.steps)},
-            "roofline": {"bound": "hbm", "kernel": scan_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": min(achieved / HBM_PEAK_GBS, 1.0), "accounting_frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "traffic_note": "PMC passes are separate rocprofv3 runs: profiles/scan_traffic_%s.json" % args.config,
-                         "algorithmic_bytes_per_launch": algo_bytes / launches,
-                         "avg_launch_ms": prof["scan_kernel_ms"] / launches, "launches": launches, "binding": binding},
-            "stage_ms_per_step": {k: stage_prof[k] / n_stage for k in ("front_ms", "tables_ms", "scan_ms", "merge_ms", "scan_kernel_ms")},
-            "encode": {"value": len(my_chunks) * chunk_n / encode_s, "unit": "vectors/s", "vectors": len(my_chunks) * chunk_n,
-                       "note": "cis_encode_dev on this rank's share of the index build, HIP events around the encode calls",
-                       "roofline": encode_roofline},
+            "recall_at_10": head["recall_at_10"],
+            "config": head["config"],
+            "roofline": head["roofline"],
+            "stage_ms_per_step": head["stage_ms_per_step"],
+            "encode": head["encode"],
             "pcie_inclusive": pcie,
             "cnn": cnn,
             "dlib": dlib,
             "cpu_baseline": cpu,
             "parity": parity,
             "ingest": ingest,
-            "build": {"encode_s": encode_s, "insert_s": insert_s, "total_s": build_s,
-                      "insert": "device-side merge of %d codes into the HBM index (cis_index_add_dev%s)" % (len(my_chunks) * chunk_n, " after the RCCL all-to-all" if use_dist else "")},
+            "build": head["build"],
+            "grid": grid,
+            "configs": configs,
         }
-    if use_dist:
-        dist.barrier()
+    if ctx.use_dist:
+        import torch.distributed as dist
+        with wd.phase("final barrier", 120):
+            dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         # the JSON line is the last thing on stdout: flush what native libraries (the RCCL banner) still hold in C stdio first

@@ -4561,7 +4561,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                                    slots, n_slots, qstart);
             }
             CIS_TRY(mark(5));
-            ix->last_scan_kernel = use3 ? 3 : 2;
+            ix->last_scan_kernel = use3 ? (geom3.two_pass == 2 ? 4 : 3) : 2;  // 4: the sampled single-pass form k_adc_scan4 does the work (k_adc_scan3 only its fall-back slots)
             if (use3)
                 launch_scan3(M, geom3, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, ix->w_slack.as<float>(), qbound, fhdr, fslots);
             else

@@ -29,7 +29,8 @@ def l2_normalize_dev(feats):
 
 class BatchIngest(object):
     """net: SentiBankNet / DLibFaceNet (forward_dev), model: LOPQModel[PCA] (predict_batch_dev),
-    searcher: LOPQSearcherHIP or ShardedSearcher (add_codes_array)."""
+    searcher: LOPQSearcherHIP, ShardedSearcher / GridSearcher (device insert) or any searcher with add_codes_array
+    (LOPQSearcherLMDB: host key / value store)."""
 
     def __init__(self, net, model, searcher, feat_dtype=None):
         self.net, self.model, self.searcher = net, model, searcher
@@ -50,13 +51,36 @@ class BatchIngest(object):
         import torch
         coarse, fine = self.encode_batch_dev(x)
         n = int(coarse.shape[0])
+        s = self.searcher
+        if not (hasattr(s, "add_codes_routed_dev") or hasattr(s, "add_codes_dev")):
+            # a searcher without a device entry point (LOPQSearcherLMDB keeps its key / value store on the host): the codes go
+            # through add_codes_array with the caller's ids as they are (any hashable, like the reference's add_codes)
+            if ids is None:
+                ids = np.arange(self.nb_ingested, self.nb_ingested + n, dtype=np.int64)
+            elif hasattr(ids, "is_cuda"):
+                ids = ids.cpu().numpy()
+            before = s.get_nb_indexed()
+            s.add_codes_array(coarse.cpu().numpy().view(np.uint16), fine.cpu().numpy(), ids)
+            self.nb_ingested += n
+            return int(s.get_nb_indexed() - before)
         if ids is None:
             ids = torch.arange(self.nb_ingested, self.nb_ingested + n, dtype=torch.int64, device=coarse.device)
         elif not hasattr(ids, "is_cuda"):
-            ids = torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int64)).to(coarse.device)
-        if hasattr(self.searcher, "add_codes_routed_dev"):
-            added = self.searcher.add_codes_routed_dev(coarse, fine, ids)
+            try:
+                ids_h = np.ascontiguousarray(ids, dtype=np.int64)
+            except (TypeError, ValueError):
+                ids_h = None
+            if ids_h is None or ids_h.shape != (n,):
+                # non-integer ids (the reference's sha1 strings): the Python mirror maps them to slots, codes take the host entry point
+                added = s.add_codes_array(coarse.cpu().numpy().view(np.uint16), fine.cpu().numpy(), list(ids))
+                self.nb_ingested += n
+                return added
+            ids = torch.as_tensor(ids_h).to(coarse.device)
+        if hasattr(s, "add_codes_routed_dev"):
+            added = s.add_codes_routed_dev(coarse, fine, ids)
         else:
-            added = self.searcher.add_codes_dev(coarse, fine, ids)[0]
+            added = s.add_codes_dev(coarse, fine, ids)
+        if isinstance(added, tuple):  # LOPQSearcherHIP.add_codes_dev -> (added, skipped); the sharded forms return the count
+            added = added[0]
         self.nb_ingested += n
-        return added
+        return int(added)

@@ -416,7 +416,7 @@ class LOPQSearcherHIP(LOPQSearcherBase):
         _lib.check(_lib.lib().cis_index_last_stats(self._ix, _lib.ptr(st)))
         kind = int(_lib.lib().cis_index_last_scan_kernel(self._ix))
         return {"candidates": int(st[0]), "items": int(st[1]), "tables": int(st[2]), "scan_launches": int(st[3]),
-                "scan_kernel": {0: None, 1: "k_adc_scan", 2: "k_adc_scan2", 3: "k_adc_scan3"}.get(kind)}
+                "scan_kernel": {0: None, 1: "k_adc_scan", 2: "k_adc_scan2", 3: "k_adc_scan3", 4: "k_adc_scan4"}.get(kind)}
 
 
     default_prefilter_only = False  # tests: new searchers keep the float32-prefilter kernel for every batch size
@@ -528,14 +528,24 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
                 import lmdb
             except ImportError:
                 lmdb = None
-            if lmdb is not None and not os.path.exists(os.path.join(str(lmdb_path), kvlog.FILE_NAME)):
+            has_mdb = os.path.exists(os.path.join(str(lmdb_path), "data.mdb"))       # the reference's own LMDB files
+            has_log = os.path.exists(os.path.join(str(lmdb_path), kvlog.FILE_NAME))
+            # never hide data: an existing LMDB index must be opened as LMDB, and two stores in one directory are ambiguous
+            if has_mdb and has_log:
+                raise RuntimeError("%s holds both an LMDB index (data.mdb) and a %s log: move one of them away -- refusing to pick"
+                                   % (lmdb_path, kvlog.FILE_NAME))
+            if has_mdb and lmdb is None:
+                raise ImportError("%s holds an LMDB index (data.mdb) but the `lmdb` module is not installed: install it to open the "
+                                  "index (a fresh %s log here would shadow the stored items)" % (lmdb_path, kvlog.FILE_NAME))
+            if lmdb is not None and not has_log:
                 self.env = lmdb.open(self.lmdb_path, map_size=1024 * 1000000 * 32, max_dbs=1)  # :416
                 self.index_db = self.env.open_db(b"index")
                 with self.env.begin(db=self.index_db) as txn:
                     for key, value in txn.cursor():
                         self._put(bytes(key), self.decode_fine_codes(value))
             else:
-                # cold start from the log: same keys, same values, later records replace earlier ones (put semantics)
+                # cold start from the log: same keys, same values, later records replace earlier ones (put semantics); an
+                # add_codes call whose write was torn by a crash is dropped as a whole, like an aborted LMDB transaction
                 self._log = kvlog.KVLog(str(lmdb_path))
                 for key, value in self._log.load():
                     self._put(bytes(key), self.decode_fine_codes(value))

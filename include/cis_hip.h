@@ -242,7 +242,8 @@ int cis_train_project(const double* X, int64_t n, int d, const int64_t* group_of
  *   stats[1] (query, cell) work items   stats[2] ADC tables built   stats[3] scan kernel launches */
 int cis_index_last_stats(cis_index* ix, int64_t stats[4]);
 /* Which scan kernel the last batch of this handle ran (bench.py names it in `roofline.kernel`): 0 none (all-candidates path),
- * 1 k_adc_scan (float64), 2 k_adc_scan2 (float32 prefilter), 3 k_adc_scan3 (16-bit fixed-point prefilter). */
+ * 1 k_adc_scan (float64), 2 k_adc_scan2 (float32 prefilter), 3 k_adc_scan3 (16-bit fixed-point prefilter: streaming / two-pass form),
+ * 4 k_adc_scan4 (the sampled single-pass form of the 16-bit prefilter; k_adc_scan3 then only works off its fall-back slots). */
 int cis_index_last_scan_kernel(cis_index* ix);
 
 /* Stage timing with HIP events recorded on the stream the kernels are launched on (bench.py's

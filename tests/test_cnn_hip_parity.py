@@ -1,6 +1,8 @@
 """GPU parity of the DeepSentibank forward against the CPU restatement (oracle/cnn_oracle.py), seeded synthetic
 weights.  float32 everywhere; the MFMA accumulates k-ascending in float32 like caffe's sgemm would, only the
 order differs => tolerance 2e-4 relative to the feature scale (parity with caffe itself is unpinned)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -266,6 +268,53 @@ def test_batch_ingest_matches_per_item_chain():
     for i in range(6):
         items = s.get_cell((int(coarse[i, 0]), int(coarse[i, 1])))
         assert any(it[0] == 100 + i and tuple(it[1][1]) == tuple(int(v) for v in fine[i]) for it in items)
+
+
+def test_batch_ingest_into_searchers_without_a_tuple_returning_device_insert(tmp_path):
+    """BatchIngest must serve every searcher the package ships -- LOPQSearcherLMDB (host key / value store, string
+    ids, no device entry point), GridSearcher (add_codes_dev returns a count, not a tuple) and non-integer ids on the HIP
+    searcher -- with the same cells and codes as LOPQSearcherHIP gets."""
+    import torch
+    import torch.distributed as dist
+    from conftest import load_golden
+    from oracle import dlib_oracle as D
+    from columbiaimagesearch_amd.distributed import GridSearcher
+    from columbiaimagesearch_amd.featurizer import DLibFaceNet
+    from columbiaimagesearch_amd.ingest import BatchIngest
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP, LOPQSearcherLMDB
+    from test_lopq_hip_parity import hip_model
+    z, X, Q = load_golden("c2")
+    model = hip_model(z)
+    net = DLibFaceNet(D.synthetic_weights(0))
+    x = torch.as_tensor(D.synthetic_chips(5, seed=9), dtype=torch.float32).cuda().contiguous()
+    ref = LOPQSearcherHIP(model)
+    assert BatchIngest(net, model, ref, feat_dtype=torch.float64).ingest_batch(x, ids=np.arange(5)) == 5
+    coarse, fine = BatchIngest(net, model, ref, feat_dtype=torch.float64).encode_batch_dev(x)
+    coarse, fine = coarse.cpu().numpy().view(np.uint16), fine.cpu().numpy()
+    sha = ["sha1_%d" % i for i in range(5)]
+    # LMDB-order searcher: string ids, host store
+    lm = LOPQSearcherLMDB(model, str(tmp_path / "ix"), id_lambda=str)
+    assert BatchIngest(net, model, lm, feat_dtype=torch.float64).ingest_batch(x, ids=sha) == 5 and lm.get_nb_indexed() == 5
+    # HIP searcher with non-integer ids (slots in the Python mirror)
+    hs = LOPQSearcherHIP(model)
+    assert BatchIngest(net, model, hs, feat_dtype=torch.float64).ingest_batch(x, ids=sha) == 5
+    for i in range(5):
+        cell = (int(coarse[i, 0]), int(coarse[i, 1]))
+        want = tuple(int(v) for v in fine[i])
+        assert any(it[0] == sha[i] and tuple(it[1][1]) == want for it in lm.get_cell(cell))
+        assert any(it[0] == sha[i] and tuple(it[1][1]) == want for it in hs.get_cell(cell))
+    lm.close()
+    # GridSearcher over a world-1 group (1 query group x 1 cell shard): add_codes_dev returns an int
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        gs = GridSearcher(model, 1)
+        ing = BatchIngest(net, model, gs, feat_dtype=torch.float64)
+        assert ing.ingest_batch(x) == 5 and gs.get_nb_indexed() == 5
+        assert ing.ingest_batch(x, ids=np.arange(5)) == 0  # the same ids in the same cells: duplicates (search.py:356-364)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_c5_sentibank_ingest_against_oracle(net_and_weights):

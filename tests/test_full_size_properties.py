@@ -299,9 +299,10 @@ def test_query_groups_times_cell_shards_with_four_ranks_on_one_gpu():
         assert "world 4 grid %s: build and search equal the single index" % shape in text, text[-3000:]
 
 
-@pytest.mark.parametrize("gpus,shards,groups", [(2, 0, 1), (4, 0, 2), (2, 1, 2)])
-def test_bench_multi_rank_protocol_on_one_gpu(gpus, shards, groups):
-    """`bench.py --gpus N` with query groups (default grid and whole copies): value counts every group's queries."""
+@pytest.mark.parametrize("gpus,shards,grid_groups", [(2, 0, 2), (4, 0, 2), (4, 1, 4)])
+def test_bench_multi_rank_protocol_on_one_gpu(gpus, shards, grid_groups):
+    """`bench.py --gpus N`: the headline is BASELINE C4's layout (ONE copy of the index sharded by cell over all N ranks, strong
+    scaling); the R x S grid rides along as the `grid` object, whose value counts every group's queries."""
     import json, os, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, CIS_BENCH_BACKEND="gloo", CIS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CIS_BENCH_N="400000",
@@ -315,9 +316,14 @@ def test_bench_multi_rank_protocol_on_one_gpu(gpus, shards, groups):
     lines = [l for l in text.splitlines() if l.startswith("{")]
     assert len(lines) == 1, text[-3000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == gpus and line["config"]["query_groups"] == groups and line["recall_at_10"] >= 0.9
-    assert abs(line["value"] - groups * line["config"]["queries_per_step"] * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
-    assert line["config"]["index_vectors"] == 400000 and line["roofline"]["frac"] <= 1.0
+    assert line["n_gpus"] == gpus and line["scaling"] == "strong" and line["recall_at_10"] >= 0.9
+    assert line["config"]["query_groups"] == 1 and line["config"]["cell_shards"] == gpus
+    assert abs(line["value"] - line["config"]["queries_per_step"] * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
+    assert line["config"]["index_vectors"] == 400000
+    g = line["grid"]
+    assert "error" not in g, g
+    assert g["config"]["query_groups"] == grid_groups and g["config"]["cell_shards"] == gpus // grid_groups and g["recall_at_10"] >= 0.9
+    assert abs(g["value"] - grid_groups * g["config"]["queries_per_step"] * 3 / (g["ms_per_step"] * 3e-3)) <= 1e-6 * g["value"]
 
 
 def test_fork_before_first_use():

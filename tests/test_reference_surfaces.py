@@ -343,10 +343,17 @@ def test_lmdb_order_index_survives_a_restart(tmp_path):
     for c in cells[:5]:
         assert [i for i, _ in before[c]] == sorted(i for i, _ in before[c])  # key (byte) order inside a cell
     s2.close()
-    # a crash in the middle of an append leaves a torn record: it is cut off, everything before it is kept
+    # a crash in the middle of an add_codes call leaves a torn group: the WHOLE call is dropped (the reference's LMDB write
+    # transaction, search.py:445-467, is all-or-nothing), everything before it is kept
+    import struct
+    import zlib
+    rec = lambda k, v: struct.pack("<II", len(k), len(v)) + k + v
+    payload = rec(s2.encode_cell((0, 0)) + b"torn_a", b"\x01" * m.M) + rec(s2.encode_cell((0, 0)) + b"torn_b", b"\x02" * m.M)
+    group = struct.pack("<III", 2, len(payload), zlib.crc32(payload) & 0xFFFFFFFF) + payload
     with open(os.path.join(path, kvlog.FILE_NAME), "ab") as f:
-        f.write(b"\x10\x00\x00\x00\x08\x00\x00\x00partial")
+        f.write(group[:-5])  # the first record of the call is complete on disk, the second is not
     s3 = LOPQSearcherLMDB(m, path, id_lambda=str)
+    assert s3._log.dropped_torn_bytes == len(group) - 5
     assert s3.get_nb_indexed() == nb and {c: s3.get_cell(c) for c in cells} == before
     # many overwrites -> close() compacts the log to one record per live key
     for _ in range(3):
@@ -357,6 +364,52 @@ def test_lmdb_order_index_survives_a_restart(tmp_path):
     s4 = LOPQSearcherLMDB(m, path, id_lambda=str)
     assert s4.get_nb_indexed() == nb and {c: s4.get_cell(c) for c in cells} == before
     s4.close()
+    # damage in the MIDDLE of the log is not a torn tail: it raises instead of silently dropping what follows
+    s4 = LOPQSearcherLMDB(m, path, id_lambda=str)
+    s4.add_codes(codes[:3], ["later_%d" % i for i in range(3)])
+    s4.close()
+    raw = bytearray(open(os.path.join(path, kvlog.FILE_NAME), "rb").read())
+    raw[len(kvlog.MAGIC) + 40] ^= 0xFF
+    open(os.path.join(path, kvlog.FILE_NAME), "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="damaged"):
+        LOPQSearcherLMDB(m, path, id_lambda=str)
+
+
+def test_lmdb_path_never_shadows_an_existing_lmdb_index(tmp_path):
+    """an lmdb_path that already holds the reference's LMDB files (data.mdb) must not be opened as an empty log when
+    the lmdb module is missing, and a directory with both stores is refused (lopq/lopq/search.py:416-417 opens what is there)."""
+    from columbiaimagesearch_amd.lopq import LOPQSearcherLMDB
+    from columbiaimagesearch_amd.lopq import kvlog
+    m, z, Q = _lmdb_fixture()
+    try:
+        import lmdb  # noqa: F401
+        have_lmdb = True
+    except ImportError:
+        have_lmdb = False
+    p1 = tmp_path / "only_mdb"
+    p1.mkdir()
+    (p1 / "data.mdb").write_bytes(b"\0" * 64)
+    if not have_lmdb:
+        with pytest.raises(ImportError, match="data.mdb"):
+            LOPQSearcherLMDB(m, str(p1), id_lambda=str)
+        assert not (p1 / kvlog.FILE_NAME).exists()
+    p2 = tmp_path / "both"
+    p2.mkdir()
+    (p2 / "data.mdb").write_bytes(b"\0" * 64)
+    (p2 / kvlog.FILE_NAME).write_bytes(kvlog.MAGIC)
+    with pytest.raises(RuntimeError, match="both"):
+        LOPQSearcherLMDB(m, str(p2), id_lambda=str)
+    # a log of the first format (bare records) is read and rewritten in the grouped one
+    p3 = tmp_path / "v1"
+    p3.mkdir()
+    import struct
+    k = LOPQSearcherLMDB.encode_cell((1, 2)) + b"abc"
+    (p3 / kvlog.FILE_NAME).write_bytes(kvlog.MAGIC_V1 + struct.pack("<II", len(k), m.M) + k + bytes(range(m.M)))
+    s = LOPQSearcherLMDB(m, str(p3), id_lambda=str)
+    assert s.get_nb_indexed() == 1 and s.get_cell((1, 2))[0][0] == "abc"
+    s.close()
+    assert (p3 / kvlog.FILE_NAME).read_bytes().startswith(kvlog.MAGIC)
+    assert LOPQSearcherLMDB(m, str(p3), id_lambda=str).get_nb_indexed() == 1
 
 
 @gpu

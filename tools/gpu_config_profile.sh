@@ -14,6 +14,7 @@ if [ -n "$pmc" ]; then
   algo=$(python -c "import json;print(json.load(open('gpurun_out/${tag}_${cfg}_bench_line.json'))['roofline']['algorithmic_bytes_per_launch'])")
   python tools/scan_traffic.py ${tag} ${cfg} 7.125 $algo > /dev/null
   tools/gpu_pmc.sh ${tag}_${cfg}_sq "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY" --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-cnn --no-pcie > /dev/null 2>&1
+  python tools/scan_binding.py ${tag} ${cfg} 7.125 > /dev/null
 fi
 python - <<PY
 import json
