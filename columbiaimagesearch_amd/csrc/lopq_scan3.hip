@@ -1127,6 +1127,12 @@ static __device__ __forceinline__ void lds_barrier() {
 #define CIS_S4_WPE 6
 #endif
 static const int S4_OCT = CIS_S4_OCT;  // table reads per pipeline unit of the main pass (4: 16 registers of reads in flight)
+#ifndef CIS_S4_DEFER
+#define CIS_S4_DEFER 1  // the main pass records positions only; the per-query split runs on a second gather of the recorded candidates
+#endif
+#ifndef CIS_S4_PF
+#define CIS_S4_PF 2  // iterations of a wave that its code rows travel ahead
+#endif
 #ifndef CIS_S4_LCAP
 #define CIS_S4_LCAP 504
 #endif
@@ -1178,6 +1184,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     constexpr bool WLISTS = true;  // every wave appends to its own quarter of a query's list (no LDS atomic in the loop)
 #endif
     constexpr int WCAP = LCAPT / NW;
+    // deferred split: 16-bit positions per wave in the list memory (PCAP_LDS of them fit), of which NRP registers' worth are used
+    constexpr int PCAP_LDS = (int)(LIST_B / (NW * 2));
+    constexpr int NRP = LCAPT > 504 ? 8 : 4;               // registers of packed positions per lane in the second gather
+    constexpr int PCAP = NRP * 128 < PCAP_LDS ? NRP * 128 : PCAP_LDS;
+    static_assert(PCAP % 2 == 0 && (PCAP_LDS * 2) % 4 == 0, "position lists are read back as 32-bit pairs");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int total = n_slots_ptr[0];
@@ -1306,7 +1317,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                 const int len = __builtin_amdgcn_readfirstlane(d->len);
                 const int64_t start = ((int64_t)__builtin_amdgcn_readfirstlane(d->start_hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(d->start_lo);
                 // ---- tables -> 16-bit entries -> LDS (scan3_group's arithmetic) --------------------------------------------------
-                for (int vt = tid; vt < nvec; vt += NW * 64) {
+                // (the thread index is laundered per slot: the staging loop's per-thread offsets are loop invariants of the slot loop,
+                // and hoisted they sat in ~20 registers across the hot loop -- spilled, and a spill reload in front of the hot loop makes the
+                // compiler wait for ALL outstanding loads at every list store: the code rows then never travel ahead)
+                int tid_st = tid;
+                asm volatile("" : "+v"(tid_st));
+                for (int vt = tid_st; vt < nvec; vt += NW * 64) {
                     // thread -> (sub-quantizer j = vt % nf, four consecutive k): the lanes of a store group spread over the nf
                     // sub-quantizers (a run of consecutive k per lane group put all sixteen lanes on one bank pair: the entry
                     // stride of k is M * 8 bytes)
@@ -1601,25 +1617,46 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #else
                     const int nit = (len + 64 * U - 1) / (64 * U);
 #endif
-                    CodeWords<M> nx[U];
-                    if (w < nit) {
+                    // code rows travel PF iterations of this wave ahead of their use (a ring of PF register sets, the loop unrolled PF
+                    // times so that the sets are static): one iteration ahead left the wave waiting at the end of most iterations --
+                    // an iteration is ~100 instructions, a code row comes from L2 / Infinity Cache / HBM
+                    constexpr int PF = CIS_S4_PF;
+                    CodeWords<M> ring[PF][U];
 #pragma unroll
-                        for (int u = 0; u < U; ++u) nx[u] = load_code_buf<M>(rs, w * 64 * U + u * 64 + lane);
+                    for (int k = 0; k < PF; ++k) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) ring[k][u] = load_code_buf<M>(rs, (w + k * NW) * 64 * U + u * 64 + lane);  // past the chunk: zeros, never consumed
+                        // (the sets are requested in the order the loop consumes them: entering the loop with set 0 as the NEWEST request would
+                        // make the wait at the loop head vmcnt(0) on every trip)
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     int wcur[G];
 #pragma unroll
                     for (int g = 0; g < G; ++g) wcur[g] = 0;
-                    for (int iter = w; iter < nit; iter += NW) {
+#if CIS_S4_DEFER
+                    // Deferred split (round 4).  ~94 % of the rows of a long chunk carry a lane that passes for SOME query (four queries x 64
+                    // lanes against a threshold that lets ~1 % through), and the per-query ballots / prefix counts / stores of such a row cost
+                    // about as many instructions as its gathers (profiles/r03zz_c4_sq_pmc.csv: 1.8x the bare loop).  The loop now only
+                    // records WHICH candidates passed -- one 16-bit position per passing lane, one ballot, in a wave-private list that lives
+                    // where the sample was -- and the ~2-3 % recorded candidates are gathered a second time afterwards (the tables are still
+                    // in LDS), where the per-query split runs on 64 passing lanes per row instead of one or two.
+                    uint16_t* plist = reinterpret_cast<uint16_t*>(lists) + (size_t)w * PCAP_LDS;
+                    int pcur = 0;
+#endif
+                    for (int iter0 = w; iter0 < nit; iter0 += NW * PF) {
+#pragma unroll
+                      for (int k = 0; k < PF; ++k) {
+                        // (no early exit inside the unrolled group: an iteration past the chunk reads zeros and its rows are masked out
+                        // below -- at most PF - 1 idle iterations per wave and slot, and the register sets keep their names)
+                        const int iter = iter0 + k * NW;
                         const int base = iter * 64 * U;
-                        CodeWords<M> cur[U];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) cur[u] = nx[u];
-                        if (iter + NW < nit) {
-#pragma unroll
-                            for (int u = 0; u < U; ++u) nx[u] = load_code_buf<M>(rs, (iter + NW) * 64 * U + u * 64 + lane);
-                        }
                         u32x2_t dd[U];
-                        adc16_rows<M, U, S4_OCT>(cur, tab, rc, dd);
+                        adc16_rows<M, U, S4_OCT>(ring[k], tab, rc, dd);
+                        // the set's next rows are requested as soon as its words have been consumed (the loads target the same registers:
+                        // no copies).  Unconditional -- past the chunk the descriptor returns zeros -- so that every path through the
+                        // loop has the same number of loads in flight and the wait before a set's use is vmcnt((PF - 1) * U), not vmcnt(0)
+#pragma unroll
+                        for (int u = 0; u < U; ++u) ring[k][u] = load_code_buf<M>(rs, (iter + PF * NW) * 64 * U + u * 64 + lane);
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             const uint32_t xx = pk_subsat_u16(tpk[0], dd[u][0]) | pk_subsat_u16(tpk[1], dd[u][1]);
@@ -1627,6 +1664,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                             const int n = len - base - u * 64;
                             if (n < 64) am &= n <= 0 ? 0ull : ((1ull << n) - 1ull);
                             if (am == 0ull) continue;  // scalar branch
+#if CIS_S4_DEFER
+                            if constexpr (WLISTS) {
+                                const int idx = __builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, pcur));
+                                if (((am >> lane) & 1ull) && idx < PCAP) plist[idx] = (uint16_t)(base + u * 64 + lane);
+                                pcur += __popcll(am);
+                                continue;
+                            }
+#endif
                             if constexpr (WLISTS) {
 #ifdef CIS_S4_SCALAR_APPEND  // measured on C4: 0.341 ms against 0.307 ms for the ballot form below (the scalar chain serialises)
                                 // A row that gets here carries one passing lane as a rule (the threshold lets ~1 % through): the lanes
@@ -1683,7 +1728,58 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                                 if (((m[g] >> lane) & 1ull) && idx < LCAP) lists[g * LCAP + idx] = (sg << 16) | (uint32_t)(base + u * 64 + lane);
                             }
                         }
+                      }
                     }
+#if CIS_S4_DEFER
+                    if constexpr (WLISTS) {
+                        // the recorded positions move to registers (two per register), then the list memory becomes the per-query lists
+                        const bool pover = pcur > PCAP;  // more passing candidates than the position list holds: the slot falls back
+                        const int pn = pover ? 0 : pcur;
+                        uint32_t pp[NRP];
+#pragma unroll
+                        for (int r = 0; r < NRP; ++r)
+                            pp[r] = (2 * (r * 64) < pn) ? reinterpret_cast<const volatile uint32_t*>(plist)[r * 64 + lane] : 0u;
+                        lds_barrier();  // B3b: every wave holds its positions; nobody still writes a position list
+                        if (pn > 0) {
+                            auto pos_of = [&](int it) -> uint32_t {  // iteration it takes half (it & 1) of register it >> 1
+                                uint32_t v = pp[0];
+#pragma unroll
+                                for (int r = 1; r < NRP; ++r) v = ((it >> 1) == r) ? pp[r] : v;
+                                return (it & 1) ? (v >> 16) : (v & 0xffffu);
+                            };
+                            auto on_of = [&](int it) -> bool { return 2 * (((it >> 1) * 64) + lane) + (it & 1) < pn; };
+                            const int nit2 = 2 * ((pn + 127) >> 7);  // iterations: halves of ceil(pn / 128) registers
+                            CodeWords<M> nxc[1];
+                            uint32_t npos = pos_of(0);
+                            nxc[0] = load_code_buf<M>(rs, on_of(0) ? (int)npos : len);  // past the chunk: zeros, masked below
+#pragma unroll 1
+                            for (int it = 0; it < nit2; ++it) {
+                                CodeWords<M> cc[1];
+                                cc[0] = nxc[0];
+                                const uint32_t pos = npos;
+                                const bool on = on_of(it);
+                                if (it + 1 < nit2) {
+                                    npos = pos_of(it + 1);
+                                    nxc[0] = load_code_buf<M>(rs, on_of(it + 1) ? (int)npos : len);
+                                }
+                                u32x2_t d1[1];
+                                adc16_rows<M, 1, S4_OCT>(cc, tab, rc, d1);
+                                const unsigned long long am2 = __ballot(on);
+#pragma unroll
+                                for (int g = 0; g < G; ++g) {
+                                    const uint32_t sg = (g & 1) ? (d1[0][g >> 1] >> 16) : (d1[0][g >> 1] & 0xffffu);
+                                    const uint32_t t1 = (g & 1) ? ((g >> 1) ? s23 >> 16 : s01 >> 16) : ((g >> 1) ? s23 & 0xffffu : s01 & 0xffffu);
+                                    const unsigned long long mg = __ballot(sg < t1) & am2;
+                                    if (mg == 0ull) continue;
+                                    const int idx = __builtin_amdgcn_mbcnt_hi((unsigned)(mg >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mg, wcur[g]));
+                                    if (((mg >> lane) & 1ull) && idx < WCAP) lists[(g * NW + w) * WCAP + idx] = (sg << 16) | pos;
+                                    wcur[g] += __popcll(mg);
+                                }
+                            }
+                        }
+                        if (pover) wcur[0] = WCAP + 1;  // reported like an overflowing quarter (the verification below sends the slot to the fall-back)
+                    }
+#endif
                     if constexpr (WLISTS) {
                         if (lane < G) {
                             int c = wcur[0];
@@ -1702,6 +1798,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     const int g = w;
                     int tot = 0;
                     int wtot[NW];
+                    int lane_v = lane;  // laundered: the verification's per-lane offsets are not to live across the hot loop
+                    asm volatile("" : "+v"(lane_v));
                     if constexpr (WLISTS) {
 #pragma unroll
                         for (int r = 0; r < NW; ++r) {
@@ -1713,7 +1811,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                         tot = s_cnt[g];
                         bad = tot > LCAP;  // the list overflowed (a crowd of equal sums, or a threshold far too loose)
                     }
-                    if (bad && lane == 0) atomicAdd(&dbg[2], 1);
+                    if (bad && lane_v == 0) atomicAdd(&dbg[2], 1);
                     if (!bad) {
                         uint32_t ent[NRV];
                         bool val[NRV];
@@ -1721,12 +1819,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                         for (int r = 0; r < NRV; ++r) {
                             if constexpr (WLISTS) {
                                 constexpr int RW = NRV / NW;  // registers per wave quarter
-                                const int e = (r % RW) * 64 + lane;
+                                const int e = (r % RW) * 64 + lane_v;
                                 val[r] = e < wtot[r / RW];
                                 ent[r] = val[r] ? lists[(g * NW + r / RW) * WCAP + e] : 0xffffffffu;
                             } else {
-                                val[r] = r * 64 + lane < tot;
-                                ent[r] = val[r] ? lists[g * LCAP + r * 64 + lane] : 0xffffffffu;
+                                val[r] = r * 64 + lane_v < tot;
+                                ent[r] = val[r] ? lists[g * LCAP + r * 64 + lane_v] : 0xffffffffu;
                             }
                         }
                         const uint32_t tau = sh[g].tau;
@@ -1735,7 +1833,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
                             for (int r = 0; r < NRV; ++r) nle += __popcll(__ballot(val[r] && (ent[r] >> 16) <= tau));
                             bad = nle < L;
-                            if (bad && lane == 0) atomicAdd(&dbg[3], 1);
+                            if (bad && lane_v == 0) atomicAdd(&dbg[3], 1);
                         }
                         if (!bad) {
                             uint32_t cut = 65535u;
@@ -1762,7 +1860,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                                 }
                                 cut = lo + (uint32_t)M + 1u;
                                 const uint64_t b = val_to_bound(lo, M, sh[g].ub);  // >= L candidates of this chunk do not exceed it
-                                if (lane == 0 && b < sh[g].ext) atomicMin(&qbound[sh[g].q], (unsigned long long)b);
+                                if (lane_v == 0 && b < sh[g].ext) atomicMin(&qbound[sh[g].q], (unsigned long long)b);
                             }
                             const int item = __builtin_amdgcn_readfirstlane(d->item[g]);
                             uint64_t* out = item_surv + (int64_t)item * S;
@@ -1771,7 +1869,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
                                 for (int r = 0; r < NRV; ++r) nk += __popcll(__ballot(val[r] && (ent[r] >> 16) <= cut));
                                 bad = nk > S;
-                                if (bad && lane == 0) atomicAdd(&dbg[4], 1);
+                                if (bad && lane_v == 0) atomicAdd(&dbg[4], 1);
                             }
                             if (!bad) {
                                 int kept = 0;
@@ -1783,11 +1881,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                                     if (kp) out[idx] = ((uint64_t)(ent[r] >> 16) << 32) | (ent[r] & 0xffffu);
                                     kept += __popcll(mk);
                                 }
-                                if (lane == 0) item_n[item] = kept;
+                                if (lane_v == 0) item_n[item] = kept;
                             }
                         }
                     }
-                    if (bad && lane == 0) *s_flag = 1;
+                    if (bad && lane_v == 0) *s_flag = 1;
                 }
                 lds_barrier();  // B5: the lists have been read, the verdict is in
                 S3_CTR(6, S3_CLK() - c0);
