@@ -318,6 +318,14 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
             return searcher.search_batch_dev(q, quota=QUOTA, limit=LIMIT)
         return sharded.search_batch_dev(q, quota=QUOTA, limit=LIMIT)  # partial scan -> RCCL all-gather -> merge
     st.step = step
+    # Steps are independent batches: `pipeline` of them are in flight at once, each through its own VIEW of the index (shared
+    # codes / ids in HBM, private per-batch workspaces: cis_index_create_view) on its own HIP stream -- the launch-bound small
+    # kernels of one batch's front end, tables and slot building fill the tail of the previous batch's scan and its merge.
+    P = max(1, ctx.pipeline) if sharded is None else 1
+    lanes = [(searcher, torch.cuda.current_stream(device))]
+    for _ in range(P - 1):
+        lanes.append((searcher.view(), torch.cuda.Stream(device=device)))
+    st.lanes = lanes
 
     def qb(b):  # a step = one batch of NQ queries PER QUERY GROUP: group g answers its own batches, the S ranks of a group the same
         return qbatches[(b * R + g_q) % len(qbatches)]
@@ -328,8 +336,16 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
         torch.cuda.synchronize()
     # timed region: only the pair of HIP events around the scan kernel (roofline); the per-stage events are small bubbles
     # between kernels, so the stage breakdown is taken from a few extra steps after the timed region
-    searcher.set_profiling(True, scan_only=True)
-    searcher.read_profile()
+    for sv, _ in lanes:
+        sv.set_profiling(True, scan_only=True)
+        sv.read_profile()
+    if P > 1:  # the views' workspaces warm up too
+        for k in range(1, P):
+            with torch.cuda.stream(lanes[k][1]):
+                lanes[k][0].search_batch_dev(qb(0), quota=QUOTA, limit=LIMIT)
+        torch.cuda.synchronize()
+        for sv, _ in lanes:
+            sv.read_profile()
     with wd.phase("%s: timed steps" % cfg_name, 600):
         if world > 1:
             dist.barrier()
@@ -339,9 +355,12 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
         cand_items = 0
         if sharded is None:
             for b in range(steps):
-                step(qb(warmup + b))
-                cand += searcher.last_stats()["candidates"]
-                cand_items += searcher.last_stats()["items"]
+                sv, stream = lanes[b % P]
+                with torch.cuda.stream(stream):
+                    sv.search_batch_dev(qb(warmup + b), quota=QUOTA, limit=LIMIT)
+                ls = sv.last_stats()
+                cand += ls["candidates"]
+                cand_items += ls["items"]
         else:
             # steps are independent batches: the exchange + merge of batch b (side stream, RCCL) overlap the partial search
             # of batch b+1 (compute stream)
@@ -361,6 +380,11 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
             dist.barrier()
         t1 = time.perf_counter()
     prof = searcher.read_profile()
+    for sv, _ in lanes[1:]:
+        pv = sv.read_profile()
+        for k in prof:
+            prof[k] += pv[k]
+        sv.set_profiling(False)
     searcher.set_profiling(True)
     n_stage = min(steps, 5)
     with wd.phase("%s: stage-profile steps" % cfg_name, 300):
@@ -434,7 +458,7 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
                    "sharding": "%d query group(s) x %d cell shard(s): each group holds the whole index sharded by coarse cell over %d GPU(s)%s "
                                "and answers its own %d queries per step" % (R, S, S, ", RCCL all-gather merge inside the group" if S > 1 else "", NQ),
                    "parallelism": "grid %dx%d" % (R, S), "query_groups": R, "cell_shards": S, "queries_per_step_all_groups": R * NQ,
-                   "index_scaling": scaling, "query_load_scaling": "weak (x%d query groups)" % R if R > 1 else "fixed",
+                   "batches_in_flight": P, "index_scaling": scaling, "query_load_scaling": "weak (x%d query groups)" % R if R > 1 else "fixed",
                    "candidates_per_query": cand_all / float(R * NQ * steps)},
         "roofline": {"bound": "hbm", "kernel": scan_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "accounting_frac": achieved / HBM_PEAK_GBS,
@@ -444,7 +468,16 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
                      "traffic": traffic, "traffic_note": traffic_note,
                      "algorithmic_bytes_per_launch": algo_bytes / launches,
                      "avg_launch_ms": prof["scan_kernel_ms"] / launches, "launches": launches,
-                     "binding": scan_binding(cfg_name, scan_name, cand, cand_items, M, scan_s, launches)},
+                     # with several batches in flight a scan launch shares the chip with the other batches' kernels: its HIP-event
+                     # duration grows although the job gets faster.  The same launch alone on the chip (the stage-profile steps
+                     # right after the timed region run one batch at a time):
+                     "isolated_launch_ms": stage_prof["scan_kernel_ms"] / max(stage_prof["scan_launches"], 1),
+                     "isolated_accounting_frac": (algo_bytes / launches) / (stage_prof["scan_kernel_ms"] / max(stage_prof["scan_launches"], 1) / 1e3) / 1e9 / HBM_PEAK_GBS
+                                                 if stage_prof["scan_kernel_ms"] > 0 else None,
+                     "batches_in_flight": P,
+                     "binding": scan_binding(cfg_name, scan_name, cand / float(launches) * max(stage_prof["scan_launches"], 1),
+                                             cand_items / float(launches) * max(stage_prof["scan_launches"], 1), M,
+                                             stage_prof["scan_kernel_ms"] / 1e3, max(stage_prof["scan_launches"], 1))},
         "stage_ms_per_step": {k: stage_prof[k] / n_stage for k in ("front_ms", "tables_ms", "scan_ms", "merge_ms", "scan_kernel_ms")},
         "encode": {"value": enc_rate, "unit": "vectors/s", "vectors": len(my_chunks) * chunk_n,
                    "note": "cis_encode_dev on this rank's share of the index build, HIP events around the encode calls",
@@ -707,6 +740,8 @@ def ingest_leg(ctx, st, net_kind, n_ing=12):
 
 def release_state(st):
     try:
+        for sv, _ in (getattr(st, "lanes", None) or [])[1:]:
+            sv.close()
         st.searcher.close()
     except Exception:
         pass
@@ -729,6 +764,8 @@ def main():
                     help="S of the second (`grid`) layout at N > 1: R = gpus / S query groups, each one copy of the index sharded by "
                          "cell over S GPUs.  Default: 2 from 4 GPUs on, 1 (whole copies) at 2.  The headline is always S = gpus")
     ap.add_argument("--no-grid", action="store_true", help="N > 1: skip the second layout")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("CIS_BENCH_PIPELINE", 3)),
+                    help="N = 1: query batches in flight at once (each through its own view of the index on its own stream); 1 = one after the other")
     ap.add_argument("--no-configs", action="store_true", help="skip the c2 / c3 / c5 sub-runs of the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cnn", action="store_true")
@@ -752,6 +789,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = ctx.device = torch.device("cuda", local_rank)
     wd = ctx.wd = Watchdog(rank)
+    ctx.pipeline = args.pipeline
     from columbiaimagesearch_amd import _lib
     _lib.check(_lib.lib().cis_set_device(local_rank))
     # CIS_BENCH_FORCE_DIST=1 runs the sharded code path (process group, all-gather, merge) even with one

@@ -39,10 +39,22 @@ struct cis_index {
     DevBuf d_gcount;   // [ncells] int64, all shards
     bool had_plain_remote = false;  // items of other shards' cells were counted without (cell, id) bookkeeping
     int64_t nb_indexed = 0;
+    // A VIEW (cis_index_create_view) shares the storage of `base` -- codes, ids, offsets, cell sizes -- and owns only its per-batch
+    // workspaces, plan read-back words and counters: two batches can then be in flight at once, each on its own stream (the front end,
+    // tables and slot kernels of one batch fill the tail of the other's scan and its merge).  A view is read-only and must not outlive
+    // its base; inserts into the base must be ordered against the views' searches by the caller (events), like searches on the base.
+    cis_index* base = nullptr;
+    const cis_index* st() const { return base ? base : this; }
     // views the search pipeline reads (current generation of `own`)
-    const uint8_t* codes_ptr() const { return own.codes[own.cur].as<uint8_t>(); }
-    const int64_t* ids_ptr() const { return own.ids[own.cur].as<int64_t>(); }
-    const int64_t* loff_ptr() const { return own.loff[own.cur].as<int64_t>(); }
+    const uint8_t* codes_ptr() const { const cis_index* s = st(); return s->own.codes[s->own.cur].as<uint8_t>(); }
+    const int64_t* ids_ptr() const { const cis_index* s = st(); return s->own.ids[s->own.cur].as<int64_t>(); }
+    const int64_t* loff_ptr() const { const cis_index* s = st(); return s->own.loff[s->own.cur].as<int64_t>(); }
+    const int64_t* gcount_ptr() const { return st()->d_gcount.as<int64_t>(); }
+    void sync_from_base() {  // scalars of the storage the search path reads
+        if (!base) return;
+        ncells = base->ncells; rank = base->rank; world = base->world; nb_indexed = base->nb_indexed; n_local = base->n_local;
+        n_total = base->n_total; max_cell = base->max_cell; nonempty_cells = base->nonempty_cells;
+    }
     int64_t n_local = 0;
     // insert workspace
     DevBuf wi_key[2], wi_val[2], wi_hist, wi_sid, wi_acc, wi_apre, wi_tmp, wi_in_ids, wi_in_coarse, wi_in_fine, wi_scan;
@@ -53,7 +65,7 @@ struct cis_index {
     DevBuf w_planfb, w_vis;  // k_plan_par: per-query fallback flags, visited (i, j) lists
     DevBuf w_tiles;          // tile sums of the candidate layout
     DevBuf w_xp, w_cd, w_order, w_sorted, w_plan, w_off, w_items, w_tabs, w_T, w_hits, w_hitn, w_part, w_q,
-        w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos, w_order2, w_px, w_T32, w_grp, w_tord;
+        w_oids, w_odists, w_onf, w_ovis, w_ocell, w_opos, w_order2, w_px, w_T32, w_grp, w_tord, w_y64, w_x64;
     int64_t stats[4] = {0, 0, 0, 0};
     // optional stage timing (hipEvents on the launch stream)
     bool force_exact_scan = false;  // tests: run every item through the float64 kernel

@@ -473,6 +473,7 @@ static int store_init(cis_index* ix, CellStore& s, bool with_codes) {
 }
 
 int cis_index_ready(cis_index* ix) {
+    CIS_REQUIRE(ix->base == nullptr, "this handle is a search view (cis_index_create_view): inserts and reads go to the base index");
     if (ix->own.init && ix->h_ins) return CIS_OK;
     CIS_TRY(cis_lazy_init());
     CIS_CHECK_HIP(hipSetDevice(ix->m->device));
@@ -507,13 +508,30 @@ extern "C" int cis_index_create(cis_index** out, cis_model* m) {
     return CIS_OK;
 }
 
+extern "C" int cis_index_create_view(cis_index** out, cis_index* base) {
+    CIS_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    CIS_REQUIRE(base != nullptr, "base index is NULL");
+    CIS_REQUIRE(base->base == nullptr, "a view of a view: create views from the base index");
+    cis_index* ix = new cis_index();
+    ix->m = base->m;
+    ix->V = base->V;
+    ix->M = base->M;
+    ix->base = base;
+    ix->force_exact_scan = base->force_exact_scan; ix->force_scan2 = base->force_scan2; ix->force_scan3 = base->force_scan3;
+    ix->force_two_pass = base->force_two_pass; ix->force_prefilter_scan = base->force_prefilter_scan;
+    ix->sync_from_base();
+    *out = ix;
+    return CIS_OK;
+}
+
 extern "C" void cis_index_destroy(cis_index* ix) {
     if (!ix) return;
     if (ix->m) (void)hipSetDevice(ix->m->device);
     DevBuf* bufs[] = {&ix->d_gcount, &ix->d_owner, &ix->w_xp, &ix->w_cd, &ix->w_order,
                       &ix->w_sorted, &ix->w_plan, &ix->w_off, &ix->w_items, &ix->w_tabs, &ix->w_T, &ix->w_hits,
                       &ix->w_hitn, &ix->w_slack, &ix->w_planfb, &ix->w_vis, &ix->w_tiles, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
-                      &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px, &ix->w_T32, &ix->w_grp, &ix->w_tord,
+                      &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px, &ix->w_T32, &ix->w_grp, &ix->w_tord, &ix->w_y64, &ix->w_x64,
                       &ix->wi_key[0], &ix->wi_key[1], &ix->wi_val[0], &ix->wi_val[1], &ix->wi_hist, &ix->wi_sid, &ix->wi_acc,
                       &ix->wi_apre, &ix->wi_tmp, &ix->wi_in_ids, &ix->wi_in_coarse, &ix->wi_in_fine, &ix->wi_scan, &ix->d_stats};
     for (DevBuf* b : bufs) b->release();

@@ -31,9 +31,11 @@ struct cis_model {
 // xp: LOPQ-space vectors [n][D] of xp_dtype.  Returns in *xc a pointer to the same vectors in the
 // coarse compute type (float when both xp and Cs are float32, else double; may alias xp or
 // m->ws_x64) and the compute type in *ct (CIS_F32 / CIS_F64).
-int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, float* d_out, hipStream_t st);
+int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, float* d_out, hipStream_t st,
+                      DevBuf* ws_y = nullptr /* float64 product before the finish pass; default: the model's own (one caller at a time) */);
 int cis_dev_coarse_type(cis_model* m, const void* d_xp, int xp_dtype, int64_t n, const void** xc, int* ct,
-                        hipStream_t st);
+                        hipStream_t st,
+                        DevBuf* ws_x = nullptr /* widened copy; default: the model's own */);
 // squared distances of n compute-type vectors to the V coarse centroids of `split`, numpy order:
 // out [n][V] of the compute type.
 int cis_launch_sqdist(cis_model* m, const void* xc, int ct, int64_t n, int split, void* out, hipStream_t st);

@@ -1460,11 +1460,12 @@ extern "C" int cis_model_create(cis_model** out, int D_in, int D, int V, int M, 
 
 static inline int grid1(int64_t n, int bs) { return (int)ceil_div(n, bs); }
 
-int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, float* d_out, hipStream_t st) {
+int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, float* d_out, hipStream_t st, DevBuf* ws_y) {
     CIS_REQUIRE(m->has_pca, "model has no PCA parameters");
     if (n == 0) return CIS_OK;
-    CIS_TRY(m->ws_y64.reserve((size_t)n * m->D * sizeof(double)));
-    double* Y = m->ws_y64.as<double>();
+    DevBuf* wy = ws_y ? ws_y : &m->ws_y64;
+    CIS_TRY(wy->reserve((size_t)n * m->D * sizeof(double)));
+    double* Y = wy->as<double>();
     // 64-row tiles when they fill the chip twice over, 32-row tiles otherwise
     const bool small = ceil_div(n, 64) * ceil_div(m->D, 64) < 512;
     dim3 g((unsigned)ceil_div(n, small ? 32 : 64), (unsigned)ceil_div(m->D, 64));
@@ -1502,7 +1503,7 @@ int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, floa
 }
 
 int cis_dev_coarse_type(cis_model* m, const void* d_xp, int xp_dtype, int64_t n, const void** xc, int* ct,
-                        hipStream_t st) {
+                        hipStream_t st, DevBuf* ws_x) {
     if (xp_dtype == CIS_F32 && m->coarse_f32) {
         *xc = d_xp;
         *ct = CIS_F32;
@@ -1513,11 +1514,12 @@ int cis_dev_coarse_type(cis_model* m, const void* d_xp, int xp_dtype, int64_t n,
         *xc = d_xp;
         return CIS_OK;
     }
-    CIS_TRY(m->ws_x64.reserve((size_t)n * m->D * sizeof(double)));
+    DevBuf* wx = ws_x ? ws_x : &m->ws_x64;
+    CIS_TRY(wx->reserve((size_t)n * m->D * sizeof(double)));
     if (n > 0)
-        hipLaunchKernelGGL(k_to_f64<float>, dim3(2048), dim3(256), 0, st, (const float*)d_xp, m->ws_x64.as<double>(),
+        hipLaunchKernelGGL(k_to_f64<float>, dim3(2048), dim3(256), 0, st, (const float*)d_xp, wx->as<double>(),
                            n * m->D);
-    *xc = m->ws_x64.p;
+    *xc = wx->p;
     return CIS_OK;
 }
 

@@ -1130,6 +1130,15 @@ static const int S4_OCT = CIS_S4_OCT;  // table reads per pipeline unit of the m
 #ifndef CIS_S4_DEFER
 #define CIS_S4_DEFER 1  // the main pass records positions only; the per-query split runs on a second gather of the recorded candidates
 #endif
+#ifndef CIS_S4_NW_LONG
+#define CIS_S4_NW_LONG 4   // waves per slot, long chunks (8: measured slower on C4, 0.275 - 0.32 against 0.243 ms: profiles/r04f_ab.txt)
+#endif
+#ifndef CIS_S4_NW_SHORT
+#define CIS_S4_NW_SHORT 4  // waves per slot, short chunks
+#endif
+#ifndef CIS_S4_WPE8
+#define CIS_S4_WPE8 6      // waves per SIMD the 8-wave long-chunk variant is compiled for (80 registers: three workgroups per CU)
+#endif
 #ifndef CIS_S4_PF
 #define CIS_S4_PF 2  // iterations of a wave that its code rows travel ahead
 #endif
@@ -1148,9 +1157,9 @@ static const int S4_NS = CIS_S4_NS;      // sample rows per chunk (64 sums per q
 
 static const int S4_LCAP_LONG = 1016;    // list entries per query for long chunks (sixteen registers per lane in the verification)
 
-static size_t scan4_lds(int M, int K, int lcap) {
+static size_t scan4_lds(int M, int K, int lcap, int nw) {
     const size_t lists = (size_t)S3G * lcap * 4, samp = (size_t)S3G * S4_NS * 64 * 2;
-    return (size_t)K * M * S3G * 2 + (lists > samp ? lists : samp) + S3G * sizeof(Scan4Shared) + 96 + (S4_DS + 1) * sizeof(Slot4);
+    return (size_t)K * M * S3G * 2 + (lists > samp ? lists : samp) + S3G * sizeof(Scan4Shared) + 32 + (size_t)S3G * nw * 4 + (S4_DS + 1) * sizeof(Slot4);
 }
 
 template <int M, int U, int NW, int WPE, int LCAPT>
@@ -1163,7 +1172,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     int nsx /* most sample rows per chunk */, int dyn /* slots from a counter instead of the static schedule */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int G = S3G;
-    static_assert(NW == G, "one wave per query in the threshold and verification phases");
+    // NW waves gather (sample, main pass, second gather); waves 0 .. G-1 also serve one query each in the threshold and verification
+    // phases.  NW = 8 (round 4): a slot's latency, not the chip's throughput, bounds the launch -- a slot alone on the chip takes as long
+    // as one among 1024 (tools/nq_sweep.py) -- so twice the waves per slot halve the main pass, and three such workgroups per CU are
+    // 24 waves against 16
+    static_assert(NW >= G && NW % G == 0 && NW <= 8, "waves 0 .. G-1 serve one query each in the threshold and verification phases");
     static_assert(M == 4 || M == 8 || M == 16, "float4s of the half tables are dealt to the threads in rounds of 256");
     constexpr int nf = M / 2;
     constexpr uint32_t CAP = 65535u / M;
@@ -1177,7 +1190,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     int* s_flag = reinterpret_cast<int*>(thr1 + 4);
     int* s_cnt = s_flag + 1;                               // [G] list cursors (the 4-lane atomic of the main pass)
     int* wcnt = reinterpret_cast<int*>(reinterpret_cast<char*>(thr1) + 32);  // [G][NW] entries of the wave-private lists (long chunks)
-    Slot4* sd = reinterpret_cast<Slot4*>(reinterpret_cast<char*>(thr1) + 96);
+    Slot4* sd = reinterpret_cast<Slot4*>(reinterpret_cast<char*>(thr1) + 32 + G * NW * 4);
 #ifdef CIS_S4_SHARED_LISTS  // short chunks with one list per query and an LDS atomic per row: 0.176 against 0.172 ms on C2
     constexpr bool WLISTS = LCAPT > 504;
 #else
@@ -1186,13 +1199,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     constexpr int WCAP = LCAPT / NW;
     // deferred split: 16-bit positions per wave in the list memory (PCAP_LDS of them fit), of which NRP registers' worth are used
     constexpr int PCAP_LDS = (int)(LIST_B / (NW * 2));
-    constexpr int NRP = LCAPT > 504 ? 8 : 4;               // registers of packed positions per lane in the second gather
+    constexpr int NRP = (LCAPT > 504 ? 32 : 16) / NW;      // registers of packed positions per lane in the second gather
     constexpr int PCAP = NRP * 128 < PCAP_LDS ? NRP * 128 : PCAP_LDS;
     static_assert(PCAP % 2 == 0 && (PCAP_LDS * 2) % 4 == 0, "position lists are read back as 32-bit pairs");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int total = n_slots_ptr[0];
-    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, LW = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+    const int LW = gridDim.x >> 3;
+    // (Balanced rounds -- the same slots over ceil(slots / rounds) workgroups, the rest leaving at once -- were measured and lost, 0.300
+    // against 0.245 ms on C4: the workgroups that leave are the ones the dispatcher placed last, so whole CUs go idle; and three
+    // rounds at three workgroups per CU cost what two full rounds and a sparse third do: profiles/r04h_ab.txt.)
     // the workgroup's k-th slot: local index li = lb + k * LW on its XCD -> run (li / 32) * 8 + xcd, place li % 32
     auto slot_of = [&](int k) -> int {
         const int li = lb + k * LW;
@@ -1428,7 +1445,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     lds_barrier();  // B2
                     S3_CTR(3, S3_CLK() - c0);
                     // ---- thresholds: wave g serves query g ---------------------------------------------------------------------------------
-                    {
+                    if (w < G) {
                         const int g = w;
                         uint32_t sv[NS];
                         int nsam = 0;
@@ -1549,7 +1566,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     lds_barrier();  // B2
                     S3_CTR(3, S3_CLK() - c0);
                     // ---- thresholds: wave g serves query g ---------------------------------------------------------------------------------
-                    {
+                    if (w < G) {
                         const int g = w;
                         uint32_t sv[NW];
 #pragma unroll
@@ -1730,6 +1747,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                         }
                       }
                     }
+                    S3_CTR(13, S3_CLK() - c0);
 #if CIS_S4_DEFER
                     if constexpr (WLISTS) {
                         // the recorded positions move to registers (two per register), then the list memory becomes the per-query lists
@@ -1850,16 +1868,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                                 wave_minmax_step<1>(mn, mx); wave_minmax_step<2>(mn, mx); wave_minmax_step<4>(mn, mx);
                                 wave_minmax_step<8>(mn, mx); wave_minmax_step<16>(mn, mx); wave_minmax_step<32>(mn, mx);
                                 uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)mn), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
+                                // hi always has >= L sums at or below it (it starts at the largest collected sum and tot >= L); the search stops
+                                // as soon as that count is within L + 16: any such value serves as v (a step costs NRV ballots, the exact L-th
+                                // smallest ~12 steps, this ~5; the merge cuts the few extra survivors before re-scoring)
                                 while (lo < hi) {  // wave-uniform bisection on the 16-bit value
                                     const uint32_t p = lo + ((hi - lo) >> 1);
                                     int c = 0;
 #pragma unroll
                                     for (int r = 0; r < NRV; ++r) c += __popcll(__ballot(val[r] && (ent[r] >> 16) <= p));
-                                    if (c >= L) hi = p;
-                                    else lo = p + 1;
+                                    if (c >= L) {
+                                        hi = p;
+                                        if (c <= L + 16) break;
+                                    } else {
+                                        lo = p + 1;
+                                    }
                                 }
-                                cut = lo + (uint32_t)M + 1u;
-                                const uint64_t b = val_to_bound(lo, M, sh[g].ub);  // >= L candidates of this chunk do not exceed it
+                                cut = hi + (uint32_t)M + 1u;
+                                const uint64_t b = val_to_bound(hi, M, sh[g].ub);  // >= L candidates of this chunk do not exceed it
                                 if (lane_v == 0 && b < sh[g].ext) atomicMin(&qbound[sh[g].q], (unsigned long long)b);
                             }
                             const int item = __builtin_amdgcn_readfirstlane(d->item[g]);
@@ -1976,24 +2001,39 @@ static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, 
             const int nsx_long = getenv("CIS_S4_NSX") ? atoi(getenv("CIS_S4_NSX")) : 128;
             const int dyn_long = getenv("CIS_S4_DYN") ? atoi(getenv("CIS_S4_DYN")) : 0;
             int* dbg4 = qctr + 9;
+            // waves per slot (NW4) and waves per SIMD the variant is compiled for (WPS): 4 x 64 threads at 4 (long chunks) / 6 (short) waves
+            // per SIMD were rounds 2-3; 8 waves per slot halve a slot's main pass, and three such workgroups per CU are 24 waves
+            const int nw4_long = getenv("CIS_S4_NWL") ? atoi(getenv("CIS_S4_NWL")) : CIS_S4_NW_LONG;
+            const int nw4_short = getenv("CIS_S4_NWS") ? atoi(getenv("CIS_S4_NWS")) : CIS_S4_NW_SHORT;
+            auto grid_of = [&](size_t lds4, int wps, int nw4) -> unsigned {
+                const int by_lds4 = (int)(163840 / lds4), by_waves4 = (wps * 4) / nw4;
+                const int per_cu4 = by_lds4 < by_waves4 ? by_lds4 : by_waves4;
+                const int64_t resident4 = 256 * (per_cu4 < 1 ? 1 : per_cu4);
+                return (unsigned)(want < resident4 ? ((want + 7) / 8) * 8 : resident4);
+            };
             if (!g.long_chunks) {
                 constexpr int WPE4 = (M == 16) ? 4 : CIS_S4_WPE;  // (M = 16: 41 KB of LDS hold three workgroups per CU anyway)
-                const size_t lds4 = scan4_lds(M, K, S4_LCAP);
-                const int by_lds4 = (int)(163840 / lds4);
-                const int per_cu4 = by_lds4 < WPE4 ? by_lds4 : WPE4;
-                const int64_t resident4 = 256 * (per_cu4 < 1 ? 1 : per_cu4);
-                const unsigned grid4 = (unsigned)(want < resident4 ? ((want + 7) / 8) * 8 : resident4);
-                hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_U, NW, WPE4, S4_LCAP>), dim3(grid4), dim3(NW * 64), lds4, st, items, tabs, slots, n_slots,
-                                   T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_short, 1 << 20, S4_NS, 0);
+                if (nw4_short == 8 && M != 16) {
+                    const size_t lds4 = scan4_lds(M, K, S4_LCAP, 8);
+                    hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_U, 8, WPE4, S4_LCAP>), dim3(grid_of(lds4, WPE4, 8)), dim3(8 * 64), lds4, st, items, tabs, slots,
+                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_short, 1 << 20, S4_NS, 0);
+                } else {
+                    const size_t lds4 = scan4_lds(M, K, S4_LCAP, NW);
+                    hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_U, NW, WPE4, S4_LCAP>), dim3(grid_of(lds4, WPE4, NW)), dim3(NW * 64), lds4, st, items, tabs, slots,
+                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_short, 1 << 20, S4_NS, 0);
+                }
             } else {
                 constexpr int WPE4 = (M == 16) ? 3 : 4;  // (M = 16: 49 KB of LDS = three workgroups per CU, 168 registers)
-                const size_t lds4 = scan4_lds(M, K, S4_LCAP_LONG);
-                const int by_lds4 = (int)(163840 / lds4);
-                const int per_cu4 = by_lds4 < WPE4 ? by_lds4 : WPE4;
-                const int64_t resident4 = 256 * (per_cu4 < 1 ? 1 : per_cu4);
-                const unsigned grid4 = (unsigned)(want < resident4 ? ((want + 7) / 8) * 8 : resident4);
-                hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_UL, NW, WPE4, S4_LCAP_LONG>), dim3(grid4), dim3(NW * 64), lds4, st, items, tabs, slots,
-                                   n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_long, frac_long, nsx_long, dyn_long);
+                if (nw4_long == 8 && M != 16) {
+                    constexpr int WPE8 = CIS_S4_WPE8;
+                    const size_t lds4 = scan4_lds(M, K, S4_LCAP_LONG, 8);
+                    hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_UL, 8, WPE8, S4_LCAP_LONG>), dim3(grid_of(lds4, WPE8, 8)), dim3(8 * 64), lds4, st, items, tabs, slots,
+                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_long, frac_long, nsx_long, dyn_long);
+                } else {
+                    const size_t lds4 = scan4_lds(M, K, S4_LCAP_LONG, NW);
+                    hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_UL, NW, WPE4, S4_LCAP_LONG>), dim3(grid_of(lds4, WPE4, NW)), dim3(NW * 64), lds4, st, items, tabs, slots,
+                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_long, frac_long, nsx_long, dyn_long);
+                }
             }
             if (getenv("CIS_SCAN4_DEBUG")) {  // diagnosis: how many slots the sample misjudged (blocks)
                 int h[6] = {0, 0, 0, 0, 0, 0};

@@ -175,6 +175,114 @@ __global__ __launch_bounds__(64) void k_plan(const CT* __restrict__ sorted, cons
     }
 }
 
+// Fused front end for small coarse codebooks (V <= 64: BASELINE configs C1-C5): the exact coarse distances of k_sqdist_rows2
+// (lopq/lopq/search.py:39 -> lopq/lopq/utils.py:33-53 arithmetic: numpy's pairwise order, compute type CT), the ascending rank of
+// k_rank (np.argsort, ties to the lower index) and the counting pass of the multisequence walk (k_plan<CT, false>) in ONE launch, one
+// wave per query: the 2 V distances never leave the CU between the three steps (three launches and two round trips through L2 of
+// the [2][nq][V] arrays before).  `sorted` / `order` still go to global memory for the emit pass and the tables.
+template <typename CT>
+__global__ __launch_bounds__(64) void k_front_small(const CT* __restrict__ X /* [nq][D] */, int D, int h, const CT* __restrict__ Cs /* [2][V][h] */,
+                                                    PwProg prog, const int64_t* __restrict__ gcount, const int64_t* __restrict__ loff,
+                                                    int nq, int V, int64_t quota, int seg_max, uint16_t* __restrict__ order /* [nq][2][V] */,
+                                                    CT* __restrict__ sorted /* [nq][2][V] */, PlanOut* __restrict__ plan,
+                                                    int* __restrict__ grp_cnt /* zeroed by the previous batch's k_plan_scan */) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* sb = reinterpret_cast<uint64_t*>(smem);            // [2V] distance bits
+    CT* sd = reinterpret_cast<CT*>(sb + 2 * V);                  // [2][V] ascending distances
+    uint16_t* so = reinterpret_cast<uint16_t*>(sb + 4 * V);      // [2][V] cluster of every rank (8 bytes reserved per value of sd)
+    int* t = reinterpret_cast<int*>(so + 2 * V);                 // [V] frontier
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const CT* xr = X + (int64_t)q * D;
+    for (int e = lane; e < 2 * V; e += 64) {
+        const int s = e / V, c = e - s * V;
+        const CT* x = xr + s * h;
+        const CT* cc = Cs + ((int64_t)s * V + c) * h;
+        auto elem = [&](int i) -> CT { const CT df = x[i] - cc[i]; return df * df; };
+        const CT d = pw_sum<CT>(prog, elem);
+        sb[e] = f2bits(d);
+    }
+    for (int i = lane; i < V; i += 64) t[i] = 0;
+    __syncthreads();
+    for (int e = lane; e < 2 * V; e += 64) {
+        const int s = e / V, v = e - s * V;
+        const uint64_t mine = sb[e];
+        int r = 0;
+        for (int u = 0; u < V; ++u) {
+            const uint64_t o = sb[s * V + u];
+            r += (o < mine) || (o == mine && u < v);
+        }
+        CT d;
+        if constexpr (sizeof(CT) == 4) d = __uint_as_float((uint32_t)mine);
+        else d = __longlong_as_double((long long)mine);
+        sd[s * V + r] = d;
+        so[s * V + r] = (uint16_t)v;
+        order[((int64_t)q * 2 + s) * V + r] = (uint16_t)v;
+        sorted[((int64_t)q * 2 + s) * V + r] = d;
+    }
+    __syncthreads();
+    const CT* d0 = sd;
+    const CT* d1 = sd + V;
+    const uint16_t* o0 = so;
+    const uint16_t* o1 = so + V;
+    // the counting pass of k_plan (same frontier walk, inputs in LDS)
+    int visited = 0, n_items = 0, max_i = -1, max_j = -1;
+    int64_t retrieved = 0, ncand = 0;
+    int rows = 1;
+    const int64_t total_cells = (int64_t)V * V;
+    while ((int64_t)visited < total_cells) {
+        uint64_t bk = ~0ull;
+        uint32_t bij = ~0u;
+        for (int i = lane; i < rows; i += 64) {
+            const int j = t[i];
+            if (j >= V) continue;
+            if (i > 0 && t[i - 1] <= j) continue;
+            const CT dist = d0[i] + d1[j];
+            const uint64_t kb = f2bits(dist);
+            const uint32_t ij = ((uint32_t)i << 16) | (uint32_t)j;
+            if (kb < bk || (kb == bk && ij < bij)) { bk = kb; bij = ij; }
+        }
+        if (rows > 1) {  // wave-uniform: the first step has one frontier cell, in lane 0
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint64_t ok = __shfl_xor(bk, off);
+                const uint32_t oij = __shfl_xor(bij, off);
+                if (ok < bk || (ok == bk && oij < bij)) { bk = ok; bij = oij; }
+            }
+        } else {
+            bij = (uint32_t)__builtin_amdgcn_readfirstlane((int)bij);
+        }
+        if (bij == ~0u) break;
+        const int bi = (int)(bij >> 16), bj = (int)(bij & 0xffff);
+        const int c0 = o0[bi], c1 = o1[bj];
+        const int64_t cell = (int64_t)c0 * V + c1;
+        const int64_t gc = gcount[cell];
+        const int64_t ls = loff[cell];
+        const int64_t ll = loff[cell + 1] - ls;
+        if (ll > 0) {
+            n_items += (int)((ll + seg_max - 1) / seg_max);
+            ncand += ll;
+            max_i = bi > max_i ? bi : max_i;
+            max_j = bj > max_j ? bj : max_j;
+        }
+        visited += 1;
+        retrieved += gc;
+        __syncthreads();
+        if (lane == 0) t[bi] = bj + 1;
+        if (bi + 2 > rows) rows = (bi + 2 < V) ? bi + 2 : V;
+        __syncthreads();
+        if (retrieved >= quota) break;
+    }
+    if (lane == 0) {
+        PlanOut p;
+        p.visited = visited; p.n_items = n_items; p.ntab0 = max_i + 1; p.ntab1 = max_j + 1; p.ncand = ncand;
+        plan[q] = p;
+    }
+    for (int i = lane; i < max_i + 1 + max_j + 1; i += 64) {
+        const int g = i <= max_i ? (int)o0[i] : V + (int)o1[i - (max_i + 1)];
+        atomicAdd(&grp_cnt[g * GRP_SUB + (q % GRP_SUB)], 1);
+    }
+}
+
 // The same plan for indexes with thousands of coarse clusters (the reference's release configurations use V = 2048 / 4096:
 // millions of tiny cells, hundreds to thousands of cells per query at quota 10000), where one frontier step per visited
 // cell is the whole cost of a search.  The multisequence order is the order of the sums s(i, j) = fl(d0[i] + d1[j]) (rank
@@ -548,7 +656,8 @@ __global__ __launch_bounds__(1024) void k_plan_scan(const PlanOut* __restrict__ 
                                                     int64_t* __restrict__ tab_off, int64_t* __restrict__ totals,
                                                     unsigned long long* __restrict__ qbound /* [nq] -> +inf */,
                                                     volatile int64_t* __restrict__ host_totals /* pinned, mapped */, int64_t seq,
-                                                    const int* __restrict__ grp_cnt, int* __restrict__ grp_base, int n_groups) {
+                                                    int* __restrict__ grp_cnt /* read, then zeroed: the next batch's count pass finds it clean */,
+                                                    int* __restrict__ grp_base, int n_groups) {
     constexpr int R = 8;  // rounds held in registers; more queries than 8192 take the slow tail loop below
     __shared__ int s_wi[R][16], s_wt[R][16];  // wave totals per round
     __shared__ int64_t s_cand[16];
@@ -576,7 +685,11 @@ __global__ __launch_bounds__(1024) void k_plan_scan(const PlanOut* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int g = g0 + lane * 16 + i;
-                if (g < n_groups) grp_base[g] = r;
+                if (g < n_groups) {
+                    grp_base[g] = r;
+                    grp_cnt[g] = 0;              // counters: clean for the next batch's count pass (k_front_small does not zero them)
+                    grp_cnt[n_groups + g] = 0;   // cursors (grp_cur = grp_cnt + n_groups): clean for this batch's emit pass
+                }
                 r += c[i];
             }
             run += __shfl(x, 63);
@@ -4145,13 +4258,13 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     int xp_dtype = q_dtype;
     if (m->has_pca) {
         CIS_TRY(ix->w_xp.reserve((size_t)nq * D * sizeof(float)));
-        CIS_TRY(cis_dev_apply_pca(m, dQ, q_dtype, nq, ix->w_xp.as<float>(), st));
+        CIS_TRY(cis_dev_apply_pca(m, dQ, q_dtype, nq, ix->w_xp.as<float>(), st, &ix->w_y64));
         xp = ix->w_xp.p;
         xp_dtype = CIS_F32;
     }
     const void* xc;
     int ct;
-    CIS_TRY(cis_dev_coarse_type(m, xp, xp_dtype, nq, &xc, &ct, st));
+    CIS_TRY(cis_dev_coarse_type(m, xp, xp_dtype, nq, &xc, &ct, st, &ix->w_x64));
     const size_t csz = (ct == CIS_F32) ? 4 : 8;
     // 2. coarse distances, rank
     CIS_TRY(ix->w_cd.reserve((size_t)2 * nq * V * csz));
@@ -4164,7 +4277,12 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     int64_t* totals = tab_off + (nq + 1);
     unsigned long long* qbound = reinterpret_cast<unsigned long long*>(totals + 4);  // per query: cross-cell bound of the scan
     PlanOut* plan = ix->w_plan.as<PlanOut>();
-    CIS_TRY(ix->w_grp.reserve((size_t)(6 * V * GRP_SUB + 2) * sizeof(int)));
+    {
+        const void* grp_before = ix->w_grp.p;
+        CIS_TRY(ix->w_grp.reserve((size_t)(6 * V * GRP_SUB + 2) * sizeof(int)));
+        if (ix->w_grp.p != grp_before)  // fresh memory: the counters start clean (afterwards every k_plan_scan leaves them clean)
+            CIS_CHECK_HIP(hipMemsetAsync(ix->w_grp.p, 0, ix->w_grp.cap, st));
+    }
     int* grp_cnt = ix->w_grp.as<int>();         // [2V][GRP_SUB] tables per (split, cluster, query % GRP_SUB)
     int* grp_cur = grp_cnt + 2 * V * GRP_SUB;    // cursors
     int* grp_base = grp_cnt + 4 * V * GRP_SUB;   // exclusive scan
@@ -4208,10 +4326,22 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         plan_fb = ix->w_planfb.as<int>();
         vis_list = ix->w_vis.as<uint32_t>();
     }
-    CIS_TRY(cis_launch_sqdist_both(m, xc, ct, nq, ix->w_cd.p, st));
     const size_t plan_lds = (size_t)V * sizeof(int);
     int Vp2 = 64;
     while (Vp2 < V) Vp2 <<= 1;
+    static const bool no_fused_front = getenv("CIS_NO_FUSED_FRONT") != nullptr;
+    const bool fused_front = V <= 64 && !par_plan && !no_fused_front;
+    if (fused_front) {
+        // coarse distances + rank + counting pass of the multisequence walk in one launch (k_front_small)
+        const size_t flds = (size_t)V * (32 + 4 + 4);
+        if (ct == CIS_F32)
+            hipLaunchKernelGGL(k_front_small<float>, dim3(nq), dim3(64), flds, st, (const float*)xc, D, h, m->d_Cs32, m->prog_h, ix->gcount_ptr(),
+                               ix->loff_ptr(), nq, V, quota, seg_max, ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), plan, grp_cnt);
+        else
+            hipLaunchKernelGGL(k_front_small<double>, dim3(nq), dim3(64), flds, st, (const double*)xc, D, h, m->d_Cs64, m->prog_h, ix->gcount_ptr(),
+                               ix->loff_ptr(), nq, V, quota, seg_max, ix->w_order.as<uint16_t>(), ix->w_sorted.as<double>(), plan, grp_cnt);
+    } else {
+    CIS_TRY(cis_launch_sqdist_both(m, xc, ct, nq, ix->w_cd.p, st));
     if (ct == CIS_F32) {
         if (V > 256 && Vp2 <= 4096)
             hipLaunchKernelGGL(k_rank_sort<float>, dim3(nq, 2), dim3(256), (size_t)Vp2 * 16, st, ix->w_cd.as<float>(), nq, V, Vp2,
@@ -4221,10 +4351,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                                ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
         if (par_plan)
             hipLaunchKernelGGL((k_plan_par<float, false>), dim3(nq), dim3(256), (size_t)2 * V * sizeof(float), st, ix->w_sorted.as<float>(), ix->w_order.as<uint16_t>(),
-                               ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
+                               ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
                                nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap);
         hipLaunchKernelGGL((k_plan<float, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<float>(),
-                           ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota,
+                           ix->w_order.as<uint16_t>(), ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota,
                            seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr, plan_fb);
     } else {
         if (V > 256 && Vp2 <= 4096)
@@ -4235,11 +4365,12 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                                V, ix->w_order.as<uint16_t>(), ix->w_sorted.as<double>(), grp_cnt);
         if (par_plan)
             hipLaunchKernelGGL((k_plan_par<double, false>), dim3(nq), dim3(256), (size_t)2 * V * sizeof(double), st, ix->w_sorted.as<double>(), ix->w_order.as<uint16_t>(),
-                               ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
+                               ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
                                nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap);
         hipLaunchKernelGGL((k_plan<double, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
-                           ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota,
+                           ix->w_order.as<uint16_t>(), ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota,
                            seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr, plan_fb);
+    }
     }
     if (par_plan && getenv("CIS_DEBUG_PLAN")) {
         std::vector<int> fbh(nq);
@@ -4355,10 +4486,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     if (ct == CIS_F32) {
         if (par_plan)
             hipLaunchKernelGGL((k_plan_par<float, true>), dim3(nq), dim3(256), 0, st, ix->w_sorted.as<float>(), ix->w_order.as<uint16_t>(),
-                               ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota, seg_max, plan, item_off, tab_off, items,
+                               ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota, seg_max, plan, item_off, tab_off, items,
                                tabs, nullptr, grp_base, grp_cur, tab_order, vis_list, plan_fb, vis_cap);
         hipLaunchKernelGGL((k_plan<float, true>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<float>(),
-                           ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota,
+                           ix->w_order.as<uint16_t>(), ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota,
                            seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order, plan_fb);
         if (n_tabs > 0)
             launch_tables<float>(n_tabs, tab_lds, st, (const float*)xc, m->d_Cs32, m->d_Rt, m->d_mus, m->d_subs, tabs, tab_order, V, h,
@@ -4366,10 +4497,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     } else {
         if (par_plan)
             hipLaunchKernelGGL((k_plan_par<double, true>), dim3(nq), dim3(256), 0, st, ix->w_sorted.as<double>(), ix->w_order.as<uint16_t>(),
-                               ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota, seg_max, plan, item_off, tab_off, items,
+                               ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota, seg_max, plan, item_off, tab_off, items,
                                tabs, nullptr, grp_base, grp_cur, tab_order, vis_list, plan_fb, vis_cap);
         hipLaunchKernelGGL((k_plan<double, true>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
-                           ix->w_order.as<uint16_t>(), ix->d_gcount.as<int64_t>(), ix->loff_ptr(), nq, V, quota,
+                           ix->w_order.as<uint16_t>(), ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota,
                            seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order, plan_fb);
         if (n_tabs > 0)
             launch_tables<double>(n_tabs, tab_lds, st, (const double*)xc, m->d_Cs64, m->d_Rt, m->d_mus, m->d_subs, tabs, tab_order, V,
@@ -4643,7 +4774,8 @@ static int search_all(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_
     CIS_REQUIRE(ix != nullptr, "index is NULL");
     CIS_REQUIRE(q_dtype == CIS_F32 || q_dtype == CIS_F64, "q_dtype must be 4 or 8");
     CIS_REQUIRE(nq >= 0, "nq must be >= 0");
-    CIS_TRY(cis_index_ready(ix));
+    CIS_TRY(cis_index_ready(ix->base ? ix->base : ix));
+    ix->sync_from_base();  // a view reads the storage of its base
     CIS_CHECK_HIP(hipSetDevice(ix->m->device));
     for (int i = 0; i < 4; ++i) ix->stats[i] = 0;
     ix->stats_pending_seq = 0;

@@ -171,6 +171,23 @@ class LOPQSearcherHIP(LOPQSearcherBase):
                 owner = np.ascontiguousarray(self._shard[2], dtype=np.int32)
             _lib.check(L.cis_index_set_shard(self._ix, int(rank), int(world), _lib.ptr(owner)))
 
+    def view(self):
+        """A second searcher over the SAME index in HBM with its own per-batch workspaces (cis_index_create_view): batches searched
+        through the view and through this object can be in flight at once, each on its own stream -- the small kernels of one batch's
+        front end fill the tail of the other's scan.  Read-only: inserts go through this object, ordered against the view's searches by
+        the caller.  The view shares the id maps and must be closed before this searcher."""
+        v = object.__new__(type(self))
+        LOPQSearcherBase.__init__(v)
+        v.model, v._shard, v._M = self.model, self._shard, self._M
+        v._slot_of, v._id_of = self._slot_of, self._id_of
+        v._model_handle, v._input_dim = self._model_handle, self._input_dim
+        v._base = self  # keeps the base alive
+        out = _lib.c_void_p()
+        _lib.check(_lib.lib().cis_index_create_view(_lib.ctypes.byref(out), self._ix))
+        v._ix = out.value
+        v.nb_indexed = self.nb_indexed
+        return v
+
     def close(self):
         if self._ix:
             _lib.lib().cis_index_destroy(self._ix)

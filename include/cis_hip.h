@@ -129,6 +129,12 @@ int cis_multisequence(const void* X, int x_dtype, const void* C0, const void* C1
 /* The index keeps a borrowed pointer to `m`: destroy the index first. */
 int cis_index_create(cis_index** out, cis_model* m);
 void cis_index_destroy(cis_index* ix);
+/* A search VIEW of `base`: shares its storage (codes, ids, offsets, cell sizes -- lopq/lopq/search.py:310-382's `index` dict) and
+ * owns only per-batch workspaces and counters, so that two query batches can be in flight at once, each handle on its own stream
+ * (the reference answers independent queries from 16 independent gunicorn workers over one LMDB index, searcher_lopqhbase.py:198-206:
+ * this is the same sharing inside one process).  A view is read-only (inserts / cell reads go to the base), must be destroyed before
+ * the base, and inserts into the base must be stream-ordered against the views' searches by the caller. */
+int cis_index_create_view(cis_index** out, cis_index* base);
 
 /* Cell-sharded operation (one process per GPU): this handle stores only the cells with
  * owner[cell] == rank but counts every cell, so that all ranks derive the same global

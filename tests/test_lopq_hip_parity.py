@@ -996,3 +996,50 @@ def test_tiny_cells_prefilter_equals_exact_kernels(V, M, D, dup, monkeypatch):
     np.testing.assert_array_equal(out["ids"].cpu().numpy(), want["ids"].cpu().numpy())
     np.testing.assert_array_equal(out["dists"].cpu().numpy().view(np.uint64), want["dists"].cpu().numpy().view(np.uint64))
     s.close()
+
+
+def test_search_views_share_the_index_and_pipeline_on_two_streams():
+    """cis_index_create_view: a view answers exactly like its base (same storage, own workspaces), batches alternated between
+    base and view on two streams give the serial results, a view is read-only, and an insert into the base is seen by the view."""
+    import torch
+    z, X, Q = load_golden("c2")
+    m = hip_model(z)
+    s = _build_searcher("c2", z, X, m)
+    v = s.view()
+    q = torch.as_tensor(Q).cuda().contiguous()
+    want = {k: t.cpu().numpy() for k, t in s.search_batch_dev(q, quota=2000, limit=50).items()}
+    got = {k: t.cpu().numpy() for k, t in v.search_batch_dev(q, quota=2000, limit=50).items()}
+    for k in ("ids", "n_found", "visited"):
+        np.testing.assert_array_equal(got[k], want[k])
+    np.testing.assert_array_equal(got["dists"].view(np.uint64), want["dists"].view(np.uint64))
+    # eight batches of different queries, alternating handles and streams, nothing synchronised in between
+    batches = [q[i::4].contiguous() for i in range(4)] * 2
+    serial = [{k: t.cpu().numpy() for k, t in s.search_batch_dev(b, quota=1000, limit=30).items()} for b in batches]
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for i, b in enumerate(batches):
+        if i % 2:
+            with torch.cuda.stream(side):
+                outs.append(v.search_batch_dev(b, quota=1000, limit=30))
+        else:
+            outs.append(s.search_batch_dev(b, quota=1000, limit=30))
+    torch.cuda.synchronize()
+    for o, w in zip(outs, serial):
+        for k in ("ids", "n_found", "visited"):
+            np.testing.assert_array_equal(o[k].cpu().numpy(), w[k])
+        np.testing.assert_array_equal(o["dists"].cpu().numpy().view(np.uint64), w["dists"].view(np.uint64))
+    # read-only
+    with pytest.raises(ValueError, match="view"):
+        v.add_codes_array(z["coarse"][:4], z["fine"][:4], ids=np.arange(10 ** 9, 10 ** 9 + 4))
+    # the view follows the base: a new item (a copy of the first query's best hit: same distance, later position) shows up
+    best = int(want["ids"][0, 0])
+    row = best if best < len(z["coarse"]) else 0  # _build_searcher's ids are the row numbers
+    s.add_codes_array(z["coarse"][row:row + 1], z["fine"][row:row + 1], ids=np.array([10 ** 12], dtype=np.int64))
+    torch.cuda.synchronize()
+    a = s.search_batch_dev(q[:1].contiguous(), quota=2000, limit=50)
+    b = v.search_batch_dev(q[:1].contiguous(), quota=2000, limit=50)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(a["ids"].cpu().numpy(), b["ids"].cpu().numpy())
+    assert (a["ids"].cpu().numpy() == 10 ** 12).any()
+    v.close()

@@ -7,6 +7,7 @@ if not lines:
 l = json.loads(lines[-1])
 r = l["roofline"]
 b = r.get("binding", {})
+b = b.get("model", b)
 print("%s q/s %.0f step %.3f ms | %s %.3f ms accounting %.3f (moved %.2f lds %.2f valu %.2f) | stages %s | parity %s recall %s" % (
     l["config"]["name"], l["value"], l["ms_per_step"], r["kernel"], r["avg_launch_ms"], r.get("accounting_frac", r["frac"]),
     (b.get("hbm_moved_bytes") or {}).get("frac") or 0, (b.get("lds_gather") or {}).get("frac") or 0, (b.get("valu_issue") or {}).get("frac") or 0,
