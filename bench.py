@@ -321,11 +321,18 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
     # Steps are independent batches: `pipeline` of them are in flight at once, each through its own VIEW of the index (shared
     # codes / ids in HBM, private per-batch workspaces: cis_index_create_view) on its own HIP stream -- the launch-bound small
     # kernels of one batch's front end, tables and slot building fill the tail of the previous batch's scan and its merge.
-    P = max(1, ctx.pipeline) if sharded is None else 1
-    lanes = [(searcher, torch.cuda.current_stream(device))]
-    for _ in range(P - 1):
-        lanes.append((searcher.view(), torch.cuda.Stream(device=device)))
-    st.lanes = lanes
+    P = max(1, ctx.pipeline)
+    if sharded is None:
+        lanes = [(searcher, torch.cuda.current_stream(device))]
+        for _ in range(P - 1):
+            lanes.append((searcher.view(), torch.cuda.Stream(device=device)))
+    elif sharded.row is not None:  # the sharded searcher rotates its partial searches over its own lanes (search_begin)
+        sharded.row.pipeline_depth = P
+        lanes = list(sharded.row.lanes())
+    else:
+        P = 1
+        lanes = [(searcher, torch.cuda.current_stream(device))]
+    st.lanes = lanes if sharded is None else lanes[:1]  # (release_state closes the views it owns; the sharded searcher keeps its own)
 
     def qb(b):  # a step = one batch of NQ queries PER QUERY GROUP: group g answers its own batches, the S ranks of a group the same
         return qbatches[(b * R + g_q) % len(qbatches)]
@@ -333,13 +340,16 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
     with wd.phase("%s: warm-up steps (first collectives of the search path)" % cfg_name, 300):
         for b in range(warmup):
             step(qb(b))
+        if sharded is not None and sharded.row is not None:  # every lane of the pipelined form once (workspaces of the views)
+            for b in range(len(lanes)):
+                sharded.search_end(sharded.search_begin(qb(b), quota=QUOTA, limit=LIMIT))
         torch.cuda.synchronize()
     # timed region: only the pair of HIP events around the scan kernel (roofline); the per-stage events are small bubbles
     # between kernels, so the stage breakdown is taken from a few extra steps after the timed region
     for sv, _ in lanes:
         sv.set_profiling(True, scan_only=True)
         sv.read_profile()
-    if P > 1:  # the views' workspaces warm up too
+    if P > 1 and sharded is None:  # the views' workspaces warm up too
         for k in range(1, P):
             with torch.cuda.stream(lanes[k][1]):
                 lanes[k][0].search_batch_dev(qb(0), quota=QUOTA, limit=LIMIT)
@@ -364,16 +374,25 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
         else:
             # steps are independent batches: the exchange + merge of batch b (side stream, RCCL) overlap the partial search
             # of batch b+1 (compute stream)
+            def stats_of(hh):
+                ls = hh.get("searcher", searcher).last_stats() if isinstance(hh, dict) else searcher.last_stats()
+                return ls["candidates"], ls["items"]
             h = sharded.search_begin(qb(warmup), quota=QUOTA, limit=LIMIT)
-            cand += searcher.last_stats()["candidates"]
-            cand_items += searcher.last_stats()["items"]
+            c_, i_ = stats_of(h)
+            cand += c_
+            cand_items += i_
+            # check=False: no host read in the exchange (fixed-size payload all-gather, offsets by a kernel); the overflow flags of
+            # all steps are read once after the loop
+            flags = []
             for b in range(1, steps):
                 h2 = sharded.search_begin(qb(warmup + b), quota=QUOTA, limit=LIMIT)
-                cand += searcher.last_stats()["candidates"]
-                cand_items += searcher.last_stats()["items"]
-                sharded.search_end(h)
+                c_, i_ = stats_of(h2)
+                cand += c_
+                cand_items += i_
+                flags.append(sharded.search_end(h, check=False).get("overflow"))
                 h = h2
-            sharded.search_end(h)
+            flags.append(sharded.search_end(h, check=False).get("overflow"))
+            st.exchange_flags = [f for f in flags if f is not None]
         scan_name = searcher.last_stats()["scan_kernel"]
         torch.cuda.synchronize()
         if world > 1:
@@ -487,6 +506,12 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
                   "insert": "device-side merge of %d codes into the HBM index (cis_index_add_dev%s)"
                             % (len(my_chunks) * chunk_n, " after the RCCL all-to-all" if ctx.use_dist else "")},
     }
+    if getattr(st, "exchange_flags", None):
+        n_over = int(torch.stack([f.reshape(()) for f in st.exchange_flags]).sum().item())
+        result["config"]["exchange"] = ("packed all-gather of a fixed %.1f x even share per rank, offsets on the device, no host read per batch; "
+                                        "%d of %d steps exceeded the fixed size (those are repeated with the exact size outside a timed loop)"
+                                        % (1.5, n_over, len(st.exchange_flags)))
+        result["config"]["exchange_overflows"] = n_over
     st.R = R
     return result, st
 

@@ -4896,6 +4896,15 @@ static int merge_parts(const cis_hit* d_parts, int world, int nq, int L, int64_t
     return CIS_OK;
 }
 
+// Records of shard w for query q that really ARRIVED: with the fixed-size exchange a shard that held more than `stride` records was
+// cut there (the overflow flag tells the caller to repeat the exchange); the merge must not read past the cut.
+static __device__ __forceinline__ int arrived(const int32_t* __restrict__ cnt, const int64_t* __restrict__ off, int64_t stride, int w, int nq, int q) {
+    const int64_t o = off[(int64_t)w * nq + q];
+    const int64_t room = stride - o;
+    const int c = cnt[(int64_t)w * nq + q];
+    return room <= 0 ? 0 : (c < room ? c : (int)room);
+}
+
 // Merge of PACKED per-shard hit lists: shard w contributed parts[w*stride + off[w*nq+q] .. + cnt[w*nq+q]) for query q
 // (its valid hits only, in query order).  One wave per query; same ranking key as everywhere: (dist, visit_rank, pos).
 template <int CAPM, int WPB /* waves (= queries) per workgroup */>
@@ -4911,12 +4920,43 @@ __global__ __launch_bounds__(WPB * 64) void k_merge_packed(const cis_hit* __rest
     uint64_t* ka = reinterpret_cast<uint64_t*>(smem) + (size_t)wq * 3 * CAPM;
     uint64_t* kb = ka + CAPM;
     uint64_t* pay = kb + CAPM;  // index of the hit in parts
+    // A query whose hits all come from ONE shard (the rule with few coarse clusters: a V = 16 query visits one or two cells, and a
+    // cell lives on one shard): that list arrives ranked, so it is copied -- no LDS, no sort.  The merge then costs what the number
+    // of non-empty lists costs, not what the number of shards does.
+    {
+        int nonempty = 0, lone = 0, lone_n = 0;
+        for (int w = 0; w < world; ++w) {
+            const int v = arrived(cnt, off, stride, w, nq, q);
+            if (v > 0) { ++nonempty; lone = w; lone_n = v; }
+        }
+        if (nonempty <= 1) {
+            const int nv1 = lone_n < limit ? lone_n : limit;
+            const int64_t base = nonempty ? (int64_t)lone * stride + off[(int64_t)lone * nq + q] : 0;
+            const int64_t o1 = (int64_t)q * limit;
+            for (int x = lane; x < limit; x += 64) {
+                int64_t id = -1;
+                double dist = __longlong_as_double(0x7ff8000000000000LL);
+                int32_t cell = -1;
+                uint32_t pos = 0xffffffffu;
+                if (x < nv1) {
+                    const cis_hit hh = parts[base + x];
+                    id = hh.id; dist = hh.dist; cell = hh.cell; pos = hh.pos;
+                }
+                out_ids[o1 + x] = id;
+                out_dists[o1 + x] = dist;
+                if (out_cells) out_cells[o1 + x] = cell;
+                if (out_pos) out_pos[o1 + x] = pos;
+            }
+            if (lane == 0 && out_n) out_n[q] = nv1;
+            return;
+        }
+    }
     int have = 0, l = 0, e = 0, total = 0;
     while (true) {
         int n = have;
         int room = CAPM - have;
         while (l < world && room > 0) {
-            const int valid = cnt[(int64_t)l * nq + q];
+            const int valid = arrived(cnt, off, stride, l, nq, q);
             const int take = (valid - e < room) ? (valid - e) : room;
             const int64_t base = (int64_t)l * stride + off[(int64_t)l * nq + q] + e;
             for (int x = lane; x < take; x += 64) {
@@ -4983,7 +5023,7 @@ __global__ __launch_bounds__(256) void k_merge_packed_ranked(const cis_hit* __re
     __shared__ int s_tot;
     if (threadIdx.x == 0) {
         int t = 0;
-        for (int w = 0; w < world; ++w) t += cnt[(int64_t)w * nq + q];
+        for (int w = 0; w < world; ++w) t += arrived(cnt, off, stride, w, nq, q);
         s_tot = t;
     }
     __syncthreads();
@@ -4997,14 +5037,14 @@ __global__ __launch_bounds__(256) void k_merge_packed_ranked(const cis_hit* __re
     };
     for (int w = 0; w < world; ++w) {
         const cis_hit* lst = parts + (int64_t)w * stride + off[(int64_t)w * nq + q];
-        const int n = cnt[(int64_t)w * nq + q];
+        const int n = arrived(cnt, off, stride, w, nq, q);
         for (int a = threadIdx.x; a < n; a += blockDim.x) {
             const cis_hit e = lst[a];
             int64_t rank = a;
             for (int w2 = 0; w2 < world && rank < limit; ++w2) {
                 if (w2 == w) continue;
                 const cis_hit* l2 = parts + (int64_t)w2 * stride + off[(int64_t)w2 * nq + q];
-                int lo = 0, hi = cnt[(int64_t)w2 * nq + q];
+                int lo = 0, hi = arrived(cnt, off, stride, w2, nq, q);
                 while (lo < hi) {  // records of list w2 with a smaller key
                     const int mid = (lo + hi) >> 1;
                     if (less(l2[mid], e)) lo = mid + 1;
@@ -5028,6 +5068,55 @@ __global__ __launch_bounds__(256) void k_merge_packed_ranked(const cis_hit* __re
         if (out_pos) out_pos[o + x] = 0xffffffffu;
     }
     if (threadIdx.x == 0 && out_n) out_n[q] = nv;
+}
+
+// Offsets of the packed exchange on the device: cnt_all [world][nq] (what the counts all-gather delivered) -> off [world][nq] =
+// exclusive scan of a shard's counts over the queries, totals[w], and *overflow = 1 when a shard holds more records than the fixed
+// stride of the payload all-gather (the caller then repeats the exchange with the exact stride).  Replaces a torch.cumsum + a host
+// read per batch (round 3).  One workgroup per shard.
+__global__ __launch_bounds__(1024) void k_exchange_offsets(const int32_t* __restrict__ cnt_all, int nq, int64_t stride, int64_t* __restrict__ off,
+                                                           int64_t* __restrict__ totals, int32_t* __restrict__ overflow) {
+    __shared__ int64_t s_w[16];
+    __shared__ int64_t s_run;
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int32_t* c = cnt_all + (int64_t)w * nq;
+    int64_t* o = off + (int64_t)w * nq;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < nq; q0 += 1024) {
+        const int q = q0 + tid;
+        const int64_t v = q < nq ? (int64_t)c[q] : 0;
+        int64_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_w[wv] = x;
+        __syncthreads();
+        int64_t base = s_run;
+        for (int k = 0; k < wv; ++k) base += s_w[k];
+        if (q < nq) o[q] = base + x - v;
+        __syncthreads();
+        if (tid == 1023) s_run = base + x;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        totals[w] = s_run;
+        if (s_run > stride) atomicExch(overflow, 1);
+    }
+}
+
+extern "C" int cis_exchange_offsets_dev(const int32_t* d_cnt_all, int world, int nq, int64_t stride, int64_t* d_off, int64_t* d_totals,
+                                        int32_t* d_overflow, void* stream) {
+    CIS_REQUIRE(world >= 1 && nq >= 0 && stride >= 0, "bad exchange arguments");
+    CIS_REQUIRE(d_cnt_all && d_off && d_totals && d_overflow, "NULL buffer");
+    CIS_TRY(cis_lazy_init());
+    hipStream_t st = (hipStream_t)stream;
+    CIS_CHECK_HIP(hipMemsetAsync(d_overflow, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_exchange_offsets, dim3((unsigned)world), dim3(1024), 0, st, d_cnt_all, nq, stride, d_off, d_totals, d_overflow);
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
 }
 
 extern "C" int cis_merge_packed_dev(const cis_hit* d_parts, int world, int64_t stride, const int64_t* d_off,

@@ -59,6 +59,39 @@ def all_gather_hits(hits, group=None):
     return all_gather_stack(hits, group)
 
 
+def exchange_stride(nq, L, world, slack=1.5):
+    """Fixed per-rank size (records) of the payload all-gather: a rank owns 1 / world of the cells, so it holds about nq * L / world
+    of the batch's hits; `slack` times that (never more than nq * L, what a rank can hold at all).  A rank above it raises the
+    overflow flag and the exchange is repeated with the exact size."""
+    full = int(nq) * int(L)
+    if world <= 1:
+        return max(full, 1)
+    return max(1, min(full, int(full / float(world) * slack) + 1024))
+
+
+def exchange_packed_fixed(packed, cnt, stride, group=None):
+    """The packed exchange WITHOUT a host read (round 4): the payload all-gather moves a fixed `stride` records per rank
+    (exchange_stride), the offsets come from a kernel (cis_exchange_offsets_dev) and a device-side flag says whether some rank
+    held more than `stride` records.  Device tensors only.  Returns (parts [world, stride, 4], off [world, nq] int64,
+    cnt_all [world, nq] int32, overflow int32 [1])."""
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    world = dist.get_world_size(group)
+    nq = int(cnt.shape[0])
+    dev = cnt.device
+    cnt_all = all_gather_stack(cnt, group)
+    off = torch.empty((world, nq), dtype=torch.int64, device=dev)
+    totals = torch.empty(world, dtype=torch.int64, device=dev)
+    overflow = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().cis_exchange_offsets_dev(cnt_all.data_ptr(), world, nq, int(stride), off.data_ptr(), totals.data_ptr(),
+                                                   overflow.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+    if packed.shape[0] < stride:
+        raise ValueError("the packed buffer holds %d records, the exchange stride is %d" % (packed.shape[0], stride))
+    parts = all_gather_stack(packed[:stride].contiguous(), group)
+    return parts, off, cnt_all, overflow
+
+
 def exchange_packed(packed, cnt, group=None):
     """The packed exchange: every rank contributes its valid hits only.  packed [>= total, 4] int64 (cis_hit records of
     this rank in query order, first `total` rows valid), cnt [nq] int32.  Returns (parts [world, stride, 4],
@@ -223,20 +256,50 @@ class ShardedSearcher(object):
         return self.local.get_nb_indexed()
 
     # -- pipelined form: the exchange + merge of batch b run on a side stream while the caller launches batch b+1 --------
+    pipeline_depth = 3   # partial searches in flight: consecutive search_begin calls rotate over this many views of the local index
+
+    def lanes(self):
+        """[(searcher, stream or None)]: the local index and its views (cis_index_create_view: shared storage, own workspaces), each
+        on its own stream, so that the small kernels of one batch's front end overlap another batch's scan."""
+        import torch
+        if getattr(self, "_lanes", None) is None:
+            self._lanes = [(self.local, None)]
+            for _ in range(max(1, int(self.pipeline_depth)) - 1):
+                self._lanes.append((self.local.view(), torch.cuda.Stream()))
+            self._turn = 0
+        return self._lanes
+
+    def _lane(self):
+        """(searcher, stream) of the next search_begin."""
+        lanes = self.lanes()
+        lane = lanes[self._turn % len(lanes)]
+        self._turn += 1
+        return lane
+
     def search_begin(self, q, quota=10, limit=None):
-        """This rank's partial search (asynchronous, current stream).  Returns a handle for search_end."""
+        """This rank's partial search (asynchronous).  Returns a handle for search_end.  Consecutive calls run on different lanes
+        (see _lane): the caller's current stream for the first, side streams that wait for the caller's stream for the others."""
         import torch
         L = self.local._dev_args(q, quota, limit)[0]
-        p = self.local.search_partial_packed_dev(q, quota=quota, limit=limit)
-        ev = torch.cuda.Event()
-        ev.record()
-        return {"p": p, "ev": ev, "nq": int(q.shape[0]), "L": L}
+        sv, stream = self._lane()
+        if stream is None:
+            p = sv.search_partial_packed_dev(q, quota=quota, limit=limit)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            stream.wait_stream(torch.cuda.current_stream())  # the queries were produced on the caller's stream
+            q.record_stream(stream)
+            with torch.cuda.stream(stream):
+                p = sv.search_partial_packed_dev(q, quota=quota, limit=limit)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+        return {"p": p, "ev": ev, "nq": int(q.shape[0]), "L": L, "searcher": sv}
 
-    def search_end(self, h):
+    def search_end(self, h, check=True):
         """Exchange + merge of a search_begin handle on the side stream; the result tensors are safe to use on the
-        current stream when this returns (it waits for the side stream's event, not for the device)."""
+        current stream when this returns (it waits for the side stream's event, not for the device).  check=False: no host
+        read at all -- the caller verifies `overflowed(outs)` once after its loop."""
         import torch
-        from .lopq.search import merge_packed_dev
         if self._side is None:
             self._side = torch.cuda.Stream()
         cur = torch.cuda.current_stream()
@@ -245,8 +308,7 @@ class ShardedSearcher(object):
             self._side.wait_event(h["ev"])
             for t in (p["packed"], p["cnt"], p["visited"]):
                 t.record_stream(self._side)
-            parts, off, cnt_all = exchange_packed(p["packed"], p["cnt"], self.group)
-            out = merge_packed_dev(parts, off, cnt_all, h["nq"], h["L"])  # HIP: one wave per query up to 3072, ranked places above
+            out = self._exchange_and_merge(p, h["nq"], h["L"], check=check)
             done = torch.cuda.Event()
             done.record(self._side)
         for t in out.values():
@@ -255,6 +317,33 @@ class ShardedSearcher(object):
         cur.wait_event(done)
         out["visited"] = p["visited"]
         return out
+
+    fixed_stride = __import__("os").environ.get("CIS_FIXED_STRIDE", "1") != "0"   # device-side offsets + fixed-size payload all-gather (no host read per batch); False: the round-3 protocol
+    stride_slack = 1.5    # x the even share nq * L / world (hits follow the query distribution, not the cell populations: +-20 % seen)
+
+    def _exchange_and_merge(self, p, nq, L, check=True):
+        """Exchange + merge of one partial result on the current stream.  check=True reads the overflow flag (one host read) and
+        repeats the exchange with the exact size when a rank held more than the fixed stride; check=False leaves the flag in
+        out["overflow"] for the caller to verify later (pipelined loops: one read after the loop, `overflowed(outs)`)."""
+        import torch.distributed as dist
+        from .lopq.search import merge_packed_dev
+        on_device = p["packed"].is_cuda
+        if self.fixed_stride and on_device and L > 0 and nq > 0:
+            stride = exchange_stride(nq, L, self.world, self.stride_slack)
+            parts, off, cnt_all, overflow = exchange_packed_fixed(p["packed"], p["cnt"], stride, self.group)
+            out = merge_packed_dev(parts, off, cnt_all, nq, L)
+            out["overflow"] = overflow
+            if not check or int(overflow.item()) == 0:
+                return out
+        parts, off, cnt_all = exchange_packed(p["packed"], p["cnt"], self.group)  # exact size (one host read)
+        return merge_packed_dev(parts, off, cnt_all, nq, L)  # HIP: one wave per query up to 3072, ranked places above
+
+    @staticmethod
+    def overflowed(outs):
+        """True when any of the results of check=False calls was cut by the fixed exchange size (repeat those batches)."""
+        import torch
+        flags = [o["overflow"] for o in outs if "overflow" in o]
+        return bool(flags) and bool(torch.stack([f.reshape(()) for f in flags]).max().item())
 
     def search_batch_dev(self, q, quota=10, limit=None, packed=True):
         """packed=True (default): only valid hits travel.  A rank owns 1/world of the cells, so its [nq, L] partial
@@ -271,8 +360,8 @@ class ShardedSearcher(object):
             return out
         nq = int(q.shape[0])
         p = self.local.search_partial_packed_dev(q, quota=quota, limit=limit)
-        parts, off, cnt_all = exchange_packed(p["packed"], p["cnt"], self.group)
-        out = merge_packed_dev(parts, off, cnt_all, nq, L)  # HIP: one wave per query up to 3072 records, ranked places above
+        out = self._exchange_and_merge(p, nq, L, check=True)
+        out.pop("overflow", None)
         out["visited"] = p["visited"]
         return out
 
@@ -378,9 +467,9 @@ class GridSearcher(object):
             return self.row.search_begin(q, quota=quota, limit=limit)
         return {"out": self.local.search_batch_dev(q, quota=quota, limit=limit)}
 
-    def search_end(self, h):
+    def search_end(self, h, check=True):
         if self.row is not None:
-            return self.row.search_end(h)
+            return self.row.search_end(h, check=check)
         return h["out"]
 
     def search_batch_dev(self, q, quota=10, limit=None):

@@ -219,6 +219,12 @@ int cis_merge_packed_dev(const cis_hit* d_parts, int world, int64_t stride, cons
                          const int32_t* d_cnt /* [world][nq] */, int nq, int limit, int64_t* d_ids, double* d_dists,
                          int32_t* d_n_found, int32_t* d_cells /* or NULL */, uint32_t* d_pos /* or NULL */, void* stream);
 
+/* Offsets of the packed exchange, on the device ("one collective per query batch" -- no host read in between):
+ * d_cnt_all [world][nq] = the all-gathered per-query hit counts -> d_off [world][nq] (exclusive scan per shard), d_totals [world],
+ * *d_overflow = 1 when a shard holds more records than `stride` (the fixed per-rank size of the payload all-gather). */
+int cis_exchange_offsets_dev(const int32_t* d_cnt_all, int world, int nq, int64_t stride, int64_t* d_off, int64_t* d_totals,
+                             int32_t* d_overflow, void* stream);
+
 /* Exact re-ranking with features resident in HBM (cufacesearch/cufacesearch/searcher/searcher_lopqhbase.py:864-912:
  * dist = np.linalg.norm(normed_feat - res_fts[pos]) for the first results of a query).  d_feats [n_feats][D] and
  * d_q [nq][D] in f_dtype (4 = float32, 8 = float64; the distance is computed in that type, NOT squared), d_rows [nq][L]

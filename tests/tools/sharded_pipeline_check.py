@@ -75,5 +75,29 @@ for quota, limit in [(3000, 100), (50, 20), (5000, 600), (20000, 3500)]:
         assert torch.equal(torch.isnan(dw), torch.isnan(dg)) and torch.equal(dw[~torch.isnan(dw)], dg[~torch.isnan(dg)])
     if rank == 0:
         print("world %d quota %d limit %d: routed insert + pipelined search ok" % (world, quota, limit))
+# the exchange without a host read: fixed payload size + offsets by a kernel; the overflow flag is raised when a rank holds
+# more than the fixed size (forced here with a tiny slack) and check=True then repeats the exchange with the exact size
+for slack, expect_flag in [(1.5, None), (0.01, True)]:
+    sh.stride_slack = slack
+    want = [single.search_batch_dev(q, quota=3000, limit=100) for q in qs]
+    outs = []
+    for q in qs:
+        outs.append(sh.search_end(sh.search_begin(q, quota=3000, limit=100), check=False))
+    torch.cuda.synchronize()
+    flagged = ShardedSearcher.overflowed(outs)
+    if expect_flag is not None and world > 1:
+        assert flagged == expect_flag, (slack, flagged)
+    if not flagged:
+        for w, g in zip(want, outs):
+            assert torch.equal(w["ids"], g["ids"]) and torch.equal(w["n_found"], g["n_found"])
+    for w, q in zip(want, qs):  # check=True: always exact, whatever the slack
+        g = sh.search_end(sh.search_begin(q, quota=3000, limit=100))
+        torch.cuda.synchronize()
+        assert torch.equal(w["ids"], g["ids"]) and torch.equal(w["n_found"], g["n_found"]) and torch.equal(w["visited"], g["visited"])
+        dw, dg = w["dists"], g["dists"]
+        assert torch.equal(dw[~torch.isnan(dw)], dg[~torch.isnan(dg)])
+sh.stride_slack = 1.5
+if rank == 0:
+    print("world %d: fixed-size exchange without a host read ok (overflow -> exact repeat)" % world)
 dist.barrier()
 dist.destroy_process_group()

@@ -48,10 +48,32 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
         out = merge_packed_dev(parts, off, cnt, 8192, 100)
     torch.cuda.synchronize()
     dp = (time.perf_counter() - t) / K
-    print("world %d rank 0: partial search, packed %.3f ms (stages %s), merge of %d lists %.3f ms, packed hits of this rank %d (%.1f MB)" % (
-        world, dt * 1e3, {k: round(prof[k] / K, 3) for k in ("front_ms", "tables_ms", "scan_ms", "merge_ms")}, world, dp * 1e3,
-        total, total * 32 / 1e6))
-    meas[world] = (dt * 1e3, dp * 1e3 if world > 1 else 0.0)
+    # realistic merge input: this rank's list in ONE slot and empty lists in the others for the queries whose hits are all here, i.e.
+    # what a V = 16 index produces (a query's one or two cells live on one or two ranks); lists = [mine, empty, ...]
+    cnt1 = torch.zeros_like(cnt); cnt1[0] = p["cnt"]
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(K):
+        out = merge_packed_dev(parts, off, cnt1, 8192, 100)
+    torch.cuda.synchronize()
+    dp1 = (time.perf_counter() - t) / K
+    # three batches in flight (views on three streams), partial search + merge per batch: what a rank sustains per step
+    lanes = [(s, torch.cuda.current_stream())] + [(s.view(), torch.cuda.Stream()) for _ in range(2)]
+    def one(i):
+        sv, stream = lanes[i % 3]
+        with torch.cuda.stream(stream):
+            pp = sv.search_partial_packed_dev(q, quota=10000, limit=100)
+            merge_packed_dev(parts, off, cnt1, 8192, 100)
+    for i in range(6): one(i)
+    torch.cuda.synchronize(); t = time.perf_counter(); K2 = 24
+    for i in range(K2): one(i)
+    torch.cuda.synchronize()
+    dpipe = (time.perf_counter() - t) / K2
+    print("world %d rank 0: partial search, packed %.3f ms (stages %s), merge of %d full lists %.3f ms / of one list + %d empty %.3f ms, packed hits of this rank %d (%.1f MB); "
+          "pipelined (3 in flight) partial search + merge %.3f ms per step" % (
+        world, dt * 1e3, {k: round(prof[k] / K, 3) for k in ("front_ms", "tables_ms", "scan_ms", "merge_ms")}, world, dp * 1e3, world - 1, dp1 * 1e3,
+        total, total * 32 / 1e6, dpipe * 1e3))
+    meas[world] = (dt * 1e3, dp1 * 1e3 if world > 1 else 0.0, dpipe * 1e3)
+    for sv, _ in lanes[1:]: sv.close()
     del s
 # projection for the R x S grid of distributed.GridSearcher: a GPU spends partial(S) + pack/merge(S) per batch of 8192 queries
 # of ITS query group (the exchange runs on the side stream under the next batch's search); R groups work side by side
@@ -62,5 +84,6 @@ for n in (1, 2, 4, 8):
     for S in sorted(set([1, min(2, n), n])):
         if S in meas and n % S == 0:
             t = (meas[S][0] + meas[S][1]) / (n // S)
-            row.append("%d groups x %d shards: %.3f (x%.2f)" % (n // S, S, t, base / t))
+            tp = meas[S][2] / (n // S)
+            row.append("%d groups x %d shards: %.3f (x%.2f), pipelined %.3f (x%.2f)" % (n // S, S, t, base / t, tp, meas[1][2] / tp))
     print("  %d GPU(s): %s" % (n, "; ".join(row)))
