@@ -54,6 +54,7 @@ _PROTOS = {
     "cis_index_create": (c_int, [POINTER(c_void_p), c_void_p]),
     "cis_index_destroy": (None, [c_void_p]),
     "cis_index_create_view": (c_int, [POINTER(c_void_p), c_void_p]),
+    "cis_index_insert_counters": (c_int, [c_void_p, c_void_p]),
     "cis_index_set_shard": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "cis_index_cell_counts": (c_int, [c_void_p, c_void_p]),
     "cis_index_add_remote_counts": (c_int, [c_void_p, c_void_p]),

@@ -12,10 +12,11 @@
 struct CellStore {
     DevBuf codes[2];  // [n][M] uint8 (not allocated for the id-only store)
     DevBuf ids[2];    // [n] int64
-    DevBuf loff[2];   // [ncells + 1] int64
+    DevBuf loff[2];   // [ncells + 1] int64 starts of the cells' rooms, then [ncells] int64 ends of their USED parts (lend)
     DevBuf cmax;      // [ncells] int64: largest id stored in the cell (-1: empty) -- an id above it cannot be a duplicate
     int cur = 0;
-    int64_t n = 0;
+    int64_t n = 0;    // items stored
+    int64_t cap = 0;  // upper bound of the layout's extent (slots incl. the cells' slack; the true extent is loff[ncells] on the device)
     bool with_codes = true;
     bool init = false;
     void release() {
@@ -39,6 +40,8 @@ struct cis_index {
     DevBuf d_gcount;   // [ncells] int64, all shards
     bool had_plain_remote = false;  // items of other shards' cells were counted without (cell, id) bookkeeping
     int64_t nb_indexed = 0;
+    bool stats_fresh = false;  // the last insert chunk already refreshed n_total / max_cell / nonempty_cells
+    int64_t n_inplace = 0, n_rebuild = 0;  // insert calls (chunks) that were written in place / that rebuilt the layout
     // A VIEW (cis_index_create_view) shares the storage of `base` -- codes, ids, offsets, cell sizes -- and owns only its per-batch
     // workspaces, plan read-back words and counters: two batches can then be in flight at once, each on its own stream (the front end,
     // tables and slot kernels of one batch fill the tail of the other's scan and its merge).  A view is read-only and must not outlive
@@ -57,7 +60,7 @@ struct cis_index {
     }
     int64_t n_local = 0;
     // insert workspace
-    DevBuf wi_key[2], wi_val[2], wi_hist, wi_sid, wi_acc, wi_apre, wi_tmp, wi_in_ids, wi_in_coarse, wi_in_fine, wi_scan;
+    DevBuf wi_key[2], wi_val[2], wi_hist, wi_sid, wi_acc, wi_apre, wi_tmp, wi_in_ids, wi_in_coarse, wi_in_fine, wi_scan, wi_cnt, wi_cnt2;
     DevBuf d_stats;              // statistics words of the last merge (see lopq_index.hip)
     int64_t* h_ins = nullptr;    // pinned host copy of them
     // per-batch workspace

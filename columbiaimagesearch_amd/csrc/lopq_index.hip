@@ -16,13 +16,21 @@
 //                   cell (looked up only when id <= cmax[cell]: ids that grow with time never scan) or when an earlier
 //                   item of the batch has the same cell and id; all lanes of a wave walk the same cell -> broadcast loads
 //   scan            exclusive prefix of the accepted flags
-//   k_ins_offsets   new CSR offsets = old + accepted items of smaller cells (binary search in the sorted keys),
+//   k_ins_counts    per cell: items after the insert, room of the rebuilt cell (items + slack); scan -> new offsets,
 //                   global cell sizes += accepted
 //   k_ins_move      old items to their new places (a cell moves as a block)
 //   k_ins_scatter   accepted items behind the old items of their cell, in arrival order: place = old offset of the next cell +
 //                   accepted items before it
 // The two generations of the arrays swap.  Cost: one read + one write of the shard's index (24 B per item at M = 16)
 // plus O(n) for the batch -- 10M items x M = 8: ~0.1 ms; the host does nothing per item and keeps no (cell, id) set.
+//
+// IN-PLACE inserts (round 4).  The reference appends to a per-cell Python list (search.py:349-364): O(batch).  A cell here owns
+// [loff[c], loff[c+1]) of the arrays but uses only [loff[c], lend[c]) of it (lend = loff + ncells + 1, same buffer): the rebuild above
+// leaves cnt / 8 + a few items of slack behind every cell, and a batch whose accepted items all fit their cells' slack is
+// written behind the cells' last items by two kernels (k_ins_place, k_ins_commit) that touch O(batch) bytes -- no move, no
+// generation swap.  A batch that does not fit raises a flag BEFORE anything becomes visible (items land beyond lend, lend is
+// advanced by the commit kernel only when the flag is clear) and takes the rebuild, which renews every cell's slack:
+// geometric growth, amortised O(1) per item.  Same first-wins / insertion-order semantics on both routes.
 //
 // A cell-sharded index that is handed EVERY item with dedup (cis_index_add on all ranks -- tests and small set-ups; the
 // production form is the routed insert of columbiaimagesearch_amd/distributed.py, where an owner sees only its cells)
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(64) void k_rs_scatter(const uint32_t* __restrict__ 
 // ================================================================================================
 // statistics words (device memory; copied into pinned host memory when the host needs them)
 enum { INS_ACC_OWN = 0, INS_INVALID = 1, INS_NTOTAL = 2, INS_MAXCELL = 3, INS_NONEMPTY = 4, INS_ERR = 5, INS_ACC_GHOST = 6,
-       INS_REMOTE_PLAIN = 7, INS_WORDS = 8 };
+       INS_REMOTE_PLAIN = 7, INS_OVERFLOW = 8, INS_WORDS = 9 };
 
 __device__ __forceinline__ bool dev_owns(int64_t cell, const int32_t* __restrict__ owner, int rank, int world) {
     if (world <= 1) return true;
@@ -227,32 +235,6 @@ __global__ void k_ins_gather(const int64_t* __restrict__ idv, const uint32_t* __
     if (j < n) sid[j] = idv[perm[j]];
 }
 
-__global__ void k_ins_dedup(const uint32_t* __restrict__ key, const int64_t* __restrict__ sid, int64_t n, int dedup,
-                            const int64_t* __restrict__ loff, const int64_t* __restrict__ old_ids,
-                            const unsigned long long* __restrict__ cmaxp, uint32_t* __restrict__ acc) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const int64_t id = sid[j];
-    uint32_t a = id >= 0 ? 1u : 0u;
-    if (a && dedup) {
-        const uint32_t c = key[j];
-        bool dup = false;
-        if ((unsigned long long)id < cmaxp[c]) {  // ids above everything stored in the cell cannot be there
-            const int64_t e = loff[c + 1];
-            for (int64_t p = loff[c]; p < e; ++p) {
-                if (old_ids[p] == id) { dup = true; break; }
-            }
-        }
-        if (!dup) {
-            for (int64_t jj = j - 1; jj >= 0 && key[jj] == c; --jj) {
-                if (sid[jj] == id) { dup = true; break; }
-            }
-        }
-        a = dup ? 0u : 1u;
-    }
-    acc[j] = a;
-}
-
 __device__ __forceinline__ int64_t lower_bound_u32(const uint32_t* __restrict__ a, int64_t n, uint32_t x) {
     int64_t lo = 0, hi = n;
     while (lo < hi) {
@@ -263,36 +245,83 @@ __device__ __forceinline__ int64_t lower_bound_u32(const uint32_t* __restrict__ 
     return lo;
 }
 
-// thread c in [0, ncells]: accepted items of cells < c
-__global__ void k_ins_offsets(const uint32_t* __restrict__ key, const uint32_t* __restrict__ apre, const uint32_t* __restrict__ total,
-                              int64_t n, int64_t ncells, const int64_t* __restrict__ loff, int64_t* __restrict__ noff,
-                              int64_t* __restrict__ gcount) {
+// first (cell, id) wins (search.py:349-364).  One WAVE per item (round 3: one thread walked the whole cell -- 39 k ids at 10M
+// vectors, 4.9 ms per 256-item batch whose ids lie below the cell's maximum): the lanes stride over the ids stored in the cell
+// (skipped when id >= cmax[cell]: ids that grow with time never scan) and over the earlier items of the batch in the same cell.
+__global__ __launch_bounds__(256) void k_ins_dedup(const uint32_t* __restrict__ key, const int64_t* __restrict__ sid, int64_t n, int dedup,
+                                                   const int64_t* __restrict__ loff, const int64_t* __restrict__ lend,
+                                                   const int64_t* __restrict__ old_ids, const unsigned long long* __restrict__ cmaxp,
+                                                   uint32_t* __restrict__ acc) {
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= n) return;
+    const int64_t id = sid[j];
+    uint32_t a = id >= 0 ? 1u : 0u;
+    if (a && dedup) {
+        const uint32_t c = key[j];
+        bool dup = false;
+        if ((unsigned long long)id < cmaxp[c]) {  // ids above everything stored in the cell cannot be there
+            const int64_t b = loff[c], e = lend[c];
+            for (int64_t p0 = b; p0 < e && !dup; p0 += 64) {
+                const int64_t p = p0 + lane;
+                dup = __ballot(p < e && old_ids[p] == id) != 0ull;
+            }
+        }
+        if (!dup) {
+            const int64_t first = lower_bound_u32(key, n, c);  // the batch is sorted by cell: earlier items of this cell are [first, j)
+            for (int64_t j0 = first; j0 < j && !dup; j0 += 64) {
+                const int64_t jj = j0 + lane;
+                dup = __ballot(jj < j && sid[jj] == id) != 0ull;
+            }
+        }
+        a = dup ? 0u : 1u;
+    }
+    if (lane == 0) acc[j] = a;
+}
+
+// thread c in [0, ncells): items of the cell after this insert and the room the rebuilt cell gets (used part + slack);
+// a0[c] = accepted items of the cells before c in the sorted batch; the global cell sizes take the accepted items
+__global__ void k_ins_counts(const uint32_t* __restrict__ key, const uint32_t* __restrict__ apre, const uint32_t* __restrict__ total,
+                             int64_t n, int64_t ncells, const int64_t* __restrict__ loff, const int64_t* __restrict__ lend,
+                             int64_t* __restrict__ cnt_new, int64_t* __restrict__ cap_new, uint32_t* __restrict__ a0v,
+                             int64_t* __restrict__ gcount, int slack_const) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > ncells) return;
+    if (c >= ncells) return;
     const uint32_t tot = total[0];
     const int64_t l0 = lower_bound_u32(key, n, (uint32_t)c);
     const int64_t a0 = l0 < n ? apre[l0] : tot;
-    noff[c] = loff[c] + a0;
-    if (c < ncells) {
-        const int64_t l1 = lower_bound_u32(key, n, (uint32_t)c + 1u);
-        const int64_t a1 = l1 < n ? apre[l1] : tot;
-        if (a1 > a0) gcount[c] += a1 - a0;
-    }
+    const int64_t l1 = lower_bound_u32(key, n, (uint32_t)c + 1u);
+    const int64_t a1 = l1 < n ? apre[l1] : tot;
+    const int64_t cn = (lend[c] - loff[c]) + (a1 - a0);
+    cnt_new[c] = cn;
+    // (an empty cell gets room too, or the first item of a cell would always force a rebuild: the full constant with few cells, one
+    // slot each with millions of them -- V = 4096 has 16 M cells, most of them empty)
+    cap_new[c] = slack_const < 0 ? cn : cn + (cn >> 3) + ((cn > 0 || ncells <= 65536) ? slack_const : 1);
+    a0v[c] = (uint32_t)a0;
+    if (a1 > a0) gcount[c] += a1 - a0;
 }
 
-// old items to their new places: a cell moves as a block (thread per item; the cell by binary search in the old offsets)
+// noff[0 .. ncells] is the exclusive scan of cap_new (written by the scan); the used ends follow it in the same buffer
+__global__ void k_ins_ends(const int64_t* __restrict__ noff, const int64_t* __restrict__ cnt_new, int64_t ncells, int64_t* __restrict__ nend) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ncells) nend[c] = noff[c] + cnt_new[c];
+}
+
+// old items to their new places: a cell moves as a block (thread per SLOT of the old layout; the cell by binary search in the
+// old offsets; slots of a cell's slack hold nothing)
 template <int MW /* code words per item, 0: bytes */>
-__global__ void k_ins_move(const int64_t* __restrict__ loff, const int64_t* __restrict__ noff, int64_t ncells, int64_t n_old,
-                           const int64_t* __restrict__ ids, const uint8_t* __restrict__ codes, int M, int64_t* __restrict__ ids_new,
-                           uint8_t* __restrict__ codes_new) {
+__global__ void k_ins_move(const int64_t* __restrict__ loff, const int64_t* __restrict__ lend, const int64_t* __restrict__ noff,
+                           int64_t ncells, int64_t cap_bound, const int64_t* __restrict__ ids, const uint8_t* __restrict__ codes, int M,
+                           int64_t* __restrict__ ids_new, uint8_t* __restrict__ codes_new) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_old) return;
+    if (p >= cap_bound || p >= loff[ncells]) return;
     int64_t lo = 0, hi = ncells;  // largest c with loff[c] <= p
     while (hi - lo > 1) {
         const int64_t mid = (lo + hi) >> 1;
         if (loff[mid] <= p) lo = mid;
         else hi = mid;
     }
+    if (p >= lend[lo]) return;
     const int64_t dst = p + (noff[lo] - loff[lo]);
     ids_new[dst] = ids[p];
     if (codes) {
@@ -308,12 +337,12 @@ __global__ void k_ins_move(const int64_t* __restrict__ loff, const int64_t* __re
 }
 
 // many tiny cells (thousands of coarse clusters): thread per cell
-__global__ void k_ins_move_cells(const int64_t* __restrict__ loff, const int64_t* __restrict__ noff, int64_t ncells,
-                                 const int64_t* __restrict__ ids, const uint8_t* __restrict__ codes, int M,
+__global__ void k_ins_move_cells(const int64_t* __restrict__ loff, const int64_t* __restrict__ lend, const int64_t* __restrict__ noff,
+                                 int64_t ncells, const int64_t* __restrict__ ids, const uint8_t* __restrict__ codes, int M,
                                  int64_t* __restrict__ ids_new, uint8_t* __restrict__ codes_new) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncells) return;
-    const int64_t a = loff[c], b = loff[c + 1], d = noff[c] - a;
+    const int64_t a = loff[c], b = lend[c], d = noff[c] - a;
     for (int64_t p = a; p < b; ++p) {
         ids_new[p + d] = ids[p];
         if (codes)
@@ -321,24 +350,42 @@ __global__ void k_ins_move_cells(const int64_t* __restrict__ loff, const int64_t
     }
 }
 
-// Place of accepted item j (sorted by cell, then arrival): behind every old item of the cells up to its own and behind the
-// accepted items before it -- loff_old[c + 1] + apre[j].  The cell's largest id: one atomic per run of equal cells in a wave
-// (the items are sorted by cell: a wave usually holds one cell, and 10M items hammering 256 addresses one by one took 22 ms).
+// Place of accepted item j (sorted by cell, then arrival): behind the items the cell already holds and behind the accepted
+// items of the same cell before it -- base[c] + used[c] + (apre[j] - apre[first item of the cell in the batch]).
+//   rebuild (INPLACE = false): base = the new offsets, used = the old used length (the moved items)
+//   in place (INPLACE = true): base = the offsets, used ends = lend; an item that would land beyond the cell's room raises
+//   stats[INS_OVERFLOW] and writes nothing; nothing it writes is visible before k_ins_commit advances lend.
+// The cell's largest id: one atomic per run of equal cells in a wave (the items are sorted by cell: a wave usually holds one
+// cell, and 10M items hammering 256 addresses one by one took 22 ms).
+template <bool INPLACE>
 __global__ void k_ins_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ perm, const int64_t* __restrict__ sid,
                               const uint32_t* __restrict__ acc, const uint32_t* __restrict__ apre, int64_t n,
-                              const int64_t* __restrict__ loff, const uint8_t* __restrict__ fine, int M,
-                              int64_t* __restrict__ ids_new, uint8_t* __restrict__ codes_new, unsigned long long* __restrict__ cmaxp) {
+                              const int64_t* __restrict__ loff_old, const int64_t* __restrict__ lend_old,
+                              const int64_t* __restrict__ noff, const uint32_t* __restrict__ a0v, const uint8_t* __restrict__ fine, int M,
+                              int64_t* __restrict__ ids_new, uint8_t* __restrict__ codes_new, unsigned long long* __restrict__ cmaxp,
+                              int64_t* __restrict__ stats) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool on = j < n && acc[j];
     const uint32_t c = on ? key[j] : 0xffffffffu;
     unsigned long long v = 0ull;
     if (on) {
-        const int64_t dst = loff[c + 1] + (int64_t)apre[j];
+        int64_t dst;
+        bool fits = true;
+        if constexpr (INPLACE) {
+            const int64_t l0 = lower_bound_u32(key, n, c);
+            dst = lend_old[c] + (int64_t)(apre[j] - apre[l0]);
+            fits = dst < loff_old[c + 1];
+            if (!fits) stats[INS_OVERFLOW] = 1;
+        } else {
+            dst = noff[c] + (lend_old[c] - loff_old[c]) + (int64_t)(apre[j] - a0v[c]);
+        }
         const int64_t id = sid[j];
-        ids_new[dst] = id;
-        if (codes_new) {
-            const int64_t i = perm[j];
-            for (int b = 0; b < M; ++b) codes_new[dst * M + b] = fine[i * M + b];
+        if (fits) {
+            ids_new[dst] = id;
+            if (codes_new) {
+                const int64_t i = perm[j];
+                for (int b = 0; b < M; ++b) codes_new[dst * M + b] = fine[i * M + b];
+            }
         }
         v = (unsigned long long)id + 1ull;
     }
@@ -352,6 +399,22 @@ __global__ void k_ins_scatter(const uint32_t* __restrict__ key, const uint32_t* 
     }
     const uint32_t cn = __shfl_down(c, 1);
     if (on && (lane == 63 || cn != c)) atomicMax(&cmaxp[c], v);  // the last lane of a run holds the run's maximum
+}
+
+// in-place insert, second kernel: the accepted items of a cell become visible -- lend and the global cell size advance by the
+// cell's accepted count -- unless some item of the batch did not fit (then the rebuild takes the whole batch)
+__global__ void k_ins_commit(const uint32_t* __restrict__ key, const uint32_t* __restrict__ acc, const uint32_t* __restrict__ apre, int64_t n,
+                             int64_t* __restrict__ lend, int64_t* __restrict__ gcount, const int64_t* __restrict__ stats) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n || stats[INS_OVERFLOW] != 0) return;
+    const uint32_t c = key[j];
+    if (j + 1 < n && key[j + 1] == c) return;  // the last item of the cell's run commits the run
+    const int64_t l0 = lower_bound_u32(key, n, c);
+    const int64_t a = (int64_t)(apre[j] + acc[j]) - (int64_t)apre[l0];
+    if (a > 0) {
+        lend[c] += a;
+        gcount[c] += a;
+    }
 }
 
 // statistics of the global cell-size table: total, largest cell, non-empty cells (atomics into zeroed words)
@@ -404,7 +467,7 @@ __global__ void k_get_codes(const int32_t* __restrict__ cells, const uint32_t* _
     if (i >= n) return;
     const int64_t c = cells[i];
     if (c < 0 || c >= ncells) { stats[INS_ERR] = 1 + i; return; }
-    const int64_t a = loff[c], b = loff[c + 1];
+    const int64_t a = loff[c], b = loff[ncells + 1 + c];  // (the used end: lend = loff + ncells + 1)
     if ((int64_t)pos[i] >= b - a) { stats[INS_ERR] = 1 + i; return; }
     for (int j = 0; j < M; ++j) out[i * M + j] = codes[(a + pos[i]) * M + j];
 }
@@ -460,11 +523,11 @@ static int store_init(cis_index* ix, CellStore& s, bool with_codes) {
     if (s.init) return CIS_OK;
     const int64_t nc = ix->ncells;
     s.with_codes = with_codes;
-    for (int g = 0; g < 2; ++g) CIS_TRY(s.loff[g].reserve((size_t)(nc + 1) * sizeof(int64_t)));
+    for (int g = 0; g < 2; ++g) CIS_TRY(s.loff[g].reserve((size_t)(2 * nc + 1) * sizeof(int64_t)));  // starts [nc + 1], used ends [nc]
     CIS_TRY(s.cmax.reserve((size_t)nc * sizeof(int64_t)));
     CIS_TRY(s.ids[0].reserve(256));
     if (with_codes) CIS_TRY(s.codes[0].reserve(256));
-    CIS_CHECK_HIP(hipMemset(s.loff[0].p, 0, (size_t)(nc + 1) * sizeof(int64_t)));
+    CIS_CHECK_HIP(hipMemset(s.loff[0].p, 0, (size_t)(2 * nc + 1) * sizeof(int64_t)));
     CIS_CHECK_HIP(hipMemset(s.cmax.p, 0, (size_t)nc * sizeof(int64_t)));
     s.cur = 0;
     s.n = 0;
@@ -533,7 +596,7 @@ extern "C" void cis_index_destroy(cis_index* ix) {
                       &ix->w_hitn, &ix->w_slack, &ix->w_planfb, &ix->w_vis, &ix->w_tiles, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
                       &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px, &ix->w_T32, &ix->w_grp, &ix->w_tord, &ix->w_y64, &ix->w_x64,
                       &ix->wi_key[0], &ix->wi_key[1], &ix->wi_val[0], &ix->wi_val[1], &ix->wi_hist, &ix->wi_sid, &ix->wi_acc,
-                      &ix->wi_apre, &ix->wi_tmp, &ix->wi_in_ids, &ix->wi_in_coarse, &ix->wi_in_fine, &ix->wi_scan, &ix->d_stats};
+                      &ix->wi_apre, &ix->wi_tmp, &ix->wi_in_ids, &ix->wi_in_coarse, &ix->wi_in_fine, &ix->wi_scan, &ix->wi_cnt, &ix->wi_cnt2, &ix->d_stats};
     for (DevBuf* b : bufs) b->release();
     ix->own.release();
     ix->ghost.release();
@@ -589,12 +652,23 @@ static int radix_sort_pairs(cis_index* ix, int64_t n, int bits, hipStream_t st, 
     return CIS_OK;
 }
 
-// one stable merge of n device-resident items into store `s` (sel 0: own, 1: ghost); accepted count -> stats word `acc_word`
+// slack items behind a rebuilt cell, next to an eighth of its size (few cells: room for several batches; thousands of coarse
+// clusters: millions of tiny cells, two items each are already 32 B x 16 M); CIS_INSERT_SLACK=-1: tight packing (rounds 1-3)
+static int slack_const(const cis_index* ix) {
+    static const int env = getenv("CIS_INSERT_SLACK") ? atoi(getenv("CIS_INSERT_SLACK")) : -2;
+    if (env != -2) return env;
+    return ix->ncells <= 65536 ? 32 : 2;
+}
+static const int64_t INPLACE_MAX = 65536;  // larger batches go straight to the rebuild (they would not fit the slack anyway)
+
+// one stable merge of n device-resident items into store `s` (sel 0: own, 1: ghost); accepted count -> stats word `acc_word`.
+// Synchronises `st` (the statistics words are read back) and adds the accepted count to s.n.
 static int store_merge(cis_index* ix, CellStore& s, int sel, const int64_t* d_ids, const uint16_t* d_coarse, const uint8_t* d_fine,
                        int64_t n, int dedup, int acc_word, hipStream_t st) {
     const int M = ix->M, V = ix->V, K = ix->m->K;
     const int64_t nc = ix->ncells;
     CIS_REQUIRE(n < ((int64_t)1 << 31), "at most 2^31 - 1 items per insert call");
+    ix->stats_fresh = false;  // this merge changes the global cell sizes
     for (int g = 0; g < 2; ++g) {
         CIS_TRY(ix->wi_key[g].reserve((size_t)n * sizeof(uint32_t)));
         CIS_TRY(ix->wi_val[g].reserve((size_t)n * sizeof(uint32_t)));
@@ -603,11 +677,7 @@ static int store_merge(cis_index* ix, CellStore& s, int sel, const int64_t* d_id
     CIS_TRY(ix->wi_sid.reserve((size_t)n * sizeof(int64_t)));   // ... in sorted order
     CIS_TRY(ix->wi_acc.reserve((size_t)n * sizeof(uint32_t)));
     CIS_TRY(ix->wi_apre.reserve((size_t)(n + 2) * sizeof(uint32_t)));
-    CIS_TRY(ix->wi_scan.reserve((size_t)(ceil_div(std::max<int64_t>(n, (int64_t)256 * ceil_div(n, RS_TILE)), SCAN_TILE) + 2) * sizeof(int64_t) + 64));
-    const int nxt = 1 - s.cur;
-    const int64_t cap = s.n + n;
-    CIS_TRY(s.ids[nxt].reserve((size_t)(cap > 0 ? cap : 1) * sizeof(int64_t)));
-    if (s.with_codes) CIS_TRY(s.codes[nxt].reserve((size_t)(cap > 0 ? cap : 1) * M + 64));
+    CIS_TRY(ix->wi_scan.reserve((size_t)(ceil_div(std::max<int64_t>(std::max<int64_t>(n, nc + 1), (int64_t)256 * ceil_div(n, RS_TILE)), SCAN_TILE) + 2) * sizeof(int64_t) + 64));
     const int32_t* d_owner = ix->d_owner.as<int32_t>();
     int64_t* stats = ix->d_stats.as<int64_t>();
     int64_t* gcount = ix->d_gcount.as<int64_t>();
@@ -622,24 +692,67 @@ static int store_merge(cis_index* ix, CellStore& s, int sel, const int64_t* d_id
     uint32_t* acc = ix->wi_acc.as<uint32_t>();
     uint32_t* apre = ix->wi_apre.as<uint32_t>();
     uint32_t* total = apre + n;  // one word behind the prefix array
-    const int64_t* loff = s.loff[s.cur].as<int64_t>();
-    int64_t* noff = s.loff[nxt].as<int64_t>();
+    int64_t* loff = s.loff[s.cur].as<int64_t>();
+    int64_t* lend = loff + nc + 1;
     unsigned long long* cmaxp = s.cmax.as<unsigned long long>();
     hipLaunchKernelGGL(k_ins_gather, dim3(grid_for(n, 256)), dim3(256), 0, st, (const int64_t*)ix->wi_tmp.as<int64_t>(), perm, n, sid);
-    hipLaunchKernelGGL(k_ins_dedup, dim3(grid_for(n, 256)), dim3(256), 0, st, skey, (const int64_t*)sid, n, dedup, loff,
-                       (const int64_t*)s.ids[s.cur].as<int64_t>(), (const unsigned long long*)cmaxp, acc);
+    hipLaunchKernelGGL(k_ins_dedup, dim3(grid_for(n, 4)), dim3(256), 0, st, skey, (const int64_t*)sid, n, dedup, (const int64_t*)loff,
+                       (const int64_t*)lend, (const int64_t*)s.ids[s.cur].as<int64_t>(), (const unsigned long long*)cmaxp, acc);
     dev_exclusive_scan<uint32_t, uint32_t>(acc, apre, n, ix->wi_scan.as<uint32_t>(), total, stats + acc_word, st);
-    hipLaunchKernelGGL(k_ins_offsets, dim3(grid_for(nc + 1, 256)), dim3(256), 0, st, skey, (const uint32_t*)apre, (const uint32_t*)total, n,
-                       nc, loff, noff, gcount);
+    const int slack = slack_const(ix);
+    int64_t* gsink = gcount;  // (the id-only store of the other shards' cells counts into the global cell sizes as well)
+    // ---- in place: the accepted items behind their cells' last items, if every one of them fits its cell's slack ----
+    if (slack >= 0 && s.n > 0 && n <= INPLACE_MAX) {
+        uint8_t* codes_cur = s.with_codes ? s.codes[s.cur].as<uint8_t>() : nullptr;
+        hipLaunchKernelGGL((k_ins_scatter<true>), dim3(grid_for(n, 256)), dim3(256), 0, st, skey, perm, (const int64_t*)sid, (const uint32_t*)acc,
+                           (const uint32_t*)apre, n, (const int64_t*)loff, (const int64_t*)lend, (const int64_t*)nullptr, (const uint32_t*)nullptr,
+                           d_fine, M, s.ids[s.cur].as<int64_t>(), codes_cur, cmaxp, stats);
+        hipLaunchKernelGGL(k_ins_commit, dim3(grid_for(n, 256)), dim3(256), 0, st, skey, (const uint32_t*)acc, (const uint32_t*)apre, n, lend,
+                           gsink, (const int64_t*)stats);
+        // the statistics of the global cell sizes in the same read-back (valid when nothing overflowed): one host round trip per batch
+        CIS_CHECK_HIP(hipMemsetAsync(stats + INS_NTOTAL, 0, 3 * sizeof(int64_t), st));
+        hipLaunchKernelGGL(k_gcount_stats, dim3((unsigned)std::min<int64_t>(ceil_div(nc, 256), 1024)), dim3(256), 0, st, (const int64_t*)gcount, nc, stats);
+        CIS_CHECK_HIP(hipGetLastError());
+        CIS_CHECK_HIP(hipMemcpyAsync(ix->h_ins, ix->d_stats.p, INS_WORDS * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        CIS_CHECK_HIP(hipStreamSynchronize(st));
+        if (ix->h_ins[INS_OVERFLOW] == 0) {
+            s.n += ix->h_ins[acc_word];
+            if (sel == 0) ix->n_inplace += 1;
+            ix->n_total = ix->h_ins[INS_NTOTAL];
+            ix->max_cell = ix->h_ins[INS_MAXCELL];
+            ix->nonempty_cells = ix->h_ins[INS_NONEMPTY];
+            ix->nb_indexed = ix->n_total;
+            ix->stats_fresh = true;
+            return CIS_OK;
+        }
+        // some cell is full: nothing became visible; the rebuild below takes the whole batch and renews every cell's slack
+        CIS_CHECK_HIP(hipMemsetAsync(stats + INS_OVERFLOW, 0, sizeof(int64_t), st));
+    }
+    // ---- rebuild: every cell moves to its place in the other generation, the accepted items behind it ----
+    const int nxt = 1 - s.cur;
+    const int64_t items_bound = s.n + n;
+    const int64_t cap_new_bound = slack < 0 ? items_bound : items_bound + items_bound / 8 + (int64_t)slack * nc + 64;
+    CIS_TRY(s.ids[nxt].reserve((size_t)(cap_new_bound > 0 ? cap_new_bound : 1) * sizeof(int64_t)));
+    if (s.with_codes) CIS_TRY(s.codes[nxt].reserve((size_t)(cap_new_bound > 0 ? cap_new_bound : 1) * M + 64));
+    CIS_TRY(ix->wi_cnt.reserve((size_t)(2 * nc + 2) * sizeof(int64_t) + (size_t)(nc + 1) * sizeof(uint32_t)));
+    int64_t* cnt_new = ix->wi_cnt.as<int64_t>();
+    int64_t* cap_new = cnt_new + nc + 1;
+    uint32_t* a0v = reinterpret_cast<uint32_t*>(cap_new + nc + 1);
+    int64_t* noff = s.loff[nxt].as<int64_t>();
+    int64_t* nend = noff + nc + 1;
+    hipLaunchKernelGGL(k_ins_counts, dim3(grid_for(nc, 256)), dim3(256), 0, st, skey, (const uint32_t*)apre, (const uint32_t*)total, n, nc,
+                       (const int64_t*)loff, (const int64_t*)lend, cnt_new, cap_new, a0v, gsink, slack);
+    dev_exclusive_scan<int64_t, int64_t>(cap_new, noff, nc, ix->wi_scan.as<int64_t>(), noff + nc, nullptr, st);
+    hipLaunchKernelGGL(k_ins_ends, dim3(grid_for(nc, 256)), dim3(256), 0, st, (const int64_t*)noff, (const int64_t*)cnt_new, nc, nend);
     const uint8_t* ocodes = s.with_codes ? s.codes[s.cur].as<uint8_t>() : nullptr;
     uint8_t* ncodes = s.with_codes ? s.codes[nxt].as<uint8_t>() : nullptr;
     if (s.n > 0) {
         if (s.n / nc < 16 && nc >= 65536) {
-            hipLaunchKernelGGL(k_ins_move_cells, dim3(grid_for(nc, 256)), dim3(256), 0, st, loff, (const int64_t*)noff, nc,
+            hipLaunchKernelGGL(k_ins_move_cells, dim3(grid_for(nc, 256)), dim3(256), 0, st, (const int64_t*)loff, (const int64_t*)lend, (const int64_t*)noff, nc,
                                (const int64_t*)s.ids[s.cur].as<int64_t>(), ocodes, M, s.ids[nxt].as<int64_t>(), ncodes);
         } else {
 #define CIS_MOVE(MW)                                                                                                             \
-    hipLaunchKernelGGL((k_ins_move<MW>), dim3(grid_for(s.n, 256)), dim3(256), 0, st, loff, (const int64_t*)noff, nc, s.n,          \
+    hipLaunchKernelGGL((k_ins_move<MW>), dim3(grid_for(s.cap, 256)), dim3(256), 0, st, (const int64_t*)loff, (const int64_t*)lend, (const int64_t*)noff, nc, s.cap, \
                        (const int64_t*)s.ids[s.cur].as<int64_t>(), ocodes, M, s.ids[nxt].as<int64_t>(), ncodes)
             if (M == 4) CIS_MOVE(1);
             else if (M == 8) CIS_MOVE(2);
@@ -649,10 +762,15 @@ static int store_merge(cis_index* ix, CellStore& s, int sel, const int64_t* d_id
 #undef CIS_MOVE
         }
     }
-    hipLaunchKernelGGL(k_ins_scatter, dim3(grid_for(n, 256)), dim3(256), 0, st, skey, perm, (const int64_t*)sid, (const uint32_t*)acc,
-                       (const uint32_t*)apre, n, loff, d_fine, M, s.ids[nxt].as<int64_t>(), ncodes, cmaxp);
+    hipLaunchKernelGGL((k_ins_scatter<false>), dim3(grid_for(n, 256)), dim3(256), 0, st, skey, perm, (const int64_t*)sid, (const uint32_t*)acc,
+                       (const uint32_t*)apre, n, (const int64_t*)loff, (const int64_t*)lend, (const int64_t*)noff, (const uint32_t*)a0v, d_fine, M,
+                       s.ids[nxt].as<int64_t>(), ncodes, cmaxp, stats);
     CIS_CHECK_HIP(hipGetLastError());
-    // the host learns the accepted count when the stream is synchronised (caller); the generation swaps now
+    CIS_CHECK_HIP(hipMemcpyAsync(ix->h_ins, ix->d_stats.p, INS_WORDS * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    CIS_CHECK_HIP(hipStreamSynchronize(st));
+    s.n += ix->h_ins[acc_word];
+    if (sel == 0) ix->n_rebuild += 1;
+    s.cap = cap_new_bound;  // (an upper bound of the new layout's extent: the move kernel's grid; the true extent is loff[ncells])
     s.cur = nxt;
     return CIS_OK;
 }
@@ -707,27 +825,22 @@ static int index_add_dev(cis_index* ix, const int64_t* d_ids, const uint16_t* d_
     int64_t added = 0, invalid = 0;
     for (int64_t a = 0; a < n; a += chunk) {
         const int64_t bn = std::min(chunk, n - a);
+        ix->stats_fresh = false;
         CIS_TRY(stats_zero(ix, st));
         CIS_TRY(store_merge(ix, ix->own, 0, d_ids + a, d_coarse + 2 * a, d_fine + a * ix->M, bn, dedup, INS_ACC_OWN, st));
         if (sharded && dedup) {
             // items of the other shards' cells: recognised as duplicates through the id-only store.  Only when such items
             // exist (the routed insert hands an owner its own cells only and never pays for this).
-            CIS_TRY(stats_fetch(ix, st));
-            const int64_t seen = ix->h_ins[INS_ACC_OWN] + ix->h_ins[INS_INVALID];
-            ix->own.n += ix->h_ins[INS_ACC_OWN];
+            const int64_t seen = ix->h_ins[INS_ACC_OWN] + ix->h_ins[INS_INVALID];  // (store_merge left the statistics words in h_ins)
             added += ix->h_ins[INS_ACC_OWN];
             invalid += ix->h_ins[INS_INVALID];
             bool foreign = seen < bn;  // some item was neither accepted nor invalid: a duplicate, or a foreign cell
             if (foreign) {
                 CIS_TRY(store_init(ix, ix->ghost, false));
                 CIS_TRY(store_merge(ix, ix->ghost, 1, d_ids + a, d_coarse + 2 * a, d_fine + a * ix->M, bn, 1, INS_ACC_GHOST, st));
-                CIS_TRY(stats_fetch(ix, st));
-                ix->ghost.n += ix->h_ins[INS_ACC_GHOST];
                 added += ix->h_ins[INS_ACC_GHOST];
             }
         } else {
-            CIS_TRY(stats_fetch(ix, st));
-            ix->own.n += ix->h_ins[INS_ACC_OWN];
             added += ix->h_ins[INS_ACC_OWN] + ix->h_ins[INS_REMOTE_PLAIN];
             invalid += ix->h_ins[INS_INVALID];
             if (ix->h_ins[INS_REMOTE_PLAIN] > 0) ix->had_plain_remote = true;
@@ -737,7 +850,7 @@ static int index_add_dev(cis_index* ix, const int64_t* d_ids, const uint16_t* d_
     if (d_cell_delta)
         hipLaunchKernelGGL(k_cell_delta, dim3(grid_for(ix->ncells, 256)), dim3(256), 0, st, (const int64_t*)ix->d_gcount.as<int64_t>(),
                            d_cell_delta, ix->ncells);
-    CIS_TRY(refresh_stats(ix, st));
+    if (!ix->stats_fresh) CIS_TRY(refresh_stats(ix, st));  // (an in-place batch read them back with its own statistics)
     if (n_added) *n_added = added;
     if (n_invalid) *n_invalid = invalid;
     return CIS_OK;
@@ -781,6 +894,13 @@ extern "C" int cis_index_add(cis_index* ix, const int64_t* ids, const uint16_t* 
 // Cell-sharded insert with routed codes (columbiaimagesearch_amd/distributed.py:add_codes_routed): a rank is handed only
 // the codes of the cells it owns; the sizes of the other cells -- which drive the quota cut of every query on every
 // rank (search.py:128-133) -- arrive as per-cell increments summed over the owners.
+extern "C" int cis_index_insert_counters(cis_index* ix, int64_t counters[2]) {
+    CIS_REQUIRE(ix != nullptr && counters != nullptr, "NULL argument");
+    counters[0] = ix->n_inplace;
+    counters[1] = ix->n_rebuild;
+    return CIS_OK;
+}
+
 extern "C" int cis_index_cell_counts(cis_index* ix, int64_t* counts) {
     CIS_REQUIRE(ix != nullptr && counts != nullptr, "NULL argument");
     CIS_TRY(cis_index_ready(ix));
@@ -835,7 +955,8 @@ extern "C" int cis_index_get_cell(cis_index* ix, int c0, int c1, int64_t cap, in
     if (cap <= 0) return CIS_OK;
     *n = 0;  // with a buffer: the number of items copied (a cell of another shard has none here)
     if (!ix->owns(cell)) return CIS_OK;
-    CIS_CHECK_HIP(hipMemcpy(ab, ix->loff_ptr() + cell, 2 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    CIS_CHECK_HIP(hipMemcpy(&ab[0], ix->loff_ptr() + cell, sizeof(int64_t), hipMemcpyDeviceToHost));
+    CIS_CHECK_HIP(hipMemcpy(&ab[1], ix->loff_ptr() + ix->ncells + 1 + cell, sizeof(int64_t), hipMemcpyDeviceToHost));  // the used end (lend)
     const int64_t k = std::min(cap, ab[1] - ab[0]);
     *n = k;
     if (k > 0) {

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void k_plan(const CT* __restrict__ sorted, cons
         const int64_t cell = (int64_t)c0 * V + c1;
         const int64_t gc = gcount[cell];
         const int64_t ls = loff[cell];
-        const int64_t ll = loff[cell + 1] - ls;
+        const int64_t ll = loff[(int64_t)V * V + 1 + cell] - ls;  // the used end (lend = loff + ncells + 1: cells keep insert slack behind their items)
         if (ll > 0) {
             const int nch = (int)((ll + seg_max - 1) / seg_max);
             if (EMIT) {
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64) void k_front_small(const CT* __restrict__ X /* 
         const int64_t cell = (int64_t)c0 * V + c1;
         const int64_t gc = gcount[cell];
         const int64_t ls = loff[cell];
-        const int64_t ll = loff[cell + 1] - ls;
+        const int64_t ll = loff[(int64_t)V * V + 1 + cell] - ls;  // the used end (lend = loff + ncells + 1: cells keep insert slack behind their items)
         if (ll > 0) {
             n_items += (int)((ll + seg_max - 1) / seg_max);
             ncand += ll;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
                 bi = (int)(ij >> 16); bj = (int)(ij & 0xffff);
                 cell = (int64_t)o0[bi] * V + o1[bj];
                 ls = loff[cell];
-                ll = loff[cell + 1] - ls;
+                ll = loff[(int64_t)V * V + 1 + cell] - ls;
                 nch = ll > 0 ? (int)((ll + seg_max - 1) / seg_max) : 0;
             }
             int x = nch;
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
             const uint32_t ij = vl[idx];
             const int bi = (int)(ij >> 16), bj = (int)(ij & 0xffff);
             const int64_t cell = (int64_t)o0[bi] * V + o1[bj];
-            const int64_t ll = loff[cell + 1] - loff[cell];
+            const int64_t ll = loff[(int64_t)V * V + 1 + cell] - loff[cell];
             if (ll > 0) {
                 n_items += (ll + seg_max - 1) / seg_max;
                 ncand += ll;

@@ -427,6 +427,12 @@ class LOPQSearcherHIP(LOPQSearcherBase):
             out["cnt"].data_ptr(), out["off"].data_ptr(), out["total"].data_ptr(), out["visited"].data_ptr(), stream))
         return out
 
+    def insert_counters(self):
+        """(batches inserted in place, batches that rebuilt the layout) -- see include/cis_hip.h:cis_index_insert_counters."""
+        c = np.zeros(2, dtype=np.int64)
+        _lib.check(_lib.lib().cis_index_insert_counters(self._ix, _lib.ptr(c)))
+        return int(c[0]), int(c[1])
+
     def last_stats(self):
         """Counters of the last search: candidates scanned, work items, tables, scan launches."""
         st = np.zeros(4, dtype=np.int64)
@@ -538,6 +544,8 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
         self._fine_arr = np.zeros((0, model.M), dtype=np.uint8)  # row -> fine codes
         self._dev = None   # LOPQSearcherHIP over the key-ordered arrays
         self._suffix_of_slot = []
+        self._tail_of_cell = {}   # cell -> largest key suffix in the device index
+        self._pending = []        # rows added since the device index was built (None: it must be rebuilt)
         self.env = None
         self._log = None   # kvlog.KVLog: the persistent form when the lmdb module is not installed
         if lmdb_path is not None:
@@ -571,6 +579,10 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
     def _put(self, key, fine):
         """put(): a new key takes the next row, an existing key has its value replaced (last write wins, :465)."""
         row = self._row_of.get(key)
+        if row is not None:
+            self._pending = None  # a stored value changes: the device index is rebuilt before the next search
+        elif self._pending is not None:
+            self._pending.append(len(self._suffixes))
         if row is None:
             row = len(self._suffixes)
             if row >= self._cap:  # grow the row arrays geometrically
@@ -652,9 +664,8 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
                 self.env.sync()
             if logged:
                 self._log.append(logged)  # one write + fsync per add_codes call (the reference: env.sync(), :468)
-        if self._dev is not None:  # the key-ordered GPU index is rebuilt before the next search
-            self._dev.close()
-            self._dev = None
+        # the key-ordered GPU index follows before the next search: the new keys alone when they all sort behind their cells' last
+        # keys (production ids arrive in time order inside an update), a rebuild otherwise (_device_index)
         self.get_nb_indexed()
 
     def add_codes_array(self, coarse, fine, ids=None, dedup=True):
@@ -672,15 +683,44 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
     def _device_index(self):
         """The GPU index in key order: one lexicographic sort of (cell, key suffix) over the row arrays (numpy, no Python loop
         over the items) and one device-side bulk insert -- rounds 1-2 re-sorted a dict of dicts item by item on every refresh."""
+        if self._dev is not None and self._pending:
+            # incremental refresh: every new key must sort after the last key of its cell in the device index, then appending the new
+            # keys in (cell, key) order keeps every cell in key order (the cursor's order, :482-499) -- the device insert is O(batch)
+            rows = sorted(self._pending, key=lambda r: (tuple(int(v) for v in self._cells_arr[r]), self._suffixes[r]))
+            ok, tails = True, dict()
+            for r in rows:
+                cell = tuple(int(v) for v in self._cells_arr[r])
+                tail = tails.get(cell, self._tail_of_cell.get(cell))
+                if tail is not None and self._suffixes[r] <= tail:
+                    ok = False
+                    break
+                tails[cell] = self._suffixes[r]
+            if ok:
+                base = len(self._suffix_of_slot)
+                rr = np.array(rows, dtype=np.int64)
+                self._dev.add_codes_array(np.ascontiguousarray(self._cells_arr[rr]), np.ascontiguousarray(self._fine_arr[rr]),
+                                          ids=np.arange(base, base + len(rows), dtype=np.int64), dedup=False)
+                self._suffix_of_slot.extend(self._suffixes[r] for r in rows)
+                self._tail_of_cell.update(tails)
+                self._pending = []
+            else:
+                self._pending = None
+        if self._dev is not None and self._pending is None:
+            self._dev.close()
+            self._dev = None
         if self._dev is None:
             n = len(self._suffixes)
             self._dev = LOPQSearcherHIP(self.model)
+            self._pending = []
+            self._tail_of_cell = {}
             if n:
                 cells = self._cells_arr[:n]
                 cell_id = cells[:, 0].astype(np.int64) * 65536 + cells[:, 1]
                 # fixed-width byte strings compare like the keys do (a shorter key sorts first; ids hold no NUL bytes)
                 order = np.lexsort((np.array(self._suffixes, dtype="S"), cell_id))
                 self._suffix_of_slot = [self._suffixes[r] for r in order]
+                for r in order:  # ascending (cell, key): the last write per cell is its tail
+                    self._tail_of_cell[(int(cells[r, 0]), int(cells[r, 1]))] = self._suffixes[r]
                 self._dev.add_codes_array(np.ascontiguousarray(cells[order]), np.ascontiguousarray(self._fine_arr[:n][order]),
                                           ids=np.arange(n, dtype=np.int64), dedup=False)
             else:

@@ -141,6 +141,11 @@ int cis_index_create_view(cis_index** out, cis_index* base);
  * multisequence order and quota cut-off without communicating (search.py:128-133).
  * owner = NULL selects cell_id % world.  Must be called on an empty index. */
 int cis_index_set_shard(cis_index* ix, int rank, int world, const int32_t* owner /* [V*V] or NULL */);
+/* How the insert calls of this handle were served: counters[0] = batches written IN PLACE behind their cells' last items (O(batch):
+ * the reference appends to a per-cell list, lopq/lopq/search.py:349-364), counters[1] = batches that rebuilt the layout (a cell's
+ * slack was exhausted, or a bulk load). */
+int cis_index_insert_counters(cis_index* ix, int64_t counters[2]);
+
 /* Routed insert into a cell-sharded index: cis_index_add is then given only the codes of
  * the cells this rank owns; cis_index_cell_counts reads the per-cell sizes [V*V] (all shards), and
  * cis_index_add_remote_counts adds per-cell increments [V*V] for the cells owned by OTHER ranks (entries of owned cells

@@ -191,3 +191,51 @@ def test_l2_normalisation_kernel_matches_numpy():
         want = np.stack([r / np.linalg.norm(r) if r.any() else r for r in x])
         assert got.dtype == dtype and (got[7] == 0).all()
         np.testing.assert_allclose(got, want, rtol=tol, atol=0)
+
+
+def test_small_batches_are_inserted_in_place_and_equal_the_dict_index(monkeypatch):
+    """Round 4: a batch whose accepted items fit the slack behind their cells is written IN PLACE (two kernels, O(batch) bytes:
+    the reference appends to a per-cell list, lopq/lopq/search.py:349-364); a batch that does not fit rebuilds the layout and
+    renews the slack.  Same cells, same order, same search results as the oracle's dict index on both routes -- ids below and above
+    the cells' maxima, duplicates inside a batch and against stored items, a cell that fills up."""
+    import torch
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    from oracle import lopq_oracle as O
+    m, z, X, Q = _model("c2")
+    V, M, K = m.V, m.M, m.subquantizer_clusters
+    rs = np.random.RandomState(11)
+    s = LOPQSearcherHIP(m)
+    oi = _oracle_index(z)
+    n0 = 20000
+    coarse0, fine0 = z["coarse"][:n0], z["fine"][:n0]
+    ids0 = rs.permutation(n0).astype(np.int64) * 3  # not monotone: later ids fall below the cells' maxima
+    oi.add_codes_arrays(coarse0, fine0, ids0.tolist())
+    assert s.add_codes_array(coarse0, fine0, ids0) == n0
+    assert s.insert_counters() == (0, 1)  # the bulk load builds the layout (with slack behind every cell)
+    for b in range(30):
+        n = int(rs.randint(1, 300))
+        pick = rs.randint(0, len(z["coarse"]), size=n)
+        coarse, fine = z["coarse"][pick].copy(), z["fine"][pick].copy()
+        ids = rs.randint(0, 3 * n0 + 500, size=n).astype(np.int64)  # ~1/3 of them already stored somewhere
+        if b % 5 == 4:  # one cell takes a burst that no slack holds: the rebuild route
+            coarse[:] = coarse[0]
+            ids = np.arange(10 ** 6 + b * 1000, 10 ** 6 + b * 1000 + n, dtype=np.int64)
+        before = oi.nb_indexed
+        oi.add_codes_arrays(coarse, fine, ids.tolist())
+        if b % 2:
+            added = s.add_codes_array(coarse, fine, ids)
+        else:
+            added, bad = s.add_codes_dev(torch.as_tensor(coarse.view(np.int16)).cuda(), torch.as_tensor(fine).cuda(), torch.as_tensor(ids).cuda())
+            assert bad == 0
+        assert added == oi.nb_indexed - before, b
+        assert s.get_nb_indexed() == oi.nb_indexed
+    inplace, rebuilt = s.insert_counters()
+    assert inplace >= 15 and rebuilt >= 2, (inplace, rebuilt)
+    _assert_same_cells(s, oi, V)
+    for qi in range(4):
+        want, visited = oi.search(Q[qi], quota=2000, limit=50)
+        r = s.search_batch(Q[qi:qi + 1], quota=2000, limit=50)
+        k = int(r["n_found"][0])
+        assert k == len(want) and int(r["visited"][0]) == visited
+        np.testing.assert_array_equal(r["ids"][0, :k], np.array([w[0] for w in want], dtype=np.int64))
+    # tight packing (CIS_INSERT_SLACK=-1 is read once per process: not switchable here) stays covered by the bulk tests above

@@ -430,3 +430,51 @@ def test_lmdb_order_index_cold_start_answers_like_the_live_one(tmp_path):
         res, visited = cold.search(Q[i], quota=200, limit=30, with_dists=True)
         assert visited == want[i][1] and [(r.id, r.code, r.dist) for r in res] == [(r.id, r.code, r.dist) for r in want[i][0]]
     cold.close()
+
+
+@gpu
+def test_lmdb_order_index_refreshes_incrementally_when_new_keys_sort_last(tmp_path):
+    """Round 4: after add_codes the key-ordered GPU index takes only the NEW keys when every one of them sorts behind the last key of
+    its cell (ids that grow with time), and is rebuilt otherwise (an earlier key, or a replaced value); either way it answers like a
+    searcher built from scratch over the same store (lopq/lopq/search.py:445-499: put = last write wins, cells in key order)."""
+    from columbiaimagesearch_amd.lopq import LOPQSearcherLMDB
+    m, z, Q = _lmdb_fixture()
+    n = 2400
+    codes = [((int(c[0]), int(c[1])), tuple(int(v) for v in f)) for c, f in zip(z["coarse"][:n], z["fine"][:n])]
+    ids = ["%08d" % i for i in range(n)]  # zero-padded: byte order == numeric order
+
+    def fresh(upto, extra=()):
+        s = LOPQSearcherLMDB(m, None, id_lambda=str)
+        s.add_codes(codes[:upto], ids[:upto])
+        for c, i in extra:
+            s.add_codes([c], [i])
+        return s
+
+    live = LOPQSearcherLMDB(m, None, id_lambda=str)
+    live.add_codes(codes[:1500], ids[:1500])
+    live.search(Q[0], quota=300, limit=20)                      # builds the device index
+    dev0 = live._dev
+    live.add_codes(codes[1500:1560], ids[1500:1560])            # later keys only: incremental, small enough for the cells' slack
+    live.search(Q[0], quota=300, limit=20)
+    assert live._dev is dev0 and live._dev.insert_counters()[0] >= 1   # same device index, the batch went in place
+    live.add_codes(codes[1560:2000], ids[1560:2000])            # later keys again (a burst: in place or a device-side rebuild, same index object)
+    got = [live.search(Q[i], quota=300, limit=20, with_dists=True) for i in range(4)]
+    assert live._dev is dev0
+    ref = fresh(2000)
+    for i in range(4):
+        want = ref.search(Q[i], quota=300, limit=20, with_dists=True)
+        assert got[i][1] == want[1] and [(r.id, r.code, r.dist) for r in got[i][0]] == [(r.id, r.code, r.dist) for r in want[0]]
+    early = (codes[7], "00000003x")                              # sorts in the middle of its cell: the rebuild route
+    live.add_codes([early[0]], [early[1]])
+    got = [live.search(Q[i], quota=300, limit=20, with_dists=True) for i in range(4)]
+    assert live._dev is not dev0
+    ref2 = fresh(2000, [early])
+    for i in range(4):
+        want = ref2.search(Q[i], quota=300, limit=20, with_dists=True)
+        assert got[i][1] == want[1] and [(r.id, r.code, r.dist) for r in got[i][0]] == [(r.id, r.code, r.dist) for r in want[0]]
+    dev1 = live._dev
+    live.add_codes([codes[11]], [ids[5]])                        # an existing key gets a new value: rebuild
+    live.search(Q[0], quota=300, limit=20)
+    assert live._dev is not dev1
+    for s in (live, ref, ref2):
+        s.close()
