@@ -82,6 +82,8 @@ _PROTOS = {
                                    c_void_p]),
     "cis_merge_packed_dev": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cis_pyramid_down2_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "cis_extract_chips_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "cis_exchange_offsets_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cis_rerank_dev": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "cis_kmeans": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

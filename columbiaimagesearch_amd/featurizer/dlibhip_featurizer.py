@@ -2,9 +2,10 @@
 
 Mirror of DLibFeaturizer (cufacesearch/cufacesearch/featurizer/dlib_featurizer.py:50-105): constructor
 ``(global_conf_in, prefix)`` reading ``<prefix>pred_path`` (68-landmark shape predictor) and ``<prefix>rec_path``
-(recognition network weights), ``featurize(img, bbox)`` -> 128 float64 values.  The landmark predictor and the chip
-alignment are dlib host code (out of scope, like image decoding); the 29-convolution ResNet runs in libcis_hip.so.
-``featurize_chips`` takes already aligned 150x150 RGB chips and is the batch entry point.
+(recognition network weights), ``featurize(img, bbox)`` -> 128 float64 values.  The landmark predictor is dlib host code (out
+of scope, like image decoding: supply it through ``landmark_fn`` or pass ``landmarks=``); the chip alignment
+(get_face_chip_details + extract_image_chip, featurizer/face_chip.py + csrc/face_chip.hip) and the 29-convolution ResNet run in
+libcis_hip.so.  ``featurize_chips`` takes already aligned 150x150 RGB chips, ``featurize_landmarks`` an image and its shapes.
 
 Weights: ``rec_path`` is an ``.npz`` with the 117 arrays of ``tensor_names()``, or the XML that dlib's own
 ``net_to_xml`` writes from ``dlib_face_recognition_resnet_model_v1.dat`` (featurizer/dlib_weights.py; the ``.dat`` itself
@@ -86,7 +87,8 @@ class DLibHIPFeaturizer(GenericFeaturizer):
                                       "117 network tensors -- see INTEGRATION.md section 4 (dlib's .dat stream is not parsed)")
         self.net = DLibFaceNet(weights)
         self._sp = None
-        self.chip_fn = None  # (img, bbox) -> aligned 150x150x3 chip; default: dlib landmarks + get_face_chip
+        self.chip_fn = None      # (img, bbox) -> aligned 150x150x3 chip
+        self.landmark_fn = None  # (img, bbox) -> [68, 2] landmarks (x, y): the chip is then cut on the GPU (featurizer/face_chip.py)
 
     def featurize_chips(self, chips):
         """aligned 150x150 RGB chips -> [n,128] float64 (dtype of the reference's descriptors, featsio.py:34-36)"""
@@ -99,11 +101,25 @@ class DLibHIPFeaturizer(GenericFeaturizer):
             img = np.stack([img] * 3, axis=-1)  # reference :97-99 gray2rgb
         return self.featurize_chips(np.stack([self._chip(img, d) for d in dets]))
 
-    def featurize(self, img, bbox=None, img_type="scikit"):
-        """reference :86-105: landmarks on the detected box, aligned chip, network.  Needs dlib for the two host steps
-        (or `chip_fn`)."""
+    def featurize_landmarks(self, img, shapes):
+        """img [H, W, 3] uint8 RGB + n landmark sets [68, 2] (what dlib.shape_predictor returns, :103) -> [n, 128] float64:
+        get_face_chip_details(shape, 150, 0.25) on the host (a similarity transform per face), chip extraction and the network on the
+        GPU -- compute_face_descriptor(img, shape) (:105) without dlib.  The chips never visit the host."""
+        from .face_chip import face_chips
         if len(img.shape) == 2:
             img = np.stack([img] * 3, axis=-1)
+        chips = face_chips(img, [np.asarray(sh, dtype=np.float64) for sh in shapes])
+        return self.net.forward_dev(chips).cpu().numpy().astype(np.float64)
+
+    def featurize(self, img, bbox=None, img_type="scikit", landmarks=None):
+        """reference :86-105: landmarks on the detected box, aligned chip, network.  The landmarks come from `landmarks` / the
+        `landmark_fn` hook (then nothing of dlib is needed), else from dlib's shape predictor (or the whole chip from `chip_fn`)."""
+        if len(img.shape) == 2:
+            img = np.stack([img] * 3, axis=-1)
+        if landmarks is None and self.landmark_fn is not None and self.chip_fn is None:
+            landmarks = self.landmark_fn(img, bbox)
+        if landmarks is not None:
+            return self.featurize_landmarks(img, [landmarks])[0]
         return self.featurize_chips(np.asarray(self._chip(img, bbox))[None])[0]
 
     def _chip(self, img, bbox):
@@ -118,4 +134,7 @@ class DLibHIPFeaturizer(GenericFeaturizer):
             self._sp = dlib.shape_predictor(str(self.pred_path))
         rect = dlib.rectangle(int(bbox["left"]), int(bbox["top"]), int(bbox["right"]), int(bbox["bottom"]))
         shape = self._sp(img, rect)
-        return np.asarray(dlib.get_face_chip(img, shape, size=INPUT_HW, padding=0.25))
+        # the landmark predictor is dlib's; the chip is cut on the GPU like everything after it
+        from .face_chip import face_chips
+        lm = np.array([[shape.part(i).x, shape.part(i).y] for i in range(68)], dtype=np.float64)
+        return face_chips(img, [lm])[0].cpu().numpy()

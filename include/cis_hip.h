@@ -304,6 +304,16 @@ int cis_cnn_feat_dim(int arch);
 int cis_cnn_forward(cis_cnn* c, const float* nchw, int n, float* feats);
 int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float* d_feats, void* stream);
 
+/* ---- aligned face chips: the image side of dlib's compute_face_descriptor(img, shape) -------------------------------------
+ * (cufacesearch/cufacesearch/featurizer/dlib_featurizer.py:103-105).  The caller supplies the 68 landmarks (the shape predictor is
+ * not on this path); columbiaimagesearch_amd/featurizer/face_chip.py turns them into dlib's chip_details (get_face_chip_details(shape,
+ * 150, 0.25): similarity transform onto the mean face) and into the affine map chip pixel -> source pixel of extract_image_chips.
+ * cis_pyramid_down2_dev: dlib's pyramid_down<2> on an RGB uint8 image [nr][nc][3] -> [(nr-3)/2][(nc-3)/2][3] (d_tmp: nr*((nc-3)/2)*3 ints).
+ * cis_extract_chips_dev: n chips [n][size][size][3] float32 0..255 (the input of cis_cnn_forward, CIS_CNN_DLIB_RESNET) out of one image
+ * or pyramid level by dlib's interpolate_bilinear; d_maps [n][6] float64: source (x, y) = (m0 + m1 c + m2 r, m3 + m4 c + m5 r). */
+int cis_pyramid_down2_dev(const uint8_t* d_img, int nr, int nc, uint8_t* d_out, int* d_tmp, void* stream);
+int cis_extract_chips_dev(const uint8_t* d_img, int nr, int nc, const double* d_maps, int n, int size, float* d_chips, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
