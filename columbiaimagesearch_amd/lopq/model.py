@@ -314,14 +314,38 @@ class LOPQModelPCA(LOPQModel):
         """reference: lopq/lopq/model.py:889-937"""
         if train_pca:
             self.fit_pca(data, pca_dims, pca_subsample)
-        pca_data = _train.apply_pca_host(data, self.pca_P, self.pca_mu, self.renorm) if apply_pca else data
+        if apply_pca and _train.ACCUM_BACKEND == "hip":  # the projection of the training set on the GPU as well (apply_PCA, :961-978)
+            pca_data = self.apply_PCA(data)
+        else:
+            pca_data = _train.apply_pca_host(data, self.pca_P, self.pca_mu, self.renorm) if apply_pca else data
         params = _train.train(pca_data, self.V, self.M, self.subquantizer_clusters,
                               (self.Cs, self.Rs, self.mus, self.subquantizers), kmeans_coarse_iters,
                               kmeans_local_iters, n_init, subquantizer_sample_ratio, random_state, verbose)
         self.Cs, self.Rs, self.mus, self.subquantizers = params
 
+    def _pca_only_handle(self):
+        """apply_PCA before the LOPQ parameters exist (the reference's training flow: fit_pca, then apply_PCA on every batch of
+        features, then fit -- lopq/lopq/model.py:878-937, cufacesearch/searcher/searcher_lopqhbase.py:340): a device model that carries
+        the PCA parameters and placeholder LOPQ parameters of the right shapes (never used by apply_PCA)."""
+        P = np.asarray(self.pca_P)
+        key = (id(self.pca_P), id(self.pca_mu), bool(self.renorm))
+        cached = self.__dict__.get("_pca_only")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        D = P.shape[1]
+        hd = D // 2
+        eye = np.eye(hd)[None]
+        tmp = LOPQModelPCA(V=1, M=2, renorm=self.renorm,
+                           parameters=((np.zeros((1, hd)), np.zeros((1, hd))), (eye, eye), (np.zeros((1, hd)), np.zeros((1, hd))),
+                                       ([np.zeros((self.subquantizer_clusters, hd))], [np.zeros((self.subquantizer_clusters, hd))]),
+                                       self.pca_P, self.pca_mu))
+        self.__dict__["_pca_only"] = (key, tmp)
+        return tmp
+
     def apply_PCA(self, x, dtype=np.float32):
         """reference: lopq/lopq/model.py:961-978 -> float32, 1-D in -> 1-D out"""
+        if (self.Cs is None or self.Rs is None or self.subquantizers is None) and self.pca_P is not None:
+            return self._pca_only_handle().apply_PCA(x, dtype)
         h = self._handle()
         X = _lib.as_float_matrix(x, self.input_dim)
         out = np.empty((X.shape[0], self.dim), dtype=np.float32)

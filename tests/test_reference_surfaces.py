@@ -478,3 +478,16 @@ def test_lmdb_order_index_refreshes_incrementally_when_new_keys_sort_last(tmp_pa
     assert live._dev is not dev1
     for s in (live, ref, ref2):
         s.close()
+
+
+@gpu
+def test_apply_pca_works_before_the_lopq_parameters_exist():
+    """The reference's training flow calls apply_PCA between fit_pca and fit (lopq/lopq/model.py:878-937,
+    searcher_lopqhbase.py:340): a model that holds only pca_P / pca_mu must project like the fitted one."""
+    from columbiaimagesearch_amd.lopq import LOPQModelPCA
+    m, z, Q = _lmdb_fixture()
+    only = LOPQModelPCA(V=m.V, M=m.M, renorm=bool(z["renorm"]), parameters=(None, None, None, None, z["pca_P"], z["pca_mu"]))
+    np.testing.assert_array_equal(only.apply_PCA(Q[:50]), m.apply_PCA(Q[:50]))
+    assert only.apply_PCA(Q[0]).shape == m.apply_PCA(Q[0]).shape
+    with pytest.raises(ValueError):
+        only.predict(Q[0])  # still no LOPQ parameters
