@@ -18,8 +18,9 @@ for line in open("gpurun_out/%s_%s_sq_pmc.csv" % (tag, cfg)).read().splitlines()
         tot[parts[2]] = tot.get(parts[2], 0.0) + float(parts[3])
         if kern is None or "scan4" in parts[0]:
             kern = parts[0]
-line = json.load(open("gpurun_out/%s_%s_bench_line.json" % (tag, cfg)))
-ms = line["roofline"]["avg_launch_ms"]
+serial = "gpurun_out/%s_%s_bench_line_serial.json" % (tag, cfg)   # one batch at a time: the launch alone on the chip
+line = json.load(open(serial if os.path.exists(serial) else "gpurun_out/%s_%s_bench_line.json" % (tag, cfg)))
+ms = line["roofline"].get("isolated_launch_ms") or line["roofline"]["avg_launch_ms"]
 cyc = ms * 1e-3 * CLK
 per = {k: v / equiv for k, v in tot.items()}
 out = {"config": cfg, "kernel": kern, "avg_launch_ms": ms,
