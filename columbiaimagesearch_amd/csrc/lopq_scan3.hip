@@ -1139,6 +1139,12 @@ static const int S4_OCT = CIS_S4_OCT;  // table reads per pipeline unit of the m
 #ifndef CIS_S4_WPE8
 #define CIS_S4_WPE8 6      // waves per SIMD the 8-wave long-chunk variant is compiled for (80 registers: three workgroups per CU)
 #endif
+#ifndef CIS_S4_GLISTS
+#define CIS_S4_GLISTS 0    // 1: long chunks keep their per-query lists in global memory (26 KB of LDS per workgroup) -- measured and lost, see GLISTS below
+#endif
+#ifndef CIS_S4_WPE_LONG
+#define CIS_S4_WPE_LONG 6  // waves per SIMD the long-chunk variant is compiled for (80 registers) when its lists are in global memory
+#endif
 #ifndef CIS_S4_PF
 #define CIS_S4_PF 2  // iterations of a wave that its code rows travel ahead
 #endif
@@ -1158,7 +1164,8 @@ static const int S4_NS = CIS_S4_NS;      // sample rows per chunk (64 sums per q
 static const int S4_LCAP_LONG = 1016;    // list entries per query for long chunks (sixteen registers per lane in the verification)
 
 static size_t scan4_lds(int M, int K, int lcap, int nw) {
-    const size_t lists = (size_t)S3G * lcap * 4, samp = (size_t)S3G * S4_NS * 64 * 2;
+    const bool glists = lcap > 504 && CIS_S4_DEFER != 0 && CIS_S4_GLISTS != 0;
+    const size_t lists = glists ? (size_t)nw * ((32 / nw) * 128) * 2 : (size_t)S3G * lcap * 4, samp = glists ? 0 : (size_t)S3G * S4_NS * 64 * 2;
     return (size_t)K * M * S3G * 2 + (lists > samp ? lists : samp) + S3G * sizeof(Scan4Shared) + 32 + (size_t)S3G * nw * 4 + (S4_DS + 1) * sizeof(Slot4);
 }
 
@@ -1181,7 +1188,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     constexpr int nf = M / 2;
     constexpr uint32_t CAP = 65535u / M;
     constexpr int LCAP = LCAPT, NS = S4_NS, NRV = (LCAP + 63) / 64;
-    constexpr size_t LIST_B = (size_t)G * LCAP * 4 > (size_t)G * NS * 64 * 2 ? (size_t)G * LCAP * 4 : (size_t)G * NS * 64 * 2;
+    // GLISTS (round 4, long chunks with the deferred split): the per-query lists live in the items' survivor rows in GLOBAL memory
+    // (written by the second gather, read back from L2 by the verification: ~1600 entries per slot), so LDS holds the tables and the
+    // 16-bit position lists only -- 26 KB per workgroup, six workgroups per CU instead of four: a slot is bound by latency, and 46 % of
+    // it is serial per-query work during which only other workgroups can use the SIMDs.
+    // MEASURED (profiles/r04_scan4_glists_ab.txt, C4, one batch at a time): 128 registers / 4 workgroups per CU 0.237 ms (= the LDS lists,
+    // 0.232-0.238), 96 registers / 5 per CU 0.256, 80 registers / 6 per CU 0.310 -- the register budget of the higher occupancies costs
+    // more (48 / 71 spilled registers) than the extra workgroups bring.  Off by default; results identical either way.
+    constexpr bool GLISTS = (LCAPT > 504) && (CIS_S4_DEFER != 0) && (CIS_S4_GLISTS != 0);
+    constexpr size_t LIST_B_FULL = (size_t)G * LCAP * 4 > (size_t)G * NS * 64 * 2 ? (size_t)G * LCAP * 4 : (size_t)G * NS * 64 * 2;
+    constexpr size_t LIST_B = GLISTS ? (size_t)NW * (((LCAPT > 504 ? 32 : 16) / NW) * 128) * 2 : LIST_B_FULL;
     char* tab = smem;                                                            // [K][M][G] uint16
     uint32_t* lists = reinterpret_cast<uint32_t*>(smem + (size_t)K * M * G * 2);  // [G][LCAP] (sum << 16 | position)
     uint16_t* samp = reinterpret_cast<uint16_t*>(lists);                         // [G][NS * 64] the sample's sums (before the main pass)
@@ -1758,6 +1774,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                         for (int r = 0; r < NRP; ++r)
                             pp[r] = (2 * (r * 64) < pn) ? reinterpret_cast<const volatile uint32_t*>(plist)[r * 64 + lane] : 0u;
                         lds_barrier();  // B3b: every wave holds its positions; nobody still writes a position list
+                        uint32_t* grow[G];  // GLISTS: the items' survivor rows as 32-bit list memory (S 8-byte entries = 2 S list entries >= LCAP)
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+                            grow[g] = reinterpret_cast<uint32_t*>(item_surv + (int64_t)__builtin_amdgcn_readfirstlane(d->item[g]) * S);
                         if (pn > 0) {
                             auto pos_of = [&](int it) -> uint32_t {  // iteration it takes half (it & 1) of register it >> 1
                                 uint32_t v = pp[0];
@@ -1790,7 +1810,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                                     const unsigned long long mg = __ballot(sg < t1) & am2;
                                     if (mg == 0ull) continue;
                                     const int idx = __builtin_amdgcn_mbcnt_hi((unsigned)(mg >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mg, wcur[g]));
-                                    if (((mg >> lane) & 1ull) && idx < WCAP) lists[(g * NW + w) * WCAP + idx] = (sg << 16) | pos;
+                                    if (((mg >> lane) & 1ull) && idx < WCAP) {
+                                        if constexpr (GLISTS) grow[g][w * WCAP + idx] = (sg << 16) | pos;
+                                        else lists[(g * NW + w) * WCAP + idx] = (sg << 16) | pos;
+                                    }
                                     wcur[g] += __popcll(mg);
                                 }
                             }
@@ -1808,7 +1831,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     }
                 }
                 S3_CTR(12, S3_CLK() - c0);
-                lds_barrier();  // B4: lists complete
+                if constexpr (GLISTS) __syncthreads();  // B4: lists complete -- in global memory: the barrier also waits for the stores (vmcnt)
+                else lds_barrier();  // B4: lists complete
                 S3_CTR(5, S3_CLK() - c0);
                 // ---- verification + cut + write-out: wave g serves query g ------------------------------------------------------------
                 bool bad = false;
@@ -1839,7 +1863,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                                 constexpr int RW = NRV / NW;  // registers per wave quarter
                                 const int e = (r % RW) * 64 + lane_v;
                                 val[r] = e < wtot[r / RW];
-                                ent[r] = val[r] ? lists[(g * NW + r / RW) * WCAP + e] : 0xffffffffu;
+                                if constexpr (GLISTS) {  // written by the other waves of this workgroup: read past the L1 (device scope)
+                                    const uint32_t* gr = reinterpret_cast<const uint32_t*>(item_surv + (int64_t)__builtin_amdgcn_readfirstlane(d->item[g]) * S);
+                                    ent[r] = val[r] ? __hip_atomic_load(gr + (r / RW) * WCAP + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                                } else {
+                                    ent[r] = val[r] ? lists[(g * NW + r / RW) * WCAP + e] : 0xffffffffu;
+                                }
                             } else {
                                 val[r] = r * 64 + lane_v < tot;
                                 ent[r] = val[r] ? lists[g * LCAP + r * 64 + lane_v] : 0xffffffffu;
@@ -2023,7 +2052,7 @@ static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, 
                                        n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_short, 1 << 20, S4_NS, 0);
                 }
             } else {
-                constexpr int WPE4 = (M == 16) ? 3 : 4;  // (M = 16: 49 KB of LDS = three workgroups per CU, 168 registers)
+                constexpr int WPE4 = (M == 16) ? 3 : ((CIS_S4_DEFER != 0 && CIS_S4_GLISTS != 0) ? CIS_S4_WPE_LONG : 4);  // (M = 16: 49 KB of LDS = three workgroups per CU, 168 registers)
                 if (nw4_long == 8 && M != 16) {
                     constexpr int WPE8 = CIS_S4_WPE8;
                     const size_t lds4 = scan4_lds(M, K, S4_LCAP_LONG, 8);
