@@ -78,6 +78,8 @@ struct cis_index {
     int batch_hint = 0;             // sub-batch size that fitted the workspace budget after a retry (search_all)
     int64_t batch_hint_quota = -1;
     double retry_fraction = 0.5;
+    int m16_holdoff = 0;            // batches the sampled scan at M = 16 stays off after a batch where its scale missed (search_batch)
+    int64_t m16_backoffs = 0;
     int last_scan_kernel = 0;       // 0 none (all-candidates path), 1 float64 scan, 2 float32 prefilter, 3 16-bit fixed-point prefilter, 4 its sampled single-pass form (k_adc_scan4)
     bool force_prefilter_scan = false;  // tests: the float32-prefilter kernel also for small batches
     int profiling = 0;  // 0 off, 1 events around the scan kernel only, 2 events around every stage

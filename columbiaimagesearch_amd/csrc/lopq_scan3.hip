@@ -1176,7 +1176,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     int* __restrict__ dbg /* [2]: slots, fallbacks */, int* __restrict__ fhdr /* fall-back list: [17] = count (queue 0 of a scan3 header) */,
     int* __restrict__ fslots, uint64_t* __restrict__ item_surv, int* __restrict__ item_n, float* __restrict__ item_slack,
     unsigned long long* __restrict__ qbound, float zq /* sample rank margin: k - zq sqrt(k) */, int frac_den /* sample one row in frac_den */,
-    int nsx /* most sample rows per chunk */, int dyn /* slots from a counter instead of the static schedule */) {
+    int nsx /* most sample rows per chunk */, int dyn /* slots from a counter instead of the static schedule */,
+    float sat /* 0, or the saturating scale: a strided sample of the chunk puts the sums of the near candidates at sat * CAP */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int G = S3G;
     // NW waves gather (sample, main pass, second gather); waves 0 .. G-1 also serve one query each in the threshold and verification
@@ -1349,6 +1350,59 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     qinv[g] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, d->qinv[g])));
                 const int len = __builtin_amdgcn_readfirstlane(d->len);
                 const int64_t start = ((int64_t)__builtin_amdgcn_readfirstlane(d->start_hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(d->start_lo);
+                if (sat > 0.0f) {
+                    // SATURATING scale (M = 16, round 4).  Scaled by the tables' LARGEST entries, sixteen 12-bit entries leave the sums of
+                    // the near candidates ~100 units, and the + M + 1 slack of the brackets is then 17 % of the cut: 84 % of the lists
+                    // overflowed.  Instead wave g takes 64 candidates of the chunk at a stride, sums them in float32 from the global
+                    // tables, and scales query g so that the FOURTH smallest of them for a long chunk (the ~6 % quantile: never one of
+                    // the limit best by bad luck alone; a later one for short chunks) lands at sat * CAP; far entries SATURATE at CAP.
+                    // Measured on C3: no slot falls back for sat in 0.5 .. 0.95, all do from 1.1 (profiles/r04v_m16.txt).  A saturated entry keeps every sum a lower
+                    // bound of d * qinv (truncation and the clamp only round down), so rejecting s > thr stays exact; the other
+                    // direction -- "the candidates with s <= v have d * qinv < v + M" -- needs unsaturated entries, which s < CAP
+                    // guarantees: thresholds and cuts at or above CAP send the slot to the forms that need no such scale.
+                    if (w < G) {
+                        const int g = w;
+                        if (g < ng) {  // wave-uniform
+                            const int t0 = __builtin_amdgcn_readfirstlane(d->tab0[g]), t1 = __builtin_amdgcn_readfirstlane(d->tab1[g]);
+                            const float* Ta = T32 + (int64_t)t0 * nf * K;
+                            const float* Tb = T32 + (int64_t)t1 * nf * K;
+                            const int c = len >= 64 ? (int)(((int64_t)lane * len) >> 6) : lane;
+                            uint32_t key = 0x7f7fffffu;
+                            if (c < len) {
+                                const CodeWords<M> cw = load_code<M>(codes, start + c);
+                                float ds = 0.f;
+#pragma unroll
+                                for (int j = 0; j < M / 2; ++j) ds += Ta[j * K + ((cw.w[j >> 2] >> (8 * (j & 3))) & 255u)];
+#pragma unroll
+                                for (int j = 0; j < M / 2; ++j) ds += Tb[j * K + ((cw.w[(M / 2 + j) >> 2] >> (8 * ((M / 2 + j) & 3))) & 255u)];
+                                key = __float_as_uint(fmaxf(ds, 0.f));  // (entries are >= 0: the bit patterns order like the values)
+                            }
+                            // rank of the sample that stands for "just above the limit-th candidate": 4 + the sample's share of the limit
+                            // best (64 L / len: short chunks keep a larger part of themselves)
+                            int rk = 4 + (int)((64 * (int64_t)L + len - 1) / len);
+                            rk = rk > 48 ? 48 : rk;
+                            uint32_t mn = key;
+                            for (int r = 0; r < rk; ++r) {
+                                uint32_t mx = 0u;
+                                mn = key;
+                                wave_minmax_step<1>(mn, mx); wave_minmax_step<2>(mn, mx); wave_minmax_step<4>(mn, mx);
+                                wave_minmax_step<8>(mn, mx); wave_minmax_step<16>(mn, mx); wave_minmax_step<32>(mn, mx);
+                                if (r + 1 < rk) {
+                                    const uint64_t hit = __ballot(key == mn);
+                                    if (lane == (int)__builtin_ctzll(hit)) key = 0x7f7fffffu;
+                                }
+                            }
+                            const float d4 = __uint_as_float(mn);
+                            const float qs = (sat * (float)CAP) / fmaxf(d4, 1e-30f);
+                            const float q0 = d->qinv[g];
+                            if (lane == 0 && q0 > 0.0f && qs > q0 && qs < 3.0e38f && d4 < 1.0e38f) const_cast<Slot4*>(d)->qinv[g] = qs;
+                        }
+                    }
+                    lds_barrier();
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        qinv[g] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, d->qinv[g])));
+                }
                 // ---- tables -> 16-bit entries -> LDS (scan3_group's arithmetic) --------------------------------------------------
                 // (the thread index is laundered per slot: the staging loop's per-thread offsets are loop invariants of the slot loop,
                 // and hoisted they sat in ~20 registers across the hot loop -- spilled, and a spill reload in front of the hot loop makes the
@@ -1492,7 +1546,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                                 else lo = p + 1;
                             }
                             tau = lo;
-                            have_bound = tau < 65534u;
+                            have_bound = tau < (sat > 0.f ? CAP - (uint32_t)M - 2u : 65534u);  // (saturating scale: the bracket needs sums below CAP)
                         }
                         if (lane == 0) {
                             uint32_t keep = 65534u;
@@ -1615,7 +1669,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                                 else lo = p + 1;
                             }
                             tau = lo;
-                            have_bound = tau < 65534u;
+                            have_bound = tau < (sat > 0.f ? CAP - (uint32_t)M - 2u : 65534u);  // (saturating scale: the bracket needs sums below CAP)
                         }
                         if (lane == 0) {
                             uint32_t keep = 65534u;
@@ -1913,8 +1967,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                                     }
                                 }
                                 cut = hi + (uint32_t)M + 1u;
+                                if (sat > 0.f && cut >= CAP) {  // saturating scale: the L best are not all below CAP -- no valid bracket from this scale
+                                    bad = true;
+                                    if (lane_v == 0) atomicAdd(&dbg[4], 1);
+                                }
                                 const uint64_t b = val_to_bound(hi, M, sh[g].ub);  // >= L candidates of this chunk do not exceed it
-                                if (lane_v == 0 && b < sh[g].ext) atomicMin(&qbound[sh[g].q], (unsigned long long)b);
+                                if (lane_v == 0 && !bad && b < sh[g].ext) atomicMin(&qbound[sh[g].q], (unsigned long long)b);
+                            } else if (sat > 0.f) {
+                                // fewer than L collected: everything leaves; with the saturating scale every survivor must still be below CAP
+                                // (the merge turns a survivor's sum into an upper bound of its distance, which a saturated entry would break)
+                                bool sat = false;
+#pragma unroll
+                                for (int r = 0; r < NRV; ++r) sat = sat || (__ballot(val[r] && (ent[r] >> 16) + (uint32_t)M + 1u >= CAP) != 0ull);
+                                if (sat) {
+                                    bad = true;
+                                    if (lane_v == 0) atomicAdd(&dbg[4], 1);
+                                }
                             }
                             const int item = __builtin_amdgcn_readfirstlane(d->item[g]);
                             uint64_t* out = item_surv + (int64_t)item * S;
@@ -1922,8 +1990,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                                 int nk = 0;
 #pragma unroll
                                 for (int r = 0; r < NRV; ++r) nk += __popcll(__ballot(val[r] && (ent[r] >> 16) <= cut));
-                                bad = nk > S;
-                                if (bad && lane_v == 0) atomicAdd(&dbg[4], 1);
+                                if (nk > S) {
+                                    bad = true;
+                                    if (lane_v == 0) atomicAdd(&dbg[4], 1);
+                                }
                             }
                             if (!bad) {
                                 int kept = 0;
@@ -1989,10 +2059,10 @@ Scan3Geom scan3_geom(int M, int K, int L, int64_t avg_chunk, int force_two_pass)
     // of 1016 entries (the sample threshold lets ~4 L candidates through) and a wider rank margin (a list that fails its
     // verification costs a whole streaming-form slot in the fall-back launch)
     g.long_chunks = avg_chunk >= 6144 ? 1 : 0;
-    // the sampled form at M = 16 (CIS_S4_M16=1, off): built and measured on C3 -- with 12-bit entries the + M + 1 slack is ~17 % of the
-    // cut, 84 % of the 1016-entry lists overflow and the slots go to the fall-back (8.99 against 0.60 ms for k_adc_scan2); it needs
-    // 17-bit sums (or a per-query scale that saturates far entries with a flag) first
-    static const int s4_m16 = getenv("CIS_S4_M16") ? atoi(getenv("CIS_S4_M16")) : 0;
+    // the sampled form at M = 16: with the tables' largest entries as the scale the + M + 1 slack was ~17 % of the cut and 84 % of the
+    // lists overflowed (8.99 against 0.60 ms for k_adc_scan2); with the SATURATING scale of k_adc_scan4 (Scan3Geom::sat) no slot of C3
+    // falls back and the scan takes 0.474 ms (profiles/r04v_m16.txt).  CIS_S4_M16=0 keeps M = 16 on k_adc_scan2.
+    static const int s4_m16 = getenv("CIS_S4_M16") ? atoi(getenv("CIS_S4_M16")) : 1;
     if (g.two_pass == 0 && g.long_chunks && (M <= 8 || s4_m16) && L <= 128) g.two_pass = 2;
     if (const char* e = getenv("CIS_SCAN3_TWOPASS")) g.two_pass = atoi(e);
     if (force_two_pass >= 0) g.two_pass = force_two_pass;  // scan modes 3 / 4 / 5 (tests)
@@ -2045,11 +2115,11 @@ static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, 
                 if (nw4_short == 8 && M != 16) {
                     const size_t lds4 = scan4_lds(M, K, S4_LCAP, 8);
                     hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_U, 8, WPE4, S4_LCAP>), dim3(grid_of(lds4, WPE4, 8)), dim3(8 * 64), lds4, st, items, tabs, slots,
-                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_short, 1 << 20, S4_NS, 0);
+                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_short, 1 << 20, S4_NS, 0, g.sat);
                 } else {
                     const size_t lds4 = scan4_lds(M, K, S4_LCAP, NW);
                     hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_U, NW, WPE4, S4_LCAP>), dim3(grid_of(lds4, WPE4, NW)), dim3(NW * 64), lds4, st, items, tabs, slots,
-                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_short, 1 << 20, S4_NS, 0);
+                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_short, 1 << 20, S4_NS, 0, g.sat);
                 }
             } else {
                 constexpr int WPE4 = (M == 16) ? 3 : ((CIS_S4_DEFER != 0 && CIS_S4_GLISTS != 0) ? CIS_S4_WPE_LONG : 4);  // (M = 16: 49 KB of LDS = three workgroups per CU, 168 registers)
@@ -2057,11 +2127,11 @@ static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, 
                     constexpr int WPE8 = CIS_S4_WPE8;
                     const size_t lds4 = scan4_lds(M, K, S4_LCAP_LONG, 8);
                     hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_UL, 8, WPE8, S4_LCAP_LONG>), dim3(grid_of(lds4, WPE8, 8)), dim3(8 * 64), lds4, st, items, tabs, slots,
-                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_long, frac_long, nsx_long, dyn_long);
+                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_long, frac_long, nsx_long, dyn_long, g.sat);
                 } else {
                     const size_t lds4 = scan4_lds(M, K, S4_LCAP_LONG, NW);
                     hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_UL, NW, WPE4, S4_LCAP_LONG>), dim3(grid_of(lds4, WPE4, NW)), dim3(NW * 64), lds4, st, items, tabs, slots,
-                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_long, frac_long, nsx_long, dyn_long);
+                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_long, frac_long, nsx_long, dyn_long, g.sat);
                 }
             }
             if (getenv("CIS_SCAN4_DEBUG")) {  // diagnosis: how many slots the sample misjudged (blocks)

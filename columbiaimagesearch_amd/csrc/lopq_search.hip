@@ -4295,8 +4295,18 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     // ... and long cells at M <= 8, limit <= 128 through its sampled single-pass form (k_adc_scan4 with a tenth of the rows as
     // the sample: profiles/r03m_*); CIS_SCAN_LONG=0 keeps them on k_adc_scan2
     static const int env_long = getenv("CIS_SCAN_LONG") ? atoi(getenv("CIS_SCAN_LONG")) : 1;
-    static const int env_m16 = getenv("CIS_S4_M16") ? atoi(getenv("CIS_S4_M16")) : 0;
-    const bool long_cells = env_long != 0 && !short_cells && (M <= 8 || env_m16) && L <= 128 && ix->ncells <= 65536;
+    // ... and at M = 16 with the saturating scale (round 4).  Its failure mode is expensive -- a slot whose scale missed runs again in
+    // the streaming form, ~14x the time when most of them do -- so the index watches the fall-back count of its last such scan
+    // (a pinned word the scan's stream writes; no wait, the value may be one batch old) and, when more than an eighth of the slots
+    // fell back, serves the next 64 batches from k_adc_scan2 before it tries again.  CIS_S4_M16=0: always k_adc_scan2.
+    static const int env_m16 = getenv("CIS_S4_M16") ? atoi(getenv("CIS_S4_M16")) : 1;
+    if (M == 16 && env_m16 && ix->h_totals) {
+        const int32_t* fb = reinterpret_cast<const int32_t*>(&ix->h_totals[4]);
+        const int32_t n_s = __atomic_load_n(&fb[0], __ATOMIC_RELAXED), n_f = __atomic_load_n(&fb[1], __ATOMIC_RELAXED);
+        if (ix->m16_holdoff > 0) --ix->m16_holdoff;
+        else if (n_s > 0 && (int64_t)n_f * 8 > n_s) { ix->m16_holdoff = 64; ++ix->m16_backoffs; ix->h_totals[4] = 0; }
+    }
+    const bool long_cells = env_long != 0 && !short_cells && (M <= 8 || (env_m16 && ix->m16_holdoff == 0)) && L <= 128 && ix->ncells <= 65536;
     const bool use3 = !ix->force_exact_scan && scan3_supported(M, K, L) && !use_all_path(ix, M, K, L, nq) &&
                       (ix->force_scan3 || (nq >= 256 && !ix->force_scan2 && (env_scan == 3 || (env_scan == 0 && (short_cells || long_cells)))));
     // (Splitting a shard's cells into chunks so that a cell-sharded index at world = 8 fills the chip again was measured
@@ -4381,9 +4391,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         fprintf(stderr, "[cis] k_plan_par: %d of %d queries fall back to the frontier walk (quota %lld)\n", nfb, nq, (long long)quota);
     }
     if (!ix->h_totals) {
-        CIS_CHECK_HIP(hipHostMalloc((void**)&ix->h_totals, 4 * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
+        CIS_CHECK_HIP(hipHostMalloc((void**)&ix->h_totals, 6 * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
         CIS_CHECK_HIP(hipHostGetDevicePointer((void**)&ix->d_h_totals, ix->h_totals, 0));
         ix->h_totals[3] = 0;
+        ix->h_totals[4] = 0;  // (slots, fall-back slots) of the last sampled scan at M = 16: see m16_holdoff
     }
     const int64_t seq = ++ix->plan_seq;
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, plan, nq, item_off, tab_off, totals, qbound, ix->d_h_totals, seq, grp_cnt, grp_base, 2 * V * GRP_SUB);
@@ -4693,8 +4704,15 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             }
             CIS_TRY(mark(5));
             ix->last_scan_kernel = use3 ? (geom3.two_pass == 2 ? 4 : 3) : 2;  // 4: the sampled single-pass form k_adc_scan4 does the work (k_adc_scan3 only its fall-back slots)
-            if (use3)
-                launch_scan3(M, geom3, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, ix->w_slack.as<float>(), qbound, fhdr, fslots);
+            if (use3) {
+                Scan3Geom g3 = geom3;
+                // M = 16 on the sampled form: the saturating scale of k_adc_scan4 (sums of the near candidates at this fraction of the entry cap)
+                const float sat16 = getenv("CIS_S4_SAT") ? (float)atof(getenv("CIS_S4_SAT")) : 0.75f;
+                if (M == 16 && g3.two_pass == 2) g3.sat = sat16;
+                launch_scan3(M, g3, n_items, st, items, tabs, slots, n_slots, T, T32, codes, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, ix->w_slack.as<float>(), qbound, fhdr, fslots);
+                if (g3.sat > 0.f && ix->h_totals)  // (slots, fall-back slots) for the back-off above
+                    CIS_CHECK_HIP(hipMemcpyAsync(&ix->h_totals[4], qctr + 9, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+            }
             else
                 launch_scan2(M, geom, n_items, st, items, slots, n_slots, T, T32, codes, ids, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn, qbound);
         }

@@ -228,7 +228,8 @@ __device__ __forceinline__ CodeWords<M> load_code_buf(__amdgpu_buffer_rsrc_t rs,
 }
 
 // ---- ADC scan v3 (lopq_scan3.hip): 16-bit fixed-point tables, four queries per workgroup ---------------------------
-struct Scan3Geom { int G, NW, U, S, two_pass, long_chunks; size_t lds; };
+struct Scan3Geom { int G, NW, U, S, two_pass, long_chunks; size_t lds;
+                   float sat = 0.f; };  // > 0: the sampled form's SATURATING scale (M = 16) -- see k_adc_scan4
 bool scan3_supported(int M, int K, int L);
 Scan3Geom scan3_geom(int M, int K, int L, int64_t avg_chunk /* candidates per work item of the batch */,
                      int force_two_pass /* -1: by chunk length, 0: streaming form, 1: two-pass form */);

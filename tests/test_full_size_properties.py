@@ -176,6 +176,57 @@ def test_sampled_scan_fall_back_on_long_chunks(world, monkeypatch):
         s.set_scan_mode(mode=0)
 
 
+def test_sampled_scan_at_m16_with_its_saturating_scale(monkeypatch):
+    """C3 at full size (1M x 4096-d, PCA to 256, V=16, M=16; tests/golden/c3full.npz): automatic routing takes the sampled
+    single-pass form with the saturating scale (k_adc_scan4, Scan3Geom::sat).  Its results are the float64 kernel's bit for
+    bit at the default scale, at a scale so fine that every threshold saturates and at one so coarse that lists overflow (the
+    slots concerned run again in the streaming form); and after a batch where the scale missed, the index serves the next
+    batches from the float32 prefilter kernel (the back-off of search_batch)."""
+    import torch
+    import bench as B
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    dev = torch.device("cuda", 0)
+    model, z = B.load_model("c3full")
+    P = B.mixture_centers("relu_mixture", dev)
+    n, chunk_n = 1_000_000, 100_000
+    s = LOPQSearcherHIP(model)
+    for c in range(n // chunk_n):
+        a, b = model.predict_batch_dev(B.gen_chunk(P, c, chunk_n, dev))
+        s.add_codes_dev(a, b, torch.arange(c * chunk_n, (c + 1) * chunk_n, dtype=torch.int64, device=dev), dedup=False)
+    x0 = B.gen_chunk(P, 0, chunk_n, dev)
+    try:
+        for b, limit in ((0, LIMIT), (1, 37)):
+            q = B.make_queries(x0, b, 4096, dev)
+            s.set_scan_mode(mode=1)
+            want = _np(s.search_batch_dev(q, quota=QUOTA, limit=limit))
+            s.set_scan_mode(mode=0)
+            for sat in (None, "0.5", "0.95", "1.3", "0.02"):
+                if sat is not None:
+                    monkeypatch.setenv("CIS_S4_SAT", sat)
+                got = _np(s.search_batch_dev(q, quota=QUOTA, limit=limit))
+                kernel = s.last_stats()["scan_kernel"]
+                monkeypatch.delenv("CIS_S4_SAT", raising=False)
+                for k in ("ids", "n_found", "visited"):
+                    np.testing.assert_array_equal(got[k], want[k], err_msg="sat %s %s" % (sat, k))
+                np.testing.assert_array_equal(got["dists"].view(np.uint64), want["dists"].view(np.uint64))
+                if sat in (None, "0.5", "0.95"):
+                    assert kernel == "k_adc_scan4", (sat, kernel)
+                if sat in ("1.3", "0.02"):
+                    # the scale missed on most slots: the next automatic batch is served by k_adc_scan2 ...
+                    torch.cuda.synchronize()
+                    got = _np(s.search_batch_dev(q, quota=QUOTA, limit=limit))
+                    assert s.last_stats()["scan_kernel"] == "k_adc_scan2"
+                    np.testing.assert_array_equal(got["ids"], want["ids"])
+                    # ... for 64 batches, then the sampled form is tried again
+                    for _ in range(64):
+                        s.search_batch_dev(q[:512].contiguous(), quota=QUOTA, limit=limit)
+                    s.search_batch_dev(q, quota=QUOTA, limit=limit)
+                    assert s.last_stats()["scan_kernel"] == "k_adc_scan4"
+    finally:
+        s.set_scan_mode(mode=0)
+        s.close()
+
+
 def test_database_vectors_find_themselves(world):
     import torch
     s, x0 = world["searcher"], world["x0"]

@@ -68,6 +68,23 @@ for quota, limit in (((10000, 100),) if FAST else ((1000, 100), (10000, 100))):
         quota, limit, dt * 1e3, NQ, NQ / dt, float(out["visited"].float().mean()), st["items"], st["candidates"] / NQ,
         {k: round(v / reps, 2) for k, v in pr.items() if k.endswith("_ms")}))
     s.set_profiling(False)
+    # three batches in flight through views of the index (what bench.py does at V = 16): the serial front end of one batch under
+    # the ranking kernels of another
+    lanes = [(s, torch.cuda.current_stream())] + [(s.view(), torch.cuda.Stream()) for _ in range(2)]
+    for sv, stq in lanes:
+        with torch.cuda.stream(stq):
+            sv.search_batch_dev(q, quota=quota, limit=limit)
+    torch.cuda.synchronize()
+    t = time.perf_counter(); reps = 9
+    for i in range(reps):
+        sv, stq = lanes[i % 3]
+        with torch.cuda.stream(stq):
+            sv.search_batch_dev(q, quota=quota, limit=limit)
+    torch.cuda.synchronize()
+    dtp = (time.perf_counter() - t) / reps
+    print("    three batches in flight: %.2f ms per %d queries = %.0f queries/s" % (dtp * 1e3, NQ, NQ / dtp))
+    for sv, _ in lanes[1:]:
+        sv.close()
 if FAST:
     sys.exit(0)
 # spot check against the oracle
