@@ -255,6 +255,8 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
                     sample_pos.append(sel.cpu().numpy() + (c - my_chunks[0]) * chunk_n)
             x = xs[0] if len(xs) == 1 else torch.cat(xs)
             del xs
+            if g0 == 0:  # one untimed call first: the workspaces' hipMalloc and the code-object load (41.6 ms cold against 3.6 ms: profiles/r04w_encode_calls.txt)
+                model.predict_batch_dev(x)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()  # predict_batch_dev launches on torch's current stream: these events bracket the encode kernels only
             co, fi = model.predict_batch_dev(x)
@@ -499,7 +501,7 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
                                              stage_prof["scan_kernel_ms"] / 1e3, max(stage_prof["scan_launches"], 1))},
         "stage_ms_per_step": {k: stage_prof[k] / n_stage for k in ("front_ms", "tables_ms", "scan_ms", "merge_ms", "scan_kernel_ms")},
         "encode": {"value": enc_rate, "unit": "vectors/s", "vectors": len(my_chunks) * chunk_n,
-                   "note": "cis_encode_dev on this rank's share of the index build, HIP events around the encode calls",
+                   "note": "cis_encode_dev on this rank's share of the index build, HIP events around the encode calls (after one untimed warm-up call)",
                    "roofline": {"bound": "mfma", "achieved": enc_rate * enc_flop / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                                 "frac": enc_rate * enc_flop / 78.6e12, "flop_per_vector": enc_flop, "dtype": "f64"}},
         "build": {"encode_s": encode_s, "insert_s": insert_s, "total_s": build_s,
