@@ -607,6 +607,13 @@ __global__ void k_nchw3_to_nhwc(const float* __restrict__ in, float* __restrict_
     const float* p = in + (img * 3 * H + y) * W + x;
     float* o = out + row * pitch + x * 3;
     o[0] = p[0]; o[1] = p[(int64_t)H * W]; o[2] = p[(int64_t)2 * H * W];
+    // the pad floats of the row and the 16 floats behind the last row are READ by the first convolution's 36-float runs (against
+    // zero weights): they must be finite whatever the memory held before -- NaN bytes left there by an earlier owner of the memory
+    // gave 0 * NaN = NaN, clamped to 0 by the ReLU: descriptors off by 0.5 % (found in round 4, tests: CIS_CNN_POISON)
+    if (x == W - 1)
+        for (int k = W * 3; k < pitch; ++k) out[row * pitch + k] = 0.f;
+    if (i == 0)
+        for (int k = 0; k < 16; ++k) out[n_rows * pitch + k] = 0.f;
 }
 
 // ---- dlib face ResNet helpers (NHWC) ---------------------------------------------------------------
@@ -1051,6 +1058,18 @@ static int conv_fill_chip(CnnWs* ws, ConvDesc d, const float* in, const LayerW& 
     return CIS_OK;
 }
 
+// Test hook (tests/test_cnn_hip_parity.py): CIS_CNN_POISON=<mask> fills the workspaces (bit 0..4: act0, act1, act2, act3, part) with
+// 0xff bytes (NaN) before a forward.  A forward must not read what it has not written: results do not change under any mask.
+static int cnn_poison(CnnWs* ws, hipStream_t st) {
+    const char* e = getenv("CIS_CNN_POISON");
+    if (!e) return CIS_OK;
+    const int mask = atoi(e);
+    DevBuf* b[5] = {&ws->act0, &ws->act1, &ws->act2, &ws->act3, &ws->part};
+    for (int i = 0; i < 5; ++i)
+        if (((mask >> i) & 1) && b[i]->p) CIS_CHECK_HIP(hipMemsetAsync(b[i]->p, 0xff, b[i]->cap, st));
+    return CIS_OK;
+}
+
 // dlib face ResNet: d_in = [n][150][150][3] float32 RGB 0..255 (aligned chips), d_feats = [n][128]
 static int cnn_forward_dlib(cis_cnn* c, CnnWs* ws, const float* d_in, int n, float* d_feats, hipStream_t st) {
     const size_t big = (size_t)n * 72 * 72 * 32;  // largest activation: first convolution's output
@@ -1058,6 +1077,7 @@ static int cnn_forward_dlib(cis_cnn* c, CnnWs* ws, const float* d_in, int n, flo
     CIS_TRY(ws->act1.reserve(big * sizeof(float)));
     CIS_TRY(ws->act2.reserve(big * sizeof(float)));
     CIS_TRY(ws->act3.reserve(big * sizeof(float)));
+    CIS_TRY(cnn_poison(ws, st));
     float* A = ws->act0.as<float>();
     float* B = ws->act1.as<float>();
     float* T1 = ws->act2.as<float>();
@@ -1214,6 +1234,7 @@ static int cnn_forward_sentibank(cis_cnn* c, CnnWs* ws, const float* d_nchw, int
     CIS_TRY(ws->act0.reserve(act_elems * sizeof(float)));
     CIS_TRY(ws->act1.reserve(act_elems * sizeof(float)));
     CIS_TRY(ws->act2.reserve((size_t)4 * n * 4096 * sizeof(float)));  // split-K partial sums of the fc layers
+    CIS_TRY(cnn_poison(ws, st));
     float* bufs[2] = {ws->act0.as<float>(), ws->act1.as<float>()};
     const float* cur = d_nchw;
     int which = 0;

@@ -56,6 +56,11 @@ struct DevBuf {
             return CIS_ENOMEM;
         }
         cap = want;
+        // Test hook: CIS_POISON_ALLOC=1 fills every new workspace with 0xff bytes (NaN / -1): nothing may rely on what fresh memory
+        // holds (the runtime hands back blocks this process freed earlier, with their contents -- see k_nchw3_to_nhwc).
+        static const bool poison = getenv("CIS_POISON_ALLOC") != nullptr && atoi(getenv("CIS_POISON_ALLOC")) != 0;
+        // (the fill runs on the null stream; the library's own streams are non-blocking: wait for it before anybody writes the block)
+        if (poison && (hipMemset(p, 0xff, want) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) { cis_set_error("hipMemset (poison) failed"); return CIS_ENOMEM; }
         return CIS_OK;
     }
     void release() {

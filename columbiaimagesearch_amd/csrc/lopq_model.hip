@@ -464,6 +464,135 @@ __global__ __launch_bounds__(256) void k_pca_gemm_mfma128(const TX* __restrict__
             }
 }
 
+// The two MFMA forms above with a fetch that is ONLY loads (round 4).  Their fetch lambdas branch on the tile borders and convert as
+// they load, and the compiler answers with one `s_waitcnt vmcnt(0)` per load inside the k loop (build/lopq_model.s: global_load ->
+// wait -> v_cvt, ten round trips in a row per stage): the "prefetch" was a chain of exposed latencies, hidden only by the CU's other
+// workgroup (2.89 ms per 62500 x 4096 -> 256 pass = 0.61 of the float64 matrix peak).  Here every address is clamped into the
+// arrays, the loads are unconditional 16-byte loads into registers that nothing touches before the MFMAs of the stage are issued,
+// and the border masks, the centring and the conversions happen when the registers go to LDS.  Needs D_in % 4 == 0 and D % 2 == 0
+// (the host keeps the forms above for other shapes).  Same instruction, same k order per output element: bit-identical results.
+template <typename TX, bool SUBF32, int BM, int BK>
+__global__ __launch_bounds__(256) void k_pca_gemm_mfma_pf(const TX* __restrict__ X, const double* __restrict__ mu,
+                                                          const double* __restrict__ P, double* __restrict__ Y,
+                                                          int64_t n, int D_in, int D) {
+    constexpr int BN = BM, TW = BM / 32;     // a wave owns (BM / 2) x (BN / 2) = TW x TW MFMA tiles
+    constexpr int QK = BK / 4;               // quads of consecutive k per row and stage
+    constexpr int NA = BM * QK / 256;        // X quads per thread and stage
+    constexpr int NB = BK * (BN / 2) / 256;  // P column pairs per thread and stage
+    static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
+    __shared__ double sA[2][BK][BM + 2];     // [stage][k][row]
+    __shared__ double sB[2][BK][BN + 2];     // [stage][k][col]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int col0 = blockIdx.y * BN;
+    f64x4 acc[TW][TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+    float4 xf4[NA];       // float32 rows: one 16-byte load per quad
+    double2 xd2[NA][2];   // float64 rows: two
+    double2 mu2[NA][2];
+    double2 pb2[NB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            const int idx = tid + e * 256;
+            const int r = idx / QK, kq = (idx % QK) * 4;
+            int64_t rr = row0 + r;
+            rr = rr < n ? rr : n - 1;
+            int kc = k0 + kq;
+            kc = kc <= D_in - 4 ? kc : D_in - 4;
+            if constexpr (sizeof(TX) == 4) {
+                xf4[e] = *reinterpret_cast<const float4*>(X + rr * D_in + kc);
+            } else {
+                xd2[e][0] = *reinterpret_cast<const double2*>(X + rr * D_in + kc);
+                xd2[e][1] = *reinterpret_cast<const double2*>(X + rr * D_in + kc + 2);
+            }
+            mu2[e][0] = *reinterpret_cast<const double2*>(mu + kc);
+            mu2[e][1] = *reinterpret_cast<const double2*>(mu + kc + 2);
+        }
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            const int idx = tid + e * 256;
+            const int k = idx / (BN / 2), c = (idx % (BN / 2)) * 2;
+            int kc = k0 + k;
+            kc = kc < D_in ? kc : D_in - 1;
+            int cc = col0 + c;
+            cc = cc <= D - 2 ? cc : D - 2;
+            pb2[e] = *reinterpret_cast<const double2*>(P + (int64_t)kc * D + cc);
+        }
+    };
+    auto stash = [&](int st, int k0) {
+#pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            const int idx = tid + e * 256;
+            const int r = idx / QK, kq = (idx % QK) * 4;
+            const bool on = row0 + r < n && k0 + kq < D_in;  // whole quads: D_in % 4 == 0
+            const double m4[4] = {mu2[e][0].x, mu2[e][0].y, mu2[e][1].x, mu2[e][1].y};
+            double v[4];
+            if constexpr (sizeof(TX) == 4) {
+                const float x4[4] = {xf4[e].x, xf4[e].y, xf4[e].z, xf4[e].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if constexpr (SUBF32) v[c] = (double)(x4[c] - (float)m4[c]);  // float32 - float32
+                    else v[c] = (double)x4[c] - m4[c];
+                }
+            } else {
+                const double x4[4] = {(double)xd2[e][0].x, (double)xd2[e][0].y, (double)xd2[e][1].x, (double)xd2[e][1].y};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = x4[c] - m4[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sA[st][kq + c][r] = on ? v[c] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            const int idx = tid + e * 256;
+            const int k = idx / (BN / 2), c = (idx % (BN / 2)) * 2;
+            const bool on = k0 + k < D_in && col0 + c < D;  // column pairs: D and col0 are even
+            sB[st][k][c] = on ? pb2[e].x : 0.0;
+            sB[st][k][c + 1] = on ? pb2[e].y : 0.0;
+        }
+    };
+    fetch(0);
+    stash(0, 0);
+    __syncthreads();
+    int st = 0;
+    for (int k0 = 0; k0 < D_in; k0 += BK) {
+        const bool more = k0 + BK < D_in;
+        if (more) fetch(k0 + BK);
+#pragma unroll
+        for (int k = 0; k < BK; k += 4) {
+            double a[TW], b[TW];
+#pragma unroll
+            for (int i = 0; i < TW; ++i) a[i] = sA[st][k + (lane >> 4)][wm * (BM / 2) + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < TW; ++j) b[j] = sB[st][k + (lane >> 4)][wn * (BN / 2) + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stash(st ^ 1, k0 + BK);
+        __syncthreads();
+        st ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + wm * (BM / 2) + i * 16 + (lane >> 4) + 4 * r;
+                const int c = col0 + wn * (BN / 2) + j * 16 + (lane & 15);
+                if (row < n && c < D) Y[row * D + c] = acc[i][j][r];
+            }
+}
+
 // Row L2 renormalisation (numpy: sqrt(add.reduce(y*y, axis=1)), then y / norm) and float32 cast.
 // One 64-lane wave per row would break the summation order, so each thread owns a row.
 __global__ void k_pca_finish(const double* __restrict__ Y, float* __restrict__ out, int64_t n, int D,
@@ -1482,9 +1611,14 @@ int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, floa
     const dim3 gm128((unsigned)ceil_div(n, 128), (unsigned)ceil_div(m->D, 128));
     const int tile_env = getenv("CIS_PCA_TILE") ? atoi(getenv("CIS_PCA_TILE")) : 0;
     const bool big_tiles = use_mfma && m->D >= 128 && tile_env != 64 && ((int64_t)gm128.x * gm128.y >= 512 || tile_env == 128);
+    // the loads-only fetch (k_pca_gemm_mfma_pf) where whole quads of k and pairs of columns exist; CIS_PCA_PF=0: the forms before it
+    const bool pf = m->D_in % 4 == 0 && m->D_in >= 4 && m->D % 2 == 0 && m->D >= 2 && !(getenv("CIS_PCA_PF") && atoi(getenv("CIS_PCA_PF")) == 0);
 #define CIS_PCA_LAUNCH(TX, SUB, XP)                                                                                              \
     do {                                                                                                                          \
-        if (big_tiles) hipLaunchKernelGGL((k_pca_gemm_mfma128<TX, SUB>), gm128, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
+        if (big_tiles && pf) hipLaunchKernelGGL((k_pca_gemm_mfma_pf<TX, SUB, 128, 16>), gm128, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
+        else if (use_mfma && bk16 && pf) hipLaunchKernelGGL((k_pca_gemm_mfma_pf<TX, SUB, 64, 16>), gm, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
+        else if (use_mfma && pf) hipLaunchKernelGGL((k_pca_gemm_mfma_pf<TX, SUB, 64, 32>), gm, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
+        else if (big_tiles) hipLaunchKernelGGL((k_pca_gemm_mfma128<TX, SUB>), gm128, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
         else if (use_mfma && bk16) hipLaunchKernelGGL((k_pca_gemm_mfma<TX, SUB, 16>), gm, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
         else if (use_mfma) hipLaunchKernelGGL((k_pca_gemm_mfma<TX, SUB, 32>), gm, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
         else if (small) hipLaunchKernelGGL((k_pca_gemm<TX, SUB, 2>), g, dim3(256), 0, st, XP, m->d_pmu, m->d_P, Y, n, m->D_in, m->D); \
