@@ -41,9 +41,12 @@ struct ConvDesc {
 // written to the other LDS buffer after them (one barrier per stage).
 // VEC = channels-last input with ICg % 16 == 0: a stage covers 16 consecutive input channels of ONE kernel tap,
 // so every thread fetches float4s along the channel axis and the tap decode is wave-uniform.
-template <int WM, int WN, int WAVES_M, int WAVES_N, bool VEC>
+// MODE: 0 = scalar gather, 1 = VEC, 2 = VEC with the row-run gather of the 3-channel first layers (ConvDesc::runq) -- a template
+// parameter since round 4: as a run-time branch inside the fetch it made the compiler emit both gathers with a wait between them.
+template <int WM, int WN, int WAVES_M, int WAVES_N, int MODE>
 __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in, const float* __restrict__ Wp,
                                                     const float* __restrict__ bias, float* __restrict__ out, ConvDesc d) {
+    constexpr bool VEC = MODE != 0, RUN = MODE == 2;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, BK = 16;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -114,27 +117,34 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
     float4 ra[VEC ? A_VEC : 1];
     float rs[VEC ? 1 : A_SCL];
     float4 rb[B_VEC];
+    bool okA[VEC ? A_VEC : 1], okB[B_VEC];
+    // The fetch of the vector path is ONLY loads (round 4): every address is clamped into the arrays, the loads are unconditional and
+    // nothing touches their registers before the stage's MFMAs are issued; what is padding, past the tile or past K is zeroed when
+    // the registers go to LDS (okA / okB).  With `if (inside) load` the compiler built a branch per load and waited for each load
+    // before the next (build/cnn.s: global_load -> s_waitcnt vmcnt(0) -> global_load ...): two to five exposed round trips per stage.
     auto fetch = [&](int kt) {
         const int k0 = kt * BK;
         if constexpr (VEC) {
-            if (d.runq > 0) {
+            if constexpr (RUN) {
                 // this thread's float4 along K: kernel row ky, quad jq of that row's contiguous run (no padding: pad == 0)
                 const int kq = kt * 4 + (tid & 3);
                 const int rky = kq / d.runq, jq = kq - rky * d.runq;
 #pragma unroll
                 for (int i = 0; i < A_VEC; ++i) {
                     const int iy = iy0[i] + rky;
-                    ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (mloc[i] < BM && rky < d.KH && iy >= 0 && iy < d.H)
-                        ra[i] = *reinterpret_cast<const float4*>(in + pbase[i] + (int64_t)iy * d.sH + (int64_t)ix0[i] * d.sW + jq * 4);
+                    okA[i] = mloc[i] < BM && rky < d.KH && iy >= 0 && iy < d.H;
+                    const int iyc = iy < 0 ? 0 : (iy < d.H ? iy : d.H - 1);
+                    const int ixc = ix0[i] < 0 ? 0 : ix0[i];
+                    ra[i] = *reinterpret_cast<const float4*>(in + pbase[i] + (int64_t)iyc * d.sH + (int64_t)ixc * d.sW + jq * 4);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < A_VEC; ++i) {
                     const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-                    ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (mloc[i] < BM && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W)
-                        ra[i] = *reinterpret_cast<const float4*>(in + pbase[i] + (int64_t)iy * d.sH + (int64_t)ix * d.sW + ic + (tid & 3) * 4);
+                    okA[i] = mloc[i] < BM && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+                    const int iyc = iy < 0 ? 0 : (iy < d.H ? iy : d.H - 1);
+                    const int ixc = ix < 0 ? 0 : (ix < d.W ? ix : d.W - 1);
+                    ra[i] = *reinterpret_cast<const float4*>(in + pbase[i] + (int64_t)iyc * d.sH + (int64_t)ixc * d.sW + ic + (tid & 3) * 4);
                 }
             }
         } else {
@@ -149,11 +159,19 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
         }
 #pragma unroll
         for (int i = 0; i < B_VEC; ++i) {
+            constexpr int LIM = BK * (BN / 4);
             const int idx = tid + 256 * i;
-            const int kl = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
-            rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < BK * (BN / 4) && k0 + kl < d.K && oc0 + n4 < d.OCg)
-                rb[i] = *reinterpret_cast<const float4*>(Wg + (int64_t)(k0 + kl) * d.OCg + oc0 + n4);
+            const int idc = idx < LIM ? idx : LIM - 1;
+            const int kl = idc / (BN / 4), n4 = (idc % (BN / 4)) * 4;
+            okB[i] = idx < LIM && k0 + kl < d.K && oc0 + n4 < d.OCg;
+            if constexpr (VEC) {
+                const int kc = k0 + kl < d.K ? k0 + kl : d.K - 1;
+                const int nc = oc0 + n4 < d.OCg ? oc0 + n4 : d.OCg - 4;  // (OCg % 4 == 0: the float4 rows of the packed weights)
+                rb[i] = *reinterpret_cast<const float4*>(Wg + (int64_t)kc * d.OCg + nc);
+            } else {
+                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (okB[i]) rb[i] = *reinterpret_cast<const float4*>(Wg + (int64_t)(k0 + kl) * d.OCg + oc0 + n4);
+            }
         }
         // advance the tap decode to the next stage
         if (!VEC && d.kx_fastest) {
@@ -170,8 +188,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
             for (int i = 0; i < A_VEC; ++i) {
                 if (mloc[i] < BM) {
                     const int kq = (tid & 3) * 4;
-                    As[st][kq + 0][mloc[i]] = ra[i].x; As[st][kq + 1][mloc[i]] = ra[i].y;
-                    As[st][kq + 2][mloc[i]] = ra[i].z; As[st][kq + 3][mloc[i]] = ra[i].w;
+                    const bool ok = okA[i];
+                    As[st][kq + 0][mloc[i]] = ok ? ra[i].x : 0.f; As[st][kq + 1][mloc[i]] = ok ? ra[i].y : 0.f;
+                    As[st][kq + 2][mloc[i]] = ok ? ra[i].z : 0.f; As[st][kq + 3][mloc[i]] = ok ? ra[i].w : 0.f;
                 }
             }
         } else {
@@ -184,7 +203,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
             const int idx = tid + 256 * i;
             if (idx < BK * (BN / 4)) {
                 const int kl = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
-                Bs[st][kl][n4 + 0] = rb[i].x; Bs[st][kl][n4 + 1] = rb[i].y; Bs[st][kl][n4 + 2] = rb[i].z; Bs[st][kl][n4 + 3] = rb[i].w;
+                const bool ok = okB[i];
+                Bs[st][kl][n4 + 0] = ok ? rb[i].x : 0.f; Bs[st][kl][n4 + 1] = ok ? rb[i].y : 0.f;
+                Bs[st][kl][n4 + 2] = ok ? rb[i].z : 0.f; Bs[st][kl][n4 + 3] = ok ? rb[i].w : 0.f;
             }
         }
     };
@@ -970,8 +991,9 @@ static void launch_conv_cfg(const ConvDesc& d, const float* in, const float* w, 
     const int64_t npix = (int64_t)d.N * d.OH * d.OW;
     dim3 g((unsigned)ceil_div(npix, BM), (unsigned)ceil_div(d.OCg, BN), (unsigned)(d.splitk > 1 ? d.splitk : d.groups));
     const bool vec = (d.sC == 1 && d.ICg % 16 == 0 && d.C % 4 == 0) || d.runq > 0;
-    if (vec) hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, true>), g, dim3(256), 0, st, in, w, b, out, d);
-    else hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, false>), g, dim3(256), 0, st, in, w, b, out, d);
+    if (d.runq > 0) hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, 2>), g, dim3(256), 0, st, in, w, b, out, d);
+    else if (vec) hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, 1>), g, dim3(256), 0, st, in, w, b, out, d);
+    else hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, 0>), g, dim3(256), 0, st, in, w, b, out, d);
 }
 
 static void launch_conv(const ConvDesc& d, const float* in, const float* w, const float* b, float* out, hipStream_t st) {
