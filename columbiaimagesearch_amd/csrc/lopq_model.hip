@@ -1110,9 +1110,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     float cmx = 0.f;
     for (int k = tid; k < KP; k += 256) {
         double sq = 0.0;
+        // (loads first, from a clamped row, then the mask: `k < K ? src[..] : 0` became a branch and a full wait per element)
+        const int kc = k < K ? k : K - 1;
+        double row[W];
+#pragma unroll
+        for (int i = 0; i < W; i += 2) {
+            const double2 q = *reinterpret_cast<const double2*>(src + (size_t)kc * W + i);  // W even, rows 16-byte aligned
+            row[i] = q.x; row[i + 1] = q.y;
+        }
 #pragma unroll
         for (int i = 0; i < W; ++i) {
-            const double v = k < K ? src[(size_t)k * W + i] : 0.0;
+            const double v = k < K ? row[i] : 0.0;
             sA[k * PITCH + i] = (float)v;
             sq = fma(v, v, sq);
         }
@@ -1420,28 +1428,54 @@ __global__ __launch_bounds__(256) void k_project_tiles(const CT* __restrict__ X,
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-    for (int k0 = 0; k0 < h; k0 += 16) {
+    // The operands of stage k0 + 16 are fetched (loads only: clamped addresses, nothing converted) while stage k0 is multiplied, and
+    // go to LDS afterwards with the border masks (round 4; before, `if (inside) load` gave one exposed round trip per load group and
+    // the loads of a stage started only after the previous stage's products).  Same products in the same order: bit-identical.
+    CT xa[4], ca[4];
+    double ma[4], rb[4];
+    const int row_any = srow[0];  // a tile holds at least one row
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = tid + e * 256;
             const int v = idx / 16, k = idx % 16;
-            double val = 0.0;
             const int row = srow[v];
-            if (row >= 0 && k0 + k < h) {
-                const CT res = X[(int64_t)row * D + pt.split * h + k0 + k] - Cc[k0 + k];  // rounds in CT
-                val = (double)res - mu[k0 + k];
-            }
-            sA[k][v] = val;
+            const int rowc = row >= 0 ? row : row_any;
+            const int kc = k0 + k < h ? k0 + k : h - 1;
+            xa[e] = X[(int64_t)rowc * D + pt.split * h + kc];
+            ca[e] = Cc[kc];
+            ma[e] = mu[kc];
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = tid + e * 256;
             const int k = idx / 64, i = idx % 64;
-            double val = 0.0;
-            if (k0 + k < h && i0 + i < h) val = R[(int64_t)(k0 + k) * h + i0 + i];
-            sB[k][i] = val;
+            const int kc = k0 + k < h ? k0 + k : h - 1;
+            const int ic = i0 + i < h ? i0 + i : h - 1;
+            rb[e] = R[(int64_t)kc * h + ic];
         }
+    };
+    auto stash = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            const int v = idx / 16, k = idx % 16;
+            const CT res = xa[e] - ca[e];  // rounds in CT
+            const double val = (double)res - ma[e];
+            sA[k][v] = (srow[v] >= 0 && k0 + k < h) ? val : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            const int k = idx / 64, i = idx % 64;
+            sB[k][i] = (k0 + k < h && i0 + i < h) ? rb[e] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < h; k0 += 16) {
+        stash(k0);
         __syncthreads();
+        if (k0 + 16 < h) fetch(k0 + 16);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             double a[4], b[4];
