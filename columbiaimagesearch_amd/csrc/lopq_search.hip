@@ -474,11 +474,14 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
             // (b) one thread per cell: row by binary search over the row starts (the LAST row whose start is <= e is the
             // one that holds e: empty rows share their start with the next row), then sum, rank pair and GLOBAL cell size
             constexpr int PER = PLAN_PAR_CAP / 256;
+            // (the global reads of the thread's PER cells go out together, level by level -- cluster ids, then sizes: as
+            // `if (e < cnt) { ... gcount[o0[i] * V + o1[j]] }` per cell they were 2 x PER round trips in a row, ~25 us per band)
             uint32_t gsz[PER];
+            int ei[PER], ej[PER];
 #pragma unroll
             for (int r = 0; r < PER; ++r) {
                 const int e = r * 256 + tid;
-                gsz[r] = 0u;
+                ei[r] = 0; ej[r] = 0;
                 if (e < cnt) {
                     int lo_ = 0, hi_ = rows;  // first row whose start is > e
                     while (lo_ < hi_) {
@@ -491,9 +494,19 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
                     const int j = e - (int)s_gc[i] + (have_prev ? row_prefix(a, tau_prev) : 0);
                     s_key[e] = f2bits((CT)(a + PL1(j)));
                     s_ij[e] = ((uint32_t)i << 16) | (uint32_t)j;
-                    const int64_t g = gcount[(int64_t)o0[i] * V + o1[j]];
-                    gsz[r] = g > 0x7fffffffll ? 0x7fffffffu : (uint32_t)g;
+                    ei[r] = i; ej[r] = j;
                 }
+            }
+            uint16_t ci[PER], cj[PER];
+#pragma unroll
+            for (int r = 0; r < PER; ++r) { ci[r] = o0[ei[r]]; cj[r] = o1[ej[r]]; }
+            int64_t gg[PER];
+#pragma unroll
+            for (int r = 0; r < PER; ++r) gg[r] = gcount[(int64_t)ci[r] * V + cj[r]];
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int e = r * 256 + tid;
+                gsz[r] = e < cnt ? (gg[r] > 0x7fffffffll ? 0x7fffffffu : (uint32_t)gg[r]) : 0u;
             }
             __syncthreads();
 #pragma unroll
@@ -989,19 +1002,30 @@ __global__ __launch_bounds__(256) void k_tables_group(const CT* __restrict__ X, 
             double a0[TB], a1[TB];
 #pragma unroll
             for (int t = 0; t < TB; ++t) { a0[t] = 0.0; a1[t] = 0.0; }
-            int k = k0;
-            for (; k + 1 < k1; k += 2) {
-                const double r0 = R[(int64_t)k * h + i], r1 = R[(int64_t)(k + 1) * h + i];
+            // sixteen elements of the thread's column of R are in flight at a time (clamped, unconditional loads): two loads per
+            // iteration and the wait for them before their products was a chain of per / 2 round trips to L2 (round 4).
+            // Same products, same two chains (even / odd k), same order.
+            for (int kb = k0; kb < k1; kb += 16) {
+                double rr[16];
 #pragma unroll
-                for (int t = 0; t < TB; ++t) {
-                    a0[t] = fma(r0, v[t * h + k], a0[t]);
-                    a1[t] = fma(r1, v[t * h + k + 1], a1[t]);
+                for (int u = 0; u < 16; ++u) {
+                    const int kc = kb + u < k1 ? kb + u : k1 - 1;
+                    rr[u] = R[(int64_t)kc * h + i];
                 }
-            }
-            if (k < k1) {
-                const double r0 = R[(int64_t)k * h + i];
 #pragma unroll
-                for (int t = 0; t < TB; ++t) a0[t] = fma(r0, v[t * h + k], a0[t]);
+                for (int u = 0; u < 16; u += 2) {
+                    const int k = kb + u;
+                    if (k + 1 < k1) {
+#pragma unroll
+                        for (int t = 0; t < TB; ++t) {
+                            a0[t] = fma(rr[u], v[t * h + k], a0[t]);
+                            a1[t] = fma(rr[u + 1], v[t * h + k + 1], a1[t]);
+                        }
+                    } else if (k < k1) {
+#pragma unroll
+                        for (int t = 0; t < TB; ++t) a0[t] = fma(rr[u], v[t * h + k], a0[t]);
+                    }
+                }
             }
 #pragma unroll
             for (int t = 0; t < TB; ++t) psum[(part * TB + t) * h + i] = a0[t] + a1[t];
