@@ -2438,6 +2438,10 @@ void k_merge_survivors(const uint64_t* __restrict__ surv /* [n_items][S] */,
             int li[NE];
             bool valid[NE];
             uint32_t mn = 0xffffffffu, mx = 0u;
+            // (the lane's NE survivors and their lists' scales are read together, from clamped addresses: as `valid ? surv[..] : ~0`
+            // they were NE round trips one after the other at the head of every query's chain of dependent loads)
+            uint64_t ent[NE];
+            float ubv[NE];
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
                 const int x = lane + 64 * i;
@@ -2447,11 +2451,18 @@ void k_merge_survivors(const uint64_t* __restrict__ surv /* [n_items][S] */,
                 for (int j = 0; j < 3; ++j)
                     if (lst == j && off >= cntl[j]) { off -= cntl[j]; lst = j + 1; }
                 li[i] = lst;
-                const uint64_t ent = valid[i] ? surv[(first + lst) * (int64_t)S + off] : ~0ull;
-                hi[i] = (uint32_t)(ent >> 32);
-                pp[i] = (uint32_t)ent;
+                ent[i] = surv[valid[i] ? (first + lst) * (int64_t)S + off : first * (int64_t)S];
+            }
+            if (item_slack) {
+#pragma unroll
+                for (int i = 0; i < NE; ++i) ubv[i] = item_slack[2 * (first + (valid[i] ? li[i] : 0)) + 1];
+            }
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                hi[i] = valid[i] ? (uint32_t)(ent[i] >> 32) : 0xffffffffu;
+                pp[i] = valid[i] ? (uint32_t)ent[i] : 0xffffffffu;
                 if (item_slack && valid[i])  // k_adc_scan3 hands over the 16-bit sum: (sum + M) * ub >= the exact distance
-                    hi[i] = __float_as_uint(__double2float_ru((double)(hi[i] + (uint32_t)MT) * (double)item_slack[2 * (first + lst) + 1]));
+                    hi[i] = __float_as_uint(__double2float_ru((double)(hi[i] + (uint32_t)MT) * (double)ubv[i]));
                 mn = (valid[i] && hi[i] < mn) ? hi[i] : mn;
                 mx = (valid[i] && hi[i] > mx) ? hi[i] : mx;
             }
