@@ -889,45 +889,13 @@ __global__ __launch_bounds__(256) void k_tables(const CT* __restrict__ X /* [nq]
         v[k] = (double)res - mu[k];
     }
     __syncthreads();
-    // px = R . v with all 256 threads: `parts` groups of h threads each take a contiguous slice of k
-    // (k-ascending fma chain inside a slice, slices added in order; the reference's BLAS order is
-    // unspecified anyway), partial sums meet in LDS.
-    {
-        const int parts = (h >= 256) ? 1 : (256 / h);
-        double* psum = px + h;  // [parts][h]
-        const int tid = threadIdx.x;
-        if (parts == 1) {
-            for (int i = tid; i < h; i += blockDim.x) {
-                double a0 = 0.0, a1 = 0.0;
-                int k = 0;
-                for (; k + 1 < h; k += 2) {
-                    a0 = fma(R[(int64_t)k * h + i], v[k], a0);
-                    a1 = fma(R[(int64_t)(k + 1) * h + i], v[k + 1], a1);
-                }
-                if (k < h) a0 = fma(R[(int64_t)k * h + i], v[k], a0);
-                px[i] = a0 + a1;
-            }
-        } else {
-            const int part = tid / h, i = tid - part * h;
-            if (part < parts) {
-                const int per = (h + parts - 1) / parts;
-                const int k0 = part * per, k1 = (k0 + per < h) ? k0 + per : h;
-                double a0 = 0.0, a1 = 0.0;
-                int k = k0;
-                for (; k + 1 < k1; k += 2) {
-                    a0 = fma(R[(int64_t)k * h + i], v[k], a0);
-                    a1 = fma(R[(int64_t)(k + 1) * h + i], v[k + 1], a1);
-                }
-                if (k < k1) a0 = fma(R[(int64_t)k * h + i], v[k], a0);
-                psum[part * h + i] = a0 + a1;
-            }
-            __syncthreads();
-            if (tid < h) {
-                double acc = psum[tid];
-                for (int q = 1; q < parts; ++q) acc = acc + psum[q * h + tid];
-                px[tid] = acc;
-            }
-        }
+    // px[i] = sum_k R[k][i] v[k] as ONE chain of fused multiply-adds, k ascending (round 4: the arithmetic of
+    // v_mfma_f64_16x16x4_f64, which k_tables_group_mfma runs the grouped tables on -- tools/probes/mfma_f64_order.hip; the
+    // reference's BLAS order is unspecified anyway).  Every route to px uses this order: the routes agree bit for bit.
+    for (int i = threadIdx.x; i < h; i += blockDim.x) {
+        double acc = 0.0;
+        for (int k = 0; k < h; ++k) acc = fma(R[(int64_t)k * h + i], v[k], acc);
+        px[i] = acc;
     }
     __syncthreads();
     if (px_out) {  // two-kernel path: the distance tables are built by k_tables_from_px
@@ -950,8 +918,9 @@ __global__ __launch_bounds__(256) void k_tables(const CT* __restrict__ X /* [nq]
 // one-kernel version was bound by L2 reads of the sub-quantizers: 160 KB per table).
 // The projection px = R[c] . ((x - C[c]) - mu[c]) for TB tables of ONE (split, cluster) group per block: the tables
 // arrive grouped by cluster (tab_order), so the 8*h*h bytes of R[c] are read once per TB tables instead of once per
-// table (k_tables is bound by exactly that L2 traffic).  Same arithmetic as k_tables, table by table: `parts` slices
-// of k, two interleaved fma chains per slice, slices added in order.  h <= 256, two-kernel path only (px_out).
+// table (k_tables is bound by exactly that L2 traffic).  Same arithmetic as k_tables, table by table: one chain of fused
+// multiply-adds over ascending k.  h <= 256, two-kernel path only (px_out).  The vector-unit form: used when h % 16 != 0
+// (or CIS_TABLES_VALU=1); k_tables_group_mfma below is the default.
 template <typename CT, int TB>
 __global__ __launch_bounds__(256) void k_tables_group(const CT* __restrict__ X, const CT* __restrict__ Cs,
                                                       const double* __restrict__ Rt, const double* __restrict__ mus,
@@ -992,67 +961,150 @@ __global__ __launch_bounds__(256) void k_tables_group(const CT* __restrict__ X, 
         v[t * h + k] = (double)res - mu[k];
     }
     __syncthreads();
-    const int parts = 256 / h;  // h <= 256 and a power-of-two divisor of 256 is not required: idle threads past parts*h
+    // one chain of fused multiply-adds per (table, output), k ascending (see k_tables): thread group g = tid / h takes the tables
+    // t = g, g + parts, ...; sixteen elements of the thread's column of R in flight at a time
+    const int parts = 256 / h;
     const int part = tid / h, i = tid - part * h;
-    const int per = (h + parts - 1) / parts;
-    const int k0 = part * per, k1 = (k0 + per < h) ? k0 + per : h;
-    if (s_same) {
-        const double* R = Rt + ((int64_t)td0.split * V + td0.cluster) * h * h;
-        if (part < parts) {
-            double a0[TB], a1[TB];
+    if (part < parts) {
+        if (s_same) {
+            const double* R = Rt + ((int64_t)td0.split * V + td0.cluster) * h * h;
+            double acc[TB];
 #pragma unroll
-            for (int t = 0; t < TB; ++t) { a0[t] = 0.0; a1[t] = 0.0; }
-            // sixteen elements of the thread's column of R are in flight at a time (clamped, unconditional loads): two loads per
-            // iteration and the wait for them before their products was a chain of per / 2 round trips to L2 (round 4).
-            // Same products, same two chains (even / odd k), same order.
-            for (int kb = k0; kb < k1; kb += 16) {
+            for (int t = 0; t < TB; ++t) acc[t] = 0.0;
+            for (int kb = 0; kb < h; kb += 16) {
                 double rr[16];
 #pragma unroll
+                for (int u = 0; u < 16; ++u) rr[u] = R[(int64_t)(kb + u < h ? kb + u : h - 1) * h + i];
+#pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    const int kc = kb + u < k1 ? kb + u : k1 - 1;
-                    rr[u] = R[(int64_t)kc * h + i];
-                }
+                    if (kb + u < h) {
 #pragma unroll
-                for (int u = 0; u < 16; u += 2) {
-                    const int k = kb + u;
-                    if (k + 1 < k1) {
-#pragma unroll
-                        for (int t = 0; t < TB; ++t) {
-                            a0[t] = fma(rr[u], v[t * h + k], a0[t]);
-                            a1[t] = fma(rr[u + 1], v[t * h + k + 1], a1[t]);
-                        }
-                    } else if (k < k1) {
-#pragma unroll
-                        for (int t = 0; t < TB; ++t) a0[t] = fma(rr[u], v[t * h + k], a0[t]);
+                        for (int t = 0; t < TB; ++t)
+                            if (t % parts == part) acc[t] = fma(rr[u], v[t * h + kb + u], acc[t]);
                     }
                 }
             }
 #pragma unroll
-            for (int t = 0; t < TB; ++t) psum[(part * TB + t) * h + i] = a0[t] + a1[t];
-        }
-    } else {  // a block that straddles two groups: every table with its own R
-        for (int t = 0; t < nt; ++t) {
-            const TabDesc td = tabs[s_tab[t]];
-            const double* R = Rt + ((int64_t)td.split * V + td.cluster) * h * h;
-            if (part < parts) {
-                double a0 = 0.0, a1 = 0.0;
-                int k = k0;
-                for (; k + 1 < k1; k += 2) {
-                    a0 = fma(R[(int64_t)k * h + i], v[t * h + k], a0);
-                    a1 = fma(R[(int64_t)(k + 1) * h + i], v[t * h + k + 1], a1);
-                }
-                if (k < k1) a0 = fma(R[(int64_t)k * h + i], v[t * h + k], a0);
-                psum[(part * TB + t) * h + i] = a0 + a1;
+            for (int t = 0; t < TB; ++t)
+                if (t % parts == part && t < nt) psum[t * h + i] = acc[t];
+        } else {  // a block that straddles two groups: every table with its own R
+            for (int t = part; t < nt; t += parts) {
+                const TabDesc td = tabs[s_tab[t]];
+                const double* R = Rt + ((int64_t)td.split * V + td.cluster) * h * h;
+                double acc = 0.0;
+                for (int k = 0; k < h; ++k) acc = fma(R[(int64_t)k * h + i], v[t * h + k], acc);
+                psum[t * h + i] = acc;
             }
         }
     }
     __syncthreads();
     for (int e = tid; e < nt * h; e += 256) {
         const int t = e / h, ii = e - t * h;
-        double acc = psum[t * h + ii];
-        for (int q = 1; q < parts; ++q) acc = acc + psum[(q * TB + t) * h + ii];
+        const double acc = psum[t * h + ii];
         px_out[(int64_t)s_tab[t] * h + ii] = acc;
         if (px32_out) px32_out[(int64_t)s_tab[t] * h + ii] = (float)acc;
+    }
+}
+
+// The grouped projection on the float64 matrix cores (round 4).  The VALU form above reads one broadcast LDS operand per fused
+// multiply-add and waits for it (195 v_fmac_f64, 140 ds_read, 185 s_waitcnt in its listing): 1.7 ms for the 1.2 M tables of a
+// V = 2048 batch, 7 % of the float64 rate.  v_mfma_f64_16x16x4_f64 takes ONE operand pair per lane for 1024 multiply-adds and is, per
+// output element, exactly the chain of fused multiply-adds over ascending k that k_tables computes (tools/probes/mfma_f64_order.hip:
+// 512000 results, none differs) -- so this kernel changes no bit.  A block = up to 16 tables of one (split, cluster) group: A = R
+// (rows = outputs i, 16 per tile; loaded straight from global memory, 128 contiguous bytes per k), B = the tables' residuals v
+// (columns = tables; staged in LDS with a pitch of h + 4), wave w owns the output tiles w, w + 4, ...  h % 16 == 0.
+template <typename CT, int CH /* MFMA steps whose A operands are in flight together: 16 when h % 64 == 0, else 4 */>
+__global__ __launch_bounds__(256) void k_tables_group_mfma(const CT* __restrict__ X, const CT* __restrict__ Cs,
+                                                           const double* __restrict__ Rt, const double* __restrict__ mus,
+                                                           const TabDesc* __restrict__ tabs, const int* __restrict__ tab_order,
+                                                           int n_tabs, int V, int h, int D, double* __restrict__ px_out,
+                                                           const int64_t* __restrict__ d_totals, float* __restrict__ px32_out) {
+    typedef double f64x4_t __attribute__((ext_vector_type(4)));
+    constexpr int TB = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (d_totals) {
+        n_tabs = (int)d_totals[1];
+        if ((int)blockIdx.x * TB >= n_tabs) return;
+    }
+    const int pitch = h + 4;
+    double* v = reinterpret_cast<double*>(smem);  // [TB][pitch]
+    __shared__ int s_tab[TB];
+    __shared__ TabDesc s_td[TB];
+    __shared__ int s_same;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int first = blockIdx.x * TB;
+    const int nt = (n_tabs - first < TB) ? (n_tabs - first) : TB;
+    if (tid < TB) {
+        const int tb = tab_order[first + (tid < nt ? tid : 0)];  // (columns past the block's tables: the first table again, masked below)
+        s_tab[tid] = tid < nt ? tb : -1;
+        s_td[tid] = tabs[tb];
+    }
+    __syncthreads();
+    const TabDesc td0 = s_td[0];
+    if (tid == 0) {
+        int same = 1;
+        for (int t = 1; t < nt; ++t) same &= (s_td[t].split == td0.split && s_td[t].cluster == td0.cluster);
+        s_same = same;
+    }
+    // residuals of the block's tables -> LDS; four elements per thread in flight (descriptors from LDS, loads unconditional)
+    for (int e0 = tid; e0 < TB * h; e0 += 1024) {
+        CT xv[4], cv[4];
+        double mv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u < TB * h ? e0 + 256 * u : tid;
+            const int t = e / h, k = e - t * h;
+            const TabDesc td = s_td[t];
+            xv[u] = X[(int64_t)td.q * D + td.split * h + k];
+            cv[u] = Cs[((int64_t)td.split * V + td.cluster) * h + k];
+            mv[u] = mus[((int64_t)td.split * V + td.cluster) * h + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            if (e < TB * h) {
+                const int t = e / h, k = e - t * h;
+                const CT res = xv[u] - cv[u];  // rounds in CT (float32 when both are float32), model.py:635
+                v[t * pitch + k] = t < nt ? (double)res - mv[u] : 0.0;  // columns past the block's tables: zeros (not stored)
+            }
+        }
+    }
+    __syncthreads();
+    if (s_same) {
+        const double* R = Rt + ((int64_t)td0.split * V + td0.cluster) * h * h;
+        const int t = lane & 15, kq = lane >> 4;
+        for (int it = wave; it < h / 16; it += 4) {
+            f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+            const double* Ra = R + (int64_t)kq * h + it * 16 + (lane & 15);  // A[row = i][k = 4 s + kq] = R[k][i]
+            const double* vb = v + t * pitch + kq;                           // B[k = 4 s + kq][col = t] = v[t][k]
+            for (int s0 = 0; s0 < h / 4; s0 += CH) {  // (h / 4) % CH == 0
+                double ra[CH], rb[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) ra[u] = Ra[(int64_t)(s0 + u) * 4 * h];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) rb[u] = vb[4 * (s0 + u)];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[u], rb[u], acc, 0, 0, 0);
+            }
+            if (t < nt) {
+                const int64_t o = (int64_t)s_tab[t] * h + it * 16 + kq;  // result r: output i = it * 16 + kq + 4 r, table t
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    px_out[o + 4 * r] = acc[r];
+                    if (px32_out) px32_out[o + 4 * r] = (float)acc[r];
+                }
+            }
+        }
+    } else {  // a block that straddles two groups: every table with its own R, the same chain on the vector unit
+        for (int e = tid; e < nt * h; e += 256) {
+            const int t = e / h, i = e - t * h;
+            const TabDesc td = s_td[t];
+            const double* R = Rt + ((int64_t)td.split * V + td.cluster) * h * h;
+            double acc = 0.0;
+            for (int k = 0; k < h; ++k) acc = fma(R[(int64_t)k * h + i], v[t * pitch + k], acc);
+            px_out[(int64_t)s_tab[t] * h + i] = acc;
+            if (px32_out) px32_out[(int64_t)s_tab[t] * h + i] = (float)acc;
+        }
     }
 }
 
@@ -1062,9 +1114,17 @@ static void launch_tables(int64_t n_tabs, size_t tab_lds, hipStream_t st, const 
                           int nf, int K, int D, double* T, PwProg prog_w, double* px_out, const int64_t* d_totals = nullptr,
                           float* px32_out = nullptr) {
     constexpr int TB = 8;
-    if (px_out && h <= 256 && 256 / h >= 1 && !getenv("CIS_TABLES_UNGROUPED")) {
-        const int parts = 256 / h;
-        const size_t lds = (size_t)(TB * h + parts * TB * h) * sizeof(double);
+    if (px_out && h <= 256 && h % 16 == 0 && !getenv("CIS_TABLES_UNGROUPED") && !getenv("CIS_TABLES_VALU")) {
+        // the grouped projection on the float64 matrix cores (16 tables per block); CIS_TABLES_VALU=1: the vector form below
+        const size_t lds = (size_t)16 * (h + 4) * sizeof(double);
+        if (h % 64 == 0)
+            hipLaunchKernelGGL((k_tables_group_mfma<CT, 16>), dim3((unsigned)ceil_div(n_tabs, 16)), dim3(256), lds, st, X, Cs, Rt, mus, tabs,
+                               tab_order, (int)n_tabs, V, h, D, px_out, d_totals, px32_out);
+        else
+            hipLaunchKernelGGL((k_tables_group_mfma<CT, 4>), dim3((unsigned)ceil_div(n_tabs, 16)), dim3(256), lds, st, X, Cs, Rt, mus, tabs,
+                               tab_order, (int)n_tabs, V, h, D, px_out, d_totals, px32_out);
+    } else if (px_out && h <= 256 && 256 / h >= 1 && !getenv("CIS_TABLES_UNGROUPED")) {
+        const size_t lds = (size_t)(TB * h + TB * h) * sizeof(double);
         hipLaunchKernelGGL((k_tables_group<CT, TB>), dim3((unsigned)ceil_div(n_tabs, TB)), dim3(256), lds, st, X, Cs, Rt, mus, tabs,
                            tab_order, (int)n_tabs, V, h, D, px_out, d_totals, px32_out);
     } else {
