@@ -1502,6 +1502,83 @@ __global__ __launch_bounds__(256) void k_project_tiles(const CT* __restrict__ X,
     }
 }
 
+// The same tile on the float64 matrix cores (round 4).  k_project_tiles reads two LDS operands per four fused multiply-adds and is a
+// single chain over ascending k per output -- exactly what v_mfma_f64_16x16x4_f64 computes per element (tools/probes/mfma_f64_order.hip),
+// so this kernel changes no bit.  A = R (rows = outputs i: wave w owns the 16 outputs blockIdx.y * 64 + 16 w ..., loaded straight from
+// global memory), B = the tile's centred residuals (columns = the tile's <= 64 vectors, four column tiles per wave; staged in LDS with a
+// pitch of KC + 4), K in chunks of KC = 4 CH (h % KC == 0).
+template <typename CT, int CH>
+__global__ __launch_bounds__(256) void k_project_tiles_mfma(const CT* __restrict__ X, const CT* __restrict__ Cs,
+                                                            const double* __restrict__ Rt, const double* __restrict__ mus,
+                                                            const ProjTile* __restrict__ tiles, const int* __restrict__ n_tiles,
+                                                            const int* __restrict__ perm, int64_t n, int V, int h, int D,
+                                                            double* __restrict__ out) {
+    if ((int)blockIdx.x >= *n_tiles) return;
+    constexpr int KC = 4 * CH, PITCH = KC + 4;
+    const ProjTile pt = tiles[blockIdx.x];
+    __shared__ double sV[64][PITCH];  // [vector][k of the chunk]
+    __shared__ int srow[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 64) srow[tid] = (tid < pt.count) ? perm[(int64_t)pt.split * n + pt.start + tid] : -1;
+    __syncthreads();
+    const CT* Cc = Cs + ((int64_t)pt.split * V + pt.cluster) * h;
+    const double* mu = mus + ((int64_t)pt.split * V + pt.cluster) * h;
+    const double* R = Rt + ((int64_t)pt.split * V + pt.cluster) * h * h;
+    const int row_any = srow[0];
+    const int i0 = blockIdx.y * 64 + wave * 16;  // this wave's outputs
+    const int kq = lane >> 4, lc = lane & 15;
+    f64x4 acc[4];
+#pragma unroll
+    for (int vt = 0; vt < 4; ++vt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[vt][r] = 0.0;
+    constexpr int NE = 64 * KC / 256;  // staged elements per thread and chunk
+    for (int kc = 0; kc < h; kc += KC) {
+        CT xa[NE], ca[NE];
+        double ma[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {  // loads only (a row that is not there: any row of the tile, masked below)
+            const int idx = tid + e * 256;
+            const int v = idx / KC, k = idx % KC;
+            const int row = srow[v];
+            xa[e] = X[(int64_t)(row >= 0 ? row : row_any) * D + pt.split * h + kc + k];
+            ca[e] = Cc[kc + k];
+            ma[e] = mu[kc + k];
+        }
+        double ra[CH];
+        if (i0 < h) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) ra[u] = R[(int64_t)(kc + 4 * u + kq) * h + i0 + lc];  // A[row = i][k] = R[k][i]
+        }
+        __syncthreads();  // the previous chunk's operands have been read
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = tid + e * 256;
+            const int v = idx / KC, k = idx % KC;
+            const CT res = xa[e] - ca[e];  // rounds in CT
+            sV[v][k] = srow[v] >= 0 ? (double)res - ma[e] : 0.0;
+        }
+        __syncthreads();
+        if (i0 < h) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+#pragma unroll
+                for (int vt = 0; vt < 4; ++vt)
+                    acc[vt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[u], sV[vt * 16 + lc][4 * u + kq], acc[vt], 0, 0, 0);
+            }
+        }
+    }
+    if (i0 < h) {
+#pragma unroll
+        for (int vt = 0; vt < 4; ++vt) {
+            const int row = srow[vt * 16 + lc];
+            if (row < 0) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(int64_t)row * D + pt.split * h + i0 + kq + 4 * r] = acc[vt][r];  // result r: output i0 + kq + 4 r
+        }
+    }
+}
+
 // reconstruct: x[s*h + k] = (sum_i R[c][i][k] * sx[i] + mu[c][k]) + C[c][k]   (model.py:662-669)
 __global__ void k_reconstruct(const uint16_t* __restrict__ coarse, const uint8_t* __restrict__ fine,
                               const double* __restrict__ Rs, const double* __restrict__ mus,
@@ -1980,12 +2057,20 @@ static int dev_project(cis_model* m, const void* xc, int ct, int64_t n, const ui
                        n_tiles, 64);
     hipLaunchKernelGGL(k_group_scatter, dim3(grid1(n, 256)), dim3(256), bins_lds, st, d_coarse, n, V, offsets, cursor, perm);
     dim3 g((unsigned)max_tiles, (unsigned)ceil_div(m->h, 64));
-    if (ct == CIS_F32)
-        hipLaunchKernelGGL(k_project_tiles<float>, g, dim3(256), 0, st, (const float*)xc, m->d_Cs32, m->d_Rt, m->d_mus,
-                           tiles, n_tiles, perm, n, V, m->h, m->D, d_proj);
-    else
-        hipLaunchKernelGGL(k_project_tiles<double>, g, dim3(256), 0, st, (const double*)xc, m->d_Cs64, m->d_Rt, m->d_mus,
-                           tiles, n_tiles, perm, n, V, m->h, m->D, d_proj);
+    // the tile product on the float64 matrix cores where h is a multiple of 16 (CIS_PROJECT_VALU=1: the vector form)
+    const bool pm = m->h % 16 == 0 && !getenv("CIS_PROJECT_VALU");
+    const bool pm64 = pm && m->h % 64 == 0;
+#define CIS_PROJ(KERN, TT, XP, CP) hipLaunchKernelGGL(KERN, g, dim3(256), 0, st, (const TT*)XP, CP, m->d_Rt, m->d_mus, tiles, n_tiles, perm, n, V, m->h, m->D, d_proj)
+    if (ct == CIS_F32) {
+        if (pm64) CIS_PROJ((k_project_tiles_mfma<float, 16>), float, xc, m->d_Cs32);
+        else if (pm) CIS_PROJ((k_project_tiles_mfma<float, 4>), float, xc, m->d_Cs32);
+        else CIS_PROJ(k_project_tiles<float>, float, xc, m->d_Cs32);
+    } else {
+        if (pm64) CIS_PROJ((k_project_tiles_mfma<double, 16>), double, xc, m->d_Cs64);
+        else if (pm) CIS_PROJ((k_project_tiles_mfma<double, 4>), double, xc, m->d_Cs64);
+        else CIS_PROJ(k_project_tiles<double>, double, xc, m->d_Cs64);
+    }
+#undef CIS_PROJ
     CIS_CHECK_HIP(hipGetLastError());
     return CIS_OK;
 }
