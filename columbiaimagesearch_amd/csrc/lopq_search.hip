@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_tables_group_mfma(const CT* __restrict_
     double* v = reinterpret_cast<double*>(smem);  // [TB][pitch]
     __shared__ int s_tab[TB];
     __shared__ TabDesc s_td[TB];
-    __shared__ int s_same;
+    __shared__ int s_first[TB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int first = blockIdx.x * TB;
     const int nt = (n_tabs - first < TB) ? (n_tabs - first) : TB;
@@ -1040,11 +1040,12 @@ __global__ __launch_bounds__(256) void k_tables_group_mfma(const CT* __restrict_
         s_td[tid] = tabs[tb];
     }
     __syncthreads();
-    const TabDesc td0 = s_td[0];
-    if (tid == 0) {
-        int same = 1;
-        for (int t = 1; t < nt; ++t) same &= (s_td[t].split == td0.split && s_td[t].cluster == td0.cluster);
-        s_same = same;
+    // s_first[t]: the first table of the block with table t's (split, cluster) -- a block that straddles groups runs one pass per group
+    if (tid < TB) {
+        int f = tid;
+        for (int u = tid - 1; u >= 0; --u)
+            if (s_td[u].split == s_td[tid].split && s_td[u].cluster == s_td[tid].cluster) f = u;
+        s_first[tid] = tid < nt ? f : -1;
     }
     // residuals of the block's tables -> LDS; four elements per thread in flight (descriptors from LDS, loads unconditional)
     for (int e0 = tid; e0 < TB * h; e0 += 1024) {
@@ -1070,9 +1071,12 @@ __global__ __launch_bounds__(256) void k_tables_group_mfma(const CT* __restrict_
         }
     }
     __syncthreads();
-    if (s_same) {
-        const double* R = Rt + ((int64_t)td0.split * V + td0.cluster) * h * h;
-        const int t = lane & 15, kq = lane >> 4;
+    const int t = lane & 15, kq = lane >> 4;
+    for (int t0 = 0; t0 < nt; ++t0) {
+        if (s_first[t0] != t0) continue;  // (uniform) one pass per (split, cluster) group present in the block: one as a rule
+        const TabDesc tdg = s_td[t0];
+        const double* R = Rt + ((int64_t)tdg.split * V + tdg.cluster) * h * h;
+        const bool mine = t < nt && s_first[t] == t0;  // columns of other groups are computed along and not stored
         for (int it = wave; it < h / 16; it += 4) {
             f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
             const double* Ra = R + (int64_t)kq * h + it * 16 + (lane & 15);  // A[row = i][k = 4 s + kq] = R[k][i]
@@ -1086,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_tables_group_mfma(const CT* __restrict_
 #pragma unroll
                 for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[u], rb[u], acc, 0, 0, 0);
             }
-            if (t < nt) {
+            if (mine) {
                 const int64_t o = (int64_t)s_tab[t] * h + it * 16 + kq;  // result r: output i = it * 16 + kq + 4 r, table t
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1094,16 +1098,6 @@ __global__ __launch_bounds__(256) void k_tables_group_mfma(const CT* __restrict_
                     if (px32_out) px32_out[o + 4 * r] = (float)acc[r];
                 }
             }
-        }
-    } else {  // a block that straddles two groups: every table with its own R, the same chain on the vector unit
-        for (int e = tid; e < nt * h; e += 256) {
-            const int t = e / h, i = e - t * h;
-            const TabDesc td = s_td[t];
-            const double* R = Rt + ((int64_t)td.split * V + td.cluster) * h * h;
-            double acc = 0.0;
-            for (int k = 0; k < h; ++k) acc = fma(R[(int64_t)k * h + i], v[t * pitch + k], acc);
-            px_out[(int64_t)s_tab[t] * h + i] = acc;
-            if (px32_out) px32_out[(int64_t)s_tab[t] * h + i] = (float)acc;
         }
     }
 }
