@@ -1028,6 +1028,8 @@ __global__ __launch_bounds__(256) void k_tables_group_mfma(const CT* __restrict_
     }
     const int pitch = h + 4;
     double* v = reinterpret_cast<double*>(smem);  // [TB][pitch]
+    double* so = v + TB * pitch;                  // [TB][h + 2]: the results, so that a table's h outputs leave as one contiguous run
+    const int opitch = h + 2;
     __shared__ int s_tab[TB];
     __shared__ TabDesc s_td[TB];
     __shared__ int s_first[TB];
@@ -1091,14 +1093,20 @@ __global__ __launch_bounds__(256) void k_tables_group_mfma(const CT* __restrict_
                 for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[u], rb[u], acc, 0, 0, 0);
             }
             if (mine) {
-                const int64_t o = (int64_t)s_tab[t] * h + it * 16 + kq;  // result r: output i = it * 16 + kq + 4 r, table t
+                double* o = so + t * opitch + it * 16 + kq;  // result r: output i = it * 16 + kq + 4 r, table t
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    px_out[o + 4 * r] = acc[r];
-                    if (px32_out) px32_out[o + 4 * r] = (float)acc[r];
-                }
+                for (int r = 0; r < 4; ++r) o[4 * r] = acc[r];
             }
         }
+    }
+    // (stored straight from the accumulators, every lane wrote four lone 8-byte values 32 bytes apart into sixteen different tables:
+    // partial-sector writes, 1.2 M tables x 64 of them per V = 2048 batch)
+    __syncthreads();
+    for (int e = tid; e < nt * h; e += 256) {
+        const int tt = e / h, i = e - tt * h;
+        const double a = so[tt * opitch + i];
+        px_out[(int64_t)s_tab[tt] * h + i] = a;
+        if (px32_out) px32_out[(int64_t)s_tab[tt] * h + i] = (float)a;
     }
 }
 
@@ -1110,7 +1118,7 @@ static void launch_tables(int64_t n_tabs, size_t tab_lds, hipStream_t st, const 
     constexpr int TB = 8;
     if (px_out && h <= 256 && h % 16 == 0 && !getenv("CIS_TABLES_UNGROUPED") && !getenv("CIS_TABLES_VALU")) {
         // the grouped projection on the float64 matrix cores (16 tables per block); CIS_TABLES_VALU=1: the vector form below
-        const size_t lds = (size_t)16 * (h + 4) * sizeof(double);
+        const size_t lds = (size_t)16 * (h + 4 + h + 2) * sizeof(double);
         if (h % 64 == 0)
             hipLaunchKernelGGL((k_tables_group_mfma<CT, 16>), dim3((unsigned)ceil_div(n_tabs, 16)), dim3(256), lds, st, X, Cs, Rt, mus, tabs,
                                tab_order, (int)n_tabs, V, h, D, px_out, d_totals, px32_out);
