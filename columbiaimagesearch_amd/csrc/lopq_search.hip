@@ -1293,6 +1293,77 @@ __global__ __launch_bounds__(256) void k_rank_sort(const CT* __restrict__ dist /
     }
 }
 
+// k_rank_sort for float32 distances with the sort in REGISTERS (round 4): thread t owns the NPT consecutive elements t * NPT ..., so of
+// the log2(N) (log2(N) + 1) / 2 compare-exchange stages of the bitonic network those with partner distance j < NPT stay inside a thread,
+// those with j < 64 NPT are one 64-bit lane exchange inside a wave, and only the 3 (N = 2048) to 6 (N = 4096) stages across waves go
+// through LDS with a barrier -- the LDS form above pays a barrier and four LDS accesses per element for every one of its 66 / 78 stages.
+// Same keys (distance bits << 32 | centroid index), same order: identical output.
+template <int NPT>
+__global__ __launch_bounds__(256) void k_rank_sort_reg(const float* __restrict__ dist /* [2][nq][V] */, int nq, int V,
+                                                       uint16_t* __restrict__ order, float* __restrict__ sorted, int* __restrict__ grp) {
+    constexpr int N = 256 * NPT;
+    __shared__ uint64_t sx[N];
+    const int q = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+    if (q == 0 && s == 0)
+        for (int i = tid; i < 4 * V * GRP_SUB; i += 256) grp[i] = 0;
+    const float* d = dist + ((int64_t)s * nq + q) * V;
+    uint64_t key[NPT];
+#pragma unroll
+    for (int r = 0; r < NPT; ++r) {
+        const int e = tid * NPT + r;
+        key[r] = e < V ? ((f2bits(d[e < V ? e : 0]) << 32) | (uint64_t)e) : ~0ull;
+    }
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64 * NPT) {  // across waves: through LDS
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < NPT; ++r) sx[tid * NPT + r] = key[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < NPT; ++r) {
+                    const int e = tid * NPT + r;
+                    const uint64_t o = sx[e ^ j];
+                    const bool keep_min = ((e & j) == 0) == ((e & k) == 0);
+                    key[r] = keep_min ? (o < key[r] ? o : key[r]) : (o > key[r] ? o : key[r]);
+                }
+            } else if (j >= NPT) {  // across lanes of the wave
+                const int lj = j / NPT;
+#pragma unroll
+                for (int r = 0; r < NPT; ++r) {
+                    const int e = tid * NPT + r;
+                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key[r], lj), hi = (uint32_t)__shfl_xor((int)(uint32_t)(key[r] >> 32), lj);
+                    const uint64_t o = ((uint64_t)hi << 32) | lo;
+                    const bool keep_min = ((e & j) == 0) == ((e & k) == 0);
+                    key[r] = keep_min ? (o < key[r] ? o : key[r]) : (o > key[r] ? o : key[r]);
+                }
+            } else {  // inside the thread
+#pragma unroll
+                for (int r = 0; r < NPT; ++r) {
+                    if ((r & j) == 0) {
+                        const int e = tid * NPT + r;
+                        const bool asc = (e & k) == 0;
+                        const uint64_t a = key[r], b = key[r | j];
+                        const bool sw = (a > b) == asc;
+                        key[r] = sw ? b : a;
+                        key[r | j] = sw ? a : b;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NPT; ++r) {
+        const int e = tid * NPT + r;
+        if (e < V) {
+            order[((int64_t)q * 2 + s) * V + e] = (uint16_t)(uint32_t)key[r];
+            sorted[((int64_t)q * 2 + s) * V + e] = __uint_as_float((uint32_t)(key[r] >> 32));
+        }
+    }
+}
+
 // ================================================================================================
 // kernel: ADC scan + block top-k   (lopq/lopq/search.py:166-175, :210-215)
 // ================================================================================================
@@ -4450,7 +4521,14 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     } else {
     CIS_TRY(cis_launch_sqdist_both(m, xc, ct, nq, ix->w_cd.p, st));
     if (ct == CIS_F32) {
-        if (V > 256 && Vp2 <= 4096)
+        static const bool sort_lds = getenv("CIS_RANK_SORT_LDS") != nullptr;  // the LDS form of the sort (A/B runs)
+        if (V > 256 && Vp2 == 1024 && !sort_lds)
+            hipLaunchKernelGGL(k_rank_sort_reg<4>, dim3(nq, 2), dim3(256), 0, st, ix->w_cd.as<float>(), nq, V, ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
+        else if (V > 256 && Vp2 == 2048 && !sort_lds)
+            hipLaunchKernelGGL(k_rank_sort_reg<8>, dim3(nq, 2), dim3(256), 0, st, ix->w_cd.as<float>(), nq, V, ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
+        else if (V > 256 && Vp2 == 4096 && !sort_lds)
+            hipLaunchKernelGGL(k_rank_sort_reg<16>, dim3(nq, 2), dim3(256), 0, st, ix->w_cd.as<float>(), nq, V, ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
+        else if (V > 256 && Vp2 <= 4096)
             hipLaunchKernelGGL(k_rank_sort<float>, dim3(nq, 2), dim3(256), (size_t)Vp2 * 16, st, ix->w_cd.as<float>(), nq, V, Vp2,
                                ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
         else
