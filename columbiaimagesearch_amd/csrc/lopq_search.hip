@@ -298,6 +298,12 @@ __global__ __launch_bounds__(64) void k_front_small(const CT* __restrict__ X /* 
 //   4. a band that cannot be cut below what the workgroup sorts (thousands of equal sums), or more visited cells than the
 //      list holds: the query is flagged and the frontier walk above (k_plan with `only`) handles it.
 // The count pass leaves the visited (i, j) list in global memory for the emit pass.
+#ifdef CIS_PLAN_DBG  // tools/build_variant.sh plandbg -DCIS_PLAN_DBG: probes / bands / cycles per phase of k_plan_par's count pass
+__device__ unsigned long long g_plan_dbg[8];
+#define PLAN_DBG(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_plan_dbg[i], (unsigned long long)(v)); } while (0)
+#else
+#define PLAN_DBG(i, v) do { } while (0)
+#endif
 static const int PLAN_PAR_CAP = 2048;   // cells a workgroup enumerates and sorts per band
 static const int PLAN_PAR_STAGE = 4096; // d0 / d1 staged in LDS: the kernel takes V <= 4096
 
@@ -434,12 +440,17 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
             // tau with want <= #{tau_prev < s <= tau} <= 2 * want (or the smallest tau that reaches `want` when values repeat)
             uint64_t lo = have_prev ? tau_prev + 1 : s_min, hi = s_max;
             int64_t c_hi = all_cells;
+            const long long dbg_t0 = wall_clock64();
+            (void)dbg_t0;
             while (c_hi - c_prev > 2 * want && lo < hi) {
                 const uint64_t mid = lo + ((hi - lo) >> 1);
                 const int64_t c = count_le(mid);
+                PLAN_DBG(0, 1);
                 if (c - c_prev >= want) { hi = mid; c_hi = c; }
                 else lo = mid + 1;
             }
+            PLAN_DBG(1, 1);
+            PLAN_DBG(2, wall_clock64() - dbg_t0);
             if (c_hi - c_prev > PLAN_PAR_CAP) { fb = true; break; }
             const int cnt = (int)(c_hi - c_prev);
             if (visited + cnt > vis_cap) { fb = true; break; }
@@ -561,6 +572,8 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
                 run64 += tot;
                 __syncthreads();
             }
+            PLAN_DBG(3, wall_clock64() - dbg_t0);
+            PLAN_DBG(4, cnt);
             if (quota <= 0) cut = 0;
             const int take = cut >= 0 ? cut + 1 : cnt;
             for (int idx = tid; idx < take; idx += 256) vl[visited + idx] = s_ij[idx];
@@ -570,7 +583,19 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
             c_prev = c_hi;
             tau_prev = hi;
             have_prev = true;
-            target = target * 4 < PLAN_PAR_CAP / 2 ? target * 4 : PLAN_PAR_CAP / 2;
+            // the next band: the cells the quota still needs at the candidates per cell seen so far, + 25 % (round 4).  Four times the
+            // last target made the second band of a V = 2048 query 1024 ... 2048 cells when ~300 more were needed: the band's
+            // enumeration and its sort (n log^2 n) were most of the count pass (tools/build_variant.sh plandbg -DCIS_PLAN_DBG).
+            // The bands' boundaries do not change what is visited.
+            {
+                int64_t nxt = target * 4;
+                if (cum > 0 && quota > cum) {
+                    const int64_t need = ((quota - cum) * (int64_t)visited + cum - 1) / cum;
+                    nxt = need + need / 4 + 16;
+                }
+                nxt = nxt < 64 ? 64 : nxt;
+                target = nxt < PLAN_PAR_CAP / 2 ? nxt : PLAN_PAR_CAP / 2;
+            }
             __syncthreads();
         }
         if (tid == 0) fallback[q] = fb ? 1 : 0;
@@ -4538,6 +4563,17 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             hipLaunchKernelGGL((k_plan_par<float, false>), dim3(nq), dim3(256), (size_t)2 * V * sizeof(float), st, ix->w_sorted.as<float>(), ix->w_order.as<uint16_t>(),
                                ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
                                nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap);
+#ifdef CIS_PLAN_DBG
+        if (par_plan) {
+            unsigned long long h[8];
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_plan_dbg), sizeof(h));
+            fprintf(stderr, "[cis] k_plan_par: %d queries, probes %.1f / query, bands %.2f / query, bisection %.1f us / query, bisection + enumeration + sort + cut %.1f us / query, cells per band %.0f (100 MHz clock)\n",
+                    nq, (double)h[0] / nq, (double)h[1] / nq, (double)h[2] / nq / 100.0, (double)h[3] / nq / 100.0, h[1] ? (double)h[4] / (double)h[1] : 0.0);
+            memset(h, 0, sizeof(h));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_plan_dbg), h, sizeof(h));
+        }
+#endif
         hipLaunchKernelGGL((k_plan<float, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<float>(),
                            ix->w_order.as<uint16_t>(), ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota,
                            seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr, plan_fb);
