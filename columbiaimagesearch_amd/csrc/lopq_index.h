@@ -38,6 +38,7 @@ struct cis_index {
                        // with dedup (cis_index_add on all ranks instead of the routed insert) -- what the duplicate
                        // test of those cells needs
     DevBuf d_gcount;   // [ncells] int64, all shards
+    DevBuf d_plan_hint;  // [2][2] uint64 (base index; views read the base's): see k_plan_par
     bool had_plain_remote = false;  // items of other shards' cells were counted without (cell, id) bookkeeping
     int64_t nb_indexed = 0;
     bool stats_fresh = false;  // the last insert chunk already refreshed n_total / max_cell / nonempty_cells
@@ -53,6 +54,7 @@ struct cis_index {
     const int64_t* ids_ptr() const { const cis_index* s = st(); return s->own.ids[s->own.cur].as<int64_t>(); }
     const int64_t* loff_ptr() const { const cis_index* s = st(); return s->own.loff[s->own.cur].as<int64_t>(); }
     const int64_t* gcount_ptr() const { return st()->d_gcount.as<int64_t>(); }
+    unsigned long long* plan_hint_ptr() const { return st()->d_plan_hint.as<unsigned long long>(); }
     void sync_from_base() {  // scalars of the storage the search path reads
         if (!base) return;
         ncells = base->ncells; rank = base->rank; world = base->world; nb_indexed = base->nb_indexed; n_local = base->n_local;

@@ -545,6 +545,10 @@ int cis_index_ready(cis_index* ix) {
         CIS_TRY(ix->d_gcount.reserve((size_t)ix->ncells * sizeof(int64_t)));
         CIS_CHECK_HIP(hipMemset(ix->d_gcount.p, 0, (size_t)ix->ncells * sizeof(int64_t)));
     }
+    if (!ix->d_plan_hint.p) {  // k_plan_par's band-size hint (cells visited per unit of quota, the two launch parities)
+        CIS_TRY(ix->d_plan_hint.reserve(4 * sizeof(unsigned long long)));
+        CIS_CHECK_HIP(hipMemset(ix->d_plan_hint.p, 0, 4 * sizeof(unsigned long long)));
+    }
     if (!ix->owner.empty() && !ix->d_owner.p) {
         CIS_TRY(ix->d_owner.reserve((size_t)ix->ncells * sizeof(int32_t)));
         CIS_CHECK_HIP(hipMemcpy(ix->d_owner.p, ix->owner.data(), (size_t)ix->ncells * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -591,7 +595,7 @@ extern "C" int cis_index_create_view(cis_index** out, cis_index* base) {
 extern "C" void cis_index_destroy(cis_index* ix) {
     if (!ix) return;
     if (ix->m) (void)hipSetDevice(ix->m->device);
-    DevBuf* bufs[] = {&ix->d_gcount, &ix->d_owner, &ix->w_xp, &ix->w_cd, &ix->w_order,
+    DevBuf* bufs[] = {&ix->d_gcount, &ix->d_plan_hint, &ix->d_owner, &ix->w_xp, &ix->w_cd, &ix->w_order,
                       &ix->w_sorted, &ix->w_plan, &ix->w_off, &ix->w_items, &ix->w_tabs, &ix->w_T, &ix->w_hits,
                       &ix->w_hitn, &ix->w_slack, &ix->w_planfb, &ix->w_vis, &ix->w_tiles, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
                       &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px, &ix->w_T32, &ix->w_grp, &ix->w_tord, &ix->w_y64, &ix->w_x64,

@@ -320,7 +320,9 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
                                                   int* __restrict__ grp_cnt, const int* __restrict__ grp_base,
                                                   int* __restrict__ grp_cur, int* __restrict__ tab_order,
                                                   uint32_t* __restrict__ vis_list /* [nq][vis_cap] (i << 16 | j) in visit order */,
-                                                  int* __restrict__ fallback /* [nq] */, int vis_cap) {
+                                                  int* __restrict__ fallback /* [nq] */, int vis_cap,
+                                                  unsigned long long* __restrict__ hint /* null, or [2][2]: (cells visited, quota) summed over the
+                                                  queries of the launches of either parity (count pass) */, int hint_slot) {
     __shared__ uint64_t s_key[PLAN_PAR_CAP];
     __shared__ uint32_t s_ij[PLAN_PAR_CAP];
     __shared__ uint32_t s_gc[PLAN_PAR_STAGE];  // row starts of the band (one per active row, <= V), then the cells' sizes (<= PLAN_PAR_CAP)
@@ -427,6 +429,15 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
         bool fb = false, done = false;
         int visited = 0;
         int64_t cum = 0, c_prev = 0, target = 256;
+        // first band: 0.6 x the cells a query of this quota visited in the previous launch (so that [target, 2 target] holds what most
+        // queries need and ONE band is enumerated and sorted); 256 without a hint.  The hint only sizes the bands.
+        if (hint && quota > 0) {
+            const unsigned long long hv = hint[(hint_slot ^ 1) * 2], hq = hint[(hint_slot ^ 1) * 2 + 1];
+            if (hq > 0) {
+                const double t0 = 0.6 * (double)hv / (double)hq * (double)quota;
+                target = t0 < 64.0 ? 64 : (t0 > (double)(PLAN_PAR_CAP / 2) ? PLAN_PAR_CAP / 2 : (int64_t)t0);
+            }
+        }
         bool have_prev = false;
         uint64_t tau_prev = 0;
         const int64_t all_cells = (int64_t)V * V;
@@ -600,6 +611,10 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
         }
         if (tid == 0) fallback[q] = fb ? 1 : 0;
         if (fb) return;
+        if (tid == 0 && hint && quota > 0) {
+            atomicAdd(&hint[hint_slot * 2], (unsigned long long)visited);
+            atomicAdd(&hint[hint_slot * 2 + 1], (unsigned long long)quota);
+        }
         __threadfence_block();
         __syncthreads();
         int64_t n_items = 0, ncand = 0;
@@ -695,7 +710,9 @@ __global__ __launch_bounds__(1024) void k_plan_scan(const PlanOut* __restrict__ 
                                                     unsigned long long* __restrict__ qbound /* [nq] -> +inf */,
                                                     volatile int64_t* __restrict__ host_totals /* pinned, mapped */, int64_t seq,
                                                     int* __restrict__ grp_cnt /* read, then zeroed: the next batch's count pass finds it clean */,
-                                                    int* __restrict__ grp_base, int n_groups) {
+                                                    int* __restrict__ grp_base, int n_groups,
+                                                    unsigned long long* __restrict__ hint_zero /* null, or the two words k_plan_par's NEXT launch adds into */) {
+    if (hint_zero && threadIdx.x == 0) { hint_zero[0] = 0ull; hint_zero[1] = 0ull; }
     constexpr int R = 8;  // rounds held in registers; more queries than 8192 take the slow tail loop below
     __shared__ int s_wi[R][16], s_wt[R][16];  // wave totals per round
     __shared__ int64_t s_cand[16];
@@ -4514,6 +4531,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     // (k_plan_par) instead of one frontier step per visited cell; queries it cannot resolve fall back to the frontier walk
     const bool no_par_plan = getenv("CIS_NO_PAR_PLAN") != nullptr;
     const bool par_plan = V >= 128 && V <= PLAN_PAR_STAGE && !no_par_plan;
+    unsigned long long* plan_hint = (par_plan && !getenv("CIS_NO_PLAN_HINT")) ? ix->plan_hint_ptr() : nullptr;
+    const int hint_slot = (int)((ix->plan_seq + 1) & 1);  // this batch's launches add into this parity and read the other
     int* plan_fb = nullptr;
     uint32_t* vis_list = nullptr;
     // visited cells per query the fast plan records: 2 GB of visit lists per batch (an outlier query far from the data walks
@@ -4562,7 +4581,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (par_plan)
             hipLaunchKernelGGL((k_plan_par<float, false>), dim3(nq), dim3(256), (size_t)2 * V * sizeof(float), st, ix->w_sorted.as<float>(), ix->w_order.as<uint16_t>(),
                                ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
-                               nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap);
+                               nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap, plan_hint, hint_slot);
 #ifdef CIS_PLAN_DBG
         if (par_plan) {
             unsigned long long h[8];
@@ -4587,7 +4606,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (par_plan)
             hipLaunchKernelGGL((k_plan_par<double, false>), dim3(nq), dim3(256), (size_t)2 * V * sizeof(double), st, ix->w_sorted.as<double>(), ix->w_order.as<uint16_t>(),
                                ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
-                               nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap);
+                               nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap, plan_hint, hint_slot);
         hipLaunchKernelGGL((k_plan<double, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
                            ix->w_order.as<uint16_t>(), ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota,
                            seg_max, plan, nullptr, nullptr, nullptr, nullptr, grp_cnt, nullptr, nullptr, nullptr, plan_fb);
@@ -4608,7 +4627,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         ix->h_totals[4] = 0;  // (slots, fall-back slots) of the last sampled scan at M = 16: see m16_holdoff
     }
     const int64_t seq = ++ix->plan_seq;
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, plan, nq, item_off, tab_off, totals, qbound, ix->d_h_totals, seq, grp_cnt, grp_base, 2 * V * GRP_SUB);
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, plan, nq, item_off, tab_off, totals, qbound, ix->d_h_totals, seq, grp_cnt, grp_base, 2 * V * GRP_SUB,
+                       plan_hint ? plan_hint + (hint_slot ^ 1) * 2 : nullptr);
     volatile int64_t* h_tot = ix->h_totals;
     // A small batch on the all-candidates path does not wait for the plan totals: the workspace is sized by upper bounds
     // (every query stops within quota + largest cell candidates, in at most `nonempty cells` cells) and the kernels
@@ -4709,7 +4729,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (par_plan)
             hipLaunchKernelGGL((k_plan_par<float, true>), dim3(nq), dim3(256), 0, st, ix->w_sorted.as<float>(), ix->w_order.as<uint16_t>(),
                                ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota, seg_max, plan, item_off, tab_off, items,
-                               tabs, nullptr, grp_base, grp_cur, tab_order, vis_list, plan_fb, vis_cap);
+                               tabs, nullptr, grp_base, grp_cur, tab_order, vis_list, plan_fb, vis_cap, nullptr, 0);
         hipLaunchKernelGGL((k_plan<float, true>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<float>(),
                            ix->w_order.as<uint16_t>(), ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota,
                            seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order, plan_fb);
@@ -4720,7 +4740,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (par_plan)
             hipLaunchKernelGGL((k_plan_par<double, true>), dim3(nq), dim3(256), 0, st, ix->w_sorted.as<double>(), ix->w_order.as<uint16_t>(),
                                ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota, seg_max, plan, item_off, tab_off, items,
-                               tabs, nullptr, grp_base, grp_cur, tab_order, vis_list, plan_fb, vis_cap);
+                               tabs, nullptr, grp_base, grp_cur, tab_order, vis_list, plan_fb, vis_cap, nullptr, 0);
         hipLaunchKernelGGL((k_plan<double, true>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
                            ix->w_order.as<uint16_t>(), ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota,
                            seg_max, plan, item_off, tab_off, items, tabs, nullptr, grp_base, grp_cur, tab_order, plan_fb);
