@@ -701,6 +701,49 @@ __global__ __launch_bounds__(64) void k_multiseq_list(const CT* __restrict__ sor
     }
 }
 
+// The table-group part of k_plan_scan for wide vocabularies (round 4): 2 V x 32 counters are 131072 words at V = 2048, and one wave
+// scanning them 1024 at a time held the whole plan scan for 0.29 ms (0.58 at V = 4096).  Here the workgroup's 16 waves take 16384 per round.
+__global__ __launch_bounds__(1024) void k_group_bases(int* __restrict__ grp_cnt, int* __restrict__ grp_base, int n_groups) {
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int run = 0;
+    for (int g0 = 0; g0 < n_groups; g0 += 16384) {
+        int c[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int g = g0 + tid * 16 + i;
+            c[i] = g < n_groups ? grp_cnt[g] : 0;
+        }
+        int tot = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += c[i];
+        int x = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        __syncthreads();  // the previous round's wave totals have been read
+        if (lane == 63) s_w[wv] = x;
+        __syncthreads();
+        int base = run, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { base += w < wv ? s_w[w] : 0; all += s_w[w]; }
+        int r = base + x - tot;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int g = g0 + tid * 16 + i;
+            if (g < n_groups) {
+                grp_base[g] = r;
+                grp_cnt[g] = 0;              // as k_plan_scan: clean counters for the next batch, clean cursors for this batch's emit pass
+                grp_cnt[n_groups + g] = 0;
+            }
+            r += c[i];
+        }
+        run += all;
+    }
+}
+
 // exclusive scans over the queries of one batch (single block of 1024 threads); totals[0]=items, [1]=tables, [2]=cands.
 // Thread t owns queries t, t + 1024, ... (<= 8 rounds for a batch of 8192): every load and store of a wave is
 // contiguous -- with eight consecutive queries per thread the wave touched 64 cache lines per instruction and this
@@ -718,7 +761,8 @@ __global__ __launch_bounds__(1024) void k_plan_scan(const PlanOut* __restrict__ 
     __shared__ int64_t s_cand[16];
     __shared__ int64_t s_base_i[R][16], s_base_t[R][16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (wv == 15) {  // exclusive scan of the table-group counters by one wave: 64 x 16 at a time, loads issued together
+    if (wv == 15 && n_groups > 0) {  // exclusive scan of the table-group counters by one wave: 64 x 16 at a time, loads issued together
+        // (n_groups == 0: k_group_bases did it -- thousands of coarse clusters)
         int run = 0;
         for (int g0 = 0; g0 < n_groups; g0 += 1024) {
             int c[16];
@@ -4627,7 +4671,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         ix->h_totals[4] = 0;  // (slots, fall-back slots) of the last sampled scan at M = 16: see m16_holdoff
     }
     const int64_t seq = ++ix->plan_seq;
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, plan, nq, item_off, tab_off, totals, qbound, ix->d_h_totals, seq, grp_cnt, grp_base, 2 * V * GRP_SUB,
+    const int n_groups = 2 * V * GRP_SUB;
+    const bool groups_apart = n_groups > 8192;  // wide vocabularies: the group bases by their own launch (all 16 waves)
+    if (groups_apart) hipLaunchKernelGGL(k_group_bases, dim3(1), dim3(1024), 0, st, grp_cnt, grp_base, n_groups);
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, plan, nq, item_off, tab_off, totals, qbound, ix->d_h_totals, seq, grp_cnt, grp_base, groups_apart ? 0 : n_groups,
                        plan_hint ? plan_hint + (hint_slot ^ 1) * 2 : nullptr);
     volatile int64_t* h_tot = ix->h_totals;
     // A small batch on the all-candidates path does not wait for the plan totals: the workspace is sized by upper bounds
