@@ -4609,7 +4609,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     } else {
     CIS_TRY(cis_launch_sqdist_both(m, xc, ct, nq, ix->w_cd.p, st));
     if (ct == CIS_F32) {
-        static const bool sort_lds = getenv("CIS_RANK_SORT_LDS") != nullptr;  // the LDS form of the sort (A/B runs)
+        const bool sort_lds = getenv("CIS_RANK_SORT_LDS") != nullptr;  // the LDS form of the sort (A/B runs)
         if (V > 256 && Vp2 == 1024 && !sort_lds)
             hipLaunchKernelGGL(k_rank_sort_reg<4>, dim3(nq, 2), dim3(256), 0, st, ix->w_cd.as<float>(), nq, V, ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
         else if (V > 256 && Vp2 == 2048 && !sort_lds)

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 PCA_FIXTURES = ["c2", "c3", "c3b", "c4", "c3full"]
 ALL = ["tiny", "c1"] + PCA_FIXTURES
 
-_ROUTE_FREE = ("encode", "near_tie", "fine_codes", "hooks", "model_pieces", "selftest", "multisequence", "rerank", "kmeans", "training", "multisequence_plan", "select_path",
+_ROUTE_FREE = ("encode", "alternative_kernels", "near_tie", "fine_codes", "hooks", "model_pieces", "selftest", "multisequence", "rerank", "kmeans", "training", "multisequence_plan", "select_path",
                "large_limit", "fuzz")
 
 
@@ -118,6 +118,23 @@ def test_near_tie_vectors(name):
     coarse, fine = m.predict_batch(z["tie_X"])
     np.testing.assert_array_equal(coarse, z["tie_coarse"])
     np.testing.assert_array_equal(fine, z["tie_fine"])
+
+
+@pytest.mark.parametrize("name", PCA_FIXTURES)
+def test_encode_pca_forms_agree(monkeypatch, name):
+    """The PCA product with the loads-only fetch (k_pca_gemm_mfma_pf, round 4) against the border-checked forms (CIS_PCA_PF=0):
+    same instruction and k order per output element -- the same bits, on a ragged row count that leaves partial tiles."""
+    z, X, Q = load_golden(name)
+    m = hip_model(z)
+    Xr = np.concatenate([X, X[::-1]])[:max(1, (2 * len(X)) - 7)]
+    a = m.apply_PCA(Xr)
+    ca, fa = m.predict_batch(Xr)
+    monkeypatch.setenv("CIS_PCA_PF", "0")
+    b = m.apply_PCA(Xr)
+    cb, fb = m.predict_batch(Xr)
+    np.testing.assert_array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+    np.testing.assert_array_equal(ca, cb)
+    np.testing.assert_array_equal(fa, fb)
 
 
 @pytest.mark.parametrize("name", ALL)
@@ -718,6 +735,41 @@ def test_wide_coarse_vocabulary_matches_oracle(V, M, K, D):
             assert r["n_found"][qi] == n and r["visited"][qi] == visited
             np.testing.assert_array_equal(r["ids"][qi, :n], ids)
             np.testing.assert_allclose(r["dists"][qi, :n], dists, rtol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,M,K,D", [(300, 8, 256, 128), (1024, 4, 256, 32), (1500, 4, 16, 32), (300, 4, 64, 24)])
+def test_alternative_kernels_agree_bit_for_bit(monkeypatch, V, M, K, D):
+    """Round 4 moved several kernels to other forms that must not change a bit: the tables' projection (float64 matrix cores /
+    vector unit grouped / one table per block -- all ONE chain of fused multiply-adds per output), the encode's tile projection
+    (matrix cores / vector unit), the coarse rank sort (registers / LDS), the band sizes of the parallel plan (with / without the
+    hint of the previous launch).  Shapes: h = 64 (16 MFMA steps in flight), h = 16 (4), h = 12 (no matrix-core form)."""
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    m, _ = _random_model(V, M, K, D, seed=V + D)
+    rs = np.random.RandomState(2)
+    X = rs.randn(20000, D).astype(np.float32)
+    Q = rs.randn(300, D).astype(np.float32)
+    coarse, fine = m.predict_batch(X)
+    monkeypatch.setenv("CIS_PROJECT_VALU", "1")
+    c2, f2 = m.predict_batch(X)
+    monkeypatch.delenv("CIS_PROJECT_VALU")
+    np.testing.assert_array_equal(coarse, c2)
+    np.testing.assert_array_equal(fine, f2)
+    s = LOPQSearcherHIP(m)
+    s.add_codes_array(coarse, fine)
+    try:
+        for quota, limit in ((40, 10), (600, 100)):
+            want = s.search_batch(Q, quota=quota, limit=limit)
+            want = s.search_batch(Q, quota=quota, limit=limit)  # (the second call runs with the plan's hint of the first)
+            for env in ("CIS_TABLES_VALU", "CIS_TABLES_UNGROUPED", "CIS_RANK_SORT_LDS", "CIS_NO_PLAN_HINT", "CIS_NO_PAR_PLAN"):
+                monkeypatch.setenv(env, "1")
+                got = s.search_batch(Q, quota=quota, limit=limit)
+                monkeypatch.delenv(env)
+                for k in ("ids", "n_found", "visited"):
+                    np.testing.assert_array_equal(got[k], want[k], err_msg="%s %s" % (env, k))
+                np.testing.assert_array_equal(np.asarray(got["dists"]).view(np.uint64), np.asarray(want["dists"]).view(np.uint64), err_msg=env)
+    finally:
+        s.close()
 
 
 @pytest.mark.gpu
