@@ -873,10 +873,10 @@ def main():
     configs = None
     if solo and not explicit_config and not args.no_configs:
         configs = {}
-        sub_steps = max(5, min(args.steps, 10))
+        sub_steps = max(5, min(args.steps, 30))  # (10 steps behind 2 warm-up steps were mostly the ramp of the three batches in flight: C2 17.9 against 19 M q/s)
         for name in ("c2", "c3"):
             try:
-                r, sst = search_leg(ctx, name, CONFIGS[name]["n"], 1, sub_steps, 2, "strong", 1024 if want_oracle else 0)
+                r, sst = search_leg(ctx, name, CONFIGS[name]["n"], 1, sub_steps, max(2, min(args.warmup, 5)), "strong", 1024 if want_oracle else 0)
                 sub = {"value": r["value"], "unit": "queries/s", "ms_per_step": r["ms_per_step"], "steps": sub_steps,
                        "recall_at_10": r["recall_at_10"], "config": r["config"], "roofline": r["roofline"],
                        "stage_ms_per_step": r["stage_ms_per_step"], "encode": r["encode"]}
