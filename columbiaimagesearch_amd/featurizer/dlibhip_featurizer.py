@@ -7,7 +7,7 @@ of scope, like image decoding: supply it through ``landmark_fn`` or pass ``landm
 (get_face_chip_details + extract_image_chip, featurizer/face_chip.py + csrc/face_chip.hip) and the 29-convolution ResNet run in
 libcis_hip.so.  ``featurize_chips`` takes already aligned 150x150 RGB chips, ``featurize_landmarks`` an image and its shapes.
 
-Weights: ``rec_path`` is an ``.npz`` with the 117 arrays of ``tensor_names()``, or the XML that dlib's own
+Weights: ``rec_path`` is dlib's ``.dat`` (featurizer/dlib_dat.py, unpinned), an ``.npz`` with the 117 arrays of ``tensor_names()``, or the XML that dlib's own
 ``net_to_xml`` writes from ``dlib_face_recognition_resnet_model_v1.dat`` (featurizer/dlib_weights.py; the ``.dat`` itself
 is dlib's private C++ stream format -- INTEGRATION.md section 4 gives the six-line export program).
 """
@@ -82,9 +82,15 @@ class DLibHIPFeaturizer(GenericFeaturizer):
         elif self.rec_path.endswith(".xml"):
             from .dlib_weights import weights_from_net_xml
             weights = weights_from_net_xml(self.rec_path)
+        elif self.rec_path.endswith(".dat"):
+            # dlib's own stream (what the reference's config holds): walked by featurizer/dlib_dat.py -- a restatement of dlib's
+            # serialisation that has never met a real file (no dlib here): it stops at the first byte that disagrees and names it;
+            # the net_to_xml export is the fallback
+            from .dlib_dat import weights_from_dat
+            weights = weights_from_dat(self.rec_path)
         else:
-            raise NotImplementedError("rec_path must be the net_to_xml export (.xml) of the dlib .dat, or an .npz with the "
-                                      "117 network tensors -- see INTEGRATION.md section 4 (dlib's .dat stream is not parsed)")
+            raise NotImplementedError("rec_path must be dlib's .dat, its net_to_xml export (.xml), or an .npz with the "
+                                      "117 network tensors -- see INTEGRATION.md section 4")
         self.net = DLibFaceNet(weights)
         self._sp = None
         self.chip_fn = None      # (img, bbox) -> aligned 150x150x3 chip

@@ -182,6 +182,44 @@ def test_dlib_net_xml_round_trip(tmp_path):
         np.testing.assert_array_equal(got[k], w[k])
 
 
+def test_dlib_dat_stream_round_trip(tmp_path):
+    """featurizer/dlib_dat.py: dlib's own serialisation of anet_type, written by the module's restatement of the serializer (both
+    add_layer versions) and read back -- the same 117 arrays as the net_to_xml route gives; primitives against hand-made bytes;
+    a stream that disagrees stops with the byte offset."""
+    from columbiaimagesearch_amd.featurizer import dlib_dat as DD
+    from columbiaimagesearch_amd.featurizer.dlib_weights import weights_from_net_xml, write_net_xml
+    from columbiaimagesearch_amd.featurizer.synthetic import dlib_weights
+    # primitives: 300 = control 0x02 + 2C 01; -5 = 0x81 05; float_details of 0.5f = mantissa 1, exponent -1
+    s = DD._In(bytes([0x02, 0x2C, 0x01, 0x81, 0x05, 0x01, 0x01, 0x81, 0x01]) + b"1" + bytes([0x01, 0x03]) + b"abc")
+    assert s.int() == 300 and s.int() == -5 and s.real() == 0.5 and s.bool() is True and s.string() == "abc"
+    o = DD._Out()
+    for v in (0.0, 1.0, -2.5, 3.0e-7, 122.782, float("inf")):
+        o.real(v)
+    s = DD._In(b"".join(o.parts))
+    assert [s.real() for _ in range(6)] == [0.0, 1.0, -2.5, 3.0e-7, 122.782, float("inf")]
+    assert len(DD.anet_layers()) == 1 + 1 + 1 + 14 * 8 + 4 * 3 + 5  # loss, fc, avg pool, 14 blocks of 8 layers, 3 more in the 4 down blocks, stem + input
+    w = dlib_weights(5)
+    for lv, iv in ((2, 3), (1, 2)):
+        data = DD.write_dat(w, str(tmp_path / "net.dat"), layer_version=lv, input_layer_version=iv)
+        got = DD.weights_from_dat(str(tmp_path / "net.dat"))
+        assert len(got) == 117
+        for k in w:
+            assert got[k].shape == w[k].shape and got[k].dtype == np.float32
+            np.testing.assert_array_equal(got[k], w[k])
+    write_net_xml(w, str(tmp_path / "net.xml"))
+    via_xml = weights_from_net_xml(str(tmp_path / "net.xml"))
+    for k in w:
+        np.testing.assert_array_equal(via_xml[k], got[k])
+    with pytest.raises(ValueError, match="byte"):
+        DD.weights_from_dat(data[:-3])
+    bad = bytearray(data)
+    bad[1] = 9  # the loss layer's version
+    with pytest.raises(ValueError, match="add_loss_layer: version 9"):
+        DD.weights_from_dat(bytes(bad))
+    with pytest.raises(ValueError, match="behind the network"):
+        DD.weights_from_dat(data + b"\x00")
+
+
 def test_bytescale_is_the_scipy_misc_formula():
     """scipy.misc.bytescale on a float image (what imresize -> toimage applies, sbpycaffe_img_featurizer.py:126):
     (x - min) * 255/(max - min), clipped, +0.5, truncated.  A low-contrast image is stretched to the full range,
