@@ -1,6 +1,6 @@
 """CNN parity against the REAL caffe / dlib stacks -- runs only where tools/pin_cnn_with_real_weights.py has produced its golden files
 (tests/golden/pin_sentibank.npz, pin_dlib.npz) AND the weights are at hand (CIS_PIN_SENTIBANK_WEIGHTS + CIS_PIN_IMGMEAN,
-CIS_PIN_DLIB_WEIGHTS = the net_to_xml export or an .npz).  Neither exists in the build container or on the GPU boxes of this pool: the
+CIS_PIN_DLIB_WEIGHTS = the .dat itself, its net_to_xml export or an .npz).  Neither exists in the build container or on the GPU boxes of this pool: the
 tests skip there, and the CNN rows stay "parity unpinned"  until someone with the weights runs the tool."""
 import io
 import os

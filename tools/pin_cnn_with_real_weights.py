@@ -14,7 +14,7 @@ closes the gap wherever caffe / dlib and the weights DO exist: it runs the refer
   -> tests/golden/pin_sentibank.npz / tests/golden/pin_dlib.npz   (commit them: data, a few hundred KB)
 
   CIS_PIN_SENTIBANK_WEIGHTS=caffe_sentibank_train_iter_250000 CIS_PIN_IMGMEAN=imagenet_mean.npy \\
-  CIS_PIN_DLIB_WEIGHTS=dlib_resnet.xml python -m pytest tests/test_cnn_pinned.py -m gpu      # (the .xml: INTEGRATION.md section 4c)
+  CIS_PIN_DLIB_WEIGHTS=dlib_resnet.xml python -m pytest tests/test_cnn_pinned.py -m gpu      # (or the .dat itself: featurizer/dlib_dat.py; the .xml: INTEGRATION.md section 4c)
 
 Python 2 or 3.  The make-* commands follow, line by line, what the reference runs:
   sentibank: sbpycaffe_img_featurizer.py:94 (caffe.Net(..., caffe.TEST)), :99-111 (Transformer: transpose, channel swap, mean),
