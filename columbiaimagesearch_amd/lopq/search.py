@@ -526,8 +526,8 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
     key (:465, last write wins -- the dict searcher keeps the first); ``get_cell`` walks the keys in byte order
     (:482-499), so items of a cell -- and therefore results with equal distances -- come in key order; ids come back
     through ``id_lambda``.  The key/value store lives on the host (a dict) and is PERSISTENT at ``lmdb_path``: in LMDB when
-    the ``lmdb`` module is importable (the reference's own files), otherwise in an append-only log of the same key / value
-    bytes (lopq/kvlog.py) -- a restart re-opens the index (cold start tested in tests/test_reference_surfaces.py); the
+    the ``lmdb`` module is importable (the reference's own files; without the module an existing ``data.mdb`` is opened
+    read-only through lopq/lmdb_read.py), otherwise in an append-only log of the same key / value bytes (lopq/kvlog.py) -- a restart re-opens the index (cold start tested in tests/test_reference_surfaces.py); the
     device index is rebuilt in key order before the first search after an insert."""
 
     def __init__(self, model, lmdb_path=None, id_lambda=int):
@@ -559,10 +559,17 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
             if has_mdb and has_log:
                 raise RuntimeError("%s holds both an LMDB index (data.mdb) and a %s log: move one of them away -- refusing to pick"
                                    % (lmdb_path, kvlog.FILE_NAME))
+            self._read_only = None
             if has_mdb and lmdb is None:
-                raise ImportError("%s holds an LMDB index (data.mdb) but the `lmdb` module is not installed: install it to open the "
-                                  "index (a fresh %s log here would shadow the stored items)" % (lmdb_path, kvlog.FILE_NAME))
-            if lmdb is not None and not has_log:
+                # the reference's own files without py-lmdb: opened for SEARCHING through the page walker of lopq/lmdb_read.py
+                # (unpinned: a restatement of LMDB's on-disk layout that stops at the first page that disagrees).  Inserts are
+                # refused -- a fresh log here would shadow the stored items, and this module does not write LMDB.
+                from . import lmdb_read
+                for key, value in lmdb_read.Env(str(lmdb_path)).items(b"index"):
+                    self._put(bytes(key), self.decode_fine_codes(value))
+                self._read_only = ("%s holds an LMDB index (data.mdb) and the `lmdb` module is not installed: the index was opened "
+                                   "read-only through lopq/lmdb_read.py; install py-lmdb to add items" % lmdb_path)
+            elif lmdb is not None and not has_log:
                 self.env = lmdb.open(self.lmdb_path, map_size=1024 * 1000000 * 32, max_dbs=1)  # :416
                 self.index_db = self.env.open_db(b"index")
                 with self.env.begin(db=self.index_db) as txn:
@@ -645,6 +652,8 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
         return self.nb_indexed
 
     def add_codes(self, codes, ids=None):
+        if getattr(self, "_read_only", None):
+            raise ImportError(self._read_only)
         id_iter = count() if ids is None else iter(ids)
         txn = self.env.begin(db=self.index_db, write=True) if self.env is not None else None
         logged = [] if self._log is not None else None

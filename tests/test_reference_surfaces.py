@@ -375,6 +375,58 @@ def test_lmdb_order_index_survives_a_restart(tmp_path):
         LOPQSearcherLMDB(m, path, id_lambda=str)
 
 
+def test_lmdb_file_walker_round_trip(tmp_path):
+    """lopq/lmdb_read.py: the B+tree walk of a data.mdb against the module's own writer (no LMDB here: unpinned) -- keys in byte order
+    over several leaf pages and two branch levels, values on overflow pages, the newer of the two meta pages, entries count, damage."""
+    from columbiaimagesearch_amd.lopq import lmdb_read as LR
+    import array
+    rs = np.random.RandomState(3)
+    items = {}
+    for i in range(30000):
+        cell = array.array("H", [int(rs.randint(0, 16)), int(rs.randint(0, 16))]).tobytes()
+        items[cell + str(int(rs.randint(0, 10**9))).encode()] = bytes(rs.randint(0, 256, size=8).astype(np.uint8))
+    items[b"\x00\x00\x00\x00big"] = bytes(rs.randint(0, 256, size=9000).astype(np.uint8))  # three overflow pages
+    counts, depth = LR.write_env(str(tmp_path / "db"), list(items.items()))
+    assert depth >= 3 and counts["leaf"] > 100
+    env = LR.Env(str(tmp_path / "db"))
+    got = list(env.items(b"index"))
+    assert [k for k, _ in got] == sorted(items) and all(items[k] == v for k, v in got)
+    assert env.entries(b"index") == len(items) and env.meta["txnid"] == 7 and list(env.items(b"other")) == []
+    LR.write_env(str(tmp_path / "empty"), [])
+    assert list(LR.Env(str(tmp_path / "empty")).items()) == []
+    raw = bytearray(open(str(tmp_path / "db" / "data.mdb"), "rb").read())
+    raw[5 * 4096] ^= 0xFF  # a page that carries another page's number
+    open(str(tmp_path / "db" / "data.mdb"), "wb").write(bytes(raw))
+    with pytest.raises(LR.LMDBFormatError, match="page 5"):
+        list(LR.Env(str(tmp_path / "db")).items())
+
+
+def test_existing_lmdb_index_opens_read_only_without_the_lmdb_module(tmp_path):
+    """A directory that holds the reference's LMDB files is opened through lopq/lmdb_read.py when py-lmdb is missing: the same cells in the
+    same key order as a searcher fed the same items, inserts refused (host logic only)."""
+    from columbiaimagesearch_amd.lopq import LOPQSearcherLMDB, lmdb_read
+    try:
+        import lmdb  # noqa: F401
+        pytest.skip("py-lmdb is installed: the directory is opened by LMDB itself")
+    except ImportError:
+        pass
+    m, z, Q = _lmdb_fixture()
+    n = 2000
+    codes = [((int(c[0]), int(c[1])), tuple(int(v) for v in f)) for c, f in zip(z["coarse"][:n], z["fine"][:n])]
+    ids = ["sha1_%05d" % (i * 7919 % n) for i in range(n)]
+    ref = LOPQSearcherLMDB(m, str(tmp_path / "log"), id_lambda=str)
+    ref.add_codes(codes, ids)
+    lmdb_read.write_env(str(tmp_path / "mdb"), [(ref.encode_cell(c[0]) + i.encode(), ref.encode_fine_codes(c[1])) for c, i in zip(codes, ids)])
+    ro = LOPQSearcherLMDB(m, str(tmp_path / "mdb"), id_lambda=str)
+    assert ro.get_nb_indexed() == ref.get_nb_indexed() == n
+    for cell in sorted({c for c, _ in codes}):
+        assert ro.get_cell(cell) == ref.get_cell(cell)
+    with pytest.raises(ImportError, match="read-only"):
+        ro.add_codes(codes[:1], ["x"])
+    assert sorted(os.listdir(str(tmp_path / "mdb"))) == ["data.mdb"]
+    ro.close(); ref.close()
+
+
 def test_lmdb_path_never_shadows_an_existing_lmdb_index(tmp_path):
     """an lmdb_path that already holds the reference's LMDB files (data.mdb) must not be opened as an empty log when
     the lmdb module is missing, and a directory with both stores is refused (lopq/lopq/search.py:416-417 opens what is there)."""
@@ -390,7 +442,8 @@ def test_lmdb_path_never_shadows_an_existing_lmdb_index(tmp_path):
     p1.mkdir()
     (p1 / "data.mdb").write_bytes(b"\0" * 64)
     if not have_lmdb:
-        with pytest.raises(ImportError, match="data.mdb"):
+        # (round 4: such a directory is walked by lopq/lmdb_read.py; 64 zero bytes are not an LMDB file)
+        with pytest.raises(ValueError, match="no valid meta page"):
             LOPQSearcherLMDB(m, str(p1), id_lambda=str)
         assert not (p1 / kvlog.FILE_NAME).exists()
     p2 = tmp_path / "both"
