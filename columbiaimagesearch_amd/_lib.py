@@ -34,6 +34,7 @@ _PROTOS = {
     # name: (restype, argtypes)
     "cis_version": (c_int, []),
     "cis_last_error": (c_char_p, []),
+    "cis_alloc_stats": (c_int, [POINTER(c_int64), POINTER(c_int64)]),
     "cis_device_count": (c_int, []),
     "cis_set_device": (c_int, [c_int]),
     "cis_selftest": (c_int, [POINTER(c_int)]),
@@ -98,6 +99,7 @@ _PROTOS = {
     "cis_cnn_forward_dev": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "cis_index_set_profiling": (c_int, [c_void_p, c_int]),
     "cis_index_set_scan_mode": (c_int, [c_void_p, c_int]),
+    "cis_index_stream_counters": (c_int, [c_void_p, c_void_p]),
     "cis_index_read_profile": (c_int, [c_void_p, c_void_p, POINTER(c_int64)]),
 }
 
@@ -197,3 +199,10 @@ def as_float_matrix(x, cols=None):
     if cols is not None and a.shape[1] != cols:
         raise ValueError("expected vectors of dimension %d, got %d" % (cols, a.shape[1]))
     return np.ascontiguousarray(a)
+
+
+def alloc_stats():
+    """(workspace allocations, bytes) since the process started -- include/cis_hip.h:cis_alloc_stats."""
+    n, b = c_int64(0), c_int64(0)
+    check(lib().cis_alloc_stats(ctypes.byref(n), ctypes.byref(b)))
+    return int(n.value), int(b.value)

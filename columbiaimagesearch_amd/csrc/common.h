@@ -40,6 +40,9 @@ int cis_current_device();
     } while (0)
 
 // ---- grow-only device buffer -------------------------------------------------------------------
+// Every growth is a hipFree (which waits for the device) + hipMalloc: tens of milliseconds when it happens inside a timed loop.
+// The counters let a harness prove that its timed region allocated nothing (cis_alloc_stats; bench.py reports them per leg).
+extern long long g_cis_allocs, g_cis_alloc_bytes;
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -56,6 +59,8 @@ struct DevBuf {
             return CIS_ENOMEM;
         }
         cap = want;
+        __atomic_add_fetch(&g_cis_allocs, 1, __ATOMIC_RELAXED);
+        __atomic_add_fetch(&g_cis_alloc_bytes, (long long)want, __ATOMIC_RELAXED);
         // Test hook: CIS_POISON_ALLOC=1 fills every new workspace with 0xff bytes (NaN / -1): nothing may rely on what fresh memory
         // holds (the runtime hands back blocks this process freed earlier, with their contents -- see k_nchw3_to_nhwc).
         static const bool poison = getenv("CIS_POISON_ALLOC") != nullptr && atoi(getenv("CIS_POISON_ALLOC")) != 0;

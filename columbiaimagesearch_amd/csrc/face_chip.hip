@@ -8,8 +8,9 @@
 //                    more than twice the chip, so that the bilinear sampling below never degenerates to point sampling;
 //   k_extract_chips  one thread per chip pixel: the affine map chip (c, r) -> source (three corner correspondences, as
 //                    find_affine_transform of extract_image_chips gives it), dlib's interpolate_bilinear on the four neighbours in
-//                    float64 ((1-tb)((1-lr) tl + lr tr) + tb((1-lr) bl + lr br)), rounded to uint8 like assign_pixel (+ 0.5,
-//                    truncated), pixels whose neighbourhood leaves the image black; written as float32 0..255, the input format of
+//                    float64 ((1-tb)((1-lr) tl + lr tr) + tb((1-lr) bl + lr br)), stored as uint8 like assign_pixel(unsigned
+//                    char&, double) does: clamped to 0..255 and TRUNCATED (static_cast, no + 0.5 -- round 5; rounds 3-4 rounded to
+//                    nearest, a bias of up to one grey level against dlib on half of the pixels), pixels whose neighbourhood leaves the image black; written as float32 0..255, the input format of
 //                    cis_cnn_forward for CIS_CNN_DLIB_RESNET.
 // dlib is a third-party dependency of the reference with an unpinned version (cufacesearch/cufacesearch/requirements.txt:3) and is not
 // installed here: this restates its published image_transforms/interpolation.h / image_pyramid.h; parity is unpinned.
@@ -67,7 +68,7 @@ __global__ void k_extract_chips(const uint8_t* __restrict__ img, int nr, int nc,
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const double v = (1.0 - tb) * ((1.0 - lr) * (double)tl[ch] + lr * (double)tr[ch]) + tb * ((1.0 - lr) * (double)bl[ch] + lr * (double)br[ch]);
-        o[ch] = (float)(unsigned char)(v + 0.5);
+        o[ch] = (float)(unsigned char)(v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v));  // pixel.h: assign(unsigned char&, double) clamps, then static_cast
     }
 }
 

@@ -48,6 +48,8 @@ struct cis_index {
     // tables and slot kernels of one batch fill the tail of the other's scan and its merge).  A view is read-only and must not outlive
     // its base; inserts into the base must be ordered against the views' searches by the caller (events), like searches on the base.
     cis_index* base = nullptr;
+    std::vector<cis_index*> views;  // base index: its live views (cis_index_destroy of the base orphans them instead of leaving them dangling)
+    bool orphaned = false;          // view: its base was destroyed first -- every search through it fails with CIS_EINVAL
     const cis_index* st() const { return base ? base : this; }
     // views the search pipeline reads (current generation of `own`)
     const uint8_t* codes_ptr() const { const cis_index* s = st(); return s->own.codes[s->own.cur].as<uint8_t>(); }
@@ -82,8 +84,11 @@ struct cis_index {
     double retry_fraction = 0.5;
     int m16_holdoff = 0;            // batches the sampled scan at M = 16 stays off after a batch where its scale missed (search_batch)
     int64_t m16_backoffs = 0;
-    int last_scan_kernel = 0;       // 0 none (all-candidates path), 1 float64 scan, 2 float32 prefilter, 3 16-bit fixed-point prefilter, 4 its sampled single-pass form (k_adc_scan4)
+    int last_scan_kernel = 0;       // 0 none (all-candidates path), 1 float64 scan, 2 float32 prefilter, 3 16-bit fixed-point prefilter, 4 its sampled single-pass form (k_adc_scan4), 5 the HBM-streaming scan (k_adc_stream)
     bool force_prefilter_scan = false;  // tests: the float32-prefilter kernel also for small batches
+    bool force_stream = false;      // scan mode 6 (tests): the HBM-streaming route (lopq_stream.hip) whatever the batch looks like
+    bool stream_off = false;        // internal: the batch is being answered again through the generic path after a failed proof
+    int64_t stream_batches = 0, stream_fallbacks = 0;  // batches the streaming route served / that it handed back to the generic path
     int profiling = 0;  // 0 off, 1 events around the scan kernel only, 2 events around every stage
     int64_t* h_totals = nullptr;    // pinned, device-mapped: the plan totals land here without a copy
     int64_t* d_h_totals = nullptr;

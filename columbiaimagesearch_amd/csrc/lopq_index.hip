@@ -586,8 +586,9 @@ extern "C" int cis_index_create_view(cis_index** out, cis_index* base) {
     ix->M = base->M;
     ix->base = base;
     ix->force_exact_scan = base->force_exact_scan; ix->force_scan2 = base->force_scan2; ix->force_scan3 = base->force_scan3;
-    ix->force_two_pass = base->force_two_pass; ix->force_prefilter_scan = base->force_prefilter_scan;
+    ix->force_two_pass = base->force_two_pass; ix->force_prefilter_scan = base->force_prefilter_scan; ix->force_stream = base->force_stream;
     ix->sync_from_base();
+    base->views.push_back(ix);
     *out = ix;
     return CIS_OK;
 }
@@ -595,6 +596,15 @@ extern "C" int cis_index_create_view(cis_index** out, cis_index* base) {
 extern "C" void cis_index_destroy(cis_index* ix) {
     if (!ix) return;
     if (ix->m) (void)hipSetDevice(ix->m->device);
+    if (ix->base) {  // a view leaves its base's list
+        std::vector<cis_index*>& v = ix->base->views;
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i] == ix) { v.erase(v.begin() + i); break; }
+    }
+    // a base destroyed before its views: the views keep their own workspaces but lose the storage -- they are marked and every
+    // later search through them is refused (no dangling pointer is ever followed)
+    for (cis_index* v : ix->views) { v->base = nullptr; v->orphaned = true; }
+    ix->views.clear();
     DevBuf* bufs[] = {&ix->d_gcount, &ix->d_plan_hint, &ix->d_owner, &ix->w_xp, &ix->w_cd, &ix->w_order,
                       &ix->w_sorted, &ix->w_plan, &ix->w_off, &ix->w_items, &ix->w_tabs, &ix->w_T, &ix->w_hits,
                       &ix->w_hitn, &ix->w_slack, &ix->w_planfb, &ix->w_vis, &ix->w_tiles, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,

@@ -37,6 +37,13 @@ void cis_set_error(const char* fmt, ...) {
 extern "C" const char* cis_last_error(void) { return g_err.c_str(); }
 extern "C" int cis_version(void) { return 100; }
 
+long long g_cis_allocs = 0, g_cis_alloc_bytes = 0;  // DevBuf::reserve (common.h)
+extern "C" int cis_alloc_stats(int64_t* n_allocs, int64_t* n_bytes) {
+    if (n_allocs) *n_allocs = (int64_t)__atomic_load_n(&g_cis_allocs, __ATOMIC_RELAXED);
+    if (n_bytes) *n_bytes = (int64_t)__atomic_load_n(&g_cis_alloc_bytes, __ATOMIC_RELAXED);
+    return CIS_OK;
+}
+
 extern "C" int cis_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

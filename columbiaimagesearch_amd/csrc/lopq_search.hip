@@ -3012,9 +3012,10 @@ extern "C" int cis_multisequence(const void* X, int x_dtype, const void* C0, con
 }
 
 extern "C" int cis_index_set_scan_mode(cis_index* ix, int mode) {
-    CIS_REQUIRE(ix != nullptr && mode >= 0 && mode <= 5, "bad scan mode");
+    CIS_REQUIRE(ix != nullptr && mode >= 0 && mode <= 6, "bad scan mode");
+    ix->force_stream = (mode == 6);
     ix->force_exact_scan = (mode == 1);
-    ix->force_prefilter_scan = (mode >= 2);
+    ix->force_prefilter_scan = (mode >= 2 && mode <= 5);
     ix->force_scan2 = (mode == 2);
     ix->force_scan3 = (mode == 3 || mode == 4 || mode == 5);
     ix->force_two_pass = mode == 3 ? 0 : (mode == 4 ? 1 : (mode == 5 ? 2 : -1));
@@ -3049,6 +3050,13 @@ extern "C" int cis_index_read_profile(cis_index* ix, double ms[5], int64_t* laun
 }
 
 extern "C" int cis_index_last_scan_kernel(cis_index* ix) { return ix ? ix->last_scan_kernel : 0; }
+
+extern "C" int cis_index_stream_counters(cis_index* ix, int64_t counters[2]) {
+    CIS_REQUIRE(ix != nullptr && counters != nullptr, "NULL argument");
+    counters[0] = ix->stream_batches;
+    counters[1] = ix->stream_fallbacks;
+    return CIS_OK;
+}
 
 extern "C" int cis_index_last_stats(cis_index* ix, int64_t stats[4]) {
     CIS_REQUIRE(ix != nullptr && stats != nullptr, "NULL argument");
@@ -3697,7 +3705,12 @@ __global__ __launch_bounds__(NT) void k_select_topl(const uint64_t* __restrict__
                                                               int64_t stride, uint64_t* __restrict__ sel_keys,
                                                               uint64_t* __restrict__ sel_vals, int* __restrict__ nsel,
                                                               int64_t* __restrict__ seg_b, int64_t* __restrict__ seg_e,
-                                                              const int* __restrict__ only = nullptr /* ranked: flagged queries only */) {
+                                                              const int* __restrict__ only = nullptr /* ranked: flagged queries only */,
+                                                              // INDIRECT (the streaming route, SORT_LDS only): the keys of query q are kcnt[q] (<= kstride) entries at
+                                                              // q * kstride in arbitrary order, entry i is the candidate of retrieval index rid[q * kstride + i]
+                                                              // (relative to seg[q]) -- ties are broken by THAT index, as the stable sort of search.py:210 does
+                                                              const uint32_t* __restrict__ rid = nullptr, const int* __restrict__ kcnt = nullptr,
+                                                              int64_t kstride = 0) {
     if (only && !only[blockIdx.x]) return;
     extern __shared__ __align__(16) unsigned char sel_lds[];
     // LDS: [okey P2][oidx P2] (SORT_LDS) | union { hist 2048 u32 ; ckey 1024 u64 + cidx 1024 u32 } | SelShared
@@ -3709,10 +3722,13 @@ __global__ __launch_bounds__(NT) void k_select_topl(const uint64_t* __restrict__
     uint32_t* cidx = reinterpret_cast<uint32_t*>(ckey + SEL_CAND);
     SelShared* sh = reinterpret_cast<SelShared*>(un + SEL_CAND * 12);
     const int q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const int64_t a = seg[q];
-    const int64_t n64 = seg[q + 1] - a;
+    const int64_t fa = seg[q];                           // retrieval index of the query's first candidate
+    const int64_t a = rid ? (int64_t)q * kstride : fa;   // where the query's keys start
+    const int64_t n64 = rid ? (int64_t)(kcnt[q] < kstride ? kcnt[q] : (int)kstride) : seg[q + 1] - a;
     const unsigned int n = (unsigned int)n64;  // a query's candidates fit 32 bits (the batch total does)
     const uint64_t* __restrict__ k = keys + a;
+    const uint32_t* __restrict__ ridq = rid ? rid + a : nullptr;
+    auto idx_of = [&](unsigned int i) -> uint32_t { return ridq ? ridq[i] : i; };  // the tie-breaking index of key i
     const int nv = n64 < (int64_t)L ? (int)n64 : L;
     uint64_t cut_key = ~0ull;
     unsigned int cut_idx = 0xffffffffu;
@@ -3767,11 +3783,11 @@ __global__ __launch_bounds__(NT) void k_select_topl(const uint64_t* __restrict__
                 if (hv == prefix) {
                     const int j = atomicAdd(&sh->cn, 1);
                     ckey[j] = v;
-                    cidx[j] = i;
+                    cidx[j] = idx_of(i);
                 } else if (SORT_LDS && hv < prefix) {  // below the threshold bin: in, whatever the order (ranked in LDS below)
                     const int j = atomicAdd(&sh->on, 1);
                     okey[j] = v;
-                    oidx[j] = i;
+                    oidx[j] = idx_of(i);
                 }
             }
             __syncthreads();
@@ -3787,6 +3803,11 @@ __global__ __launch_bounds__(NT) void k_select_topl(const uint64_t* __restrict__
                 gathered = true;
             }
             __syncthreads();
+        } else if (rid) {
+            // INDIRECT: a crowd of more than SEL_CAND exact ties at the cut is not resolved here -- the query reports no result and
+            // the streaming route's verification sends it to the generic path
+            if (tid == 0) nsel[q] = 0;
+            return;
         } else {
             // a crowd of exact ties at the cut (every bit fixed): the first r of them in retrieval order
             cut_key = prefix;
@@ -3819,7 +3840,7 @@ __global__ __launch_bounds__(NT) void k_select_topl(const uint64_t* __restrict__
 #pragma unroll
         for (int j = 0; j < SEL_PER; ++j) {
             v[j] = (i + j < n) ? k[i + j] : 0ull;
-            f[j] = (i + j < n) && (v[j] < cut_key || (v[j] == cut_key && i + j <= cut_idx));
+            f[j] = (i + j < n) && (v[j] < cut_key || (v[j] == cut_key && (ridq ? ridq[i + j] : i + j) <= cut_idx));
             local += f[j];
         }
         int tot;
@@ -3829,7 +3850,7 @@ __global__ __launch_bounds__(NT) void k_select_topl(const uint64_t* __restrict__
             if (f[j]) {
                 if (SORT_LDS) {
                     okey[o] = v[j];
-                    oidx[o] = i + j;
+                    oidx[o] = idx_of(i + j);
                 } else {
                     sel_keys[ob + o] = v[j];
                     sel_vals[ob + o] = sel_val_of(a + i + j, cand_start, it_lo, it_hi);
@@ -3846,7 +3867,7 @@ __global__ __launch_bounds__(NT) void k_select_topl(const uint64_t* __restrict__
         sel_block_bitonic(okey, oidx, n2);
         for (int j = tid; j < nv; j += nt) {
             sel_keys[ob + j] = okey[j];
-            sel_vals[ob + j] = sel_val_of(a + oidx[j], cand_start, it_lo, it_hi);
+            sel_vals[ob + j] = sel_val_of(fa + oidx[j], cand_start, it_lo, it_hi);
         }
     }
     if (tid == 0) {
@@ -4570,11 +4591,33 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     // of 20480 candidates, each with its own slots, so that they spread over the chip -- emulated rank 0 of world 8: scan 0.169 -> 0.126
     // ms, partial search 0.343 -> 0.307 ms (10240: 0.445 ms; on one GPU whole cells win: profiles/r03zb_chunk_keys.txt)
     if (use3 && ix->world >= 4 && nq >= 64) seg_max = 20480;
+    // The HBM-streaming route (lopq_stream.hip): few queries, very many candidates each -- an exhaustive quota, or any quota on cells
+    // of hundreds of thousands of codes.  Decided here from the bound of the candidates per query (the chunk size is part of the
+    // plan); the exact count confirms it below.  Chunks of 65536 candidates, longer when the largest cell would need more than the
+    // slot builder's 16 chunk keys (the items of a slot must be the SAME chunk of a cell).
+    static const int64_t stream_min = getenv("CIS_STREAM_MIN") ? atoll(getenv("CIS_STREAM_MIN")) : 262144;  // candidates per query from which it pays
+    static const int stream_nq = getenv("CIS_STREAM_NQ") ? atoi(getenv("CIS_STREAM_NQ")) : 16;               // 0: never
+    const bool stream_auto = !ix->stream_off && !ix->force_exact_scan && !ix->force_prefilter_scan && !ix->force_scan2 && !ix->force_scan3 &&
+                             nq <= stream_nq && L <= 440 && ix->world == 1 &&
+                             ((quota < ix->n_total ? (quota < 0 ? 0 : quota) : ix->n_total) + ix->max_cell) >= stream_min;
+    const bool stream_hint = (ix->force_stream || stream_auto) && !ix->stream_off && stream_supported(M, K, L) && (K % 4 == 0) &&
+                             ix->ncells <= 65536 && !index_has_tiny_cells(ix);
+    if (stream_hint) {
+        seg_max = 65536;
+        if (ix->force_stream && getenv("CIS_STREAM_SEG")) seg_max = atoi(getenv("CIS_STREAM_SEG")) > 0 ? atoi(getenv("CIS_STREAM_SEG")) : seg_max;  // tests: short chunks on small fixtures
+        const int64_t need = ceil_div(ix->max_cell > 0 ? ix->max_cell : 1, (int64_t)16);
+        if (need > seg_max) seg_max = (int)ceil_div(need, (int64_t)1024) * 1024;
+    }
     if (const char* e = getenv("CIS_SEG_MAX")) seg_max = atoi(e) > 0 ? atoi(e) : seg_max;  // A/B runs (tools/emulate_shard.py)
     // thousands of coarse clusters (the release configurations' V = 2048 / 4096): the plan is a per-query selection + sort
     // (k_plan_par) instead of one frontier step per visited cell; queries it cannot resolve fall back to the frontier walk
     const bool no_par_plan = getenv("CIS_NO_PAR_PLAN") != nullptr;
-    const bool par_plan = V >= 128 && V <= PLAN_PAR_STAGE && !no_par_plan;
+    // ... and few queries that visit MANY cells of a small vocabulary (the streaming route's exhaustive quota: all 256 cells of V = 16):
+    // the frontier walk costs ~1.3 us per visited cell and runs twice (count, emit) -- 0.67 of the 1.25 ms of a single exhaustive
+    // query over 200 M codes; the sort-based plan does the same cells in one band
+    const bool stream_par = stream_hint && V >= 8 && ix->n_total > 0 &&
+                            (double)(quota < 0 ? 0 : quota) * (double)ix->nonempty_cells >= 32.0 * (double)ix->n_total;
+    const bool par_plan = ((V >= 128 || stream_par) && V <= PLAN_PAR_STAGE) && !no_par_plan;
     unsigned long long* plan_hint = (par_plan && !getenv("CIS_NO_PLAN_HINT")) ? ix->plan_hint_ptr() : nullptr;
     const int hint_slot = (int)((ix->plan_seq + 1) & 1);  // this batch's launches add into this parity and read the other
     int* plan_fb = nullptr;
@@ -4665,10 +4708,11 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         fprintf(stderr, "[cis] k_plan_par: %d of %d queries fall back to the frontier walk (quota %lld)\n", nfb, nq, (long long)quota);
     }
     if (!ix->h_totals) {
-        CIS_CHECK_HIP(hipHostMalloc((void**)&ix->h_totals, 6 * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
+        CIS_CHECK_HIP(hipHostMalloc((void**)&ix->h_totals, 12 * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
         CIS_CHECK_HIP(hipHostGetDevicePointer((void**)&ix->d_h_totals, ix->h_totals, 0));
         ix->h_totals[3] = 0;
         ix->h_totals[4] = 0;  // (slots, fall-back slots) of the last sampled scan at M = 16: see m16_holdoff
+        for (int i = 6; i < 12; ++i) ix->h_totals[i] = 0;  // [6] failed proofs, [7] overflowed lists, [8] sequence word of the streaming route
     }
     const int64_t seq = ++ix->plan_seq;
     const int n_groups = 2 * V * GRP_SUB;
@@ -4689,7 +4733,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         const int64_t per_q = (q_eff < ix->n_total ? q_eff : ix->n_total) + ix->max_cell;
         const int64_t items_q = ix->nonempty_cells + per_q / seg_max + 2;
         const bool split_ok = (m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) && K <= 256;
-        if (!no_bounds && nq <= 64 && L <= MAX_LDS_LIMIT && split_ok && use_all_path(ix, M, K, L, nq) && items_q <= 4096 &&
+        if (!no_bounds && !stream_hint && nq <= 64 && L <= MAX_LDS_LIMIT && split_ok && use_all_path(ix, M, K, L, nq) && items_q <= 4096 &&
             (double)nq * (double)per_q < 64.0e6) {
             d_tot = totals;
             n_items = (int64_t)nq * items_q;
@@ -4720,6 +4764,9 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     // tiny cells on the all-candidates path: entries computed per candidate from px (k_adc_direct), no tables
     const bool direct_elig = !d_tot && use_all_path(ix, M, K, L, nq) && index_has_tiny_cells(ix) && h <= 256 && direct_jp(M, K, m->w) > 0 &&
                              !getenv("CIS_TABLES_UNGROUPED") && !getenv("CIS_NO_DIRECT");
+    const bool stream = stream_hint && !d_tot && n_items > 0 && ((m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) || (scan2_supported(M, K, L) && !ix->force_exact_scan)) &&
+                        (ix->force_stream || n_cand_all / (nq > 0 ? nq : 1) >= stream_min);
+    if (!stream)
     {
         // workspace budget: per-item hit lists and the float64 tables.  A batch that would need more (e.g. an
         // exhaustive quota: every query visits every cell) is split by the caller and planned again.
@@ -4754,7 +4801,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     const Scan2Geom geom = scan2_geom(M, K, L, nq);
     const Scan3Geom geom3 = scan3_geom(M, K, L, n_items > 0 ? n_cand_all / n_items : 0, ix->force_two_pass);
     const int S = fast ? (use3 ? geom3.S : geom.S) : L;  // hit slots per work item (fast kernels: a full region per wave)
-    if (!big) CIS_TRY(ix->w_hits.reserve((size_t)(n_items + 1) * S * (fast ? sizeof(uint64_t) : sizeof(cis_hit))));
+    if (!big && !stream) CIS_TRY(ix->w_hits.reserve((size_t)(n_items + 1) * S * (fast ? sizeof(uint64_t) : sizeof(cis_hit))));
     CIS_TRY(ix->w_hitn.reserve((size_t)(n_items + 1) * 2 * sizeof(int)));
     if (use3) CIS_TRY(ix->w_slack.reserve((size_t)(n_items + 1) * 2 * sizeof(float)));
     WorkItem* items = ix->w_items.as<WorkItem>();
@@ -4808,6 +4855,122 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     } else if (fast && n_tabs > 0) {
         const int64_t ne = n_tabs * nf * K;
         hipLaunchKernelGGL(k_tables_f32, dim3((unsigned)ceil_div(ne, 256)), dim3(256), 0, st, T, ne, nf, K, T32, tabs);
+    }
+    if (stream) {
+        // 4''. the HBM-streaming route (lopq_stream.hip): sample -> threshold -> stream -> exact keys of the listed candidates ->
+        // ranking (k_select_topl, ties by retrieval index) -> proof; a failed proof hands the batch to the generic path below
+        CIS_TRY(mark(2));
+        const uint8_t* codes = ix->codes_ptr();
+        const int64_t* ids = ix->ids_ptr();
+        const int G = nq >= 2 ? 2 : 1;
+        const int cap = STREAM_CAP, B = STREAM_B;
+        const SelectPlan sp = select_plan(L, nq, (int64_t)nq * cap);
+        CIS_REQUIRE(sp.sort_lds, "streaming route: limit above the LDS-ranked range");
+        // slots: the work items of one chunk of one cell, G per slot (the slot builder of the scan kernels)
+        int64_t CH = ceil_div(ix->max_cell > 0 ? ix->max_cell : 1, (int64_t)seg_max);
+        CH = CH < 1 ? 1 : (CH > 16 ? 16 : CH);
+        const int64_t nkeys = 2 * ix->ncells * CH;
+        const int64_t max_slots = (n_items + nkeys) / G + nkeys + 2;
+        CIS_TRY(ix->w_order2.reserve((size_t)(64 + 2 * nkeys + 2 * max_slots * G) * sizeof(int)));
+        int* qctr = ix->w_order2.as<int>();
+        int* n_slots = qctr + 8;
+        int* qstart = qctr + 16;
+        int* cell_cnt = qctr + 64;
+        int* slot_off = cell_cnt + nkeys;
+        int* slots = slot_off + nkeys;
+        {
+            const int64_t ninit = max_slots * G > nkeys ? max_slots * G : nkeys;
+            hipLaunchKernelGGL(k_slots_init, dim3((unsigned)ceil_div(ninit < 16 ? 16 : ninit, 256)), dim3(256), 0, st, qctr, cell_cnt, (int)nkeys, slots, max_slots * G);
+            hipLaunchKernelGGL(k_item_hist, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, cell_cnt, (int)ix->ncells, (int)CH, seg_max);
+            hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(256), 0, st, cell_cnt, slot_off, (int)nkeys, G, n_slots, qstart, (int)CH);
+            hipLaunchKernelGGL(k_item_scatter, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, slot_off, cell_cnt, G, slots, (int)ix->ncells, (int)CH, seg_max);
+        }
+        // workspace: candidate layout, lists, keys, ranked pairs
+        const size_t n_i64 = (size_t)(n_items + 1) + (size_t)3 * (nq + 2);
+        const size_t bytes = n_i64 * 8 + (size_t)(nq + 2) * 4 * 4 + (size_t)nq * B * 4 + (size_t)nq * cap * 4 + (size_t)nq * cap * 8 + (size_t)2 * nq * sp.stride * 8 + 1024;
+        CIS_TRY(ix->w_hits.reserve(bytes));
+        int64_t* cand_start = ix->w_hits.as<int64_t>();
+        int64_t* seg = cand_start + (n_items + 1);
+        unsigned long long* qmin = reinterpret_cast<unsigned long long*>(seg + (nq + 2));
+        unsigned long long* qmax = qmin + (nq + 2);
+        uint64_t* skeys = reinterpret_cast<uint64_t*>(qmax + (nq + 2));   // [nq][cap]
+        uint64_t* sel_keys = skeys + (size_t)nq * cap;                     // [nq][stride]
+        uint64_t* sel_vals = sel_keys + (size_t)nq * sp.stride;
+        uint32_t* surv = reinterpret_cast<uint32_t*>(sel_vals + (size_t)nq * sp.stride);  // [nq][cap]
+        uint32_t* bmin = surv + (size_t)nq * cap;                          // [nq][B]
+        int* cnt = reinterpret_cast<int*>(bmin + (size_t)nq * B);          // [nq + 2]
+        int* nsel = cnt + (nq + 2);
+        float* tau = reinterpret_cast<float*>(nsel + (nq + 2));
+        int* status = reinterpret_cast<int*>(tau + (nq + 2));
+        if (n_items > 16384) {
+            const int64_t ntiles = ceil_div(n_items, CAND_TILE);
+            CIS_TRY(ix->w_tiles.reserve((size_t)(ntiles + 1) * sizeof(int64_t)));
+            int64_t* tile_sums = ix->w_tiles.as<int64_t>();
+            hipLaunchKernelGGL(k_cand_tile_sum, dim3((unsigned)ntiles), dim3(256), 0, st, items, n_items, tile_sums);
+            hipLaunchKernelGGL(k_cand_tile_scan, dim3(1), dim3(1024), 0, st, tile_sums, ntiles);
+            hipLaunchKernelGGL(k_cand_tile_apply, dim3((unsigned)ntiles), dim3(256), 0, st, items, n_items, tile_sums, cand_start);
+            hipLaunchKernelGGL(k_seg_begin, dim3((unsigned)ceil_div(nq + 1, 256)), dim3(256), 0, st, cand_start, item_off, nq, n_items, n_cand_all, seg, qmin, qmax);
+        } else
+            hipLaunchKernelGGL(k_cand_layout, dim3(1), dim3(1024), 0, st, items, n_items, item_off, nq, n_cand_all, cand_start, seg, qmin, qmax, (const int64_t*)nullptr);
+        launch_stream_init(st, bmin, (int64_t)nq * B, cnt, nq, status);
+        // sample: every SS-th row; the k-th smallest of the bucket minima lets about k * SS candidates of a query through -- aim at
+        // ~max(4096, 16 limit) of them, with k >= 8 so that the count is stable (relative spread 1 / sqrt(k))
+        const int64_t per_q = n_cand_all / nq;
+        const int row = 64 * (16 / M);
+        int64_t target = 4096 > 16 * L ? 4096 : 16 * L;
+        if (const char* e = getenv("CIS_STREAM_TARGET")) target = atoll(e) > 0 ? atoll(e) : target;
+        int64_t ss = per_q / row / 4096;            // ~4096 sampled rows per query
+        ss = ss < 8 ? 8 : (ss > 4096 ? 4096 : ss);
+        int64_t kth = target / ss;
+        kth = kth < 8 ? 8 : (kth > B / 4 ? B / 4 : kth);
+        if (ix->force_stream && getenv("CIS_STREAM_SS")) { ss = atoll(getenv("CIS_STREAM_SS")); kth = getenv("CIS_STREAM_K") ? atoll(getenv("CIS_STREAM_K")) : kth; }  // tests
+        const int grid = stream_grid(M, G, K, max_slots);
+        launch_stream_scan(M, G, true, grid, st, items, slots, n_slots, T32, codes, K, cand_start, seg, tau, bmin, B, (int)ss, surv, cnt, cap);
+        launch_stream_tau(st, bmin, B, (int)kth, nq, tau);
+        CIS_TRY(mark(5));
+        pr.has_scan = true;
+        ix->last_scan_kernel = 5;
+        launch_stream_scan(M, G, false, grid, st, items, slots, n_slots, T32, codes, K, cand_start, seg, tau, bmin, B, (int)ss, surv, cnt, cap);
+        CIS_TRY(mark(3));
+        launch_stream_keys(M, st, items, cand_start, seg, item_off, n_items, T, codes, K, surv, cnt, cap, nq, skeys, qmin, qmax);
+        hipLaunchKernelGGL((k_select_topl<true, 1024>), dim3((unsigned)nq), dim3(1024), sp.lds, st, skeys, seg, cand_start, item_off, qmin, qmax, n_items, L, sp.p2,
+                           sp.stride, sel_keys, sel_vals, nsel, (int64_t*)nullptr, (int64_t*)nullptr, (const int*)nullptr, surv, cnt, (int64_t)cap);
+        const int64_t sseq = ++ix->stream_batches;
+        launch_stream_verify(st, sel_keys, nsel, sp.stride, cnt, cap, seg, tau, nq, L, M, status, ix->d_h_totals + 6, sseq);
+        hipLaunchKernelGGL(k_emit_sorted, dim3(1, (unsigned)nq), dim3(256), 0, st, sel_keys, sel_vals, seg, nsel, sp.stride, items, ids, nq, L, out.hits, out.ids,
+                           out.dists, out.n_found, out.cells, out.pos);
+        if (out.visited)
+            hipLaunchKernelGGL(k_copy_visited, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, plan, nq, out.visited);
+        CIS_CHECK_HIP(hipGetLastError());
+        CIS_TRY(mark(4));
+        ix->stats[3] += 1;
+        if (ix->profiling) ix->prof.push_back(pr);
+        // the proof: two words behind a sequence number in pinned memory (this route serves scans of hundreds of microseconds and
+        // more: waiting for their end costs the caller nothing it would not wait for anyway)
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            bool got = false;
+            while (!got) {
+                if (__atomic_load_n(&ix->h_totals[8], __ATOMIC_ACQUIRE) == sseq) { got = true; break; }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+            }
+            if (!got) {
+                CIS_CHECK_HIP(hipStreamSynchronize(st));
+                CIS_REQUIRE(__atomic_load_n(&ix->h_totals[8], __ATOMIC_ACQUIRE) == sseq, "the streaming route's status did not arrive");
+            }
+        }
+        if (ix->h_totals[6] == 0 && ix->h_totals[7] == 0) return CIS_OK;
+        // a failed proof (an unlucky sample) or an overflowed list (a crowd of equal codes): the generic path answers the batch
+        ++ix->stream_fallbacks;
+        if (getenv("CIS_STREAM_DEBUG"))
+            fprintf(stderr, "[cis] streaming route: %lld failed proofs, %lld overflowed lists of %d queries -> generic path\n", (long long)ix->h_totals[6], (long long)ix->h_totals[7], nq);
+        ix->stream_off = true;
+        const int saved_stats3 = (int)ix->stats[3];
+        for (int i = 0; i < 3; ++i) ix->stats[i] = 0;  // (the generic pass counts the batch again)
+        (void)saved_stats3;
+        const int rc = search_batch(ix, dQ, q_dtype, nq, quota, L, out, st);
+        ix->stream_off = false;
+        return rc;
     }
     if (big) {
         // 4'. every candidate's exact distance; then per query either a radix select of the `limit` best (ranked in LDS
@@ -5070,6 +5233,7 @@ static int search_all(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_
     CIS_REQUIRE(ix != nullptr, "index is NULL");
     CIS_REQUIRE(q_dtype == CIS_F32 || q_dtype == CIS_F64, "q_dtype must be 4 or 8");
     CIS_REQUIRE(nq >= 0, "nq must be >= 0");
+    CIS_REQUIRE(!ix->orphaned, "this view's base index was destroyed: close views before their base");
     CIS_TRY(cis_index_ready(ix->base ? ix->base : ix));
     ix->sync_from_base();  // a view reads the storage of its base
     CIS_CHECK_HIP(hipSetDevice(ix->m->device));

@@ -237,3 +237,19 @@ void launch_scan3(int M, const Scan3Geom& g, int64_t n_items, hipStream_t st, co
                   const int* slots, const int* n_slots, const double* T, const float* T32, const uint8_t* codes, int K, int L,
                   int* qctr, uint64_t* hits, int* hitn, float* slack, unsigned long long* qbound,
                   int* fhdr /* [32] zeroed: fall-back slot header of the sampled form */, int* fslots /* [n_slots * G] */);
+
+// ---- the HBM-streaming scan (lopq_stream.hip): few queries, very many candidates each --------------------------------------
+static const int STREAM_B = 16384;    // buckets of sample minima per query
+static const int STREAM_CAP = 16384;  // listed candidates per query at most
+bool stream_supported(int M, int K, int L);
+int stream_grid(int M, int G, int K, int64_t max_slots);
+void launch_stream_init(hipStream_t st, uint32_t* bmin, int64_t n_b, int* cnt, int nq, int* status);
+void launch_stream_scan(int M, int G, bool sample, int grid, hipStream_t st, const WorkItem* items, const int* slots, const int* n_slots,
+                        const float* T32, const uint8_t* codes, int K, const int64_t* cand_start, const int64_t* seg, const float* tau,
+                        uint32_t* bmin, int B, int sample_stride, uint32_t* surv, int* cnt, int cap);
+void launch_stream_tau(hipStream_t st, const uint32_t* bmin, int B, int k, int nq, float* tau);
+void launch_stream_keys(int M, hipStream_t st, const WorkItem* items, const int64_t* cand_start, const int64_t* seg, const int64_t* item_off,
+                        int64_t n_items, const double* T, const uint8_t* codes, int K, const uint32_t* surv, const int* cnt, int cap, int nq,
+                        uint64_t* keys, unsigned long long* qmin, unsigned long long* qmax);
+void launch_stream_verify(hipStream_t st, const uint64_t* sel_keys, const int* nsel, int64_t stride, const int* cnt, int cap, const int64_t* seg,
+                          const float* tau, int nq, int L, int M, int* status, int64_t* status_host_dev, int64_t seq);

@@ -164,9 +164,59 @@ class ShardedSearcher(object):
         self._owner = None if owner is None else np.ascontiguousarray(owner, dtype=np.int32)
         self._side = None
 
+    # -- inserts against searches in flight -----------------------------------------------------------------------------------
+    # search_begin runs partial searches on this object's own lane streams over VIEWS of the local index (lanes()); an insert
+    # rewrites the arrays those kernels read (in place: lend / gcount / ids / codes; a rebuild swaps the generations).  The caller
+    # cannot see the lane streams, so every insert entry point orders itself against them: the insert starts after the searches
+    # that were begun before it, and searches begun after it start after the insert.
+    def _lane_streams(self):
+        return [s for _, s in (getattr(self, "_lanes", None) or []) if s is not None]
+
+    def _insert_fence(self, host=False):
+        """Before an insert.  host=True: the host-pointer entry points run on the library's own stream -- wait on the host."""
+        import torch
+        streams = self._lane_streams()
+        if not streams:
+            return
+        if host:
+            torch.cuda.current_stream().synchronize()
+            for s in streams:
+                s.synchronize()
+        else:
+            cur = torch.cuda.current_stream()
+            for s in streams:
+                cur.wait_stream(s)
+
+    def _insert_release(self):
+        """After an insert: later searches on the lane streams wait for it."""
+        import torch
+        cur = torch.cuda.current_stream()
+        for s in self._lane_streams():
+            s.wait_stream(cur)
+
     def add_codes_array(self, coarse, fine, ids=None, dedup=True):
         """Every rank is given ALL codes (it keeps its own cells and counts the rest)."""
+        self._insert_fence(host=True)
         return self.local.add_codes_array(coarse, fine, ids, dedup)
+
+    def add_codes_dev(self, coarse, fine, ids, dedup=True):
+        """add_codes_array on tensors in HBM (every rank is given ALL codes), ordered against the searches in flight."""
+        self._insert_fence()
+        try:
+            return self.local.add_codes_dev(coarse, fine, ids, dedup=dedup)
+        finally:
+            self._insert_release()
+
+    def close(self):
+        """The views of the lanes first (they share the local index's storage), then the local index."""
+        import torch
+        for sv, s in (getattr(self, "_lanes", None) or [])[1:]:
+            if s is not None:
+                s.synchronize()
+            sv.close()
+        self._lanes = None
+        if self.local is not None:
+            self.local.close()
 
     def add_codes_routed(self, coarse, fine, ids, dedup=True):
         """Every rank brings ITS slice of a batch (e.g. what it encoded itself); the codes travel once, to the owner of
@@ -179,6 +229,7 @@ class ShardedSearcher(object):
         L = _lib.lib()
         V = self.local.model.V
         owner = self._owner if self._owner is not None else np.arange(V * V) % self.world
+        self._insert_fence(host=True)
         c, f, i = route_codes(coarse, fine, ids, owner, V, self.group, M=self.local._M)
         before = np.zeros(V * V, dtype=np.int64)
         _lib.check(L.cis_index_cell_counts(self.local._ix, _lib.ptr(before)))
@@ -210,6 +261,7 @@ class ShardedSearcher(object):
             raise ValueError("coarse [n,2], fine [n,%d] and ids [n] expected" % M)
         dev = coarse.device
         stream = torch.cuda.current_stream(dev).cuda_stream
+        self._insert_fence()  # the partial searches begun before this call read the arrays the insert rewrites
         rec_b = 12 + M
         send = torch.empty(max(n, 1) * rec_b, dtype=torch.uint8, device=dev)
         sc = torch.empty(self.world, dtype=torch.int64, device=dev)
@@ -247,6 +299,7 @@ class ShardedSearcher(object):
         else:
             dist.all_reduce(delta, group=self.group)
         _lib.check(L.cis_index_add_remote_counts_dev(ix, delta.data_ptr(), stream))
+        self._insert_release()
         self.local.nb_indexed = int(L.cis_index_size(ix))
         if bad.value:
             print("Could not push {} codes (out of range for this model, or negative ids).".format(bad.value))

@@ -163,7 +163,7 @@ def extract_chips_numpy(level_img, map6, size=CHIP_SIZE):
     lr, tb = (x - left)[..., None], (y - top)[..., None]
     im = level_img.astype(np.float64)
     v = (1 - tb) * ((1 - lr) * im[t2, l2] + lr * im[t2, l2 + 1]) + tb * ((1 - lr) * im[t2 + 1, l2] + lr * im[t2 + 1, l2 + 1])
-    out = np.floor(v + 0.5).clip(0, 255)
+    out = np.floor(v.clip(0, 255))  # assign_pixel(unsigned char&, double): clamp, then static_cast (truncation, no + 0.5)
     out[~ok] = 0
     return out.astype(np.float32)
 

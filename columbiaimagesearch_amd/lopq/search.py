@@ -186,9 +186,23 @@ class LOPQSearcherHIP(LOPQSearcherBase):
         _lib.check(_lib.lib().cis_index_create_view(_lib.ctypes.byref(out), self._ix))
         v._ix = out.value
         v.nb_indexed = self.nb_indexed
+        if getattr(self, "_views", None) is None:
+            import weakref
+            self._views = weakref.WeakSet()
+        self._views.add(v)
         return v
 
+    def get_nb_indexed(self):
+        base = getattr(self, "_base", None)  # a view reads through to its base (inserts go through the base)
+        if base is not None:
+            self.nb_indexed = base.get_nb_indexed()
+        return self.nb_indexed
+
     def close(self):
+        """Destroys the device index.  Views created from this searcher are closed first (they share its storage; the library
+        also refuses searches through a view whose base is gone: include/cis_hip.h:cis_index_create_view)."""
+        for v in list(getattr(self, "_views", None) or ()):
+            v.close()
         if self._ix:
             _lib.lib().cis_index_destroy(self._ix)
             self._ix = None
@@ -433,13 +447,19 @@ class LOPQSearcherHIP(LOPQSearcherBase):
         _lib.check(_lib.lib().cis_index_insert_counters(self._ix, _lib.ptr(c)))
         return int(c[0]), int(c[1])
 
+    def stream_counters(self):
+        """(batches served by the HBM-streaming route, batches it handed back to the generic path) -- include/cis_hip.h."""
+        c = np.zeros(2, dtype=np.int64)
+        _lib.check(_lib.lib().cis_index_stream_counters(self._ix, _lib.ptr(c)))
+        return int(c[0]), int(c[1])
+
     def last_stats(self):
         """Counters of the last search: candidates scanned, work items, tables, scan launches."""
         st = np.zeros(4, dtype=np.int64)
         _lib.check(_lib.lib().cis_index_last_stats(self._ix, _lib.ptr(st)))
         kind = int(_lib.lib().cis_index_last_scan_kernel(self._ix))
         return {"candidates": int(st[0]), "items": int(st[1]), "tables": int(st[2]), "scan_launches": int(st[3]),
-                "scan_kernel": {0: None, 1: "k_adc_scan", 2: "k_adc_scan2", 3: "k_adc_scan3", 4: "k_adc_scan4"}.get(kind)}
+                "scan_kernel": {0: None, 1: "k_adc_scan", 2: "k_adc_scan2", 3: "k_adc_scan3", 4: "k_adc_scan4", 5: "k_adc_stream"}.get(kind)}
 
 
     default_prefilter_only = False  # tests: new searchers keep the float32-prefilter kernel for every batch size
@@ -655,24 +675,24 @@ class LOPQSearcherLMDB(LOPQSearcherBase):
         if getattr(self, "_read_only", None):
             raise ImportError(self._read_only)
         id_iter = count() if ids is None else iter(ids)
-        txn = self.env.begin(db=self.index_db, write=True) if self.env is not None else None
-        logged = [] if self._log is not None else None
-        try:
-            for item_id, code in zip(id_iter, codes):
-                cell = (int(code[0][0]), int(code[0][1]))
-                fine = tuple(int(v) for v in code[1])
-                suffix = self._key_suffix(item_id)
-                self._put(self.encode_cell(cell) + suffix, fine)  # put(): an existing key is overwritten
-                if txn is not None:
-                    txn.put(self.encode_cell(cell) + suffix, self.encode_fine_codes(fine))
-                if logged is not None:
-                    logged.append((self.encode_cell(cell) + suffix, self.encode_fine_codes(fine)))
-        finally:
-            if txn is not None:
-                txn.commit()
-                self.env.sync()
-            if logged:
-                self._log.append(logged)  # one write + fsync per add_codes call (the reference: env.sync(), :468)
+        # One call = one transaction, stored as a whole or not at all (the reference: `with env.begin(write=True)`, :459-467 -- an
+        # exception inside it aborts the transaction).  The keys and values are made first (what can raise: a malformed code, an
+        # id that does not encode), then written (LMDB transaction / one log transaction), and only then applied to the rows in
+        # memory: a call that raises leaves memory and disk as they were.
+        batch = []
+        for item_id, code in zip(id_iter, codes):
+            cell = (int(code[0][0]), int(code[0][1]))
+            fine = tuple(int(v) for v in code[1])
+            batch.append((self.encode_cell(cell) + self._key_suffix(item_id), fine))
+        if self.env is not None:
+            with self.env.begin(db=self.index_db, write=True) as txn:
+                for key, fine in batch:
+                    txn.put(key, self.encode_fine_codes(fine))
+            self.env.sync()
+        elif self._log is not None and batch:
+            self._log.append((key, self.encode_fine_codes(fine)) for key, fine in batch)  # one transaction + fsync (the reference: env.sync(), :468)
+        for key, fine in batch:
+            self._put(key, fine)  # put(): an existing key is overwritten
         # the key-ordered GPU index follows before the next search: the new keys alone when they all sort behind their cells' last
         # keys (production ids arrive in time order inside an update), a rebuild otherwise (_device_index)
         self.get_nb_indexed()

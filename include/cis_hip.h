@@ -63,6 +63,10 @@ typedef struct cis_hit {
 /* ---- library ------------------------------------------------------------------------------ */
 int cis_version(void);
 const char* cis_last_error(void);
+/* Device workspace growth since the process started: every handle's workspaces are grow-only, and a growth is a hipFree (which
+ * waits for the device) + hipMalloc -- tens of milliseconds when it lands inside a measured loop.  A harness reads the counters
+ * before and after its timed region to prove that nothing was allocated in it (bench.py does).  Either pointer may be NULL. */
+int cis_alloc_stats(int64_t* n_allocs, int64_t* n_bytes);
 /* Number of visible HIP devices (0 when none); never fails. */
 int cis_device_count(void);
 /* Select the device used by handles created afterwards by this process (default 0). */
@@ -132,8 +136,10 @@ void cis_index_destroy(cis_index* ix);
 /* A search VIEW of `base`: shares its storage (codes, ids, offsets, cell sizes -- lopq/lopq/search.py:310-382's `index` dict) and
  * owns only per-batch workspaces and counters, so that two query batches can be in flight at once, each handle on its own stream
  * (the reference answers independent queries from 16 independent gunicorn workers over one LMDB index, searcher_lopqhbase.py:198-206:
- * this is the same sharing inside one process).  A view is read-only (inserts / cell reads go to the base), must be destroyed before
- * the base, and inserts into the base must be stream-ordered against the views' searches by the caller. */
+ * this is the same sharing inside one process).  A view is read-only (inserts / cell reads go to the base) and should be destroyed
+ * before the base: a base destroyed first ORPHANS its views -- they stay valid handles, every later search through them returns
+ * CIS_EINVAL, and they must still be destroyed.  Inserts into the base must be stream-ordered against the views' searches by the
+ * caller (columbiaimagesearch_amd/distributed.py:ShardedSearcher._insert_fence does it for its own lanes). */
 int cis_index_create_view(cis_index** out, cis_index* base);
 
 /* Cell-sharded operation (one process per GPU): this handle stores only the cells with
@@ -278,9 +284,17 @@ int cis_index_set_profiling(cis_index* ix, int level /* 0 off, 1 only the pair o
  * exact float64 scan kernel otherwise), 1 = exact float64 scan kernel wherever it applies (limit <= 3072),
  * 2 = the float32-prefilter kernel for every batch size, 3 / 4 = the 16-bit fixed-point kernel for every batch size in its
  * streaming / two-pass (histogram threshold, then collection) form, 5 = the same kernel family's sampled single-pass form
- * (threshold from a sample of the chunk, verified after the pass; what large batches over short cells take by default).
+ * (threshold from a sample of the chunk, verified after the pass; what large batches over short cells take by default),
+ * 6 = the HBM-streaming route (csrc/lopq_stream.hip: what batches of <= 16 queries with >= 262144 candidates each take by
+ * default -- an exhaustive quota = N run (lopq/lopq/search.py:128-133 consumes whole cells until the quota), or any quota over
+ * cells of hundreds of thousands of codes: a sampled threshold per query, one pass over the codes at the HBM rate that lists the
+ * few thousand candidates under it, exact float64 keys and ranking of the list, and a proof that the list holds the true top
+ * `limit`; a query whose proof fails is answered again by the generic path).
  * All routes produce identical results; the switch exists so that tests can prove it. */
 int cis_index_set_scan_mode(cis_index* ix, int mode);
+/* counters[0] = batches the HBM-streaming route served, counters[1] = batches it handed back to the generic path (failed proof or
+ * overflowed candidate list). */
+int cis_index_stream_counters(cis_index* ix, int64_t counters[2]);
 int cis_index_read_profile(cis_index* ix, double ms[5], int64_t* launches);
 
 /* ---- CNN descriptors: replaces the caffe forward behind SentiBankPyCaffeImgFeaturizer.featurize -----

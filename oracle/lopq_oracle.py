@@ -467,6 +467,52 @@ class OracleCSRIndex(object):
         return (np.array([it[0] for _, it in scored], dtype=np.int64), np.array([d for d, _ in scored]), visited)
 
 
+def search_exhaustive_blocked(model, coarse, fine, x, limit, ids=None, block=4_000_000):
+    """OracleCSRIndex(model, coarse, fine, ids).search(x, quota=len(coarse), limit) WITHOUT grouping the rows by cell -- for indexes
+    of hundreds of millions of rows, where the stable sort of the CSR build alone takes minutes.  With an exhaustive quota every
+    cell is visited (lopq/lopq/search.py:128-133 stops only when the quota is reached), so the candidates are all rows, a row's
+    distance is the left-to-right float64 sum of its M table entries (:166-175; tables memoised per coarse id, :151-164), and the
+    stable sorted() of :210 orders equal distances by retrieval order = (visit rank of the row's cell, insertion position inside the
+    cell) -- insertion position grows with the row number.  Rows are scored block by block, the best `limit` of every block are
+    kept.  Returns (ids, dists, visited) like OracleCSRIndex.search; pinned against it in tests/test_oracle_golden.py."""
+    m = model
+    if m.has_pca:
+        x = apply_pca(m, x)
+    V, nf = m.V, m.num_fine_splits
+    coarse = np.asarray(coarse)
+    n = coarse.shape[0]
+    # visit rank of every cell: an exhaustive quota walks the cells until the last non-empty one (empty ones on the way count as visited)
+    rank = np.zeros(V * V, dtype=np.int64)
+    for r, (_, (c0, c1)) in enumerate(multisequence(m, x)):
+        rank[int(c0) * V + int(c1)] = r
+    tabs0 = [subquantizer_distances(m, x, (c, 0), coarse_split=0) for c in range(V)]  # [c0][j] -> (K,)
+    tabs1 = [subquantizer_distances(m, x, (0, c), coarse_split=1) for c in range(V)]
+    T0 = np.stack([np.stack(t) for t in tabs0])  # [V][nf][K]
+    T1 = np.stack([np.stack(t) for t in tabs1])
+    best_d, best_r, best_i = [], [], []
+    last_rank = -1  # the walk stops with the cell that completes the quota: the last NON-EMPTY cell in visit order
+    for a in range(0, n, block):
+        b = min(n, a + block)
+        c0 = coarse[a:b, 0].astype(np.int64)
+        c1 = coarse[a:b, 1].astype(np.int64)
+        f = np.asarray(fine[a:b])
+        d = np.zeros(b - a, dtype=np.float64)
+        for i in range(2 * nf):  # left-to-right float64 accumulation, search.py:173
+            d = d + (T0[c0, i, f[:, i]] if i < nf else T1[c1, i - nf, f[:, i]])
+        rk = rank[c0 * V + c1]
+        last_rank = max(last_rank, int(rk.max())) if b > a else last_rank
+        k = min(limit, b - a)
+        part = np.argpartition(d, k - 1)[:k] if k < b - a else np.arange(b - a)
+        # everything that ties with the block's k-th distance must stay in play (the tie is decided by retrieval order)
+        cut = d[part].max() if k else 0.0
+        keep = np.nonzero(d <= cut)[0]
+        best_d.append(d[keep]); best_r.append(rk[keep]); best_i.append(keep + a)
+    d = np.concatenate(best_d); rk = np.concatenate(best_r); ii = np.concatenate(best_i)
+    order = np.lexsort((ii, rk, d))[:limit]  # (dist, visit rank, row number)
+    out_ids = ii[order] if ids is None else np.asarray(ids)[ii[order]]
+    return out_ids.astype(np.int64), d[order], last_rank + 1
+
+
 HIT_DTYPE = np.dtype([("dist", "<f8"), ("visit_rank", "<u4"), ("pos", "<u4"), ("id", "<i8"),
                       ("cell", "<i4"), ("reserved", "<i4")])  # == cis_hit (include/cis_hip.h)
 

@@ -95,7 +95,7 @@ def test_chips_on_the_gpu_equal_the_numpy_restatement_and_feed_the_network():
     assert n_levels >= 1 and any(lv >= 0 for lv, _ in maps)
     for i, (lv, m6) in enumerate(maps):
         want = F.extract_chips_numpy(levels[lv], m6)
-        # float64 on both sides; a pixel whose value lands within rounding of x.5 may differ by one grey level
+        # float64 on both sides; a pixel whose value lands within rounding of an integer may differ by one grey level
         diff = np.abs(chips[i] - want)
         assert diff.max() <= 1.0 and (diff > 0).mean() < 1e-3, (i, diff.max(), (diff > 0).mean())
     assert (chips[2] == 0).any() and (chips[0] > 0).any()
@@ -105,7 +105,10 @@ def test_chips_on_the_gpu_equal_the_numpy_restatement_and_feed_the_network():
     S = 150.0 / 1.5
     lm = _synthetic_landmarks(S, 0.0, 300.0 - 0.5 + 0.25 * S, 200.0 - 0.5 + 0.25 * S)
     c0 = F.face_chips(img, [lm]).cpu().numpy()[0]
-    np.testing.assert_array_equal(c0, img[200:350, 300:450].astype(np.float32))
+    # (assign_pixel truncates: where the float64 interpolation of an exactly aligned sample lands a hair under the integer, the chip is
+    # one grey level below the crop -- never above, never more)
+    diff = img[200:350, 300:450].astype(np.float32) - c0
+    assert diff.min() >= 0.0 and diff.max() <= 1.0, (diff.min(), diff.max())
     # ... and the chips feed the network like any aligned chips do
     net = DLibFaceNet(dlib_weights(0))
     a = net.forward_dev(F.face_chips(img, shapes[:2])).cpu().numpy()

@@ -352,27 +352,40 @@ def test_query_groups_times_cell_shards_with_four_ranks_on_one_gpu():
         assert "world 4 grid %s: build and search equal the single index" % shape in text, text[-3000:]
 
 
-@pytest.mark.parametrize("gpus,shards,grid_groups", [(2, 0, 2), (4, 0, 2), (4, 1, 4)])
+@pytest.mark.parametrize("gpus,shards,grid_groups", [(2, 0, 2), (4, 0, 2), (4, 1, 4), (8, 0, 4)])
 def test_bench_multi_rank_protocol_on_one_gpu(gpus, shards, grid_groups):
     """`bench.py --gpus N`: the headline is BASELINE C4's layout (ONE copy of the index sharded by cell over all N ranks, strong
-    scaling); the R x S grid rides along as the `grid` object, whose value counts every group's queries."""
+    scaling); the R x S grid rides along as the `grid` object, whose value counts every group's queries.  N = 8 is the size the
+    driver's scaling run uses: cells only (1 x 8) as the headline, the default 4 x 2 grid beside it.  stdout ends with the `#detail`
+    line (every field) and ONE compact JSON line (what the driver parses)."""
     import json, os, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, CIS_BENCH_BACKEND="gloo", CIS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CIS_BENCH_N="400000",
-               CIS_BENCH_CELL_SHARDS=str(shards))
+               CIS_BENCH_CELL_SHARDS=str(shards), CIS_BENCH_MIN_REPS="2", CIS_BENCH_MIN_TIMED_S="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
            "--master-port", "29589", os.path.join(repo, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--config", "c2",
            "--no-cnn", "--no-cpu-baseline", "--no-pcie"]
-    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, cwd=repo)
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500, cwd=repo)
     text = out.stdout.decode()
     assert out.returncode == 0, text[-3000:]
     lines = [l for l in text.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, text[-3000:]
-    line = json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0]) <= 4096, text[-3000:]
+    compact = json.loads(lines[0])
+    details = [l for l in text.splitlines() if l.startswith("#detail ")]
+    assert len(details) == 1
+    line = json.loads(details[0][len("#detail "):])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in compact, k
+        if k not in ("config", "roofline", "cpu_baseline"):
+            assert compact[k] == line[k] or abs(compact[k] - line[k]) <= 1e-4 * abs(line[k]), k
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(compact["roofline"])
+    assert compact["grid"]["parallelism"] == "grid %dx%d" % (grid_groups, gpus // grid_groups)
     assert line["n_gpus"] == gpus and line["scaling"] == "strong" and line["recall_at_10"] >= 0.9
     assert line["config"]["query_groups"] == 1 and line["config"]["cell_shards"] == gpus
     assert abs(line["value"] - line["config"]["queries_per_step"] * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
     assert line["config"]["index_vectors"] == 400000
+    assert line["timing"]["repetitions"] >= 2 and line["timing"]["steps_per_repetition"] == 3
     g = line["grid"]
     assert "error" not in g, g
     assert g["config"]["query_groups"] == grid_groups and g["config"]["cell_shards"] == gpus // grid_groups and g["recall_at_10"] >= 0.9

@@ -190,3 +190,24 @@ def test_tiny_edge_semantics():
     first = int(z["ids"][0])
     tied = [i for i, d in zip(ids.tolist(), dd.tolist()) if d == dd[0]]
     assert tied[0] == first and tied[1:21] == dup.tolist()
+
+
+@pytest.mark.parametrize("name", ["tiny", "c2", "c4"])
+def test_exhaustive_blocked_search_equals_the_csr_index(name):
+    """oracle.search_exhaustive_blocked (what checks the HBM-streaming route at 200 M rows, where the CSR build's sort is too slow)
+    == OracleCSRIndex.search(quota = N) -- itself pinned to the reference's ranked ids above -- incl. a block of exact duplicates that
+    straddles the block boundary (ties by retrieval order) and rows in a cell order that differs from the row order."""
+    z, X, Q = load_golden(name)
+    om = _model(z)
+    coarse, fine = z["coarse"].copy(), z["fine"].copy()
+    n = coarse.shape[0]
+    oc, of = O.compute_codes(om, Q[:1])
+    coarse[n // 2 - 40:n // 2 + 40] = oc[0]   # 80 copies of the first query's own code around the middle of the rows
+    fine[n // 2 - 40:n // 2 + 40] = of[0]
+    oi = O.OracleCSRIndex(om, coarse, fine)
+    for qi in range(3):
+        for limit in (10, 100):
+            ids, dists, visited = oi.search(Q[qi], quota=n, limit=limit)
+            for block in (n // 2, 997, n):  # the first splits the duplicates over two blocks
+                bi, bd, bv = O.search_exhaustive_blocked(om, coarse, fine, Q[qi], limit, block=block)
+                assert (bi == ids).all() and np.array_equal(bd, dists) and bv == visited

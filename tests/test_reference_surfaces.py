@@ -349,7 +349,8 @@ def test_lmdb_order_index_survives_a_restart(tmp_path):
     import zlib
     rec = lambda k, v: struct.pack("<II", len(k), len(v)) + k + v
     payload = rec(s2.encode_cell((0, 0)) + b"torn_a", b"\x01" * m.M) + rec(s2.encode_cell((0, 0)) + b"torn_b", b"\x02" * m.M)
-    group = struct.pack("<III", 2, len(payload), zlib.crc32(payload) & 0xFFFFFFFF) + payload
+    head = kvlog.HEADER.pack(kvlog.GROUP_TAG, 2, len(payload), zlib.crc32(payload) & 0xFFFFFFFF, 0)
+    group = head + struct.pack("<I", zlib.crc32(head) & 0xFFFFFFFF) + payload
     with open(os.path.join(path, kvlog.FILE_NAME), "ab") as f:
         f.write(group[:-5])  # the first record of the call is complete on disk, the second is not
     s3 = LOPQSearcherLMDB(m, path, id_lambda=str)
@@ -369,10 +370,81 @@ def test_lmdb_order_index_survives_a_restart(tmp_path):
     s4.add_codes(codes[:3], ["later_%d" % i for i in range(3)])
     s4.close()
     raw = bytearray(open(os.path.join(path, kvlog.FILE_NAME), "rb").read())
-    raw[len(kvlog.MAGIC) + 40] ^= 0xFF
+    raw[len(kvlog.MAGIC) + kvlog.HEADER_BYTES + 12] ^= 0xFF   # a payload byte of the first group
     open(os.path.join(path, kvlog.FILE_NAME), "wb").write(bytes(raw))
     with pytest.raises(ValueError, match="damaged"):
         LOPQSearcherLMDB(m, path, id_lambda=str)
+    raw[len(kvlog.MAGIC) + kvlog.HEADER_BYTES + 12] ^= 0xFF
+    raw[len(kvlog.MAGIC) + 9] ^= 0xFF                            # a size byte of the first group's HEADER: caught by the header's own checksum
+    open(os.path.join(path, kvlog.FILE_NAME), "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="header at byte"):
+        LOPQSearcherLMDB(m, path, id_lambda=str)
+
+
+def test_kvlog_transactions_are_bounded_groups_and_all_or_nothing(tmp_path):
+    """lopq/kvlog.py: sizes are 64-bit and a transaction is written as BOUNDED groups (here 200 bytes, so a 40-record
+    call spans several): a crash after some groups of a call drops the whole call; a zero-filled tail (file extended, data never
+    written) is a torn tail, not valid empty groups; compaction streams; a CISKV2 log is migrated; an add_codes call that raises
+    half way leaves memory and disk as they were (the reference's `with env.begin(write=True)`, lopq/lopq/search.py:459-467)."""
+    import struct
+    import zlib
+    from columbiaimagesearch_amd.lopq import kvlog
+    d = str(tmp_path / "log")
+    log = kvlog.KVLog(d, group_bytes=200)
+    a = [(b"\x00\x00\x01\x00key_%03d" % i, bytes([i % 251] * 8)) for i in range(40)]
+    b = [(b"\x00\x00\x02\x00key_%03d" % i, bytes([(i + 7) % 251] * 8)) for i in range(40)]
+    log.append(iter(a))
+    size_a = os.path.getsize(log.path)
+    log.append(iter(b))
+    raw = open(log.path, "rb").read()
+    n_groups = raw.count(kvlog.GROUP_TAG)
+    assert n_groups >= 8 and log.records == 80
+    assert kvlog.KVLog(d, group_bytes=200).load() == a + b
+    # cut inside the LAST group of transaction b: every group of b goes, a stays
+    open(log.path, "wb").write(raw[:-5])
+    l2 = kvlog.KVLog(d, group_bytes=200)
+    assert l2.load() == a and l2.dropped_torn_bytes == len(raw) - 5 - size_a and os.path.getsize(log.path) == size_a
+    # cut exactly after a complete group in the middle of b (the transaction's closing group never arrived)
+    second = raw.index(kvlog.GROUP_TAG, size_a + 4)
+    open(log.path, "wb").write(raw[:second])
+    l3 = kvlog.KVLog(d, group_bytes=200)
+    assert l3.load() == a and os.path.getsize(log.path) == size_a
+    # a zero-filled tail is a torn tail
+    open(log.path, "wb").write(raw[:size_a] + b"\x00" * 5000)
+    l4 = kvlog.KVLog(d, group_bytes=200)
+    assert l4.load() == a and l4.dropped_torn_bytes == 5000 and os.path.getsize(log.path) == size_a
+    # compaction: bounded groups again, same content, last write wins is the caller's job
+    l4.compact(iter(a[:10] + b[:10]))
+    assert kvlog.KVLog(d, group_bytes=200).load() == a[:10] + b[:10]
+    # an append whose items cannot be written leaves nothing behind
+    size0 = os.path.getsize(log.path)
+    with pytest.raises(TypeError):
+        l4.append(iter(a[:30] + [(b"k", None)]))
+    assert os.path.getsize(log.path) == size0 and kvlog.KVLog(d, group_bytes=200).load() == a[:10] + b[:10]
+    # the previous format (32-bit groups) is read and rewritten
+    d2 = str(tmp_path / "old")
+    os.makedirs(d2)
+    rec = lambda k, v: struct.pack("<II", len(k), len(v)) + k + v
+    payload = b"".join(rec(k, v) for k, v in a[:5])
+    open(os.path.join(d2, kvlog.FILE_NAME), "wb").write(kvlog.MAGIC_V2 + struct.pack("<III", 5, len(payload), zlib.crc32(payload) & 0xFFFFFFFF) + payload)
+    l5 = kvlog.KVLog(d2)
+    assert l5.load() == a[:5] and open(l5.path, "rb").read().startswith(kvlog.MAGIC)
+    # LOPQSearcherLMDB.add_codes: a malformed code in the middle of a call -> nothing of the call is applied or stored
+    from columbiaimagesearch_amd.lopq import LOPQSearcherLMDB
+    m, z, Q = _lmdb_fixture()
+    path = str(tmp_path / "lmdb_index")
+    s = LOPQSearcherLMDB(m, path, id_lambda=str)
+    good = [((1, 2), tuple(range(m.M))), ((3, 4), tuple(range(m.M)))]
+    s.add_codes(good, ["x", "y"])
+    size1 = os.path.getsize(os.path.join(path, kvlog.FILE_NAME))
+    with pytest.raises((TypeError, ValueError)):
+        s.add_codes(good + [((5, "not a cluster"), tuple(range(m.M)))], ["p", "q", "r"])
+    assert s.get_nb_indexed() == 2 and os.path.getsize(os.path.join(path, kvlog.FILE_NAME)) == size1
+    assert s.get_cell((1, 2))[0][0] == "x" and s.get_cell((5, 0)) == []
+    s.close()
+    s2 = LOPQSearcherLMDB(m, path, id_lambda=str)
+    assert s2.get_nb_indexed() == 2
+    s2.close()
 
 
 def test_lmdb_file_walker_round_trip(tmp_path):

@@ -1,0 +1,140 @@
+"""The HBM-streaming route (csrc/lopq_stream.hip, scan mode 6) on its own mechanics: chunk boundaries, pairs of queries per slot,
+the sample's parameters, the proof that fails on purpose (-> generic path), crowds of equal codes, and the automatic routing of
+an exhaustive query.  Results are compared bit for bit with the exact float64 kernel (scan mode 1) and with the oracle
+(lopq/lopq/search.py:128-133, :137-177, :210-216 restated in oracle/lopq_oracle.py)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _searchers(name, n=None):
+    from test_lopq_hip_parity import hip_model
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    z, X, Q = load_golden(name)
+    m = hip_model(z)
+    coarse, fine = z["coarse"], z["fine"]
+    if n is not None:
+        coarse, fine = coarse[:n], fine[:n]
+    a, b = LOPQSearcherHIP(m), LOPQSearcherHIP(m)
+    a.add_codes_array(coarse, fine)
+    b.add_codes_array(coarse, fine)
+    a.set_scan_mode(mode=6)
+    b.set_scan_mode(mode=1)
+    return z, Q, a, b
+
+
+def _same(r, w):
+    assert (r["n_found"] == w["n_found"]).all() and (r["visited"] == w["visited"]).all()
+    assert (r["ids"] == w["ids"]).all()
+    assert np.array_equal(r["dists"].view(np.uint64), w["dists"].view(np.uint64))
+
+
+@pytest.mark.parametrize("name", ["c2", "c4", "c3", "tiny"])
+@pytest.mark.parametrize("seg", [512, 1024, 65536])
+def test_stream_route_equals_exact_kernel(name, seg, monkeypatch):
+    monkeypatch.setenv("CIS_STREAM_SEG", str(seg))
+    z, Q, s, e = _searchers(name)
+    n = int(z["coarse"].shape[0])
+    M, K = int(z["fine"].shape[1]), int(z["subs"].shape[-2])
+    w = int(z["subs"].shape[-1])
+    shape_ok = M in (4, 8, 16) and K <= 256 and K % 4 == 0   # other shapes stay on the generic routes (scan mode 6 is a request)
+    for nq in (1, 2, 3, 7):
+        for quota, limit in ((n, 100), (n, 10), (3000, 100), (n, 440), (50, 20), (n, 1000)):
+            before = s.stream_counters()
+            r = s.search_batch(Q[:nq], quota=quota, limit=limit)
+            after = s.stream_counters()
+            if shape_ok and (w in (4, 8, 16, 32) or limit <= 952):  # (the float32 tables exist on these paths only)
+                assert after[0] == before[0] + 1, "the streaming route did not serve the batch"
+                assert s.last_stats()["scan_kernel"] == "k_adc_stream"
+            _same(r, e.search_batch(Q[:nq], quota=quota, limit=limit))
+
+
+def test_stream_route_against_the_oracle():
+    from oracle import lopq_oracle as O
+    z, Q, s, _ = _searchers("c2")
+    om = O.OracleModel.from_npz(z)
+    oi = O.OracleCSRIndex(om, z["coarse"], z["fine"])
+    n = int(z["coarse"].shape[0])
+    r = s.search_batch(Q[:5], quota=n, limit=100)
+    for qi in range(5):
+        ids, dists, visited = oi.search(Q[qi], quota=n, limit=100)
+        k = int(r["n_found"][qi])
+        assert k == len(ids) and visited == int(r["visited"][qi])
+        assert (r["ids"][qi, :k] == ids).all()
+        assert np.allclose(r["dists"][qi, :k], dists, rtol=1e-9, atol=1e-12)
+
+
+def test_failed_proof_hands_the_batch_to_the_generic_path(monkeypatch):
+    """A threshold that is far too tight (the smallest bucket minimum of a sparse sample): fewer than `limit` candidates are listed,
+    the proof fails, the batch is answered by the generic path -- same bits, and the counter says so."""
+    monkeypatch.setenv("CIS_STREAM_SEG", "1024")
+    monkeypatch.setenv("CIS_STREAM_SS", "64")
+    monkeypatch.setenv("CIS_STREAM_K", "1")
+    z, Q, s, e = _searchers("c2")
+    n = int(z["coarse"].shape[0])
+    before = s.stream_counters()
+    r = s.search_batch(Q[:4], quota=n, limit=100)
+    after = s.stream_counters()
+    assert after[1] == before[1] + 1, "the proof should have failed"
+    _same(r, e.search_batch(Q[:4], quota=n, limit=100))
+    # a generous threshold (every bucket): everything is listed until the lists overflow -> generic path as well
+    monkeypatch.setenv("CIS_STREAM_SS", "1")
+    monkeypatch.setenv("CIS_STREAM_K", "4000")
+    r = s.search_batch(Q[:4], quota=n, limit=100)
+    _same(r, e.search_batch(Q[:4], quota=n, limit=100))
+
+
+def test_crowd_of_equal_codes(monkeypatch):
+    """Thousands of identical codes next to the query: more exact ties at the cut than the ranking holds -> the generic path; fewer:
+    ranked by retrieval order (insertion order, search.py:210: stable sort) on the streaming route itself."""
+    from test_lopq_hip_parity import hip_model
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    monkeypatch.setenv("CIS_STREAM_SEG", "1024")
+    z, X, Q = load_golden("c2")
+    m = hip_model(z)
+    coarse, fine = z["coarse"][:20000].copy(), z["fine"][:20000].copy()
+    qc, qf = m.predict_batch(Q[:1])
+    for dup in (300, 5000):
+        c2, f2 = coarse.copy(), fine.copy()
+        c2[1000:1000 + dup] = qc[0]
+        f2[1000:1000 + dup] = qf[0]
+        a, b = LOPQSearcherHIP(m), LOPQSearcherHIP(m)
+        a.add_codes_array(c2, f2)
+        b.add_codes_array(c2, f2)
+        a.set_scan_mode(mode=6)
+        b.set_scan_mode(mode=1)
+        for limit in (100, 440):
+            r = a.search_batch(Q[:2], quota=20000, limit=limit)
+            w = b.search_batch(Q[:2], quota=20000, limit=limit)
+            _same(r, w)
+            assert (r["ids"][0, :min(limit, dup)] == np.arange(1000, 1000 + min(limit, dup))).all()  # insertion order among the ties
+        a.close()
+        b.close()
+
+
+def test_exhaustive_query_takes_the_streaming_route_by_itself():
+    """Automatic routing: one query, quota = N over 400 k codes (>= 262144 candidates per query) -> k_adc_stream, and the result is the
+    exact kernel's; the same query at quota 1000 stays on the small-batch path."""
+    from test_lopq_hip_parity import hip_model
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    z, X, Q = load_golden("c4")
+    m = hip_model(z)
+    rs = np.random.RandomState(5)
+    n = 400000
+    V, M = m.V, m.M
+    coarse = rs.randint(0, V, size=(n, 2)).astype(np.uint16)
+    fine = rs.randint(0, 256, size=(n, M)).astype(np.uint8)
+    a, b = LOPQSearcherHIP(m), LOPQSearcherHIP(m)
+    a.add_codes_array(coarse, fine)
+    b.add_codes_array(coarse, fine)
+    b.set_scan_mode(mode=1)
+    for nq in (1, 2, 5):
+        r = a.search_batch(Q[:nq], quota=n, limit=100)
+        assert a.last_stats()["scan_kernel"] == "k_adc_stream"
+        _same(r, b.search_batch(Q[:nq], quota=n, limit=100))
+    served = a.stream_counters()[0]
+    a.search_batch(Q[:1], quota=1000, limit=100)
+    assert a.stream_counters()[0] == served and a.last_stats()["scan_kernel"] != "k_adc_stream"
