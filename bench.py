@@ -579,7 +579,8 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
                   "insert": "device-side merge of %d codes into the HBM index (cis_index_add_dev%s)"
                             % (len(my_chunks) * chunk_n, " after the RCCL all-to-all" if ctx.use_dist else "")},
     }
-    if getattr(st, "exchange_flags", None):
+    st.exchange_flags = [f for f in (getattr(st, "exchange_flags", None) or []) if f is not None]
+    if st.exchange_flags:
         n_over = int(torch.stack([f.reshape(()) for f in st.exchange_flags]).sum().item())
         result["config"]["exchange"] = ("packed all-gather of a fixed %.1f x even share per rank, offsets on the device, no host read per batch; "
                                         "%d of %d steps exceeded the fixed size (those are repeated with the exact size outside a timed loop)"

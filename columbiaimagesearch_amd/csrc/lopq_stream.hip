@@ -227,7 +227,10 @@ __global__ __launch_bounds__(1024) void k_stream_tau(const uint32_t* __restrict_
         if (tid == 0) tau[q] = __uint_as_float(0x7f800000u);
         return;
     }
-    while (lo < hi) {  // uniform over the workgroup
+    // (hi always has >= k buckets at or below it.  Sixteen halvings of [min, max] of the bucket minima -- floats of one or two
+    // binades -- leave an interval of ~1e-5 of the value: tau = hi then admits a few more candidates than the exact k-th smallest
+    // would, which only lengthens the list; the proof does not care where tau came from)
+    for (int step = 0; step < 16 && lo < hi; ++step) {  // uniform over the workgroup
         const uint32_t p = lo + ((hi - lo) >> 1);
         int c = 0;
 #pragma unroll
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(1024) void k_stream_tau(const uint32_t* __restrict_
         if (tot >= k) hi = p; else lo = p + 1;
         ++it;
     }
-    if (tid == 0) tau[q] = __uint_as_float(lo);
+    if (tid == 0) tau[q] = __uint_as_float(hi);
 }
 
 // exact float64 key of every listed candidate + the key range of the query (for k_select_topl)
