@@ -775,6 +775,79 @@ __global__ void k_global_avgpool(const float* __restrict__ in, float* __restrict
     out[i] = s / (float)HW;
 }
 
+// The tail of the dlib net in one launch (round 5).  The last residual block works on 4 x 4 x 256 maps: its first convolution
+// (3 x 3 / 2, no padding) leaves ONE pixel per chip, so its second convolution (3 x 3, padding 1, on a 1 x 1 map) only ever meets its
+// centre tap -- a 256 x 256 product per chip that ran as a K = 2304 implicit GEMM with eight zero taps -- the skip branch is the 2 x 2
+// average pool of the block's input, add_prev pads the 1 x 1 branch to 2 x 2, then come ReLU, the global average and fc_no_bias<128>.
+// Six launches (convolution + split-K reduction, pool, add, global pool, fc: 51 us of a 1.99 ms forward for 0.1 % of its arithmetic)
+// become one: a workgroup takes IMG chips, thread = output channel, the chips' 256-vectors sit in LDS.
+//   t1  [n][256]        first convolution's output (bias + ReLU applied)
+//   x   [n][4][4][256]  the block's input (skip branch)
+//   wb  [9 * 256][256]  second convolution, packed [k][oc], k = (ky * 3 + kx) * 256 + ic: rows 4 * 256 .. 5 * 256 are the centre tap
+//   wfc [256][128]
+template <int IMG>
+__global__ __launch_bounds__(256) void k_dlib_tail(const float* __restrict__ t1, const float* __restrict__ x, const float* __restrict__ wb,
+                                                   const float* __restrict__ bb, const float* __restrict__ wfc, float* __restrict__ feats, int n) {
+    __shared__ float s_in[IMG][256];
+    __shared__ float s_g[IMG][256];
+    const int oc = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * IMG;
+#pragma unroll
+    for (int i = 0; i < IMG; ++i) s_in[i][oc] = i0 + i < n ? t1[(i0 + i) * 256 + oc] : 0.f;
+    __syncthreads();
+    float acc[IMG];
+#pragma unroll
+    for (int i = 0; i < IMG; ++i) acc[i] = bb[oc];
+    const float* w = wb + (size_t)4 * 256 * 256 + oc;
+    for (int c0 = 0; c0 < 256; c0 += 32) {  // 32 weights of the thread's column in flight (8 left every round trip exposed: 20 us per launch)
+        float wv[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) wv[c] = w[(size_t)(c0 + c) * 256];
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+#pragma unroll
+            for (int i = 0; i < IMG; ++i) acc[i] = fmaf(s_in[i][c0 + c], wv[c], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < IMG; ++i) {
+        float g = 0.f;
+        if (i0 + i < n) {
+            const float* p = x + ((i0 + i) * 16) * 256 + oc;
+            float sum = 0.f;
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    const float* q = p + ((2 * py) * 4 + 2 * px) * 256;
+                    const float sk = ((q[0] + q[256]) + (q[4 * 256] + q[5 * 256])) * 0.25f;   // avg_pool<2,2,2,2> (k_avgpool2_nhwc's order)
+                    float v = sk + ((py == 0 && px == 0) ? acc[i] : 0.f);                    // add_prev: the 1 x 1 branch zero-padded to 2 x 2
+                    v = v > 0.f ? v : 0.f;
+                    sum += v;
+                }
+            g = sum / 4.0f;                                                                // avg_pool_everything
+        }
+        s_g[i][oc] = g;
+    }
+    __syncthreads();
+    if (oc < 128) {
+        float o[IMG];
+#pragma unroll
+        for (int i = 0; i < IMG; ++i) o[i] = 0.f;
+        for (int c0 = 0; c0 < 256; c0 += 32) {
+            float wv[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) wv[c] = wfc[(size_t)(c0 + c) * 128 + oc];
+#pragma unroll
+            for (int c = 0; c < 32; ++c)
+#pragma unroll
+                for (int i = 0; i < IMG; ++i) o[i] = fmaf(s_g[i][c0 + c], wv[c], o[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < IMG; ++i)
+            if (i0 + i < n) feats[(i0 + i) * 128 + oc] = o[i];
+    }
+}
+
 // ================================================================================================
 // host
 // ================================================================================================
@@ -967,8 +1040,11 @@ extern "C" int cis_cnn_create(cis_cnn** out, int arch, const float* const* tenso
 }
 
 // out = relu?(bias + part[0] + part[1] + ...) in that order (deterministic), four outputs per thread
+// pool_w > 0: the residual branch is avg_pool<2,2,2,2> of a [N][2 OH'..][pool_w][resC] map taken on the fly (dlib's down blocks: the
+// pooled skip was a launch and a round trip of its own) -- pool_oh / pool_ow = the OUTPUT's spatial size, pool_h / pool_w the input's
 __global__ void k_splitk_reduce(const float* __restrict__ part, int splitk, int64_t part_stride, const float* __restrict__ bias,
-                                float* __restrict__ out, int64_t n4, int OC, int relu, const float* __restrict__ res, int resC) {
+                                float* __restrict__ out, int64_t n4, int OC, int relu, const float* __restrict__ res, int resC,
+                                int pool_h = 0, int pool_w = 0, int pool_oh = 0, int pool_ow = 0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const int oc = (int)((i * 4) % OC);
@@ -977,6 +1053,16 @@ __global__ void k_splitk_reduce(const float* __restrict__ part, int splitk, int6
         const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)s * part_stride + i * 4);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
+    if (res && oc < resC && pool_w > 0) {
+        const int64_t pix = (i * 4) / OC;
+        const int ox = (int)(pix % pool_ow), oy = (int)((pix / pool_ow) % pool_oh);
+        const int64_t nn = pix / ((int64_t)pool_ow * pool_oh);
+        const float* p = res + ((nn * pool_h + 2 * oy) * pool_w + 2 * ox) * resC + oc;
+        const float4 p0 = *reinterpret_cast<const float4*>(p), p1 = *reinterpret_cast<const float4*>(p + resC);
+        const float4 p2 = *reinterpret_cast<const float4*>(p + (int64_t)pool_w * resC), p3 = *reinterpret_cast<const float4*>(p + (int64_t)pool_w * resC + resC);
+        a.x += ((p0.x + p1.x) + (p2.x + p3.x)) * 0.25f; a.y += ((p0.y + p1.y) + (p2.y + p3.y)) * 0.25f;
+        a.z += ((p0.z + p1.z) + (p2.z + p3.z)) * 0.25f; a.w += ((p0.w + p1.w) + (p2.w + p3.w)) * 0.25f;
+    } else
     if (res && oc < resC) {  // residual branch (resC % 4 == 0 channels, zero-padded above)
         const float4 v = *reinterpret_cast<const float4*>(res + ((i * 4) / OC) * resC + oc);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
@@ -1135,6 +1221,16 @@ static int cnn_forward_dlib(cis_cnn* c, CnnWs* ws, const float* d_in, int n, flo
     for (int i = 0; i < 14; ++i) {
         const DlibBlock& b = kDlibBlocks[i];
         const int s = b.down ? 2 : 1, p = b.down ? 0 : 1;
+        if (i == 13 && H == 4 && W == 4 && C == 256 && b.cout == 256 && b.down && !getenv("CIS_CNN_NO_TAIL")) {
+            // the last block's second convolution, skip branch, add_prev, ReLU, global average and the fully connected layer: one launch
+            // (k_dlib_tail; CIS_CNN_NO_TAIL=1 keeps the six launches it replaces)
+            ConvDesc da = nhwc_conv(n, 4, 4, 256, 256, 3, 2, 0, 1);
+            CIS_TRY(conv_fill_chip(ws, da, x, c->dl[27], T1, st));  // [n][1][1][256]
+            hipLaunchKernelGGL(k_dlib_tail<2>, dim3((unsigned)ceil_div(n, 2)), dim3(256), 0, st, (const float*)T1, (const float*)x, (const float*)c->dl[28].d_w,
+                               (const float*)c->dl[28].d_b, (const float*)c->dl[29].d_w, d_feats, n);
+            CIS_CHECK_HIP(hipGetLastError());
+            return CIS_OK;
+        }
         ConvDesc da = nhwc_conv(n, H, W, C, b.cout, 3, s, p, 1);
         CIS_TRY(conv_fill_chip(ws, da, x, c->dl[1 + 2 * i], T1, st));
         ConvDesc db = nhwc_conv(n, da.OH, da.OW, b.cout, b.cout, 3, 1, 1, 0);

@@ -84,8 +84,10 @@ struct cis_index {
     double retry_fraction = 0.5;
     int m16_holdoff = 0;            // batches the sampled scan at M = 16 stays off after a batch where its scale missed (search_batch)
     int64_t m16_backoffs = 0;
-    int last_scan_kernel = 0;       // 0 none (all-candidates path), 1 float64 scan, 2 float32 prefilter, 3 16-bit fixed-point prefilter, 4 its sampled single-pass form (k_adc_scan4), 5 the HBM-streaming scan (k_adc_stream)
+    int last_scan_kernel = 0;       // 0 none (all-candidates path), 1 float64 scan, 2 float32 prefilter, 3 16-bit fixed-point prefilter, 4 its sampled single-pass form (k_adc_scan4), 5 the HBM-streaming scan (k_adc_stream), 6 k_adc_scan5
     bool force_prefilter_scan = false;  // tests: the float32-prefilter kernel also for small batches
+    bool force_scan5 = false;       // scan mode 7 (tests): k_adc_scan5 (one threshold per query, eight queries per slot) whatever the batch size
+    DevBuf w_s5;                    // its per-batch buckets, counters and thresholds
     bool force_stream = false;      // scan mode 6 (tests): the HBM-streaming route (lopq_stream.hip) whatever the batch looks like
     bool stream_off = false;        // internal: the batch is being answered again through the generic path after a failed proof
     int64_t stream_batches = 0, stream_fallbacks = 0;  // batches the streaming route served / that it handed back to the generic path

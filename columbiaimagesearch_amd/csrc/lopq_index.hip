@@ -586,7 +586,7 @@ extern "C" int cis_index_create_view(cis_index** out, cis_index* base) {
     ix->M = base->M;
     ix->base = base;
     ix->force_exact_scan = base->force_exact_scan; ix->force_scan2 = base->force_scan2; ix->force_scan3 = base->force_scan3;
-    ix->force_two_pass = base->force_two_pass; ix->force_prefilter_scan = base->force_prefilter_scan; ix->force_stream = base->force_stream;
+    ix->force_two_pass = base->force_two_pass; ix->force_prefilter_scan = base->force_prefilter_scan; ix->force_stream = base->force_stream; ix->force_scan5 = base->force_scan5;
     ix->sync_from_base();
     base->views.push_back(ix);
     *out = ix;
@@ -610,7 +610,7 @@ extern "C" void cis_index_destroy(cis_index* ix) {
                       &ix->w_hitn, &ix->w_slack, &ix->w_planfb, &ix->w_vis, &ix->w_tiles, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
                       &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px, &ix->w_T32, &ix->w_grp, &ix->w_tord, &ix->w_y64, &ix->w_x64,
                       &ix->wi_key[0], &ix->wi_key[1], &ix->wi_val[0], &ix->wi_val[1], &ix->wi_hist, &ix->wi_sid, &ix->wi_acc,
-                      &ix->wi_apre, &ix->wi_tmp, &ix->wi_in_ids, &ix->wi_in_coarse, &ix->wi_in_fine, &ix->wi_scan, &ix->wi_cnt, &ix->wi_cnt2, &ix->d_stats};
+                      &ix->w_s5, &ix->wi_apre, &ix->wi_tmp, &ix->wi_in_ids, &ix->wi_in_coarse, &ix->wi_in_fine, &ix->wi_scan, &ix->wi_cnt, &ix->wi_cnt2, &ix->d_stats};
     for (DevBuf* b : bufs) b->release();
     ix->own.release();
     ix->ghost.release();

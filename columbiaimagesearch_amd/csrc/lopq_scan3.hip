@@ -2035,6 +2035,493 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     S3_CTR(10, 1);
 }
 
+// ---- k_adc_scan5 (round 5): ONE threshold per query for the whole batch, eight queries per slot ------------------------------
+// k_adc_scan4 spends 46 % of a slot in serial per-query phases (sample, threshold bisection, second gather, verification: one wave per
+// query while the others idle) and issues 2.3 x the instructions of its gather loop.  The streaming route
+// (lopq_stream.hip) showed the alternative: take the threshold out of the slot.
+//   1. k_adc_scan5<SAMPLE>  every slot stages its tables and gathers one row in `ss`; a lane folds the smallest upper bound
+//                           (sum + M) * ub it saw into one of B buckets of its query (atomicMin on float bits);
+//   2. k_scan5_tau          tau[q] = the k-th smallest bucket minimum, k = P x sampled fraction: about P (~2.4 x limit) candidates of
+//                           the query lie under it (count(buckets <= v) <= count(samples <= v): never tighter than the sample's own);
+//   3. k_adc_scan5          the slot's only phases are staging and gathering: thresholds thr_g = floor(tau[q_g] * qinv_g (1 + 2^-22)) + 1
+//                           -- a candidate with d <= tau has sum <= d qinv (1 + 2^-23) < thr (truncated, saturating entries only round
+//                           sums DOWN) -- the loop records the positions where ANY of the eight queries passes (one packed compare,
+//                           one ballot), a second gather of those ~5 % splits them per query, counts, reserves room in the items'
+//                           survivor rows with one atomic per (wave, query) and writes (sum << 32 | position): k_merge_survivors'
+//                           input.  It also counts, per query, the listed candidates whose UPPER bound (sum + M) ub is <= tau;
+//   4. k_scan5_check        the proof: that count >= min(limit, candidates) -- then the limit-th smallest upper bound is <= tau, every
+//                           candidate of the true top `limit` has d <= tau and was listed (ties included) -- and no row or position list
+//                           overflowed.  Slots with a query that fails go to the fall-back list k_adc_scan3 works off (as k_adc_scan4's).
+// Eight queries per slot (ds_read_b128: 8 x 16-bit entries; four packed adds per gather): a code row is fetched, rotated and its
+// bytes extracted once for eight queries instead of four, and a 16-lane read group meets two lanes per sub-quantizer instead of four.
+static const int S5G = 8;
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+template <int M, int OCT>
+__device__ __forceinline__ void adc16x8_issue(const uint32_t (&D)[(M + 3) / 4], int o, const char* __restrict__ tab, const RotConsts<M>& rc,
+                                              u32x4v (&f)[OCT]) {
+    constexpr int SH = ((M == 4) ? 2 : (M == 8 ? 3 : 4)) + 4;  // log2(M * 16 bytes): one k-row of the table
+#pragma unroll
+    for (int i = 0; i < OCT; ++i) {
+        const int t = o * OCT + i;
+        const uint32_t k = __builtin_amdgcn_ubfe(D[t >> 2], rc.sh[t & 3], 8);
+        f[i] = *reinterpret_cast<const u32x4v*>(tab + ((k << SH) | (rc.cj[t] << 2)));
+    }
+}
+
+template <int OCT>
+__device__ __forceinline__ u32x4v adc16x8_sum(const u32x4v (&f)[OCT]) {
+    u32x4v a = f[0];
+#pragma unroll
+    for (int i = 1; i < OCT; ++i) {
+        a[0] = pk_add_u16(a[0], f[i][0]);
+        a[1] = pk_add_u16(a[1], f[i][1]);
+        a[2] = pk_add_u16(a[2], f[i][2]);
+        a[3] = pk_add_u16(a[3], f[i][3]);
+    }
+    return a;
+}
+
+// sums of UU rows of 64 candidates for eight queries (software pipelined like adc16_rows)
+template <int M, int UU, int OCT>
+__device__ __forceinline__ void adc16x8_rows(const CodeWords<M> (&cur)[UU], const char* __restrict__ tab, const RotConsts<M>& rc, u32x4v (&d)[UU]) {
+    constexpr int NU = M / OCT;
+    u32x4v fbuf[2][OCT];
+    uint32_t D[2][(M + 3) / 4];
+    rot_words<M>(cur[0], rc, D[0]);
+    adc16x8_issue<M, OCT>(D[0], 0, tab, rc, fbuf[0]);
+#pragma unroll
+    for (int q = 0; q < UU * NU; ++q) {
+        const int u = q / NU, o = q % NU;
+        if (q + 1 < UU * NU) {
+            const int u1 = (q + 1) / NU, o1 = (q + 1) % NU;
+            if (o1 == 0) rot_words<M>(cur[u1], rc, D[u1 & 1]);
+            adc16x8_issue<M, OCT>(D[u1 & 1], o1, tab, rc, fbuf[(q + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4v part = adc16x8_sum<OCT>(fbuf[q & 1]);
+        if (o == 0) {
+            d[u] = part;
+        } else {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) d[u][x] = pk_add_u16(d[u][x], part[x]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+struct Slot5 {
+    int item[S5G], tab0[S5G], tab1[S5G], q[S5G];
+    float qinv[S5G];
+    uint32_t thr1[S5G], ok1[S5G];  // keep sum < thr1; sum < ok1: the candidate's upper bound is <= tau
+    float ubf[S5G];                // (1 + 2^-21) / qinv, rounded up
+    int start_lo, start_hi, len, ng, same;
+};
+
+static __device__ __forceinline__ uint32_t s5_sum_of(const u32x4v& d, int g) {  // query g's 16-bit sum
+    const uint32_t w = d[g >> 1];
+    return (g & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+static const int S5_PCAP = 1024;  // recorded positions per wave and slot
+
+static size_t scan5_lds(int M, int K) { return (size_t)K * M * S5G * 2 + (size_t)4 * S5_PCAP * 2 + sizeof(Slot5) + 64; }
+
+template <int M, bool SAMPLE, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_adc_scan5(
+    const WorkItem* __restrict__ items, const TabDesc* __restrict__ tabs, const int* __restrict__ slots, const int* __restrict__ n_slots_ptr,
+    const float* __restrict__ T32, const uint8_t* __restrict__ codes, int K, int S,
+    const float* __restrict__ tau, uint32_t* __restrict__ bmin, int B, int* __restrict__ nsamp, int ss,
+    uint64_t* __restrict__ item_surv, int* __restrict__ item_n, float* __restrict__ item_slack, int* __restrict__ cnt_ok, int* __restrict__ ovf) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int G = S5G, NW = 4, nf = M / 2, U = 2, PF = 2, OCT = 4;
+    constexpr uint32_t CAP = 65535u / M;
+    char* tab = smem;                                                                  // [K][M][G] uint16
+    uint16_t* plist_all = reinterpret_cast<uint16_t*>(smem + (size_t)K * M * G * 2);    // [NW][S5_PCAP]
+    Slot5* sd = reinterpret_cast<Slot5*>(reinterpret_cast<char*>(plist_all) + (size_t)NW * S5_PCAP * 2);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = n_slots_ptr[0];
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, LW = gridDim.x >> 3;
+    const RotConsts<M> rc = make_rot<M>(lane);
+    const int nvec = (nf * K) >> 2;  // float4 per half table
+    for (int kk = 0;; ++kk) {
+        // the workgroup's kk-th slot: runs of 32 consecutive slots (a few cells) stay on one XCD, as in k_adc_scan4
+        const int li = lb + kk * LW;
+        const int j = (((li >> 5) * 8 + xcd) << 5) | (li & 31);
+        if ((li >> 5) * 256 >= total + 256) break;   // past every run (uniform)
+        if (j >= total) continue;
+        __syncthreads();  // the previous slot's tables, lists and descriptor are dead
+        if (tid < G) {    // lane g resolves item g of the slot
+            const int g = tid;
+            int idx = slots[j * G + g];
+            const int idx0 = slots[j * G];
+            const bool on = idx >= 0;
+            idx = on ? idx : idx0;
+            const WorkItem it = items[idx];
+            const WorkItem it0 = items[idx0];
+            float mxT = fmaxf(__int_as_float(tabs[it.tab0].pad), __int_as_float(tabs[it.tab1].pad));
+            mxT = fmaxf(mxT, 1e-30f);
+            float qi = ((float)CAP / mxT) * (1.0f - 9.5367431640625e-7f);  // as k_adc_scan4: T32 * qinv stays below cap
+            qi = (mxT < 3.0e38f) ? qi : 0.0f;
+            qi = (qi < 3.0e38f) ? qi : 3.0e38f;
+            sd->item[g] = idx; sd->tab0[g] = it.tab0; sd->tab1[g] = it.tab1; sd->q[g] = on ? it.q : -1;
+            sd->qinv[g] = qi;
+            const double inv_up = (double)qi * (1.0 + 2.384185791015625e-7);
+            const double ub = qi > 0.0f ? (1.0 + 4.76837158203125e-7) / (double)qi : __longlong_as_double(0x7ff0000000000000LL);
+            sd->ubf[g] = __double2float_ru(ub);
+            uint32_t t1 = 0u, o1 = 0u;
+            if (on && !SAMPLE) {
+                const float tq = tau[it.q];
+                if (!(tq < 3.0e38f)) { t1 = 65535u; o1 = 65535u; }   // no threshold: everything is listed (and counts)
+                else {
+                    const double x = (double)tq * inv_up;
+                    t1 = x >= 65533.0 ? 65535u : (uint32_t)x + 2u;    // keep sum <= floor(x) + 1 (bound_to_thr), as sum < t1
+                    const double y = (double)tq / ((double)sd->ubf[g]) - (double)M - 1.0;  // (sum + M) ubf <= tau  <=  sum <= y
+                    o1 = y <= 0.0 ? 0u : (y >= 65533.0 ? 65535u : (uint32_t)y + 1u);      // counted: sum < o1
+                }
+            }
+            sd->thr1[g] = t1; sd->ok1[g] = o1;
+            if (on && !SAMPLE) {
+                item_slack[2 * (int64_t)idx + 0] = __double2float_ru(ub * ((double)M + 0.1));
+                item_slack[2 * (int64_t)idx + 1] = __double2float_ru(ub);
+            }
+            // all items of a slot are the SAME chunk of one cell (the slot key); a slot that mixes chunks (a cell of more than 16
+            // chunks) is not scanned here: its queries are flagged and take the fall-back
+            const bool same = it.start == it0.start && it.len == it0.len;
+            const unsigned long long sm = __ballot(same || !on);
+            if (g == 0) {
+                sd->start_lo = (int)(uint32_t)it0.start; sd->start_hi = (int)(it0.start >> 32); sd->len = it0.len;
+                sd->same = ((sm & 0xffull) == 0xffull) ? 1 : 0;
+            }
+            const unsigned long long om = __ballot(on);
+            if (g == 0) sd->ng = 64 - __builtin_clzll((om & 0xffull) | 0ull) ;
+        }
+        __syncthreads();
+        const int ng = __builtin_amdgcn_readfirstlane(sd->ng);
+        const int len = __builtin_amdgcn_readfirstlane(sd->len);
+        const int64_t start = ((int64_t)__builtin_amdgcn_readfirstlane(sd->start_hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(sd->start_lo);
+        if (!__builtin_amdgcn_readfirstlane(sd->same)) {
+            if (!SAMPLE && tid < ng && sd->q[tid] >= 0) ovf[sd->q[tid]] = 1;
+            continue;
+        }
+        // ---- tables -> 16-bit entries -> LDS: thread -> (sub-quantizer j = vt % nf, four consecutive k), half tables one after the other
+        {
+            float qinv[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) qinv[g] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sd->qinv[g])));
+            int tid_st = tid;
+            asm volatile("" : "+v"(tid_st));
+            for (int vt = tid_st; vt < nvec; vt += 256) {
+                const int jq = vt & (nf - 1), kq = vt / nf, k0 = 4 * kq;
+                const int vidx = jq * (K >> 2) + kq;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float4 pv[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int tb = __builtin_amdgcn_readfirstlane(s2 ? sd->tab1[g] : sd->tab0[g]);
+                        pv[g] = reinterpret_cast<const float4*>(T32 + (int64_t)tb * nf * K)[vidx];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        uint32_t qv[G];
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            const float x = c == 0 ? pv[g].x : (c == 1 ? pv[g].y : (c == 2 ? pv[g].z : pv[g].w));
+                            qv[g] = (g < ng) ? (uint32_t)(x * qinv[g]) : CAP;  // truncation: a lower bound of x * qinv
+                            qv[g] = qv[g] > CAP ? CAP : qv[g];
+                        }
+                        u32x4v pk;
+                        pk[0] = qv[0] | (qv[1] << 16); pk[1] = qv[2] | (qv[3] << 16); pk[2] = qv[4] | (qv[5] << 16); pk[3] = qv[6] | (qv[7] << 16);
+                        *reinterpret_cast<u32x4v*>(tab + ((size_t)((k0 + c) * M + s2 * nf + jq) << 4)) = pk;
+                    }
+                }
+            }
+        }
+        __amdgpu_buffer_rsrc_t rs;
+        {
+            const uint64_t cbase = (uint64_t)(uintptr_t)(codes + start * M);
+            const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cbase);
+            const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cbase >> 32));
+            rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)bhi << 32) | blo), 0, len * M, 0x00020000);
+        }
+        const int nrows = (len + 63) >> 6;
+        if constexpr (SAMPLE) {
+            // every ss-th row (all rows of a chunk shorter than that: at least one row per wave where there is one)
+            lds_barrier();
+            const int step = nrows >= 4 * ss ? ss : 1;
+            u32x4v bm;
+            bm[0] = bm[1] = bm[2] = bm[3] = 0xffffffffu;
+            int nval = 0;
+            for (int r0 = w * step; r0 < nrows; r0 += 4 * step * U) {
+                CodeWords<M> sc[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) sc[u] = load_code_buf<M>(rs, (r0 + u * 4 * step) * 64 + lane);  // past the chunk: zeros, masked below
+                u32x4v dd[U];
+                adc16x8_rows<M, U, OCT>(sc, tab, rc, dd);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool ok = (r0 + u * 4 * step) * 64 + lane < len;
+                    nval += __popcll(__ballot(ok));
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) bm[x] = pk_min_u16(bm[x], ok ? dd[u][x] : 0xffffffffu);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g < ng) {
+                    const int q = __builtin_amdgcn_readfirstlane(sd->q[g]);
+                    const uint32_t sg = s5_sum_of(bm, g);
+                    if (sg != 0xffffu) {
+                        const float ubv = (float)(sg + (uint32_t)M) * sd->ubf[g] * 1.0000002f;  // >= the candidate's exact distance
+                        atomicMin(&bmin[(int64_t)q * B + (((unsigned)j * 131u + (unsigned)tid) & (unsigned)(B - 1))], __float_as_uint(ubv));
+                    }
+                    if (lane == 0 && nval > 0) atomicAdd(&nsamp[q], nval);
+                }
+            }
+            continue;
+        } else {
+        lds_barrier();  // tables and the descriptor's thresholds visible
+        u32x4v tpk;  // the eight thresholds, packed like the sums
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const uint32_t a = sd->thr1[2 * x], b = sd->thr1[2 * x + 1];
+            tpk[x] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((a & 0xffffu) | (b << 16)));
+        }
+        // ---- main pass: every candidate once, the positions where ANY query passes are recorded ---------------------------------
+        uint16_t* plist = plist_all + (size_t)w * S5_PCAP;
+        int pcur = 0;
+        {
+            const int nit = (len + 64 * U - 1) / (64 * U);
+            CodeWords<M> ring[PF][U];
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) ring[k][u] = load_code_buf<M>(rs, (w + k * NW) * 64 * U + u * 64 + lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (int iter0 = w; iter0 < nit; iter0 += NW * PF) {
+#pragma unroll
+                for (int k = 0; k < PF; ++k) {
+                    const int iter = iter0 + k * NW;
+                    const int base = iter * 64 * U;
+                    u32x4v dd[U];
+                    adc16x8_rows<M, U, OCT>(ring[k], tab, rc, dd);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) ring[k][u] = load_code_buf<M>(rs, (iter + PF * NW) * 64 * U + u * 64 + lane);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t xx = (pk_subsat_u16(tpk[0], dd[u][0]) | pk_subsat_u16(tpk[1], dd[u][1])) |
+                                            (pk_subsat_u16(tpk[2], dd[u][2]) | pk_subsat_u16(tpk[3], dd[u][3]));
+                        unsigned long long am = __ballot(xx != 0u);
+                        const int n = len - base - u * 64;
+                        if (n < 64) am &= n <= 0 ? 0ull : ((1ull << n) - 1ull);
+                        if (am == 0ull) continue;  // scalar branch
+                        const int idx = __builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, pcur));
+                        if (((am >> lane) & 1ull) && idx < S5_PCAP) plist[idx] = (uint16_t)(base + u * 64 + lane);
+                        pcur += __popcll(am);
+                    }
+                }
+            }
+        }
+        // ---- second gather of the recorded candidates: per-query split, counts, room, write-out --------------------------------------
+        const bool pover = pcur > S5_PCAP;
+        const int pn = pover ? 0 : pcur;
+        if (pover) {
+            if (lane < ng) ovf[sd->q[lane]] = 1;
+        }
+        if (pn > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own position stores
+            const int nit2 = (pn + 63) >> 6;
+            int cnt[G], okc[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) { cnt[g] = 0; okc[g] = 0; }
+            uint32_t thr1[G], ok1[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                thr1[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)sd->thr1[g]);
+                ok1[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)sd->ok1[g]);
+            }
+            for (int it = 0; it < nit2; ++it) {   // pass A: counts
+                const bool on = it * 64 + lane < pn;
+                const uint32_t pos = on ? (uint32_t)ld16(&plist[it * 64 + lane]) : (uint32_t)len;
+                CodeWords<M> cc[1];
+                cc[0] = load_code_buf<M>(rs, (int)pos);
+                u32x4v d1[1];
+                adc16x8_rows<M, 1, OCT>(cc, tab, rc, d1);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const uint32_t sg = s5_sum_of(d1[0], g);
+                    cnt[g] += __popcll(__ballot(on && sg < thr1[g]));
+                    okc[g] += __popcll(__ballot(on && sg < ok1[g]));
+                }
+            }
+            // room in the items' survivor rows: lane g reserves for query g (one atomic per wave and query), counts the proven ones
+            int mine = cnt[0], mok = okc[0];
+#pragma unroll
+            for (int g = 1; g < G; ++g) { mine = (lane == g) ? cnt[g] : mine; mok = (lane == g) ? okc[g] : mok; }
+            int base_l = 0;
+            if (lane < ng && mine > 0) {
+                base_l = atomicAdd(&item_n[sd->item[lane]], mine);
+                if (base_l + mine > S) ovf[sd->q[lane]] = 1;
+                if (mok > 0) atomicAdd(&cnt_ok[sd->q[lane]], mok);
+            }
+            int wbase[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) wbase[g] = __builtin_amdgcn_readlane(base_l, g);
+            for (int it = 0; it < nit2; ++it) {   // pass B: the entries
+                const bool on = it * 64 + lane < pn;
+                const uint32_t pos = on ? (uint32_t)ld16(&plist[it * 64 + lane]) : (uint32_t)len;
+                CodeWords<M> cc[1];
+                cc[0] = load_code_buf<M>(rs, (int)pos);
+                u32x4v d1[1];
+                adc16x8_rows<M, 1, OCT>(cc, tab, rc, d1);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (g >= ng) continue;  // uniform
+                    const uint32_t sg = s5_sum_of(d1[0], g);
+                    const bool pass = on && sg < thr1[g];
+                    const unsigned long long mg = __ballot(pass);
+                    if (mg == 0ull) continue;
+                    const int idx = __builtin_amdgcn_mbcnt_hi((unsigned)(mg >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mg, wbase[g]));
+                    if (pass && idx < S) item_surv[(int64_t)__builtin_amdgcn_readfirstlane(sd->item[g]) * S + idx] = ((uint64_t)sg << 32) | pos;
+                    wbase[g] += __popcll(mg);
+                }
+            }
+        }
+        }
+    }
+}
+
+// tau[q] = the k-th smallest of the query's B bucket minima (float bits), k = P x sampled fraction; +inf when the query is short or
+// the sample thin (everything is listed then).  One wave per query; also clears the query's counters for the main pass.
+template <int PER>
+__global__ __launch_bounds__(256) void k_scan5_tau(const uint32_t* __restrict__ bmin, int B, const int* __restrict__ nsamp, const PlanOut* __restrict__ plan,
+                                                   int nq, int P, float* __restrict__ tau) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    uint32_t v[PER];
+    bool ok[PER];
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    int fin = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        v[i] = bmin[(int64_t)q * B + i * 64 + lane];
+        ok[i] = v[i] < 0x7f800000u;
+        lo = (ok[i] && v[i] < lo) ? v[i] : lo;
+        hi = (ok[i] && v[i] > hi) ? v[i] : hi;
+        fin += __popcll(__ballot(ok[i]));
+    }
+    const int64_t ncand = plan[q].ncand;
+    const int ns = nsamp[q];
+    float t = __uint_as_float(0x7f800000u);
+    if (ns > 0 && ncand > 2 * (int64_t)P) {
+        int k = (int)(((int64_t)P * ns + ncand - 1) / ncand);
+        k = k < 4 ? 4 : k;
+        if (k <= fin && k <= B / 2) {
+            wave_minmax_step<1>(lo, hi); wave_minmax_step<2>(lo, hi); wave_minmax_step<4>(lo, hi);
+            wave_minmax_step<8>(lo, hi); wave_minmax_step<16>(lo, hi); wave_minmax_step<32>(lo, hi);
+            lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+            hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
+            t = __uint_as_float(wave_kth_bisect<PER>(v, ok, lo, hi, k));
+        }
+    }
+    if (lane == 0) tau[q] = t;
+}
+
+// the proof (see the header comment of k_adc_scan5): a thread per slot; a slot with a query that fails goes to the fall-back list
+__global__ void k_scan5_check(const int* __restrict__ slots, const int* __restrict__ n_slots_ptr, const WorkItem* __restrict__ items,
+                              const PlanOut* __restrict__ plan, const int* __restrict__ cnt_ok, const int* __restrict__ ovf, int L,
+                              int* __restrict__ fhdr, int* __restrict__ fslots, int* __restrict__ item_n, int* __restrict__ dbg) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_slots_ptr[0]) return;
+    int bad[S5G], nb = 0;
+#pragma unroll
+    for (int g = 0; g < S5G; ++g) {
+        const int idx = slots[j * S5G + g];
+        if (idx < 0) continue;
+        const int q = items[idx].q;
+        const int64_t nc = plan[q].ncand;
+        const int need = nc < (int64_t)L ? (int)nc : L;
+        if (ovf[q] != 0 || cnt_ok[q] < need) bad[nb++] = idx;
+    }
+    if (nb == 0) return;
+    atomicAdd(&dbg[1], 1);
+    for (int b0 = 0; b0 < nb; b0 += S3G) {  // fall-back slots hold S3G items
+        const int f = atomicAdd(&fhdr[17], 1);
+#pragma unroll
+        for (int g = 0; g < S3G; ++g) {
+            fslots[f * S3G + g] = b0 + g < nb ? bad[b0 + g] : -1;
+            if (b0 + g < nb) item_n[bad[b0 + g]] = 0;  // whatever the slot wrote is replaced
+        }
+    }
+}
+
+__global__ void k_scan5_init(uint32_t* __restrict__ bmin, int64_t n_b, int* __restrict__ ints, int n_ints) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_b) bmin[i] = 0x7f800000u;
+    if (i < n_ints) ints[i] = 0;
+}
+
+bool scan5_supported(int M, int K, int L) { return (M == 4 || M == 8) && K <= 256 && K % 4 == 0 && L >= 1 && L <= 440; }
+static const int S5_B = 512;
+size_t scan5_workspace_bytes(int nq) { return (size_t)nq * S5_B * 4 + (size_t)nq * 4 * 4 + 256; }
+
+template <int M, int NR>
+static void launch_scan5_t(const Scan3Geom& g, int64_t n_items, int nq, hipStream_t st, const WorkItem* items, const TabDesc* tabs, const int* slots,
+                           const int* n_slots, const PlanOut* plan, const double* T, const float* T32, const uint8_t* codes, int K, int L, int* qctr,
+                           uint64_t* hits, int* hitn, float* slack, unsigned long long* qbound, int* fhdr, int* fslots, void* ws, hipEvent_t ev_main) {
+    uint32_t* bmin = reinterpret_cast<uint32_t*>(ws);
+    int* ints = reinterpret_cast<int*>(bmin + (size_t)nq * S5_B);
+    int* nsamp = ints;
+    int* cnt_ok = ints + nq;
+    int* ovf = ints + 2 * nq;
+    float* tau = reinterpret_cast<float*>(ints + 3 * nq);
+    const int64_t n_b = (int64_t)nq * S5_B;
+    hipLaunchKernelGGL(k_scan5_init, dim3((unsigned)((n_b + 255) / 256)), dim3(256), 0, st, bmin, n_b, ints, 3 * nq);
+    (void)hipMemsetAsync(hitn, 0, (size_t)(n_items + 1) * sizeof(int), st);
+    constexpr int WPE = 4;
+    const size_t lds = scan5_lds(M, K);
+    const int by_lds = (int)(163840 / lds);
+    const int per_cu = by_lds < WPE ? by_lds : WPE;
+    const unsigned grid = 256u * (unsigned)(per_cu < 1 ? 1 : per_cu);
+    static const int P_env = getenv("CIS_S5_P") ? atoi(getenv("CIS_S5_P")) : 0;
+    static const int ss_env = getenv("CIS_S5_SS") ? atoi(getenv("CIS_S5_SS")) : 4;
+    const int P = P_env > 0 ? P_env : (L < 100 ? 240 : (int)(2.4 * L));
+    hipLaunchKernelGGL((k_adc_scan5<M, true, WPE>), dim3(grid), dim3(256), lds, st, items, tabs, slots, n_slots, T32, codes, K, g.S, (const float*)nullptr, bmin,
+                       S5_B, nsamp, ss_env, hits, hitn, slack, cnt_ok, ovf);
+    hipLaunchKernelGGL(k_scan5_tau<S5_B / 64>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, bmin, S5_B, nsamp, plan, nq, P, tau);
+    if (ev_main) (void)hipEventRecord(ev_main, st);
+    hipLaunchKernelGGL((k_adc_scan5<M, false, WPE>), dim3(grid), dim3(256), lds, st, items, tabs, slots, n_slots, T32, codes, K, g.S, tau, bmin, S5_B, nsamp,
+                       ss_env, hits, hitn, slack, cnt_ok, ovf);
+    const int64_t max_slots = n_items + 8;  // (an upper bound of the slot count: the kernel reads the real one)
+    hipLaunchKernelGGL(k_scan5_check, dim3((unsigned)((max_slots + 255) / 256)), dim3(256), 0, st, slots, n_slots, items, plan, cnt_ok, ovf, L, fhdr, fslots, hitn,
+                       qctr + 9);
+    if (getenv("CIS_SCAN5_DEBUG")) {
+        int h[6] = {0, 0, 0, 0, 0, 0};
+        if (hipMemcpyAsync(h, qctr + 9, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+            fprintf(stderr, "[cis] k_adc_scan5: %d slots to the fall-back list\n", h[1]);
+    }
+    // the slots it could not settle: k_adc_scan3's two-pass form for short chunks, its streaming form for long ones (as after k_adc_scan4)
+    constexpr int U = 4, NW = 4;
+    constexpr int WPE3 = 4;
+    hipLaunchKernelGGL((k_adc_scan3<M, NR, U, NW, WPE3>), dim3(256), dim3(NW * 64), g.lds, st, items, tabs, fslots, fhdr + 8, T, T32, codes, K, L, g.S, fhdr, hits, hitn,
+                       slack, qbound, g.long_chunks ? 0 : 1, 1);
+}
+
+void launch_scan5(int M, const Scan3Geom& g, int64_t n_items, int nq, hipStream_t st, const WorkItem* items, const TabDesc* tabs, const int* slots,
+                  const int* n_slots, const PlanOut* plan, const double* T, const float* T32, const uint8_t* codes, int K, int L, int* qctr, uint64_t* hits,
+                  int* hitn, float* slack, unsigned long long* qbound, int* fhdr, int* fslots, void* ws, hipEvent_t ev_main) {
+    if (M == 4) {
+        if (L <= 184) launch_scan5_t<4, 4>(g, n_items, nq, st, items, tabs, slots, n_slots, plan, T, T32, codes, K, L, qctr, hits, hitn, slack, qbound, fhdr, fslots, ws, ev_main);
+        else launch_scan5_t<4, 8>(g, n_items, nq, st, items, tabs, slots, n_slots, plan, T, T32, codes, K, L, qctr, hits, hitn, slack, qbound, fhdr, fslots, ws, ev_main);
+    } else {
+        if (L <= 184) launch_scan5_t<8, 4>(g, n_items, nq, st, items, tabs, slots, n_slots, plan, T, T32, codes, K, L, qctr, hits, hitn, slack, qbound, fhdr, fslots, ws, ev_main);
+        else launch_scan5_t<8, 8>(g, n_items, nq, st, items, tabs, slots, n_slots, plan, T, T32, codes, K, L, qctr, hits, hitn, slack, qbound, fhdr, fslots, ws, ev_main);
+    }
+}
+
 bool scan3_supported(int M, int K, int L) {
     return (M == 4 || M == 8 || M == 16) && K <= 256 && K % 4 == 0 && L >= 1 && L <= 440;
 }

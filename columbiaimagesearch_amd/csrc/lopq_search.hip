@@ -3023,13 +3023,14 @@ extern "C" int cis_multisequence(const void* X, int x_dtype, const void* C0, con
 }
 
 extern "C" int cis_index_set_scan_mode(cis_index* ix, int mode) {
-    CIS_REQUIRE(ix != nullptr && mode >= 0 && mode <= 6, "bad scan mode");
+    CIS_REQUIRE(ix != nullptr && mode >= 0 && mode <= 7, "bad scan mode");
     ix->force_stream = (mode == 6);
+    ix->force_scan5 = (mode == 7);
     ix->force_exact_scan = (mode == 1);
-    ix->force_prefilter_scan = (mode >= 2 && mode <= 5);
+    ix->force_prefilter_scan = (mode >= 2 && mode <= 5) || mode == 7;
     ix->force_scan2 = (mode == 2);
-    ix->force_scan3 = (mode == 3 || mode == 4 || mode == 5);
-    ix->force_two_pass = mode == 3 ? 0 : (mode == 4 ? 1 : (mode == 5 ? 2 : -1));
+    ix->force_scan3 = (mode == 3 || mode == 4 || mode == 5 || mode == 7);
+    ix->force_two_pass = mode == 3 ? 0 : (mode == 4 ? 1 : ((mode == 5 || mode == 7) ? 2 : -1));
     return CIS_OK;
 }
 
@@ -5125,7 +5126,14 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (fast) {
             // slot list: work items grouped by coarse cell (counting sort; skipped for huge V), G per slot
             const bool sort_items = ix->ncells <= 65536;
-            const int G = use3 ? geom3.G : geom.G;
+            // k_adc_scan5 (round 5): where the sampled form k_adc_scan4 would run -- one threshold per query for the whole batch
+            // instead of one per slot, eight queries per slot.  MEASURED AND LEFT OFF (profiles/r05g_*, r05h_*: C4 sample 64 + thresholds 17 +
+            // main pass 200 + check 12 us against 231 us for the whole of k_adc_scan4, and a merge of 134 instead of 76 us for the longer
+            // lists; both pipes ~40 % busy at three workgroups per CU: the loop is bound by latency, not by instructions).  CIS_SCAN5=1
+            // routes large batches to it, scan mode 7 forces it (tests: every search test passes on it).
+            static const int env_s5 = getenv("CIS_SCAN5") ? atoi(getenv("CIS_SCAN5")) : 0;
+            const bool use5 = use3 && geom3.two_pass == 2 && scan5_supported(M, K, L) && (ix->force_scan5 || (env_s5 != 0 && !ix->force_scan3 && L <= 128));
+            const int G = use5 ? 8 : (use3 ? geom3.G : geom.G);
             // chunks per cell that get their own slot keys: what the largest cell needs (all shards' sizes bound this shard's)
             int64_t CH = use3 ? ceil_div(ix->max_cell > 0 ? ix->max_cell : 1, (int64_t)seg_max) : 1;
             CH = CH < 1 ? 1 : (CH > 16 ? 16 : CH);
@@ -5155,7 +5163,12 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                                    slots, n_slots, qstart);
             }
             CIS_TRY(mark(5));
-            ix->last_scan_kernel = use3 ? (geom3.two_pass == 2 ? 4 : 3) : 2;  // 4: the sampled single-pass form k_adc_scan4 does the work (k_adc_scan3 only its fall-back slots)
+            ix->last_scan_kernel = use5 ? 6 : (use3 ? (geom3.two_pass == 2 ? 4 : 3) : 2);  // 4: the sampled single-pass form k_adc_scan4 does the work (k_adc_scan3 only its fall-back slots)
+            if (use5) {
+                CIS_TRY(ix->w_s5.reserve(scan5_workspace_bytes(nq)));
+                launch_scan5(M, geom3, n_items, nq, st, items, tabs, slots, n_slots, plan, T, T32, codes, K, L, qctr, ix->w_hits.as<uint64_t>(), hitn,
+                             ix->w_slack.as<float>(), qbound, fhdr, fslots, ix->w_s5.p, nullptr);
+            } else
             if (use3) {
                 Scan3Geom g3 = geom3;
                 // M = 16 on the sampled form: the saturating scale of k_adc_scan4 (sums of the near candidates at this fraction of the entry cap)

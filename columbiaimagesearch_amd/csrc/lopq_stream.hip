@@ -28,6 +28,10 @@
 //      memory; the host then answers the batch through the generic path.  The result never depends on the sample.
 #include "scan_common.h"
 
+#ifndef CIS_STREAM_REPL
+#define CIS_STREAM_REPL 0
+#endif
+
 static __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 
 __global__ void k_stream_init(uint32_t* __restrict__ bmin, int64_t n_b, int* __restrict__ cnt, int nq, int* __restrict__ status) {
@@ -49,14 +53,24 @@ __global__ __launch_bounds__(256) void k_adc_stream(const WorkItem* __restrict__
     constexpr int CPL = 16 / M;        // candidates per lane and 16-byte load
     constexpr int ROW = 64 * CPL;      // candidates per wave and load
     constexpr int U = 4;               // loads in flight per wave
-    extern __shared__ __align__(16) float s_tab[];  // [K][M][G]: entry (k, j) of the slot's queries side by side
+    // Tables in LDS, entry-major, the sub-quantizers rotated over the lanes.  Measured (profiles/r05f_c4x_*): SQ_LDS_BANK_CONFLICT /
+    // SQ_LDS_IDX_ACTIVE = 0.66 -- the worst of the eight 4-lane groups of a read is 2.9-way, not the 2.1-way of one group -- and the LDS
+    // pipe 0.72 busy at 0.60 of 8 TB/s.  CIS_STREAM_REPL=1 REPLICATES the tables so that the gathers meet no conflict at all (a row of 128
+    // bytes per k holds R copies of the M entries; lane l uses copy (l % 32) / M, so the 32 lanes of a read group own distinct banks
+    // whatever their k): built, bit-identical, and slower -- see the macro.
+    // MEASURED (profiles/r05g_*): 357 us against 333-339 us per exhaustive launch over 200 M codes -- the conflicts go (the LDS pipe was
+    // 0.72 busy, not saturated), four times the staging and 32 KB per workgroup cost more: the stream waits on HBM.
+    constexpr int R = CIS_STREAM_REPL ? (32 / G) / M : 1;    // copies
+    constexpr int ROWSH = (R * M * G * 4 == 128) ? 7 : (R * M * G * 4 == 64 ? 6 : (R * M * G * 4 == 32 ? 5 : 4));  // log2(row bytes)
+    static_assert(R >= 1 && (1 << ROWSH) == R * M * G * 4, "rows of 16 .. 128 bytes");
+    extern __shared__ __align__(16) float s_tab[];  // [K][R][M][G]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ns = *n_slots;
     const RotConsts<M> rc = make_rot<M>(lane);
     uint32_t cjb[M];  // byte offset of sub-quantizer j(t, lane) inside an entry row: j * G * 4
 #pragma unroll
     for (int t = 0; t < M; ++t) {
-        cjb[t] = rc.cj[t] * (uint32_t)G;
+        cjb[t] = (((uint32_t)(lane & 31) / (uint32_t)M) % (uint32_t)R * (uint32_t)M + (rc.cj[t] >> 2)) * (uint32_t)(G * 4);
         asm volatile("" : "+v"(cjb[t]));  // M registers for the whole kernel (else re-derived per use)
     }
     for (int s = blockIdx.x; s < ns; s += gridDim.x) {
@@ -83,8 +97,11 @@ __global__ __launch_bounds__(256) void k_adc_stream(const WorkItem* __restrict__
             const float* t1 = T32 + (int64_t)it.tab1 * nf * K;
             for (int k = tid; k < K; k += 256) {
 #pragma unroll
-                for (int j = 0; j < M; ++j)
-                    s_tab[((size_t)k * M + j) * G + g] = on ? (j < nf ? t0[j * K + k] : t1[(j - nf) * K + k]) : 0.f;
+                for (int j = 0; j < M; ++j) {
+                    const float e = on ? (j < nf ? t0[j * K + k] : t1[(j - nf) * K + k]) : 0.f;
+#pragma unroll
+                    for (int c = 0; c < R; ++c) s_tab[(((size_t)k * R + c) * M + j) * G + g] = e;
+                }
             }
         }
         __syncthreads();
@@ -127,10 +144,10 @@ __global__ __launch_bounds__(256) void k_adc_stream(const WorkItem* __restrict__
                         // byte of sub-quantizer j(t, lane), then the byte address of entry (byte, j): two VALU instructions
                         uint32_t byte, addr;
                         asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(byte) : "v"(wsel[th]), "v"(rc.sh[tq]));
-                        if constexpr (M * G * 4 == 16) asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
-                        else if constexpr (M * G * 4 == 32) asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
-                        else if constexpr (M * G * 4 == 64) asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
-                        else asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
+                        if constexpr (ROWSH == 7) asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
+                        else if constexpr (ROWSH == 6) asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
+                        else if constexpr (ROWSH == 5) asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
+                        else asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
                         const char* ep = reinterpret_cast<const char*>(s_tab) + addr;
                         if constexpr (G == 1) {
                             const float e = *reinterpret_cast<const float*>(ep);
@@ -323,7 +340,7 @@ __global__ void k_stream_verify(const uint64_t* __restrict__ sel_keys, const int
 // ---- host ------------------------------------------------------------------------------------------------------------------------
 bool stream_supported(int M, int K, int L) { return (M == 4 || M == 8 || M == 16) && K <= 256 && L >= 1 && L <= 1024; }
 
-size_t stream_lds(int M, int K, int G) { return (size_t)K * M * G * sizeof(float); }
+size_t stream_lds(int M, int K, int G) { return CIS_STREAM_REPL ? (size_t)K * 128 : (size_t)K * M * G * sizeof(float); }
 
 template <int M, int G, bool SAMPLE>
 static void launch_stream_t(int grid, hipStream_t st, const WorkItem* items, const int* slots, const int* n_slots, const float* T32,

@@ -253,3 +253,10 @@ void launch_stream_keys(int M, hipStream_t st, const WorkItem* items, const int6
                         uint64_t* keys, unsigned long long* qmin, unsigned long long* qmax);
 void launch_stream_verify(hipStream_t st, const uint64_t* sel_keys, const int* nsel, int64_t stride, const int* cnt, int cap, const int64_t* seg,
                           const float* tau, int nq, int L, int M, int* status, int64_t* status_host_dev, int64_t seq);
+
+// ---- k_adc_scan5 (lopq_scan3.hip): one threshold per query for the whole batch, eight queries per slot -----------------------
+bool scan5_supported(int M, int K, int L);
+size_t scan5_workspace_bytes(int nq);
+void launch_scan5(int M, const Scan3Geom& g, int64_t n_items, int nq, hipStream_t st, const WorkItem* items, const TabDesc* tabs, const int* slots,
+                  const int* n_slots, const PlanOut* plan, const double* T, const float* T32, const uint8_t* codes, int K, int L, int* qctr, uint64_t* hits,
+                  int* hitn, float* slack, unsigned long long* qbound, int* fhdr, int* fslots, void* ws, hipEvent_t ev_main);

@@ -459,7 +459,7 @@ class LOPQSearcherHIP(LOPQSearcherBase):
         _lib.check(_lib.lib().cis_index_last_stats(self._ix, _lib.ptr(st)))
         kind = int(_lib.lib().cis_index_last_scan_kernel(self._ix))
         return {"candidates": int(st[0]), "items": int(st[1]), "tables": int(st[2]), "scan_launches": int(st[3]),
-                "scan_kernel": {0: None, 1: "k_adc_scan", 2: "k_adc_scan2", 3: "k_adc_scan3", 4: "k_adc_scan4", 5: "k_adc_stream"}.get(kind)}
+                "scan_kernel": {0: None, 1: "k_adc_scan", 2: "k_adc_scan2", 3: "k_adc_scan3", 4: "k_adc_scan4", 5: "k_adc_stream", 6: "k_adc_scan5"}.get(kind)}
 
 
     default_prefilter_only = False  # tests: new searchers keep the float32-prefilter kernel for every batch size

@@ -220,6 +220,29 @@ def test_dlib_direct_first_layer_agrees_with_implicit_gemm(monkeypatch):
     net.close()
 
 
+def test_dlib_fused_tail_agrees_with_the_six_launches_it_replaces(monkeypatch):
+    """k_dlib_tail (round 5: the last block's second convolution -- its centre tap, all a 1 x 1 map ever meets --, pooled skip branch,
+    add_prev, ReLU, global average and fc_no_bias in one launch) against the separate launches (CIS_CNN_NO_TAIL) and the CPU
+    restatement; odd batch sizes (two chips per workgroup), a chip's descriptor independent of its place in the batch."""
+    from oracle import dlib_oracle as D
+    from columbiaimagesearch_amd.featurizer import DLibFaceNet
+    w = D.synthetic_weights(11)
+    net = DLibFaceNet(w)
+    for n, seed in ((1, 4), (2, 5), (5, 6), (33, 7)):
+        chips = D.synthetic_chips(n, seed=seed)
+        monkeypatch.setenv("CIS_CNN_NO_TAIL", "1")
+        ref = net.forward(chips)
+        monkeypatch.delenv("CIS_CNN_NO_TAIL")
+        got = net.forward(chips)
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=3e-5 * np.abs(ref).max())  # same products, another float32 summation order
+        np.testing.assert_array_equal(net.forward(chips[n - 1:n])[0], got[n - 1])
+        if n <= 5:
+            cpu = D.forward_torch(chips, w)
+            np.testing.assert_allclose(got, cpu, rtol=0, atol=3e-4 * np.abs(cpu).max())
+    net.close()
+
+
 @pytest.mark.parametrize("n", [128, 257, 512])
 def test_dlib_batch_in_concurrent_parts_equals_the_single_chain(monkeypatch, n):
     """A batch of 128-512 chips runs as two parts on the handle's own streams (own workspaces, event fences on the caller's

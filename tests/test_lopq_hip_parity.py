@@ -18,19 +18,20 @@ _ROUTE_FREE = ("encode", "alternative_kernels", "near_tie", "fine_codes", "hooks
                "large_limit", "fuzz")
 
 
-@pytest.fixture(autouse=True, params=["auto", "prefilter", "scan3", "scan4", "scan5", "stream"])
+@pytest.fixture(autouse=True, params=["auto", "prefilter", "scan3", "scan4", "scan5", "stream", "scan7"])
 def route(request):
     """Every search test runs on the three routes of limit <= 440: "auto" (small batches -- what most fixtures are -- take
     the all-candidates path: exact distances + radix select), "prefilter" (the float32-prefilter scan kernel k_adc_scan2
     whatever the batch size), "scan3" / "scan4" (the 16-bit fixed-point kernel k_adc_scan3 whatever the batch size, in its
     streaming and in its two-pass form), "scan5" (the sampled single-pass form k_adc_scan4: what large batches over short
     cells run), "stream" (the HBM-streaming route of csrc/lopq_stream.hip, scan mode 6: what a few queries over hundreds of
-    thousands of candidates each take -- forced here onto the fixtures' small cells, with 1024-candidate chunks)."""
+    thousands of candidates each take -- forced here onto the fixtures' small cells, with 1024-candidate chunks), "scan7" (scan mode
+    7 = k_adc_scan5: one sampled threshold per query for the whole batch, eight queries per slot -- what large batches run by default)."""
     from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
     if request.param != "auto" and any(k in request.node.name for k in _ROUTE_FREE):
         pytest.skip("does not depend on the search route")
     LOPQSearcherHIP.default_prefilter_only = request.param == "prefilter"
-    LOPQSearcherHIP.default_scan_mode = {"scan3": 3, "scan4": 4, "scan5": 5, "stream": 6}.get(request.param, 0)
+    LOPQSearcherHIP.default_scan_mode = {"scan3": 3, "scan4": 4, "scan5": 5, "stream": 6, "scan7": 7}.get(request.param, 0)
     if request.param == "stream":
         os.environ["CIS_STREAM_SEG"] = "1024"
     yield request.param

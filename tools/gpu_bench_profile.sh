@@ -7,10 +7,5 @@ mkdir -p gpurun_out
 rm -rf /tmp/prof_$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o r -- python bench.py "$@" > gpurun_out/${tag}_bench.log 2>&1
 cp /tmp/prof_$tag/r_kernel_stats.csv gpurun_out/${tag}_kernel_stats.csv
-grep '^{' gpurun_out/${tag}_bench.log | tail -1 | python -c "
-import sys, json
-d = json.loads(sys.stdin.read())
-print('value %.0f q/s  ms/step %.3f  roofline frac %.3f achieved %.0f GB/s  launch %.3f ms' % (d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['achieved'], d['roofline']['avg_launch_ms']))
-print('stages', {k: round(v, 3) for k, v in d['stage_ms_per_step'].items()}, 'recall@10', d['recall_at_10'], 'parity', d['parity'])
-"
+grep '^{' gpurun_out/${tag}_bench.log | tail -1 | python tools/bench_summary.py
 python tools/kstats.py gpurun_out/${tag}_kernel_stats.csv "^(void )?k_"
