@@ -73,6 +73,11 @@ _PROTOS = {
     "cis_index_get_codes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "cis_index_search": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
+    "cis_index_search_async": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
+    "cis_index_search_wait": (c_int, [c_void_p]),
+    "cis_host_alloc": (c_int, [POINTER(c_void_p), ctypes.c_size_t]),
+    "cis_host_free": (None, [c_void_p]),
     "cis_index_search_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "cis_index_search_partial_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p,
@@ -206,3 +211,36 @@ def alloc_stats():
     n, b = c_int64(0), c_int64(0)
     check(lib().cis_alloc_stats(ctypes.byref(n), ctypes.byref(b)))
     return int(n.value), int(b.value)
+
+
+class _PinnedBlock(object):
+    """Owner of one cis_host_alloc block (freed when the last array view on it goes away)."""
+
+    def __init__(self, nbytes):
+        p = c_void_p()
+        check(lib().cis_host_alloc(ctypes.byref(p), int(nbytes)))
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().cis_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """numpy array in page-locked host memory (include/cis_hip.h:cis_host_alloc): what search_batch_async copies from / into by DMA."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    blk = _PinnedBlock(max(n * dt.itemsize, 1))
+    buf = (ctypes.c_char * blk.nbytes).from_address(blk.ptr)
+    a = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+    _PINNED_OWNERS[id(buf)] = blk  # the ctypes buffer does not own the block: keep it alive as long as the buffer object lives
+    import weakref
+    weakref.finalize(buf, _PINNED_OWNERS.pop, id(buf), None)
+    return a
+
+
+_PINNED_OWNERS = {}

@@ -86,6 +86,11 @@ struct cis_index {
     int64_t m16_backoffs = 0;
     int last_scan_kernel = 0;       // 0 none (all-candidates path), 1 float64 scan, 2 float32 prefilter, 3 16-bit fixed-point prefilter, 4 its sampled single-pass form (k_adc_scan4), 5 the HBM-streaming scan (k_adc_stream), 6 k_adc_scan5
     bool force_prefilter_scan = false;  // tests: the float32-prefilter kernel also for small batches
+    hipStream_t h_stream = nullptr; // the host-pointer entry points' own stream (cis_index_search[_async])
+    hipEvent_t h_ev_in = nullptr, h_ev_out = nullptr, h_ev_done = nullptr;  // copy-in landed / search done / copy-out landed
+    bool h_pending = false;         // a batch of cis_index_search_async is in flight on it
+    struct HostOut { int64_t* ids; double* dists; int32_t* n_found; int32_t* visited; int32_t* cells; uint32_t* pos; int nq, L; };
+    HostOut h_out = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};  // where its results go (copied out by cis_index_search_wait)
     bool force_scan5 = false;       // scan mode 7 (tests): k_adc_scan5 (one threshold per query, eight queries per slot) whatever the batch size
     DevBuf w_s5;                    // its per-batch buckets, counters and thresholds
     bool force_stream = false;      // scan mode 6 (tests): the HBM-streaming route (lopq_stream.hip) whatever the batch looks like

@@ -605,6 +605,14 @@ extern "C" void cis_index_destroy(cis_index* ix) {
     // later search through them is refused (no dangling pointer is ever followed)
     for (cis_index* v : ix->views) { v->base = nullptr; v->orphaned = true; }
     ix->views.clear();
+    if (ix->h_stream) {
+        if (ix->h_pending && ix->h_ev_done) (void)hipEventSynchronize(ix->h_ev_done);
+        (void)hipStreamSynchronize(ix->h_stream);
+        (void)hipStreamDestroy(ix->h_stream);
+        ix->h_stream = nullptr;
+        for (hipEvent_t e : {ix->h_ev_in, ix->h_ev_out, ix->h_ev_done})
+            if (e) (void)hipEventDestroy(e);
+    }
     DevBuf* bufs[] = {&ix->d_gcount, &ix->d_plan_hint, &ix->d_owner, &ix->w_xp, &ix->w_cd, &ix->w_order,
                       &ix->w_sorted, &ix->w_plan, &ix->w_off, &ix->w_items, &ix->w_tabs, &ix->w_T, &ix->w_hits,
                       &ix->w_hitn, &ix->w_slack, &ix->w_planfb, &ix->w_vis, &ix->w_tiles, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,

@@ -348,6 +348,34 @@ class LOPQSearcherHIP(LOPQSearcherBase):
             out["cells"], out["pos"] = cells, pos
         return out
 
+    def search_batch_async(self, X, quota=10, limit=None, out=None):
+        """search_batch in two halves (include/cis_hip.h:cis_index_search_async): copy-in, search and copy-out are enqueued on this
+        handle's own stream and the call returns; `search_wait()` returns the result dict once it has landed.  X and the arrays of
+        `out` (a dict like search_batch's result: ids, dists, n_found, visited) should live in pinned memory (`_lib.pinned_empty`) so
+        that the copies are DMA transfers; they must not be touched before search_wait.  One batch in flight per searcher -- views
+        (`view()`) give several."""
+        X = _lib.as_float_matrix(X, self._input_dim)
+        nq = X.shape[0]
+        L = max(int(quota) if limit is None else int(limit), 0)
+        if out is None:
+            out = {"ids": _lib.pinned_empty((nq, L), np.int64), "dists": _lib.pinned_empty((nq, L), np.float64),
+                   "n_found": _lib.pinned_empty((nq,), np.int32), "visited": _lib.pinned_empty((nq,), np.int32)}
+        for k, dt, shp in (("ids", np.int64, (nq, L)), ("dists", np.float64, (nq, L)), ("n_found", np.int32, (nq,)), ("visited", np.int32, (nq,))):
+            a = out[k]
+            if a.dtype != dt or tuple(a.shape) != shp or not a.flags["C_CONTIGUOUS"]:
+                raise ValueError("out[%r] must be a C-contiguous %s array of shape %r" % (k, np.dtype(dt).name, shp))
+        self._async = (X, out)  # the buffers stay referenced until search_wait
+        _lib.check(_lib.lib().cis_index_search_async(self._ix, _lib.ptr(X), _lib.dtype_code(X), nq, int(quota),
+                                                     -1 if limit is None else int(limit), _lib.ptr(out["ids"]), _lib.ptr(out["dists"]),
+                                                     _lib.ptr(out["n_found"]), _lib.ptr(out["visited"]), None, None))
+        return out
+
+    def search_wait(self):
+        """Blocks until the batch of the last search_batch_async has landed; returns its result dict (None when nothing is in flight)."""
+        _lib.check(_lib.lib().cis_index_search_wait(self._ix))
+        pend, self._async = getattr(self, "_async", None), None
+        return pend[1] if pend else None
+
     def caller_ids(self, dev_ids):
         """Map device ids of search_batch back to the ids given to add_codes."""
         return [self._caller_id(i) for i in dev_ids if i >= 0]

@@ -27,6 +27,7 @@
 #ifndef CIS_HIP_H
 #define CIS_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -205,6 +206,19 @@ int cis_index_search(cis_index* ix, const void* Q, int q_dtype, int nq, int64_t 
 int cis_index_search_dev(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota, int limit,
                          int64_t* d_ids, double* d_dists, int32_t* d_n_found, int32_t* d_visited,
                          int32_t* d_cells, uint32_t* d_pos, void* stream);
+/* The host-pointer search in two halves (round 5): cis_index_search_async enqueues copy-in, search and copy-out on the handle's OWN
+ * stream and returns once the search's launches are queued; cis_index_search_wait blocks until the results have landed in the caller's
+ * buffers, which must stay valid and untouched until then.  One batch in flight per handle (a second call waits for the first); views
+ * of one index (cis_index_create_view) give several -- the reference serves independent queries from 16 gunicorn workers over one
+ * index (searcher_lopqhbase.py:198-206), this is that inside one process.  cis_index_search = async + wait.
+ * cis_host_alloc / cis_host_free: page-locked host memory.  With Q and the outputs in it the copies are DMA transfers that overlap the
+ * other handles' searches; pageable memory works too and is staged by the runtime (slower, and the call then blocks while it copies). */
+int cis_index_search_async(cis_index* ix, const void* Q, int q_dtype, int nq, int64_t quota, int limit,
+                           int64_t* ids, double* dists, int32_t* n_found, int32_t* visited,
+                           int32_t* cells, uint32_t* pos);
+int cis_index_search_wait(cis_index* ix);
+int cis_host_alloc(void** out, size_t bytes);
+void cis_host_free(void* p);
 /* Fine codes of n stored items addressed by (cell, pos) as returned by a search.  fine [n][M].
  * Items of cells owned by another shard yield CIS_EINVAL. */
 int cis_index_get_codes(cis_index* ix, const int32_t* cells, const uint32_t* pos, int64_t n, uint8_t* fine);

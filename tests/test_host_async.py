@@ -1,0 +1,58 @@
+"""The host-pointer search in two halves (include/cis_hip.h: cis_index_search_async / cis_index_search_wait, cis_host_alloc): what the
+reference's callers use -- queries and results in host memory (searcher_lopqhbase.py:849-857) -- without a blocking copy per batch."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_async_search_on_pinned_buffers_equals_the_blocking_call():
+    from test_lopq_hip_parity import hip_model
+    from columbiaimagesearch_amd import _lib
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    z, X, Q = load_golden("c2")
+    m = hip_model(z)
+    s = LOPQSearcherHIP(m)
+    s.add_codes_array(z["coarse"], z["fine"])
+    nq = 20   # (the fixture holds 64 queries)
+    want = [s.search_batch(Q[i * nq:(i + 1) * nq], quota=1000, limit=50) for i in range(3)]
+    lanes = [s, s.view(), s.view()]
+    qpin = []
+    for i in range(3):
+        q = _lib.pinned_empty((nq, Q.shape[1]), Q.dtype)
+        q[...] = Q[i * nq:(i + 1) * nq]
+        qpin.append(q)
+    # three batches in flight, each on its own handle, results in library-made pinned arrays
+    outs = [lanes[i].search_batch_async(qpin[i], quota=1000, limit=50) for i in range(3)]
+    for i in range(3):
+        r = lanes[i].search_wait()
+        assert r is outs[i]
+        for k in ("ids", "n_found", "visited"):
+            assert (r[k] == want[i][k]).all(), (i, k)
+        assert np.array_equal(np.nan_to_num(r["dists"]), np.nan_to_num(want[i]["dists"]))
+    assert lanes[0].search_wait() is None  # nothing in flight any more
+    # pageable arrays work as well (the runtime stages them), and a second call on the same handle waits for the first
+    out = {"ids": np.empty((nq, 50), np.int64), "dists": np.empty((nq, 50)), "n_found": np.empty(nq, np.int32), "visited": np.empty(nq, np.int32)}
+    s.search_batch_async(Q[:nq], quota=1000, limit=50, out=out)
+    out2 = s.search_batch_async(Q[nq:2 * nq], quota=1000, limit=50)
+    s.search_wait()
+    assert (out["ids"] == want[0]["ids"]).all() and (out2["ids"] == want[1]["ids"]).all()
+    with pytest.raises(ValueError):
+        s.search_batch_async(Q[:nq], quota=1000, limit=50, out={"ids": np.empty((nq, 49), np.int64), "dists": out["dists"], "n_found": out["n_found"], "visited": out["visited"]})
+    # a view whose base is closed first is orphaned, not dangling: searches through it fail cleanly
+    v = s.view()
+    import gc
+    s2 = LOPQSearcherHIP(m)
+    s2.add_codes_array(z["coarse"][:1000], z["fine"][:1000])
+    v2 = s2.view()
+    _lib.lib().cis_index_destroy(s2._ix)   # the library call itself, bypassing the Python close() that closes the views first
+    s2._ix = None
+    with pytest.raises(ValueError, match="base index was destroyed"):
+        v2.search_batch(Q[:2], quota=10, limit=5)
+    v2.close()
+    for x in lanes[1:] + [v]:
+        x.close()
+    s.close()
+    gc.collect()
