@@ -3199,12 +3199,11 @@ static void launch_scan2(int M, const Scan2Geom& g, int64_t n_items, hipStream_t
 }
 
 // ---- large `limit` (above what the LDS top-k kernels hold): exact distance of EVERY candidate, stable segmented
-// radix sort per query (rocPRIM, csrc/lopq_sort.hip).  Candidates are laid out in retrieval order (items of a query
+// sort per query (the merge sort of csrc/lopq_sort.hip; rocPRIM until round 4).  Candidates are laid out in retrieval order (items of a query
 // in visit order, positions ascending), so a stable sort on the distance alone yields the (dist, visit_rank, pos)
 // ranking = the reference's stable sorted() over the retrieved list (search.py:210).
 int cis_seg_sort_u64(void* temp, size_t* temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint64_t* vals_in,
                      uint64_t* vals_out, int64_t n, int nseg, const int64_t* seg_begin, const int64_t* seg_end, hipStream_t st);
-int cis_exclusive_scan_i64(void* temp, size_t* temp_bytes, const int64_t* in, int64_t* out, int64_t n, hipStream_t st);
 
 __global__ void k_item_lens(const WorkItem* __restrict__ items, int64_t n, int64_t* __restrict__ lens) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

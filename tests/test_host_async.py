@@ -56,3 +56,31 @@ def test_async_search_on_pinned_buffers_equals_the_blocking_call():
         x.close()
     s.close()
     gc.collect()
+
+
+def test_limit_equals_quota_ranks_through_the_own_segmented_sort():
+    """limit = None => limit = quota (lopq/lopq/search.py:213-214): with quota = 10000 every one of ~10 k retrieved candidates is returned,
+    ranked by the stable sort of :210.  Above 3072 results per query the ranking is the library's own segmented merge sort
+    (csrc/lopq_sort.hip: LDS tile sort + merge-path passes; rocPRIM until round 4) -- against the oracle, for segment lengths around
+    the 4096-pair tile and across several merge passes, incl. a block of equal distances (stable: retrieval order)."""
+    from test_lopq_hip_parity import hip_model
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    from oracle import lopq_oracle as O
+    z, X, Q = load_golden("c2")
+    m = hip_model(z)
+    coarse, fine = z["coarse"].copy(), z["fine"].copy()
+    coarse[2000:2300] = coarse[2000]   # 300 identical codes: equal distances in the ranked list
+    fine[2000:2300] = fine[2000]
+    s = LOPQSearcherHIP(m)
+    s.add_codes_array(coarse, fine)
+    om = O.OracleModel.from_npz(z)
+    oi = O.OracleCSRIndex(om, coarse, fine)
+    for quota, limit in ((10000, None), (4000, None), (4096, 4096), (4097, None), (20000, 17000), (50000, None)):
+        r = s.search_batch(Q[:6], quota=quota, limit=limit)
+        for qi in range(6):
+            ids, dists, visited = oi.search(Q[qi], quota=quota, limit=limit)
+            k = int(r["n_found"][qi])
+            assert k == len(ids) and visited == int(r["visited"][qi]), (quota, limit, qi)
+            assert (r["ids"][qi, :k] == ids).all(), (quota, limit, qi)
+            assert np.allclose(r["dists"][qi, :k], dists, rtol=1e-9, atol=1e-12)
+    s.close()
