@@ -84,3 +84,43 @@ def test_hand_counted_waits_behind_inline_asm_loads(tmp_path):
     r = subprocess.run(["make", "-C", os.path.join(repo, "columbiaimagesearch_amd", "csrc"), "check-asm"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=1200)
     assert r.returncode == 0 and b" 0 violations" in r.stdout, r.stdout.decode()[-2000:]
+
+
+def _asan_env():
+    import glob
+    rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    lib = os.path.join(REPO, "columbiaimagesearch_amd", "lib", "libcis_hip_asan.so")
+    if not rt:
+        pytest.skip("no clang AddressSanitizer runtime in this image")
+    return rt[-1], lib
+
+
+def test_asan_build_of_the_host_shim():
+    """`make asan`: the library with its HOST side under AddressSanitizer (device code as usual); tests/tools/asan_abi_paths.py then
+    drives the argument-validation and error paths of the entry points through it in a fresh interpreter (LD_PRELOAD of the ASan
+    runtime).  No GPU needed: every call must come back with an error code and ASan must stay silent."""
+    import subprocess, sys
+    rt, lib = _asan_env()
+    r = subprocess.run(["make", "-C", os.path.join(REPO, "columbiaimagesearch_amd", "csrc"), "asan", "-j4"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=1500)
+    assert r.returncode == 0 and os.path.exists(lib), r.stdout.decode()[-2000:]
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23", CIS_LIB_PATH=lib)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "tools", "asan_abi_paths.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    text = r.stdout.decode()
+    assert r.returncode == 0 and "asan abi paths ok" in text and "AddressSanitizer" not in text, text[-3000:]
+
+
+@pytest.mark.gpu
+def test_asan_host_shim_through_a_real_life_cycle():
+    """The same library on a GPU: encode, inserts (bulk, duplicates, in place), every scan route, limit = quota, the asynchronous host
+    entry points on a view, close order -- real workspace bookkeeping under AddressSanitizer."""
+    import subprocess, sys
+    rt, lib = _asan_env()
+    if not os.path.exists(lib):
+        pytest.skip("libcis_hip_asan.so was not built (make -C columbiaimagesearch_amd/csrc asan)")
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23:protect_shadow_gap=0", CIS_LIB_PATH=lib)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "tools", "asan_abi_paths.py"), "gpu"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900)
+    text = r.stdout.decode()
+    assert r.returncode == 0 and "gpu life cycle ok" in text and "asan abi paths ok" in text and "AddressSanitizer" not in text, text[-3000:]
