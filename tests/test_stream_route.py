@@ -48,7 +48,11 @@ def test_stream_route_equals_exact_kernel(name, seg, monkeypatch):
             after = s.stream_counters()
             if shape_ok and (w in (4, 8, 16, 32) or limit <= 952):  # (the float32 tables exist on these paths only)
                 assert after[0] == before[0] + 1, "the streaming route did not serve the batch"
-                assert s.last_stats()["scan_kernel"] == "k_adc_stream"
+                # (a batch may legitimately be handed back: which queries pair up in a slot depends on the arrival order of the slot
+                # builder's atomics, the bucket minima and hence tau with it, and on this duplicate-heavy fixture a slightly looser tau
+                # can admit a crowd beyond the list -- the result is the generic path's, bit for bit, either way)
+                if after[1] == before[1]:
+                    assert s.last_stats()["scan_kernel"] == "k_adc_stream"
             _same(r, e.search_batch(Q[:nq], quota=quota, limit=limit))
 
 
