@@ -737,6 +737,93 @@ __global__ __launch_bounds__(256) void k_conv7x7s2_direct(const float* __restric
     }
 }
 
+// First layer + max_pool<3,3,2,2> in one kernel (round 5).  The separate pool pass read the 170 MB the convolution had just written
+// (44 us per 256 chips behind a 135 us convolution whose own stores were a third of its time).  A workgroup now owns THREE pooled rows of
+// one image = the seven convolution rows 2 Y0 .. 2 Y0 + 6 (504 pixels: sixteen 32-pixel tiles, the last one three quarters used; one
+// row in seven is computed by two workgroups), keeps the four accumulators of each wave in registers until every wave has finished with
+// the staged input window, writes bias + ReLU'd convolution values OVER the window (7 x 72 x 32 floats = 64.5 KB: two workgroups per
+// CU), and pools from there: only the 35 x 35 x 32 pooled map leaves the CU (40 MB per 256 chips instead of 170 MB out + 170 MB in).
+// Same products in the same order as k_conv7x7s2_direct, and max is exact: bit-identical to the two-kernel route.
+__global__ __launch_bounds__(256) void k_conv7x7s2_pool(const float* __restrict__ in /* [n][150][150][3] raw RGB */,
+                                                        const float* __restrict__ wpk /* [196][32]: k = ky * 28 + kx * 4 + c */,
+                                                        const float* __restrict__ bias /* [32] */, float* __restrict__ out /* [n][35][35][32] */,
+                                                        int n, float m0, float m1, float m2) {
+    constexpr int IW = 150, OW = 72, PW = 35, ROWF = IW * 3;
+    constexpr int KSTEPS = 74, GROUPS = 12, CONVR = 7;
+    __shared__ float buf[CONVR * OW * 32];   // first the input window (<= 19 rows of 450 floats), then the convolution rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int img = blockIdx.x / GROUPS, grp = blockIdx.x % GROUPS;
+    const int Y0 = 3 * grp;
+    const int npool = PW - Y0 < 3 ? PW - Y0 : 3;
+    const int nconv = 2 * npool + 1, r0 = 2 * Y0;
+    const int nrows = 2 * (nconv - 1) + 7;   // input rows 2 r0 .. 2 (r0 + nconv - 1) + 6
+    float w[KSTEPS];
+    {
+        const int oc = lane & 31, kh = lane >> 5;
+#pragma unroll
+        for (int s2 = 0; s2 < KSTEPS; ++s2) {
+            const int k = 2 * s2 + kh;
+            const int ky = k / 21, rem = k - ky * 21, kx = rem / 3, cc = rem - kx * 3;
+            w[s2] = k < 147 ? wpk[(ky * 28 + kx * 4 + cc) * 32 + oc] : 0.f;
+        }
+    }
+    {
+        const float* src = in + ((int64_t)img * IW + 2 * r0) * ROWF;
+        const int tot = nrows * ROWF;
+        for (int e = tid; e < tot; e += 256) {
+            const int cc = e % 3;
+            const float mean = cc == 0 ? m0 : (cc == 1 ? m1 : m2);
+            buf[e] = (src[e] - mean) * (1.0f / 256.0f);
+        }
+    }
+    __syncthreads();
+    const float bv = bias[lane & 31];
+    f32x16 acc[4];   // tiles wave, wave + 4, wave + 8, wave + 12
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int p = (wave + 4 * t) * 32 + (lane & 31);   // pixel of the group's 512 (rows past nconv read in-bounds garbage: discarded below)
+        const int oy = p / OW, ox = p - oy * OW;
+        const float* a0 = buf + (2 * oy) * ROWF + 6 * ox + (lane >> 5);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < KSTEPS; ++s2) {
+            const int k = 2 * s2;
+            const int off = (k / 21) * ROWF + (k % 21);
+            const bool row_end = (k % 21) == 20;
+            float av = row_end ? a0[off + (lane >> 5) * (ROWF - 21)] : a0[off];
+            if (k + 1 >= 147) av = (lane >> 5) ? 0.f : av;
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w[s2], acc[t], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // every wave is done with the window
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int p = (wave + 4 * t) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            const float v = acc[t][q] + bv;
+            if (p < nconv * OW) buf[p * 32 + (lane & 31)] = v > 0.f ? v : 0.f;
+        }
+    }
+    __syncthreads();
+    const int tot = npool * PW * 32;
+    float* o = out + ((int64_t)img * PW + Y0) * PW * 32;
+    for (int e = tid; e < tot; e += 256) {
+        const int c = e & 31, x = (e >> 5) % PW, y = (e >> 5) / PW;
+        const float* q = buf + ((2 * y) * OW + 2 * x) * 32 + c;
+        float mx = q[0];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const float v = q[(dy * OW + dx) * 32];
+                mx = v > mx ? v : mx;
+            }
+        o[e] = mx;
+    }
+}
+
 // avg_pool<2,2,2,2>, no padding, output floor((H-2)/2)+1
 __global__ void k_avgpool2_nhwc(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C, int OH, int OW) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1191,6 +1278,13 @@ static int cnn_forward_dlib(cis_cnn* c, CnnWs* ws, const float* d_in, int n, flo
     float* T1 = ws->act2.as<float>();
     float* T2 = ws->act3.as<float>();
     auto grid = [](int64_t total) { return dim3((unsigned)ceil_div(total, 256)); };
+    bool pooled = false;
+    if (!getenv("CIS_CNN_NO_DIRECT7") && !getenv("CIS_CNN_NO_POOL7")) {
+        // first layer AND the max pool behind it in one kernel (k_conv7x7s2_pool, round 5): the pooled 35 x 35 x 32 map goes to A
+        hipLaunchKernelGGL(k_conv7x7s2_pool, dim3((unsigned)n * 12), dim3(256), 0, st, d_in, (const float*)c->dl[0].d_w, (const float*)c->dl[0].d_b, A, n,
+                           122.782f, 117.001f, 104.298f);
+        pooled = true;
+    } else
     if (!getenv("CIS_CNN_NO_DIRECT7")) {
         // first layer: direct 7 x 7 / 2 convolution, normalisation + bias + ReLU fused (k_conv7x7s2_direct)
         // tiles per wave (the staged window and the weight registers serve 4 x that many tiles): 1 / 2 / 4 -> 161 / 141 / 133 us per 256 chips, forward 1.97 / 1.92 / 1.90 ms (profiles/r03r_dlib_first_layer.txt)
@@ -1215,7 +1309,7 @@ static int cnn_forward_dlib(cis_cnn* c, CnnWs* ws, const float* d_in, int n, flo
         launch_conv(d0, A, c->dl[0].d_w, c->dl[0].d_b, B, st);  // 72 x 72 x 32, affine folded, relu
     }
     int H = (72 - 3) / 2 + 1, W = H, C = 32;                  // max_pool<3,3,2,2>: 35
-    hipLaunchKernelGGL(k_maxpool_nhwc_v4, grid((int64_t)n * H * W * C / 4), dim3(256), 0, st, B, A, n, 72, 72, C, H, W);
+    if (!pooled) hipLaunchKernelGGL(k_maxpool_nhwc_v4, grid((int64_t)n * H * W * C / 4), dim3(256), 0, st, B, A, n, 72, 72, C, H, W);
     float* x = A;      // current activation
     float* other = B;  // free buffer for the next activation
     for (int i = 0; i < 14; ++i) {

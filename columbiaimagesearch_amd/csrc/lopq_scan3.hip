@@ -482,8 +482,8 @@ __device__ __forceinline__ void scan3_group(const WorkItem* __restrict__ items, 
             float4 v[G][2];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                v[g][0] = reinterpret_cast<const float4*>(T32 + (int64_t)tab0[g] * nf * K)[e];
-                v[g][1] = reinterpret_cast<const float4*>(T32 + (int64_t)tab1[g] * nf * K)[e];
+                v[g][0] = tab_f4(T32, T, tab0[g], nf * K, e);
+                v[g][1] = tab_f4(T32, T, tab1[g], nf * K, e);
             }
             const int j = (4 * e) / K, k0 = 4 * e - j * K;
 #pragma unroll
@@ -1172,7 +1172,8 @@ static size_t scan4_lds(int M, int K, int lcap, int nw) {
 template <int M, int U, int NW, int WPE, int LCAPT>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_adc_scan4(
     const WorkItem* __restrict__ items, const TabDesc* __restrict__ tabs, const int* __restrict__ slots,
-    const int* __restrict__ n_slots_ptr, const float* __restrict__ T32, const uint8_t* __restrict__ codes, int K, int L, int S,
+    const int* __restrict__ n_slots_ptr, const float* __restrict__ T32 /* null: converted from T */, const double* __restrict__ T,
+    const uint8_t* __restrict__ codes, int K, int L, int S,
     int* __restrict__ dbg /* [2]: slots, fallbacks */, int* __restrict__ fhdr /* fall-back list: [17] = count (queue 0 of a scan3 header) */,
     int* __restrict__ fslots, uint64_t* __restrict__ item_surv, int* __restrict__ item_n, float* __restrict__ item_slack,
     unsigned long long* __restrict__ qbound, float zq /* sample rank margin: k - zq sqrt(k) */, int frac_den /* sample one row in frac_den */,
@@ -1364,17 +1365,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                         const int g = w;
                         if (g < ng) {  // wave-uniform
                             const int t0 = __builtin_amdgcn_readfirstlane(d->tab0[g]), t1 = __builtin_amdgcn_readfirstlane(d->tab1[g]);
-                            const float* Ta = T32 + (int64_t)t0 * nf * K;
-                            const float* Tb = T32 + (int64_t)t1 * nf * K;
+                            const int64_t Ta = (int64_t)t0 * nf * K, Tb = (int64_t)t1 * nf * K;
                             const int c = len >= 64 ? (int)(((int64_t)lane * len) >> 6) : lane;
                             uint32_t key = 0x7f7fffffu;
                             if (c < len) {
                                 const CodeWords<M> cw = load_code<M>(codes, start + c);
                                 float ds = 0.f;
 #pragma unroll
-                                for (int j = 0; j < M / 2; ++j) ds += Ta[j * K + ((cw.w[j >> 2] >> (8 * (j & 3))) & 255u)];
+                                for (int j = 0; j < M / 2; ++j) ds += tab_f1(T32, T, Ta + j * K + ((cw.w[j >> 2] >> (8 * (j & 3))) & 255u));
 #pragma unroll
-                                for (int j = 0; j < M / 2; ++j) ds += Tb[j * K + ((cw.w[(M / 2 + j) >> 2] >> (8 * ((M / 2 + j) & 3))) & 255u)];
+                                for (int j = 0; j < M / 2; ++j) ds += tab_f1(T32, T, Tb + j * K + ((cw.w[(M / 2 + j) >> 2] >> (8 * ((M / 2 + j) & 3))) & 255u));
                                 key = __float_as_uint(fmaxf(ds, 0.f));  // (entries are >= 0: the bit patterns order like the values)
                             }
                             // rank of the sample that stands for "just above the limit-th candidate": 4 + the sample's share of the limit
@@ -1419,8 +1419,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const int t0 = __builtin_amdgcn_readfirstlane(d->tab0[g]), t1 = __builtin_amdgcn_readfirstlane(d->tab1[g]);
-                        pv[g][0] = reinterpret_cast<const float4*>(T32 + (int64_t)t0 * nf * K)[vidx];
-                        pv[g][1] = reinterpret_cast<const float4*>(T32 + (int64_t)t1 * nf * K)[vidx];
+                        pv[g][0] = tab_f4(T32, T, t0, nf * K, vidx);
+                        pv[g][1] = tab_f4(T32, T, t1, nf * K, vidx);
                     }
                     uint32_t* tw = reinterpret_cast<uint32_t*>(tab);
 #pragma unroll
@@ -2130,7 +2130,7 @@ static size_t scan5_lds(int M, int K) { return (size_t)K * M * S5G * 2 + (size_t
 template <int M, bool SAMPLE, int WPE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_adc_scan5(
     const WorkItem* __restrict__ items, const TabDesc* __restrict__ tabs, const int* __restrict__ slots, const int* __restrict__ n_slots_ptr,
-    const float* __restrict__ T32, const uint8_t* __restrict__ codes, int K, int S,
+    const float* __restrict__ T32 /* null: converted from T */, const double* __restrict__ T, const uint8_t* __restrict__ codes, int K, int S,
     const float* __restrict__ tau, uint32_t* __restrict__ bmin, int B, int* __restrict__ nsamp, int ss,
     uint64_t* __restrict__ item_surv, int* __restrict__ item_n, float* __restrict__ item_slack, int* __restrict__ cnt_ok, int* __restrict__ ovf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2221,7 +2221,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const int tb = __builtin_amdgcn_readfirstlane(s2 ? sd->tab1[g] : sd->tab0[g]);
-                        pv[g] = reinterpret_cast<const float4*>(T32 + (int64_t)tb * nf * K)[vidx];
+                        pv[g] = tab_f4(T32, T, tb, nf * K, vidx);
                     }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -2489,11 +2489,11 @@ static void launch_scan5_t(const Scan3Geom& g, int64_t n_items, int nq, hipStrea
     static const int P_env = getenv("CIS_S5_P") ? atoi(getenv("CIS_S5_P")) : 0;
     static const int ss_env = getenv("CIS_S5_SS") ? atoi(getenv("CIS_S5_SS")) : 4;
     const int P = P_env > 0 ? P_env : (L < 100 ? 240 : (int)(2.4 * L));
-    hipLaunchKernelGGL((k_adc_scan5<M, true, WPE>), dim3(grid), dim3(256), lds, st, items, tabs, slots, n_slots, T32, codes, K, g.S, (const float*)nullptr, bmin,
+    hipLaunchKernelGGL((k_adc_scan5<M, true, WPE>), dim3(grid), dim3(256), lds, st, items, tabs, slots, n_slots, T32, T, codes, K, g.S, (const float*)nullptr, bmin,
                        S5_B, nsamp, ss_env, hits, hitn, slack, cnt_ok, ovf);
     hipLaunchKernelGGL(k_scan5_tau<S5_B / 64>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, bmin, S5_B, nsamp, plan, nq, P, tau);
     if (ev_main) (void)hipEventRecord(ev_main, st);
-    hipLaunchKernelGGL((k_adc_scan5<M, false, WPE>), dim3(grid), dim3(256), lds, st, items, tabs, slots, n_slots, T32, codes, K, g.S, tau, bmin, S5_B, nsamp,
+    hipLaunchKernelGGL((k_adc_scan5<M, false, WPE>), dim3(grid), dim3(256), lds, st, items, tabs, slots, n_slots, T32, T, codes, K, g.S, tau, bmin, S5_B, nsamp,
                        ss_env, hits, hitn, slack, cnt_ok, ovf);
     const int64_t max_slots = n_items + 8;  // (an upper bound of the slot count: the kernel reads the real one)
     hipLaunchKernelGGL(k_scan5_check, dim3((unsigned)((max_slots + 255) / 256)), dim3(256), 0, st, slots, n_slots, items, plan, cnt_ok, ovf, L, fhdr, fslots, hitn,
@@ -2602,11 +2602,11 @@ static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, 
                 if (nw4_short == 8 && M != 16) {
                     const size_t lds4 = scan4_lds(M, K, S4_LCAP, 8);
                     hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_U, 8, WPE4, S4_LCAP>), dim3(grid_of(lds4, WPE4, 8)), dim3(8 * 64), lds4, st, items, tabs, slots,
-                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_short, 1 << 20, S4_NS, 0, g.sat);
+                                       n_slots, T32, T, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_short, 1 << 20, S4_NS, 0, g.sat);
                 } else {
                     const size_t lds4 = scan4_lds(M, K, S4_LCAP, NW);
                     hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_U, NW, WPE4, S4_LCAP>), dim3(grid_of(lds4, WPE4, NW)), dim3(NW * 64), lds4, st, items, tabs, slots,
-                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_short, 1 << 20, S4_NS, 0, g.sat);
+                                       n_slots, T32, T, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_short, 1 << 20, S4_NS, 0, g.sat);
                 }
             } else {
                 constexpr int WPE4 = (M == 16) ? 3 : ((CIS_S4_DEFER != 0 && CIS_S4_GLISTS != 0) ? CIS_S4_WPE_LONG : 4);  // (M = 16: 49 KB of LDS = three workgroups per CU, 168 registers)
@@ -2614,11 +2614,11 @@ static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, 
                     constexpr int WPE8 = CIS_S4_WPE8;
                     const size_t lds4 = scan4_lds(M, K, S4_LCAP_LONG, 8);
                     hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_UL, 8, WPE8, S4_LCAP_LONG>), dim3(grid_of(lds4, WPE8, 8)), dim3(8 * 64), lds4, st, items, tabs, slots,
-                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_long, frac_long, nsx_long, dyn_long, g.sat);
+                                       n_slots, T32, T, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_long, frac_long, nsx_long, dyn_long, g.sat);
                 } else {
                     const size_t lds4 = scan4_lds(M, K, S4_LCAP_LONG, NW);
                     hipLaunchKernelGGL((k_adc_scan4<M, CIS_S4_UL, NW, WPE4, S4_LCAP_LONG>), dim3(grid_of(lds4, WPE4, NW)), dim3(NW * 64), lds4, st, items, tabs, slots,
-                                       n_slots, T32, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_long, frac_long, nsx_long, dyn_long, g.sat);
+                                       n_slots, T32, T, codes, K, L, g.S, dbg4, fhdr, fslots, hits, hitn, slack, qbound, z_long, frac_long, nsx_long, dyn_long, g.sat);
                 }
             }
             if (getenv("CIS_SCAN4_DEBUG")) {  // diagnosis: how many slots the sample misjudged (blocks)

@@ -1278,7 +1278,7 @@ __global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict
         const float v32 = (float)v;
         if (on) {
             T[((int64_t)(t0 + t) * nf + j) * K + k] = v;
-            T32[((int64_t)(t0 + t) * nf + j) * K + k] = v32;
+            if (T32) T32[((int64_t)(t0 + t) * nf + j) * K + k] = v32;  // (null: the scans convert the float64 entries themselves, see tab_f4)
         }
         // largest float32 entry of the table (entries are >= 0: the bit patterns order like the values), for the
         // fixed-point scan's scale (lopq_scan3.hip); TabDesc::pad was zeroed when the descriptor was written
@@ -2145,8 +2145,8 @@ __device__ __forceinline__ void scan2_group(const WorkItem* __restrict__ items_a
             for (int g = 0; g < G; ++g) {
                 const bool on = (g < ng) && (e < nvec);  // an absent second query gets +inf tables: nothing ever passes
                 const int eg = e < nvec ? e : 0;
-                v[g][0] = reinterpret_cast<const float4*>(T32 + (int64_t)it_tab0[g] * nf * K)[eg];
-                v[g][1] = reinterpret_cast<const float4*>(T32 + (int64_t)it_tab1[g] * nf * K)[eg];
+                v[g][0] = tab_f4(T32, T, it_tab0[g], nf * K, eg);
+                v[g][1] = tab_f4(T32, T, it_tab1[g], nf * K, eg);
                 if (!on) { v[g][0] = make_float4(INF, INF, INF, INF); v[g][1] = v[g][0]; }
             }
             if (e < nvec) {
@@ -4822,8 +4822,13 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     int* tab_order = ix->w_tord.as<int>();  // table indices grouped by (split, cluster)
     double* T = ix->w_T.as<double>();
     // tiny cells: the float32 copy of px for k_tiny_select lives here (no tables on that path)
-    CIS_TRY(ix->w_T32.reserve(direct_elig ? (size_t)(n_tabs + 1) * h * sizeof(float) : (size_t)(n_tabs + 1) * nf * K * sizeof(float)));
-    float* T32 = ix->w_T32.as<float>();
+    // The float32 copy of the tables is a third of what the tables kernel writes (8 + 4 bytes per entry: 402 MB per C2 batch, and that
+    // kernel is bound by its writes); CIS_NO_T32=1 drops it -- the scans then convert the float64 entries while they stage them
+    // (tab_f4: the same bits).  The tiny-cell path keeps its float32 px copy in this buffer.
+    static const bool no_t32 = getenv("CIS_NO_T32") != nullptr && atoi(getenv("CIS_NO_T32")) != 0;
+    const bool drop_t32 = no_t32 && !direct_elig && (m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) && K <= 256;
+    if (!drop_t32) CIS_TRY(ix->w_T32.reserve(direct_elig ? (size_t)(n_tabs + 1) * h * sizeof(float) : (size_t)(n_tabs + 1) * nf * K * sizeof(float)));
+    float* T32 = drop_t32 ? nullptr : ix->w_T32.as<float>();
     const size_t tab_lds = (size_t)(2 * h + (h < 256 ? 256 : 0)) * sizeof(double);
     const bool split_tables = (m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) && K <= 256;
     double* px_buf = nullptr;
@@ -4937,12 +4942,12 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         kth = kth < 8 ? 8 : (kth > B / 4 ? B / 4 : kth);
         if (ix->force_stream && getenv("CIS_STREAM_SS")) { ss = atoll(getenv("CIS_STREAM_SS")); kth = getenv("CIS_STREAM_K") ? atoll(getenv("CIS_STREAM_K")) : kth; }  // tests
         const int grid = stream_grid(M, G, K, max_slots);
-        launch_stream_scan(M, G, true, grid, st, items, slots, n_slots, T32, codes, K, cand_start, seg, tau, bmin, B, (int)ss, surv, cnt, cap);
+        launch_stream_scan(M, G, true, grid, st, items, slots, n_slots, T32, T, codes, K, cand_start, seg, tau, bmin, B, (int)ss, surv, cnt, cap);
         launch_stream_tau(st, bmin, B, (int)kth, nq, tau);
         CIS_TRY(mark(5));
         pr.has_scan = true;
         ix->last_scan_kernel = 5;
-        launch_stream_scan(M, G, false, grid, st, items, slots, n_slots, T32, codes, K, cand_start, seg, tau, bmin, B, (int)ss, surv, cnt, cap);
+        launch_stream_scan(M, G, false, grid, st, items, slots, n_slots, T32, T, codes, K, cand_start, seg, tau, bmin, B, (int)ss, surv, cnt, cap);
         CIS_TRY(mark(3));
         launch_stream_keys(M, st, items, cand_start, seg, item_off, n_items, T, codes, K, surv, cnt, cap, nq, skeys, qmin, qmax);
         hipLaunchKernelGGL((k_select_topl<true, 1024>), dim3((unsigned)nq), dim3(1024), sp.lds, st, skeys, seg, cand_start, item_off, qmin, qmax, n_items, L, sp.p2,

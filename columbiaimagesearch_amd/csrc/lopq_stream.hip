@@ -45,7 +45,8 @@ __global__ void k_stream_init(uint32_t* __restrict__ bmin, int64_t n_b, int* __r
 // cell for up to G queries (the slot builder of lopq_search.hip groups the work items of a cell chunk).
 template <int M, int G, bool SAMPLE>
 __global__ __launch_bounds__(256) void k_adc_stream(const WorkItem* __restrict__ items, const int* __restrict__ slots, const int* __restrict__ n_slots,
-                                                    const float* __restrict__ T32, const uint8_t* __restrict__ codes, int K,
+                                                    const float* __restrict__ T32 /* null: converted from T */, const double* __restrict__ T,
+                                                    const uint8_t* __restrict__ codes, int K,
                                                     const int64_t* __restrict__ cand_start, const int64_t* __restrict__ seg,
                                                     const float* __restrict__ tau, uint32_t* __restrict__ bmin, int B, int sample_stride,
                                                     uint32_t* __restrict__ surv, int* __restrict__ cnt, int cap) {
@@ -93,12 +94,11 @@ __global__ __launch_bounds__(256) void k_adc_stream(const WorkItem* __restrict__
             rbase[g] = on ? (uint32_t)(cand_start[ii[g]] - seg[it.q]) : 0u;
             tg[g] = (on && !SAMPLE) ? tau[it.q] : -1.0f;
             // tables: thread t stages entries k = t, t + 256, ... of every sub-quantizer (coalesced reads of T32[tab][j][k])
-            const float* t0 = T32 + (int64_t)it.tab0 * nf * K;
-            const float* t1 = T32 + (int64_t)it.tab1 * nf * K;
+            const int64_t t0 = (int64_t)it.tab0 * nf * K, t1 = (int64_t)it.tab1 * nf * K;
             for (int k = tid; k < K; k += 256) {
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
-                    const float e = on ? (j < nf ? t0[j * K + k] : t1[(j - nf) * K + k]) : 0.f;
+                    const float e = on ? (j < nf ? tab_f1(T32, T, t0 + j * K + k) : tab_f1(T32, T, t1 + (j - nf) * K + k)) : 0.f;
 #pragma unroll
                     for (int c = 0; c < R; ++c) s_tab[(((size_t)k * R + c) * M + j) * G + g] = e;
                 }
@@ -343,21 +343,21 @@ bool stream_supported(int M, int K, int L) { return (M == 4 || M == 8 || M == 16
 size_t stream_lds(int M, int K, int G) { return CIS_STREAM_REPL ? (size_t)K * 128 : (size_t)K * M * G * sizeof(float); }
 
 template <int M, int G, bool SAMPLE>
-static void launch_stream_t(int grid, hipStream_t st, const WorkItem* items, const int* slots, const int* n_slots, const float* T32,
+static void launch_stream_t(int grid, hipStream_t st, const WorkItem* items, const int* slots, const int* n_slots, const float* T32, const double* T,
                             const uint8_t* codes, int K, const int64_t* cand_start, const int64_t* seg, const float* tau, uint32_t* bmin, int B,
                             int sample_stride, uint32_t* surv, int* cnt, int cap) {
-    hipLaunchKernelGGL((k_adc_stream<M, G, SAMPLE>), dim3((unsigned)grid), dim3(256), stream_lds(M, K, G), st, items, slots, n_slots, T32, codes, K,
+    hipLaunchKernelGGL((k_adc_stream<M, G, SAMPLE>), dim3((unsigned)grid), dim3(256), stream_lds(M, K, G), st, items, slots, n_slots, T32, T, codes, K,
                        cand_start, seg, tau, bmin, B, sample_stride, surv, cnt, cap);
 }
 
 void launch_stream_scan(int M, int G, bool sample, int grid, hipStream_t st, const WorkItem* items, const int* slots, const int* n_slots,
-                        const float* T32, const uint8_t* codes, int K, const int64_t* cand_start, const int64_t* seg, const float* tau,
+                        const float* T32, const double* T, const uint8_t* codes, int K, const int64_t* cand_start, const int64_t* seg, const float* tau,
                         uint32_t* bmin, int B, int sample_stride, uint32_t* surv, int* cnt, int cap) {
 #define CIS_STREAM(MM, GG)                                                                                                              \
     if (M == MM && G == GG) {                                                                                                           \
-        if (sample) launch_stream_t<MM, GG, true>(grid, st, items, slots, n_slots, T32, codes, K, cand_start, seg, tau, bmin, B,         \
+        if (sample) launch_stream_t<MM, GG, true>(grid, st, items, slots, n_slots, T32, T, codes, K, cand_start, seg, tau, bmin, B,         \
                                                   sample_stride, surv, cnt, cap);                                                       \
-        else launch_stream_t<MM, GG, false>(grid, st, items, slots, n_slots, T32, codes, K, cand_start, seg, tau, bmin, B,               \
+        else launch_stream_t<MM, GG, false>(grid, st, items, slots, n_slots, T32, T, codes, K, cand_start, seg, tau, bmin, B,               \
                                             sample_stride, surv, cnt, cap);                                                             \
         return;                                                                                                                         \
     }

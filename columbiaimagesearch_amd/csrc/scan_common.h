@@ -227,6 +227,19 @@ __device__ __forceinline__ CodeWords<M> load_code_buf(__amdgpu_buffer_rsrc_t rs,
     return c;
 }
 
+// Four consecutive float32 table entries (float4 number e4 of half table `tab`, nfK entries per half table): from the float32 copy when
+// the batch has one, else converted from the float64 tables (round 5: the copy is a third of the tables kernel's writes -- 402 MB per C2
+// batch -- and (float)T is the value the copy holds, so the scans see the same bits either way).
+static __device__ __forceinline__ float4 tab_f4(const float* __restrict__ T32, const double* __restrict__ T, int64_t tab, int nfK, int e4) {
+    if (T32) return reinterpret_cast<const float4*>(T32 + tab * nfK)[e4];
+    const double2* p = reinterpret_cast<const double2*>(T + tab * nfK) + 2 * e4;
+    const double2 a = p[0], b = p[1];
+    return make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+}
+static __device__ __forceinline__ float tab_f1(const float* __restrict__ T32, const double* __restrict__ T, int64_t idx) {
+    return T32 ? T32[idx] : (float)T[idx];
+}
+
 // ---- ADC scan v3 (lopq_scan3.hip): 16-bit fixed-point tables, four queries per workgroup ---------------------------
 struct Scan3Geom { int G, NW, U, S, two_pass, long_chunks; size_t lds;
                    float sat = 0.f; };  // > 0: the sampled form's SATURATING scale (M = 16) -- see k_adc_scan4
@@ -245,7 +258,7 @@ bool stream_supported(int M, int K, int L);
 int stream_grid(int M, int G, int K, int64_t max_slots);
 void launch_stream_init(hipStream_t st, uint32_t* bmin, int64_t n_b, int* cnt, int nq, int* status);
 void launch_stream_scan(int M, int G, bool sample, int grid, hipStream_t st, const WorkItem* items, const int* slots, const int* n_slots,
-                        const float* T32, const uint8_t* codes, int K, const int64_t* cand_start, const int64_t* seg, const float* tau,
+                        const float* T32, const double* T, const uint8_t* codes, int K, const int64_t* cand_start, const int64_t* seg, const float* tau,
                         uint32_t* bmin, int B, int sample_stride, uint32_t* surv, int* cnt, int cap);
 void launch_stream_tau(hipStream_t st, const uint32_t* bmin, int B, int k, int nq, float* tau);
 void launch_stream_keys(int M, hipStream_t st, const WorkItem* items, const int64_t* cand_start, const int64_t* seg, const int64_t* item_off,

@@ -220,6 +220,26 @@ def test_dlib_direct_first_layer_agrees_with_implicit_gemm(monkeypatch):
     net.close()
 
 
+def test_dlib_first_layer_with_the_max_pool_inside_equals_the_two_kernels(monkeypatch):
+    """k_conv7x7s2_pool (round 5: the 7 x 7 / 2 convolution and max_pool<3,3,2,2> in one kernel, pooled from LDS) against
+    k_conv7x7s2_direct + k_maxpool_nhwc_v4 (CIS_CNN_NO_POOL7): the same products in the same order and an exact max -- the descriptors
+    are bit-identical; batch sizes that end inside a workgroup's image range, a chip's descriptor independent of its place."""
+    from oracle import dlib_oracle as D
+    from columbiaimagesearch_amd.featurizer import DLibFaceNet
+    w = D.synthetic_weights(13)
+    net = DLibFaceNet(w)
+    for n, seed in ((1, 1), (3, 2), (34, 3)):
+        chips = D.synthetic_chips(n, seed=seed)
+        monkeypatch.setenv("CIS_CNN_NO_POOL7", "1")
+        ref = net.forward(chips)
+        monkeypatch.delenv("CIS_CNN_NO_POOL7")
+        got = net.forward(chips)
+        assert np.isfinite(got).all()
+        np.testing.assert_array_equal(got, ref)
+        np.testing.assert_array_equal(net.forward(chips[n - 1:n])[0], got[n - 1])
+    net.close()
+
+
 def test_dlib_fused_tail_agrees_with_the_six_launches_it_replaces(monkeypatch):
     """k_dlib_tail (round 5: the last block's second convolution -- its centre tap, all a 1 x 1 map ever meets --, pooled skip branch,
     add_prev, ReLU, global average and fc_no_bias in one launch) against the separate launches (CIS_CNN_NO_TAIL) and the CPU
