@@ -33,6 +33,11 @@ struct ConvDesc {
                              // float4 of contiguous NHWC input (KW*C floats, zero-weight padded), k = ky*4*runq + (kx*C + ic)
     const float* res = nullptr;  // residual input [npix][resC] added before the ReLU (channels >= resC get nothing): dlib add_prev
     int resC = 0;
+    int run_planes = 0;      // > 0 (with runq): the runs are taken from the caller's NCHW planes directly -- run r = ic * KH + ky is the KW
+                             // contiguous floats of channel plane ic, row iy0 + ky, from column ix0 (runq float4, the tail meets zero
+                             // weights), k = r * 4 * runq + kx; run_planes = ICg * KH runs; in_elems = floats in the input (the last
+                             // float4 of the last run would end past it: it is loaded one to three floats earlier and shifted)
+    int64_t in_elems = 0;
 };
 
 // C[pixel][oc] = sum_k A[pixel][k] * Wp[k][oc] + bias[oc]; block tile BM x BN, 256 threads = 4 waves laid
@@ -41,12 +46,13 @@ struct ConvDesc {
 // written to the other LDS buffer after them (one barrier per stage).
 // VEC = channels-last input with ICg % 16 == 0: a stage covers 16 consecutive input channels of ONE kernel tap,
 // so every thread fetches float4s along the channel axis and the tap decode is wave-uniform.
-// MODE: 0 = scalar gather, 1 = VEC, 2 = VEC with the row-run gather of the 3-channel first layers (ConvDesc::runq) -- a template
+// MODE: 0 = scalar gather, 1 = VEC, 2 = VEC with the row-run gather of the 3-channel first layers (ConvDesc::runq), 3 = the run gather
+// over NCHW planes (ConvDesc::run_planes) -- a template
 // parameter since round 4: as a run-time branch inside the fetch it made the compiler emit both gathers with a wait between them.
 template <int WM, int WN, int WAVES_M, int WAVES_N, int MODE>
-__global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in, const float* __restrict__ Wp,
+__global__ __launch_bounds__(256, 4) void k_conv_igemm(const float* __restrict__ in, const float* __restrict__ Wp,
                                                     const float* __restrict__ bias, float* __restrict__ out, ConvDesc d) {
-    constexpr bool VEC = MODE != 0, RUN = MODE == 2;
+    constexpr bool VEC = MODE != 0, RUN = MODE >= 2, PLANES = MODE == 3;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, BK = 16;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -114,10 +120,17 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
             while (ic >= d.ICg) { ic -= d.ICg; if (++kx == d.KW) { kx = 0; ++ky; } }
         }
     }
+    int run_r = 0, run_jq = 0, run_ic = 0, run_ky = 0;  // RUN: this thread's float4 of the stage = quad run_jq of run run_r = (run_ic, run_ky)
+    if constexpr (RUN) {
+        const int kq0 = kt_begin * 4 + (tid & 3);
+        run_r = kq0 / d.runq; run_jq = kq0 - run_r * d.runq;
+        run_ic = run_r / d.KH; run_ky = run_r - run_ic * d.KH;
+    }
     float4 ra[VEC ? A_VEC : 1];
     float rs[VEC ? 1 : A_SCL];
     float4 rb[B_VEC];
     bool okA[VEC ? A_VEC : 1], okB[B_VEC];
+    int shA[PLANES ? A_VEC : 1];
     // The fetch of the vector path is ONLY loads (round 4): every address is clamped into the arrays, the loads are unconditional and
     // nothing touches their registers before the stage's MFMAs are issued; what is padding, past the tile or past K is zeroed when
     // the registers go to LDS (okA / okB).  With `if (inside) load` the compiler built a branch per load and waited for each load
@@ -126,16 +139,32 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
         const int k0 = kt * BK;
         if constexpr (VEC) {
             if constexpr (RUN) {
-                // this thread's float4 along K: kernel row ky, quad jq of that row's contiguous run (no padding: pad == 0)
-                const int kq = kt * 4 + (tid & 3);
-                const int rky = kq / d.runq, jq = kq - rky * d.runq;
+                // this thread's float4 along K: run r (kernel row ky of the NHWC rows, or (channel plane, kernel row) of the NCHW planes),
+                // quad jq of that run's contiguous floats (no padding: pad == 0)
+                // (the run decode is carried from stage to stage: as kq / runq and r / KH per stage the two integer divisions were a
+                // fifth of the first layer's instructions)
+                const int r = run_r, jq = run_jq, ric = run_ic, rky = run_ky;
+                const int nruns = PLANES ? d.run_planes : d.KH;
+                run_jq += 4;
+                while (run_jq >= d.runq) {
+                    run_jq -= d.runq; ++run_r;
+                    if (++run_ky == d.KH) { run_ky = 0; ++run_ic; }
+                }
 #pragma unroll
                 for (int i = 0; i < A_VEC; ++i) {
                     const int iy = iy0[i] + rky;
-                    okA[i] = mloc[i] < BM && rky < d.KH && iy >= 0 && iy < d.H;
+                    okA[i] = mloc[i] < BM && r < nruns && iy >= 0 && iy < d.H;
                     const int iyc = iy < 0 ? 0 : (iy < d.H ? iy : d.H - 1);
                     const int ixc = ix0[i] < 0 ? 0 : ix0[i];
-                    ra[i] = *reinterpret_cast<const float4*>(in + pbase[i] + (int64_t)iyc * d.sH + (int64_t)ixc * d.sW + jq * 4);
+                    if constexpr (PLANES) {
+                        const int64_t off = pbase[i] + (int64_t)(r < nruns ? ric : 0) * d.sC + (int64_t)(iyc * (int)d.sH + ixc + jq * 4);
+                        const int64_t over = off + 4 - d.in_elems;  // 1 ... 3 for the last runs of the last plane, else <= 0
+                        const int sh = over > 0 ? (int)over : 0;
+                        shA[i] = sh;  // applied when the registers go to LDS
+                        ra[i] = *reinterpret_cast<const float4*>(in + (off - sh));
+                    } else {
+                        ra[i] = *reinterpret_cast<const float4*>(in + pbase[i] + (int64_t)iyc * d.sH + (int64_t)ixc * d.sW + jq * 4);
+                    }
                 }
             } else {
 #pragma unroll
@@ -189,8 +218,14 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float* __restrict__ in
                 if (mloc[i] < BM) {
                     const int kq = (tid & 3) * 4;
                     const bool ok = okA[i];
-                    As[st][kq + 0][mloc[i]] = ok ? ra[i].x : 0.f; As[st][kq + 1][mloc[i]] = ok ? ra[i].y : 0.f;
-                    As[st][kq + 2][mloc[i]] = ok ? ra[i].z : 0.f; As[st][kq + 3][mloc[i]] = ok ? ra[i].w : 0.f;
+                    float4 v = ra[i];
+                    if constexpr (PLANES) {  // a load that was moved back from the end of the input: its floats move down, zeros follow
+                        const int sh = shA[i];
+                        v = make_float4(sh == 0 ? v.x : (sh == 1 ? v.y : (sh == 2 ? v.z : v.w)), sh == 0 ? v.y : (sh == 1 ? v.z : (sh == 2 ? v.w : 0.f)),
+                                        sh == 0 ? v.z : (sh == 1 ? v.w : 0.f), sh == 0 ? v.w : 0.f);
+                    }
+                    As[st][kq + 0][mloc[i]] = ok ? v.x : 0.f; As[st][kq + 1][mloc[i]] = ok ? v.y : 0.f;
+                    As[st][kq + 2][mloc[i]] = ok ? v.z : 0.f; As[st][kq + 3][mloc[i]] = ok ? v.w : 0.f;
                 }
             }
         } else {
@@ -573,12 +608,17 @@ __global__ void k_maxpool_lrn_nhwc(const float* __restrict__ in, float* __restri
 // x^-0.75 as rsqrt(x) * rsqrt(sqrt(x)) (the network's beta), powf otherwise.
 __global__ __launch_bounds__(256) void k_maxpool_lrn_nhwc_v4(const float* __restrict__ in, float* __restrict__ out, int N, int H,
                                                              int W, int C, int OH, int OW, int size, float alpha, float beta,
-                                                             int ppb /* pixels per block */) {
+                                                             int ppb /* pixels per block */, int xcd_remap) {
     extern __shared__ float sp[];  // [ppb][C]
     const int tpp = C >> 2;        // threads per pixel
     const int lp = threadIdx.x / tpp, lc = (threadIdx.x - lp * tpp) << 2;
     const int64_t total = (int64_t)N * OH * OW;
-    const int64_t pix = (int64_t)blockIdx.x * ppb + lp;
+    // Workgroups go to the 8 XCDs round-robin and every XCD has its own L2: with blockIdx.x as the tile number, the output rows that
+    // share an input row (3 x 3 windows, stride 2) sit on different XCDs and every input row is fetched 2.25 times.  The grid is a
+    // multiple of 8; XCD x works on the x-th eighth of the tiles, consecutive tiles in consecutive slots.
+    const unsigned per_xcd = gridDim.x >> 3;
+    const int64_t tile = xcd_remap ? (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    const int64_t pix = tile * ppb + lp;
     const bool on = lp < ppb && pix < total;
     if (on) {
         const int ox = (int)(pix % OW);
@@ -980,7 +1020,7 @@ extern "C" int cis_cnn_feat_dim(int arch) { return arch == 1 ? 4096 : (arch == 2
 extern "C" void cis_cnn_destroy(cis_cnn* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (auto& l : c->conv) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
+    for (auto& l : c->conv) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_w2) (void)hipFree(l.d_w2); }
     for (auto& l : c->fc) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
     for (auto& l : c->dl) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_w2) (void)hipFree(l.d_w2); }
     for (auto& w : c->ws) w.release();
@@ -1082,6 +1122,15 @@ extern "C" int cis_cnn_create(cis_cnn** out, int arch, const float* const* tenso
                             pr[(size_t)(ky * RUNP + kx * C + ic) * OC + o] = w[(((size_t)o * C + ic) * k + ky) * k + kx];
             if ((rc = upload_f(&c->conv[l].d_w, pr.data(), pr.size())) != CIS_OK) return fail(rc);
             if ((rc = upload_f(&c->conv[l].d_b, tensors[2 * l + 1], OC)) != CIS_OK) return fail(rc);
+            // the same layer over the caller's NCHW planes (no re-layout pass): k = (ic * 11 + ky) * 12 + kx, kx = 11 a zero weight
+            const int RUNW = ((k + 3) / 4) * 4, Kq = C * k * RUNW;
+            std::vector<float> pq((size_t)Kq * OC, 0.f);
+            for (int o = 0; o < OC; ++o)
+                for (int ic = 0; ic < C; ++ic)
+                    for (int ky = 0; ky < k; ++ky)
+                        for (int kx = 0; kx < k; ++kx)
+                            pq[(size_t)((ic * k + ky) * RUNW + kx) * OC + o] = w[(((size_t)o * C + ic) * k + ky) * k + kx];
+            if ((rc = upload_f(&c->conv[l].d_w2, pq.data(), pq.size())) != CIS_OK) return fail(rc);
             hw = (hw + 2 * p - k) / s + 1;
             C = OC;
             if (kPoolAfter[l]) hw = (hw - 3 + 1) / 2 + 1;
@@ -1164,7 +1213,10 @@ static void launch_conv_cfg(const ConvDesc& d, const float* in, const float* w, 
     const int64_t npix = (int64_t)d.N * d.OH * d.OW;
     dim3 g((unsigned)ceil_div(npix, BM), (unsigned)ceil_div(d.OCg, BN), (unsigned)(d.splitk > 1 ? d.splitk : d.groups));
     const bool vec = (d.sC == 1 && d.ICg % 16 == 0 && d.C % 4 == 0) || d.runq > 0;
-    if (d.runq > 0) hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, 2>), g, dim3(256), 0, st, in, w, b, out, d);
+    if (d.runq > 0 && d.run_planes > 0) {
+        if constexpr (WM == 1 && WN == 3) hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, 3>), g, dim3(256), 0, st, in, w, b, out, d);
+        else cis_set_error("plane-run gather: built for the 128 x 96 tile only");
+    } else if (d.runq > 0) hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, 2>), g, dim3(256), 0, st, in, w, b, out, d);
     else if (vec) hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, 1>), g, dim3(256), 0, st, in, w, b, out, d);
     else hipLaunchKernelGGL((k_conv_igemm<WM, WN, WAVES_M, WAVES_N, 0>), g, dim3(256), 0, st, in, w, b, out, d);
 }
@@ -1175,7 +1227,17 @@ static void launch_conv(const ConvDesc& d, const float* in, const float* w, cons
     auto blocks = [&](int bm, int bn) { return ceil_div(npix, bm) * ceil_div(d.OCg, bn) * z; };
     const int64_t want = 2 * 256;  // at least two workgroups per CU, else a smaller tile
     if (d.OCg <= 32) launch_conv_cfg<1, 1, 4, 1>(d, in, w, b, out, st);                // 128 x 32 tiles
-    else if (npix <= 2048) launch_conv_cfg<1, 1, 1, 4>(d, in, w, b, out, st);          // fc layers: 32 x 128 tiles fill the chip
+    else if (npix <= 2048) {
+        // fc layers.  32 x 128 tiles fill the chip at any batch, but every 32 rows stream the whole weight matrix again (batch 256: 8 x
+        // 151 MB for fc6); from 64 rows up 64 x 128 tiles halve that (the tile shape does not change a sum's order: same bits)
+        const char* e = getenv("CIS_CNN_FC_TILE");
+        const int t = e ? atoi(e) : (npix >= 64 ? 1 : 0);
+        if (t == 1) launch_conv_cfg<1, 2, 2, 2>(d, in, w, b, out, st);
+        else if (t == 2) launch_conv_cfg<2, 2, 2, 2>(d, in, w, b, out, st);
+        else if (t == 3) launch_conv_cfg<1, 1, 2, 2>(d, in, w, b, out, st);
+        else if (t == 4) launch_conv_cfg<2, 1, 2, 2>(d, in, w, b, out, st);
+        else launch_conv_cfg<1, 1, 1, 4>(d, in, w, b, out, st);
+    }
     else if (d.OCg <= 64) {
         if (blocks(128, 64) >= want) launch_conv_cfg<2, 1, 2, 2>(d, in, w, b, out, st);   // 128 x 64 tiles
         else launch_conv_cfg<1, 1, 2, 2>(d, in, w, b, out, st);                           // 64 x 64
@@ -1445,7 +1507,10 @@ static int cnn_forward_sentibank(cis_cnn* c, CnnWs* ws, const float* d_nchw, int
     const size_t act_elems = (size_t)n * 55 * 55 * 96;
     CIS_TRY(ws->act0.reserve(act_elems * sizeof(float)));
     CIS_TRY(ws->act1.reserve(act_elems * sizeof(float)));
-    CIS_TRY(ws->act2.reserve((size_t)4 * n * 4096 * sizeof(float)));  // split-K partial sums of the fc layers
+    const char* sk_e = getenv("CIS_CNN_FC_SPLITK");  // measurement switch: the order of a sum depends on it
+    const int fc_splitk = sk_e ? atoi(sk_e) : 8;
+    CIS_REQUIRE(fc_splitk >= 1 && fc_splitk <= 32, "CIS_CNN_FC_SPLITK out of range");
+    CIS_TRY(ws->act2.reserve((size_t)fc_splitk * n * 4096 * sizeof(float)));  // split-K partial sums of the fc layers
     CIS_TRY(cnn_poison(ws, st));
     float* bufs[2] = {ws->act0.as<float>(), ws->act1.as<float>()};
     const float* cur = d_nchw;
@@ -1465,7 +1530,17 @@ static int cnn_forward_sentibank(cis_cnn* c, CnnWs* ws, const float* d_nchw, int
         d.relu = 1;
         d.kx_fastest = 0;
         float* o = bufs[which];
-        if (l == 0) {
+        const float* wl = c->conv[l].d_w;
+        if (l == 0 && !getenv("CIS_CNN_NHWC_FIRST")) {
+            // first layer straight from the caller's NCHW planes (round 5): a (pixel, channel, kernel row) is a run of 11 contiguous
+            // floats, gathered as three 16-byte loads (4-byte aligned: the planes' rows are 227 floats); the re-layout pass below
+            // (57 us per 256 images, a 158 MB round trip) is gone.  K = 3 * 11 * 12 = 396 as before.
+            d.runq = (d.KW + 3) / 4;                 // 3 float4 per run
+            d.run_planes = C * d.KH;                 // 33 runs
+            d.K = d.run_planes * d.runq * 4;         // 396
+            d.in_elems = (int64_t)n * C * H * W;
+            wl = c->conv[l].d_w2;
+        } else if (l == 0) {
             // first layer: the NCHW batch is re-laid as NHWC rows (pitch 684 floats) once, then every (pixel, kernel row)
             // is a run of 33 contiguous floats gathered with aligned 16-byte loads instead of 363 scalar loads per pixel
             const int pitch = ((W * 3 + 3) / 4) * 4;
@@ -1478,7 +1553,7 @@ static int cnn_forward_sentibank(cis_cnn* c, CnnWs* ws, const float* d_nchw, int
             d.K = d.KH * d.runq * 4;            // 396
             cur = xt;
         }
-        launch_conv(d, cur, c->conv[l].d_w, c->conv[l].d_b, o, st);
+        launch_conv(d, cur, wl, c->conv[l].d_b, o, st);
         cur = o; which ^= 1; nchw = false;
         H = d.OH; W = d.OW; C = d.OC;
         if (kPoolAfter[l] && kLrnAfter[l]) {
@@ -1486,8 +1561,10 @@ static int cnn_forward_sentibank(cis_cnn* c, CnnWs* ws, const float* d_nchw, int
             float* po = bufs[which];
             if (C % 4 == 0 && C <= 1024) {
                 const int tpp = C / 4, ppb = 256 / tpp;
-                hipLaunchKernelGGL(k_maxpool_lrn_nhwc_v4, dim3((unsigned)ceil_div((int64_t)n * OH * OW, ppb)), dim3(256),
-                                   (size_t)ppb * C * sizeof(float), st, cur, po, n, H, W, C, OH, OW, 5, 1e-4f, 0.75f, ppb);
+                const int remap = getenv("CIS_CNN_NO_XCD_REMAP") ? 0 : 1;
+                const int64_t tiles = ceil_div((int64_t)n * OH * OW, ppb);
+                hipLaunchKernelGGL(k_maxpool_lrn_nhwc_v4, dim3((unsigned)(remap ? ceil_div(tiles, 8) * 8 : tiles)), dim3(256),
+                                   (size_t)ppb * C * sizeof(float), st, cur, po, n, H, W, C, OH, OW, 5, 1e-4f, 0.75f, ppb, remap);
             } else {
                 const int threads = C <= 64 ? 64 : (C <= 128 ? 128 : 256);
                 hipLaunchKernelGGL(k_maxpool_lrn_nhwc, dim3((unsigned)((int64_t)n * OH * OW)), dim3(threads), (size_t)C * sizeof(float), st,
@@ -1519,9 +1596,9 @@ static int cnn_forward_sentibank(cis_cnn* c, CnnWs* ws, const float* d_nchw, int
         d.relu = 1;
         d.kx_fastest = 0;
         float* o = (l == 1) ? d_feats : bufs[which];
-        // few output tiles (n x 4096) and a long K: split K over four blocks per tile so that every CU holds several
+        // few output tiles (n x 4096) and a long K: split K over eight blocks per tile (round 5; four before) so that every CU holds several
         // workgroups (the K loop is a chain of dependent loads), then add the partial sums in a fixed order
-        const int splitk = (fin % 16 == 0 && (int64_t)n * 4096 % 4 == 0 && n <= 4096) ? 4 : 1;
+        const int splitk = (fin % 16 == 0 && (int64_t)n * 4096 % 4 == 0 && n <= 4096) ? fc_splitk : 1;
         if (splitk > 1) {
             d.splitk = splitk;
             d.part_stride = (int64_t)n * 4096;

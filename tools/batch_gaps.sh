@@ -2,7 +2,7 @@
 # usage (GPU box): tools/batch_gaps.sh [config] -- kernel timeline of ONE timed batch (rocprofv3 kernel trace): durations and the idle gaps between kernels
 cfg=${1:-c4}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rm -rf /tmp/kt; timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o r -- python bench.py --config $cfg --steps 6 --warmup 2 --no-cnn --no-pcie --no-cpu-baseline > /dev/null 2>&1
+rm -rf /tmp/kt; CIS_BENCH_MIN_REPS=2 CIS_BENCH_MIN_TIMED_S=0 timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o r -- python bench.py --config $cfg --steps 6 --warmup 2 --no-cnn --no-pcie --no-cpu-baseline --no-c4x --pipeline 1 > /dev/null 2>&1
 python - <<PY
 import csv, re
 rows = list(csv.DictReader(open("/tmp/kt/r_kernel_trace.csv")))
