@@ -1294,8 +1294,10 @@ static int conv_fill_chip(CnnWs* ws, ConvDesc d, const float* in, const LayerW& 
     // the chip is full, instead of 64 x 64 tiles: 70 -> 66 us and 74 -> 64 us per layer at batch 256 (CIS_CNN_NO_BIGTILE: old choice)
     if (!off && vec && !getenv("CIS_CNN_NO_BIGTILE") && d.OCg >= 128 && d.OCg % 128 == 0 && npix > 2048) {
         const int64_t t128 = ceil_div(npix, 128) * (d.OCg / 128);
+        const char* te = getenv("CIS_CNN_SPLIT_TARGET");
+        const int64_t target = te ? atoi(te) : 512;
         int s = 1;
-        while (t128 * s < 512 && s < 32 && nkt / (s * 2) >= 6) s *= 2;
+        while (t128 * s < target && s < 32 && nkt / (s * 2) >= 6) s *= 2;
         if (t128 * s >= 512) splitk = s;
     }
     if (splitk == 1) {

@@ -28,6 +28,12 @@
 //      memory; the host then answers the batch through the generic path.  The result never depends on the sample.
 #include "scan_common.h"
 
+#ifndef CIS_STREAM_RING
+#define CIS_STREAM_RING 1   // 1: the next iteration's code rows are requested before the current ones are used (0: requested and awaited per iteration)
+#endif
+#ifndef CIS_STREAM_U
+#define CIS_STREAM_U 0      // 16-byte loads per lane and iteration; 0: two for one query per slot and for the sample pass, four for a pair
+#endif                      // (measured on 200 M codes, profiles/r05_experiments.txt: 324 / 333 / 339 us for ring + 2, ring + 4, no ring + 4)
 #ifndef CIS_STREAM_REPL
 #define CIS_STREAM_REPL 0
 #endif
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(256) void k_adc_stream(const WorkItem* __restrict__
     constexpr int nf = M / 2;
     constexpr int CPL = 16 / M;        // candidates per lane and 16-byte load
     constexpr int ROW = 64 * CPL;      // candidates per wave and load
-    constexpr int U = 4;               // loads in flight per wave
+    constexpr int U = CIS_STREAM_U > 0 ? CIS_STREAM_U : ((SAMPLE || G == 1) ? 2 : 4);  // loads per wave and iteration (the ring doubles what is in flight)
     // Tables in LDS, entry-major, the sub-quantizers rotated over the lanes.  Measured (profiles/r05f_c4x_*): SQ_LDS_BANK_CONFLICT /
     // SQ_LDS_IDX_ACTIVE = 0.66 -- the worst of the eight 4-lane groups of a read is 2.9-way, not the 2.1-way of one group -- and the LDS
     // pipe 0.72 busy at 0.60 of 8 TB/s.  CIS_STREAM_REPL=1 REPLICATES the tables so that the gathers meet no conflict at all (a row of 128
@@ -85,6 +91,17 @@ __global__ __launch_bounds__(256) void k_adc_stream(const WorkItem* __restrict__
         int qg[G];
         uint32_t rbase[G];   // retrieval index of the chunk's first candidate, relative to the query's first candidate
         float tg[G];
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(codes + start * M), 0, len * M, 0x00020000);
+        const int rows = (len + ROW - 1) / ROW;
+        const int rstep = SAMPLE ? 4 * sample_stride : 4;
+        const int rfirst = wv * (SAMPLE ? sample_stride : 1);
+        // past the chunk the descriptor returns zeros (no memory access); such candidates are masked below
+        auto request = [&](int r0, u32x4_t(&dst)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) dst[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((r0 + u * rstep) * ROW + lane * CPL) * M, 0, 0);
+        };
+        u32x4_t cw[U], cn[U];
+        if (CIS_STREAM_RING) request(rfirst, cw);  // the slot's first rows travel while its tables are staged
         __syncthreads();     // the previous slot's readers are done with the tables
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -105,19 +122,15 @@ __global__ __launch_bounds__(256) void k_adc_stream(const WorkItem* __restrict__
             }
         }
         __syncthreads();
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(codes + start * M), 0, len * M, 0x00020000);
-        const int rows = (len + ROW - 1) / ROW;
-        const int rstep = SAMPLE ? 4 * sample_stride : 4;
         float mn[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) mn[g] = __uint_as_float(0x7f800000u);
-        for (int r0 = wv * (SAMPLE ? sample_stride : 1); r0 < rows; r0 += rstep * U) {
-            u32x4_t cw[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {  // past the chunk the descriptor returns zeros; such candidates are masked below
-                const int r = r0 + u * rstep;
-                cw[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (r * ROW + lane * CPL) * M, 0, 0);
-            }
+        for (int r0 = rfirst; r0 < rows; r0 += rstep * U) {
+            // The ring: the rows of iteration i + 1 are requested before those of iteration i are used, so a wave has U .. 2 U kilobytes
+            // on their way at any time instead of none while it gathers (round 5: without it ~40 % of the waves had requests in
+            // flight, 4.8-5.0 TB/s = what ~8 MB in flight sustain at the loaded latency).
+            if (CIS_STREAM_RING) request(r0 + rstep * U, cn);
+            else request(r0, cw);
             // all U * CPL candidates' distances first (their gathers overlap), the rare appends afterwards
             float d[U * CPL][G];
 #pragma unroll
@@ -191,6 +204,10 @@ __global__ __launch_bounds__(256) void k_adc_stream(const WorkItem* __restrict__
                                 }
                         }
                 }
+            }
+            if (CIS_STREAM_RING) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) cw[u] = cn[u];
             }
         }
         if (SAMPLE) {
