@@ -5299,6 +5299,185 @@ static int search_all(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_
     return CIS_OK;
 }
 
+// ---- routed cell-sharded search (round 5): which ranks own the cells a query visits ---------------------------------------------
+// The all-gather protocol hands every rank the whole batch: projection, cell ranking and walk are done `world` times over.  Routed,
+// a query's HOME rank (1 / world of the batch each) walks the multisequence against the cell sizes of the whole index -- the same
+// walk as k_plan (lopq/lopq/search.py:58-82, :128-133), no items -- and notes the owner of every non-empty visited cell; only those
+// ranks (one or two at V = 16) receive the query (columbiaimagesearch_amd/distributed.py: RoutedSearcher).
+template <typename CT>
+__global__ __launch_bounds__(64) void k_plan_owners(const CT* __restrict__ sorted, const uint16_t* __restrict__ order,
+                                                    const int64_t* __restrict__ gcount, const int32_t* __restrict__ owner, int world,
+                                                    int nq, int V, int64_t quota, unsigned long long* __restrict__ mask,
+                                                    int32_t* __restrict__ visited_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* t = reinterpret_cast<int*>(smem);  // [V]
+    const int q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const CT* d0 = sorted + ((int64_t)q * 2 + 0) * V;
+    const CT* d1 = sorted + ((int64_t)q * 2 + 1) * V;
+    const uint16_t* o0 = order + ((int64_t)q * 2 + 0) * V;
+    const uint16_t* o1 = order + ((int64_t)q * 2 + 1) * V;
+    for (int i = lane; i < V; i += 64) t[i] = 0;
+    __syncthreads();
+    int visited = 0, rows = 1;
+    int64_t retrieved = 0;
+    unsigned long long mk = 0ull;
+    const int64_t total_cells = (int64_t)V * V;
+    while ((int64_t)visited < total_cells) {
+        uint64_t bk = ~0ull;
+        uint32_t bij = ~0u;
+        for (int i = lane; i < rows; i += 64) {
+            const int j = t[i];
+            if (j >= V) continue;
+            if (i > 0 && t[i - 1] <= j) continue;
+            const CT dist = d0[i] + d1[j];
+            const uint64_t kb = f2bits(dist);
+            const uint32_t ij = ((uint32_t)i << 16) | (uint32_t)j;
+            if (kb < bk || (kb == bk && ij < bij)) { bk = kb; bij = ij; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint64_t ok = __shfl_xor(bk, off);
+            const uint32_t oij = __shfl_xor(bij, off);
+            if (ok < bk || (ok == bk && oij < bij)) { bk = ok; bij = oij; }
+        }
+        if (bij == ~0u) break;
+        const int bi = (int)(bij >> 16), bj = (int)(bij & 0xffff);
+        const int64_t cell = (int64_t)o0[bi] * V + o1[bj];
+        const int64_t gc = gcount[cell];
+        if (gc > 0) mk |= 1ull << (owner ? owner[cell] : (int)(cell % world));
+        visited += 1;
+        retrieved += gc;
+        __syncthreads();
+        if (lane == 0) t[bi] = bj + 1;
+        if (bi + 2 > rows) rows = (bi + 2 < V) ? bi + 2 : V;
+        __syncthreads();
+        if (retrieved >= quota) break;
+    }
+    if (lane == 0) {
+        mask[q] = mk;
+        if (visited_out) visited_out[q] = visited;
+    }
+}
+
+extern "C" int cis_index_query_owners_dev(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota, uint64_t* d_mask,
+                                          int32_t* d_visited, void* stream) {
+    CIS_REQUIRE(ix != nullptr, "index is NULL");
+    CIS_REQUIRE(q_dtype == CIS_F32 || q_dtype == CIS_F64, "q_dtype must be 4 or 8");
+    CIS_REQUIRE(nq >= 0 && (nq == 0 || (dQ && d_mask)), "NULL buffer");
+    CIS_REQUIRE(!ix->orphaned, "this view's base index was destroyed: close views before their base");
+    CIS_REQUIRE(ix->world >= 1 && ix->world <= 64, "owner masks hold 64 ranks");
+    if (nq == 0) return CIS_OK;
+    CIS_TRY(cis_index_ready(ix->base ? ix->base : ix));
+    ix->sync_from_base();
+    cis_model* m = ix->m;
+    CIS_CHECK_HIP(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int V = m->V, D = m->D;
+    CIS_REQUIRE(V <= 4096, "owner walk: V <= 4096");
+    const void* xp = dQ;
+    int xp_dtype = q_dtype;
+    if (m->has_pca) {
+        CIS_TRY(ix->w_xp.reserve((size_t)nq * D * sizeof(float)));
+        CIS_TRY(cis_dev_apply_pca(m, dQ, q_dtype, nq, ix->w_xp.as<float>(), st, &ix->w_y64));
+        xp = ix->w_xp.p;
+        xp_dtype = CIS_F32;
+    }
+    const void* xc;
+    int ct;
+    CIS_TRY(cis_dev_coarse_type(m, xp, xp_dtype, nq, &xc, &ct, st, &ix->w_x64));
+    const size_t csz = (ct == CIS_F32) ? 4 : 8;
+    CIS_TRY(ix->w_cd.reserve((size_t)2 * nq * V * csz));
+    CIS_TRY(ix->w_sorted.reserve((size_t)2 * nq * V * csz));
+    CIS_TRY(ix->w_order.reserve((size_t)2 * nq * V * sizeof(uint16_t)));
+    {
+        const void* grp_before = ix->w_grp.p;
+        CIS_TRY(ix->w_grp.reserve((size_t)(6 * V * GRP_SUB + 2) * sizeof(int)));
+        if (ix->w_grp.p != grp_before) CIS_CHECK_HIP(hipMemsetAsync(ix->w_grp.p, 0, ix->w_grp.cap, st));
+    }
+    int* grp_cnt = ix->w_grp.as<int>();  // the rank kernels leave the table-group counters zeroed, as every search expects to find them
+    CIS_TRY(cis_launch_sqdist_both(m, xc, ct, nq, ix->w_cd.p, st));
+    int Vp2 = 64;
+    while (Vp2 < V) Vp2 <<= 1;
+    const cis_index* own = ix->base ? ix->base : ix;  // a view reads the owner table of its base
+    const int32_t* d_owner = own->owner.empty() ? nullptr : own->d_owner.as<int32_t>();
+    CIS_REQUIRE(own->owner.empty() || d_owner != nullptr, "owner table not on the device");
+    if (ct == CIS_F32) {
+        if (V > 256) hipLaunchKernelGGL(k_rank_sort<float>, dim3(nq, 2), dim3(256), (size_t)Vp2 * 16, st, ix->w_cd.as<float>(), nq, V, Vp2,
+                                        ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
+        else hipLaunchKernelGGL(k_rank<float>, dim3(nq, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, st, ix->w_cd.as<float>(), nq, V,
+                                ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
+        hipLaunchKernelGGL(k_plan_owners<float>, dim3(nq), dim3(64), (size_t)V * sizeof(int), st, ix->w_sorted.as<float>(), ix->w_order.as<uint16_t>(),
+                           ix->gcount_ptr(), d_owner, ix->world, nq, V, quota, (unsigned long long*)d_mask, d_visited);
+    } else {
+        if (V > 256) hipLaunchKernelGGL(k_rank_sort<double>, dim3(nq, 2), dim3(256), (size_t)Vp2 * 16, st, ix->w_cd.as<double>(), nq, V, Vp2,
+                                        ix->w_order.as<uint16_t>(), ix->w_sorted.as<double>(), grp_cnt);
+        else hipLaunchKernelGGL(k_rank<double>, dim3(nq, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, st, ix->w_cd.as<double>(), nq, V,
+                                ix->w_order.as<uint16_t>(), ix->w_sorted.as<double>(), grp_cnt);
+        hipLaunchKernelGGL(k_plan_owners<double>, dim3(nq), dim3(64), (size_t)V * sizeof(int), st, ix->w_sorted.as<double>(), ix->w_order.as<uint16_t>(),
+                           ix->gcount_ptr(), d_owner, ix->world, nq, V, quota, (unsigned long long*)d_mask, d_visited);
+    }
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
+}
+
+// Routing tables of a home rank: slot[d][i] = the row of query i in the buffer that goes to rank d (-1: not sent), in query order;
+// cnt[d] = rows used (at most cap; *overflow = 1 when a destination would need more).  One workgroup per destination.
+__global__ __launch_bounds__(1024) void k_route_slots(const unsigned long long* __restrict__ mask, int nq, int cap, int32_t* __restrict__ slot,
+                                                      int32_t* __restrict__ cnt, int32_t* __restrict__ overflow) {
+    __shared__ int s_w[16];
+    __shared__ int s_base;
+    const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < nq; i0 += 1024) {
+        const int i = i0 + tid;
+        const bool f = i < nq && ((mask[i] >> d) & 1ull);
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(f);
+        const int before = __builtin_popcountll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_w[wv] = __builtin_popcountll(b);
+        __syncthreads();
+        int wbase = s_base;
+        for (int w = 0; w < wv; ++w) wbase += s_w[w];
+        if (i < nq) {
+            const int pos = wbase + before;
+            slot[(int64_t)d * nq + i] = (f && pos < cap) ? pos : -1;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = s_base;
+            for (int w = 0; w < 16; ++w) tot += s_w[w];
+            s_base = tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        cnt[d] = s_base < cap ? s_base : cap;
+        if (s_base > cap) atomicExch(overflow, 1);
+    }
+}
+
+__global__ void k_route_rows(const float* __restrict__ q, int nq, int D, const int32_t* __restrict__ slot, int cap, float* __restrict__ out) {
+    const int i = blockIdx.x, d = blockIdx.y;
+    const int sl = slot[(int64_t)d * nq + i];
+    if (sl < 0) return;
+    const float* src = q + (int64_t)i * D;
+    float* dst = out + ((int64_t)d * cap + sl) * D;
+    for (int k = threadIdx.x; k < D; k += blockDim.x) dst[k] = src[k];
+}
+
+extern "C" int cis_route_queries_dev(const float* d_q, int nq, int D, const uint64_t* d_mask, int world, int cap, float* d_out_q,
+                                     int32_t* d_slot, int32_t* d_cnt, int32_t* d_overflow, void* stream) {
+    CIS_REQUIRE(nq >= 0 && D > 0 && world >= 1 && world <= 64 && cap >= 1, "route: sizes out of range");
+    CIS_REQUIRE(d_slot && d_cnt && d_overflow && (nq == 0 || (d_q && d_mask && d_out_q)), "NULL buffer");
+    hipStream_t st = (hipStream_t)stream;
+    CIS_CHECK_HIP(hipMemsetAsync(d_overflow, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_route_slots, dim3(world), dim3(1024), 0, st, (const unsigned long long*)d_mask, nq, cap, d_slot, d_cnt, d_overflow);
+    if (nq > 0) hipLaunchKernelGGL(k_route_rows, dim3(nq, world), dim3(D >= 256 ? 256 : 64), 0, st, d_q, nq, D, d_slot, cap, d_out_q);
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
+}
+
 extern "C" int cis_index_search_partial_dev(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota,
                                             int limit, cis_hit* d_hits, int32_t* d_visited, void* stream) {
     int L;
@@ -5391,6 +5570,7 @@ static __device__ __forceinline__ int arrived(const int32_t* __restrict__ cnt, c
     const int64_t o = off[(int64_t)w * nq + q];
     const int64_t room = stride - o;
     const int c = cnt[(int64_t)w * nq + q];
+    if (stride == 0) return c;  // one flat buffer, absolute offsets, nothing was cut (the routed search's return trip)
     return room <= 0 ? 0 : (c < room ? c : (int)room);
 }
 

@@ -419,6 +419,219 @@ class ShardedSearcher(object):
         return out
 
 
+# ---- routed cell-sharded search (round 5) --------------------------------------------------------------------------------------------
+# The all-gather protocol above hands every rank the whole batch: projection, cell ranking, the multisequence walk and the per-query
+# part of the merge are done `world` times over, which is why one copy of the index over 8 GPUs projected to x1.9 only
+# (profiles/archive/r04/r04f_shards.txt).  Routed:
+#   home    every rank takes 1 / world of the batch, walks the multisequence against the cell sizes of the whole index and notes which
+#           ranks own the non-empty cells each query visits (cis_index_query_owners_dev: one or two ranks at V = 16);
+#   out     ONE all-to-all of fixed-size blocks carries each query to those owners (cis_route_queries_dev builds the blocks; the row
+#           counts ride in a second, tiny all-to-all);
+#   scan    an owner answers the queries it received with the ordinary partial search -- same walk, same quota cut, same visit ranks;
+#   back    the ranked lists return to the home ranks (all-to-all, exact sizes) and are merged there by (dist, visit_rank, pos).
+# A cell lives on one rank, so the merged list is the single index's, bit for bit.  Results stay with the home rank (rank r holds
+# queries [nq r / world, nq (r + 1) / world)).  The host reads one small record per batch (rows sent / received) when the return trip
+# is sized -- of an event two batches old in a pipelined loop.  A destination block that overflows sends the whole batch through the
+# all-gather protocol instead (the flag is all-reduced: every rank takes the same branch).
+
+
+def home_slice(nq, rank, world):
+    """Queries [lo, hi) of a batch of nq that rank `rank` is the home of."""
+    return (int(nq) * rank) // world, (int(nq) * (rank + 1)) // world
+
+
+def route_capacity(nq_home, D, world, slack=2.0):
+    """Rows of a destination block of the query all-to-all.  Small rows: the whole home slice fits any block (no overflow possible).
+    Long rows (a 4096-d query is 16 KB): `slack` x the even share of ~1.3 owners per query, overflow falls back."""
+    nq_home = max(int(nq_home), 1)
+    if world <= 1 or D <= 512:
+        return nq_home
+    return min(nq_home, int(slack * 1.3 * nq_home / world) + 64)
+
+
+def route_slots_torch(mask, world, cap):
+    """The tables of cis_route_queries_dev in torch (CPU tensors under gloo; the check of the HIP kernel): slot int32 [world, nq] --
+    row of query i in the block for rank d, -1 = not sent --, cnt int32 [world], overflow int32 [1].  No host read."""
+    import torch
+    m = mask.to(torch.int64)
+    bits = (m[None, :] >> torch.arange(world, dtype=torch.int64, device=m.device)[:, None]) & 1
+    pos = torch.cumsum(bits, dim=1) - 1
+    slot = torch.where((bits == 1) & (pos < cap), pos, torch.full_like(pos, -1)).to(torch.int32)
+    tot = bits.sum(dim=1)
+    return slot, torch.clamp(tot, max=cap).to(torch.int32), (tot > cap).any().to(torch.int32).reshape(1)
+
+
+def route_rows_torch(q, slot, cap):
+    """The send blocks [world, cap, D] for the tables of route_slots_torch (reference form; unused rows are zero)."""
+    import torch
+    world, nq = int(slot.shape[0]), int(slot.shape[1])
+    out = torch.zeros((world, cap, q.shape[1]), dtype=q.dtype, device=q.device)
+    for d in range(world):
+        sel = slot[d] >= 0
+        out[d, slot[d][sel].long()] = q[sel]
+    return out
+
+
+def _a2a(out, inp, out_splits=None, in_splits=None, group=None):
+    """all_to_all_single; gloo has no all-to-all on device buffers: staged through the host there."""
+    import torch.distributed as dist
+    if dist.get_backend(group) != "nccl" and inp.is_cuda:
+        o = out.cpu()
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    return out
+
+
+def routed_send_queries(q_home, slot, send_q, cnt, overflow, group=None):
+    """`out`: the fixed-size query all-to-all, the row counts, and the overflow flag agreed over the group.  Returns (recv_q
+    [world, cap, D], recv_cnt int32 [world], overflow int32 [1]); tensors stay on the device of the inputs, no host read."""
+    import torch
+    import torch.distributed as dist
+    recv_q = torch.empty_like(send_q)
+    recv_cnt = torch.empty_like(cnt)
+    _a2a(recv_cnt, cnt, group=group)
+    _a2a(recv_q, send_q, group=group)
+    ov = overflow.clone()
+    if dist.get_backend(group) != "nccl" and ov.is_cuda:
+        o = ov.cpu()
+        dist.all_reduce(o, op=dist.ReduceOp.MAX, group=group)
+        ov.copy_(o)
+    else:
+        dist.all_reduce(ov, op=dist.ReduceOp.MAX, group=group)
+    return recv_q, recv_cnt, ov
+
+
+def routed_return_hits(hits, n_recv, n_sent, group=None):
+    """`back`: hits [sum(n_recv), L, 32] uint8 of the queries this rank answered (grouped by source rank, a source's rows in the
+    order they arrived) go home.  n_recv / n_sent: rows received from / sent to every rank (host ints).  Returns [sum(n_sent), L, 32]:
+    the lists of this rank's own queries, grouped by answering rank, in slot order."""
+    import torch
+    L = int(hits.shape[1])
+    rec = L * 32
+    out = torch.empty((int(sum(n_sent)), L, 32), dtype=torch.uint8, device=hits.device)
+    _a2a(out.reshape(-1), hits.reshape(-1), out_splits=[int(c) * rec for c in n_sent], in_splits=[int(c) * rec for c in n_recv], group=group)
+    return out
+
+
+def routed_merge_tables(slot, n_sent, valid, L):
+    """Where the list of home query i from rank d sits in the buffer routed_return_hits returned: off int64 [world, nq] (record
+    offsets), cnt int32 [world, nq] (valid hits; 0 = rank d was not asked).  valid int32 [rows]: hits with id >= 0 per returned row."""
+    import torch
+    world, nq = int(slot.shape[0]), int(slot.shape[1])
+    base = [0]
+    for c in n_sent[:-1]:
+        base.append(base[-1] + int(c))
+    base_t = torch.tensor(base, dtype=torch.int64, device=slot.device)[:, None]
+    row = torch.clamp(slot.to(torch.int64), min=0) + base_t
+    sent = slot >= 0
+    if valid.shape[0] == 0:
+        cnt = torch.zeros((world, nq), dtype=torch.int32, device=slot.device)
+    else:
+        cnt = torch.where(sent, valid[torch.clamp(row, max=valid.shape[0] - 1)], torch.zeros_like(valid[:1])).to(torch.int32)
+    off = torch.where(sent, row * L, torch.zeros_like(row))
+    return off.contiguous(), cnt.contiguous()
+
+
+class RoutedSearcher(object):
+    """Cell-sharded search with every query routed to the owners of the cells it visits (see the comment above).
+
+    Wraps a ShardedSearcher (its local index, lanes and process group).  ``search_begin(q_home)`` takes THIS rank's home slice of the
+    batch (``home_slice``) and runs home + out asynchronously; ``search_end`` sizes the return trip (one host read), runs scan + back +
+    merge and returns the results of the home slice, like ``search_batch_dev``."""
+
+    def __init__(self, sharded, slack=2.0):
+        import torch.distributed as dist
+        self.sh = sharded
+        self.group = sharded.group
+        self.world = dist.get_world_size(self.group)
+        self.rank = dist.get_rank(self.group)
+        self.slack = slack
+        self.fallbacks = 0
+
+    def search_begin(self, q_home, quota=10, limit=None, nq_total=None):
+        """q_home: this rank's home slice (home_slice(nq_total, rank, world)) of a batch of nq_total queries.  nq_total sizes the blocks
+        of the query all-to-all, which must be the same on every rank: pass it when the slices are ragged (default: world x this slice)."""
+        import torch
+        from . import _lib
+        sv, stream = self.sh._lane()
+        cur = torch.cuda.current_stream()
+        st = stream if stream is not None else cur
+        L = sv._dev_args(q_home, quota, limit)[0]
+        if q_home.dtype != torch.float32:
+            raise ValueError("routed search: float32 queries")
+        nqh, D = int(q_home.shape[0]), int(q_home.shape[1])
+        cap = route_capacity(-(-int(nq_total) // self.world) if nq_total is not None else nqh, D, self.world, self.slack)
+        dev = q_home.device
+        if stream is not None:
+            stream.wait_stream(cur)
+            q_home.record_stream(stream)
+        with torch.cuda.stream(st):
+            mask, visited = sv.query_owners_dev(q_home, quota=quota)
+            send_q = torch.empty((self.world, cap, D), dtype=torch.float32, device=dev)
+            slot = torch.empty((self.world, nqh), dtype=torch.int32, device=dev)
+            cnt = torch.empty(self.world, dtype=torch.int32, device=dev)
+            overflow = torch.empty(1, dtype=torch.int32, device=dev)
+            _lib.check(_lib.lib().cis_route_queries_dev(q_home.data_ptr(), nqh, D, mask.data_ptr(), self.world, cap, send_q.data_ptr(),
+                                                        slot.data_ptr(), cnt.data_ptr(), overflow.data_ptr(), st.cuda_stream))
+            recv_q, recv_cnt, ov = routed_send_queries(q_home, slot, send_q, cnt, overflow, self.group)
+            host = torch.empty(2 * self.world + 1, dtype=torch.int32, pin_memory=True)
+            host.copy_(torch.cat([cnt, recv_cnt, ov]), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        return {"sv": sv, "st": st, "q_home": q_home, "slot": slot, "recv_q": recv_q, "visited": visited, "host": host, "ev": ev,
+                "quota": quota, "limit": limit, "L": L, "nqh": nqh}
+
+    def search_end(self, h):
+        import torch
+        from .lopq.search import merge_packed_dev
+        h["ev"].synchronize()  # the one host read of the batch: rows sent / received, overflow
+        W = self.world
+        host = h["host"].tolist()
+        n_sent, n_recv, ov = host[:W], host[W:2 * W], host[2 * W]
+        sv, st, L, nqh = h["sv"], h["st"], h["L"], h["nqh"]
+        cur = torch.cuda.current_stream()
+        if ov:  # a destination block overflowed somewhere: the whole batch through the all-gather protocol (same results)
+            self.fallbacks += 1
+            with torch.cuda.stream(st):
+                q_all = all_gather_rows(h["q_home"], self.group)
+                sizes = all_gather_stack(torch.tensor([nqh], dtype=torch.int64, device=q_all.device), self.group).reshape(-1).tolist()
+                lo = int(sum(sizes[:self.rank]))
+                p = sv.search_partial_packed_dev(q_all.contiguous(), quota=h["quota"], limit=h["limit"])  # this lane's handle and stream
+                full = self.sh._exchange_and_merge(p, int(q_all.shape[0]), L, check=True)
+                full.pop("overflow", None)
+                out = {k: v[lo:lo + nqh] for k, v in full.items()}
+                out["visited"] = p["visited"][lo:lo + nqh]
+                done = torch.cuda.Event()
+                done.record(st)
+            cur.wait_event(done)
+            return out
+        with torch.cuda.stream(st):
+            rows = torch.cat([h["recv_q"][s, :n_recv[s]] for s in range(W)]) if sum(n_recv) else h["recv_q"][0, :0]
+            if rows.shape[0] and L > 0:
+                hits, _ = sv.search_partial_dev(rows.contiguous(), quota=h["quota"], limit=h["limit"])
+            else:
+                hits = torch.empty((0, L, 32), dtype=torch.uint8, device=rows.device)
+            back = routed_return_hits(hits, n_recv, n_sent, self.group)
+            rec = back.reshape(-1).view(torch.int64).reshape(-1, 4)
+            valid = (rec[:, 2].reshape(-1, L) >= 0).sum(dim=1, dtype=torch.int32) if back.shape[0] and L > 0 else torch.zeros(0, dtype=torch.int32, device=rows.device)
+            off, cnt = routed_merge_tables(h["slot"], n_sent, valid, L)
+            if rec.shape[0] == 0:
+                rec = torch.zeros((1, 4), dtype=torch.int64, device=rows.device)
+            out = merge_packed_dev(rec, off, cnt, nqh, L)
+            out["visited"] = h["visited"]
+            done = torch.cuda.Event(); done.record(st)
+        for t in out.values():
+            if hasattr(t, "record_stream"):
+                t.record_stream(cur)
+        cur.wait_event(done)
+        return out
+
+    def search_batch_dev(self, q_home, quota=10, limit=None, nq_total=None):
+        return self.search_end(self.search_begin(q_home, quota=quota, limit=limit, nq_total=nq_total))
+
+
 def all_gather_rows(x, group=None):
     """All-gather tensors that differ in their first dimension only -> the concatenation in group-rank order (same device).
     The row counts travel first (one small all-gather); the payload is padded to the largest count because neither RCCL nor

@@ -453,6 +453,18 @@ class LOPQSearcherHIP(LOPQSearcherBase):
                                                            visited.data_ptr(), stream))
         return hits, visited
 
+    def query_owners_dev(self, q, quota=10):
+        """Routed cell-sharded search, step 0 (cis_index_query_owners_dev): (mask int64 [nq] -- bit r: rank r owns a non-empty cell
+        the query visits --, visited int32 [nq]) for queries in HBM; no synchronisation."""
+        import torch
+        _, code, stream = self._dev_args(q, quota, 1)
+        nq = q.shape[0]
+        mask = torch.empty(nq, dtype=torch.int64, device=q.device)
+        visited = torch.empty(nq, dtype=torch.int32, device=q.device)
+        _lib.check(_lib.lib().cis_index_query_owners_dev(self._ix, q.data_ptr(), code, nq, int(quota), mask.data_ptr(),
+                                                         visited.data_ptr(), stream))
+        return mask, visited
+
     def search_partial_packed_dev(self, q, quota=10, limit=None):
         """This shard's ranked hits packed for the exchange: dict(packed int64 [nq*L, 4] (first `total` rows valid),
         cnt int32 [nq], off int64 [nq], total int64 [1], visited int32 [nq], L)."""
@@ -541,13 +553,18 @@ def merge_hits_dev(parts, with_codes=False):
 
 
 def merge_packed_dev(parts, off, cnt, nq, L, with_codes=False):
-    """Merge packed per-shard hit lists: parts [world, stride, 4] int64 (cis_hit records), off [world, nq] int64,
+    """Merge packed per-shard hit lists: parts [world, stride, 4] int64 (cis_hit records; or flat [n, 4] with absolute offsets), off [world, nq] int64,
     cnt [world, nq] int32 -> dict like search_batch_dev.  This is what follows the all-gather over xGMI: only valid
     hits travel (about nq*L records in total instead of world*nq*L)."""
     import torch
-    world, stride = int(parts.shape[0]), int(parts.shape[1])
-    if not (parts.is_cuda and parts.is_contiguous() and parts.dtype == torch.int64 and parts.shape[2] == 4):
-        raise ValueError("parts must be a contiguous int64 [world, stride, 4] tensor on the GPU")
+    if parts.dim() == 2:  # one flat record buffer [n, 4], off holds absolute record offsets (the routed search's return trip)
+        world, stride = int(off.shape[0]), 0
+        if not (parts.is_cuda and parts.is_contiguous() and parts.dtype == torch.int64 and parts.shape[1] == 4):
+            raise ValueError("parts must be a contiguous int64 [n, 4] tensor on the GPU")
+    else:
+        world, stride = int(parts.shape[0]), int(parts.shape[1])
+        if not (parts.is_cuda and parts.is_contiguous() and parts.dtype == torch.int64 and parts.shape[2] == 4):
+            raise ValueError("parts must be a contiguous int64 [world, stride, 4] tensor on the GPU")
     if not (off.is_contiguous() and off.dtype == torch.int64 and cnt.is_contiguous() and cnt.dtype == torch.int32
             and tuple(off.shape) == (world, nq) and tuple(cnt.shape) == (world, nq)):
         raise ValueError("off / cnt must be contiguous [world, nq] int64 / int32 tensors")

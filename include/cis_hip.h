@@ -232,6 +232,19 @@ int cis_index_search_partial_dev(cis_index* ix, const void* dQ, int q_dtype, int
 int cis_index_search_partial_packed_dev(cis_index* ix, const void* dQ, int q_dtype, int nq, int64_t quota, int limit,
                                         cis_hit* d_packed, int32_t* d_cnt, int64_t* d_off, int64_t* d_total,
                                         int32_t* d_visited, void* stream);
+/* Routed cell-sharded search (round 5; the all-gather protocol above replicates projection, cell ranking and walk on every rank):
+ * step 0, on a query's HOME rank -- d_mask[q] bit r = rank r owns a non-empty cell among those the multisequence walk of query q
+ * visits before the quota is reached (the walk of lopq/lopq/search.py:58-82,:128-133 against the cell sizes of the WHOLE index;
+ * world <= 64), d_visited[q] (or NULL) = the number of cells it looks at (the `visited` of the reference's result).  Uses the
+ * handle's workspaces: call it on the stream the handle's searches run on. */
+int cis_index_query_owners_dev(cis_index* ix, const void* d_q, int q_dtype, int nq, int64_t quota, uint64_t* d_mask,
+                               int32_t* d_visited, void* stream);
+/* ... step 1: the send buffers of the query all-to-all.  d_slot [world][nq]: row of query i in the block for rank d (-1: not sent;
+ * rows in query order), d_out_q [world][cap][D]: the rows, d_cnt [world]: rows used per destination, *d_overflow = 1 when a
+ * destination needed more than cap rows (the caller then answers the batch through the all-gather protocol). */
+int cis_route_queries_dev(const float* d_q, int nq, int D, const uint64_t* d_mask, int world, int cap, float* d_out_q,
+                          int32_t* d_slot, int32_t* d_cnt, int32_t* d_overflow, void* stream);
+
 /* Sharded search, step 2 (after the all-gather): merge `world` partial lists
  * d_parts [world][nq][L] into the final ranking. */
 int cis_merge_hits_dev(const cis_hit* d_parts, int world, int nq, int limit, int64_t* d_ids,
@@ -239,7 +252,8 @@ int cis_merge_hits_dev(const cis_hit* d_parts, int world, int nq, int limit, int
                        uint32_t* d_pos /* or NULL */, void* stream);
 
 /* The same for PACKED partial lists (what travels over xGMI): shard w contributed its valid hits only, in query
- * order, d_parts[w*stride + d_off[w*nq + q] .. + d_cnt[w*nq + q]) for query q.  limit <= 3072 (one wave per query; above that the caller ranks the packed lists itself: distributed.merge_packed_sorted). */
+ * order, d_parts[w*stride + d_off[w*nq + q] .. + d_cnt[w*nq + q]) for query q (stride = 0: ONE buffer, d_off holds absolute record
+ * offsets -- the return trip of the routed search).  limit <= 3072 (one wave per query; above that the caller ranks the packed lists itself: distributed.merge_packed_sorted). */
 int cis_merge_packed_dev(const cis_hit* d_parts, int world, int64_t stride, const int64_t* d_off /* [world][nq] */,
                          const int32_t* d_cnt /* [world][nq] */, int nq, int limit, int64_t* d_ids, double* d_dists,
                          int32_t* d_n_found, int32_t* d_cells /* or NULL */, uint32_t* d_pos /* or NULL */, void* stream);

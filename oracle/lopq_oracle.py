@@ -555,6 +555,26 @@ def search_partial(index, x, quota, limit, owner, rank):
     return out, visited
 
 
+def query_owners(index, x, quota, owner):
+    """Routed cell-sharded search, step 0: (bit mask of the ranks that own a non-empty cell among those the multisequence walk
+    visits before the quota is reached, visited) -- the walk and cut of search_partial (lopq/lopq/search.py:128-133), no scan."""
+    m = index.model
+    if m.has_pca:
+        x = apply_pca(m, x)
+    V = m.V
+    mask, n, visited = 0, 0, 0
+    for _, (c0, c1) in multisequence(m, x):
+        cid = int(c0) * V + int(c1)
+        size = int(index.offsets[cid + 1] - index.offsets[cid])
+        if size > 0:
+            mask |= 1 << int(owner[cid])
+        visited += 1
+        n += size
+        if n >= quota:
+            break
+    return mask, visited
+
+
 def merge_partials(parts, limit):
     """Reference merge of per-shard hit lists [world][limit] by (dist, visit_rank, pos)."""
     allh = np.concatenate([p[p["id"] >= 0] for p in parts])

@@ -210,3 +210,87 @@ def test_grid_build_four_gloo_ranks(S):
         assert p.exitcode == 0
     assert all(ret[r][0] for r in range(world))
     assert sum(ret[r][1] for r in range(world)) == 9000 * (world // S)
+
+
+def _routed_worker(rank, world, port, quota, limit, cap, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from columbiaimagesearch_amd.distributed import (greedy_cell_owner, home_slice, route_slots_torch, route_rows_torch,
+                                                          routed_send_queries, routed_return_hits, routed_merge_tables)
+        from oracle import lopq_oracle as O
+        z, X, Q = load_golden("c2")
+        m = O.OracleModel.from_npz(z)
+        ix = O.OracleCSRIndex(m, z["coarse"], z["fine"])
+        owner = greedy_cell_owner(np.diff(ix.offsets), world)
+        nq = 14
+        lo, hi = home_slice(nq, rank, world)
+        qh = np.ascontiguousarray(Q[lo:hi], dtype=np.float32)
+        # home: owners of the visited cells
+        mv = [O.query_owners(ix, q, quota, owner) for q in qh]
+        mask = torch.tensor([a for a, _ in mv], dtype=torch.int64)
+        slot, cnt, ov = route_slots_torch(mask, world, cap)
+        send = route_rows_torch(torch.from_numpy(qh), slot, cap)
+        # out: queries to the owners
+        recv_q, recv_cnt, ov = routed_send_queries(torch.from_numpy(qh), slot, send, cnt, ov)
+        if int(ov.item()):  # a block overflowed on SOME rank: every rank sees the flag
+            ret[rank] = ("overflow", int(cnt.max()))
+            return
+        n_sent, n_recv = cnt.tolist(), recv_cnt.tolist()
+        rows = torch.cat([recv_q[s, :n_recv[s]] for s in range(world)]).numpy()
+        # scan: the oracle answers for this rank's cells
+        hits = np.zeros((rows.shape[0], limit), dtype=O.HIT_DTYPE)
+        for i in range(rows.shape[0]):
+            hits[i], _ = O.search_partial(ix, rows[i], quota, limit, owner, rank)
+        ht = torch.from_numpy(hits.view(np.uint8).reshape(rows.shape[0], limit, 32).copy())
+        # back + merge tables
+        back = routed_return_hits(ht, n_recv, n_sent)
+        rec = back.reshape(-1).view(torch.int64).reshape(-1, 4)
+        valid = (rec[:, 2].reshape(-1, limit) >= 0).sum(dim=1, dtype=torch.int32)
+        off, c2 = routed_merge_tables(slot, n_sent, valid, limit)
+        flat = back.numpy().reshape(-1).view(O.HIT_DTYPE)
+        ok = True
+        asked = 0
+        for i in range(hi - lo):
+            lists = [flat[int(off[d, i]):int(off[d, i]) + int(c2[d, i])] for d in range(world)]
+            asked += sum(1 for d in range(world) if int(slot[d, i]) >= 0)
+            merged = O.merge_partials(lists, limit) if sum(len(l) for l in lists) else np.zeros(0, dtype=O.HIT_DTYPE)
+            ids, dists, visited = ix.search(qh[i], quota=quota, limit=limit)
+            ok = ok and visited == mv[i][1] and np.array_equal(merged["id"], ids) and np.array_equal(merged["dist"], dists)
+        ret[rank] = (ok, asked, hi - lo, rows.shape[0])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("quota,limit", [(50, 20), (3000, 100)])
+def test_routed_search_three_gloo_ranks(quota, limit):
+    """The routed protocol of columbiaimagesearch_amd/distributed.py (home -> owners -> home) on CPU tensors, the oracle standing in
+    for the GPU kernels: every home slice equals the single index, and a query travels to the owners of its cells only."""
+    world = 3
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_routed_worker, args=(r, world, port, quota, limit, 8, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert all(ret[r][0] is True for r in range(world)), dict(ret)
+    asked, homes, received = sum(ret[r][1] for r in range(world)), sum(ret[r][2] for r in range(world)), sum(ret[r][3] for r in range(world))
+    assert homes == 14 and asked == received and homes <= asked < homes * world  # owners only, not everybody
+
+
+def test_routed_search_overflow_flag_is_seen_by_every_rank():
+    world = 3
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_routed_worker, args=(r, world, port, 3000, 10, 1, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert all(ret[r][0] == "overflow" for r in range(world)), dict(ret)

@@ -318,6 +318,8 @@ def test_routed_insert_and_pipelined_sharded_search_rccl():
     assert out.returncode == 0, text[-3000:]
     assert text.count("routed insert + pipelined search ok") == 4, text[-3000:]
     assert "fixed-size exchange without a host read ok" in text, text[-3000:]
+    assert "routed search (owners only) == single index on every home slice" in text, text[-3000:]
+    assert "overflowing block -> all-gather protocol ok" in text, text[-3000:]
 
 
 def test_routed_device_insert_with_two_ranks_on_one_gpu():
@@ -335,6 +337,8 @@ def test_routed_device_insert_with_two_ranks_on_one_gpu():
     assert "world 2: routed device insert == routed host insert" in text, text[-3000:]
     assert text.count("routed insert + pipelined search ok") == 4, text[-3000:]
     assert "world 2: fixed-size exchange without a host read ok" in text, text[-3000:]
+    assert "world 2: routed search (owners only) == single index on every home slice" in text, text[-3000:]
+    assert "world 2: routed search, overflowing block -> all-gather protocol ok" in text, text[-3000:]
 
 
 def test_query_groups_times_cell_shards_with_four_ranks_on_one_gpu():

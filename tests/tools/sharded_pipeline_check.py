@@ -99,5 +99,62 @@ for slack, expect_flag in [(1.5, None), (0.01, True)]:
 sh.stride_slack = 1.5
 if rank == 0:
     print("world %d: fixed-size exchange without a host read ok (overflow -> exact repeat)" % world)
+# the routed search (round 5): every rank is the home of 1 / world of a batch, a query travels only to the owners of the cells it
+# visits, results stay with the home rank -- equal to the single index on the home slice; pipelined over the lanes; and once more
+# with destination blocks of one row (overflow -> the all-gather protocol answers the batch)
+from columbiaimagesearch_amd.distributed import RoutedSearcher, home_slice, route_slots_torch, route_rows_torch
+import columbiaimagesearch_amd.distributed as D_
+rt = RoutedSearcher(sh_dev)
+qall = torch.as_tensor(Q[:64]).float().cuda().contiguous()  # the routed rows travel as float32
+# the HIP routing tables against their torch restatement
+mask, vis = sh_dev.local.query_owners_dev(qall, quota=3000)
+want_vis = single.search_batch_dev(qall, quota=3000, limit=10)["visited"]
+assert torch.equal(vis, want_vis)
+for cap in (64, 5):
+    slot_t, cnt_t, ov_t = route_slots_torch(mask, world, cap)
+    send = torch.full((world, cap, qall.shape[1]), -1.0, dtype=torch.float32, device="cuda")
+    slot = torch.empty((world, 64), dtype=torch.int32, device="cuda"); cnt = torch.empty(world, dtype=torch.int32, device="cuda"); ov = torch.empty(1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().cis_route_queries_dev(qall.data_ptr(), 64, qall.shape[1], mask.data_ptr(), world, cap, send.data_ptr(), slot.data_ptr(),
+                                                cnt.data_ptr(), ov.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(slot, slot_t) and torch.equal(cnt, cnt_t) and torch.equal(ov, ov_t), cap
+    rows_t = route_rows_torch(qall, slot_t, cap)
+    used = (torch.arange(cap, device="cuda")[None, :] < cnt_t[:, None].long())
+    assert torch.equal(send[used], rows_t[used])
+assert int((mask != 0).sum()) == 64 and int(mask.max()) < (1 << world)
+for quota, limit in [(3000, 100), (50, 20), (5000, 600), (20000, 3500), (10, 0)]:
+    got, want = [], []
+    batches = [qall[i:i + 16] for i in (0, 16, 32, 48)] + [qall[:7], qall]
+    hs = []
+    for qb in batches:
+        lo, hi = home_slice(qb.shape[0], rank, world)
+        w = single.search_batch_dev(qb.contiguous(), quota=quota, limit=limit)
+        want.append({k: v[lo:hi] for k, v in w.items()})
+        hs.append(rt.search_begin(qb[lo:hi].contiguous(), quota=quota, limit=limit, nq_total=qb.shape[0]))
+        if len(hs) == 2:
+            got.append(rt.search_end(hs.pop(0)))
+    while hs:
+        got.append(rt.search_end(hs.pop(0)))
+    torch.cuda.synchronize()
+    for bi, (w, g) in enumerate(zip(want, got)):
+        for k in ("ids", "n_found", "visited"):
+            assert torch.equal(w[k], g[k]), (rank, quota, limit, bi, k, (w[k] != g[k]).nonzero()[:4].tolist(), w[k].reshape(-1)[:6].tolist(), g[k].reshape(-1)[:6].tolist())
+        dw, dg = w["dists"], g["dists"]
+        assert torch.equal(torch.isnan(dw), torch.isnan(dg)) and torch.equal(dw[~torch.isnan(dw)], dg[~torch.isnan(dg)])
+assert rt.fallbacks == 0
+if rank == 0:
+    print("world %d: routed search (owners only) == single index on every home slice" % world)
+cap_fn = D_.route_capacity
+D_.route_capacity = lambda nq_home, D, world, slack=2.0: 1
+try:
+    lo, hi = home_slice(64, rank, world)
+    g = rt.search_batch_dev(qall[lo:hi].contiguous(), quota=3000, limit=100, nq_total=64)
+    w = single.search_batch_dev(qall, quota=3000, limit=100)
+    torch.cuda.synchronize()
+    assert torch.equal(w["ids"][lo:hi], g["ids"]) and torch.equal(w["n_found"][lo:hi], g["n_found"]) and torch.equal(w["visited"][lo:hi], g["visited"])
+    assert rt.fallbacks == 1
+finally:
+    D_.route_capacity = cap_fn
+if rank == 0:
+    print("world %d: routed search, overflowing block -> all-gather protocol ok" % world)
 dist.barrier()
 dist.destroy_process_group()
