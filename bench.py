@@ -21,8 +21,12 @@ BASELINE configurations (their own ms/step, scan roofline, parity flag against t
 shapes (DeepSentibank batch 256 -> L2 normalise -> PCA 4096 -> 256, V=16 M=16 encode -> insert into the resident c3 index).
 
 N > 1: the HEADLINE is BASELINE config C4's layout -- the same 10M index sharded by coarse cell over all N GPUs (S = N cell
-shards, one query group), every rank sees the whole query batch, scans its own cells, the per-shard top-`limit` lists are
-all-gathered over RCCL and merged: "scaling": "strong" (--scaling weak: every rank brings its own --n vectors).  A second
+shards, one query group) -- answered by the ROUTED protocol (distributed.RoutedSearcher, round 5): a step is N x 8192 queries over
+the job, every rank the home of 8192; a query goes to the owners of the cells it visits only (one all-to-all out, one back):
+"scaling": "weak" (per-GPU work fixed as N grows: the query load grows, the index does not).  It is the headline only after it
+reproduced the all-gather protocol's answers on a batch; that protocol (every rank sees the whole batch of 8192
+queries, scans its own cells, the per-shard top-`limit` lists are all-gathered over RCCL and merged: strong scaling) stays in the
+line as "allgather", and is the headline with --no-routed or when the routed leg fails.  A further
 object "grid" in the same line carries the R x S layout (R query groups, each one copy of the index sharded over S GPUs;
 --cell-shards, default 2 from 4 GPUs on, whole copies at 2): its value counts every group's queries (weak in the query load).
 
@@ -1165,6 +1169,81 @@ def _roof_c(r):
     return out
 
 
+def routed_leg(ctx, st, steps, warmup):
+    """N > 1, cells only (S = N): the ROUTED protocol (columbiaimagesearch_amd/distributed.py: RoutedSearcher) on the index of the headline
+    leg.  A step = one batch of world x NQ queries over the job: every rank is the HOME of NQ of them (its own batch), finds the owners
+    of the cells they visit, sends each query to those owners only (one all-to-all), answers what it receives and merges its home
+    queries' lists.  Per-GPU work is fixed as N grows (NQ home queries, ~NQ received): weak scaling of the QUERY load over ONE 10M
+    index sharded by coarse cell.  Before the timed region the protocol is compared with the all-gather protocol on one batch."""
+    import torch.distributed as dist
+    from columbiaimagesearch_amd.distributed import RoutedSearcher, home_slice
+    device, rank, world, wd = ctx.device, ctx.rank, ctx.world, ctx.wd
+    sh = st.sharded.row
+    rt = RoutedSearcher(sh)
+    qbs = st.qbatches
+    tdev = device if ctx.backend == "nccl" else "cpu"
+
+    def agree(flag):  # every rank takes the same decision
+        t = torch.tensor([1 if flag else 0], device=tdev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+    with wd.phase("routed: equality with the all-gather protocol on one batch", 300):
+        ref = sh.search_batch_dev(qbs[0], quota=QUOTA, limit=LIMIT)      # every rank: the same NQ queries
+        lo, hi = home_slice(NQ, rank, world)
+        got = rt.search_batch_dev(qbs[0][lo:hi].contiguous(), quota=QUOTA, limit=LIMIT, nq_total=NQ)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(ref["ids"][lo:hi], got["ids"]) and torch.equal(ref["n_found"][lo:hi], got["n_found"]) and
+                    torch.equal(ref["visited"][lo:hi], got["visited"]))
+        dr, dg = ref["dists"][lo:hi], got["dists"]
+        same = same and bool(torch.equal(dr[~torch.isnan(dr)], dg[~torch.isnan(dg)]))
+        same = agree(same)
+
+    def home(b):  # this rank's home batch of step b
+        return qbs[(b * world + rank) % len(qbs)]
+
+    def run(first, n):
+        h = rt.search_begin(home(first), quota=QUOTA, limit=LIMIT, nq_total=NQ * world)
+        for b in range(1, n):
+            h2 = rt.search_begin(home(first + b), quota=QUOTA, limit=LIMIT, nq_total=NQ * world)
+            rt.search_end(h)
+            h = h2
+        rt.search_end(h)
+    with wd.phase("routed: warm-up (every lane, every batch)", 300):
+        run(0, max(warmup, 3 * len(qbs)))
+        torch.cuda.synchronize()
+    walls, reps = [], 0
+    min_reps = int(os.environ.get("CIS_BENCH_MIN_REPS", 5))
+    min_timed_s = float(os.environ.get("CIS_BENCH_MIN_TIMED_S", 0.5))
+    fb0 = rt.fallbacks
+    with wd.phase("routed: timed steps", 900):
+        while True:
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(reps * steps, steps)
+            torch.cuda.synchronize()
+            dist.barrier()
+            el = time.perf_counter() - t0
+            tt = torch.tensor([el], device=tdev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            walls.append(float(tt.item()))
+            reps += 1
+            if reps >= 400 or (reps >= min_reps and sum(walls) >= min_timed_s):
+                break
+    med = sorted(walls)[len(walls) // 2]
+    return {"metric": "queries/sec @ recall@10 on 10M LOPQ index",
+            "value": world * NQ * steps / med, "unit": "queries/s", "ms_per_step": med / steps * 1e3, "scaling": "weak",
+            "equals_allgather_protocol": same, "fallbacks_in_timed_region": rt.fallbacks - fb0,
+            "timing": {"repetitions": reps, "steps_per_repetition": steps, "timed_s": round(sum(walls), 4),
+                       "ms_per_step": {"median": med / steps * 1e3, "min": min(walls) / steps * 1e3, "max": max(walls) / steps * 1e3}},
+            "config": {"name": st.cfg_name, "index_vectors": st.N, "queries_per_step": world * NQ, "home_queries_per_gpu_and_step": NQ,
+                       "quota": QUOTA, "limit": LIMIT, "query_groups": 1, "cell_shards": world, "parallelism": "cells 1x%d, routed" % world,
+                       "batches_in_flight": 2,
+                       "workload": "ONE copy of the %d-vector index sharded by coarse cell over %d GPUs; a step = %d queries over the job, every GPU "
+                                   "the home of %d: owners of the visited cells found at home, ONE all-to-all carries a query to those owners only, "
+                                   "ranked lists return (all-to-all) and are merged at home (distributed.RoutedSearcher)" % (st.N, world, world * NQ, NQ)}}
+
+
 def compact_line(line):
     """The driver keeps the last ~8 KB of stdout: the FINAL line is a compact form (<= 4 KB) that still carries the contract's fields,
     `roofline`, `cpu_baseline` and value + roofline fraction of every leg; the full detail object is printed before it."""
@@ -1204,6 +1283,12 @@ def compact_line(line):
                             "single_query_ids_bit_exact")
     if line.get("ingest"):
         c["ingest"] = _pick(line["ingest"], "value", "unit", "ms_per_batch", "insert_ms")
+    if line.get("allgather"):
+        a = line["allgather"]
+        c["allgather"] = {"value": a["value"], "ms_per_step": a["ms_per_step"], "scaling": a["scaling"], "queries_per_step": a["config"]["queries_per_step"]}
+    if line.get("routed"):
+        r = line["routed"]
+        c["routed"] = {"error": r["error"][:160]} if "error" in r else _pick(r, "equals_allgather_protocol", "fallbacks_in_timed_region", "value", "ms_per_step")
     g = line.get("grid")
     if g:
         c["grid"] = g if "error" in g else {"value": g["value"], "ms_per_step": g["ms_per_step"], "recall_at_10": g["recall_at_10"],
@@ -1280,6 +1365,7 @@ def main():
                     help="S of the second (`grid`) layout at N > 1: R = gpus / S query groups, each one copy of the index sharded by "
                          "cell over S GPUs.  Default: 2 from 4 GPUs on, 1 (whole copies) at 2.  The headline is always S = gpus")
     ap.add_argument("--no-grid", action="store_true", help="N > 1: skip the second layout")
+    ap.add_argument("--no-routed", action="store_true", help="N > 1: skip the routed protocol (the headline is then the all-gather protocol at 8192 queries per step)")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("CIS_BENCH_PIPELINE", 3)),
                     help="N = 1: query batches in flight at once (each through its own view of the index on its own stream); 1 = one after the other")
     ap.add_argument("--no-configs", action="store_true", help="skip the c2 / c3 / c5 sub-runs of the default line")
@@ -1341,6 +1427,13 @@ def main():
     # ---- headline: BASELINE C4's layout -- ONE copy of the index sharded by coarse cell over all N GPUs ---------------------------
     head, st = search_leg(ctx, cfg_name, args.n, world, args.steps, args.warmup, args.scaling, 4096 if want_oracle else 0)
 
+    routed = None
+    if world > 1 and st.sharded is not None and st.sharded.row is not None and not args.no_routed:
+        try:
+            routed = routed_leg(ctx, st, args.steps, args.warmup)
+        except Exception as e:  # the all-gather headline stands on its own
+            routed = {"error": repr(e)}
+            sys.stderr.write("[bench rank %d] routed leg failed: %r\n" % (rank, e))
     pcie = pcie_leg(st, head["value"]) if solo and not args.no_pcie else None
     cpu = parity = None
     if want_oracle:
@@ -1441,6 +1534,19 @@ def main():
             "grid": grid,
             "configs": configs,
         }
+        if routed is not None:
+            # N > 1: the headline is the ROUTED protocol when it ran and reproduced the all-gather protocol's answers -- same index
+            # layout (one copy, sharded by coarse cell over all N GPUs), per-GPU work fixed as N grows (weak scaling of the query
+            # load); the all-gather protocol at 8192 queries per step over the whole job (strong) stays in the line as `allgather`.
+            if "error" not in routed and routed["equals_allgather_protocol"] and routed["fallbacks_in_timed_region"] == 0:
+                line["allgather"] = {"value": head["value"], "ms_per_step": head["ms_per_step"], "scaling": args.scaling, "config": head["config"],
+                                     "timing": head["timing"], "recall_at_10": head["recall_at_10"]}
+                line.update({"value": routed["value"], "ms_per_step": routed["ms_per_step"], "scaling": "weak", "config": routed["config"],
+                             "timing": routed["timing"]})
+                line["routed"] = {"equals_allgather_protocol": True, "fallbacks_in_timed_region": 0}
+                line["roofline"] = dict(line["roofline"], note="k_adc_scan launches of the all-gather leg on the same index (the routed leg runs the same kernels on the queries a rank receives)")
+            else:
+                line["routed"] = routed
     if ctx.use_dist:
         import torch.distributed as dist
         with wd.phase("final barrier", 120):

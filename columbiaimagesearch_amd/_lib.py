@@ -83,6 +83,7 @@ _PROTOS = {
     "cis_index_search_partial_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p,
                                              c_void_p]),
     "cis_index_query_owners_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    "cis_routed_merge_tables_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "cis_route_queries_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cis_index_search_partial_packed_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -4599,10 +4599,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     // (Splitting a shard's cells into chunks so that a cell-sharded index at world = 8 fills the chip again was measured
     // and lost: 0.516 against 0.306 ms per partial search -- more survivors, colder bounds: profiles/r02d_shard_emulation.txt.)
     int seg_max = use3 ? (nq >= 64 ? 65536 : 4096) : (nq >= 1024 ? (1 << 20) : (nq >= 64 ? 16384 : 4096));
-    // a shard of four or more holds few work items per batch (a rank owns 1 / world of the cells): its long cells are cut into chunks
-    // of 20480 candidates, each with its own slots, so that they spread over the chip -- emulated rank 0 of world 8: scan 0.169 -> 0.126
-    // ms, partial search 0.343 -> 0.307 ms (10240: 0.445 ms; on one GPU whole cells win: profiles/r03zb_chunk_keys.txt)
-    if (use3 && ix->world >= 4 && nq >= 64) seg_max = 20480;
+    // (Round 3 cut the long cells of a shard of four or more into chunks of 20480 candidates so that its few work items spread over
+    // the chip: partial search 0.343 -> 0.307 ms alone on the device.  With three batches in flight the whole-cell chunks win -- emulated
+    // rank 0 of world 8: 0.227 -> 0.163 ms per step, and 0.552 -> 0.479 ms for the routed protocol's full batches
+    // (profiles/r05_shards.txt) -- so the rule is gone; CIS_SEG_MAX=20480 brings it back for A/B runs.)
     // The HBM-streaming route (lopq_stream.hip): few queries, very many candidates each -- an exhaustive quota, or any quota on cells
     // of hundreds of thousands of codes.  Decided here from the bound of the candidates per query (the chunk size is part of the
     // plan); the exact count confirms it below.  Chunks of 65536 candidates, longer when the largest cell would need more than the
@@ -5457,23 +5457,59 @@ __global__ __launch_bounds__(1024) void k_route_slots(const unsigned long long* 
     }
 }
 
-__global__ void k_route_rows(const float* __restrict__ q, int nq, int D, const int32_t* __restrict__ slot, int cap, float* __restrict__ out) {
+__global__ void k_route_rows(const uint32_t* __restrict__ q, int nq, int W /* 32-bit words per row */, const int32_t* __restrict__ slot, int cap,
+                             uint32_t* __restrict__ out) {
     const int i = blockIdx.x, d = blockIdx.y;
     const int sl = slot[(int64_t)d * nq + i];
     if (sl < 0) return;
-    const float* src = q + (int64_t)i * D;
-    float* dst = out + ((int64_t)d * cap + sl) * D;
-    for (int k = threadIdx.x; k < D; k += blockDim.x) dst[k] = src[k];
+    const uint32_t* src = q + (int64_t)i * W;
+    uint32_t* dst = out + ((int64_t)d * cap + sl) * W;
+    for (int k = threadIdx.x; k < W; k += blockDim.x) dst[k] = src[k];
 }
 
-extern "C" int cis_route_queries_dev(const float* d_q, int nq, int D, const uint64_t* d_mask, int world, int cap, float* d_out_q,
+extern "C" int cis_route_queries_dev(const void* d_q, int nq, int row_bytes, const uint64_t* d_mask, int world, int cap, void* d_out_q,
                                      int32_t* d_slot, int32_t* d_cnt, int32_t* d_overflow, void* stream) {
-    CIS_REQUIRE(nq >= 0 && D > 0 && world >= 1 && world <= 64 && cap >= 1, "route: sizes out of range");
+    CIS_REQUIRE(nq >= 0 && row_bytes > 0 && row_bytes % 4 == 0 && world >= 1 && world <= 64 && cap >= 1, "route: sizes out of range");
     CIS_REQUIRE(d_slot && d_cnt && d_overflow && (nq == 0 || (d_q && d_mask && d_out_q)), "NULL buffer");
     hipStream_t st = (hipStream_t)stream;
+    const int W = row_bytes / 4;
     CIS_CHECK_HIP(hipMemsetAsync(d_overflow, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_route_slots, dim3(world), dim3(1024), 0, st, (const unsigned long long*)d_mask, nq, cap, d_slot, d_cnt, d_overflow);
-    if (nq > 0) hipLaunchKernelGGL(k_route_rows, dim3(nq, world), dim3(D >= 256 ? 256 : 64), 0, st, d_q, nq, D, d_slot, cap, d_out_q);
+    if (nq > 0) hipLaunchKernelGGL(k_route_rows, dim3(nq, world), dim3(W >= 256 ? 256 : 64), 0, st, (const uint32_t*)d_q, nq, W, d_slot, cap, (uint32_t*)d_out_q);
+    CIS_CHECK_HIP(hipGetLastError());
+    return CIS_OK;
+}
+
+// Merge tables of the routed search's return trip: the list of home query i from rank d is row base[d] + slot[d][i] of the returned
+// buffer (L records per row, ranked, valid hits first).  off = the row's first record, cnt = its valid hits (0: rank d was not asked).
+struct RouteBase { int64_t v[64]; };
+__global__ void k_routed_tables(const int32_t* __restrict__ slot, int world, int nq, RouteBase base, const cis_hit* __restrict__ hits, int L,
+                                int64_t* __restrict__ off, int32_t* __restrict__ cnt) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)world * nq) return;
+    const int d = (int)(t / nq);
+    const int sl = slot[t];
+    if (sl < 0) { off[t] = 0; cnt[t] = 0; return; }
+    const int64_t row = base.v[d] + sl;
+    const cis_hit* h = hits + row * L;
+    int lo = 0, hi = L;  // first empty slot (id < 0): the valid hits are a prefix
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (h[mid].id >= 0) lo = mid + 1; else hi = mid;
+    }
+    off[t] = row * L;
+    cnt[t] = lo;
+}
+
+extern "C" int cis_routed_merge_tables_dev(const int32_t* d_slot, int world, int nq, const int64_t* h_base, const cis_hit* d_hits, int L,
+                                           int64_t* d_off, int32_t* d_cnt, void* stream) {
+    CIS_REQUIRE(world >= 1 && world <= 64 && nq >= 0 && L >= 0, "routed merge tables: sizes out of range");
+    CIS_REQUIRE(nq == 0 || (d_slot && h_base && d_off && d_cnt && (L == 0 || d_hits)), "NULL buffer");
+    if (nq == 0) return CIS_OK;
+    RouteBase b;
+    for (int d = 0; d < 64; ++d) b.v[d] = d < world ? h_base[d] : 0;
+    const int64_t n = (int64_t)world * nq;
+    hipLaunchKernelGGL(k_routed_tables, dim3((unsigned)ceil_div(n, (int64_t)256)), dim3(256), 0, (hipStream_t)stream, d_slot, world, nq, b, d_hits, L, d_off, d_cnt);
     CIS_CHECK_HIP(hipGetLastError());
     return CIS_OK;
 }

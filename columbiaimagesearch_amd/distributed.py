@@ -441,8 +441,9 @@ def home_slice(nq, rank, world):
 
 
 def route_capacity(nq_home, D, world, slack=2.0):
-    """Rows of a destination block of the query all-to-all.  Small rows: the whole home slice fits any block (no overflow possible).
-    Long rows (a 4096-d query is 16 KB): `slack` x the even share of ~1.3 owners per query, overflow falls back."""
+    """Rows of a destination block of the query all-to-all (D = 32-bit words per row).  Small rows: the whole home slice fits any
+    block (no overflow possible).  Long rows (a 4096-d float32 query is 16 KB): `slack` x the even share of ~1.3 owners per query,
+    overflow falls back."""
     nq_home = max(int(nq_home), 1)
     if world <= 1 or D <= 512:
         return nq_home
@@ -534,6 +535,24 @@ def routed_merge_tables(slot, n_sent, valid, L):
     return off.contiguous(), cnt.contiguous()
 
 
+def routed_merge_tables_dev(slot, n_sent, rec, L):
+    """routed_merge_tables on the GPU in one launch (cis_routed_merge_tables_dev): rec int64 [rows * L, 4] = the returned lists."""
+    import ctypes
+    import torch
+    from . import _lib
+    world, nq = int(slot.shape[0]), int(slot.shape[1])
+    base = (ctypes.c_int64 * world)()
+    acc = 0
+    for d in range(world):
+        base[d] = acc
+        acc += int(n_sent[d])
+    off = torch.empty((world, nq), dtype=torch.int64, device=slot.device)
+    cnt = torch.empty((world, nq), dtype=torch.int32, device=slot.device)
+    _lib.check(_lib.lib().cis_routed_merge_tables_dev(slot.data_ptr(), world, nq, ctypes.cast(base, ctypes.c_void_p), rec.data_ptr(), int(L),
+                                                      off.data_ptr(), cnt.data_ptr(), torch.cuda.current_stream(slot.device).cuda_stream))
+    return off, cnt
+
+
 class RoutedSearcher(object):
     """Cell-sharded search with every query routed to the owners of the cells it visits (see the comment above).
 
@@ -559,21 +578,20 @@ class RoutedSearcher(object):
         cur = torch.cuda.current_stream()
         st = stream if stream is not None else cur
         L = sv._dev_args(q_home, quota, limit)[0]
-        if q_home.dtype != torch.float32:
-            raise ValueError("routed search: float32 queries")
         nqh, D = int(q_home.shape[0]), int(q_home.shape[1])
-        cap = route_capacity(-(-int(nq_total) // self.world) if nq_total is not None else nqh, D, self.world, self.slack)
+        row_bytes = D * q_home.element_size()
+        cap = route_capacity(-(-int(nq_total) // self.world) if nq_total is not None else nqh, row_bytes // 4, self.world, self.slack)
         dev = q_home.device
         if stream is not None:
             stream.wait_stream(cur)
             q_home.record_stream(stream)
         with torch.cuda.stream(st):
             mask, visited = sv.query_owners_dev(q_home, quota=quota)
-            send_q = torch.empty((self.world, cap, D), dtype=torch.float32, device=dev)
+            send_q = torch.empty((self.world, cap, D), dtype=q_home.dtype, device=dev)
             slot = torch.empty((self.world, nqh), dtype=torch.int32, device=dev)
             cnt = torch.empty(self.world, dtype=torch.int32, device=dev)
             overflow = torch.empty(1, dtype=torch.int32, device=dev)
-            _lib.check(_lib.lib().cis_route_queries_dev(q_home.data_ptr(), nqh, D, mask.data_ptr(), self.world, cap, send_q.data_ptr(),
+            _lib.check(_lib.lib().cis_route_queries_dev(q_home.data_ptr(), nqh, row_bytes, mask.data_ptr(), self.world, cap, send_q.data_ptr(),
                                                         slot.data_ptr(), cnt.data_ptr(), overflow.data_ptr(), st.cuda_stream))
             recv_q, recv_cnt, ov = routed_send_queries(q_home, slot, send_q, cnt, overflow, self.group)
             host = torch.empty(2 * self.world + 1, dtype=torch.int32, pin_memory=True)
@@ -615,10 +633,9 @@ class RoutedSearcher(object):
                 hits = torch.empty((0, L, 32), dtype=torch.uint8, device=rows.device)
             back = routed_return_hits(hits, n_recv, n_sent, self.group)
             rec = back.reshape(-1).view(torch.int64).reshape(-1, 4)
-            valid = (rec[:, 2].reshape(-1, L) >= 0).sum(dim=1, dtype=torch.int32) if back.shape[0] and L > 0 else torch.zeros(0, dtype=torch.int32, device=rows.device)
-            off, cnt = routed_merge_tables(h["slot"], n_sent, valid, L)
             if rec.shape[0] == 0:
                 rec = torch.zeros((1, 4), dtype=torch.int64, device=rows.device)
+            off, cnt = routed_merge_tables_dev(h["slot"], n_sent, rec, L)
             out = merge_packed_dev(rec, off, cnt, nqh, L)
             out["visited"] = h["visited"]
             done = torch.cuda.Event(); done.record(st)

@@ -239,11 +239,18 @@ int cis_index_search_partial_packed_dev(cis_index* ix, const void* dQ, int q_dty
  * handle's workspaces: call it on the stream the handle's searches run on. */
 int cis_index_query_owners_dev(cis_index* ix, const void* d_q, int q_dtype, int nq, int64_t quota, uint64_t* d_mask,
                                int32_t* d_visited, void* stream);
-/* ... step 1: the send buffers of the query all-to-all.  d_slot [world][nq]: row of query i in the block for rank d (-1: not sent;
- * rows in query order), d_out_q [world][cap][D]: the rows, d_cnt [world]: rows used per destination, *d_overflow = 1 when a
- * destination needed more than cap rows (the caller then answers the batch through the all-gather protocol). */
-int cis_route_queries_dev(const float* d_q, int nq, int D, const uint64_t* d_mask, int world, int cap, float* d_out_q,
+/* ... step 1: the send buffers of the query all-to-all.  d_q [nq] rows of row_bytes bytes (a multiple of 4: float32 or float64
+ * queries), d_slot [world][nq]: row of query i in the block for rank d (-1: not sent; rows in query order), d_out_q [world][cap]
+ * rows, d_cnt [world]: rows used per destination, *d_overflow = 1 when a destination needed more than cap rows (the caller then
+ * answers the batch through the all-gather protocol). */
+int cis_route_queries_dev(const void* d_q, int nq, int row_bytes, const uint64_t* d_mask, int world, int cap, void* d_out_q,
                           int32_t* d_slot, int32_t* d_cnt, int32_t* d_overflow, void* stream);
+
+/* ... step 3, back on the home rank: where the list of home query i from rank d sits in the buffer of returned lists (rows of
+ * `limit` cis_hit, grouped by answering rank; h_base [world] (HOST) = first row of rank d's group): d_off [world][nq] record
+ * offsets, d_cnt [world][nq] valid hits (0: rank d was not asked) -- the inputs of cis_merge_packed_dev with stride = 0. */
+int cis_routed_merge_tables_dev(const int32_t* d_slot, int world, int nq, const int64_t* h_base, const cis_hit* d_hits, int limit,
+                                int64_t* d_off, int32_t* d_cnt, void* stream);
 
 /* Sharded search, step 2 (after the all-gather): merge `world` partial lists
  * d_parts [world][nq][L] into the final ranking. */

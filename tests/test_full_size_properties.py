@@ -358,8 +358,8 @@ def test_query_groups_times_cell_shards_with_four_ranks_on_one_gpu():
 
 @pytest.mark.parametrize("gpus,shards,grid_groups", [(2, 0, 2), (4, 0, 2), (4, 1, 4), (8, 0, 4)])
 def test_bench_multi_rank_protocol_on_one_gpu(gpus, shards, grid_groups):
-    """`bench.py --gpus N`: the headline is BASELINE C4's layout (ONE copy of the index sharded by cell over all N ranks, strong
-    scaling); the R x S grid rides along as the `grid` object, whose value counts every group's queries.  N = 8 is the size the
+    """`bench.py --gpus N`: the headline is BASELINE C4's layout (ONE copy of the index sharded by cell over all N ranks) answered by the
+    routed protocol; the all-gather protocol (`allgather`) and the R x S grid (`grid`, whose value counts every group's queries) ride along.  N = 8 is the size the
     driver's scaling run uses: cells only (1 x 8) as the headline, the default 4 x 2 grid beside it.  stdout ends with the `#detail`
     line (every field) and ONE compact JSON line (what the driver parses)."""
     import json, os, subprocess, sys
@@ -385,11 +385,19 @@ def test_bench_multi_rank_protocol_on_one_gpu(gpus, shards, grid_groups):
             assert compact[k] == line[k] or abs(compact[k] - line[k]) <= 1e-4 * abs(line[k]), k
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(compact["roofline"])
     assert compact["grid"]["parallelism"] == "grid %dx%d" % (grid_groups, gpus // grid_groups)
-    assert line["n_gpus"] == gpus and line["scaling"] == "strong" and line["recall_at_10"] >= 0.9
-    assert line["config"]["query_groups"] == 1 and line["config"]["cell_shards"] == gpus
+    # the headline: ONE copy of the index sharded by cell over all ranks, the ROUTED protocol (a step = gpus x 8192 queries, every rank
+    # the home of 8192: weak scaling of the query load), accepted only because it reproduced the all-gather protocol's answers
+    assert line["n_gpus"] == gpus and line["scaling"] == "weak" and line["recall_at_10"] >= 0.9
+    assert line["routed"] == {"equals_allgather_protocol": True, "fallbacks_in_timed_region": 0}, line.get("routed")
+    assert line["config"]["query_groups"] == 1 and line["config"]["cell_shards"] == gpus and line["config"]["queries_per_step"] == gpus * 8192
     assert abs(line["value"] - line["config"]["queries_per_step"] * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
     assert line["config"]["index_vectors"] == 400000
     assert line["timing"]["repetitions"] >= 2 and line["timing"]["steps_per_repetition"] == 3
+    # ... and the all-gather protocol at 8192 queries per step over the whole job (strong) beside it
+    a = line["allgather"]
+    assert a["scaling"] == "strong" and a["config"]["cell_shards"] == gpus and a["config"]["queries_per_step"] == 8192 and a["recall_at_10"] >= 0.9
+    assert abs(a["value"] - 8192 * 3 / (a["ms_per_step"] * 3e-3)) <= 1e-6 * a["value"]
+    assert abs(compact["allgather"]["value"] - a["value"]) <= 1e-4 * a["value"] and compact["routed"]["equals_allgather_protocol"] is True
     g = line["grid"]
     assert "error" not in g, g
     assert g["config"]["query_groups"] == grid_groups and g["config"]["cell_shards"] == gpus // grid_groups and g["recall_at_10"] >= 0.9

@@ -114,13 +114,24 @@ for cap in (64, 5):
     slot_t, cnt_t, ov_t = route_slots_torch(mask, world, cap)
     send = torch.full((world, cap, qall.shape[1]), -1.0, dtype=torch.float32, device="cuda")
     slot = torch.empty((world, 64), dtype=torch.int32, device="cuda"); cnt = torch.empty(world, dtype=torch.int32, device="cuda"); ov = torch.empty(1, dtype=torch.int32, device="cuda")
-    _lib.check(_lib.lib().cis_route_queries_dev(qall.data_ptr(), 64, qall.shape[1], mask.data_ptr(), world, cap, send.data_ptr(), slot.data_ptr(),
+    _lib.check(_lib.lib().cis_route_queries_dev(qall.data_ptr(), 64, qall.shape[1] * 4, mask.data_ptr(), world, cap, send.data_ptr(), slot.data_ptr(),
                                                 cnt.data_ptr(), ov.data_ptr(), torch.cuda.current_stream().cuda_stream))
     assert torch.equal(slot, slot_t) and torch.equal(cnt, cnt_t) and torch.equal(ov, ov_t), cap
     rows_t = route_rows_torch(qall, slot_t, cap)
     used = (torch.arange(cap, device="cuda")[None, :] < cnt_t[:, None].long())
     assert torch.equal(send[used], rows_t[used])
 assert int((mask != 0).sum()) == 64 and int(mask.max()) < (1 << world)
+# the merge tables of the return trip: one launch against their torch restatement
+from columbiaimagesearch_amd.distributed import routed_merge_tables, routed_merge_tables_dev
+slot_t, cnt_t, _ = route_slots_torch(mask, world, 64)
+n_sent_t = cnt_t.tolist()
+fake = sh_dev.local.search_partial_dev(qall, quota=50, limit=20)[0]  # 64 ranked lists, some short
+rows_back = fake[torch.arange(int(sum(n_sent_t)), device="cuda") % 64].contiguous()
+rec_t = rows_back.reshape(-1).view(torch.int64).reshape(-1, 4)
+valid_t = (rec_t[:, 2].reshape(-1, 20) >= 0).sum(dim=1, dtype=torch.int32)
+o1, c1 = routed_merge_tables(slot_t, n_sent_t, valid_t, 20)
+o2, c2 = routed_merge_tables_dev(slot_t, n_sent_t, rec_t, 20)
+assert torch.equal(c1, c2) and torch.equal(o1[c1 > 0], o2[c1 > 0])
 for quota, limit in [(3000, 100), (50, 20), (5000, 600), (20000, 3500), (10, 0)]:
     got, want = [], []
     batches = [qall[i:i + 16] for i in (0, 16, 32, 48)] + [qall[:7], qall]
@@ -140,6 +151,13 @@ for quota, limit in [(3000, 100), (50, 20), (5000, 600), (20000, 3500), (10, 0)]
             assert torch.equal(w[k], g[k]), (rank, quota, limit, bi, k, (w[k] != g[k]).nonzero()[:4].tolist(), w[k].reshape(-1)[:6].tolist(), g[k].reshape(-1)[:6].tolist())
         dw, dg = w["dists"], g["dists"]
         assert torch.equal(torch.isnan(dw), torch.isnan(dg)) and torch.equal(dw[~torch.isnan(dw)], dg[~torch.isnan(dg)])
+# float64 queries travel as float64 rows
+q64 = torch.as_tensor(Q[:40]).double().cuda().contiguous()
+lo, hi = home_slice(40, rank, world)
+w = single.search_batch_dev(q64, quota=3000, limit=100)
+g = rt.search_batch_dev(q64[lo:hi].contiguous(), quota=3000, limit=100, nq_total=40)
+torch.cuda.synchronize()
+assert torch.equal(w["ids"][lo:hi], g["ids"]) and torch.equal(w["visited"][lo:hi], g["visited"]) and torch.equal(w["dists"][lo:hi], g["dists"])
 assert rt.fallbacks == 0
 if rank == 0:
     print("world %d: routed search (owners only) == single index on every home slice" % world)
