@@ -2593,7 +2593,8 @@ static void launch_scan3_t(const Scan3Geom& g, int64_t n_items, hipStream_t st, 
             const int nw4_short = getenv("CIS_S4_NWS") ? atoi(getenv("CIS_S4_NWS")) : CIS_S4_NW_SHORT;
             auto grid_of = [&](size_t lds4, int wps, int nw4) -> unsigned {
                 const int by_lds4 = (int)(163840 / lds4), by_waves4 = (wps * 4) / nw4;
-                const int per_cu4 = by_lds4 < by_waves4 ? by_lds4 : by_waves4;
+                int per_cu4 = by_lds4 < by_waves4 ? by_lds4 : by_waves4;
+                if (const char* e = getenv("CIS_S4_PER_CU")) per_cu4 = atoi(e) > 0 && atoi(e) < per_cu4 ? atoi(e) : per_cu4;  // A/B: room for other batches' kernels
                 const int64_t resident4 = 256 * (per_cu4 < 1 ? 1 : per_cu4);
                 return (unsigned)(want < resident4 ? ((want + 7) / 8) * 8 : resident4);
             };

@@ -15,6 +15,7 @@
 //   PCA -> coarse distances (numpy order) -> per-split rank -> multisequence plan (count) ->
 //   exclusive scan -> plan (emit work items + table list) -> ADC tables -> ADC scan + block
 //   top-k -> per-query merge -> ids/dists.
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <algorithm>
@@ -4528,6 +4529,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                         hipStream_t st) {
     cis_model* m = ix->m;
     const int V = m->V, D = m->D, K = m->K, M = m->M, h = m->h, nf = m->nf;
+    const auto t_entry = std::chrono::steady_clock::now();
     ix->last_scan_kernel = 0;
     cis_index::ProfRec pr;
     pr.has_scan = false;
@@ -4768,6 +4770,18 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (!got) {
             CIS_CHECK_HIP(hipStreamSynchronize(st));
             CIS_REQUIRE(__atomic_load_n(&ix->h_totals[3], __ATOMIC_ACQUIRE) == seq, "plan totals did not arrive");
+        }
+        {   // CIS_HOST_TIMING=1: where the host spends a batch (stderr, every 400 batches): entry -> plan totals requested, the wait for them
+            static const bool ht = getenv("CIS_HOST_TIMING") != nullptr;
+            if (ht) {
+                static std::atomic<long long> n_{0}, wait_ns{0}, front_ns{0};
+                const auto t1 = std::chrono::steady_clock::now();
+                wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+                front_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(t0 - t_entry).count();
+                if (++n_ % 400 == 0)
+                    fprintf(stderr, "[cis] host timing over %lld batches: front-end enqueue %.1f us, wait for the plan totals %.1f us per batch\n", (long long)n_,
+                            front_ns / 1e3 / n_, wait_ns / 1e3 / n_);
+            }
         }
         n_items = h_tot[0]; n_tabs = h_tot[1]; n_cand_all = h_tot[2];
         ix->stats_pending_seq = 0;
