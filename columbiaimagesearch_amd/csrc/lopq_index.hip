@@ -417,6 +417,178 @@ __global__ void k_ins_commit(const uint32_t* __restrict__ key, const uint32_t* _
     }
 }
 
+// ---- small batches (round 5): a 256-item insert was twelve launches of 5-7 us each behind each other (keys, four radix passes, gather,
+// dedup, three scan kernels, scatter, commit, memset, statistics).  Up to 1024 items ONE workgroup does the keys, a stable sort by
+// cell in LDS and the gather (k_ins_small_sort), k_ins_dedup stays what it is (a wave per item walks a cell), and ONE workgroup does
+// the prefix sums, the in-place scatter, the commit and the statistics of the global cell sizes (k_ins_small_place).  Same arrays,
+// same order of the accepted items, same statistics words as the general path, which remains for larger batches and for the rebuild.
+static const int INS_SMALL = 1024;
+
+__global__ __launch_bounds__(1024) void k_ins_small_sort(const int64_t* __restrict__ ids, const uint16_t* __restrict__ coarse,
+                                                         const uint8_t* __restrict__ fine, int n, int V, int M, int K,
+                                                         const int32_t* __restrict__ owner, int rank, int world, int sel, int dedup,
+                                                         uint32_t* __restrict__ skey, uint32_t* __restrict__ perm, int64_t* __restrict__ idv,
+                                                         int64_t* __restrict__ sid, int64_t* __restrict__ gcount, int64_t* __restrict__ stats) {
+    __shared__ uint64_t s_k[INS_SMALL];
+    __shared__ int64_t s_id[INS_SMALL];
+    const int i = threadIdx.x;
+    uint32_t k = 0xffffffffu;  // padding sorts behind every item
+    if (i < n) {
+        const int c0 = coarse[2 * i], c1 = coarse[2 * i + 1];
+        const int64_t id = ids[i];
+        bool valid = c0 < V && c1 < V && id >= 0;
+        if (valid && K < 256)
+            for (int j = 0; j < M; ++j) valid = valid && fine[(int64_t)i * M + j] < K;
+        int64_t keep = -1;
+        k = 0;
+        if (!valid) {
+            if (sel == 0) atomicAdd((unsigned long long*)&stats[INS_INVALID], 1ull);
+        } else {
+            const int64_t cell = (int64_t)c0 * V + c1;
+            const bool mine = dev_owns(cell, owner, rank, world);
+            if (mine == (sel == 0)) {
+                k = (uint32_t)cell;
+                keep = id;
+            } else if (sel == 0 && !dedup) {
+                atomicAdd((unsigned long long*)&gcount[cell], 1ull);
+                atomicAdd((unsigned long long*)&stats[INS_REMOTE_PLAIN], 1ull);
+            }
+        }
+        s_id[i] = keep;
+        idv[i] = keep;
+    }
+    s_k[i] = ((uint64_t)k << 32) | (uint32_t)i;  // the position makes every key unique: the network's order IS the stable order
+    int n2 = 64;
+    while (n2 < n) n2 <<= 1;
+    for (int kk = 2; kk <= n2; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            if (i < (n2 >> 1)) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+                const bool up = (lo & kk) == 0;
+                const uint64_t a = s_k[lo], b = s_k[hi];
+                if ((b < a) == up) { s_k[lo] = b; s_k[hi] = a; }
+            }
+        }
+    __syncthreads();
+    if (i < n) {
+        const uint64_t v = s_k[i];
+        const uint32_t src = (uint32_t)v;
+        skey[i] = (uint32_t)(v >> 32);
+        perm[i] = src;
+        sid[i] = s_id[src];
+    }
+}
+
+// One workgroup: apre = exclusive scan of acc (total behind it, added to stats[acc_word]); the in-place scatter of k_ins_scatter<true>;
+// if nothing overflowed, the commit of k_ins_commit; the statistics of the global cell sizes (ncells <= STAT_CELLS: in here, else the
+// caller launches k_gcount_stats).
+__global__ __launch_bounds__(1024) void k_ins_small_place(const uint32_t* __restrict__ key, const uint32_t* __restrict__ perm,
+                                                          const int64_t* __restrict__ sid, const uint32_t* __restrict__ acc,
+                                                          uint32_t* __restrict__ apre, int n, int acc_word, const int64_t* __restrict__ loff,
+                                                          int64_t* __restrict__ lend, const uint8_t* __restrict__ fine, int M,
+                                                          int64_t* __restrict__ ids_cur, uint8_t* __restrict__ codes_cur,
+                                                          unsigned long long* __restrict__ cmaxp, int64_t* __restrict__ gcount, int64_t ncells,
+                                                          int do_stats, int64_t* __restrict__ stats) {
+    __shared__ uint32_t s_pre[INS_SMALL + 1];
+    __shared__ uint32_t s_key[INS_SMALL];
+    __shared__ uint32_t s_w[17];
+    __shared__ int s_over;
+    __shared__ long long s_sum[16], s_max[16], s_ne[16];
+    const int j = threadIdx.x, lane = j & 63, wv = j >> 6;
+    if (j == 0) s_over = 0;
+    const uint32_t a = j < n ? acc[j] : 0u;
+    const uint32_t c = j < n ? key[j] : 0xffffffffu;
+    s_key[j] = c;
+    // exclusive scan of the 0 / 1 flags: ballot inside the wave, the waves' totals through LDS
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(a != 0u);
+    const uint32_t before = (uint32_t)__builtin_popcountll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) s_w[wv] = (uint32_t)__builtin_popcountll(b);
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wv) wbase += s_w[w];
+        total += s_w[w];
+    }
+    const uint32_t pre = wbase + before;
+    s_pre[j] = pre;
+    if (j < n) apre[j] = pre;
+    if (j == 0) {
+        apre[n] = total;  // `total`: one word behind the prefix array
+        stats[acc_word] += (int64_t)total;
+    }
+    __syncthreads();
+    // first item of this item's cell in the sorted batch (n <= 1024: a binary search in LDS)
+    int l0 = 0;
+    {
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_key[mid] < c) lo = mid + 1; else hi = mid;
+        }
+        l0 = lo;
+    }
+    const bool on = j < n && a != 0u;
+    unsigned long long v = 0ull;
+    if (on) {
+        const int64_t dst = lend[c] + (int64_t)(pre - s_pre[l0]);
+        const bool fits = dst < loff[c + 1];
+        if (!fits) { s_over = 1; stats[INS_OVERFLOW] = 1; }
+        const int64_t id = sid[j];
+        if (fits) {
+            ids_cur[dst] = id;
+            if (codes_cur) {
+                const int64_t i = perm[j];
+                for (int bb = 0; bb < M; ++bb) codes_cur[dst * M + bb] = fine[i * M + bb];
+            }
+        }
+        v = (unsigned long long)id + 1ull;
+    }
+    // the cell's largest id: segmented maximum over the runs of equal cells inside the wave.  Rejected items take no part (as in
+    // k_ins_scatter, where they carry no cell): a run that ENDS with a rejected item must still publish its maximum.
+    const uint32_t cm = on ? c : 0xffffffffu;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long u = __shfl_up(v, o);
+        const uint32_t cu = __shfl_up(cm, o);
+        if (lane >= o && cu == cm && u > v) v = u;
+    }
+    const uint32_t cn = __shfl_down(cm, 1);
+    if (on && (lane == 63 || cn != cm)) atomicMax(&cmaxp[c], v);
+    __threadfence();   // the items are in place before a cell's used end moves
+    __syncthreads();
+    if (s_over != 0) return;  // nothing became visible: the caller's rebuild takes the whole batch
+    if (j < n && (j + 1 >= n || s_key[j + 1] != c)) {  // the last item of a cell's run commits the run
+        const int64_t add = (int64_t)(pre + a) - (int64_t)s_pre[l0];
+        if (add > 0) {
+            lend[c] += add;
+            gcount[c] += add;
+        }
+    }
+    if (!do_stats) return;
+    __threadfence();
+    __syncthreads();
+    long long sum = 0, mx = 0, ne = 0;
+    for (int64_t cc = j; cc < ncells; cc += 1024) {
+        const long long g = gcount[cc];
+        sum += g;
+        mx = g > mx ? g : mx;
+        ne += g > 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_xor(sum, o);
+        const long long m2 = __shfl_xor(mx, o);
+        mx = m2 > mx ? m2 : mx;
+        ne += __shfl_xor(ne, o);
+    }
+    if (lane == 0) { s_sum[wv] = sum; s_max[wv] = mx; s_ne[wv] = ne; }
+    __syncthreads();
+    if (j == 0) {
+        for (int w = 1; w < 16; ++w) { sum += s_sum[w]; mx = s_max[w] > mx ? s_max[w] : mx; ne += s_ne[w]; }
+        stats[INS_NTOTAL] = sum; stats[INS_MAXCELL] = mx; stats[INS_NONEMPTY] = ne;
+    }
+}
+
 // statistics of the global cell-size table: total, largest cell, non-empty cells (atomics into zeroed words)
 __global__ __launch_bounds__(256) void k_gcount_stats(const int64_t* __restrict__ gcount, int64_t ncells, int64_t* __restrict__ stats) {
     __shared__ long long s_sum[4], s_max[4], s_ne[4];
@@ -703,28 +875,62 @@ static int store_merge(cis_index* ix, CellStore& s, int sel, const int64_t* d_id
     const int32_t* d_owner = ix->d_owner.as<int32_t>();
     int64_t* stats = ix->d_stats.as<int64_t>();
     int64_t* gcount = ix->d_gcount.as<int64_t>();
-    hipLaunchKernelGGL(k_ins_keys, dim3(grid_for(n, 256)), dim3(256), 0, st, d_ids, d_coarse, d_fine, n, V, M, K, d_owner, ix->rank,
-                       ix->world, sel, dedup, ix->wi_key[0].as<uint32_t>(), ix->wi_val[0].as<uint32_t>(), ix->wi_tmp.as<int64_t>(),
-                       gcount, stats);
+    static const bool no_small = getenv("CIS_INS_NO_SMALL") != nullptr;  // A/B and tests: the general path for every batch size
+    const bool small = n > 0 && n <= INS_SMALL && !no_small;
     int gen = 0;
-    CIS_TRY(radix_sort_pairs(ix, n, key_bits(nc), st, &gen));
+    int64_t* sid = ix->wi_sid.as<int64_t>();
+    if (small) {
+        gen = 1;
+        hipLaunchKernelGGL(k_ins_small_sort, dim3(1), dim3(1024), 0, st, d_ids, d_coarse, d_fine, (int)n, V, M, K, d_owner, ix->rank, ix->world, sel,
+                           dedup, ix->wi_key[1].as<uint32_t>(), ix->wi_val[1].as<uint32_t>(), ix->wi_tmp.as<int64_t>(), sid, gcount, stats);
+    } else {
+        hipLaunchKernelGGL(k_ins_keys, dim3(grid_for(n, 256)), dim3(256), 0, st, d_ids, d_coarse, d_fine, n, V, M, K, d_owner, ix->rank,
+                           ix->world, sel, dedup, ix->wi_key[0].as<uint32_t>(), ix->wi_val[0].as<uint32_t>(), ix->wi_tmp.as<int64_t>(),
+                           gcount, stats);
+        CIS_TRY(radix_sort_pairs(ix, n, key_bits(nc), st, &gen));
+    }
     const uint32_t* skey = ix->wi_key[gen].as<uint32_t>();
     const uint32_t* perm = ix->wi_val[gen].as<uint32_t>();
-    int64_t* sid = ix->wi_sid.as<int64_t>();
     uint32_t* acc = ix->wi_acc.as<uint32_t>();
     uint32_t* apre = ix->wi_apre.as<uint32_t>();
     uint32_t* total = apre + n;  // one word behind the prefix array
     int64_t* loff = s.loff[s.cur].as<int64_t>();
     int64_t* lend = loff + nc + 1;
     unsigned long long* cmaxp = s.cmax.as<unsigned long long>();
-    hipLaunchKernelGGL(k_ins_gather, dim3(grid_for(n, 256)), dim3(256), 0, st, (const int64_t*)ix->wi_tmp.as<int64_t>(), perm, n, sid);
+    if (!small) hipLaunchKernelGGL(k_ins_gather, dim3(grid_for(n, 256)), dim3(256), 0, st, (const int64_t*)ix->wi_tmp.as<int64_t>(), perm, n, sid);
     hipLaunchKernelGGL(k_ins_dedup, dim3(grid_for(n, 4)), dim3(256), 0, st, skey, (const int64_t*)sid, n, dedup, (const int64_t*)loff,
                        (const int64_t*)lend, (const int64_t*)s.ids[s.cur].as<int64_t>(), (const unsigned long long*)cmaxp, acc);
-    dev_exclusive_scan<uint32_t, uint32_t>(acc, apre, n, ix->wi_scan.as<uint32_t>(), total, stats + acc_word, st);
     const int slack = slack_const(ix);
     int64_t* gsink = gcount;  // (the id-only store of the other shards' cells counts into the global cell sizes as well)
+    const bool small_place = small && slack >= 0 && s.n > 0;
+    if (!small_place) dev_exclusive_scan<uint32_t, uint32_t>(acc, apre, n, ix->wi_scan.as<uint32_t>(), total, stats + acc_word, st);
+    // ---- in place, up to 1024 items: prefix sums, scatter, commit and statistics in one workgroup (three launches per insert) ----
+    if (small_place) {
+        uint8_t* codes_cur = s.with_codes ? s.codes[s.cur].as<uint8_t>() : nullptr;
+        const int do_stats = nc <= 65536 ? 1 : 0;
+        hipLaunchKernelGGL(k_ins_small_place, dim3(1), dim3(1024), 0, st, skey, perm, (const int64_t*)sid, (const uint32_t*)acc, apre, (int)n, acc_word,
+                           (const int64_t*)loff, lend, d_fine, M, s.ids[s.cur].as<int64_t>(), codes_cur, cmaxp, gsink, nc, do_stats, stats);
+        if (!do_stats) {
+            CIS_CHECK_HIP(hipMemsetAsync(stats + INS_NTOTAL, 0, 3 * sizeof(int64_t), st));
+            hipLaunchKernelGGL(k_gcount_stats, dim3((unsigned)std::min<int64_t>(ceil_div(nc, 256), 1024)), dim3(256), 0, st, (const int64_t*)gcount, nc, stats);
+        }
+        CIS_CHECK_HIP(hipGetLastError());
+        CIS_CHECK_HIP(hipMemcpyAsync(ix->h_ins, ix->d_stats.p, INS_WORDS * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        CIS_CHECK_HIP(hipStreamSynchronize(st));
+        if (ix->h_ins[INS_OVERFLOW] == 0) {
+            s.n += ix->h_ins[acc_word];
+            if (sel == 0) ix->n_inplace += 1;
+            ix->n_total = ix->h_ins[INS_NTOTAL];
+            ix->max_cell = ix->h_ins[INS_MAXCELL];
+            ix->nonempty_cells = ix->h_ins[INS_NONEMPTY];
+            ix->nb_indexed = ix->n_total;
+            ix->stats_fresh = true;
+            return CIS_OK;
+        }
+        CIS_CHECK_HIP(hipMemsetAsync(stats + INS_OVERFLOW, 0, sizeof(int64_t), st));
+    }
     // ---- in place: the accepted items behind their cells' last items, if every one of them fits its cell's slack ----
-    if (slack >= 0 && s.n > 0 && n <= INPLACE_MAX) {
+    if (!small_place && slack >= 0 && s.n > 0 && n <= INPLACE_MAX) {
         uint8_t* codes_cur = s.with_codes ? s.codes[s.cur].as<uint8_t>() : nullptr;
         hipLaunchKernelGGL((k_ins_scatter<true>), dim3(grid_for(n, 256)), dim3(256), 0, st, skey, perm, (const int64_t*)sid, (const uint32_t*)acc,
                            (const uint32_t*)apre, n, (const int64_t*)loff, (const int64_t*)lend, (const int64_t*)nullptr, (const uint32_t*)nullptr,

@@ -110,6 +110,23 @@ def test_dedup_after_plain_adds_and_non_monotone_ids():
     assert s.get_nb_indexed() == 8
 
 
+def test_a_cell_run_that_ends_with_a_rejected_item_still_raises_the_cells_maximum():
+    """The duplicate lookup skips the walk of a cell for ids at or above the cell's recorded maximum.  An in-place batch whose items of
+    one cell END with a rejected one (a duplicate) must still record the larger id it accepted before it -- found in round 5: the fused
+    small-batch kernel published a run's maximum from the run's last lane, which a rejected item does not do."""
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    m, z, X, Q = _model("tiny")
+    M = m.M
+    s = LOPQSearcherHIP(m)
+    c = np.zeros((4, 2), dtype=np.uint16)
+    f = np.arange(4 * M, dtype=np.uint8).reshape(4, M) % 8
+    assert s.add_codes_array(c, f, np.array([50, 10, 20, 30]), dedup=True) == 4           # the bulk load: maximum 50
+    assert s.add_codes_array(c[:2], f[:2], np.array([100, 50]), dedup=True) == 1           # in place; the run ends with the duplicate 50
+    assert s.add_codes_array(c[:3], f[:3], np.array([100, 70, 100]), dedup=True) == 1      # 100 is stored: only 70 is new
+    assert [i for i, _ in s.get_cell((0, 0))] == [50, 10, 20, 30, 100, 70]
+    assert s.insert_counters()[0] >= 2                                                     # both small batches went in place
+
+
 @pytest.mark.parametrize("V", [300, 1024])
 def test_device_insert_with_thousands_of_cells(V):
     """V*V = 90 000 / 1 M cells: several radix passes over the cell keys, the thread-per-cell move of tiny cells."""
@@ -194,7 +211,8 @@ def test_l2_normalisation_kernel_matches_numpy():
 
 
 def test_small_batches_are_inserted_in_place_and_equal_the_dict_index(monkeypatch):
-    """Round 4: a batch whose accepted items fit the slack behind their cells is written IN PLACE (two kernels, O(batch) bytes:
+    """Round 4: a batch whose accepted items fit the slack behind their cells is written IN PLACE (O(batch) bytes; round 5: up to 1024
+    items in three launches -- k_ins_small_sort, k_ins_dedup, k_ins_small_place --:
     the reference appends to a per-cell list, lopq/lopq/search.py:349-364); a batch that does not fit rebuilds the layout and
     renews the slack.  Same cells, same order, same search results as the oracle's dict index on both routes -- ids below and above
     the cells' maxima, duplicates inside a batch and against stored items, a cell that fills up."""
