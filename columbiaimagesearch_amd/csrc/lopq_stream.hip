@@ -34,6 +34,9 @@
 #ifndef CIS_STREAM_U
 #define CIS_STREAM_U 0      // 16-byte loads per lane and iteration; 0: two for one query per slot and for the sample pass, four for a pair
 #endif                      // (measured on 200 M codes, profiles/r05_experiments.txt: 324 / 333 / 339 us for ring + 2, ring + 4, no ring + 4)
+#ifndef CIS_STREAM_NW
+#define CIS_STREAM_NW 4     // waves per workgroup = per slot: the workgroup reads NW KB of contiguous codes per load round
+#endif
 #ifndef CIS_STREAM_REPL
 #define CIS_STREAM_REPL 0
 #endif
@@ -50,7 +53,7 @@ __global__ void k_stream_init(uint32_t* __restrict__ bmin, int64_t n_b, int* __r
 // One workgroup (four waves) per slot at a time, persistent over the slots with a stride of the grid.  A slot = one chunk of one
 // cell for up to G queries (the slot builder of lopq_search.hip groups the work items of a cell chunk).
 template <int M, int G, bool SAMPLE>
-__global__ __launch_bounds__(256) void k_adc_stream(const WorkItem* __restrict__ items, const int* __restrict__ slots, const int* __restrict__ n_slots,
+__global__ __launch_bounds__(64 * CIS_STREAM_NW) void k_adc_stream(const WorkItem* __restrict__ items, const int* __restrict__ slots, const int* __restrict__ n_slots,
                                                     const float* __restrict__ T32 /* null: converted from T */, const double* __restrict__ T,
                                                     const uint8_t* __restrict__ codes, int K,
                                                     const int64_t* __restrict__ cand_start, const int64_t* __restrict__ seg,
@@ -67,7 +70,10 @@ __global__ __launch_bounds__(256) void k_adc_stream(const WorkItem* __restrict__
     // whatever their k): built, bit-identical, and slower -- see the macro.
     // MEASURED (profiles/r05g_*): 357 us against 333-339 us per exhaustive launch over 200 M codes -- the conflicts go (the LDS pipe was
     // 0.72 busy, not saturated), four times the staging and 32 KB per workgroup cost more: the stream waits on HBM.
-    constexpr int R = CIS_STREAM_REPL ? (32 / G) / M : 1;    // copies
+    // CIS_STREAM_REPL = 1: as many copies as a 128-byte row holds (no conflict at all); = 2: TWO copies (rows of 64 bytes: lanes l and
+    // l + 16 of a read group share a copy and a sub-quantizer, so a read is two passes instead of ~2.9, at 16 KB per workgroup)
+    constexpr int RMAX = (32 / G) / M > 0 ? (32 / G) / M : 1;
+    constexpr int R = CIS_STREAM_REPL == 1 ? RMAX : (CIS_STREAM_REPL == 2 ? (RMAX >= 2 ? 2 : 1) : 1);    // copies
     constexpr int ROWSH = (R * M * G * 4 == 128) ? 7 : (R * M * G * 4 == 64 ? 6 : (R * M * G * 4 == 32 ? 5 : 4));  // log2(row bytes)
     static_assert(R >= 1 && (1 << ROWSH) == R * M * G * 4, "rows of 16 .. 128 bytes");
     extern __shared__ __align__(16) float s_tab[];  // [K][R][M][G]
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256) void k_adc_stream(const WorkItem* __restrict__
         float tg[G];
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(codes + start * M), 0, len * M, 0x00020000);
         const int rows = (len + ROW - 1) / ROW;
-        const int rstep = SAMPLE ? 4 * sample_stride : 4;
+        const int rstep = SAMPLE ? CIS_STREAM_NW * sample_stride : CIS_STREAM_NW;
         const int rfirst = wv * (SAMPLE ? sample_stride : 1);
         // past the chunk the descriptor returns zeros (no memory access); such candidates are masked below
         auto request = [&](int r0, u32x4_t(&dst)[U]) {
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void k_adc_stream(const WorkItem* __restrict__
             tg[g] = (on && !SAMPLE) ? tau[it.q] : -1.0f;
             // tables: thread t stages entries k = t, t + 256, ... of every sub-quantizer (coalesced reads of T32[tab][j][k])
             const int64_t t0 = (int64_t)it.tab0 * nf * K, t1 = (int64_t)it.tab1 * nf * K;
-            for (int k = tid; k < K; k += 256) {
+            for (int k = tid; k < K; k += 64 * CIS_STREAM_NW) {
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
                     const float e = on ? (j < nf ? tab_f1(T32, T, t0 + j * K + k) : tab_f1(T32, T, t1 + (j - nf) * K + k)) : 0.f;
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256) void k_adc_stream(const WorkItem* __restrict__
 #pragma unroll
             for (int g = 0; g < G; ++g)
                 if (qg[g] >= 0 && f2u(mn[g]) < 0x7f800000u)
-                    atomicMin(&bmin[(int64_t)qg[g] * B + (((unsigned)s * 256u + (unsigned)tid) & (unsigned)(B - 1))], f2u(mn[g]));
+                    atomicMin(&bmin[(int64_t)qg[g] * B + (((unsigned)s * (64u * CIS_STREAM_NW) + (unsigned)tid) & (unsigned)(B - 1))], f2u(mn[g]));
         }
     }
 }
@@ -357,13 +363,17 @@ __global__ void k_stream_verify(const uint64_t* __restrict__ sel_keys, const int
 // ---- host ------------------------------------------------------------------------------------------------------------------------
 bool stream_supported(int M, int K, int L) { return (M == 4 || M == 8 || M == 16) && K <= 256 && L >= 1 && L <= 1024; }
 
-size_t stream_lds(int M, int K, int G) { return CIS_STREAM_REPL ? (size_t)K * 128 : (size_t)K * M * G * sizeof(float); }
+size_t stream_lds(int M, int K, int G) {
+    const int rmax = (32 / G) / M > 0 ? (32 / G) / M : 1;
+    const int R = CIS_STREAM_REPL == 1 ? rmax : (CIS_STREAM_REPL == 2 ? (rmax >= 2 ? 2 : 1) : 1);
+    return (size_t)K * R * M * G * sizeof(float);
+}
 
 template <int M, int G, bool SAMPLE>
 static void launch_stream_t(int grid, hipStream_t st, const WorkItem* items, const int* slots, const int* n_slots, const float* T32, const double* T,
                             const uint8_t* codes, int K, const int64_t* cand_start, const int64_t* seg, const float* tau, uint32_t* bmin, int B,
                             int sample_stride, uint32_t* surv, int* cnt, int cap) {
-    hipLaunchKernelGGL((k_adc_stream<M, G, SAMPLE>), dim3((unsigned)grid), dim3(256), stream_lds(M, K, G), st, items, slots, n_slots, T32, T, codes, K,
+    hipLaunchKernelGGL((k_adc_stream<M, G, SAMPLE>), dim3((unsigned)grid), dim3(64 * CIS_STREAM_NW), stream_lds(M, K, G), st, items, slots, n_slots, T32, T, codes, K,
                        cand_start, seg, tau, bmin, B, sample_stride, surv, cnt, cap);
 }
 
@@ -390,7 +400,7 @@ int stream_grid(int M, int G, int K, int64_t max_slots) {
         int nb = 0;
         hipError_t e = hipErrorUnknown;
         const size_t lds = stream_lds(M, 256, G);
-#define CIS_OCC(MM, GG) if (M == MM && G == GG) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_adc_stream<MM, GG, false>, 256, lds);
+#define CIS_OCC(MM, GG) if (M == MM && G == GG) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_adc_stream<MM, GG, false>, 64 * CIS_STREAM_NW, lds);
         CIS_OCC(4, 1) CIS_OCC(4, 2) CIS_OCC(8, 1) CIS_OCC(8, 2) CIS_OCC(16, 1) CIS_OCC(16, 2)
 #undef CIS_OCC
         per_cu[mi][gi] = (e == hipSuccess && nb > 0) ? (nb > 8 ? 8 : nb) : 4;

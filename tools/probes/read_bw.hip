@@ -1,0 +1,59 @@
+// What a READ-ONLY stream over 1.6 GB reaches on this part (the ceiling of k_adc_stream's memory side): 16-byte loads per lane, U loads in
+// flight per wave, a persistent grid, one xor per dword (nothing else).  Build + run: tools/probes/run_read_bw.sh
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int U>
+__global__ __launch_bounds__(256) void k_read(const u32x4* __restrict__ p, int64_t n16, uint32_t* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    uint32_t acc = 0;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < n16; i += stride) { const u32x4 v = p[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x12345678u) out[0] = acc;  // never true for the pattern below: keeps the loads alive
+}
+
+template <int U>
+static int run(const u32x4* d, int64_t n16, uint32_t* out, int per_cu) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int grid = 256 * per_cu;
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_read<U>, dim3(grid), dim3(256), 0, 0, d, n16, out);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e9f;
+    for (int r = 0; r < 8; ++r) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_read<U>, dim3(grid), dim3(256), 0, 0, d, n16, out);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    printf("read-only stream, %d x 16-byte loads per lane in flight, %2d workgroups per CU: %.3f ms  %.2f TB/s  (%.3f of 8 TB/s)\n", U, per_cu, best,
+           n16 * 16.0 / best / 1e9, n16 * 16.0 / best / 1e9 / 8.0);
+    return 0;
+}
+
+int main() {
+    const int64_t bytes = 1600000000ll, n16 = bytes / 16;
+    uint32_t *d, *out;
+    CHECK(hipMalloc(&d, bytes)); CHECK(hipMalloc(&out, 64));
+    CHECK(hipMemset(d, 0x5a, bytes));
+    for (int per_cu : {4, 8, 16}) {
+        if (run<1>((const u32x4*)d, n16, out, per_cu)) return 1;
+        if (run<2>((const u32x4*)d, n16, out, per_cu)) return 1;
+        if (run<4>((const u32x4*)d, n16, out, per_cu)) return 1;
+        if (run<8>((const u32x4*)d, n16, out, per_cu)) return 1;
+    }
+    return 0;
+}

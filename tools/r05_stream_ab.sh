@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/r05_stream_ab.sh -- k_adc_stream variants (tools/build_variant.sh ... lopq_stream) on the 200 M index
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for v in hip ring0 ring1u2 ring1u3 ring0u8; do
+for v in ${VARIANTS:-hip repl2 repl2u4}; do
   lib=$GRAFT_REPO_ROOT/columbiaimagesearch_amd/lib/libcis_$v.so
   echo "== $v"
   rm -rf /tmp/prof_ab
