@@ -23,6 +23,47 @@ __global__ __launch_bounds__(256) void k_read(const u32x4* __restrict__ p, int64
     if (acc == 0x12345678u) out[0] = acc;  // never true for the pattern below: keeps the loads alive
 }
 
+// every workgroup streams its OWN contiguous chunk (what k_adc_stream's slots do): `chunk16` float4 per workgroup-visit, chunks dealt round-robin
+template <int U>
+__global__ __launch_bounds__(256) void k_read_chunks(const u32x4* __restrict__ p, int64_t n16, int64_t chunk16, uint32_t* __restrict__ out) {
+    uint32_t acc = 0;
+    const int64_t nchunks = (n16 + chunk16 - 1) / chunk16;
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int64_t b = c * chunk16, e = b + chunk16 < n16 ? b + chunk16 : n16;
+        int64_t i = b + threadIdx.x;
+        for (; i + (U - 1) * 256 < e; i += U * 256) {
+            u32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + i + u * 256);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+        }
+        for (; i < e; i += 256) { const u32x4 v = p[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <int U>
+static int run_chunks(const u32x4* d, int64_t n16, uint32_t* out, int per_cu, int64_t chunk_bytes) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int grid = 256 * per_cu;
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_read_chunks<U>, dim3(grid), dim3(256), 0, 0, d, n16, chunk_bytes / 16, out);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e9f;
+    for (int r = 0; r < 8; ++r) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_read_chunks<U>, dim3(grid), dim3(256), 0, 0, d, n16, chunk_bytes / 16, out);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    printf("own chunk of %4lld KB per workgroup, %d loads in flight per lane, %2d workgroups per CU: %.3f ms  %.2f TB/s\n", (long long)(chunk_bytes / 1024), U, per_cu, best,
+           n16 * 16.0 / best / 1e9);
+    return 0;
+}
+
 template <int U>
 static int run(const u32x4* d, int64_t n16, uint32_t* out, int per_cu) {
     hipEvent_t e0, e1;
@@ -55,5 +96,10 @@ int main() {
         if (run<4>((const u32x4*)d, n16, out, per_cu)) return 1;
         if (run<8>((const u32x4*)d, n16, out, per_cu)) return 1;
     }
+    for (int64_t cb : {524288ll, 65536ll, 16384ll, 4096ll})
+        for (int per_cu : {5, 8}) {
+            if (run_chunks<2>((const u32x4*)d, n16, out, per_cu, cb)) return 1;
+            if (run_chunks<4>((const u32x4*)d, n16, out, per_cu, cb)) return 1;
+        }
     return 0;
 }
