@@ -558,7 +558,8 @@ class RoutedSearcher(object):
 
     Wraps a ShardedSearcher (its local index, lanes and process group).  ``search_begin(q_home)`` takes THIS rank's home slice of the
     batch (``home_slice``) and runs home + out asynchronously; ``search_end`` sizes the return trip (one host read), runs scan + back +
-    merge and returns the results of the home slice, like ``search_batch_dev``."""
+    merge and returns the results of the home slice, like ``search_batch_dev``.  At most ``sharded.pipeline_depth`` handles may be
+    open at a time (a lane -- index view, stream, pinned record -- holds one batch)."""
 
     def __init__(self, sharded, slack=2.0):
         import torch.distributed as dist
@@ -568,6 +569,7 @@ class RoutedSearcher(object):
         self.rank = dist.get_rank(self.group)
         self.slack = slack
         self.fallbacks = 0
+        self._host = {}   # lane -> pinned record (rows sent / received, overflow) of the lane's batch in flight
 
     def search_begin(self, q_home, quota=10, limit=None, nq_total=None):
         """q_home: this rank's home slice (home_slice(nq_total, rank, world)) of a batch of nq_total queries.  nq_total sizes the blocks
@@ -594,7 +596,9 @@ class RoutedSearcher(object):
             _lib.check(_lib.lib().cis_route_queries_dev(q_home.data_ptr(), nqh, row_bytes, mask.data_ptr(), self.world, cap, send_q.data_ptr(),
                                                         slot.data_ptr(), cnt.data_ptr(), overflow.data_ptr(), st.cuda_stream))
             recv_q, recv_cnt, ov = routed_send_queries(q_home, slot, send_q, cnt, overflow, self.group)
-            host = torch.empty(2 * self.world + 1, dtype=torch.int32, pin_memory=True)
+            host = self._host.get(id(sv))  # one page-locked record per lane (a lane holds one batch at a time: at most
+            if host is None:               # `pipeline_depth` handles may be open, as for ShardedSearcher.search_begin)
+                host = self._host[id(sv)] = torch.empty(2 * self.world + 1, dtype=torch.int32, pin_memory=True)
             host.copy_(torch.cat([cnt, recv_cnt, ov]), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(st)
