@@ -102,13 +102,27 @@ def exchange_packed(packed, cnt, group=None):
     world = dist.get_world_size(group)
     nq = int(cnt.shape[0])
     cnt_all = all_gather_stack(cnt, group)
-    csum = torch.cumsum(cnt_all, dim=1, dtype=torch.int64)
-    stride = max(int(csum[:, -1].max().item()), 1) if nq else 1
-    mine = packed[:stride]
-    if mine.shape[0] < stride:  # a buffer sized for this rank's own total only
-        mine = torch.cat([mine, torch.zeros((stride - mine.shape[0], 4), dtype=packed.dtype, device=packed.device)])
+    if cnt_all.is_cuda and nq:
+        # offsets and per-rank totals by the kernel of the fixed-size exchange (round 5: this path used torch.cumsum); the ONE host read
+        # of this exact-size form is the largest total -- it is only taken after a fixed-size exchange overflowed
+        from . import _lib
+        off = torch.empty((world, nq), dtype=torch.int64, device=cnt.device)
+        totals = torch.empty(world, dtype=torch.int64, device=cnt.device)
+        flag = torch.empty(1, dtype=torch.int32, device=cnt.device)
+        _lib.check(_lib.lib().cis_exchange_offsets_dev(cnt_all.data_ptr(), world, nq, (1 << 62), off.data_ptr(), totals.data_ptr(),
+                                                       flag.data_ptr(), torch.cuda.current_stream(cnt.device).cuda_stream))
+        stride = max(int(totals.max().item()), 1)
+    else:
+        csum = torch.cumsum(cnt_all, dim=1, dtype=torch.int64)
+        stride = max(int(csum[:, -1].max().item()), 1) if nq else 1
+        off = (csum - cnt_all).contiguous()
+    if packed.shape[0] >= stride:
+        mine = packed[:stride]
+    else:  # a buffer sized for this rank's own total only
+        mine = torch.zeros((stride, 4), dtype=packed.dtype, device=packed.device)
+        mine[:packed.shape[0]] = packed
     parts = all_gather_stack(mine.contiguous(), group)
-    return parts, (csum - cnt_all).contiguous(), cnt_all
+    return parts, off, cnt_all
 
 
 def route_codes(coarse, fine, ids, owner, V, group=None, M=None):
