@@ -1011,22 +1011,44 @@ def cnn_legs(ctx):
     gcn = torch.Generator(device=device)
     gcn.manual_seed(5)
 
-    def time_net(net, xb, ob, reps=8):
-        for _ in range(2):
-            net.forward_dev(xb, ob)
+    def time_net(net, xb, ob, reps=8, lanes=1):
+        """Seconds per forward: `lanes` batches in flight -- the net and lanes - 1 views of it (shared weights, own workspaces), each on
+        its own stream with its own input and output -- round-robin; median of five measurements of reps x lanes forwards."""
+        handles = [net] + [net.view() for _ in range(lanes - 1)]
+        streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device=device) for _ in range(lanes - 1)]
+        xs = [xb] + [xb.clone() for _ in range(lanes - 1)]
+        obs = [ob] + [torch.empty_like(ob) for _ in range(lanes - 1)]
+
+        def go(k):
+            for i in range(k):
+                l = i % lanes
+                with torch.cuda.stream(streams[l]):
+                    handles[l].forward_dev(xs[l], obs[l])
+        go(2 * lanes)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        tc = time.perf_counter()
-        for _ in range(reps):
-            net.forward_dev(xb, ob)
-        torch.cuda.synchronize()
-        dt_ = (time.perf_counter() - tc) / reps
-        if world > 1:
-            tt_ = torch.tensor([dt_], device=device if ctx.backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
-            dt_ = float(tt_.item())
-        return dt_
+        dts = []
+        for _ in range(5):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            go(reps * lanes)
+            torch.cuda.synchronize()
+            dt_ = (time.perf_counter() - tc) / (reps * lanes)
+            if world > 1:
+                tt_ = torch.tensor([dt_], device=device if ctx.backend == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                dt_ = float(tt_.item())
+            dts.append(dt_)
+        same = True
+        if lanes > 1:  # a forward gives the same descriptors alone and with others in flight
+            ref = obs[0].clone()
+            handles[0].forward_dev(xs[0], obs[0])
+            torch.cuda.synchronize()
+            same = bool(torch.equal(ref, obs[0]))
+        for h in handles[1:]:
+            h.close()
+        return sorted(dts)[len(dts) // 2], same
 
     def roof(mac, b, dt):
         flop = 2.0 * mac * b
@@ -1034,26 +1056,33 @@ def cnn_legs(ctx):
                 "frac": flop / dt / (F32_MFMA_PEAK_TFLOPS * 1e12), "flop_per_image": 2 * mac}
 
     with ctx.wd.phase("CNN legs (replicas, barrier + all-reduce of the time)", 600):
+        LANES = 3  # batches in flight (like the search legs): consecutive forwards are in different layers and fill each other's rounds
         net = SentiBankNet(sentibank_weights(0))
         xb = (torch.randn((B, 3, 227, 227), generator=gcn, device=device) * 50.0).contiguous()
-        dt = time_net(net, xb, torch.empty((B, 4096), device=device))
+        dt1, _ = time_net(net, xb, torch.empty((B, 4096), device=device))
+        dt, same = time_net(net, xb, torch.empty((B, 4096), device=device), lanes=LANES)
         cnn = {"metric": "CNN descriptors/sec (DeepSentibank forward to fc7, batch 256 per GPU, synthetic weights)",
                "value": world * B / dt, "unit": "descriptors/s", "n_gpus": world, "parallelism": "replicas, no collective",
-               "ms_per_batch": dt * 1e3, "dtype": "f32", "roofline": roof(SENTIBANK_MAC, B, dt)}
+               "ms_per_batch": dt * 1e3, "dtype": "f32", "roofline": roof(SENTIBANK_MAC, B, dt), "batches_in_flight": LANES,
+               "same_descriptors_in_flight": same,
+               "one_batch_at_a_time": {"value": world * B / dt1, "ms_per_batch": dt1 * 1e3, "frac": roof(SENTIBANK_MAC, B, dt1)["frac"]}}
         net.close()
         del xb
         net = DLibFaceNet(dlib_weights(0))
         xb = (torch.rand((B, 150, 150, 3), generator=gcn, device=device) * 255).contiguous()
-        dt = time_net(net, xb, torch.empty((B, 128), device=device))
-        dlib = {"metric": "CNN descriptors/sec (dlib face ResNet forward, batch 256 aligned chips per GPU, synthetic weights)",
-                "value": world * B / dt, "unit": "descriptors/s", "n_gpus": world, "parallelism": "replicas, no collective",
-                "ms_per_batch": dt * 1e3, "dtype": "f32", "roofline": roof(DLIB_MAC, B, dt)}
+        dt1, _ = time_net(net, xb, torch.empty((B, 128), device=device))   # (a single handle: two half-batch chains on its own streams)
         # the same forward at 1024 chips per call: a launch of the 256-chip batch lasts 60-80 us, of which the ramp and the tail
         # of the workgroup rounds are a fifth -- reported next to the BASELINE batch, not instead of it
-        del xb
         B4 = 1024
-        xb = (torch.rand((B4, 150, 150, 3), generator=gcn, device=device) * 255).contiguous()
-        dt4 = time_net(net, xb, torch.empty((B4, 128), device=device), reps=4)
+        xb4 = (torch.rand((B4, 150, 150, 3), generator=gcn, device=device) * 255).contiguous()
+        dt4, _ = time_net(net, xb4, torch.empty((B4, 128), device=device), reps=4)
+        del xb4
+        dt, same = time_net(net, xb, torch.empty((B, 128), device=device), lanes=LANES)  # (views: every handle runs its batch as one chain)
+        dlib = {"metric": "CNN descriptors/sec (dlib face ResNet forward, batch 256 aligned chips per GPU, synthetic weights)",
+                "value": world * B / dt, "unit": "descriptors/s", "n_gpus": world, "parallelism": "replicas, no collective",
+                "ms_per_batch": dt * 1e3, "dtype": "f32", "roofline": roof(DLIB_MAC, B, dt), "batches_in_flight": LANES,
+                "same_descriptors_in_flight": same,
+                "one_batch_at_a_time": {"value": world * B / dt1, "ms_per_batch": dt1 * 1e3, "frac": roof(DLIB_MAC, B, dt1)["frac"]}}
         dlib["batch_1024"] = {"value": world * B4 / dt4, "unit": "descriptors/s", "ms_per_batch": dt4 * 1e3,
                               "frac": 2.0 * DLIB_MAC * B4 / dt4 / (F32_MFMA_PEAK_TFLOPS * 1e12)}
         net.close()
@@ -1269,6 +1298,9 @@ def compact_line(line):
         x = line.get(k)
         if x:
             c[k] = {"value": x["value"], "unit": x["unit"], "ms_per_batch": x["ms_per_batch"], "frac": x["roofline"]["frac"], "dtype": x["dtype"]}
+            if "one_batch_at_a_time" in x:
+                c[k]["in_flight"] = x["batches_in_flight"]
+                c[k]["frac_one_at_a_time"] = x["one_batch_at_a_time"]["frac"]
             if "batch_1024" in x:
                 c[k]["frac_batch_1024"] = x["batch_1024"]["frac"]
     cb = line.get("cpu_baseline")

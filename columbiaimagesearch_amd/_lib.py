@@ -102,6 +102,7 @@ _PROTOS = {
     "cis_index_last_scan_kernel": (c_int, [c_void_p]),
     "cis_cnn_create": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_int]),
     "cis_cnn_destroy": (None, [c_void_p]),
+    "cis_cnn_create_view": (c_int, [POINTER(c_void_p), c_void_p]),
     "cis_cnn_feat_dim": (c_int, [c_int]),
     "cis_cnn_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "cis_cnn_forward_dev": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

@@ -12,8 +12,11 @@
 // LDS, never materialised.  Activations are kept channels-last (NHWC) between layers so that the K
 // axis of the gather and the across-channel LRN window are contiguous.  Bias + ReLU are fused into the
 // GEMM epilogue; pooling uses caffe's ceil-mode output size with windows clipped to the input.
+#include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <thread>
+#include <vector>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1002,6 +1005,13 @@ struct cis_cnn {
     hipStream_t ps[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_in = nullptr, ev_done[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf in_buf, out_buf;
+    // views (round 5): a handle that shares the weights of its base and owns workspaces, streams and events -- several BATCHES in flight
+    // on the caller's streams (consecutive forwards are in different layers at any time and fill each other's workgroup rounds:
+    // dlib 0.47-0.52 -> 0.60, DeepSentibank 0.61 -> 0.68 of the f32 MFMA peak at batch 256, profiles/r05_experiments.txt)
+    cis_cnn* base = nullptr;
+    std::vector<cis_cnn*> views;
+    bool orphaned = false;      // a view whose base was destroyed first: every call fails, nothing dangles
+    int parts_override = 0;     // > 0: parts of a batch that run concurrently (views and their base: 1 -- whole batches overlap instead)
 };
 
 // dlib anet_type block plan: (in channels, out channels, down-sampling block)
@@ -1017,9 +1027,25 @@ static const bool kLrnAfter[5] = {true, true, false, false, false};
 
 extern "C" int cis_cnn_feat_dim(int arch) { return arch == 1 ? 4096 : (arch == 2 ? 128 : 0); }
 
+static std::mutex g_cnn_views_mu;  // guards base <-> view links
+
 extern "C" void cis_cnn_destroy(cis_cnn* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    {
+        std::lock_guard<std::mutex> lk(g_cnn_views_mu);
+        if (c->base) {  // a view: unlink; the weights are the base's
+            auto& v = c->base->views;
+            v.erase(std::remove(v.begin(), v.end(), c), v.end());
+        }
+        for (cis_cnn* v : c->views) { v->orphaned = true; v->base = nullptr; }  // views that outlive their base answer CIS_EINVAL
+        c->views.clear();
+    }
+    if (c->base || c->orphaned) {  // weights are not this handle's to free (an orphan's pointers died with its base)
+        for (auto& l : c->conv) l = LayerW();
+        for (auto& l : c->fc) l = LayerW();
+        c->dl.clear();
+    }
     for (auto& l : c->conv) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_w2) (void)hipFree(l.d_w2); }
     for (auto& l : c->fc) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
     for (auto& l : c->dl) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_w2) (void)hipFree(l.d_w2); }
@@ -1170,6 +1196,29 @@ extern "C" int cis_cnn_create(cis_cnn** out, int arch, const float* const* tenso
             for (int k = 0; k < 4096; ++k) packed[(size_t)k * 4096 + o] = w[(size_t)o * 4096 + k];
         if ((rc = upload_f(&c->fc[1].d_w, packed.data(), packed.size())) != CIS_OK) return fail(rc);
         if ((rc = upload_f(&c->fc[1].d_b, tensors[13], 4096)) != CIS_OK) return fail(rc);
+    }
+    *out = c;
+    return CIS_OK;
+}
+
+extern "C" int cis_cnn_create_view(cis_cnn** out, cis_cnn* base) {
+    CIS_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    CIS_REQUIRE(base != nullptr, "base is NULL");
+    CIS_REQUIRE(!base->orphaned, "the base of this handle was destroyed");
+    cis_cnn* root = base->base ? base->base : base;  // a view of a view is a view of the base
+    cis_cnn* c = new cis_cnn();
+    c->arch = root->arch;
+    c->device = root->device;
+    for (int i = 0; i < 5; ++i) c->conv[i] = root->conv[i];
+    for (int i = 0; i < 2; ++i) c->fc[i] = root->fc[i];
+    c->dl = root->dl;
+    c->base = root;
+    c->parts_override = 1;
+    {
+        std::lock_guard<std::mutex> lk(g_cnn_views_mu);
+        root->views.push_back(c);
+        root->parts_override = 1;  // batches overlap through the views from now on, not parts of one batch
     }
     *out = c;
     return CIS_OK;
@@ -1439,7 +1488,9 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
     // parts of the batch in flight together (CIS_CNN_PARTS=1: one launch chain on the caller's stream)
     // measured (dlib): two parts at 256 chips 2.16 -> 2.03 ms; four parts lose (the host enqueues the parts' ~50 launches one part after
     // the other, so the last part starts late); 1024 chips: launches are long enough alone; DeepSentibank: +2 %, left alone
+    CIS_REQUIRE(!c->orphaned, "this view's base was destroyed: close views before their base");
     int parts = (c->arch == 2 && n >= 128 && n <= 512) ? 2 : 1;
+    if (c->parts_override > 0) parts = c->parts_override;
     if (const char* e = getenv("CIS_CNN_PARTS")) parts = atoi(e);
     if (parts > kMaxParts) parts = kMaxParts;
     if (parts > n) parts = n;
@@ -1620,6 +1671,7 @@ static int cnn_forward_sentibank(cis_cnn* c, CnnWs* ws, const float* d_nchw, int
 
 extern "C" int cis_cnn_forward(cis_cnn* c, const float* nchw, int n, float* feats) {
     CIS_REQUIRE(c != nullptr, "cnn is NULL");
+    CIS_REQUIRE(!c->orphaned, "this view's base was destroyed: close views before their base");
     CIS_REQUIRE(n >= 0 && (n == 0 || (nchw && feats)), "NULL buffer");
     if (n == 0) return CIS_OK;
     CIS_CHECK_HIP(hipSetDevice(c->device));

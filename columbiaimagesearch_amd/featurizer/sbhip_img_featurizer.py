@@ -87,7 +87,22 @@ class SentiBankNet(object):
         _lib.check(_lib.lib().cis_cnn_create(_lib.ctypes.byref(out), 1, ptrs, len(arrs)))
         self._h = out.value
 
+    def view(self):
+        """A second handle on the same weights with its own workspaces and streams (cis_cnn_create_view): run consecutive batches
+        through the net and its views, each on its own torch stream -- several batches in flight fill the chip better than one.  The
+        view keeps its base alive; close views before the base."""
+        out = _lib.c_void_p()
+        _lib.check(_lib.lib().cis_cnn_create_view(_lib.ctypes.byref(out), self._h))
+        v = object.__new__(type(self))
+        v._h = out.value
+        v._base = self
+        self._views = getattr(self, "_views", __import__("weakref").WeakSet())
+        self._views.add(v)
+        return v
+
     def close(self):
+        for v in list(getattr(self, "_views", ())):
+            v.close()
         if getattr(self, "_h", None):
             _lib.lib().cis_cnn_destroy(self._h)
             self._h = None

@@ -352,6 +352,11 @@ void cis_cnn_destroy(cis_cnn* c);
 int cis_cnn_feat_dim(int arch);
 int cis_cnn_forward(cis_cnn* c, const float* nchw, int n, float* feats);
 int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float* d_feats, void* stream);
+/* A second handle on the same network (round 5): shares the weights of `base` (which must outlive it; a view whose base was destroyed
+ * answers CIS_EINVAL), owns its workspaces, streams and events.  Several BATCHES in flight -- one per handle, each on its own stream --
+ * fill each other's workgroup rounds: consecutive forwards are in different layers at any time.  From the first view on, base and views
+ * run a batch as ONE chain (the two-part forward of the dlib net is for a single handle).  Destroy with cis_cnn_destroy. */
+int cis_cnn_create_view(cis_cnn** out, cis_cnn* base);
 
 /* ---- aligned face chips: the image side of dlib's compute_face_descriptor(img, shape) -------------------------------------
  * (cufacesearch/cufacesearch/featurizer/dlib_featurizer.py:103-105).  The caller supplies the 68 landmarks (the shape predictor is

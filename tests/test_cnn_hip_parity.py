@@ -436,3 +436,50 @@ def test_c5_sentibank_ingest_against_oracle(net_and_weights):
         assert k == len(wid) and int(r["visited"][qi]) == wv
         np.testing.assert_array_equal(r["ids"][qi, :k], wid)
         np.testing.assert_allclose(r["dists"][qi, :k], wd, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sentibank", "dlib"])
+def test_views_share_the_weights_and_overlap_batches(kind):
+    """cis_cnn_create_view (round 5): a view computes what its base computes (same weights), batches in flight on three handles and three
+    streams give the descriptors of the serial forwards bit for bit, a view outlives nothing: after the base is destroyed through the C
+    API it answers an error instead of touching freed weights."""
+    import torch
+    from columbiaimagesearch_amd import _lib
+    from columbiaimagesearch_amd.featurizer import DLibFaceNet, SentiBankNet
+    from columbiaimagesearch_amd.featurizer.synthetic import dlib_weights, sentibank_weights
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    if kind == "dlib":
+        net = DLibFaceNet(dlib_weights(1)); xs = [(torch.rand((n, 150, 150, 3), generator=g, device="cuda") * 255).contiguous() for n in (130, 9, 64)]
+    else:
+        net = SentiBankNet(sentibank_weights(1)); xs = [(torch.randn((n, 3, 227, 227), generator=g, device="cuda") * 50).contiguous() for n in (40, 3, 17)]
+    views = [net.view(), net.view()]
+    # reference: every batch alone through a view (one chain), everything synchronised
+    want = []
+    for x in xs:
+        want.append(views[0].forward_dev(x).clone())
+        torch.cuda.synchronize()
+    # base == view on the same batch
+    for x, w in zip(xs, want):
+        assert torch.equal(net.forward_dev(x), w)
+    torch.cuda.synchronize()
+    # three batches in flight, twice around, nothing synchronised in between
+    handles, streams = [net] + views, [torch.cuda.Stream() for _ in range(3)]
+    outs = [None] * 6
+    for i in range(6):
+        with torch.cuda.stream(streams[i % 3]):
+            outs[i] = handles[i % 3].forward_dev(xs[i % 3])
+    torch.cuda.synchronize()
+    for i in range(6):
+        assert torch.equal(outs[i], want[i % 3]), i
+    # the host entry point works on a view too
+    assert np.array_equal(views[1].forward(xs[1].cpu().numpy()), want[1].cpu().numpy())
+    # a base destroyed under its views (C API): the views answer an error
+    h = net._h
+    _lib.lib().cis_cnn_destroy(h)
+    net._h = None
+    out = torch.empty_like(want[1])
+    rc = _lib.lib().cis_cnn_forward_dev(views[0]._h, xs[1].data_ptr(), xs[1].shape[0], out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc != 0 and "base was destroyed" in _lib.last_error()
+    for v in views:
+        v.close()
