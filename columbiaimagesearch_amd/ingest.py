@@ -50,6 +50,10 @@ class BatchIngest(object):
         distributed.ShardedSearcher.add_codes_routed_dev when the searcher is sharded)."""
         import torch
         coarse, fine = self.encode_batch_dev(x)
+        return self._insert_codes(coarse, fine, ids)
+
+    def _insert_codes(self, coarse, fine, ids=None):
+        import torch
         n = int(coarse.shape[0])
         s = self.searcher
         if not (hasattr(s, "add_codes_routed_dev") or hasattr(s, "add_codes_dev")):
@@ -84,3 +88,49 @@ class BatchIngest(object):
             added = added[0]
         self.nb_ingested += n
         return int(added)
+
+    def ingest_batches(self, batches, ids=None, lanes=3):
+        """Ingest a sequence of preprocessed batches with the CNN forwards of the NEXT batches in flight while the current one is
+        encoded and inserted (round 5): `lanes` handles on the same weights (net.view()), each on its own stream, run forward +
+        normalisation; encode and insert follow on the caller's stream in batch order, so ids, insertion order and dedup are those
+        of calling ingest_batch batch by batch.  batches: an iterable of GPU tensors (they must stay valid until their batch was
+        inserted); ids: None or an iterable of per-batch id tensors / arrays.  Returns the list of per-batch new-item counts."""
+        import torch
+        from collections import deque
+        cur = torch.cuda.current_stream()
+        lanes = max(1, int(lanes))
+        if not hasattr(self.net, "view"):
+            lanes = 1
+        if getattr(self, "_lanes", None) is None or len(self._lanes) != lanes:
+            for h, _ in (getattr(self, "_lanes", None) or [])[1:]:
+                h.close()
+            self._lanes = [(self.net, torch.cuda.Stream())] + [(self.net.view(), torch.cuda.Stream()) for _ in range(lanes - 1)]
+        ids_it = iter(ids) if ids is not None else None
+        out, queue = [], deque()
+
+        def finish():
+            feats, ev, bid = queue.popleft()
+            cur.wait_event(ev)
+            feats.record_stream(cur)
+            if self.feat_dtype is not None and feats.dtype != self.feat_dtype:
+                feats = feats.to(self.feat_dtype)
+            coarse, fine = self.model.predict_batch_dev(l2_normalize_dev(feats).contiguous())
+            out.append(self._insert_codes(coarse, fine, bid))
+        for i, x in enumerate(batches):
+            net, stream = self._lanes[i % lanes]
+            stream.wait_stream(cur)  # the batch was produced on the caller's stream
+            with torch.cuda.stream(stream):
+                feats = net.forward_dev(x)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            queue.append((feats, ev, next(ids_it) if ids_it is not None else None))
+            if len(queue) >= lanes:
+                finish()
+        while queue:
+            finish()
+        return out
+
+    def close(self):
+        for h, _ in (getattr(self, "_lanes", None) or [])[1:]:
+            h.close()
+        self._lanes = None

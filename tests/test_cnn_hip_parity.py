@@ -342,6 +342,38 @@ def test_batch_ingest_matches_per_item_chain():
         assert any(it[0] == 100 + i and tuple(it[1][1]) == tuple(int(v) for v in fine[i]) for it in items)
 
 
+def test_pipelined_ingest_equals_batch_by_batch():
+    """BatchIngest.ingest_batches (round 5): CNN forwards of the next batches in flight on views of the net while the current batch is
+    encoded and inserted -- same counts, same cells in the same order as ingest_batch batch by batch (duplicates across batches incl.)."""
+    import torch
+    from conftest import load_golden
+    from oracle import dlib_oracle as D
+    from columbiaimagesearch_amd.featurizer import DLibFaceNet
+    from columbiaimagesearch_amd.ingest import BatchIngest
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    from test_lopq_hip_parity import hip_model
+    z, X, Q = load_golden("c2")
+    model = hip_model(z)
+    net = DLibFaceNet(D.synthetic_weights(0))
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    xs = [(torch.rand((n, 150, 150, 3), generator=g, device="cuda") * 255).contiguous() for n in (7, 1, 33, 12, 5)]
+    xs.append(xs[2])  # a whole batch again under new ids, and ...
+    ids = [torch.arange(1000 * i, 1000 * i + x.shape[0], device="cuda") for i, x in enumerate(xs)]
+    ids.append(ids[0])  # ... one under ids that are stored already: every item a duplicate
+    xs.append(xs[0])
+    a, b = LOPQSearcherHIP(model), LOPQSearcherHIP(model)
+    ia, ib = BatchIngest(net, model, a, feat_dtype=torch.float64), BatchIngest(net, model, b, feat_dtype=torch.float64)
+    want = [ia.ingest_batch(x, ids=i) for x, i in zip(xs, ids)]
+    got = ib.ingest_batches(xs, ids=ids, lanes=3)
+    assert got == want and want[-1] == 0 and a.get_nb_indexed() == b.get_nb_indexed() == sum(want)
+    V = model.V
+    for c in range(V * V):
+        ca, cb = a.get_cell((c // V, c % V)), b.get_cell((c // V, c % V))
+        assert [i for i, _ in ca] == [i for i, _ in cb] and [tuple(x[1]) for _, x in ca] == [tuple(x[1]) for _, x in cb], c
+    assert ib.ingest_batches(xs[:2], ids=[ids[0] + 50000, ids[1] + 50000], lanes=1) == [7, 1]  # one lane: the serial chain
+    ib.close()
+
+
 def test_batch_ingest_into_searchers_without_a_tuple_returning_device_insert(tmp_path):
     """BatchIngest must serve every searcher the package ships -- LOPQSearcherLMDB (host key / value store, string
     ids, no device entry point), GridSearcher (add_codes_dev returns a count, not a tuple) and non-integer ids on the HIP
