@@ -1291,7 +1291,7 @@ def compact_line(line):
     c["vs_baseline"] = line.get("vs_baseline")
     cfg = line.get("config") or {}
     c["config"] = _pick(cfg, "name", "index_vectors", "queries_per_step", "quota", "limit", "parallelism", "batches_in_flight", "candidates_per_query")
-    c["config"]["workload"] = (cfg.get("workload") or "")[:110]
+    c["config"]["workload"] = (cfg.get("workload") or "")[:80]
     c["roofline"] = _roof_c(line.get("roofline"))
     t = line.get("timing") or {}
     c["timing"] = _pick(t, "repetitions", "timed_s", "wall_over_events", "workspace_allocations_in_timed_region", "suspect")
@@ -1317,7 +1317,7 @@ def compact_line(line):
     if cb:
         c["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind", "search_vectorised_1core_qps", "search_vectorised_allcore_qps", "allcore_workers",
                                   "encode_loop_1core_vps", "encode_vectorised_allcore_vps", "cnn_torch_cpu_batch1_x_cores_ips", "cnn_torch_cpu_batch256_ips")
-        c["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:70]
+        c["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:48]
     else:
         c["cpu_baseline"] = None
     if line.get("parity"):
