@@ -1100,3 +1100,27 @@ def test_search_views_share_the_index_and_pipeline_on_two_streams():
     np.testing.assert_array_equal(a["ids"].cpu().numpy(), b["ids"].cpu().numpy())
     assert (a["ids"].cpu().numpy() == 10 ** 12).any()
     v.close()
+
+
+@pytest.mark.gpu
+def test_model_twin_encodes_alike_on_its_own_stream():
+    """model.twin(): a second device handle on the same parameter arrays; passes through the model and its twin on two streams give
+    the codes of the serial passes."""
+    import torch
+    z, X, Q = load_golden("c2")
+    m = hip_model(z)
+    t = m.twin()
+    assert t is not m and t.Cs is m.Cs and t._handle() != m._handle()
+    xa = torch.as_tensor(X[:3000]).cuda().contiguous()
+    xb = torch.as_tensor(X[3000:5000]).cuda().contiguous()
+    wa, wb = m.predict_batch_dev(xa), m.predict_batch_dev(xb)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            ga = m.predict_batch_dev(xa)
+        with torch.cuda.stream(s2):
+            gb = t.predict_batch_dev(xb)
+    torch.cuda.synchronize()
+    assert torch.equal(ga[0], wa[0]) and torch.equal(ga[1], wa[1]) and torch.equal(gb[0], wb[0]) and torch.equal(gb[1], wb[1])
+    assert (ga[0].cpu().numpy().view(np.uint16) == z["coarse"][:3000]).all() and (ga[1].cpu().numpy() == z["fine"][:3000]).all()
