@@ -294,3 +294,43 @@ def test_routed_search_overflow_flag_is_seen_by_every_rank():
         p.join(300)
         assert p.exitcode == 0
     assert all(ret[r][0] == "overflow" for r in range(world)), dict(ret)
+
+
+def test_routing_tables_against_a_brute_force():
+    """route_slots_torch / route_rows_torch / routed_merge_tables (the restatements the HIP kernels are checked against on the GPU)
+    against plain loops: stable compaction per destination, capacity cut + overflow flag, offsets and counts of the returned lists."""
+    from columbiaimagesearch_amd.distributed import home_slice, route_capacity, route_rows_torch, route_slots_torch, routed_merge_tables
+    rs = np.random.RandomState(4)
+    for world, nq, cap in [(1, 5, 5), (3, 17, 17), (8, 64, 9), (5, 0, 4), (64, 33, 33)]:
+        mask = rs.randint(0, 1 << min(world, 62), size=nq, dtype=np.int64) if nq else np.zeros(0, dtype=np.int64)
+        if world == 64 and nq:
+            mask[0] = -1  # all 64 bits
+        slot, cnt, ov = route_slots_torch(torch.from_numpy(mask), world, cap)
+        q = torch.arange(nq * 3, dtype=torch.float32).reshape(nq, 3)
+        rows = route_rows_torch(q, slot, cap)
+        over = False
+        for d in range(world):
+            want = [i for i in range(nq) if (int(mask[i]) >> d) & 1]
+            over = over or len(want) > cap
+            assert int(cnt[d]) == min(len(want), cap)
+            for pos, i in enumerate(want):
+                assert int(slot[d, i]) == (pos if pos < cap else -1)
+                if pos < cap:
+                    assert torch.equal(rows[d, pos], q[i])
+            assert all(int(slot[d, i]) == -1 for i in range(nq) if i not in want)
+        assert bool(ov.item()) == over
+        # the return trip: rank d answers cnt[d] rows; row r of its group holds valid[...] hits
+        n_sent = cnt.tolist()
+        L = 7
+        valid = torch.from_numpy(rs.randint(0, L + 1, size=int(sum(n_sent))).astype(np.int32))
+        off, c = routed_merge_tables(slot, n_sent, valid, L)
+        base = np.concatenate([[0], np.cumsum(n_sent)[:-1]]) if world else []
+        for d in range(world):
+            for i in range(nq):
+                sl = int(slot[d, i])
+                if sl < 0:
+                    assert int(c[d, i]) == 0
+                else:
+                    assert int(off[d, i]) == (int(base[d]) + sl) * L and int(c[d, i]) == int(valid[int(base[d]) + sl])
+    assert [home_slice(10, r, 4) for r in range(4)] == [(0, 2), (2, 5), (5, 7), (7, 10)]
+    assert route_capacity(100, 32, 8) == 100 and route_capacity(100, 1024, 8) < 100 and route_capacity(0, 32, 8) == 1
