@@ -207,6 +207,11 @@ def scan_binding(cfg_name, scan_name, cand, cand_items, M, scan_s, launches):
         except Exception as e:
             out["measured"] = {"error": repr(e)}
     fracs = {k: model[k]["frac"] or 0.0 for k in ("hbm_moved_bytes", "lds_gather", "valu_issue")}
+    if out["measured"] and out["measured"].get("lds_conflict_ratio") is not None and model["lds_gather"]["frac"] is not None:
+        # the same minimum at the MEASURED conflict ratio (conflict cycles / active cycles): what the gathers cost on this kernel
+        cr = float(out["measured"]["lds_conflict_ratio"])
+        if 0.0 <= cr < 1.0:
+            model["lds_gather"]["frac_at_measured_conflicts"] = model["lds_gather"]["frac"] / (1.0 - cr)
     if out["measured"] and "valu_busy_frac" in out["measured"]:
         fracs = {"valu_issue": out["measured"]["valu_busy_frac"], "lds_gather": out["measured"].get("lds_busy_frac", 0.0),
                  "hbm_moved_bytes": out["measured"].get("hbm_frac", fracs["hbm_moved_bytes"])}
