@@ -1489,8 +1489,13 @@ def main():
         del orc
     ingest = None
     if not args.no_cnn and st.sharded is None:
-        ingest = ingest_leg(ctx, st, "sentibank" if cfg["d_in"] == 4096 else "dlib")
-        if cfg["d_in"] != 4096:
+        try:
+            ingest = ingest_leg(ctx, st, "sentibank" if cfg["d_in"] == 4096 else "dlib")
+        except Exception as e:  # a side leg must never cost the headline line
+            ingest = None
+            sys.stderr.write("[bench] ingest leg failed: %r\n" % (e,))
+            torch.cuda.empty_cache()
+        if ingest is not None and cfg["d_in"] != 4096:
             ingest["note"] = "dlib 128-d descriptors on this config's model; C5 at its true shapes (DeepSentibank 4096-d -> PCA 256, M=16) is configs.c5"
     release_state(st)
 
@@ -1549,7 +1554,12 @@ def main():
 
     cnn = dlib = None
     if not args.no_cnn:
-        cnn, dlib = cnn_legs(ctx)
+        try:
+            cnn, dlib = cnn_legs(ctx)
+        except Exception as e:  # (every rank fails alike or none does: the legs hold no data-dependent branch before their collectives)
+            cnn = dlib = None
+            sys.stderr.write("[bench rank %d] CNN legs failed: %r\n" % (rank, e))
+            torch.cuda.empty_cache()
 
     if rank == 0:
         line = {
