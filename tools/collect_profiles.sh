@@ -12,6 +12,7 @@ done
 for nq in 1 2; do cp $g/${tag}_c4x_nq${nq}_FETCH_SIZE_pmc.csv $g/${tag}_c4x_nq${nq}_WRITE_SIZE_pmc.csv $g/${tag}_c4x_nq${nq}_sq_pmc.csv $g/${tag}_c4x_nq${nq}_kernel_stats.csv $p/; done
 cp $g/scan_traffic_c4x.json $g/${tag}_c4x_pmc.txt $g/${tag}_c4x_kernels.txt $g/${tag}_c4x_kernel_stats.csv $p/
 cp $g/${tag}_batch_timeline_c4.txt $g/${tag}_batch_timeline_c2.txt $g/${tag}_overlap_c4.txt $g/${tag}_overlap_c2.txt $p/
+cp $g/${tag}_cnn_lanes.txt $p/ 2>/dev/null
 cp $g/${tag}_cnn.txt $g/${tag}_mfma_utilisation.txt $g/${tag}_cnn_mfma_pmc.csv $g/${tag}_dlib_mfma_pmc.csv $g/${tag}_cnn_timelines.txt $p/
 cp $g/${tag}_prodv.txt $g/${tag}_shards.txt $g/${tag}_insert.txt $g/${tag}_limits.txt $p/
 ls $p | grep -c "^${tag}_"
