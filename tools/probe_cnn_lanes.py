@@ -1,4 +1,4 @@
-"""Two (three) batches of 256 in flight through two (three) CNN handles on their own streams: do consecutive forwards fill each other's
+"""Two (three) batches of 256 in flight through a CNN handle and its views (shared weights) on their own streams: do consecutive forwards fill each other's
 workgroup rounds?  usage: probe_cnn_lanes.py dlib|cnn [batch] [lanes]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,7 @@ if which == "dlib":
     mk = lambda: DLibFaceNet(dlib_weights(0)); xs = lambda: (torch.rand(B, 150, 150, 3, device="cuda") * 255).contiguous(); od = 128; mac = 270854144
 else:
     mk = lambda: SentiBankNet(sentibank_weights(0)); xs = lambda: (torch.randn(B, 3, 227, 227, device="cuda") * 50).contiguous(); od = 4096; mac = 720310816
-nets = [mk() for _ in range(NL)]
+nets = [mk()]   # the views are created after the one-at-a-time measurement: from the first view on every handle runs its batch as ONE chain
 x = [xs() for _ in range(NL)]
 out = [torch.empty(B, od, device="cuda") for _ in range(NL)]
 streams = [torch.cuda.Stream() for _ in range(NL)]
@@ -25,6 +25,8 @@ def run(K, lanes):
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / K
 for lanes in range(1, NL + 1):
+    while len(nets) < lanes:
+        nets.append(nets[0].view())
     run(2 * lanes, lanes)
     dt = min(run(12, lanes) for _ in range(3))
     print("%s batch %d, %d forward(s) in flight: %.3f ms per forward  %.0f descriptors/s  MFMA(f32) util %.3f" % (which, B, lanes, dt * 1e3, B / dt, 2.0 * mac * B / dt / 157.3e12))
