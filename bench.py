@@ -42,6 +42,8 @@ import argparse
 import contextlib
 import json
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime initialises: see columbiaimagesearch_amd/_lib.py
 import sys
 import threading
 import time

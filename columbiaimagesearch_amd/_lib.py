@@ -15,6 +15,12 @@ CIS_OK, CIS_EINVAL, CIS_EHIP, CIS_ENOMEM, CIS_EUNSUPPORTED, CIS_ENODEVICE = 0, -
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CIS_LIB_PATH") or os.path.join(_HERE, "lib", "libcis_hip.so")  # override: kernel A/B experiments
 
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue do not overlap.  This
+# package runs batches in flight on several streams (index views, CNN views, copy streams, RCCL): ask for 8 queues unless the caller
+# decided otherwise.  Read by the HIP runtime when it initialises, i.e. effective when this module is imported before the first
+# torch.cuda / HIP call of the process (bench.py sets it first thing; a caller that initialises HIP earlier sets it itself).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 
 class cis_hit(ctypes.Structure):
     _fields_ = [("dist", c_double), ("visit_rank", c_uint32), ("pos", c_uint32), ("id", c_int64),

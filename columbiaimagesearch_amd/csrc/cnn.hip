@@ -1220,6 +1220,14 @@ extern "C" int cis_cnn_create_view(cis_cnn** out, cis_cnn* base) {
         root->views.push_back(c);
         root->parts_override = 1;  // batches overlap through the views from now on, not parts of one batch
     }
+    // the base's part streams are idle from now on: give their hardware queues back (see cis_cnn_forward_dev)
+    (void)hipSetDevice(root->device);
+    for (int p = 0; p < kMaxParts; ++p)
+        if (root->ps[p]) {
+            (void)hipStreamSynchronize(root->ps[p]);
+            (void)hipStreamDestroy(root->ps[p]);
+            root->ps[p] = nullptr;
+        }
     *out = c;
     return CIS_OK;
 }
@@ -1497,12 +1505,12 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
     const size_t in_item = c->arch == 2 ? (size_t)150 * 150 * 3 : (size_t)3 * 227 * 227, out_item = c->arch == 2 ? 128 : 4096;
     if (parts <= 1)
         return c->arch == 2 ? cnn_forward_dlib(c, &c->ws[0], d_nchw, n, d_feats, st) : cnn_forward_sentibank(c, &c->ws[0], d_nchw, n, d_feats, st);
-    if (!c->ev_in) {
-        CIS_CHECK_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-        for (int p = 0; p < kMaxParts; ++p) {
-            CIS_CHECK_HIP(hipStreamCreateWithFlags(&c->ps[p], hipStreamNonBlocking));
-            CIS_CHECK_HIP(hipEventCreateWithFlags(&c->ev_done[p], hipEventDisableTiming));
-        }
+    // (streams are made for the parts in use only: HIP maps a process's streams onto four hardware queues by default, and streams that
+    // share a queue do not overlap -- four idle part streams of a handle were enough to serialise two of three lanes of views)
+    if (!c->ev_in) CIS_CHECK_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    for (int p = 0; p < parts; ++p) {
+        if (!c->ps[p]) CIS_CHECK_HIP(hipStreamCreateWithFlags(&c->ps[p], hipStreamNonBlocking));
+        if (!c->ev_done[p]) CIS_CHECK_HIP(hipEventCreateWithFlags(&c->ev_done[p], hipEventDisableTiming));
     }
     CIS_CHECK_HIP(hipEventRecord(c->ev_in, st));  // the parts start after the caller's earlier work ...
     // A failure inside the loop must not leave parts that are already running unfenced: every part that was started is still

@@ -24,12 +24,16 @@ def run(K, lanes):
             nets[l].forward_dev(x[l], out[l])
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / K
+run(2, 1)
+dt = min(run(24, 1) for _ in range(3))
+print("%s batch %d, the handle alone (no views%s): %.3f ms per forward  %.0f descriptors/s  MFMA(f32) util %.3f" % (
+    which, B, "; two half-batch chains on its own streams" if which == "dlib" else "", dt * 1e3, B / dt, 2.0 * mac * B / dt / 157.3e12))
+while len(nets) < NL:
+    nets.append(nets[0].view())
 for lanes in range(1, NL + 1):
-    while len(nets) < lanes:
-        nets.append(nets[0].view())
     run(2 * lanes, lanes)
-    dt = min(run(12, lanes) for _ in range(3))
-    print("%s batch %d, %d forward(s) in flight: %.3f ms per forward  %.0f descriptors/s  MFMA(f32) util %.3f" % (which, B, lanes, dt * 1e3, B / dt, 2.0 * mac * B / dt / 157.3e12))
+    dt = min(run(24, lanes) for _ in range(3))
+    print("%s batch %d, %d forward(s) in flight on the handle and its views (one chain each): %.3f ms per forward  %.0f descriptors/s  MFMA(f32) util %.3f" % (which, B, lanes, dt * 1e3, B / dt, 2.0 * mac * B / dt / 157.3e12))
 ref = out[0].clone()
 with torch.cuda.stream(streams[0]):
     nets[0].forward_dev(x[0], out[0])

@@ -12,7 +12,7 @@ timeout 300 tools/profile_c4x.sh ${tag} 200000000 1,2 > gpurun_out/${tag}_c4x_ke
 for c in c4 c2; do tools/batch_gaps.sh $c > gpurun_out/${tag}_batch_timeline_$c.txt 2>&1; done
 for c in c4 c2; do tools/overlap_trace.sh $c 3 > gpurun_out/${tag}_overlap_$c.txt 2>&1; done
 { timeout 200 python tools/bench_dlib.py 256; timeout 200 python tools/bench_dlib.py 1024; timeout 200 python tools/bench_cnn.py; } 2>&1 | grep batch > gpurun_out/${tag}_cnn.txt
-{ CIS_CNN_PARTS= ; for a in "dlib 256 3" "cnn 256 3"; do timeout 300 python tools/probe_cnn_lanes.py $a; done; } 2>&1 | grep "in flight\|same" > gpurun_out/${tag}_cnn_lanes.txt
+{ CIS_CNN_PARTS= ; for a in "dlib 256 3" "cnn 256 3"; do timeout 300 python tools/probe_cnn_lanes.py $a; done; } 2>&1 | grep "in flight\|same\|alone" > gpurun_out/${tag}_cnn_lanes.txt
 timeout 600 tools/gpu_pmc_cnn.sh ${tag} > /dev/null 2>&1   # writes gpurun_out/${tag}_mfma_utilisation.txt
 { echo "== dlib forward, one chain, per kernel =="; CIS_CNN_PARTS=1 tools/dlib_timeline.sh 256; echo "== DeepSentibank forward, per kernel =="; tools/cnn_timeline.sh 256; echo "== DeepSentibank forward, batch 1024, per kernel =="; tools/cnn_timeline.sh 1024; } > gpurun_out/${tag}_cnn_timelines.txt 2>&1
 { for a in "2048 10000000 8192" "4096 10000000 8192"; do echo "== tools/bench_prodv.py $a =="; timeout 600 python tools/bench_prodv.py $a 2>&1 | grep -v amdgpu | grep "V=\|quota\|parity\|routes\|in flight"; done; } > gpurun_out/${tag}_prodv.txt
