@@ -4617,10 +4617,17 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     const bool stream_hint = (ix->force_stream || stream_auto) && !ix->stream_off && stream_supported(M, K, L) && (K % 4 == 0) &&
                              ix->ncells <= 65536 && !index_has_tiny_cells(ix);
     if (stream_hint) {
-        seg_max = 65536;
-        if (ix->force_stream && getenv("CIS_STREAM_SEG")) seg_max = atoi(getenv("CIS_STREAM_SEG")) > 0 ? atoi(getenv("CIS_STREAM_SEG")) : seg_max;  // tests: short chunks on small fixtures
-        const int64_t need = ceil_div(ix->max_cell > 0 ? ix->max_cell : 1, (int64_t)16);
+        // One chunk per cell (round 6): the stream kernel cuts the ROWS of all slots into equal ranges itself, so short chunks buy
+        // nothing and cost plan, slot builder and candidate layout their work items (2398 -> 256 for the exhaustive query over 200 M
+        // codes).  A chunk stays below 2^31 code bytes (32-bit buffer offsets).
+        const int64_t cap_len = (((int64_t)1 << 31) - 65536) / M;
+        int64_t want = ix->max_cell > 65536 ? ix->max_cell : 65536;
+        want = want < cap_len ? want : cap_len;
+        if (const char* e = getenv("CIS_STREAM_CHUNK")) want = atoi(e) > 0 ? atoi(e) : want;  // A/B runs
+        seg_max = (int)(ceil_div(want, (int64_t)1024) * 1024);
+        const int64_t need = ceil_div(ix->max_cell > 0 ? ix->max_cell : 1, (int64_t)16);   // (at most 16 chunk keys per cell)
         if (need > seg_max) seg_max = (int)ceil_div(need, (int64_t)1024) * 1024;
+        if (ix->force_stream && getenv("CIS_STREAM_SEG")) seg_max = atoi(getenv("CIS_STREAM_SEG")) > 0 ? atoi(getenv("CIS_STREAM_SEG")) : seg_max;  // tests: short chunks on small fixtures
     }
     if (const char* e = getenv("CIS_SEG_MAX")) seg_max = atoi(e) > 0 ? atoi(e) : seg_max;  // A/B runs (tools/emulate_shard.py)
     // thousands of coarse clusters (the release configurations' V = 2048 / 4096): the plan is a per-query selection + sort
@@ -4893,7 +4900,10 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         CIS_TRY(mark(2));
         const uint8_t* codes = ix->codes_ptr();
         const int64_t* ids = ix->ids_ptr();
-        const int G = nq >= 2 ? 2 : 1;
+        // queries per slot: a pair costs the launch what one query costs (the codes are the bound), four cost ~1.45 of a pair
+        // (profiles/r06_stream_probe.txt) -- worth it when the queries share their cells, i.e. the quota covers most of the index
+        const bool shared_cells = quota >= ix->n_total / 2;
+        const int G = (nq >= 3 && shared_cells && stream_max_group() >= 4) ? 4 : (nq >= 2 ? 2 : 1);
         const int cap = STREAM_CAP, B = STREAM_B;
         const SelectPlan sp = select_plan(L, nq, (int64_t)nq * cap);
         CIS_REQUIRE(sp.sort_lds, "streaming route: limit above the LDS-ranked range");
@@ -4917,14 +4927,16 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             hipLaunchKernelGGL(k_item_scatter, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, slot_off, cell_cnt, G, slots, (int)ix->ncells, (int)CH, seg_max);
         }
         // workspace: candidate layout, lists, keys, ranked pairs
-        const size_t n_i64 = (size_t)(n_items + 1) + (size_t)3 * (nq + 2);
+        const size_t n_i64 = (size_t)(n_items + 1) + (size_t)3 * (nq + 2) + (size_t)(max_slots + 2) + (size_t)(max_slots + 1) * ((stream_slot_bytes() + 7) / 8);
         const size_t bytes = n_i64 * 8 + (size_t)(nq + 2) * 4 * 4 + (size_t)nq * B * 4 + (size_t)nq * cap * 4 + (size_t)nq * cap * 8 + (size_t)2 * nq * sp.stride * 8 + 1024;
         CIS_TRY(ix->w_hits.reserve(bytes));
         int64_t* cand_start = ix->w_hits.as<int64_t>();
         int64_t* seg = cand_start + (n_items + 1);
         unsigned long long* qmin = reinterpret_cast<unsigned long long*>(seg + (nq + 2));
         unsigned long long* qmax = qmin + (nq + 2);
-        uint64_t* skeys = reinterpret_cast<uint64_t*>(qmax + (nq + 2));   // [nq][cap]
+        int64_t* rowoff = reinterpret_cast<int64_t*>(qmax + (nq + 2));     // [max_slots + 1]: rows of the slots before each (k_stream_init)
+        void* sdesc = rowoff + (max_slots + 2);                             // [max_slots] slot records (k_stream_init)
+        uint64_t* skeys = reinterpret_cast<uint64_t*>(rowoff + (max_slots + 2) + (size_t)(max_slots + 1) * ((stream_slot_bytes() + 7) / 8));   // [nq][cap]
         uint64_t* sel_keys = skeys + (size_t)nq * cap;                     // [nq][stride]
         uint64_t* sel_vals = sel_keys + (size_t)nq * sp.stride;
         uint32_t* surv = reinterpret_cast<uint32_t*>(sel_vals + (size_t)nq * sp.stride);  // [nq][cap]
@@ -4943,7 +4955,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             hipLaunchKernelGGL(k_seg_begin, dim3((unsigned)ceil_div(nq + 1, 256)), dim3(256), 0, st, cand_start, item_off, nq, n_items, n_cand_all, seg, qmin, qmax);
         } else
             hipLaunchKernelGGL(k_cand_layout, dim3(1), dim3(1024), 0, st, items, n_items, item_off, nq, n_cand_all, cand_start, seg, qmin, qmax, (const int64_t*)nullptr);
-        launch_stream_init(st, bmin, (int64_t)nq * B, cnt, nq, status);
+        launch_stream_init(st, bmin, (int64_t)nq * B, cnt, nq, status, items, slots, n_slots, max_slots, G, M, cand_start, seg, rowoff, sdesc);
         // sample: every SS-th row; the k-th smallest of the bucket minima lets about k * SS candidates of a query through -- aim at
         // ~max(4096, 16 limit) of them, with k >= 8 so that the count is stable (relative spread 1 / sqrt(k))
         const int64_t per_q = n_cand_all / nq;
@@ -4955,13 +4967,16 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         int64_t kth = target / ss;
         kth = kth < 8 ? 8 : (kth > B / 4 ? B / 4 : kth);
         if (ix->force_stream && getenv("CIS_STREAM_SS")) { ss = atoll(getenv("CIS_STREAM_SS")); kth = getenv("CIS_STREAM_K") ? atoll(getenv("CIS_STREAM_K")) : kth; }  // tests
-        const int grid = stream_grid(M, G, K, max_slots);
-        launch_stream_scan(M, G, true, grid, st, items, slots, n_slots, T32, T, codes, K, cand_start, seg, tau, bmin, B, (int)ss, surv, cnt, cap);
+        // a lane folds `flush` of its sampled rows into one bucket: ~4 B bucket writes per query (a query's sampled rows x 64 lanes / flush)
+        int64_t flush = ceil_div(ceil_div(per_q, (int64_t)row * ss) * 64, (int64_t)4 * B);
+        flush = flush < 1 ? 1 : flush;
+        const int grid = stream_grid(M, G, K, ceil_div(n_cand_all, (int64_t)row) + n_items);
+        launch_stream_scan(M, G, true, grid, st, sdesc, n_slots, rowoff, T32, T, codes, K, tau, bmin, B, (int)ss, (int)flush, surv, cnt, cap);
         launch_stream_tau(st, bmin, B, (int)kth, nq, tau);
         CIS_TRY(mark(5));
         pr.has_scan = true;
         ix->last_scan_kernel = 5;
-        launch_stream_scan(M, G, false, grid, st, items, slots, n_slots, T32, T, codes, K, cand_start, seg, tau, bmin, B, (int)ss, surv, cnt, cap);
+        launch_stream_scan(M, G, false, grid, st, sdesc, n_slots, rowoff, T32, T, codes, K, tau, bmin, B, (int)ss, (int)flush, surv, cnt, cap);
         CIS_TRY(mark(3));
         launch_stream_keys(M, st, items, cand_start, seg, item_off, n_items, T, codes, K, surv, cnt, cap, nq, skeys, qmin, qmax);
         hipLaunchKernelGGL((k_select_topl<true, 1024>), dim3((unsigned)nq), dim3(1024), sp.lds, st, skeys, seg, cand_start, item_off, qmin, qmax, n_items, L, sp.p2,

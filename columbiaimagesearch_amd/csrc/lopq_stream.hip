@@ -28,199 +28,306 @@
 //      memory; the host then answers the batch through the generic path.  The result never depends on the sample.
 #include "scan_common.h"
 
-#ifndef CIS_STREAM_RING
-#define CIS_STREAM_RING 1   // 1: the next iteration's code rows are requested before the current ones are used (0: requested and awaited per iteration)
-#endif
-#ifndef CIS_STREAM_U
-#define CIS_STREAM_U 0      // 16-byte loads per lane and iteration; 0: two for one query per slot and for the sample pass, four for a pair
-#endif                      // (measured on 200 M codes, profiles/r05_experiments.txt: 324 / 333 / 339 us for ring + 2, ring + 4, no ring + 4)
+// Geometry of the stream (round 6; every choice below is a measurement of tools/probes/stream_probe.hip on 200 M x 8-byte codes,
+// profiles/r06_stream_probe.txt -- the round-5 kernel is that probe's "slots round-robin" form):
+//   * the ROWS (one 16-byte load per lane = 1 KB per wave) of all slots are cut into one equal range per workgroup: the launch ends
+//     together whatever the number and the length of the slots (round 5 dealt whole slots: 2.3 rounds, the last a third full);
+//   * ONE load per wave and iteration, the next iteration's requested before the current is used, NON-TEMPORAL (each byte is used once:
+//     the bare read of the same structure goes from 0.74-0.78 to 0.84 of 8 TB/s with it, and only with one load per wave);
+//   * the tables REPLICATED in LDS so that a gather meets no bank conflict (32 / (M G) copies of an entry row, rows of 128 bytes: the
+//     32 lanes of a read group own distinct banks whatever their bytes), 32 KB per workgroup, staged with 16-byte stores;
+//   * eight waves per workgroup, two workgroups per CU: half the stagings of four-wave workgroups, and a CU never idles on one
+//     workgroup's barrier.
 #ifndef CIS_STREAM_NW
-#define CIS_STREAM_NW 4     // waves per workgroup = per slot: the workgroup reads NW KB of contiguous codes per load round
+#define CIS_STREAM_NW 8     // waves per workgroup
 #endif
-#ifndef CIS_STREAM_REPL
-#define CIS_STREAM_REPL 0
+#ifndef CIS_STREAM_PER_CU
+#define CIS_STREAM_PER_CU 2 // resident workgroups per CU
 #endif
+#ifndef CIS_STREAM_AUX
+#define CIS_STREAM_AUX 2    // cache policy of the code loads: 2 = nt
+#endif
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 static __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 
-__global__ void k_stream_init(uint32_t* __restrict__ bmin, int64_t n_b, int* __restrict__ cnt, int nq, int* __restrict__ status) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_b) bmin[i] = 0x7f800000u;  // +inf
-    if (i < nq) cnt[i] = 0;
-    if (i < 4) status[i] = 0;
+constexpr int stream_copies(int M, int G) { return (32 / G) / M > 0 ? (32 / G) / M : 1; }
+
+// What the stream needs to know of a slot, in one record (one scalar load instead of slots -> items -> cand_start / seg hops at every piece)
+struct StreamSlot {
+    int64_t start;      // first candidate (position in codes)
+    int len;            // candidates of the chunk; 0: empty slot
+    int pad;
+    int q[4];           // query of each item, -1: none
+    int tab0[4], tab1[4];
+    uint32_t rbase[4];  // retrieval index of the chunk's first candidate, relative to the query's first candidate
+};
+
+// Block 0: rowoff[s] = rows of the slots before s (a slot's rows = ceil(len / ROW); an empty slot has none), rowoff[n_slots] = all rows.
+// The others: a StreamSlot per slot; the sample buckets, the list counters and the status words reset.
+__global__ __launch_bounds__(1024) void k_stream_init(uint32_t* __restrict__ bmin, int64_t n_b, int* __restrict__ cnt, int nq, int* __restrict__ status,
+                                                      const WorkItem* __restrict__ items, const int* __restrict__ slots, const int* __restrict__ n_slots, int G, int row,
+                                                      const int64_t* __restrict__ cand_start, const int64_t* __restrict__ seg,
+                                                      int64_t* __restrict__ rowoff, StreamSlot* __restrict__ desc) {
+    const int tid = threadIdx.x;
+    const int ns = *n_slots;
+    if (blockIdx.x > 0) {
+        const int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + tid;
+        if (i < n_b) bmin[i] = 0x7f800000u;  // +inf
+        if (i < nq) cnt[i] = 0;
+        if (i < 4) status[i] = 0;
+        for (int64_t sl = i; sl < ns; sl += (int64_t)(gridDim.x - 1) * 1024) {
+            StreamSlot d;
+            d.start = 0; d.len = 0; d.pad = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ii = g < G ? slots[sl * G + g] : -1;
+                d.q[g] = -1; d.tab0[g] = -2; d.tab1[g] = -2; d.rbase[g] = 0u;
+                if (ii >= 0) {
+                    const WorkItem it = items[ii];
+                    if (g == 0) { d.start = it.start; d.len = it.len; }
+                    d.q[g] = it.q; d.tab0[g] = it.tab0; d.tab1[g] = it.tab1;
+                    d.rbase[g] = (uint32_t)(cand_start[ii] - seg[it.q]);
+                }
+            }
+            desc[sl] = d;
+        }
+        return;
+    }
+    __shared__ int64_t s_w[16];
+    const int lane = tid & 63, wv = tid >> 6;
+    int64_t run = 0;
+    for (int s0 = 0; s0 < ns; s0 += 1024) {
+        const int s = s0 + tid;
+        int64_t x = 0;
+        if (s < ns) {
+            const int ii = slots[(int64_t)s * G];
+            if (ii >= 0) x = (items[ii].len + row - 1) / row;
+        }
+        int64_t inc = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t y = __shfl_up(inc, d);
+            if (lane >= d) inc += y;
+        }
+        __syncthreads();
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        int64_t base = run, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int64_t v = s_w[w];
+            if (w < wv) base += v;
+            tot += v;
+        }
+        if (s < ns) rowoff[s] = base + inc - x;
+        run += tot;
+    }
+    if (tid == 0) rowoff[ns] = run;
 }
 
-// One workgroup (four waves) per slot at a time, persistent over the slots with a stride of the grid.  A slot = one chunk of one
-// cell for up to G queries (the slot builder of lopq_search.hip groups the work items of a cell chunk).
+// Persistent workgroups, one equal range of rows each.  A range spans PIECES of consecutive slots; a slot = one chunk of one cell for
+// up to G queries (the slot builder of lopq_search.hip groups the work items of a cell chunk).  SAMPLE: every sample_stride-th row
+// of every slot (rows counted inside the slot, so the sample does not depend on the ranges).
 template <int M, int G, bool SAMPLE>
-__global__ __launch_bounds__(64 * CIS_STREAM_NW) void k_adc_stream(const WorkItem* __restrict__ items, const int* __restrict__ slots, const int* __restrict__ n_slots,
+__global__ __launch_bounds__(64 * CIS_STREAM_NW) void k_adc_stream(const StreamSlot* __restrict__ desc, const int* __restrict__ n_slots,
+                                                    const int64_t* __restrict__ rowoff,
                                                     const float* __restrict__ T32 /* null: converted from T */, const double* __restrict__ T,
                                                     const uint8_t* __restrict__ codes, int K,
-                                                    const int64_t* __restrict__ cand_start, const int64_t* __restrict__ seg,
-                                                    const float* __restrict__ tau, uint32_t* __restrict__ bmin, int B, int sample_stride,
+                                                    const float* __restrict__ tau, uint32_t* __restrict__ bmin, int B, int sample_stride, int flush,
                                                     uint32_t* __restrict__ surv, int* __restrict__ cnt, int cap) {
+    constexpr int NW = CIS_STREAM_NW;
     constexpr int nf = M / 2;
     constexpr int CPL = 16 / M;        // candidates per lane and 16-byte load
     constexpr int ROW = 64 * CPL;      // candidates per wave and load
-    constexpr int U = CIS_STREAM_U > 0 ? CIS_STREAM_U : ((SAMPLE || G == 1) ? 2 : 4);  // loads per wave and iteration (the ring doubles what is in flight)
-    // Tables in LDS, entry-major, the sub-quantizers rotated over the lanes.  Measured (profiles/r05f_c4x_*): SQ_LDS_BANK_CONFLICT /
-    // SQ_LDS_IDX_ACTIVE = 0.66 -- the worst of the eight 4-lane groups of a read is 2.9-way, not the 2.1-way of one group -- and the LDS
-    // pipe 0.72 busy at 0.60 of 8 TB/s.  CIS_STREAM_REPL=1 REPLICATES the tables so that the gathers meet no conflict at all (a row of 128
-    // bytes per k holds R copies of the M entries; lane l uses copy (l % 32) / M, so the 32 lanes of a read group own distinct banks
-    // whatever their k): built, bit-identical, and slower -- see the macro.
-    // MEASURED (profiles/r05g_*): 357 us against 333-339 us per exhaustive launch over 200 M codes -- the conflicts go (the LDS pipe was
-    // 0.72 busy, not saturated), four times the staging and 32 KB per workgroup cost more: the stream waits on HBM.
-    // CIS_STREAM_REPL = 1: as many copies as a 128-byte row holds (no conflict at all); = 2: TWO copies (rows of 64 bytes: lanes l and
-    // l + 16 of a read group share a copy and a sub-quantizer, so a read is two passes instead of ~2.9, at 16 KB per workgroup)
-    constexpr int RMAX = (32 / G) / M > 0 ? (32 / G) / M : 1;
-    constexpr int R = CIS_STREAM_REPL == 1 ? RMAX : (CIS_STREAM_REPL == 2 ? (RMAX >= 2 ? 2 : 1) : 1);    // copies
-    constexpr int ROWSH = (R * M * G * 4 == 128) ? 7 : (R * M * G * 4 == 64 ? 6 : (R * M * G * 4 == 32 ? 5 : 4));  // log2(row bytes)
-    static_assert(R >= 1 && (1 << ROWSH) == R * M * G * 4, "rows of 16 .. 128 bytes");
+    constexpr int R = stream_copies(M, G);
+    constexpr int ROWB = R * M * G * 4;  // bytes of an entry's row: R copies of the M sub-quantizers' entries of the G queries
+    constexpr int ROWSH = ROWB == 256 ? 8 : (ROWB == 128 ? 7 : (ROWB == 64 ? 6 : 5));
+    static_assert((1 << ROWSH) == ROWB, "rows of 32 .. 256 bytes");
     extern __shared__ __align__(16) float s_tab[];  // [K][R][M][G]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ns = *n_slots;
     const RotConsts<M> rc = make_rot<M>(lane);
-    uint32_t cjb[M];  // byte offset of sub-quantizer j(t, lane) inside an entry row: j * G * 4
+    uint32_t cjb[M];  // byte offset of sub-quantizer j(t, lane) inside an entry row: (copy * M + j) * G * 4
 #pragma unroll
     for (int t = 0; t < M; ++t) {
         cjb[t] = (((uint32_t)(lane & 31) / (uint32_t)M) % (uint32_t)R * (uint32_t)M + (rc.cj[t] >> 2)) * (uint32_t)(G * 4);
         asm volatile("" : "+v"(cjb[t]));  // M registers for the whole kernel (else re-derived per use)
     }
-    for (int s = blockIdx.x; s < ns; s += gridDim.x) {
-        int ii[G];
+    int cur0[G], cur1[G];  // the half tables in LDS
 #pragma unroll
-        for (int g = 0; g < G; ++g) ii[g] = __builtin_amdgcn_readfirstlane(slots[(int64_t)s * G + g]);
-        if (ii[0] < 0) continue;
-        const WorkItem it0 = items[ii[0]];
-        const int len = __builtin_amdgcn_readfirstlane(it0.len);
-        const int64_t start = it0.start;
-        int qg[G];
+    for (int g = 0; g < G; ++g) { cur0[g] = -1; cur1[g] = -1; }
+    float mn[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) mn[g] = __uint_as_float(0x7f800000u);
+
+    const int64_t total = rowoff[ns];
+    int64_t r_lo = total * blockIdx.x / gridDim.x;
+    const int64_t r_hi = total * (blockIdx.x + 1) / gridDim.x;
+    if (r_lo >= r_hi) return;
+    int s;
+    {   // the last slot with rowoff[s] <= r_lo (empty slots in front of it have the same offset: skipped by the search)
+        int lo = 0, hi = ns;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (rowoff[mid] <= r_lo) lo = mid; else hi = mid;
+        }
+        s = lo;
+    }
+    for (; r_lo < r_hi; ++s) {
+        const int64_t sb = rowoff[s], se = rowoff[s + 1];
+        if (se <= r_lo) continue;  // (an empty slot)
+        const int ra = (int)(r_lo - sb);
+        const int rb = (int)((r_hi < se ? r_hi : se) - sb);
+        r_lo = sb + rb;
+        // ---- rows [ra, rb) of slot s -------------------------------------------------------------------------------------------------
+        const StreamSlot* sp = desc + s;   // uniform: scalar loads
+        const int len = __builtin_amdgcn_readfirstlane(sp->len);
+        const int64_t start = sp->start;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(codes + start * M), 0, len * M, 0x00020000);
+        const int ss = SAMPLE ? sample_stride : 1;
+        const int rstep = NW * ss;
+        const int rfirst = (ra + ss - 1) / ss * ss + wv * ss;
+        // rows past the piece belong to another workgroup (or to no one): an offset past the descriptor returns zeros without a memory access
+        auto request = [&](int r) -> u32x4_t {
+            const int off = r < rb ? (r * ROW + lane * CPL) * M : 0x7ffffff0;
+            return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, CIS_STREAM_AUX);
+        };
+        u32x4_t cw = request(rfirst), cn;  // the piece's first rows travel while its tables are staged
+        int qg[G], t0g[G], t1g[G];
         uint32_t rbase[G];   // retrieval index of the chunk's first candidate, relative to the query's first candidate
         float tg[G];
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(codes + start * M), 0, len * M, 0x00020000);
-        const int rows = (len + ROW - 1) / ROW;
-        const int rstep = SAMPLE ? CIS_STREAM_NW * sample_stride : CIS_STREAM_NW;
-        const int rfirst = wv * (SAMPLE ? sample_stride : 1);
-        // past the chunk the descriptor returns zeros (no memory access); such candidates are masked below
-        auto request = [&](int r0, u32x4_t(&dst)[U]) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) dst[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((r0 + u * rstep) * ROW + lane * CPL) * M, 0, 0);
-        };
-        u32x4_t cw[U], cn[U];
-        if (CIS_STREAM_RING) request(rfirst, cw);  // the slot's first rows travel while its tables are staged
-        __syncthreads();     // the previous slot's readers are done with the tables
+        bool any_new = false;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const bool on = ii[g] >= 0;
-            const WorkItem it = items[on ? ii[g] : ii[0]];
-            qg[g] = on ? it.q : -1;
-            rbase[g] = on ? (uint32_t)(cand_start[ii[g]] - seg[it.q]) : 0u;
-            tg[g] = (on && !SAMPLE) ? tau[it.q] : -1.0f;
-            // tables: thread t stages entries k = t, t + 256, ... of every sub-quantizer (coalesced reads of T32[tab][j][k])
-            const int64_t t0 = (int64_t)it.tab0 * nf * K, t1 = (int64_t)it.tab1 * nf * K;
-            for (int k = tid; k < K; k += 64 * CIS_STREAM_NW) {
+            qg[g] = sp->q[g];
+            const bool on = qg[g] >= 0;
+            rbase[g] = sp->rbase[g];
+            tg[g] = (on && !SAMPLE) ? tau[qg[g]] : -1.0f;
+            t0g[g] = sp->tab0[g];
+            t1g[g] = sp->tab1[g];
+            any_new = any_new || t0g[g] != cur0[g] || t1g[g] != cur1[g];
+        }
+        if (any_new) {   // uniform over the workgroup
+            __syncthreads();     // the previous piece's readers are done with the tables
+            // entry k by thread k: its M x G values (coalesced reads of T32[tab][j][k]), then the row's R copies as 16-byte stores, the
+            // copy order rotated by k so that the lanes of a store group spread over the banks
+            for (int k = tid; k < K; k += 64 * NW) {
+                float v[M * G];
 #pragma unroll
-                for (int j = 0; j < M; ++j) {
-                    const float e = on ? (j < nf ? tab_f1(T32, T, t0 + j * K + k) : tab_f1(T32, T, t1 + (j - nf) * K + k)) : 0.f;
+                for (int g = 0; g < G; ++g) {
+                    const int64_t u0 = (int64_t)t0g[g] * nf * K, u1 = (int64_t)t1g[g] * nf * K;
 #pragma unroll
-                    for (int c = 0; c < R; ++c) s_tab[(((size_t)k * R + c) * M + j) * G + g] = e;
+                    for (int j = 0; j < M; ++j) v[j * G + g] = t0g[g] >= 0 ? (j < nf ? tab_f1(T32, T, u0 + j * K + k) : tab_f1(T32, T, u1 + (j - nf) * K + k)) : 0.f;
+                }
+                char* rowp = reinterpret_cast<char*>(s_tab) + (size_t)k * ROWB;
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const int cc = (c + k) & (R - 1);
+#pragma unroll
+                    for (int x = 0; x < M * G / 4; ++x) {
+                        const f32x4_t q4 = {v[4 * x], v[4 * x + 1], v[4 * x + 2], v[4 * x + 3]};
+                        *reinterpret_cast<f32x4_t*>(rowp + cc * (M * G * 4) + 16 * x) = q4;
+                    }
                 }
             }
+#pragma unroll
+            for (int g = 0; g < G; ++g) { cur0[g] = t0g[g]; cur1[g] = t1g[g]; }
+            __syncthreads();
         }
-        __syncthreads();
-        float mn[G];
+        unsigned blk = 0u;
+        for (int r0 = rfirst; r0 < rb; r0 += rstep) {
+            cn = request(r0 + rstep);  // in flight while this iteration gathers
+            float d[CPL][G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) mn[g] = __uint_as_float(0x7f800000u);
-        for (int r0 = rfirst; r0 < rows; r0 += rstep * U) {
-            // The ring: the rows of iteration i + 1 are requested before those of iteration i are used, so a wave has U .. 2 U kilobytes
-            // on their way at any time instead of none while it gathers (round 5: without it ~40 % of the waves had requests in
-            // flight, 4.8-5.0 TB/s = what ~8 MB in flight sustain at the loaded latency).
-            if (CIS_STREAM_RING) request(r0 + rstep * U, cn);
-            else request(r0, cw);
-            // all U * CPL candidates' distances first (their gathers overlap), the rare appends afterwards
-            float d[U * CPL][G];
+            for (int c = 0; c < CPL; ++c) {
+                uint32_t w[(M + 3) / 4];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+                for (int x = 0; x < (M + 3) / 4; ++x) w[x] = cw[c * ((M + 3) / 4) + x];
+                // the lane's rotation: which dword holds the byte of step t (M = 8: two candidates of swapped dwords)
+                uint32_t wsel[(M + 3) / 4];
+                if constexpr (M == 4) wsel[0] = w[0];
+                else if constexpr (M == 8) { wsel[0] = rc.hsel ? w[1] : w[0]; wsel[1] = rc.hsel ? w[0] : w[1]; }
+                else {
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) {
-                    uint32_t w[(M + 3) / 4];
-#pragma unroll
-                    for (int x = 0; x < (M + 3) / 4; ++x) w[x] = cw[u][c * ((M + 3) / 4) + x];
-                    // the lane's rotation: which dword holds the byte of step t (M = 8: two candidates of swapped dwords)
-                    uint32_t wsel[(M + 3) / 4];
-                    if constexpr (M == 4) wsel[0] = w[0];
-                    else if constexpr (M == 8) { wsel[0] = rc.hsel ? w[1] : w[0]; wsel[1] = rc.hsel ? w[0] : w[1]; }
-                    else {
-#pragma unroll
-                        for (int th = 0; th < 4; ++th) {
-                            const uint32_t hs = rc.hsel ^ (uint32_t)th;
-                            wsel[th] = hs == 0 ? w[0] : (hs == 1 ? w[1] : (hs == 2 ? w[2] : w[3]));
-                        }
+                    for (int th = 0; th < 4; ++th) {
+                        const uint32_t hs = rc.hsel ^ (uint32_t)th;
+                        wsel[th] = hs == 0 ? w[0] : (hs == 1 ? w[1] : (hs == 2 ? w[2] : w[3]));
                     }
+                }
 #pragma unroll
-                    for (int t = 0; t < M; ++t) {
-                        const int th = t >> 2, tq = t & 3;
-                        // byte of sub-quantizer j(t, lane), then the byte address of entry (byte, j): two VALU instructions
-                        uint32_t byte, addr;
-                        asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(byte) : "v"(wsel[th]), "v"(rc.sh[tq]));
-                        if constexpr (ROWSH == 7) asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
-                        else if constexpr (ROWSH == 6) asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
-                        else if constexpr (ROWSH == 5) asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
-                        else asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
-                        const char* ep = reinterpret_cast<const char*>(s_tab) + addr;
-                        if constexpr (G == 1) {
-                            const float e = *reinterpret_cast<const float*>(ep);
-                            d[u * CPL + c][0] = t == 0 ? e : d[u * CPL + c][0] + e;
-                        } else {
-                            const f32x2_t e = *reinterpret_cast<const f32x2_t*>(ep);
-                            d[u * CPL + c][0] = t == 0 ? e[0] : d[u * CPL + c][0] + e[0];
-                            d[u * CPL + c][1] = t == 0 ? e[1] : d[u * CPL + c][1] + e[1];
-                        }
+                for (int t = 0; t < M; ++t) {
+                    const int th = t >> 2, tq = t & 3;
+                    // byte of sub-quantizer j(t, lane), then the byte address of entry (byte, j): two VALU instructions
+                    uint32_t byte, addr;
+                    asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(byte) : "v"(wsel[th]), "v"(rc.sh[tq]));
+                    if constexpr (ROWSH == 8) asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
+                    else if constexpr (ROWSH == 7) asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
+                    else if constexpr (ROWSH == 6) asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
+                    else asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
+                    const char* ep = reinterpret_cast<const char*>(s_tab) + addr;
+                    if constexpr (G == 1) {
+                        const float e = *reinterpret_cast<const float*>(ep);
+                        d[c][0] = t == 0 ? e : d[c][0] + e;
+                    } else if constexpr (G == 2) {
+                        const f32x2_t e = *reinterpret_cast<const f32x2_t*>(ep);
+                        d[c][0] = t == 0 ? e[0] : d[c][0] + e[0];
+                        d[c][1] = t == 0 ? e[1] : d[c][1] + e[1];
+                    } else {
+                        static_assert(G == 1 || G == 2 || G == 4, "one, two or four queries per slot");
+                        const f32x4_t e = *reinterpret_cast<const f32x4_t*>(ep);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) d[c][g] = t == 0 ? e[g] : d[c][g] + e[g];
                     }
                 }
             }
             if (SAMPLE) {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
+                for (int c = 0; c < CPL; ++c) {
+                    const bool valid = r0 * ROW + lane * CPL + c < len;
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c) {
-                        const bool valid = (r0 + u * rstep) * ROW + lane * CPL + c < len;
+                    for (int g = 0; g < G; ++g) mn[g] = (valid && d[c][g] < mn[g]) ? d[c][g] : mn[g];
+                }
+                // a lane folds `flush` sampled rows into one bucket (any partition of the samples into buckets keeps the bound of the
+                // header comment; the more non-empty buckets, the tighter): a query that meets ONE long chunk still fills its buckets
+                const int itn = r0 / rstep;   // counted inside the slot: ranges of different workgroups fill different buckets
+                blk = (unsigned)s * 40503u + (unsigned)(itn / flush);
+                if ((itn + 1) % flush == 0) {
 #pragma unroll
-                        for (int g = 0; g < G; ++g) mn[g] = (valid && d[u * CPL + c][g] < mn[g]) ? d[u * CPL + c][g] : mn[g];
+                    for (int g = 0; g < G; ++g) {
+                        if (qg[g] >= 0 && f2u(mn[g]) < 0x7f800000u)
+                            atomicMin(&bmin[(int64_t)qg[g] * B + ((blk * (64u * NW) + (unsigned)tid) & (unsigned)(B - 1))], f2u(mn[g]));
+                        mn[g] = __uint_as_float(0x7f800000u);
                     }
+                }
             } else {
                 bool any = false;
 #pragma unroll
-                for (int u = 0; u < U; ++u)
+                for (int c = 0; c < CPL; ++c)
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c)
-#pragma unroll
-                        for (int g = 0; g < G; ++g) any = any || d[u * CPL + c][g] <= tg[g];
+                    for (int g = 0; g < G; ++g) any = any || d[c][g] <= tg[g];
                 if (__builtin_amdgcn_ballot_w64(any) != 0ull) {  // rare: a few thousand candidates of hundreds of millions pass
 #pragma unroll
-                    for (int u = 0; u < U; ++u)
+                    for (int c = 0; c < CPL; ++c) {
+                        const int p = r0 * ROW + lane * CPL + c;
 #pragma unroll
-                        for (int c = 0; c < CPL; ++c) {
-                            const int p = (r0 + u * rstep) * ROW + lane * CPL + c;
-#pragma unroll
-                            for (int g = 0; g < G; ++g)
-                                if (p < len && d[u * CPL + c][g] <= tg[g]) {
-                                    const int j = atomicAdd(&cnt[qg[g]], 1);
-                                    if (j < cap) surv[(int64_t)qg[g] * cap + j] = rbase[g] + (uint32_t)p;
-                                }
-                        }
+                        for (int g = 0; g < G; ++g)
+                            if (p < len && d[c][g] <= tg[g]) {
+                                const int j = atomicAdd(&cnt[qg[g]], 1);
+                                if (j < cap) surv[(int64_t)qg[g] * cap + j] = rbase[g] + (uint32_t)p;
+                            }
+                    }
                 }
             }
-            if (CIS_STREAM_RING) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) cw[u] = cn[u];
-            }
+            cw = cn;
         }
         if (SAMPLE) {
 #pragma unroll
-            for (int g = 0; g < G; ++g)
+            for (int g = 0; g < G; ++g) {
                 if (qg[g] >= 0 && f2u(mn[g]) < 0x7f800000u)
-                    atomicMin(&bmin[(int64_t)qg[g] * B + (((unsigned)s * (64u * CIS_STREAM_NW) + (unsigned)tid) & (unsigned)(B - 1))], f2u(mn[g]));
+                    atomicMin(&bmin[(int64_t)qg[g] * B + ((blk * (64u * NW) + (unsigned)tid) & (unsigned)(B - 1))], f2u(mn[g]));
+                mn[g] = __uint_as_float(0x7f800000u);
+            }
         }
     }
 }
@@ -339,8 +446,13 @@ __global__ void k_stream_verify(const uint64_t* __restrict__ sel_keys, const int
         const int64_t ncand = seg[q + 1] - seg[q];
         const int c = cnt[q];
         if (c > cap) { atomicAdd(&s_bad[1], 1); continue; }
-        if ((int64_t)c == ncand) continue;  // every candidate was listed (tau = +inf, or a short query)
         const int nv = nsel[q];
+        // k_select_topl ranks nothing (nsel = 0) when more than its tie capacity of exact ties sit at the cut: the generic path resolves
+        // those (first ties in retrieval order).  Checked BEFORE the shortcut below -- a short query whose every candidate was listed can
+        // be such a crowd (round-5 advice: it returned n_found = 0 with no fall-back).
+        const int64_t want = (int64_t)L < ncand ? (int64_t)L : ncand;
+        if ((int64_t)nv != want) { atomicAdd(&s_bad[0], 1); continue; }
+        if ((int64_t)c == ncand) continue;  // every candidate was listed (tau = +inf, or a short query)
         bool ok = nv == L;                    // (c < ncand and fewer than L listed: the threshold was too tight)
         if (ok) {
             const double Bd = __longlong_as_double((long long)sel_keys[(int64_t)q * stride + nv - 1]);
@@ -363,58 +475,55 @@ __global__ void k_stream_verify(const uint64_t* __restrict__ sel_keys, const int
 // ---- host ------------------------------------------------------------------------------------------------------------------------
 bool stream_supported(int M, int K, int L) { return (M == 4 || M == 8 || M == 16) && K <= 256 && L >= 1 && L <= 1024; }
 
-size_t stream_lds(int M, int K, int G) {
-    const int rmax = (32 / G) / M > 0 ? (32 / G) / M : 1;
-    const int R = CIS_STREAM_REPL == 1 ? rmax : (CIS_STREAM_REPL == 2 ? (rmax >= 2 ? 2 : 1) : 1);
-    return (size_t)K * R * M * G * sizeof(float);
-}
+size_t stream_lds(int M, int K, int G) { return (size_t)K * stream_copies(M, G) * M * G * sizeof(float); }
+
+int stream_max_group() { return 4; }
 
 template <int M, int G, bool SAMPLE>
-static void launch_stream_t(int grid, hipStream_t st, const WorkItem* items, const int* slots, const int* n_slots, const float* T32, const double* T,
-                            const uint8_t* codes, int K, const int64_t* cand_start, const int64_t* seg, const float* tau, uint32_t* bmin, int B,
-                            int sample_stride, uint32_t* surv, int* cnt, int cap) {
-    hipLaunchKernelGGL((k_adc_stream<M, G, SAMPLE>), dim3((unsigned)grid), dim3(64 * CIS_STREAM_NW), stream_lds(M, K, G), st, items, slots, n_slots, T32, T, codes, K,
-                       cand_start, seg, tau, bmin, B, sample_stride, surv, cnt, cap);
+static void launch_stream_t(int grid, hipStream_t st, const StreamSlot* desc, const int* n_slots, const int64_t* rowoff, const float* T32,
+                            const double* T, const uint8_t* codes, int K, const float* tau, uint32_t* bmin, int B,
+                            int sample_stride, int flush, uint32_t* surv, int* cnt, int cap) {
+    hipLaunchKernelGGL((k_adc_stream<M, G, SAMPLE>), dim3((unsigned)grid), dim3(64 * CIS_STREAM_NW), stream_lds(M, K, G), st, desc, n_slots, rowoff, T32, T,
+                       codes, K, tau, bmin, B, sample_stride, flush < 1 ? 1 : flush, surv, cnt, cap);
 }
 
-void launch_stream_scan(int M, int G, bool sample, int grid, hipStream_t st, const WorkItem* items, const int* slots, const int* n_slots,
-                        const float* T32, const double* T, const uint8_t* codes, int K, const int64_t* cand_start, const int64_t* seg, const float* tau,
-                        uint32_t* bmin, int B, int sample_stride, uint32_t* surv, int* cnt, int cap) {
+void launch_stream_scan(int M, int G, bool sample, int grid, hipStream_t st, const void* desc_, const int* n_slots, const int64_t* rowoff,
+                        const float* T32, const double* T, const uint8_t* codes, int K, const float* tau,
+                        uint32_t* bmin, int B, int sample_stride, int flush, uint32_t* surv, int* cnt, int cap) {
+    const StreamSlot* desc = static_cast<const StreamSlot*>(desc_);
 #define CIS_STREAM(MM, GG)                                                                                                              \
     if (M == MM && G == GG) {                                                                                                           \
-        if (sample) launch_stream_t<MM, GG, true>(grid, st, items, slots, n_slots, T32, T, codes, K, cand_start, seg, tau, bmin, B,         \
-                                                  sample_stride, surv, cnt, cap);                                                       \
-        else launch_stream_t<MM, GG, false>(grid, st, items, slots, n_slots, T32, T, codes, K, cand_start, seg, tau, bmin, B,               \
-                                            sample_stride, surv, cnt, cap);                                                             \
+        if (sample) launch_stream_t<MM, GG, true>(grid, st, desc, n_slots, rowoff, T32, T, codes, K, tau, bmin, B, sample_stride, flush, surv, cnt, cap);  \
+        else launch_stream_t<MM, GG, false>(grid, st, desc, n_slots, rowoff, T32, T, codes, K, tau, bmin, B, sample_stride, flush, surv, cnt, cap);        \
         return;                                                                                                                         \
     }
-    CIS_STREAM(8, 1) CIS_STREAM(8, 2) CIS_STREAM(4, 1) CIS_STREAM(4, 2) CIS_STREAM(16, 1) CIS_STREAM(16, 2)
+    CIS_STREAM(8, 1) CIS_STREAM(8, 2) CIS_STREAM(8, 4) CIS_STREAM(4, 1) CIS_STREAM(4, 2) CIS_STREAM(4, 4) CIS_STREAM(16, 1) CIS_STREAM(16, 2) CIS_STREAM(16, 4)
 #undef CIS_STREAM
 }
 
-// workgroups of the persistent launch: what the chip holds at once (registers, LDS: the occupancy API), at most one per slot
-int stream_grid(int M, int G, int K, int64_t max_slots) {
-    static int per_cu[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-    const int mi = M == 4 ? 0 : (M == 8 ? 1 : 2), gi = G - 1;
-    if (per_cu[mi][gi] == 0) {
-        int nb = 0;
-        hipError_t e = hipErrorUnknown;
-        const size_t lds = stream_lds(M, 256, G);
-#define CIS_OCC(MM, GG) if (M == MM && G == GG) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_adc_stream<MM, GG, false>, 64 * CIS_STREAM_NW, lds);
-        CIS_OCC(4, 1) CIS_OCC(4, 2) CIS_OCC(8, 1) CIS_OCC(8, 2) CIS_OCC(16, 1) CIS_OCC(16, 2)
-#undef CIS_OCC
-        per_cu[mi][gi] = (e == hipSuccess && nb > 0) ? (nb > 8 ? 8 : nb) : 4;
-    }
-    (void)K;
-    int64_t g = (int64_t)256 * per_cu[mi][gi];
+size_t stream_slot_bytes() { return sizeof(StreamSlot); }
+
+// workgroups of the persistent launch: CIS_STREAM_PER_CU per CU (two 8-wave workgroups: measured best, see the head of the file),
+// fewer when the batch has fewer rows than that
+int stream_grid(int M, int G, int K, int64_t max_rows) {
+    (void)M; (void)G; (void)K;
+    int64_t g = (int64_t)256 * CIS_STREAM_PER_CU;
     if (const char* e = getenv("CIS_STREAM_GRID")) g = atoll(e) > 0 ? atoll(e) : g;  // experiments
-    g = g < max_slots ? g : max_slots;
+    const int64_t by_rows = ceil_div(max_rows < 1 ? 1 : max_rows, (int64_t)CIS_STREAM_NW);
+    g = g < by_rows ? g : by_rows;
     return (int)(g < 1 ? 1 : g);
 }
 
-void launch_stream_init(hipStream_t st, uint32_t* bmin, int64_t n_b, int* cnt, int nq, int* status) {
-    const int64_t n = n_b > nq ? n_b : nq;
-    hipLaunchKernelGGL(k_stream_init, dim3((unsigned)ceil_div(n < 4 ? 4 : n, 256)), dim3(256), 0, st, bmin, n_b, cnt, nq, status);
+void launch_stream_init(hipStream_t st, uint32_t* bmin, int64_t n_b, int* cnt, int nq, int* status, const WorkItem* items, const int* slots, const int* n_slots,
+                        int64_t max_slots, int G, int M, const int64_t* cand_start, const int64_t* seg, int64_t* rowoff, void* desc) {
+    int64_t n = n_b > nq ? n_b : nq;
+    n = n > max_slots ? n : max_slots;
+    int64_t blocks = ceil_div(n < 4 ? 4 : n, (int64_t)1024);
+    blocks = blocks > 4096 ? 4096 : blocks;  // (the descriptor loop strides; the resets need ceil(max(n_b, nq) / 1024) blocks)
+    const int64_t need = ceil_div((n_b > nq ? n_b : nq) < 4 ? 4 : (n_b > nq ? n_b : nq), (int64_t)1024);
+    blocks = blocks < need ? need : blocks;
+    hipLaunchKernelGGL(k_stream_init, dim3(1 + (unsigned)blocks), dim3(1024), 0, st, bmin, n_b, cnt, nq, status, items, slots, n_slots, G, 64 * (16 / M), cand_start,
+                       seg, rowoff, static_cast<StreamSlot*>(desc));
 }
 
 void launch_stream_tau(hipStream_t st, const uint32_t* bmin, int B, int k, int nq, float* tau) {

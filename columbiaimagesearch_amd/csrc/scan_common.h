@@ -255,11 +255,15 @@ void launch_scan3(int M, const Scan3Geom& g, int64_t n_items, hipStream_t st, co
 static const int STREAM_B = 16384;    // buckets of sample minima per query
 static const int STREAM_CAP = 16384;  // listed candidates per query at most
 bool stream_supported(int M, int K, int L);
-int stream_grid(int M, int G, int K, int64_t max_slots);
-void launch_stream_init(hipStream_t st, uint32_t* bmin, int64_t n_b, int* cnt, int nq, int* status);
-void launch_stream_scan(int M, int G, bool sample, int grid, hipStream_t st, const WorkItem* items, const int* slots, const int* n_slots,
-                        const float* T32, const double* T, const uint8_t* codes, int K, const int64_t* cand_start, const int64_t* seg, const float* tau,
-                        uint32_t* bmin, int B, int sample_stride, uint32_t* surv, int* cnt, int cap);
+int stream_grid(int M, int G, int K, int64_t max_rows);
+int stream_max_group();  // queries per slot at most (1, 2 or 4 are instantiated)
+size_t stream_slot_bytes();  // one record per slot (lopq_stream.hip: StreamSlot), written by launch_stream_init
+void launch_stream_init(hipStream_t st, uint32_t* bmin, int64_t n_b, int* cnt, int nq, int* status, const WorkItem* items, const int* slots, const int* n_slots,
+                        int64_t max_slots, int G, int M, const int64_t* cand_start, const int64_t* seg, int64_t* rowoff /* [n_slots + 1]: rows of the slots before each */,
+                        void* desc /* [max_slots] records */);
+void launch_stream_scan(int M, int G, bool sample, int grid, hipStream_t st, const void* desc, const int* n_slots, const int64_t* rowoff,
+                        const float* T32, const double* T, const uint8_t* codes, int K, const float* tau,
+                        uint32_t* bmin, int B, int sample_stride, int flush /* sampled rows a lane folds into one bucket */, uint32_t* surv, int* cnt, int cap);
 void launch_stream_tau(hipStream_t st, const uint32_t* bmin, int B, int k, int nq, float* tau);
 void launch_stream_keys(int M, hipStream_t st, const WorkItem* items, const int64_t* cand_start, const int64_t* seg, const int64_t* item_off,
                         int64_t n_items, const double* T, const uint8_t* codes, int K, const uint32_t* surv, const int* cnt, int cap, int nq,

@@ -1,0 +1,698 @@
+// Round-6 probe of the HBM-streaming ADC scan (csrc/lopq_stream.hip): timing-and-agreement harness for variants of the main pass on a
+// synthetic 200 M x 8-byte code array cut into cell chunks like the c4x exhaustive query (256 cells of uneven size, chunks of <= 83968
+// candidates).  One process, every variant a few launches: a GPU call explores the whole matrix in seconds.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off tools/probes/stream_probe.hip -o tools/probes/stream_probe
+//   tools/probes/stream_probe [N=200000000]
+// Every variant must list the same survivors (count and index sum are compared with variant 0).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int GMAX = 4;
+struct PSlot {
+    int64_t start;   // first candidate
+    int len;         // candidates
+    int ng;          // queries of the slot
+    int tab0[GMAX], tab1[GMAX];  // half tables (nf * K floats each)
+    int q[GMAX];
+    uint32_t rbase[GMAX];
+};
+
+template <int M>
+struct Rot { uint32_t sh[4]; uint32_t cj[M]; uint32_t hsel; };
+template <int M>
+__device__ __forceinline__ Rot<M> make_rot(int lane) {
+    Rot<M> rc;
+    const int r = lane & (M - 1);
+    const int h = r >> 2, q = r & 3;
+    rc.hsel = (uint32_t)h;
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq) rc.sh[tq] = 8u * (uint32_t)((q + tq) & 3);
+#pragma unroll
+    for (int t = 0; t < M; ++t) {
+        const int th = t >> 2, tq = t & 3;
+        const int j = ((h ^ th) << 2) | ((q + tq) & 3);
+        rc.cj[t] = (uint32_t)j << 2;
+    }
+    return rc;
+}
+
+__global__ void k_fill(uint32_t* __restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t x = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        p[i] = (uint32_t)x;
+    }
+}
+
+// MODE 0: slots dealt round-robin over the persistent grid (round 5's kernel).
+// MODE 1: the ROWS of all slots cut into `parts` equal ranges, range p to workgroup p % grid (static; parts = grid: one range each);
+//         a range spans pieces of consecutive slots.
+// MODE 2: as 1, but every WAVE owns a contiguous quarter of the piece instead of interleaving rows with its neighbours.
+// R: table copies per row (1: rotated single copy; 32 / (M G): no bank conflict).  RING: next rows requested before the current are used.
+// BARE: 1 = loads only (xor), 2 = loads + staging, no gathers.
+template <int M, int G, int NW, int U, int R, int MODE, int RING, int BARE, int STG = 0, int AUX = 0, int PK = 0>
+__global__ __launch_bounds__(64 * NW) void k_stream(const PSlot* __restrict__ slots, int ns, const int64_t* __restrict__ rowoff, int parts,
+                                                   const float* __restrict__ T32, const uint8_t* __restrict__ codes, int K,
+                                                   const float* __restrict__ tau, uint32_t* __restrict__ surv, int* __restrict__ cnt, int cap) {
+    constexpr int nf = M / 2;
+    constexpr int CPL = 16 / M;
+    constexpr int ROW = 64 * CPL;
+    constexpr int ROWB = R * M * G * 4;  // bytes of a table row
+    constexpr int ROWSH = ROWB == 256 ? 8 : (ROWB == 128 ? 7 : (ROWB == 64 ? 6 : (ROWB == 32 ? 5 : 4)));
+    static_assert((1 << ROWSH) == ROWB, "row bytes");
+    extern __shared__ __align__(16) float s_tab[];  // [K][R][M][G]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const Rot<M> rc = make_rot<M>(lane);
+    uint32_t cjb[M];
+#pragma unroll
+    for (int t = 0; t < M; ++t) {
+        cjb[t] = (((uint32_t)(lane & 31) / (uint32_t)M) % (uint32_t)R * (uint32_t)M + (rc.cj[t] >> 2)) * (uint32_t)(G * 4);
+        asm volatile("" : "+v"(cjb[t]));
+    }
+    uint32_t bare_acc = 0;
+    int cur0[G], cur1[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { cur0[g] = -1; cur1[g] = -1; }
+
+    auto piece = [&](int s, int ra, int rb) {   // rows [ra, rb) of slot s
+        const PSlot* sp = slots + s;
+        const int len = __builtin_amdgcn_readfirstlane(sp->len);
+        const int64_t start = sp->start;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(codes + start * M), 0, len * M, 0x00020000);
+        int rfirst, rstep, rend;
+        if (MODE == 2) {
+            const int per = (rb - ra + NW - 1) / NW;
+            rfirst = ra + wv * per;
+            rend = rfirst + per < rb ? rfirst + per : rb;
+            rstep = 1;
+        } else {
+            rfirst = ra + wv;
+            rend = rb;
+            rstep = NW;
+        }
+        auto request = [&](int r0, u32x4_t(&dst)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * rstep;
+                // rows past the piece belong to another workgroup: an offset past the descriptor returns zeros without a memory access
+                const int off = r < rend ? (r * ROW + lane * CPL) * M : 0x7ffffff0;
+                dst[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX);
+            }
+        };
+        u32x4_t cw[U], cn[U];
+        if (RING) request(rfirst, cw);
+        int qg[G];
+        uint32_t rbase[G];
+        float tg[G];
+        if (BARE != 1) {
+            bool any_new = false;
+#pragma unroll
+            for (int g = 0; g < G; ++g) any_new = any_new || sp->tab0[g] != cur0[g] || sp->tab1[g] != cur1[g];
+            if (any_new) __syncthreads();
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const bool on = g < sp->ng;
+                qg[g] = on ? sp->q[g] : -1;
+                rbase[g] = sp->rbase[g];
+                tg[g] = on ? tau[sp->q[g]] : -1.0f;
+                const int a0 = sp->tab0[g], a1 = sp->tab1[g];
+                const bool n0 = a0 != cur0[g], n1 = a1 != cur1[g];
+                const int64_t t0 = (int64_t)a0 * nf * K, t1 = (int64_t)a1 * nf * K;
+                if (STG == 0) {
+                if (n0 || n1) {
+                    for (int k = tid; k < K; k += 64 * NW) {
+#pragma unroll
+                        for (int j = 0; j < M; ++j) {
+                            if (j < nf ? n0 : n1) {
+                                const float e = on ? (j < nf ? T32[t0 + j * K + k] : T32[t1 + (j - nf) * K + k]) : 0.f;
+#pragma unroll
+                                for (int c = 0; c < R; ++c) s_tab[(((size_t)k * R + c) * M + j) * G + g] = e;
+                            }
+                        }
+                    }
+                }
+                } else if (STG == 2) {
+                    // every query's entries of row k by thread k, then the row's copies as 16-byte stores (copy order rotated by k)
+                    if (g == 0 && any_new) {
+                        for (int k = tid; k < K; k += 64 * NW) {
+                            float v[M * G];
+#pragma unroll
+                            for (int gg = 0; gg < G; ++gg) {
+                                const bool on2 = gg < sp->ng;
+                                const int64_t u0 = (int64_t)sp->tab0[gg] * nf * K, u1 = (int64_t)sp->tab1[gg] * nf * K;
+#pragma unroll
+                                for (int j = 0; j < M; ++j) v[j * G + gg] = on2 ? (j < nf ? T32[u0 + j * K + k] : T32[u1 + (j - nf) * K + k]) : 0.f;
+                            }
+                            char* rowp = reinterpret_cast<char*>(s_tab) + (size_t)k * ROWB;
+#pragma unroll
+                            for (int c = 0; c < R; ++c) {
+                                const int cc = (c + k) & (R - 1);
+#pragma unroll
+                                for (int x = 0; x < M * G / 4; ++x) {
+                                    const f32x4_t q4 = {v[4 * x], v[4 * x + 1], v[4 * x + 2], v[4 * x + 3]};
+                                    *reinterpret_cast<f32x4_t*>(rowp + cc * (M * G * 4) + 16 * x) = q4;
+                                }
+                            }
+                        }
+                    }
+                } else if (G == 1 && M == 8) {
+                    // entry k by thread k: eight coalesced loads, the row's R copies as 16-byte stores, the copy order rotated by k so that
+                    // the eight lanes of a store group spread over the banks
+                    if (n0 || n1) {
+                        for (int k = tid; k < K; k += 64 * NW) {
+                            f32x4_t lo, hi;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { lo[j] = on ? T32[t0 + j * K + k] : 0.f; hi[j] = on ? T32[t1 + j * K + k] : 0.f; }
+                            char* rowp = reinterpret_cast<char*>(s_tab) + (size_t)k * ROWB;
+#pragma unroll
+                            for (int c = 0; c < R; ++c) {
+                                const int cc = (c + k) & (R - 1);
+                                if (n0) *reinterpret_cast<f32x4_t*>(rowp + cc * 32) = lo;
+                                if (n1) *reinterpret_cast<f32x4_t*>(rowp + cc * 32 + 16) = hi;
+                            }
+                        }
+                    }
+                }
+                cur0[g] = a0; cur1[g] = a1;
+            }
+            if (any_new) __syncthreads();
+        }
+        auto compute = [&](const u32x4_t(&cw)[U], int r0) {
+            if (BARE == 1 || BARE == 2) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) bare_acc ^= cw[u][0] ^ cw[u][1] ^ cw[u][2] ^ cw[u][3];
+            } else {
+                float d[U * CPL][G];
+                float ev[PK ? U * CPL : 1][PK ? M : 1];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) {
+                        uint32_t w[(M + 3) / 4];
+#pragma unroll
+                        for (int x = 0; x < (M + 3) / 4; ++x) w[x] = cw[u][c * ((M + 3) / 4) + x];
+                        uint32_t wsel[(M + 3) / 4];
+                        if constexpr (M == 4) wsel[0] = w[0];
+                        else if constexpr (M == 8) { wsel[0] = rc.hsel ? w[1] : w[0]; wsel[1] = rc.hsel ? w[0] : w[1]; }
+                        else {
+#pragma unroll
+                            for (int th = 0; th < 4; ++th) {
+                                const uint32_t hs = rc.hsel ^ (uint32_t)th;
+                                wsel[th] = hs == 0 ? w[0] : (hs == 1 ? w[1] : (hs == 2 ? w[2] : w[3]));
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0; t < M; ++t) {
+                            const int th = t >> 2, tq = t & 3;
+                            uint32_t byte, addr;
+                            asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(byte) : "v"(wsel[th]), "v"(rc.sh[tq]));
+                            if constexpr (ROWSH == 8) asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
+                            else if constexpr (ROWSH == 7) asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
+                            else if constexpr (ROWSH == 6) asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
+                            else if constexpr (ROWSH == 5) asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
+                            else asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
+                            if constexpr (BARE == 4) { addr = cjb[t] + ((uint32_t)(u * CPL + c) << ROWSH); asm volatile("" : "+v"(addr)); }
+                            const char* ep = reinterpret_cast<const char*>(s_tab) + addr;
+                            if constexpr (G == 1) {
+                                float e;
+                                if constexpr (BARE == 3) e = __uint_as_float(addr | 0x3f800000u);
+                                else e = *reinterpret_cast<const float*>(ep);
+                                if constexpr (PK) ev[u * CPL + c][t] = e;
+                                else
+                                d[u * CPL + c][0] = t == 0 ? e : d[u * CPL + c][0] + e;
+                            } else if constexpr (G == 2) {
+                                const f32x2_t e = *reinterpret_cast<const f32x2_t*>(ep);
+                                d[u * CPL + c][0] = t == 0 ? e[0] : d[u * CPL + c][0] + e[0];
+                                d[u * CPL + c][1] = t == 0 ? e[1] : d[u * CPL + c][1] + e[1];
+                            } else {
+                                const f32x4_t e = *reinterpret_cast<const f32x4_t*>(ep);
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) d[u * CPL + c][g] = t == 0 ? e[g] : d[u * CPL + c][g] + e[g];
+                            }
+                        }
+                    }
+                }
+                if constexpr (PK && G == 1) {   // pairs of candidates summed with packed adds (left-to-right per candidate, as before)
+#pragma unroll
+                    for (int x = 0; x < U * CPL; x += 2) {
+                        f32x2_t acc = {ev[x][0], ev[x + 1][0]};
+#pragma unroll
+                        for (int t = 1; t < M; ++t) { const f32x2_t e2 = {ev[x][t], ev[x + 1][t]}; acc = acc + e2; }
+                        d[x][0] = acc[0]; d[x + 1][0] = acc[1];
+                    }
+                }
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c)
+#pragma unroll
+                        for (int g = 0; g < G; ++g) any = any || d[u * CPL + c][g] <= tg[g];
+                if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c) {
+                            const int r = r0 + u * rstep;
+                            const int p = r * ROW + lane * CPL + c;
+#pragma unroll
+                            for (int g = 0; g < G; ++g)
+                                if (r < rend && p < len && d[u * CPL + c][g] <= tg[g]) {
+                                    const int j = atomicAdd(&cnt[qg[g]], 1);
+                                    if (j < cap) surv[(int64_t)qg[g] * cap + j] = rbase[g] + (uint32_t)p;
+                                }
+                        }
+                }
+            }
+        };
+        if (RING <= 1) {
+            for (int r0 = rfirst; r0 < rend; r0 += rstep * U) {
+                if (RING) request(r0 + rstep * U, cn);
+                else request(r0, cw);
+                compute(cw, r0);
+                if (RING) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) cw[u] = cn[u];
+                }
+            }
+        } else if (RING == 3) {   // one iteration ahead, two register sets swapping roles (no copies)
+            const int st = rstep * U;
+            for (int r0 = rfirst; r0 < rend; r0 += 2 * st) {
+                request(r0 + st, cn);
+                compute(cw, r0);
+                if (r0 + st >= rend) break;
+                request(r0 + 2 * st, cw);
+                compute(cn, r0 + st);
+            }
+        } else {                  // two iterations ahead, three register sets
+            const int st = rstep * U;
+            u32x4_t c2[U];
+            request(rfirst + st, cn);
+            for (int r0 = rfirst; r0 < rend; r0 += 3 * st) {
+                request(r0 + 2 * st, c2);
+                compute(cw, r0);
+                if (r0 + st >= rend) break;
+                request(r0 + 3 * st, cw);
+                compute(cn, r0 + st);
+                if (r0 + 2 * st >= rend) break;
+                request(r0 + 4 * st, cn);
+                compute(c2, r0 + 2 * st);
+            }
+        }
+    };
+
+    if (MODE == 0) {
+        for (int s = blockIdx.x; s < ns; s += gridDim.x) {
+            const int rows = (slots[s].len + ROW - 1) / ROW;
+            piece(s, 0, rows);
+        }
+    } else {
+        const int64_t total = rowoff[ns];
+        for (int p = blockIdx.x; p < parts; p += gridDim.x) {
+            int64_t r_lo = total * p / parts;
+            const int64_t r_hi = total * (p + 1) / parts;
+            int lo = 0, hi = ns;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (rowoff[mid] <= r_lo) lo = mid; else hi = mid;
+            }
+            int s = lo;
+            while (r_lo < r_hi) {
+                const int64_t sb = rowoff[s], se = rowoff[s + 1];
+                const int ra = (int)(r_lo - sb);
+                const int rb = (int)((r_hi < se ? r_hi : se) - sb);
+                piece(s, ra, rb);
+                r_lo = sb + rb;
+                ++s;
+            }
+        }
+    }
+    if (BARE && bare_acc == 0x12345678u) cnt[0] = 1;
+}
+
+struct Setup {
+    int64_t N;
+    int ns;
+    PSlot* d_slots;
+    int64_t* d_rowoff;
+    float* d_T32;
+    uint8_t* d_codes;
+    float* d_tau;
+    uint32_t* d_surv;
+    int* d_cnt;
+    int cap;
+    int nq;
+};
+
+static long long g_ref_cnt[GMAX + 1] = {-1, -1, -1, -1, -1};
+static unsigned long long g_ref_sum[GMAX + 1];
+
+template <int M, int G, int NW, int U, int R, int MODE, int RING, int BARE, int STG = 0, int AUX = 0, int PK = 0>
+static void run(const Setup& S, int per_cu, int parts_per_wg, const char* label) {
+    const size_t lds = (size_t)256 * R * M * G * 4;
+    auto kern = k_stream<M, G, NW, U, R, MODE, RING, BARE, STG, AUX, PK>;
+    if (lds > 65536) CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int occ = 0;
+    CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * NW, lds));
+    hipFuncAttributes fa;
+    CHECK(hipFuncGetAttributes(&fa, (const void*)kern));
+    const int grid = 256 * per_cu;
+    const int parts = grid * parts_per_wg;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    float best = 1e9f, sum = 0.f;
+    const int reps = 6;
+    for (int r = 0; r < reps + 1; ++r) {
+        CHECK(hipMemsetAsync(S.d_cnt, 0, 64 * sizeof(int), 0));
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, 0, S.d_slots, S.ns, S.d_rowoff, parts, S.d_T32, S.d_codes, 256, S.d_tau, S.d_surv, S.d_cnt, S.cap);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) { best = ms < best ? ms : best; sum += ms; }
+    }
+    CHECK(hipGetLastError());
+    // agreement
+    const char* agree = "-";
+    if (BARE == 0) {
+        std::vector<int> c(64);
+        CHECK(hipMemcpy(c.data(), S.d_cnt, 64 * sizeof(int), hipMemcpyDeviceToHost));
+        long long tot = 0;
+        unsigned long long isum = 0;
+        for (int q = 0; q < S.nq && q < G; ++q) {
+            const int n = c[q] < S.cap ? c[q] : S.cap;
+            std::vector<uint32_t> v(n);
+            CHECK(hipMemcpy(v.data(), S.d_surv + (size_t)q * S.cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+            for (int i = 0; i < n; ++i) isum += (unsigned long long)v[i] * (q + 1);
+            tot += c[q];
+        }
+        if (g_ref_cnt[G] < 0) { g_ref_cnt[G] = tot; g_ref_sum[G] = isum; agree = "ref"; }
+        else agree = (g_ref_cnt[G] == tot && g_ref_sum[G] == isum) ? "ok" : "MISMATCH";
+        static char buf[64];
+        snprintf(buf, sizeof buf, "%s(%lld)", agree, tot);
+        agree = buf;
+    }
+    const double gb = (double)S.N * M / 1e9;
+    printf("%-58s G%d NW%d U%d R%d mode%d ring%d | regs %3d lds %6zu occ %d grid %dx256 parts %d | best %.1f us avg %.1f us  %.2f TB/s = %.3f of 8 | %s\n", label, G, NW, U, R, MODE, RING,
+           fa.numRegs, lds, occ, per_cu, parts, best * 1e3, sum / reps * 1e3, gb / best, gb / best / 8.0, agree);
+    fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+    const int64_t N = argc > 1 ? atoll(argv[1]) : 200000000ll;
+    const int sel = argc > 2 ? atoi(argv[2]) : 0;  // 0: everything
+    constexpr int M = 8, K = 256, nf = 4;
+    Setup S;
+    S.N = N;
+    S.cap = 1 << 20;
+    S.nq = GMAX;
+    CHECK(hipMalloc(&S.d_codes, (size_t)N * M + 4096));
+    hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, 0, (uint32_t*)S.d_codes, (N * M + 4096) / 4);
+    // cells: 256 of uneven size; chunks of <= 83968 candidates (what the plan makes of 781 k-candidate cells with 16 chunk keys)
+    std::vector<int64_t> cell(257, 0);
+    {
+        uint64_t x = 12345;
+        std::vector<double> w(256);
+        double tot = 0;
+        for (int c = 0; c < 256; ++c) { x = x * 6364136223846793005ull + 1442695040888963407ull; w[c] = 0.5 + (double)(x >> 40) / (double)(1 << 24); tot += w[c]; }
+        int64_t acc = 0;
+        for (int c = 0; c < 256; ++c) { cell[c] = acc; acc += (int64_t)(N * w[c] / tot); }
+        cell[256] = N;
+    }
+    // half tables: query q, split s, cluster c -> ((q * 2 + s) * 16 + c); values in [0, 1)
+    const int ntab = GMAX * 2 * 16;
+    {
+        std::vector<float> T((size_t)ntab * nf * K);
+        uint64_t x = 999;
+        for (auto& v : T) { x = x * 6364136223846793005ull + 1442695040888963407ull; v = (float)(x >> 40) / (float)(1 << 24); }
+        CHECK(hipMalloc(&S.d_T32, T.size() * 4));
+        CHECK(hipMemcpy(S.d_T32, T.data(), T.size() * 4, hipMemcpyHostToDevice));
+    }
+    auto build_slots = [&](int G, int chunk, std::vector<PSlot>& sl, std::vector<int64_t>& ro) {
+        sl.clear(); ro.clear();
+        ro.push_back(0);
+        int64_t seg_before = 0;
+        for (int c = 0; c < 256; ++c) {
+            const int64_t len_c = cell[c + 1] - cell[c];
+            int64_t maxc = (len_c + 15) / 16;
+            int ch = chunk;
+            if (maxc > ch) ch = (int)((maxc + 1023) / 1024 * 1024);
+            for (int64_t o = 0; o < len_c; o += ch) {
+                PSlot p;
+                p.start = cell[c] + o;
+                p.len = (int)std::min<int64_t>(ch, len_c - o);
+                p.ng = G;
+                for (int g = 0; g < GMAX; ++g) {
+                    p.tab0[g] = (g * 2 + 0) * 16 + (c >> 4);
+                    p.tab1[g] = (g * 2 + 1) * 16 + (c & 15);
+                    p.q[g] = g;
+                    p.rbase[g] = (uint32_t)(seg_before + o);
+                }
+                sl.push_back(p);
+                ro.push_back(ro.back() + (p.len + 127) / 128);
+            }
+            seg_before += len_c;
+        }
+    };
+    std::vector<PSlot> sl;
+    std::vector<int64_t> ro;
+    build_slots(1, 65536, sl, ro);
+    S.ns = (int)sl.size();
+    CHECK(hipMalloc(&S.d_slots, sl.size() * sizeof(PSlot)));
+    CHECK(hipMalloc(&S.d_rowoff, ro.size() * 8));
+    CHECK(hipMemcpy(S.d_slots, sl.data(), sl.size() * sizeof(PSlot), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(S.d_rowoff, ro.data(), ro.size() * 8, hipMemcpyHostToDevice));
+    {
+        std::vector<float> tau(GMAX, 1.0f);  // P(sum of 8 U(0,1) <= 1) = 1 / 8! = 2.5e-5 -> ~5000 of 200 M
+        CHECK(hipMalloc(&S.d_tau, GMAX * 4));
+        CHECK(hipMemcpy(S.d_tau, tau.data(), GMAX * 4, hipMemcpyHostToDevice));
+    }
+    CHECK(hipMalloc(&S.d_surv, (size_t)GMAX * S.cap * 4));
+    CHECK(hipMalloc(&S.d_cnt, 64 * sizeof(int)));
+    CHECK(hipDeviceSynchronize());
+    printf("N %lld, %d slots, %lld rows of 1 KB\n", (long long)N, S.ns, (long long)ro.back());
+
+    //            M  G  NW U  R  MODE RING BARE
+    if (sel == 0 || sel == 1) {
+        run<M, 1, 4, 2, 1, 0, 1, 0>(S, 4, 1, "round-5 kernel: slots round-robin");
+        run<M, 1, 4, 2, 1, 0, 1, 0>(S, 5, 1, "  same, 5 per CU (if registers allow)");
+        run<M, 1, 4, 2, 1, 0, 1, 1>(S, 4, 1, "  bare read, slots round-robin");
+        run<M, 1, 4, 2, 1, 1, 1, 1>(S, 4, 1, "  bare read, equal row ranges");
+        run<M, 1, 4, 2, 1, 1, 1, 1>(S, 8, 1, "  bare read, equal row ranges, 8 per CU");
+        run<M, 1, 4, 2, 1, 0, 1, 2>(S, 4, 1, "  loads + staging, slots round-robin");
+        run<M, 1, 4, 2, 1, 1, 1, 0>(S, 4, 1, "equal row ranges (one per workgroup)");
+        run<M, 1, 4, 2, 1, 1, 1, 0>(S, 4, 2, "equal row ranges, 2 per workgroup");
+        run<M, 1, 4, 2, 1, 1, 1, 0>(S, 4, 4, "equal row ranges, 4 per workgroup");
+        run<M, 1, 4, 2, 1, 2, 1, 0>(S, 4, 1, "equal row ranges, wave-contiguous");
+        run<M, 1, 4, 4, 1, 1, 1, 0>(S, 4, 1, "equal row ranges, U = 4");
+        run<M, 1, 4, 1, 1, 1, 1, 0>(S, 4, 1, "equal row ranges, U = 1");
+        run<M, 1, 4, 2, 1, 1, 0, 0>(S, 4, 1, "equal row ranges, no ring");
+        run<M, 1, 4, 4, 1, 1, 0, 0>(S, 4, 1, "equal row ranges, no ring, U = 4");
+        run<M, 1, 4, 2, 4, 1, 1, 0>(S, 4, 1, "equal row ranges, 4 table copies (no conflicts)");
+        run<M, 1, 4, 2, 4, 1, 1, 0>(S, 5, 1, "equal row ranges, 4 table copies, 5 per CU");
+        run<M, 1, 4, 2, 2, 1, 1, 0>(S, 4, 1, "equal row ranges, 2 table copies");
+        run<M, 1, 4, 4, 4, 1, 1, 0>(S, 4, 1, "equal row ranges, 4 copies, U = 4");
+        run<M, 1, 8, 2, 4, 1, 1, 0>(S, 2, 1, "equal row ranges, 4 copies, 8 waves per workgroup");
+        run<M, 1, 8, 2, 1, 1, 1, 0>(S, 2, 1, "equal row ranges, 8 waves per workgroup");
+        run<M, 1, 2, 2, 1, 1, 1, 0>(S, 8, 1, "equal row ranges, 2 waves per workgroup, 8 per CU");
+        run<M, 1, 1, 2, 1, 1, 1, 0>(S, 16, 1, "equal row ranges, 1 wave per workgroup, 16 per CU");
+        run<M, 1, 1, 2, 1, 1, 1, 0>(S, 20, 1, "equal row ranges, 1 wave per workgroup, 20 per CU");
+    }
+    if (sel == 0 || sel == 2) {
+        for (int G : {2, 4}) {
+            build_slots(G, 65536, sl, ro);
+            CHECK(hipMemcpy(S.d_slots, sl.data(), sl.size() * sizeof(PSlot), hipMemcpyHostToDevice));
+            if (G == 2) {
+                run<M, 2, 4, 4, 1, 0, 1, 0>(S, 4, 1, "pair: round-5 kernel");
+                run<M, 2, 4, 4, 1, 1, 1, 0>(S, 4, 1, "pair: equal row ranges");
+                run<M, 2, 4, 2, 1, 1, 1, 0>(S, 4, 1, "pair: equal row ranges, U = 2");
+                run<M, 2, 4, 2, 2, 1, 1, 0>(S, 4, 1, "pair: equal row ranges, U = 2, 2 copies (no conflicts)");
+            } else {
+                run<M, 4, 4, 2, 1, 0, 1, 0>(S, 4, 1, "four: slots round-robin");
+                run<M, 4, 4, 2, 1, 1, 1, 0>(S, 4, 1, "four: equal row ranges");
+                run<M, 4, 4, 2, 1, 1, 1, 0>(S, 3, 1, "four: equal row ranges, 3 per CU");
+                run<M, 4, 4, 1, 1, 1, 1, 0>(S, 4, 1, "four: equal row ranges, U = 1");
+                run<M, 4, 4, 4, 1, 1, 1, 0>(S, 4, 1, "four: equal row ranges, U = 4");
+                run<M, 4, 8, 2, 1, 1, 1, 0>(S, 2, 1, "four: equal row ranges, 8 waves per workgroup");
+            }
+        }
+    }
+    if (sel == 3) {
+        run<M, 1, 4, 2, 1, 1, 1, 0, 0>(S, 4, 1, "ranges, old staging");
+        run<M, 1, 4, 2, 1, 1, 1, 0, 1>(S, 4, 1, "ranges, wide staging");
+        run<M, 1, 4, 2, 2, 1, 1, 0, 1>(S, 4, 1, "ranges, wide staging, 2 copies");
+        run<M, 1, 4, 2, 4, 1, 1, 0, 1>(S, 4, 1, "ranges, wide staging, 4 copies");
+        run<M, 1, 4, 2, 4, 1, 1, 0, 1>(S, 5, 1, "ranges, wide staging, 4 copies, 5 per CU");
+        run<M, 1, 4, 1, 4, 1, 1, 0, 1>(S, 4, 1, "ranges, wide staging, 4 copies, U = 1");
+        run<M, 1, 4, 4, 4, 1, 1, 0, 1>(S, 4, 1, "ranges, wide staging, 4 copies, U = 4");
+        run<M, 1, 4, 2, 4, 1, 0, 0, 1>(S, 4, 1, "ranges, wide staging, 4 copies, no ring");
+        run<M, 1, 4, 4, 4, 1, 0, 0, 1>(S, 4, 1, "ranges, wide staging, 4 copies, no ring, U = 4");
+        run<M, 1, 8, 2, 1, 1, 1, 0, 1>(S, 2, 1, "ranges, wide staging, 8 waves");
+        run<M, 1, 8, 2, 4, 1, 1, 0, 1>(S, 2, 1, "ranges, wide staging, 8 waves, 4 copies");
+        run<M, 1, 8, 2, 4, 1, 1, 0, 1>(S, 3, 1, "ranges, wide staging, 8 waves, 4 copies, 3 per CU");
+        run<M, 1, 16, 2, 1, 1, 1, 0, 1>(S, 1, 1, "ranges, wide staging, 16 waves");
+        run<M, 1, 16, 2, 4, 1, 1, 0, 1>(S, 1, 1, "ranges, wide staging, 16 waves, 4 copies");
+        run<M, 1, 16, 1, 4, 1, 1, 0, 1>(S, 1, 1, "ranges, wide staging, 16 waves, 4 copies, U = 1");
+        run<M, 1, 16, 4, 4, 1, 1, 0, 1>(S, 1, 1, "ranges, wide staging, 16 waves, 4 copies, U = 4");
+        run<M, 1, 2, 2, 4, 1, 1, 0, 1>(S, 8, 1, "ranges, wide staging, 2 waves, 4 copies, 8 per CU (LDS: 5 fit)");
+        run<M, 1, 4, 2, 4, 0, 1, 0, 1>(S, 4, 1, "slots round-robin, wide staging, 4 copies");
+        run<M, 1, 4, 2, 1, 1, 1, 2, 1>(S, 4, 1, "loads + wide staging only (no gathers)");
+        run<M, 1, 4, 2, 4, 1, 1, 2, 1>(S, 4, 1, "loads + wide staging of 4 copies only (no gathers)");
+    }
+    if (sel == 4) {
+        run<M, 1, 4, 2, 1, 1, 1, 2, 0>(S, 4, 1, "loads + staging");
+        run<M, 1, 4, 2, 1, 1, 1, 3, 0>(S, 4, 1, "loads + staging + VALU (no LDS reads)");
+        run<M, 1, 4, 2, 1, 1, 1, 4, 0>(S, 4, 1, "loads + staging + LDS reads at fixed addresses");
+        run<M, 1, 4, 2, 4, 1, 1, 4, 1>(S, 4, 1, "loads + staging + LDS reads at fixed addresses, 4 copies");
+        run<M, 1, 4, 2, 1, 1, 1, 0, 0>(S, 4, 1, "everything");
+        run<M, 1, 4, 1, 1, 1, 1, 2, 0>(S, 4, 1, "U = 1: loads + staging");
+        run<M, 1, 4, 1, 1, 1, 1, 3, 0>(S, 4, 1, "U = 1: loads + staging + VALU (no LDS reads)");
+        run<M, 1, 4, 1, 1, 1, 1, 4, 0>(S, 4, 1, "U = 1: loads + staging + LDS reads at fixed addresses");
+        run<M, 1, 4, 1, 1, 1, 1, 0, 0>(S, 4, 1, "U = 1: everything");
+        run<M, 1, 16, 1, 4, 1, 1, 2, 1>(S, 1, 1, "16 waves U = 1 4 copies: loads + staging");
+        run<M, 1, 16, 1, 4, 1, 1, 3, 1>(S, 1, 1, "16 waves U = 1 4 copies: + VALU");
+        run<M, 1, 16, 1, 4, 1, 1, 4, 1>(S, 1, 1, "16 waves U = 1 4 copies: + LDS reads fixed");
+        run<M, 1, 16, 1, 4, 1, 1, 0, 1>(S, 1, 1, "16 waves U = 1 4 copies: everything");
+        run<M, 1, 16, 1, 1, 1, 1, 0, 0>(S, 1, 1, "16 waves U = 1 1 copy: everything");
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1>(S, 2, 1, "8 waves U = 1 4 copies: everything");
+        run<M, 1, 8, 1, 1, 1, 1, 0, 0>(S, 2, 1, "8 waves U = 1 1 copy: everything");
+        run<M, 1, 8, 1, 1, 1, 1, 0, 0>(S, 3, 1, "8 waves U = 1 1 copy, 3 per CU: everything");
+        run<M, 1, 4, 1, 1, 1, 1, 0, 0>(S, 5, 1, "4 waves U = 1 1 copy, 5 per CU: everything");
+        run<M, 1, 4, 1, 1, 1, 1, 0, 0>(S, 6, 1, "4 waves U = 1 1 copy, 6 per CU: everything");
+        run<M, 1, 4, 1, 1, 1, 1, 0, 0>(S, 7, 1, "4 waves U = 1 1 copy, 7 per CU: everything");
+        run<M, 1, 4, 1, 1, 1, 1, 2, 0>(S, 6, 1, "4 waves U = 1, 6 per CU: loads + staging");
+    }
+    if (sel == 5) {
+        //            M  G  NW U  R MODE RING BARE STG AUX PK
+        run<M, 1, 16, 1, 4, 1, 1, 0, 1, 0, 0>(S, 1, 1, "16w U1 R4 ring1");
+        run<M, 1, 16, 1, 4, 1, 3, 0, 1, 0, 0>(S, 1, 1, "16w U1 R4 ring3 (no copies)");
+        run<M, 1, 16, 1, 4, 1, 2, 0, 1, 0, 0>(S, 1, 1, "16w U1 R4 ring2 (two ahead)");
+        run<M, 1, 16, 2, 4, 1, 3, 0, 1, 0, 0>(S, 1, 1, "16w U2 R4 ring3");
+        run<M, 1, 16, 2, 4, 1, 2, 0, 1, 0, 0>(S, 1, 1, "16w U2 R4 ring2");
+        run<M, 1, 16, 1, 4, 1, 2, 0, 1, 2, 0>(S, 1, 1, "16w U1 R4 ring2 nt");
+        run<M, 1, 16, 1, 4, 1, 2, 0, 1, 0, 1>(S, 1, 1, "16w U1 R4 ring2 pk");
+        run<M, 1, 16, 1, 4, 1, 1, 0, 1, 0, 1>(S, 1, 1, "16w U1 R4 ring1 pk");
+        run<M, 1, 16, 1, 4, 1, 2, 0, 1, 2, 1>(S, 1, 1, "16w U1 R4 ring2 nt pk");
+        run<M, 1, 8, 1, 4, 1, 2, 0, 1, 0, 0>(S, 2, 1, "8w U1 R4 ring2");
+        run<M, 1, 8, 1, 4, 1, 2, 0, 1, 0, 1>(S, 2, 1, "8w U1 R4 ring2 pk");
+        run<M, 1, 8, 2, 4, 1, 3, 0, 1, 0, 1>(S, 2, 1, "8w U2 R4 ring3 pk");
+        run<M, 1, 4, 1, 4, 1, 2, 0, 1, 0, 0>(S, 4, 1, "4w U1 R4 ring2");
+        run<M, 1, 4, 1, 4, 1, 2, 0, 1, 0, 1>(S, 4, 1, "4w U1 R4 ring2 pk");
+        run<M, 1, 4, 1, 1, 1, 2, 0, 0, 0, 0>(S, 4, 1, "4w U1 R1 ring2");
+        run<M, 1, 4, 1, 1, 1, 2, 0, 0, 0, 1>(S, 4, 1, "4w U1 R1 ring2 pk");
+        run<M, 1, 4, 1, 1, 1, 2, 0, 0, 0, 1>(S, 5, 1, "4w U1 R1 ring2 pk 5/CU");
+        run<M, 1, 4, 1, 1, 1, 2, 0, 0, 0, 1>(S, 6, 1, "4w U1 R1 ring2 pk 6/CU");
+        run<M, 1, 4, 2, 1, 1, 3, 0, 0, 0, 1>(S, 4, 1, "4w U2 R1 ring3 pk");
+        run<M, 1, 4, 2, 1, 1, 2, 0, 0, 0, 1>(S, 4, 1, "4w U2 R1 ring2 pk");
+        run<M, 1, 16, 1, 4, 1, 2, 2, 1, 0, 0>(S, 1, 1, "16w U1 R4 ring2: loads + staging only");
+        run<M, 1, 16, 2, 4, 1, 2, 2, 1, 0, 0>(S, 1, 1, "16w U2 R4 ring2: loads + staging only");
+        run<M, 1, 16, 2, 4, 1, 2, 2, 1, 2, 0>(S, 1, 1, "16w U2 R4 ring2 nt: loads + staging only");
+        run<M, 1, 4, 2, 1, 1, 2, 2, 0, 2, 0>(S, 4, 1, "4w U2 R1 ring2 nt: loads + staging only");
+        run<M, 1, 4, 2, 1, 1, 2, 2, 0, 0, 0>(S, 4, 1, "4w U2 R1 ring2: loads + staging only");
+    }
+    if (sel == 6) {
+        //            M  G  NW U  R MODE RING BARE STG AUX PK
+        run<M, 1, 4, 2, 1, 0, 1, 0, 0, 0, 0>(S, 4, 1, "round-5 kernel");
+        run<M, 1, 4, 2, 1, 0, 1, 0, 0, 2, 0>(S, 4, 1, "round-5 kernel nt");
+        run<M, 1, 4, 2, 1, 1, 1, 0, 0, 2, 0>(S, 4, 1, "ranges 4w U2 R1 ring1 nt");
+        run<M, 1, 4, 2, 1, 1, 1, 0, 0, 2, 1>(S, 4, 1, "ranges 4w U2 R1 ring1 nt pk");
+        run<M, 1, 4, 1, 1, 1, 1, 0, 0, 2, 0>(S, 4, 1, "ranges 4w U1 R1 ring1 nt");
+        run<M, 1, 4, 1, 1, 1, 1, 0, 0, 2, 0>(S, 6, 1, "ranges 4w U1 R1 ring1 nt 6/CU");
+        run<M, 1, 4, 1, 1, 1, 2, 0, 0, 2, 1>(S, 6, 1, "ranges 4w U1 R1 ring2 nt pk 6/CU");
+        run<M, 1, 4, 2, 4, 1, 1, 0, 1, 2, 0>(S, 4, 1, "ranges 4w U2 R4 ring1 nt");
+        run<M, 1, 4, 1, 4, 1, 1, 0, 1, 2, 0>(S, 4, 1, "ranges 4w U1 R4 ring1 nt");
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 0>(S, 2, 1, "ranges 8w U1 R4 ring1 nt");
+        run<M, 1, 8, 2, 4, 1, 1, 0, 1, 2, 0>(S, 2, 1, "ranges 8w U2 R4 ring1 nt");
+        run<M, 1, 8, 1, 1, 1, 1, 0, 0, 2, 0>(S, 2, 1, "ranges 8w U1 R1 ring1 nt");
+        run<M, 1, 8, 2, 1, 1, 1, 0, 0, 2, 0>(S, 2, 1, "ranges 8w U2 R1 ring1 nt");
+        run<M, 1, 16, 1, 4, 1, 1, 0, 1, 2, 0>(S, 1, 1, "ranges 16w U1 R4 ring1 nt");
+        run<M, 1, 16, 1, 4, 1, 1, 0, 1, 2, 1>(S, 1, 1, "ranges 16w U1 R4 ring1 nt pk");
+        run<M, 1, 16, 2, 4, 1, 1, 0, 1, 2, 0>(S, 1, 1, "ranges 16w U2 R4 ring1 nt");
+        run<M, 1, 16, 2, 4, 1, 1, 0, 1, 2, 1>(S, 1, 1, "ranges 16w U2 R4 ring1 nt pk");
+        run<M, 1, 16, 1, 4, 1, 2, 0, 1, 2, 1>(S, 1, 1, "ranges 16w U1 R4 ring2 nt pk");
+        run<M, 1, 16, 1, 4, 1, 2, 0, 1, 2, 1>(S, 1, 2, "ranges 16w U1 R4 ring2 nt pk, 2 parts");
+        run<M, 1, 16, 1, 4, 1, 2, 0, 1, 2, 1>(S, 1, 4, "ranges 16w U1 R4 ring2 nt pk, 4 parts");
+        run<M, 1, 16, 1, 1, 1, 2, 0, 0, 2, 1>(S, 1, 1, "ranges 16w U1 R1 ring2 nt pk");
+        run<M, 1, 16, 1, 2, 1, 2, 0, 1, 2, 1>(S, 1, 1, "ranges 16w U1 R2 ring2 nt pk");
+        run<M, 1, 16, 1, 4, 1, 2, 0, 1, 3, 1>(S, 1, 1, "ranges 16w U1 R4 ring2 nt+sc0 pk");
+        run<M, 1, 16, 1, 4, 1, 2, 0, 1, 18, 1>(S, 1, 1, "ranges 16w U1 R4 ring2 nt+sc1 pk");
+        run<M, 1, 16, 1, 4, 1, 2, 0, 1, 16, 1>(S, 1, 1, "ranges 16w U1 R4 ring2 sc1 pk");
+        run<M, 1, 16, 2, 4, 1, 2, 2, 1, 2, 0>(S, 1, 1, "16w U2 R4 ring2 nt: loads + staging only");
+        run<M, 1, 16, 1, 4, 1, 2, 2, 1, 2, 0>(S, 1, 1, "16w U1 R4 ring2 nt: loads + staging only");
+        run<M, 1, 16, 1, 4, 1, 1, 2, 1, 2, 0>(S, 1, 1, "16w U1 R4 ring1 nt: loads + staging only");
+        run<M, 1, 16, 1, 4, 1, 2, 3, 1, 2, 0>(S, 1, 1, "16w U1 R4 ring2 nt: loads + staging + VALU");
+    }
+    if (sel == 7) {
+        //            M  G  NW U  R MODE RING BARE STG AUX PK
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 0>(S, 2, 1, "8w U1 R4 ring1 nt");
+        run<M, 1, 8, 1, 4, 1, 1, 0, 2, 2, 0>(S, 2, 1, "8w U1 R4 ring1 nt, general staging");
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 0>(S, 2, 2, "8w U1 R4 ring1 nt, 2 parts");
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 0>(S, 2, 4, "8w U1 R4 ring1 nt, 4 parts");
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 0>(S, 3, 1, "8w U1 R4 ring1 nt, 3 per CU");
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 0>(S, 4, 1, "8w U1 R4 ring1 nt, 4 per CU");
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 1>(S, 2, 1, "8w U1 R4 ring1 nt pk");
+        run<M, 1, 8, 1, 4, 0, 1, 0, 1, 2, 0>(S, 2, 1, "8w U1 R4 ring1 nt, slots round-robin");
+        run<M, 1, 8, 1, 4, 1, 0, 0, 1, 2, 0>(S, 2, 1, "8w U1 R4 no ring nt");
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 0, 0>(S, 2, 1, "8w U1 R4 ring1 (default policy)");
+        run<M, 1, 8, 1, 4, 1, 1, 2, 1, 2, 0>(S, 2, 1, "8w U1 R4 ring1 nt: loads + staging only");
+        run<M, 1, 4, 1, 4, 1, 1, 0, 1, 2, 0>(S, 4, 1, "4w U1 R4 ring1 nt");
+        run<M, 1, 4, 1, 4, 1, 1, 0, 1, 2, 0>(S, 5, 1, "4w U1 R4 ring1 nt 5 per CU");
+        run<M, 1, 16, 1, 4, 1, 1, 0, 1, 2, 0>(S, 1, 1, "16w U1 R4 ring1 nt");
+        run<M, 1, 16, 1, 4, 1, 1, 0, 1, 2, 0>(S, 1, 2, "16w U1 R4 ring1 nt, 2 parts");
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 0>(S, 2, 1, "8w U1 R4 ring1 nt (again)");
+        for (int G : {2, 4}) {
+            build_slots(G, 65536, sl, ro);
+            CHECK(hipMemcpy(S.d_slots, sl.data(), sl.size() * sizeof(PSlot), hipMemcpyHostToDevice));
+            if (G == 2) {
+                run<M, 2, 4, 4, 1, 0, 1, 0, 0, 0, 0>(S, 4, 1, "pair: round-5 kernel");
+                run<M, 2, 8, 1, 2, 1, 1, 0, 2, 2, 0>(S, 2, 1, "pair: 8w U1 R2 ring1 nt");
+                run<M, 2, 8, 1, 1, 1, 1, 0, 2, 2, 0>(S, 2, 1, "pair: 8w U1 R1 ring1 nt");
+                run<M, 2, 8, 2, 2, 1, 1, 0, 2, 2, 0>(S, 2, 1, "pair: 8w U2 R2 ring1 nt");
+                run<M, 2, 8, 1, 2, 1, 1, 0, 2, 2, 0>(S, 3, 1, "pair: 8w U1 R2 ring1 nt, 3 per CU");
+                run<M, 2, 4, 1, 2, 1, 1, 0, 2, 2, 0>(S, 4, 1, "pair: 4w U1 R2 ring1 nt");
+                run<M, 2, 16, 1, 2, 1, 1, 0, 2, 2, 0>(S, 1, 1, "pair: 16w U1 R2 ring1 nt");
+            } else {
+                run<M, 4, 4, 2, 1, 1, 1, 0, 0, 0, 0>(S, 4, 1, "four: ranges 4w U2 R1 (first probe)");
+                run<M, 4, 8, 1, 1, 1, 1, 0, 2, 2, 0>(S, 2, 1, "four: 8w U1 R1 ring1 nt");
+                run<M, 4, 8, 2, 1, 1, 1, 0, 2, 2, 0>(S, 2, 1, "four: 8w U2 R1 ring1 nt");
+                run<M, 4, 8, 1, 1, 1, 1, 0, 2, 2, 0>(S, 3, 1, "four: 8w U1 R1 ring1 nt, 3 per CU");
+                run<M, 4, 4, 1, 1, 1, 1, 0, 2, 2, 0>(S, 4, 1, "four: 4w U1 R1 ring1 nt");
+                run<M, 4, 16, 1, 1, 1, 1, 0, 2, 2, 0>(S, 1, 1, "four: 16w U1 R1 ring1 nt");
+                run<M, 4, 8, 1, 1, 1, 1, 0, 2, 0, 0>(S, 2, 1, "four: 8w U1 R1 ring1 (default policy)");
+            }
+        }
+    }
+    if (sel == 8) {   // the forms kept (run next to the library on the same box)
+        //            M  G  NW U  R MODE RING BARE STG AUX PK
+        run<M, 1, 4, 2, 1, 0, 1, 0, 0, 0, 0>(S, 4, 1, "round-5 kernel");
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 0>(S, 2, 1, "8w U1 R4 ring1 nt (the library's form)");
+        run<M, 1, 8, 1, 4, 1, 1, 2, 1, 2, 0>(S, 2, 1, "8w U1 R4 ring1 nt: loads + staging only");
+        build_slots(2, 65536, sl, ro);
+        CHECK(hipMemcpy(S.d_slots, sl.data(), sl.size() * sizeof(PSlot), hipMemcpyHostToDevice));
+        run<M, 2, 8, 1, 2, 1, 1, 0, 2, 2, 0>(S, 2, 1, "pair: 8w U1 R2 ring1 nt");
+        build_slots(4, 65536, sl, ro);
+        CHECK(hipMemcpy(S.d_slots, sl.data(), sl.size() * sizeof(PSlot), hipMemcpyHostToDevice));
+        run<M, 4, 8, 1, 1, 1, 1, 0, 2, 2, 0>(S, 2, 1, "four: 8w U1 R1 ring1 nt");
+    }
+    if (sel == 8) {   // the forms kept (run next to the library on the same box)
+        //            M  G  NW U  R MODE RING BARE STG AUX PK
+        run<M, 1, 4, 2, 1, 0, 1, 0, 0, 0, 0>(S, 4, 1, "round-5 kernel");
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 0>(S, 2, 1, "8w U1 R4 ring1 nt (the library's form)");
+        run<M, 1, 8, 1, 4, 1, 1, 2, 1, 2, 0>(S, 2, 1, "8w U1 R4 ring1 nt: loads + staging only");
+        build_slots(2, 65536, sl, ro);
+        CHECK(hipMemcpy(S.d_slots, sl.data(), sl.size() * sizeof(PSlot), hipMemcpyHostToDevice));
+        run<M, 2, 8, 1, 2, 1, 1, 0, 2, 2, 0>(S, 2, 1, "pair: 8w U1 R2 ring1 nt");
+        build_slots(4, 65536, sl, ro);
+        CHECK(hipMemcpy(S.d_slots, sl.data(), sl.size() * sizeof(PSlot), hipMemcpyHostToDevice));
+        run<M, 4, 8, 1, 1, 1, 1, 0, 2, 2, 0>(S, 2, 1, "four: 8w U1 R1 ring1 nt");
+    }
+    return 0;
+}
