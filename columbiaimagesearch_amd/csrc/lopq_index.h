@@ -93,6 +93,7 @@ struct cis_index {
     HostOut h_out = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};  // where its results go (copied out by cis_index_search_wait)
     bool force_scan5 = false;       // scan mode 7 (tests): k_adc_scan5 (one threshold per query, eight queries per slot) whatever the batch size
     DevBuf w_s5;                    // its per-batch buckets, counters and thresholds
+    DevBuf w_bmin;                  // the streaming route's sample buckets [nq][STREAM_B]: "empty" between batches (k_stream_tau resets what it reads)
     bool force_stream = false;      // scan mode 6 (tests): the HBM-streaming route (lopq_stream.hip) whatever the batch looks like
     bool stream_off = false;        // internal: the batch is being answered again through the generic path after a failed proof
     int64_t stream_batches = 0, stream_fallbacks = 0;  // batches the streaming route served / that it handed back to the generic path

@@ -790,7 +790,7 @@ extern "C" void cis_index_destroy(cis_index* ix) {
                       &ix->w_hitn, &ix->w_slack, &ix->w_planfb, &ix->w_vis, &ix->w_tiles, &ix->w_part, &ix->w_q, &ix->w_oids, &ix->w_odists, &ix->w_onf, &ix->w_ovis,
                       &ix->w_ocell, &ix->w_opos, &ix->w_order2, &ix->w_px, &ix->w_T32, &ix->w_grp, &ix->w_tord, &ix->w_y64, &ix->w_x64,
                       &ix->wi_key[0], &ix->wi_key[1], &ix->wi_val[0], &ix->wi_val[1], &ix->wi_hist, &ix->wi_sid, &ix->wi_acc,
-                      &ix->w_s5, &ix->wi_apre, &ix->wi_tmp, &ix->wi_in_ids, &ix->wi_in_coarse, &ix->wi_in_fine, &ix->wi_scan, &ix->wi_cnt, &ix->wi_cnt2, &ix->d_stats};
+                      &ix->w_s5, &ix->w_bmin, &ix->wi_apre, &ix->wi_tmp, &ix->wi_in_ids, &ix->wi_in_coarse, &ix->wi_in_fine, &ix->wi_scan, &ix->wi_cnt, &ix->wi_cnt2, &ix->d_stats};
     for (DevBuf* b : bufs) b->release();
     ix->own.release();
     ix->ghost.release();

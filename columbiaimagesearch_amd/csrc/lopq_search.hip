@@ -4919,43 +4919,43 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         int* cell_cnt = qctr + 64;
         int* slot_off = cell_cnt + nkeys;
         int* slots = slot_off + nkeys;
-        {
+        if (G > 1) {
             const int64_t ninit = max_slots * G > nkeys ? max_slots * G : nkeys;
             hipLaunchKernelGGL(k_slots_init, dim3((unsigned)ceil_div(ninit < 16 ? 16 : ninit, 256)), dim3(256), 0, st, qctr, cell_cnt, (int)nkeys, slots, max_slots * G);
             hipLaunchKernelGGL(k_item_hist, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, cell_cnt, (int)ix->ncells, (int)CH, seg_max);
             hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, cell_cnt, slot_off, (int)nkeys, G, n_slots, qstart, (int)CH);
             hipLaunchKernelGGL(k_item_scatter, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, slot_off, cell_cnt, G, slots, (int)ix->ncells, (int)CH, seg_max);
+        } else
+            slots = nullptr;   // one query per slot: slot i = work item i (k_stream_prep)
+        // workspace: candidate layout, lists, keys, ranked pairs; the sample buckets live in their own buffer (k_stream_tau leaves them
+        // clean for the next batch; fresh memory is set to "empty" here)
+        {
+            const size_t need = (size_t)nq * B * sizeof(uint32_t);
+            if (need > ix->w_bmin.cap) {
+                CIS_TRY(ix->w_bmin.reserve(need > (size_t)16 * B * sizeof(uint32_t) ? need : (size_t)16 * B * sizeof(uint32_t)));
+                CIS_CHECK_HIP(hipMemsetAsync(ix->w_bmin.p, 0xff, ix->w_bmin.cap, st));
+            }
         }
-        // workspace: candidate layout, lists, keys, ranked pairs
         const size_t n_i64 = (size_t)(n_items + 1) + (size_t)3 * (nq + 2) + (size_t)(max_slots + 2) + (size_t)(max_slots + 1) * ((stream_slot_bytes() + 7) / 8);
-        const size_t bytes = n_i64 * 8 + (size_t)(nq + 2) * 4 * 4 + (size_t)nq * B * 4 + (size_t)nq * cap * 4 + (size_t)nq * cap * 8 + (size_t)2 * nq * sp.stride * 8 + 1024;
+        const size_t bytes = n_i64 * 8 + (size_t)(nq + 2) * 4 * 4 + (size_t)nq * cap * 4 + (size_t)nq * cap * 8 + (size_t)2 * nq * sp.stride * 8 + 1024;
         CIS_TRY(ix->w_hits.reserve(bytes));
         int64_t* cand_start = ix->w_hits.as<int64_t>();
         int64_t* seg = cand_start + (n_items + 1);
         unsigned long long* qmin = reinterpret_cast<unsigned long long*>(seg + (nq + 2));
         unsigned long long* qmax = qmin + (nq + 2);
-        int64_t* rowoff = reinterpret_cast<int64_t*>(qmax + (nq + 2));     // [max_slots + 1]: rows of the slots before each (k_stream_init)
-        void* sdesc = rowoff + (max_slots + 2);                             // [max_slots] slot records (k_stream_init)
+        int64_t* rowoff = reinterpret_cast<int64_t*>(qmax + (nq + 2));     // [max_slots + 1]: rows of the slots before each (k_stream_prep)
+        void* sdesc = rowoff + (max_slots + 2);                             // [max_slots] slot records (k_stream_prep)
         uint64_t* skeys = reinterpret_cast<uint64_t*>(rowoff + (max_slots + 2) + (size_t)(max_slots + 1) * ((stream_slot_bytes() + 7) / 8));   // [nq][cap]
         uint64_t* sel_keys = skeys + (size_t)nq * cap;                     // [nq][stride]
         uint64_t* sel_vals = sel_keys + (size_t)nq * sp.stride;
         uint32_t* surv = reinterpret_cast<uint32_t*>(sel_vals + (size_t)nq * sp.stride);  // [nq][cap]
-        uint32_t* bmin = surv + (size_t)nq * cap;                          // [nq][B]
-        int* cnt = reinterpret_cast<int*>(bmin + (size_t)nq * B);          // [nq + 2]
+        uint32_t* bmin = ix->w_bmin.as<uint32_t>();                        // [nq][B]
+        int* cnt = reinterpret_cast<int*>(surv + (size_t)nq * cap);        // [nq + 2]
         int* nsel = cnt + (nq + 2);
         float* tau = reinterpret_cast<float*>(nsel + (nq + 2));
         int* status = reinterpret_cast<int*>(tau + (nq + 2));
-        if (n_items > 16384) {
-            const int64_t ntiles = ceil_div(n_items, CAND_TILE);
-            CIS_TRY(ix->w_tiles.reserve((size_t)(ntiles + 1) * sizeof(int64_t)));
-            int64_t* tile_sums = ix->w_tiles.as<int64_t>();
-            hipLaunchKernelGGL(k_cand_tile_sum, dim3((unsigned)ntiles), dim3(256), 0, st, items, n_items, tile_sums);
-            hipLaunchKernelGGL(k_cand_tile_scan, dim3(1), dim3(1024), 0, st, tile_sums, ntiles);
-            hipLaunchKernelGGL(k_cand_tile_apply, dim3((unsigned)ntiles), dim3(256), 0, st, items, n_items, tile_sums, cand_start);
-            hipLaunchKernelGGL(k_seg_begin, dim3((unsigned)ceil_div(nq + 1, 256)), dim3(256), 0, st, cand_start, item_off, nq, n_items, n_cand_all, seg, qmin, qmax);
-        } else
-            hipLaunchKernelGGL(k_cand_layout, dim3(1), dim3(1024), 0, st, items, n_items, item_off, nq, n_cand_all, cand_start, seg, qmin, qmax, (const int64_t*)nullptr);
-        launch_stream_init(st, bmin, (int64_t)nq * B, cnt, nq, status, items, slots, n_slots, max_slots, G, M, cand_start, seg, rowoff, sdesc);
+        // candidate layout + slot records + row offsets + resets: one launch of one workgroup
+        launch_stream_prep(st, items, n_items, item_off, nq, n_cand_all, slots, n_slots, G, M, cand_start, seg, qmin, qmax, cnt, status, rowoff, sdesc);
         // sample: every SS-th row; the k-th smallest of the bucket minima lets about k * SS candidates of a query through -- aim at
         // ~max(4096, 16 limit) of them, with k >= 8 so that the count is stable (relative spread 1 / sqrt(k))
         const int64_t per_q = n_cand_all / nq;
@@ -4982,11 +4982,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         hipLaunchKernelGGL((k_select_topl<true, 1024>), dim3((unsigned)nq), dim3(1024), sp.lds, st, skeys, seg, cand_start, item_off, qmin, qmax, n_items, L, sp.p2,
                            sp.stride, sel_keys, sel_vals, nsel, (int64_t*)nullptr, (int64_t*)nullptr, (const int*)nullptr, surv, cnt, (int64_t)cap);
         const int64_t sseq = ++ix->stream_batches;
-        launch_stream_verify(st, sel_keys, nsel, sp.stride, cnt, cap, seg, tau, nq, L, M, status, ix->d_h_totals + 6, sseq);
-        hipLaunchKernelGGL(k_emit_sorted, dim3(1, (unsigned)nq), dim3(256), 0, st, sel_keys, sel_vals, seg, nsel, sp.stride, items, ids, nq, L, out.hits, out.ids,
-                           out.dists, out.n_found, out.cells, out.pos);
-        if (out.visited)
-            hipLaunchKernelGGL(k_copy_visited, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, plan, nq, out.visited);
+        launch_stream_finish(st, sel_keys, sel_vals, nsel, sp.stride, cnt, cap, seg, tau, nq, L, M, items, ids, plan, out.hits, out.ids, out.dists, out.n_found,
+                             out.cells, out.pos, out.visited, status, ix->d_h_totals + 6, sseq);
         CIS_CHECK_HIP(hipGetLastError());
         CIS_TRY(mark(4));
         ix->stats[3] += 1;

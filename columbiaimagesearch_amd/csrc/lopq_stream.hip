@@ -51,7 +51,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 static __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 
-constexpr int stream_copies(int M, int G) { return (32 / G) / M > 0 ? (32 / G) / M : 1; }
+// copies of an entry row: what makes a gather conflict-free -- a ds_read_b32 (G = 1) serves 32 lanes per cycle, ds_read_b64 / b128
+// (G = 2 / 4) measured best with 16 lanes' worth ((copy, sub-quantizer) pairs distinct inside a 16-lane group); rows of 128 or 256 bytes
+constexpr int stream_copies(int M, int G) { return ((G == 1 ? 32 : 16) / M) > 0 ? ((G == 1 ? 32 : 16) / M) : 1; }
 
 // What the stream needs to know of a slot, in one record (one scalar load instead of slots -> items -> cand_start / seg hops at every piece)
 struct StreamSlot {
@@ -63,67 +65,96 @@ struct StreamSlot {
     uint32_t rbase[4];  // retrieval index of the chunk's first candidate, relative to the query's first candidate
 };
 
-// Block 0: rowoff[s] = rows of the slots before s (a slot's rows = ceil(len / ROW); an empty slot has none), rowoff[n_slots] = all rows.
-// The others: a StreamSlot per slot; the sample buckets, the list counters and the status words reset.
-__global__ __launch_bounds__(1024) void k_stream_init(uint32_t* __restrict__ bmin, int64_t n_b, int* __restrict__ cnt, int nq, int* __restrict__ status,
-                                                      const WorkItem* __restrict__ items, const int* __restrict__ slots, const int* __restrict__ n_slots, int G, int row,
-                                                      const int64_t* __restrict__ cand_start, const int64_t* __restrict__ seg,
-                                                      int64_t* __restrict__ rowoff, StreamSlot* __restrict__ desc) {
+// Everything between the plan and the stream in ONE launch of one workgroup (round 6; before: k_cand_layout, k_stream_init and -- for one
+// query per slot -- the four launches of the slot builder, ~5 us each for a few hundred work items):
+//   A. cand_start[i] = candidates of the work items before i (retrieval order), seg[q] = the query's first candidate, key ranges reset
+//      (what k_cand_layout does on the all-candidates path);
+//   B. a StreamSlot per slot; slots == null: slot i = work item i alone (G = 1 needs no grouping);
+//   C. rowoff[s] = rows of the slots before s (a slot's rows = ceil(len / ROW)), rowoff[n_slots] = all rows;
+//   D. the list counters and status words reset.  (The sample buckets are left clean by their reader, k_stream_tau.)
+// Work items by the thousand are walked in rounds of 1024: a batch of this route has few (one chunk per visited cell and query).
+__device__ __forceinline__ int64_t prep_block_excl_scan(int64_t x, int64_t* s_w, int64_t* total) {  // two barriers
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t inc = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t y = __shfl_up(inc, d);
+        if (lane >= d) inc += y;
+    }
+    __syncthreads();
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    int64_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int64_t v = s_w[w];
+        if (w < wv) base += v;
+        tot += v;
+    }
+    *total = tot;
+    return base + inc - x;
+}
+
+__global__ __launch_bounds__(1024) void k_stream_prep(const WorkItem* __restrict__ items, int64_t n_items, const int64_t* __restrict__ item_off, int nq, int64_t n_cand,
+                                                      const int* __restrict__ slots, int* __restrict__ n_slots, int G, int row,
+                                                      int64_t* cand_start, int64_t* seg, unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax,
+                                                      int* __restrict__ cnt, int* __restrict__ status, int64_t* __restrict__ rowoff, StreamSlot* __restrict__ desc) {
+    __shared__ int64_t s_w[16];
     const int tid = threadIdx.x;
-    const int ns = *n_slots;
-    if (blockIdx.x > 0) {
-        const int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + tid;
-        if (i < n_b) bmin[i] = 0x7f800000u;  // +inf
-        if (i < nq) cnt[i] = 0;
-        if (i < 4) status[i] = 0;
-        for (int64_t sl = i; sl < ns; sl += (int64_t)(gridDim.x - 1) * 1024) {
+    // A. (cand_start and seg are written and read by this workgroup through agent-scope atomics: no stale L1 line, as in k_cand_layout)
+    int64_t run = 0;
+    for (int64_t i0 = 0; i0 < n_items; i0 += 1024) {
+        const int64_t i = i0 + tid;
+        const int64_t x = i < n_items ? (int64_t)items[i].len : 0;
+        int64_t tot;
+        const int64_t ex = prep_block_excl_scan(x, s_w, &tot);
+        if (i < n_items) __hip_atomic_store(&cand_start[i], run + ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        run += tot;
+    }
+    __threadfence();
+    __syncthreads();
+    for (int q = tid; q <= nq; q += 1024) {
+        const int64_t it = item_off[q];
+        const int64_t v = (q == nq || it >= n_items) ? n_cand : __hip_atomic_load(&cand_start[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&seg[q], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (q < nq) { qmin[q] = ~0ull; qmax[q] = 0ull; cnt[q] = 0; }
+    }
+    if (tid < 4) status[tid] = 0;
+    __threadfence();
+    __syncthreads();
+    // B + C.
+    const int ns = slots ? *n_slots : (int)n_items;
+    run = 0;
+    for (int s0 = 0; s0 < ns; s0 += 1024) {
+        const int sl = s0 + tid;
+        int64_t x = 0;
+        if (sl < ns) {
             StreamSlot d;
             d.start = 0; d.len = 0; d.pad = 0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int ii = g < G ? slots[sl * G + g] : -1;
+                const int ii = slots ? (g < G ? slots[(int64_t)sl * G + g] : -1) : (g == 0 ? sl : -1);
                 d.q[g] = -1; d.tab0[g] = -2; d.tab1[g] = -2; d.rbase[g] = 0u;
                 if (ii >= 0) {
                     const WorkItem it = items[ii];
                     if (g == 0) { d.start = it.start; d.len = it.len; }
                     d.q[g] = it.q; d.tab0[g] = it.tab0; d.tab1[g] = it.tab1;
-                    d.rbase[g] = (uint32_t)(cand_start[ii] - seg[it.q]);
+                    d.rbase[g] = (uint32_t)(__hip_atomic_load(&cand_start[ii], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                                            __hip_atomic_load(&seg[it.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 }
             }
             desc[sl] = d;
+            x = (d.len + row - 1) / row;
         }
-        return;
-    }
-    __shared__ int64_t s_w[16];
-    const int lane = tid & 63, wv = tid >> 6;
-    int64_t run = 0;
-    for (int s0 = 0; s0 < ns; s0 += 1024) {
-        const int s = s0 + tid;
-        int64_t x = 0;
-        if (s < ns) {
-            const int ii = slots[(int64_t)s * G];
-            if (ii >= 0) x = (items[ii].len + row - 1) / row;
-        }
-        int64_t inc = x;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int64_t y = __shfl_up(inc, d);
-            if (lane >= d) inc += y;
-        }
-        __syncthreads();
-        if (lane == 63) s_w[wv] = inc;
-        __syncthreads();
-        int64_t base = run, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int64_t v = s_w[w];
-            if (w < wv) base += v;
-            tot += v;
-        }
-        if (s < ns) rowoff[s] = base + inc - x;
+        int64_t tot;
+        const int64_t ex = prep_block_excl_scan(x, s_w, &tot);
+        if (sl < ns) rowoff[sl] = run + ex;
         run += tot;
     }
-    if (tid == 0) rowoff[ns] = run;
+    if (tid == 0) {
+        rowoff[ns] = run;
+        if (!slots) *n_slots = ns;
+    }
 }
 
 // Persistent workgroups, one equal range of rows each.  A range spans PIECES of consecutive slots; a slot = one chunk of one cell for
@@ -148,10 +179,13 @@ __global__ __launch_bounds__(64 * CIS_STREAM_NW) void k_adc_stream(const StreamS
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ns = *n_slots;
     const RotConsts<M> rc = make_rot<M>(lane);
-    uint32_t cjb[M];  // byte offset of sub-quantizer j(t, lane) inside an entry row: (copy * M + j) * G * 4
+    // LDS byte address of sub-quantizer j(t, lane)'s entry in row 0: the tables' base + (copy * M + j) * G * 4.  Entry addresses are
+    // integers all the way (bit-field extract, shift-add, ds_read): pointer arithmetic on s_tab costs an add of the base per gather.
+    const uint32_t tab_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)s_tab;
+    uint32_t cjb[M];
 #pragma unroll
     for (int t = 0; t < M; ++t) {
-        cjb[t] = (((uint32_t)(lane & 31) / (uint32_t)M) % (uint32_t)R * (uint32_t)M + (rc.cj[t] >> 2)) * (uint32_t)(G * 4);
+        cjb[t] = tab_base + (((uint32_t)(lane & 31) / (uint32_t)M) % (uint32_t)R * (uint32_t)M + (rc.cj[t] >> 2)) * (uint32_t)(G * 4);
         asm volatile("" : "+v"(cjb[t]));  // M registers for the whole kernel (else re-derived per use)
     }
     int cur0[G], cur1[G];  // the half tables in LDS
@@ -258,24 +292,19 @@ __global__ __launch_bounds__(64 * CIS_STREAM_NW) void k_adc_stream(const StreamS
 #pragma unroll
                 for (int t = 0; t < M; ++t) {
                     const int th = t >> 2, tq = t & 3;
-                    // byte of sub-quantizer j(t, lane), then the byte address of entry (byte, j): two VALU instructions
-                    uint32_t byte, addr;
-                    asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(byte) : "v"(wsel[th]), "v"(rc.sh[tq]));
-                    if constexpr (ROWSH == 8) asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
-                    else if constexpr (ROWSH == 7) asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
-                    else if constexpr (ROWSH == 6) asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
-                    else asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
-                    const char* ep = reinterpret_cast<const char*>(s_tab) + addr;
+                    // byte of sub-quantizer j(t, lane), then the LDS address of entry (byte, j): v_bfe_u32 + v_lshl_add_u32
+                    const uint32_t addr = (__builtin_amdgcn_ubfe(wsel[th], rc.sh[tq], 8u) << ROWSH) + cjb[t];
+                    const __attribute__((address_space(3))) char* ep = (const __attribute__((address_space(3))) char*)(uintptr_t)addr;
                     if constexpr (G == 1) {
-                        const float e = *reinterpret_cast<const float*>(ep);
+                        const float e = *reinterpret_cast<const __attribute__((address_space(3))) float*>(ep);
                         d[c][0] = t == 0 ? e : d[c][0] + e;
                     } else if constexpr (G == 2) {
-                        const f32x2_t e = *reinterpret_cast<const f32x2_t*>(ep);
+                        const f32x2_t e = *reinterpret_cast<const __attribute__((address_space(3))) f32x2_t*>(ep);
                         d[c][0] = t == 0 ? e[0] : d[c][0] + e[0];
                         d[c][1] = t == 0 ? e[1] : d[c][1] + e[1];
                     } else {
                         static_assert(G == 1 || G == 2 || G == 4, "one, two or four queries per slot");
-                        const f32x4_t e = *reinterpret_cast<const f32x4_t*>(ep);
+                        const f32x4_t e = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_t*>(ep);
 #pragma unroll
                         for (int g = 0; g < 4; ++g) d[c][g] = t == 0 ? e[g] : d[c][g] + e[g];
                     }
@@ -296,7 +325,7 @@ __global__ __launch_bounds__(64 * CIS_STREAM_NW) void k_adc_stream(const StreamS
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         if (qg[g] >= 0 && f2u(mn[g]) < 0x7f800000u)
-                            atomicMin(&bmin[(int64_t)qg[g] * B + ((blk * (64u * NW) + (unsigned)tid) & (unsigned)(B - 1))], f2u(mn[g]));
+                            atomicMin(&bmin[(int64_t)qg[g] * B + ((((blk * (64u * NW) + (unsigned)tid) * 2654435761u) >> 12) & (unsigned)(B - 1))], f2u(mn[g]));
                         mn[g] = __uint_as_float(0x7f800000u);
                     }
                 }
@@ -325,72 +354,116 @@ __global__ __launch_bounds__(64 * CIS_STREAM_NW) void k_adc_stream(const StreamS
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (qg[g] >= 0 && f2u(mn[g]) < 0x7f800000u)
-                    atomicMin(&bmin[(int64_t)qg[g] * B + ((blk * (64u * NW) + (unsigned)tid) & (unsigned)(B - 1))], f2u(mn[g]));
+                    atomicMin(&bmin[(int64_t)qg[g] * B + ((((blk * (64u * NW) + (unsigned)tid) * 2654435761u) >> 12) & (unsigned)(B - 1))], f2u(mn[g]));
                 mn[g] = __uint_as_float(0x7f800000u);
             }
         }
     }
 }
 
-// tau[q] = the k-th smallest of the query's B bucket minima (bisection on the bit patterns: non-negative floats order like their
-// bits); +inf when fewer than k buckets were touched.  One workgroup of 1024 threads per query, B / 1024 values per thread.
+// tau[q] = (an upper bound within 2^-16 of the range of) the k-th smallest of the query's B bucket minima; +inf when fewer than k buckets
+// were touched.  One workgroup of 1024 threads per query, B / 1024 values per thread.  Non-negative floats order like their bits: four
+// rounds of FIFTEEN pivots each narrow [min, max] sixteen-fold per round (round 5: sixteen halvings, a barrier pair each: 20 us).
+// hi always has >= k buckets at or below it, so tau = hi admits a few more candidates than the exact k-th smallest would, which only
+// lengthens the list; the proof does not care where tau came from.
+// The buckets are RESET here, by their only reader: the next batch's sample pass finds them clean (the index memsets them when it
+// allocates them; values >= 0x7f800000 are empty).
+// sum over the wave on the VALU (DPP / permlane swaps: a ds_bpermute shuffle costs ~0.2 us of dependent latency per step here)
+static __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
+    v += lane_xor<1>(v);
+    v += lane_xor<2>(v);
+    v += lane_xor<4>(v);
+    v += lane_xor<8>(v);
+    v += lane_xor<16>(v);
+    v += lane_xor<32>(v);
+    return v;
+}
+
+static __device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v) {
+    uint32_t o;
+    o = lane_xor<1>(v); v = o < v ? o : v;
+    o = lane_xor<2>(v); v = o < v ? o : v;
+    o = lane_xor<4>(v); v = o < v ? o : v;
+    o = lane_xor<8>(v); v = o < v ? o : v;
+    o = lane_xor<16>(v); v = o < v ? o : v;
+    o = lane_xor<32>(v); v = o < v ? o : v;
+    return v;
+}
+static __device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v) {
+    uint32_t o;
+    o = lane_xor<1>(v); v = o > v ? o : v;
+    o = lane_xor<2>(v); v = o > v ? o : v;
+    o = lane_xor<4>(v); v = o > v ? o : v;
+    o = lane_xor<8>(v); v = o > v ? o : v;
+    o = lane_xor<16>(v); v = o > v ? o : v;
+    o = lane_xor<32>(v); v = o > v ? o : v;
+    return v;
+}
+
 template <int PER>
-__global__ __launch_bounds__(1024) void k_stream_tau(const uint32_t* __restrict__ bmin, int B, int k, float* __restrict__ tau) {
-    __shared__ int s_c[2][16];
+__global__ __launch_bounds__(1024) void k_stream_tau(uint32_t* __restrict__ bmin, int B, int k, float* __restrict__ tau) {
+    __shared__ int s_tot[5][16];   // [0]: finite buckets; [1 + round]: buckets <= pivot j of the round (summed by one atomic per wave and pivot)
     __shared__ uint32_t s_mm[2];
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     uint32_t v[PER];
     uint32_t lo = 0xffffffffu, hi = 0u;
+    int nfin = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        v[i] = bmin[(int64_t)q * B + i * 1024 + tid];
-        lo = v[i] < lo ? v[i] : lo;
-        if (v[i] < 0x7f800000u) hi = v[i] > hi ? v[i] : hi;
+        uint32_t* bp = bmin + (int64_t)q * B + i * 1024 + tid;
+        v[i] = *bp;
+        *bp = 0x7f800000u;
+        if (v[i] < 0x7f800000u) { hi = v[i] > hi ? v[i] : hi; lo = v[i] < lo ? v[i] : lo; ++nfin; }
+        else v[i] = 0xffffffffu;
     }
     if (tid == 0) { s_mm[0] = 0xffffffffu; s_mm[1] = 0u; }
+    if (tid < 80) s_tot[tid >> 4][tid & 15] = 0;
     __syncthreads();
-    atomicMin(&s_mm[0], lo);
-    atomicMax(&s_mm[1], hi);
+    lo = wave_min_dpp(lo);
+    hi = wave_max_dpp(hi);
+    nfin = (int)wave_sum_dpp((uint32_t)nfin);
+    if (lane == 0) {
+        atomicMin(&s_mm[0], lo);
+        atomicMax(&s_mm[1], hi);
+        atomicAdd(&s_tot[0][0], nfin);
+    }
     __syncthreads();
     lo = s_mm[0];
     hi = s_mm[1];
-    int it = 0;
-    bool enough = true;
-    {   // finite buckets >= k ?
-        int c = 0;
-#pragma unroll
-        for (int i = 0; i < PER; ++i) c += v[i] < 0x7f800000u ? 1 : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if (lane == 0) s_c[0][wv] = c;
-        __syncthreads();
-        int tot = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) tot += s_c[0][w];
-        enough = tot >= k;
-        it = 1;
-    }
-    if (!enough) {
+    if (s_tot[0][0] < k) {   // uniform over the workgroup
         if (tid == 0) tau[q] = __uint_as_float(0x7f800000u);
         return;
     }
-    // (hi always has >= k buckets at or below it.  Sixteen halvings of [min, max] of the bucket minima -- floats of one or two
-    // binades -- leave an interval of ~1e-5 of the value: tau = hi then admits a few more candidates than the exact k-th smallest
-    // would, which only lengthens the list; the proof does not care where tau came from)
-    for (int step = 0; step < 16 && lo < hi; ++step) {  // uniform over the workgroup
-        const uint32_t p = lo + ((hi - lo) >> 1);
-        int c = 0;
+    for (int round = 0; round < 4 && lo < hi; ++round) {  // uniform over the workgroup
+        const uint64_t span = (uint64_t)(hi - lo);
+        int c[15];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) c += v[i] <= p ? 1 : 0;
+        for (int j = 0; j < 15; ++j) {
+            const uint32_t pj = lo + (uint32_t)((span * (uint64_t)(j + 1)) >> 4);
+            int cc = 0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if (lane == 0) s_c[it & 1][wv] = c;
-        __syncthreads();  // (two buffers: a wave that runs ahead writes the other one)
-        int tot = 0;
+            for (int i = 0; i < PER; ++i) cc += v[i] <= pj ? 1 : 0;
+            c[j] = cc;
+        }
+        // wave sums: two counts (<= 1024 each) per register
 #pragma unroll
-        for (int w = 0; w < 16; ++w) tot += s_c[it & 1][w];
-        if (tot >= k) hi = p; else lo = p + 1;
-        ++it;
+        for (int j = 0; j < 14; j += 2) c[j] |= c[j + 1] << 16;
+#pragma unroll
+        for (int j = 0; j < 15; j += 2) c[j] = (int)wave_sum_dpp((uint32_t)c[j]);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 14; j += 2) { atomicAdd(&s_tot[1 + round][j], c[j] & 0xffff); atomicAdd(&s_tot[1 + round][j + 1], c[j] >> 16); }
+            atomicAdd(&s_tot[1 + round][14], c[14]);
+        }
+        __syncthreads();
+        int pick = 15;
+#pragma unroll
+        for (int j = 14; j >= 0; --j)
+            if (s_tot[1 + round][j] >= k) pick = j;
+        const uint32_t nlo = pick > 0 ? lo + (uint32_t)((span * (uint64_t)pick) >> 4) + 1u : lo;
+        const uint32_t nhi = pick < 15 ? lo + (uint32_t)((span * (uint64_t)(pick + 1)) >> 4) : hi;
+        lo = nlo < nhi ? nlo : nhi;
+        hi = nhi;
     }
     if (tid == 0) tau[q] = __uint_as_float(hi);
 }
@@ -434,41 +507,73 @@ __global__ __launch_bounds__(256) void k_stream_keys(const WorkItem* __restrict_
     }
 }
 
-// The proof of the header comment, per query.  status[0] = queries whose proof failed, status[1] = lists that overflowed;
-// the words land in pinned host memory (status_host) behind a sequence number.
-__global__ void k_stream_verify(const uint64_t* __restrict__ sel_keys, const int* __restrict__ nsel, int64_t stride, const int* __restrict__ cnt, int cap,
-                                const int64_t* __restrict__ seg, const float* __restrict__ tau, int nq, int L, double eps,
-                                int* __restrict__ status, volatile int64_t* __restrict__ status_host, int64_t seq) {
-    __shared__ int s_bad[2];
-    if (threadIdx.x == 0) { s_bad[0] = 0; s_bad[1] = 0; }
-    __syncthreads();
-    for (int q = threadIdx.x; q < nq; q += blockDim.x) {
+// The proof of the header comment, the ranked output and the visited counts of a query, one workgroup per query (round 6: one launch for
+// k_stream_verify + k_emit_sorted + k_copy_visited).  status[0] = queries whose proof failed, status[1] = lists that overflowed,
+// status[2] = workgroups done; the last one lands the words in pinned host memory (status_host) behind a sequence number.
+__global__ __launch_bounds__(256) void k_stream_finish(const uint64_t* __restrict__ sel_keys, const uint64_t* __restrict__ sel_vals, const int* __restrict__ nsel,
+                                                       int64_t stride, const int* __restrict__ cnt, int cap, const int64_t* __restrict__ seg, const float* __restrict__ tau,
+                                                       int nq, int L, double eps, const WorkItem* __restrict__ items, const int64_t* __restrict__ ids,
+                                                       const PlanOut* __restrict__ plan, cis_hit* __restrict__ out_hits, int64_t* __restrict__ out_ids,
+                                                       double* __restrict__ out_dists, int* __restrict__ out_n, int32_t* __restrict__ out_cells,
+                                                       uint32_t* __restrict__ out_pos, int32_t* __restrict__ out_visited,
+                                                       int* __restrict__ status, volatile int64_t* __restrict__ status_host, int64_t seq) {
+    const int q = blockIdx.x;
+    const int nv_all = nsel[q];
+    const int nv = nv_all < L ? nv_all : L;
+    const int64_t a = (int64_t)q * stride, o = (int64_t)q * L;
+    for (int x = threadIdx.x; x < L; x += blockDim.x) {
+        cis_hit hh;
+        hh.dist = __longlong_as_double(0x7ff0000000000000LL);
+        hh.visit_rank = 0xffffffffu; hh.pos = 0xffffffffu; hh.id = -1; hh.cell = -1; hh.reserved = 0;
+        if (x < nv) {
+            const uint64_t v = sel_vals[a + x];
+            const WorkItem it = items[v >> 32];
+            const uint32_t p = (uint32_t)v;
+            hh.dist = __longlong_as_double((long long)sel_keys[a + x]);
+            hh.visit_rank = (uint32_t)it.rank;
+            hh.pos = (uint32_t)it.pos0 + p;
+            hh.id = ids[it.start + p];
+            hh.cell = it.cell;
+        }
+        if (out_hits) out_hits[o + x] = hh;
+        if (out_ids) {
+            out_ids[o + x] = hh.id;
+            out_dists[o + x] = (x < nv) ? hh.dist : __longlong_as_double(0x7ff8000000000000LL);
+        }
+        if (out_cells) out_cells[o + x] = hh.cell;
+        if (out_pos) out_pos[o + x] = hh.pos;
+    }
+    if (threadIdx.x == 0) {
+        if (out_n) out_n[q] = nv;
+        if (out_visited) out_visited[q] = plan[q].visited;
         const int64_t ncand = seg[q + 1] - seg[q];
         const int c = cnt[q];
-        if (c > cap) { atomicAdd(&s_bad[1], 1); continue; }
-        const int nv = nsel[q];
-        // k_select_topl ranks nothing (nsel = 0) when more than its tie capacity of exact ties sit at the cut: the generic path resolves
-        // those (first ties in retrieval order).  Checked BEFORE the shortcut below -- a short query whose every candidate was listed can
-        // be such a crowd (round-5 advice: it returned n_found = 0 with no fall-back).
-        const int64_t want = (int64_t)L < ncand ? (int64_t)L : ncand;
-        if ((int64_t)nv != want) { atomicAdd(&s_bad[0], 1); continue; }
-        if ((int64_t)c == ncand) continue;  // every candidate was listed (tau = +inf, or a short query)
-        bool ok = nv == L;                    // (c < ncand and fewer than L listed: the threshold was too tight)
-        if (ok) {
-            const double Bd = __longlong_as_double((long long)sel_keys[(int64_t)q * stride + nv - 1]);
-            ok = Bd * (1.0 + 2.0 * eps) <= (double)tau[q];
+        int bad = 0, over = 0;
+        if (c > cap) over = 1;
+        else {
+            // k_select_topl ranks nothing (nsel = 0) when more than its tie capacity of exact ties sit at the cut: the generic path resolves
+            // those (first ties in retrieval order).  Checked BEFORE the every-candidate-listed shortcut -- a short query whose every
+            // candidate was listed can be such a crowd (round-5 advice: it returned n_found = 0 with no fall-back).
+            const int64_t want = (int64_t)L < ncand ? (int64_t)L : ncand;
+            if ((int64_t)nv_all != want) bad = 1;
+            else if ((int64_t)c != ncand) {   // (c == ncand: every candidate was listed -- tau = +inf, or a short query)
+                // c < ncand and L ranked: B (1 + 2 eps) <= tau proves that every candidate at or below the cut was listed
+                const double Bd = __longlong_as_double((long long)sel_keys[a + nv_all - 1]);
+                if (!(nv_all == L && Bd * (1.0 + 2.0 * eps) <= (double)tau[q])) bad = 1;
+            }
         }
-        if (!ok) atomicAdd(&s_bad[0], 1);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        status[0] = s_bad[0];
-        status[1] = s_bad[1];
-        status_host[0] = s_bad[0];
-        status_host[1] = s_bad[1];
-        __threadfence_system();
-        status_host[2] = seq;
-        __threadfence_system();
+        if (bad) atomicAdd(&status[0], 1);
+        if (over) atomicAdd(&status[1], 1);
+        __threadfence();
+        const int done = atomicAdd(&status[2], 1) + 1;
+        if (done == nq) {
+            __threadfence();
+            status_host[0] = __hip_atomic_load(&status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            status_host[1] = __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            status_host[2] = seq;
+            __threadfence_system();
+        }
     }
 }
 
@@ -514,21 +619,16 @@ int stream_grid(int M, int G, int K, int64_t max_rows) {
     return (int)(g < 1 ? 1 : g);
 }
 
-void launch_stream_init(hipStream_t st, uint32_t* bmin, int64_t n_b, int* cnt, int nq, int* status, const WorkItem* items, const int* slots, const int* n_slots,
-                        int64_t max_slots, int G, int M, const int64_t* cand_start, const int64_t* seg, int64_t* rowoff, void* desc) {
-    int64_t n = n_b > nq ? n_b : nq;
-    n = n > max_slots ? n : max_slots;
-    int64_t blocks = ceil_div(n < 4 ? 4 : n, (int64_t)1024);
-    blocks = blocks > 4096 ? 4096 : blocks;  // (the descriptor loop strides; the resets need ceil(max(n_b, nq) / 1024) blocks)
-    const int64_t need = ceil_div((n_b > nq ? n_b : nq) < 4 ? 4 : (n_b > nq ? n_b : nq), (int64_t)1024);
-    blocks = blocks < need ? need : blocks;
-    hipLaunchKernelGGL(k_stream_init, dim3(1 + (unsigned)blocks), dim3(1024), 0, st, bmin, n_b, cnt, nq, status, items, slots, n_slots, G, 64 * (16 / M), cand_start,
-                       seg, rowoff, static_cast<StreamSlot*>(desc));
+void launch_stream_prep(hipStream_t st, const WorkItem* items, int64_t n_items, const int64_t* item_off, int nq, int64_t n_cand, const int* slots, int* n_slots,
+                        int G, int M, int64_t* cand_start, int64_t* seg, unsigned long long* qmin, unsigned long long* qmax, int* cnt, int* status, int64_t* rowoff,
+                        void* desc) {
+    hipLaunchKernelGGL(k_stream_prep, dim3(1), dim3(1024), 0, st, items, n_items, item_off, nq, n_cand, slots, n_slots, G, 64 * (16 / M), cand_start, seg, qmin, qmax,
+                       cnt, status, rowoff, static_cast<StreamSlot*>(desc));
 }
 
-void launch_stream_tau(hipStream_t st, const uint32_t* bmin, int B, int k, int nq, float* tau) {
-    // B is 16384 (PER = 16)
-    hipLaunchKernelGGL(k_stream_tau<16>, dim3((unsigned)nq), dim3(1024), 0, st, bmin, B, k, tau);
+void launch_stream_tau(hipStream_t st, uint32_t* bmin, int B, int k, int nq, float* tau) {
+    // B = STREAM_B = 1024 threads x PER
+    hipLaunchKernelGGL(k_stream_tau<STREAM_B / 1024>, dim3((unsigned)nq), dim3(1024), 0, st, bmin, B, k, tau);
 }
 
 void launch_stream_keys(int M, hipStream_t st, const WorkItem* items, const int64_t* cand_start, const int64_t* seg, const int64_t* item_off,
@@ -540,8 +640,11 @@ void launch_stream_keys(int M, hipStream_t st, const WorkItem* items, const int6
     else hipLaunchKernelGGL(k_stream_keys<16>, g, dim3(256), 0, st, items, cand_start, seg, item_off, n_items, T, codes, K, surv, cnt, cap, keys, qmin, qmax);
 }
 
-void launch_stream_verify(hipStream_t st, const uint64_t* sel_keys, const int* nsel, int64_t stride, const int* cnt, int cap, const int64_t* seg,
-                          const float* tau, int nq, int L, int M, int* status, int64_t* status_host_dev, int64_t seq) {
+void launch_stream_finish(hipStream_t st, const uint64_t* sel_keys, const uint64_t* sel_vals, const int* nsel, int64_t stride, const int* cnt, int cap,
+                          const int64_t* seg, const float* tau, int nq, int L, int M, const WorkItem* items, const int64_t* ids, const PlanOut* plan,
+                          cis_hit* out_hits, int64_t* out_ids, double* out_dists, int* out_n, int32_t* out_cells, uint32_t* out_pos, int32_t* out_visited,
+                          int* status, int64_t* status_host_dev, int64_t seq) {
     const double eps = 2.0 * M * 5.9604644775390625e-08;  // 2 M 2^-24
-    hipLaunchKernelGGL(k_stream_verify, dim3(1), dim3(256), 0, st, sel_keys, nsel, stride, cnt, cap, seg, tau, nq, L, eps, status, status_host_dev, seq);
+    hipLaunchKernelGGL(k_stream_finish, dim3((unsigned)nq), dim3(256), 0, st, sel_keys, sel_vals, nsel, stride, cnt, cap, seg, tau, nq, L, eps, items, ids, plan,
+                       out_hits, out_ids, out_dists, out_n, out_cells, out_pos, out_visited, status, status_host_dev, seq);
 }

@@ -252,24 +252,27 @@ void launch_scan3(int M, const Scan3Geom& g, int64_t n_items, hipStream_t st, co
                   int* fhdr /* [32] zeroed: fall-back slot header of the sampled form */, int* fslots /* [n_slots * G] */);
 
 // ---- the HBM-streaming scan (lopq_stream.hip): few queries, very many candidates each --------------------------------------
-static const int STREAM_B = 16384;    // buckets of sample minima per query
+static const int STREAM_B = 4096;     // buckets of sample minima per query (k_stream_tau: 1024 threads x 4; the k-th smallest of them, k <= B / 4, bounds the k-th smallest sample)
 static const int STREAM_CAP = 16384;  // listed candidates per query at most
 bool stream_supported(int M, int K, int L);
 int stream_grid(int M, int G, int K, int64_t max_rows);
 int stream_max_group();  // queries per slot at most (1, 2 or 4 are instantiated)
 size_t stream_slot_bytes();  // one record per slot (lopq_stream.hip: StreamSlot), written by launch_stream_init
-void launch_stream_init(hipStream_t st, uint32_t* bmin, int64_t n_b, int* cnt, int nq, int* status, const WorkItem* items, const int* slots, const int* n_slots,
-                        int64_t max_slots, int G, int M, const int64_t* cand_start, const int64_t* seg, int64_t* rowoff /* [n_slots + 1]: rows of the slots before each */,
+void launch_stream_prep(hipStream_t st, const WorkItem* items, int64_t n_items, const int64_t* item_off, int nq, int64_t n_cand,
+                        const int* slots /* null: slot i = work item i alone */, int* n_slots, int G, int M, int64_t* cand_start, int64_t* seg,
+                        unsigned long long* qmin, unsigned long long* qmax, int* cnt, int* status, int64_t* rowoff /* [n_slots + 1]: rows of the slots before each */,
                         void* desc /* [max_slots] records */);
 void launch_stream_scan(int M, int G, bool sample, int grid, hipStream_t st, const void* desc, const int* n_slots, const int64_t* rowoff,
                         const float* T32, const double* T, const uint8_t* codes, int K, const float* tau,
                         uint32_t* bmin, int B, int sample_stride, int flush /* sampled rows a lane folds into one bucket */, uint32_t* surv, int* cnt, int cap);
-void launch_stream_tau(hipStream_t st, const uint32_t* bmin, int B, int k, int nq, float* tau);
+void launch_stream_tau(hipStream_t st, uint32_t* bmin /* read, then reset */, int B, int k, int nq, float* tau);
 void launch_stream_keys(int M, hipStream_t st, const WorkItem* items, const int64_t* cand_start, const int64_t* seg, const int64_t* item_off,
                         int64_t n_items, const double* T, const uint8_t* codes, int K, const uint32_t* surv, const int* cnt, int cap, int nq,
                         uint64_t* keys, unsigned long long* qmin, unsigned long long* qmax);
-void launch_stream_verify(hipStream_t st, const uint64_t* sel_keys, const int* nsel, int64_t stride, const int* cnt, int cap, const int64_t* seg,
-                          const float* tau, int nq, int L, int M, int* status, int64_t* status_host_dev, int64_t seq);
+void launch_stream_finish(hipStream_t st, const uint64_t* sel_keys, const uint64_t* sel_vals, const int* nsel, int64_t stride, const int* cnt, int cap,
+                          const int64_t* seg, const float* tau, int nq, int L, int M, const WorkItem* items, const int64_t* ids, const PlanOut* plan,
+                          cis_hit* out_hits, int64_t* out_ids, double* out_dists, int* out_n, int32_t* out_cells, uint32_t* out_pos, int32_t* out_visited,
+                          int* status, int64_t* status_host_dev, int64_t seq);
 
 // ---- k_adc_scan5 (lopq_scan3.hip): one threshold per query for the whole batch, eight queries per slot -----------------------
 bool scan5_supported(int M, int K, int L);

@@ -4,7 +4,7 @@
 tag=$1; N=${2:-200000000}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for nq in 1 2; do
+for nq in 1 2 4; do
   for c in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY"; do
     name=$c; [ "${c:0:3}" = "SQ_" ] && name=sq
     rm -rf /tmp/pmc_c4x

@@ -21,7 +21,7 @@ res = {"config": "c4x", "index_vectors": N, "code_bytes": N * 8, "per_nq": {},
        "source": "tools/c4x_pmc.sh: rocprofv3 --pmc (one counter set per pass, kernel trace only) over tools/stream_pmc_driver.py N nq 8 -- every "
                  "k_adc_stream<M, G, false> dispatch is one exhaustive launch over the whole index",
        "correction": "gfx950: FETCH_SIZE x 2 (16-byte-per-lane streaming loads are tallied at half their size); WRITE_SIZE as reported; KB"}
-for nq in (1, 2):
+for nq in (1, 2, 4):
     ent = {}
     try:
         f = rows("gpurun_out/%s_c4x_nq%d_FETCH_SIZE_pmc.csv" % (tag, nq))

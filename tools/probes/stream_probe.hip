@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64 * NW) void k_stream(const PSlot* __restrict__ sl
             }
         };
         u32x4_t cw[U], cn[U];
-        if (RING) request(rfirst, cw);
+        if (RING && RING < 10) request(rfirst, cw);
         int qg[G];
         uint32_t rbase[G];
         float tg[G];
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64 * NW) void k_stream(const PSlot* __restrict__ sl
                 for (int u = 0; u < U; ++u) bare_acc ^= cw[u][0] ^ cw[u][1] ^ cw[u][2] ^ cw[u][3];
             } else {
                 float d[U * CPL][G];
-                float ev[PK ? U * CPL : 1][PK ? M : 1];
+                float ev[PK == 1 ? U * CPL : 1][PK == 1 ? M : 1];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -220,12 +220,16 @@ __global__ __launch_bounds__(64 * NW) void k_stream(const PSlot* __restrict__ sl
                             else if constexpr (ROWSH == 5) asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
                             else asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(byte), "v"(cjb[t]));
                             if constexpr (BARE == 4) { addr = cjb[t] + ((uint32_t)(u * CPL + c) << ROWSH); asm volatile("" : "+v"(addr)); }
+                            if constexpr (PK == 2) {   // no inline assembly: bit-field extract builtin, shift-add left to the compiler, the LDS address as an integer
+                                addr = (__builtin_amdgcn_ubfe(wsel[th], rc.sh[tq], 8u) << ROWSH) + cjb[t];
+                            }
                             const char* ep = reinterpret_cast<const char*>(s_tab) + addr;
+                            if constexpr (PK == 2) ep = (const char*)(const __attribute__((address_space(3))) char*)(uintptr_t)addr;
                             if constexpr (G == 1) {
                                 float e;
                                 if constexpr (BARE == 3) e = __uint_as_float(addr | 0x3f800000u);
                                 else e = *reinterpret_cast<const float*>(ep);
-                                if constexpr (PK) ev[u * CPL + c][t] = e;
+                                if constexpr (PK == 1) ev[u * CPL + c][t] = e;
                                 else
                                 d[u * CPL + c][0] = t == 0 ? e : d[u * CPL + c][0] + e;
                             } else if constexpr (G == 2) {
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(64 * NW) void k_stream(const PSlot* __restrict__ sl
                         }
                     }
                 }
-                if constexpr (PK && G == 1) {   // pairs of candidates summed with packed adds (left-to-right per candidate, as before)
+                if constexpr (PK == 1 && G == 1) {   // pairs of candidates summed with packed adds (left-to-right per candidate, as before)
 #pragma unroll
                     for (int x = 0; x < U * CPL; x += 2) {
                         f32x2_t acc = {ev[x][0], ev[x + 1][0]};
@@ -281,6 +285,96 @@ __global__ __launch_bounds__(64 * NW) void k_stream(const PSlot* __restrict__ sl
                 if (RING) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) cw[u] = cn[u];
+                }
+            }
+        } else if constexpr (RING >= 30) {  // LDS DMA: the code rows go L1 -> LDS (a private ring of RING - 30 + 1 KB slots per wave) without
+            // touching registers; a lane then reads its 16 bytes back with one ds_read_b128.  Loads and waits as inline assembly.
+            constexpr int D = RING >= 30 ? RING - 30 : 1;
+            static_assert(U == 1, "one load per wave and iteration");
+            typedef int i32x4_t __attribute__((ext_vector_type(4)));
+            const uint64_t base = (uint64_t)(codes + start * M);
+            i32x4_t rsv;
+            rsv[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+            rsv[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32) & 0xffff);
+            rsv[2] = __builtin_amdgcn_readfirstlane(len * M);
+            rsv[3] = 0x00020000;
+            const uint32_t ring0 = (uint32_t)(256 * ROWB) + (uint32_t)wv * (uint32_t)((D + 1) * 1024);   // byte address of the wave's ring in LDS
+            auto req = [&](int r, int slot) {
+                const int off = r < rend ? (r * ROW + lane * CPL) * M : 0x7ffffff0;
+                const uint32_t m0v = __builtin_amdgcn_readfirstlane(ring0 + (uint32_t)slot * 1024u);
+                if (AUX == 2) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" :: "s"(m0v), "v"(off), "s"(rsv) : "memory");
+                else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(m0v), "v"(off), "s"(rsv) : "memory");
+            };
+            const int st = rstep;
+#pragma unroll
+            for (int i = 0; i < D; ++i) req(rfirst + i * st, i);
+            for (int r0 = rfirst; r0 < rend; r0 += (D + 1) * st) {
+#pragma unroll
+                for (int i = 0; i <= D; ++i) {
+                    const int r = r0 + i * st;
+                    if (r >= rend) break;
+                    req(r + D * st, (i + D) % (D + 1));
+                    if constexpr (D == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    else if constexpr (D == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else if constexpr (D == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else if constexpr (D == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if constexpr (D == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    u32x4_t b[1];
+                    b[0] = *reinterpret_cast<const volatile u32x4_t*>(reinterpret_cast<const char*>(s_tab) + ring0 + (uint32_t)i * 1024u + (uint32_t)lane * 16u);
+                    compute(b, r);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (RING >= 20) {  // RING - 20 iterations ahead with loads and waits as inline assembly: the compiler's own
+            // wait insertion drains the ring at the loop head (s_waitcnt vmcnt(0)); here a use waits for its OWN load only
+            constexpr int D = (RING >= 20 && RING < 30) ? RING - 20 : 1;
+            static_assert(U == 1, "one load per wave and iteration");
+            typedef int i32x4_t __attribute__((ext_vector_type(4)));
+            const uint64_t base = (uint64_t)(codes + start * M);
+            i32x4_t rsv;
+            rsv[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+            rsv[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32) & 0xffff);
+            rsv[2] = __builtin_amdgcn_readfirstlane(len * M);
+            rsv[3] = 0x00020000;
+            auto req = [&](int r, u32x4_t& dst) {
+                const int off = r < rend ? (r * ROW + lane * CPL) * M : 0x7ffffff0;
+                if (AUX == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "=v"(dst) : "v"(off), "s"(rsv) : "memory");
+                else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(off), "s"(rsv) : "memory");
+            };
+            const int st = rstep;
+            u32x4_t b[D + 1][1];
+#pragma unroll
+            for (int i = 0; i < D; ++i) req(rfirst + i * st, b[i][0]);
+            for (int r0 = rfirst; r0 < rend; r0 += (D + 1) * st) {
+#pragma unroll
+                for (int i = 0; i <= D; ++i) {
+                    const int r = r0 + i * st;
+                    if (r >= rend) break;
+                    req(r + D * st, b[(i + D) % (D + 1)][0]);
+                    if constexpr (D == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    else if constexpr (D == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else if constexpr (D == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else if constexpr (D == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    asm volatile("" : "+v"(b[i][0]));
+                    compute(b[i], r);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the requests past the piece (zeros, no memory access) before the registers are reused
+        } else if constexpr (RING >= 10) {  // RING - 10 iterations ahead, that many + 1 register sets, the loop unrolled over them
+            constexpr int D = (RING >= 10 && RING < 20) ? RING - 10 : 1;
+            const int st = rstep * U;
+            u32x4_t b[D + 1][U];
+#pragma unroll
+            for (int i = 0; i < D; ++i) request(rfirst + i * st, b[i]);
+            for (int r0 = rfirst; r0 < rend; r0 += (D + 1) * st) {
+#pragma unroll
+                for (int i = 0; i <= D; ++i) {
+                    const int r = r0 + i * st;
+                    if (r >= rend) break;
+                    request(r + D * st, b[(i + D) % (D + 1)]);
+                    compute(b[i], r);
                 }
             }
         } else if (RING == 3) {   // one iteration ahead, two register sets swapping roles (no copies)
@@ -357,7 +451,7 @@ static unsigned long long g_ref_sum[GMAX + 1];
 
 template <int M, int G, int NW, int U, int R, int MODE, int RING, int BARE, int STG = 0, int AUX = 0, int PK = 0>
 static void run(const Setup& S, int per_cu, int parts_per_wg, const char* label) {
-    const size_t lds = (size_t)256 * R * M * G * 4;
+    const size_t lds = (size_t)256 * R * M * G * 4 + (RING >= 30 ? (size_t)NW * (RING - 30 + 1) * 1024 : 0);
     auto kern = k_stream<M, G, NW, U, R, MODE, RING, BARE, STG, AUX, PK>;
     if (lds > 65536) CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int occ = 0;
@@ -693,6 +787,93 @@ int main(int argc, char** argv) {
         build_slots(4, 65536, sl, ro);
         CHECK(hipMemcpy(S.d_slots, sl.data(), sl.size() * sizeof(PSlot), hipMemcpyHostToDevice));
         run<M, 4, 8, 1, 1, 1, 1, 0, 2, 2, 0>(S, 2, 1, "four: 8w U1 R1 ring1 nt");
+    }
+    if (sel == 9) {
+        //            M  G  NW U  R MODE RING BARE STG AUX PK
+        for (int rep = 0; rep < 2; ++rep) {
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 0>(S, 2, 1, "8w U1 R4 ring1 nt (inline asm address ops)");
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 ring1 nt, builtins + integer LDS address");
+        run<M, 1, 8, 2, 4, 1, 1, 0, 1, 2, 2>(S, 2, 1, "8w U2 R4 ring1 nt, builtins");
+        run<M, 1, 8, 1, 4, 1, 2, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 ring2 nt, builtins");
+        run<M, 1, 8, 1, 4, 1, 3, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 ring3 nt, builtins");
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 2>(S, 3, 1, "8w U1 R4 ring1 nt, builtins, 3 per CU");
+        run<M, 1, 4, 1, 4, 1, 1, 0, 1, 2, 2>(S, 4, 1, "4w U1 R4 ring1 nt, builtins");
+        run<M, 1, 16, 1, 4, 1, 1, 0, 1, 2, 2>(S, 1, 1, "16w U1 R4 ring1 nt, builtins");
+        run<M, 1, 8, 1, 4, 1, 1, 2, 1, 2, 0>(S, 2, 1, "8w U1 R4 ring1 nt: loads + staging only");
+        }
+    }
+    if (sel == 10) {
+        //            M  G  NW U  R MODE RING BARE STG AUX PK
+        for (int rep = 0; rep < 2; ++rep) {
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 ring1 nt");
+        run<M, 1, 8, 1, 4, 1, 12, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 depth 2 nt");
+        run<M, 1, 8, 1, 4, 1, 13, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 depth 3 nt");
+        run<M, 1, 8, 1, 4, 1, 14, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 depth 4 nt");
+        run<M, 1, 8, 1, 4, 1, 16, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 depth 6 nt");
+        run<M, 1, 16, 1, 4, 1, 12, 0, 1, 2, 2>(S, 1, 1, "16w U1 R4 depth 2 nt");
+        run<M, 1, 16, 1, 4, 1, 13, 0, 1, 2, 2>(S, 1, 1, "16w U1 R4 depth 3 nt");
+        run<M, 1, 16, 1, 4, 1, 14, 0, 1, 2, 2>(S, 1, 1, "16w U1 R4 depth 4 nt");
+        run<M, 1, 4, 1, 4, 1, 13, 0, 1, 2, 2>(S, 4, 1, "4w U1 R4 depth 3 nt");
+        run<M, 1, 8, 1, 4, 1, 12, 2, 1, 2, 0>(S, 2, 1, "8w U1 R4 depth 2 nt: loads + staging only");
+        run<M, 1, 8, 1, 4, 1, 13, 2, 1, 2, 0>(S, 2, 1, "8w U1 R4 depth 3 nt: loads + staging only");
+        run<M, 1, 8, 1, 4, 1, 14, 2, 1, 2, 0>(S, 2, 1, "8w U1 R4 depth 4 nt: loads + staging only");
+        run<M, 1, 8, 1, 4, 1, 16, 2, 1, 2, 0>(S, 2, 1, "8w U1 R4 depth 6 nt: loads + staging only");
+        run<M, 1, 16, 1, 4, 1, 14, 2, 1, 2, 0>(S, 1, 1, "16w U1 R4 depth 4 nt: loads + staging only");
+        run<M, 1, 8, 1, 4, 1, 14, 0, 1, 0, 2>(S, 2, 1, "8w U1 R4 depth 4 (default policy)");
+        }
+    }
+    if (sel == 11) {
+        //            M  G  NW U  R MODE RING BARE STG AUX PK
+        for (int rep = 0; rep < 2; ++rep) {
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 ring1 nt");
+        run<M, 1, 8, 1, 4, 1, 21, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 asm ring depth 1 nt");
+        run<M, 1, 8, 1, 4, 1, 22, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 asm ring depth 2 nt");
+        run<M, 1, 8, 1, 4, 1, 23, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 asm ring depth 3 nt");
+        run<M, 1, 8, 1, 4, 1, 24, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 asm ring depth 4 nt");
+        run<M, 1, 8, 1, 4, 1, 26, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 asm ring depth 6 nt");
+        run<M, 1, 16, 1, 4, 1, 22, 0, 1, 2, 2>(S, 1, 1, "16w U1 R4 asm ring depth 2 nt");
+        run<M, 1, 16, 1, 4, 1, 23, 0, 1, 2, 2>(S, 1, 1, "16w U1 R4 asm ring depth 3 nt");
+        run<M, 1, 4, 1, 4, 1, 22, 0, 1, 2, 2>(S, 4, 1, "4w U1 R4 asm ring depth 2 nt");
+        run<M, 1, 4, 1, 4, 1, 23, 0, 1, 2, 2>(S, 4, 1, "4w U1 R4 asm ring depth 3 nt");
+        run<M, 1, 8, 1, 4, 1, 22, 0, 1, 2, 2>(S, 3, 1, "8w U1 R4 asm ring depth 2 nt, 3 per CU");
+        run<M, 1, 8, 1, 1, 1, 22, 0, 0, 2, 2>(S, 2, 1, "8w U1 R1 asm ring depth 2 nt");
+        run<M, 1, 8, 1, 4, 1, 22, 0, 1, 0, 2>(S, 2, 1, "8w U1 R4 asm ring depth 2 (default policy)");
+        run<M, 1, 8, 1, 4, 1, 22, 2, 1, 2, 0>(S, 2, 1, "8w U1 R4 asm ring depth 2 nt: loads + staging only");
+        }
+    }
+    if (sel == 12) {
+        //            M  G  NW U  R MODE RING BARE STG AUX PK
+        for (int rep = 0; rep < 2; ++rep) {
+        run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 ring1 nt");
+        run<M, 1, 8, 1, 4, 1, 31, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 LDS-DMA ring depth 1 nt");
+        run<M, 1, 8, 1, 4, 1, 32, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 LDS-DMA ring depth 2 nt");
+        run<M, 1, 8, 1, 4, 1, 33, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 LDS-DMA ring depth 3 nt");
+        run<M, 1, 8, 1, 4, 1, 34, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 LDS-DMA ring depth 4 nt");
+        run<M, 1, 8, 1, 4, 1, 36, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 LDS-DMA ring depth 6 nt");
+        run<M, 1, 8, 1, 4, 1, 38, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 LDS-DMA ring depth 8 nt");
+        run<M, 1, 16, 1, 4, 1, 33, 0, 1, 2, 2>(S, 1, 1, "16w U1 R4 LDS-DMA ring depth 3 nt");
+        run<M, 1, 4, 1, 4, 1, 33, 0, 1, 2, 2>(S, 3, 1, "4w U1 R4 LDS-DMA ring depth 3 nt, 3 per CU");
+        run<M, 1, 8, 1, 4, 1, 34, 0, 1, 0, 2>(S, 2, 1, "8w U1 R4 LDS-DMA ring depth 4 (default policy)");
+        run<M, 1, 8, 1, 1, 1, 34, 0, 0, 2, 2>(S, 2, 1, "8w U1 R1 LDS-DMA ring depth 4 nt");
+        run<M, 1, 8, 1, 4, 1, 34, 2, 1, 2, 0>(S, 2, 1, "8w U1 R4 LDS-DMA ring depth 4 nt: loads + staging only");
+        }
+    }
+    if (sel == 13) {
+        //            M  G  NW U  R MODE RING BARE STG AUX PK
+        for (int rep = 0; rep < 2; ++rep) {
+        build_slots(2, 65536, sl, ro);
+        CHECK(hipMemcpy(S.d_slots, sl.data(), sl.size() * sizeof(PSlot), hipMemcpyHostToDevice));
+        run<M, 2, 8, 1, 2, 1, 1, 0, 2, 2, 0>(S, 2, 1, "pair: 8w U1 R2 ring1 nt (32 KB)");
+        run<M, 2, 8, 1, 4, 1, 1, 0, 2, 2, 0>(S, 2, 1, "pair: 8w U1 R4 ring1 nt (64 KB, no conflicts)");
+        run<M, 2, 8, 1, 4, 1, 1, 0, 2, 2, 2>(S, 2, 1, "pair: 8w U1 R4 ring1 nt, builtins");
+        run<M, 2, 8, 1, 2, 1, 1, 0, 2, 2, 2>(S, 2, 1, "pair: 8w U1 R2 ring1 nt, builtins");
+        build_slots(4, 65536, sl, ro);
+        CHECK(hipMemcpy(S.d_slots, sl.data(), sl.size() * sizeof(PSlot), hipMemcpyHostToDevice));
+        run<M, 4, 8, 1, 1, 1, 1, 0, 2, 2, 0>(S, 2, 1, "four: 8w U1 R1 ring1 nt (32 KB)");
+        run<M, 4, 8, 1, 2, 1, 1, 0, 2, 2, 0>(S, 2, 1, "four: 8w U1 R2 ring1 nt (64 KB)");
+        run<M, 4, 8, 1, 2, 1, 1, 0, 2, 2, 2>(S, 2, 1, "four: 8w U1 R2 ring1 nt, builtins");
+        run<M, 4, 8, 1, 1, 1, 1, 0, 2, 2, 2>(S, 2, 1, "four: 8w U1 R1 ring1 nt, builtins");
+        }
     }
     return 0;
 }
