@@ -177,6 +177,28 @@ class Ctx(object):
     pass
 
 
+def pmc_source(path, d):
+    """Where a replayed PMC summary came from: file, the commit it was copied in at, the kernel symbol, and whether the kernel sources it
+    was measured on are the ones this build was compiled from (sha1 of the csrc files, recorded on the GPU box by the collecting tool)."""
+    out = {"file": os.path.relpath(path, REPO), "commit": d.get("commit"), "kernel": d.get("kernel")}
+    want = d.get("kernel_sources_sha1")
+    if want:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        try:
+            from pmc_stamp import kernel_sources_sha1
+            have = kernel_sources_sha1()
+            changed = sorted(f for f in want if want[f] != have.get(f))
+            out["sources_match_this_build"] = not changed
+            if changed:
+                out["changed_since"] = changed
+        except Exception as e:
+            out["sources_match_this_build"] = None
+            out["error"] = repr(e)
+    else:
+        out["sources_match_this_build"] = None   # a summary from before round 6: no record of the kernel build
+    return out
+
+
 def scan_binding(cfg_name, scan_name, cand, cand_items, M, scan_s, launches):
     """What binds the scan kernel.  `model`: the share of the launch time that each resource's MINIMUM accounts for (conflict-free
     LDS, the bare gather-and-add loop) -- a lower bound per resource.  `measured`: the SQ counters of the same kernel on the same
@@ -221,6 +243,23 @@ def scan_binding(cfg_name, scan_name, cand, cand_items, M, scan_s, launches):
     else:
         out["binds_source"] = "model"
     out["binds"] = max(fracs, key=lambda k: fracs[k] or 0.0)
+    # binding_frac: the launch's MINIMUM time under the resource that binds it / the launch time -- <= 1 by construction, the roofline
+    # fraction of a kernel that no byte count describes.  Minima of the NECESSARY work only: the bare gather-and-add instructions at the
+    # VALU's issue rate (2 cycles per wave64 instruction and SIMD: MI355X_MICROARCH.md, tools/probes/valu_rate.hip), the gathers at the
+    # MEASURED bank-conflict ratio (conflicts are the layout's, not the launch's, to lose), the measured fabric traffic at 8 TB/s.
+    t_valu2 = valu_instr * 2.0 / (4 * n_cu * clk)
+    mins = {"valu_issue": t_valu2, "lds_gather": t_lds, "hbm": t_mem}
+    mm = out["measured"] or {}
+    if mm.get("lds_conflict_ratio") is not None and 0.0 <= float(mm["lds_conflict_ratio"]) < 1.0:
+        mins["lds_gather"] = t_lds / (1.0 - float(mm["lds_conflict_ratio"]))
+    if mm.get("hbm_bytes_per_launch"):
+        mins["hbm"] = float(mm["hbm_bytes_per_launch"]) * launches / (HBM_PEAK_GBS * 1e9)
+    res = max(mins, key=lambda k: mins[k])
+    out["binding_resource"] = res
+    out["binding_min_ms_per_launch"] = {k: v / launches * 1e3 for k, v in mins.items()}
+    out["binding_frac"] = min(1.0, mins[res] / scan_s) if scan_s > 0 else None
+    if out["measured"] and "error" not in out["measured"]:
+        out["pmc_source"] = pmc_source(p, out["measured"])
     return out
 
 
@@ -566,10 +605,13 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
                    "batches_in_flight": P, "index_scaling": scaling, "query_load_scaling": "weak (x%d query groups)" % R if R > 1 else "fixed",
                    "candidates_per_query": cand_all / float(R * NQ * steps_total)},
         "roofline": {"bound": "hbm", "kernel": scan_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "accounting_frac": achieved / HBM_PEAK_GBS,
-                     "frac_note": "SURVEY.md 8(d) accounting (every (candidate, query) pair = M bytes) over the scan kernel's own launch duration "
-                                  "(HIP events on its stream, one batch at a time); > 1 = the accounting is not a physical bound (codes are shared "
-                                  "by the queries of a workgroup and served from L2 / Infinity Cache): see physical_frac, binding, configs.c4x",
+                     "unit": "GB/s", "frac": None, "accounting_frac": achieved / HBM_PEAK_GBS,
+                     "frac_note": "frac = binding_frac: the launch's minimum time under the resource that binds it (LDS gathers at the measured "
+                                  "conflict ratio / VALU issue of the bare gather-and-add loop / measured fabric bytes at 8 TB/s) over its duration, "
+                                  "<= 1 by construction.  accounting_frac = achieved / peak = SURVEY.md 8(d)'s accounting (every (candidate, query) "
+                                  "pair = M bytes) over the kernel's own launch duration (HIP events on its stream, one batch at a time): > 1 = not a "
+                                  "physical bound (codes are shared by the queries of a workgroup and served from L2 / Infinity Cache).  "
+                                  "physical_frac = PMC fabric bytes over the same duration.  The physically HBM-bound regime: configs.c4x",
                      "traffic": traffic, "traffic_note": traffic_note,
                      "physical_frac": (traffic / (iso_launch_ms / 1e3) / 1e9 / HBM_PEAK_GBS) if (traffic and iso_launch_ms > 0) else None,
                      "algorithmic_bytes_per_launch": algo_per_launch,
@@ -590,6 +632,11 @@ def search_leg(ctx, cfg_name, n_vectors, S, steps, warmup, scaling, oracle_rows)
                   "insert": "device-side merge of %d codes into the HBM index (cis_index_add_dev%s)"
                             % (len(my_chunks) * chunk_n, " after the RCCL all-to-all" if ctx.use_dist else "")},
     }
+    rb = result["roofline"]["binding"]
+    result["roofline"]["binding_frac"] = rb.get("binding_frac")
+    result["roofline"]["binding_resource"] = rb.get("binding_resource")
+    result["roofline"]["frac"] = rb.get("binding_frac")
+    result["roofline"]["pmc_source"] = rb.get("pmc_source") or {"file": None, "note": "no PMC summary committed for this configuration"}
     st.exchange_flags = [f for f in (getattr(st, "exchange_flags", None) or []) if f is not None]
     if st.exchange_flags:
         n_over = int(torch.stack([f.reshape(()) for f in st.exchange_flags]).sum().item())
@@ -867,7 +914,8 @@ def c4x_leg(ctx, want_oracle, steps, warmup):
                  "traffic": None,
                  "frac_note": "PHYSICAL: N x M code bytes (each needed once per launch, 1.6 GB >> L2 + Infinity Cache) / the kernel's own duration "
                               "(HIP events around the launch) / 8 TB/s; accounting_frac counts them once per query of the launch"}
-            if pmc and str(nq) in pmc.get("per_nq", {}):
+            if pmc and str(nq) in pmc.get("per_nq", {}) and "hbm_bytes_per_launch" in pmc["per_nq"][str(nq)]:
+                r["pmc_source"] = pmc_source(tp, dict(pmc, kernel=pmc["per_nq"][str(nq)].get("kernel")))
                 r["traffic"] = pmc["per_nq"][str(nq)]["hbm_bytes_per_launch"]
                 r["traffic_frac"] = r["traffic"] / (k_ms / 1e3) / 1e9 / HBM_PEAK_GBS
                 r["traffic_note"] = "profiles/scan_traffic_c4x.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel in their own passes (gfx950 correction applied)"
@@ -1205,7 +1253,9 @@ def _roof_c(r):
     if not isinstance(r, dict):
         return None
     out = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "physical_frac", "traffic_frac", "accounting_frac",
-                "pipeline_accounting_frac", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch")
+                "binding_frac", "binding_resource", "pipeline_accounting_frac", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch")
+    if isinstance(r.get("pmc_source"), dict):
+        out["pmc_source"] = _pick(r["pmc_source"], "file", "commit", "kernel", "sources_match_this_build")
     out.setdefault("traffic", None)
     b = r.get("binding") or {}
     m = b.get("measured") or {}

@@ -5,7 +5,9 @@ passes (FETCH_SIZE, WRITE_SIZE, the SQ set): the MEDIAN over the kernel's dispat
 whatever the number of repetitions the run made (round 4 divided totals by a hand-counted number of "full-launch equivalents").
 usage: pmc_scan.py <tag> <config> <serial bench line json>   (reads gpurun_out/<tag>_<config>_{FETCH_SIZE,WRITE_SIZE,sq}_raw.csv)
 writes gpurun_out/scan_traffic_<config>.json and gpurun_out/scan_binding_<config>.json (copy to profiles/: bench.py reads them)."""
-import csv, json, statistics, sys
+import csv, json, os, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_stamp import kernel_sources_sha1
 tag, cfg, line_path = sys.argv[1], sys.argv[2], sys.argv[3]
 CLK, SIMDS, CUS = 2.4e9, 1024, 256
 
@@ -39,6 +41,7 @@ traffic = {"kernel": kern, "config": cfg, "dispatches_in_pass": nf.get("FETCH_SI
                          "estimate); WRITE_SIZE as reported",
            "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "write_bytes_per_launch": wk * 1024.0,
            "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"]}
+traffic["kernel_sources_sha1"] = kernel_sources_sha1()
 json.dump(traffic, open("gpurun_out/scan_traffic_%s.json" % cfg, "w"), indent=1)
 cyc = ms * 1e-3 * CLK
 b = {"config": cfg, "kernel": kern, "avg_launch_ms": ms, "dispatches_in_pass": nsq.get("SQ_INSTS_VALU"),
@@ -52,6 +55,7 @@ if sq.get("SQ_LDS_IDX_ACTIVE"):
     b["lds_conflict_ratio"] = sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / sq["SQ_LDS_IDX_ACTIVE"]
 b["hbm_bytes_per_launch"] = traffic["hbm_bytes_per_launch"]
 b["hbm_frac"] = traffic["hbm_bytes_per_launch"] / (ms * 1e-3) / 8.0e12
+b["kernel_sources_sha1"] = kernel_sources_sha1()
 json.dump(b, open("gpurun_out/scan_binding_%s.json" % cfg, "w"), indent=1)
 print(json.dumps({"traffic_MB": traffic["hbm_bytes_per_launch"] / 1e6, "valu_busy": b.get("valu_busy_frac"), "lds_busy": b.get("lds_busy_frac"),
                   "conflicts": b.get("lds_conflict_ratio"), "valu_insts": sq.get("SQ_INSTS_VALU"), "launch_ms": ms, "kernel": kern}))
