@@ -6015,20 +6015,24 @@ extern "C" int cis_index_search_async(cis_index* ix, const void* Q, int q_dtype,
         CIS_CHECK_HIP(hipMemcpyAsync(ix->w_q.p, Q, qbytes, hipMemcpyHostToDevice, cp));
         CIS_CHECK_HIP(hipEventRecord(ix->h_ev_in, cp));
     }
-    ix->h_pending = true;
+    // h_pending is set LAST, with this batch's h_out in place: an error exit in between must not leave the flag set over the previous
+    // call's h_out (whose host buffers may be gone) -- cis_index_search_wait / cis_index_destroy would copy results into them.  Every
+    // error exit below drains the stream (the copy-in may still be reading Q) and leaves the handle idle.
+    struct Guard {
+        cis_index* ix; hipStream_t st; bool armed;
+        ~Guard() { if (armed) { (void)hipStreamSynchronize(st); ix->h_pending = false; ix->h_out = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}; } }
+    } guard{ix, st, true};
     CIS_CHECK_HIP(hipStreamWaitEvent(st, ix->h_ev_in, 0));
     int rc = cis_index_search_dev(ix, ix->w_q.p, q_dtype, nq, quota, limit, ix->w_oids.as<int64_t>(),
                                   ix->w_odists.as<double>(), ix->w_onf.as<int32_t>(), ix->w_ovis.as<int32_t>(),
                                   ix->w_ocell.as<int32_t>(), ix->w_opos.as<uint32_t>(), st);
-    if (rc != CIS_OK) {
-        (void)hipStreamSynchronize(st);
-        ix->h_pending = false;
-        return rc;
-    }
+    if (rc != CIS_OK) return rc;
     CIS_CHECK_HIP(hipEventRecord(ix->h_ev_out, st));
     // the copy-out is enqueued by cis_index_search_wait, once the search has finished: enqueued here it would sit at the head of the
     // shared copy stream, waiting for the search, with every later copy-in of the other handles stuck behind it
     ix->h_out = {ids, dists, n_found, visited, cells, pos, nq, L};
+    ix->h_pending = true;
+    guard.armed = false;
     return CIS_OK;
 }
 

@@ -276,44 +276,46 @@ class ShardedSearcher(object):
         dev = coarse.device
         stream = torch.cuda.current_stream(dev).cuda_stream
         self._insert_fence()  # the partial searches begun before this call read the arrays the insert rewrites
-        rec_b = 12 + M
-        send = torch.empty(max(n, 1) * rec_b, dtype=torch.uint8, device=dev)
-        sc = torch.empty(self.world, dtype=torch.int64, device=dev)
-        _lib.check(L.cis_index_route_pack_dev(ix, ids.data_ptr(), coarse.data_ptr(), fine.data_ptr(), n, send.data_ptr(),
-                                              sc.data_ptr(), stream))
-        staged = dist.get_backend(self.group) != "nccl"  # gloo has no all-to-all on device buffers: stage the collectives
-        rc = torch.empty_like(sc)
-        if staged:
-            sc_h = sc.cpu()
-            rc_h = torch.empty_like(sc_h)
-            dist.all_to_all_single(rc_h, sc_h, group=self.group)
-        else:
-            dist.all_to_all_single(rc, sc, group=self.group)
-            sc_h, rc_h = sc.cpu(), rc.cpu()
-        in_split = [int(c) * rec_b for c in sc_h.tolist()]
-        out_split = [int(c) * rec_b for c in rc_h.tolist()]
-        n_recv = sum(out_split) // rec_b
-        recv = torch.empty(max(n_recv, 1) * rec_b, dtype=torch.uint8, device=dev)
-        if staged:
-            recv_h = torch.empty(n_recv * rec_b, dtype=torch.uint8)
-            dist.all_to_all_single(recv_h, send[:n * rec_b].cpu(), output_split_sizes=out_split, input_split_sizes=in_split,
-                                   group=self.group)
-            recv[:n_recv * rec_b].copy_(recv_h)
-        else:
-            dist.all_to_all_single(recv[:n_recv * rec_b], send[:n * rec_b], output_split_sizes=out_split,
-                                   input_split_sizes=in_split, group=self.group)
-        delta = torch.empty(V * V, dtype=torch.int64, device=dev)
-        added, bad = _lib.c_int64(0), _lib.c_int64(0)
-        _lib.check(L.cis_index_add_records_dev(ix, recv.data_ptr(), n_recv, 1 if dedup else 0, _lib.ctypes.byref(added),
-                                               _lib.ctypes.byref(bad), delta.data_ptr(), stream))
-        if staged:
-            d_h = delta.cpu()
-            dist.all_reduce(d_h, group=self.group)
-            delta.copy_(d_h)
-        else:
-            dist.all_reduce(delta, group=self.group)
-        _lib.check(L.cis_index_add_remote_counts_dev(ix, delta.data_ptr(), stream))
-        self._insert_release()
+        try:   # (an exception from _lib.check or a collective must not leave later lane-stream searches unordered against a partly enqueued insert)
+            rec_b = 12 + M
+            send = torch.empty(max(n, 1) * rec_b, dtype=torch.uint8, device=dev)
+            sc = torch.empty(self.world, dtype=torch.int64, device=dev)
+            _lib.check(L.cis_index_route_pack_dev(ix, ids.data_ptr(), coarse.data_ptr(), fine.data_ptr(), n, send.data_ptr(),
+                                                  sc.data_ptr(), stream))
+            staged = dist.get_backend(self.group) != "nccl"  # gloo has no all-to-all on device buffers: stage the collectives
+            rc = torch.empty_like(sc)
+            if staged:
+                sc_h = sc.cpu()
+                rc_h = torch.empty_like(sc_h)
+                dist.all_to_all_single(rc_h, sc_h, group=self.group)
+            else:
+                dist.all_to_all_single(rc, sc, group=self.group)
+                sc_h, rc_h = sc.cpu(), rc.cpu()
+            in_split = [int(c) * rec_b for c in sc_h.tolist()]
+            out_split = [int(c) * rec_b for c in rc_h.tolist()]
+            n_recv = sum(out_split) // rec_b
+            recv = torch.empty(max(n_recv, 1) * rec_b, dtype=torch.uint8, device=dev)
+            if staged:
+                recv_h = torch.empty(n_recv * rec_b, dtype=torch.uint8)
+                dist.all_to_all_single(recv_h, send[:n * rec_b].cpu(), output_split_sizes=out_split, input_split_sizes=in_split,
+                                       group=self.group)
+                recv[:n_recv * rec_b].copy_(recv_h)
+            else:
+                dist.all_to_all_single(recv[:n_recv * rec_b], send[:n * rec_b], output_split_sizes=out_split,
+                                       input_split_sizes=in_split, group=self.group)
+            delta = torch.empty(V * V, dtype=torch.int64, device=dev)
+            added, bad = _lib.c_int64(0), _lib.c_int64(0)
+            _lib.check(L.cis_index_add_records_dev(ix, recv.data_ptr(), n_recv, 1 if dedup else 0, _lib.ctypes.byref(added),
+                                                   _lib.ctypes.byref(bad), delta.data_ptr(), stream))
+            if staged:
+                d_h = delta.cpu()
+                dist.all_reduce(d_h, group=self.group)
+                delta.copy_(d_h)
+            else:
+                dist.all_reduce(delta, group=self.group)
+            _lib.check(L.cis_index_add_remote_counts_dev(ix, delta.data_ptr(), stream))
+        finally:
+            self._insert_release()
         self.local.nb_indexed = int(L.cis_index_size(ix))
         if bad.value:
             print("Could not push {} codes (out of range for this model, or negative ids).".format(bad.value))

@@ -93,8 +93,8 @@ class BatchIngest(object):
         """Ingest a sequence of preprocessed batches with the CNN forwards of the NEXT batches in flight while the current one is
         encoded and inserted (round 5): `lanes` handles on the same weights (net.view()), each on its own stream, run forward +
         normalisation; encode and insert follow on the caller's stream in batch order, so ids, insertion order and dedup are those
-        of calling ingest_batch batch by batch.  batches: an iterable of GPU tensors (they must stay valid until their batch was
-        inserted); ids: None or an iterable of per-batch id tensors / arrays.  Returns the list of per-batch new-item counts."""
+        of calling ingest_batch batch by batch.  batches: an iterable of GPU tensors (each is kept alive, and its block recorded on the lane stream, until its
+        forward has been waited for: a generator may drop them); ids: None or an iterable of per-batch id tensors / arrays.  Returns the list of per-batch new-item counts."""
         import torch
         from collections import deque
         cur = torch.cuda.current_stream()
@@ -109,7 +109,7 @@ class BatchIngest(object):
         out, queue = [], deque()
 
         def finish():
-            feats, ev, bid = queue.popleft()
+            feats, ev, bid, _x = queue.popleft()   # (_x: the input batch, kept alive until its forward has been waited for)
             cur.wait_event(ev)
             feats.record_stream(cur)
             if self.feat_dtype is not None and feats.dtype != self.feat_dtype:
@@ -123,7 +123,11 @@ class BatchIngest(object):
                 feats = net.forward_dev(x)
                 ev = torch.cuda.Event()
                 ev.record(stream)
-            queue.append((feats, ev, next(ids_it) if ids_it is not None else None))
+            # the lane stream reads x: the caching allocator must not hand its block to the caller's stream before that read is done
+            # (a generator that drops x_i after yielding it would otherwise have x_{i+1} written over it)
+            if hasattr(x, "record_stream"):
+                x.record_stream(stream)
+            queue.append((feats, ev, next(ids_it) if ids_it is not None else None, x))
             if len(queue) >= lanes:
                 finish()
         while queue:

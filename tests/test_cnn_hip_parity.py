@@ -515,3 +515,24 @@ def test_views_share_the_weights_and_overlap_batches(kind):
     assert rc != 0 and "base was destroyed" in _lib.last_error()
     for v in views:
         v.close()
+
+
+@pytest.mark.parametrize("arch", ["sentibank", "dlib"])
+def test_feature_bits_are_pinned(arch):
+    """The float32 summation ORDER of a forward is part of what an index is built with: a descriptor near a quantiser boundary encodes
+    differently when the order changes (round 5 changed the fc layers' K split from 4 to 8: features of rounds 1-4 and of round 5 differ
+    in their last bits, INTEGRATION.md "feature kernel versions").  The sha1 of the descriptors of a seeded network on a seeded batch is
+    pinned in tests/golden/cnn_feature_pins.json (made on an MI355X by this test's own code: tests/golden/make_cnn_feature_pins.py),
+    so that the next order change is a deliberate one: regenerate the pins AND bump FEATURE_KERNEL_VERSION."""
+    import hashlib
+    import json
+    from columbiaimagesearch_amd import featurizer as F
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    pins = json.load(open(os.path.join(sys_path, "cnn_feature_pins.json")))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_cnn_feature_pins", os.path.join(sys_path, "make_cnn_feature_pins.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    got = mk.feature_sha1(arch)
+    assert pins["feature_kernel_version"] == F.FEATURE_KERNEL_VERSION
+    assert got == pins[arch], "the %s descriptors changed bits (%s, pinned %s): regenerate the pins and bump FEATURE_KERNEL_VERSION" % (arch, got, pins[arch])
