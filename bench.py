@@ -1267,7 +1267,94 @@ def _roof_c(r):
     return out
 
 
-def routed_leg(ctx, st, steps, warmup):
+XGMI_LINK_GBS = 153.0   # one xGMI link of an MI355X (MI355X_MICROARCH.md / the task statement: 7 links x ~153 GB/s per GPU, point to point)
+COLLECTIVE_LATENCY_US = 15.0   # what a small RCCL collective costs whatever its size (assumed until a node measures it: `collectives.measured`)
+
+
+def exchange_model(world, nq_total, nq_home, L, row_bytes):
+    """Bytes the two protocols move per step and rank, and what they should cost on xGMI: every peer has its own link, so a collective
+    costs (the largest per-peer share) / 153 GB/s + a fixed latency.  The sizes are those of columbiaimagesearch_amd/distributed.py:
+      all-gather protocol  counts [nq] int32 + a FIXED exchange_stride(nq, L, world) x 32-byte records per rank, gathered by every rank;
+      routed protocol      row counts [world] int32, the fixed query blocks [world, cap, row] (cap = route_capacity), an overflow word
+                           (all-reduce), the ranked lists back (~1.3 owners per query x L x 32 bytes, by the rows actually sent)."""
+    from columbiaimagesearch_amd.distributed import exchange_stride, route_capacity
+    link = XGMI_LINK_GBS * 1e9
+    stride = exchange_stride(nq_total, L, world)
+    ag = {"counts_bytes_per_rank": nq_total * 4, "payload_bytes_per_rank": stride * 32,
+          "received_bytes_per_rank": (world - 1) * (stride * 32 + nq_total * 4)}
+    ag["projected_us"] = 2 * COLLECTIVE_LATENCY_US + (ag["counts_bytes_per_rank"] + ag["payload_bytes_per_rank"]) / link * 1e6
+    cap = route_capacity(nq_home, row_bytes // 4, world)
+    hits_back = int(1.3 * nq_home * L * 32)
+    rt = {"query_block_bytes_per_peer": cap * row_bytes, "query_bytes_sent_per_rank": (world - 1) * cap * row_bytes,
+          "hits_back_bytes_per_rank": hits_back, "hits_back_bytes_per_peer": hits_back // max(world, 1), "small_collectives": 2}
+    rt["projected_us"] = 4 * COLLECTIVE_LATENCY_US + (rt["query_block_bytes_per_peer"] + rt["hits_back_bytes_per_peer"]) / link * 1e6
+    return {"link_GBs": XGMI_LINK_GBS, "assumed_latency_us_per_collective": COLLECTIVE_LATENCY_US,
+            "allgather": dict(ag, exchange_bytes_per_step=ag["counts_bytes_per_rank"] + ag["payload_bytes_per_rank"]),
+            "routed": dict(rt, exchange_bytes_per_step=rt["query_bytes_sent_per_rank"] + rt["hits_back_bytes_per_rank"] + 8 * world)}
+
+
+def collectives_leg(ctx, L=None, row_bytes=1024):
+    """Bare collectives of the protocols' REAL payload sizes, before anything else touches the GPUs: a slow or hanging collective is
+    named here (every one runs in its own watchdog phase) instead of inside a search step.  Every rank; returns rank 0's view."""
+    import torch.distributed as dist
+    from columbiaimagesearch_amd.distributed import exchange_stride, route_capacity
+    device, rank, world, wd = ctx.device, ctx.rank, ctx.world, ctx.wd
+    L = LIMIT if L is None else L
+    dev = device if ctx.backend == "nccl" else "cpu"
+    out = {"backend": ctx.backend, "world": world, "sizes": {}}
+
+    def timed(key, name, fn, bytes_per_peer):
+        with wd.phase("collectives-only: %s" % name, 120):
+            for _ in range(3):
+                fn()
+            if dev != "cpu":
+                torch.cuda.synchronize()
+            ts = []
+            for _ in range(20):
+                dist.barrier()
+                if dev != "cpu":
+                    torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                if dev != "cpu":
+                    torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            tt = torch.tensor([sorted(ts)[len(ts) // 2]], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            us = float(tt.item()) * 1e6
+        out["sizes"][key] = {"what": name, "bytes_per_peer": int(bytes_per_peer), "median_us_max_over_ranks": us,
+                              "GBs_per_link": (bytes_per_peer / (us * 1e-6) / 1e9) if us > 0 else None,
+                              "projected_us": COLLECTIVE_LATENCY_US + bytes_per_peer / (XGMI_LINK_GBS * 1e9) * 1e6}
+
+    for label, nq_total, nq_home in (("strong", NQ, max(NQ // world, 1)), ("weak", NQ * world, NQ)):
+        stride = exchange_stride(nq_total if label == "strong" else NQ, L, world)
+        if label == "strong":
+            cnt = torch.zeros(NQ, dtype=torch.int32, device=dev)
+            cnt_all = torch.empty(world * NQ, dtype=torch.int32, device=dev)
+            timed("ag_counts", "all_gather counts [%d] int32" % NQ, lambda: dist.all_gather_into_tensor(cnt_all, cnt), NQ * 4)
+            pay = torch.zeros(stride * 32, dtype=torch.uint8, device=dev)
+            pay_all = torch.empty(world * stride * 32, dtype=torch.uint8, device=dev)
+            timed("ag_payload", "all_gather payload %d x 32 B (all-gather protocol, %d queries per step)" % (stride, NQ),
+                  lambda: dist.all_gather_into_tensor(pay_all, pay), stride * 32)
+            small = torch.zeros(world, dtype=torch.int32, device=dev)
+            small_o = torch.empty_like(small)
+            timed("a2a_counts", "all_to_all row counts [%d] int32" % world, lambda: dist.all_to_all_single(small_o, small), 4)
+            one = torch.zeros(1, dtype=torch.int32, device=dev)
+            timed("allreduce_word", "all_reduce overflow word", lambda: dist.all_reduce(one, op=dist.ReduceOp.MAX), 4)
+        cap = route_capacity(nq_home, row_bytes // 4, world)
+        sq = torch.zeros(world * cap * row_bytes, dtype=torch.uint8, device=dev)
+        rq = torch.empty_like(sq)
+        timed("a2a_queries_" + label, "all_to_all query blocks [%d, %d, %d B] (routed, %s: %d home queries per rank)" % (world, cap, row_bytes, label, nq_home),
+              lambda: dist.all_to_all_single(rq, sq), cap * row_bytes)
+        per_peer = int(1.3 * nq_home * L * 32) // world // 32 * 32
+        sh = torch.zeros(world * per_peer, dtype=torch.uint8, device=dev)
+        rh = torch.empty_like(sh)
+        timed("a2a_lists_" + label, "all_to_all ranked lists back %d B per peer (routed, %s)" % (per_peer, label), lambda: dist.all_to_all_single(rh, sh), per_peer)
+        del sq, rq, sh, rh
+    return out
+
+
+def routed_leg(ctx, st, steps, warmup, strong=False):
     """N > 1, cells only (S = N): the ROUTED protocol (columbiaimagesearch_amd/distributed.py: RoutedSearcher) on the index of the headline
     leg.  A step = one batch of world x NQ queries over the job: every rank is the HOME of NQ of them (its own batch), finds the owners
     of the cells they visit, sends each query to those owners only (one all-to-all), answers what it receives and merges its home
@@ -1296,13 +1383,17 @@ def routed_leg(ctx, st, steps, warmup):
         same = same and bool(torch.equal(dr[~torch.isnan(dr)], dg[~torch.isnan(dg)]))
         same = agree(same)
 
-    def home(b):  # this rank's home batch of step b
-        return qbs[(b * world + rank) % len(qbs)]
+    nq_job = NQ if strong else NQ * world   # queries per step over the job
+    lo_s, hi_s = home_slice(NQ, rank, world)
+    strong_slices = [qb[lo_s:hi_s].contiguous() for qb in qbs] if strong else None
+
+    def home(b):  # this rank's home batch of step b: weak = a whole batch of its own, strong = its slice of the job's ONE batch of NQ
+        return strong_slices[b % len(qbs)] if strong else qbs[(b * world + rank) % len(qbs)]
 
     def run(first, n):
-        h = rt.search_begin(home(first), quota=QUOTA, limit=LIMIT, nq_total=NQ * world)
+        h = rt.search_begin(home(first), quota=QUOTA, limit=LIMIT, nq_total=nq_job)
         for b in range(1, n):
-            h2 = rt.search_begin(home(first + b), quota=QUOTA, limit=LIMIT, nq_total=NQ * world)
+            h2 = rt.search_begin(home(first + b), quota=QUOTA, limit=LIMIT, nq_total=nq_job)
             rt.search_end(h)
             h = h2
         rt.search_end(h)
@@ -1330,16 +1421,16 @@ def routed_leg(ctx, st, steps, warmup):
                 break
     med = sorted(walls)[len(walls) // 2]
     return {"metric": "queries/sec @ recall@10 on 10M LOPQ index",
-            "value": world * NQ * steps / med, "unit": "queries/s", "ms_per_step": med / steps * 1e3, "scaling": "weak",
+            "value": nq_job * steps / med, "unit": "queries/s", "ms_per_step": med / steps * 1e3, "scaling": "strong" if strong else "weak",
             "equals_allgather_protocol": same, "fallbacks_in_timed_region": rt.fallbacks - fb0,
             "timing": {"repetitions": reps, "steps_per_repetition": steps, "timed_s": round(sum(walls), 4),
                        "ms_per_step": {"median": med / steps * 1e3, "min": min(walls) / steps * 1e3, "max": max(walls) / steps * 1e3}},
-            "config": {"name": st.cfg_name, "index_vectors": st.N, "queries_per_step": world * NQ, "home_queries_per_gpu_and_step": NQ,
+            "config": {"name": st.cfg_name, "index_vectors": st.N, "queries_per_step": nq_job, "home_queries_per_gpu_and_step": nq_job // world,
                        "quota": QUOTA, "limit": LIMIT, "query_groups": 1, "cell_shards": world, "parallelism": "cells 1x%d, routed" % world,
                        "batches_in_flight": 2,
                        "workload": "ONE copy of the %d-vector index sharded by coarse cell over %d GPUs; a step = %d queries over the job, every GPU "
                                    "the home of %d: owners of the visited cells found at home, ONE all-to-all carries a query to those owners only, "
-                                   "ranked lists return (all-to-all) and are merged at home (distributed.RoutedSearcher)" % (st.N, world, world * NQ, NQ)}}
+                                   "ranked lists return (all-to-all) and are merged at home (distributed.RoutedSearcher)" % (st.N, world, nq_job, nq_job // world)}}
 
 
 def compact_line(line):
@@ -1387,6 +1478,15 @@ def compact_line(line):
     if line.get("allgather"):
         a = line["allgather"]
         c["allgather"] = {"value": a["value"], "ms_per_step": a["ms_per_step"], "scaling": a["scaling"], "queries_per_step": a["config"]["queries_per_step"]}
+    if line.get("strong"):
+        c["strong"] = line["strong"]
+    if line.get("exchange"):
+        e = line["exchange"]
+        c["exchange"] = {"link_GBs": e["link_GBs"], "bytes_per_step": line.get("exchange_bytes_per_step"),
+                         "projected_us": {"allgather": round(e["allgather"]["projected_us"], 1), "routed_strong": round(e["routed"]["projected_us"], 1),
+                                          "routed_weak": round(e["weak_routed"]["projected_us"], 1)}}
+    if isinstance(line.get("collectives"), dict) and line["collectives"].get("sizes"):
+        c["collectives_us"] = {k: round(v["median_us_max_over_ranks"], 1) for k, v in line["collectives"]["sizes"].items()}
     if line.get("routed"):
         r = line["routed"]
         c["routed"] = {"error": r["error"][:160]} if "error" in r else _pick(r, "equals_allgather_protocol", "fallbacks_in_timed_region", "value", "ms_per_step")
@@ -1468,6 +1568,9 @@ def main():
                     help="S of the second (`grid`) layout at N > 1: R = gpus / S query groups, each one copy of the index sharded by "
                          "cell over S GPUs.  Default: 2 from 4 GPUs on, 1 (whole copies) at 2.  The headline is always S = gpus")
     ap.add_argument("--no-grid", action="store_true", help="N > 1: skip the second layout")
+    ap.add_argument("--collectives-only", action="store_true",
+                    help="N > 1: time the bare RCCL collectives of the protocols' payload sizes (all-gather counts / payload, all-to-all query blocks / "
+                         "ranked lists, the small ones), print them and stop -- the first thing to run on a new node")
     ap.add_argument("--no-routed", action="store_true", help="N > 1: skip the routed protocol (the headline is then the all-gather protocol at 8192 queries per step)")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("CIS_BENCH_PIPELINE", 3)),
                     help="N = 1: query batches in flight at once (each through its own view of the index on its own stream); 1 = one after the other")
@@ -1513,6 +1616,23 @@ def main():
             else:
                 dist.init_process_group(backend, device_id=device if backend == "nccl" else None, **kw)  # nccl == RCCL on ROCm
 
+    collectives = None
+    if ctx.use_dist and (world > 1 or args.collectives_only):
+        try:
+            collectives = collectives_leg(ctx)
+        except Exception as e:
+            collectives = {"error": repr(e)}
+            sys.stderr.write("[bench rank %d] collectives leg failed: %r\n" % (rank, e))
+        if rank == 0:
+            sys.stderr.write("[bench] collectives (median us, max over ranks): %s\n" % json.dumps(collectives))
+    if args.collectives_only:
+        if rank == 0:
+            line = {"metric": "bare collectives of the search protocols' payloads", "value": None, "unit": "us", "n_gpus": world, "steps": 20, "warmup": 3,
+                    "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                    "config": {"workload": "collectives only: the all-gather and all-to-all payload sizes of an %d-query step at limit %d" % (NQ, LIMIT)},
+                    "collectives": collectives, "exchange": exchange_model(world, NQ, max(NQ // world, 1), LIMIT, 1024) if world > 1 else None}
+            emit_lines(line, line, args.detail_file)
+        return
     ctx.c4x_oracle_exhaustive = bool(args.c4x_oracle)
     solo = rank == 0 and world == 1
     want_oracle = solo and not args.no_cpu_baseline
@@ -1530,13 +1650,18 @@ def main():
     # ---- headline: BASELINE C4's layout -- ONE copy of the index sharded by coarse cell over all N GPUs ---------------------------
     head, st = search_leg(ctx, cfg_name, args.n, world, args.steps, args.warmup, args.scaling, 4096 if want_oracle else 0)
 
-    routed = None
+    routed = routed_strong = None
     if world > 1 and st.sharded is not None and st.sharded.row is not None and not args.no_routed:
         try:
             routed = routed_leg(ctx, st, args.steps, args.warmup)
         except Exception as e:  # the all-gather headline stands on its own
             routed = {"error": repr(e)}
             sys.stderr.write("[bench rank %d] routed leg failed: %r\n" % (rank, e))
+        try:   # the SAME job as N = 1 (8192 queries per step over all GPUs) through the routed protocol: like with like
+            routed_strong = routed_leg(ctx, st, args.steps, args.warmup, strong=True)
+        except Exception as e:
+            routed_strong = {"error": repr(e)}
+            sys.stderr.write("[bench rank %d] routed leg (strong) failed: %r\n" % (rank, e))
     pcie = pcie_leg(st, head["value"]) if solo and not args.no_pcie else None
     cpu = parity = None
     if want_oracle:
@@ -1660,6 +1785,24 @@ def main():
                 line["roofline"] = dict(line["roofline"], note="k_adc_scan launches of the all-gather leg on the same index (the routed leg runs the same kernels on the queries a rank receives)")
             else:
                 line["routed"] = routed
+        if world > 1:
+            # The SAME job as N = 1 -- 8192 queries per step over all GPUs -- next to the weak headline: N = 1 -> N compares like with like.
+            strong = {"queries_per_step": NQ,
+                      "allgather": {"value": head["value"], "ms_per_step": head["ms_per_step"]}}
+            if routed_strong is not None:
+                strong["routed"] = ({"error": routed_strong["error"][:160]} if "error" in routed_strong else
+                                    {"value": routed_strong["value"], "ms_per_step": routed_strong["ms_per_step"],
+                                     "fallbacks_in_timed_region": routed_strong["fallbacks_in_timed_region"],
+                                     "equals_allgather_protocol": routed_strong["equals_allgather_protocol"]})
+            line["strong"] = strong
+            row_bytes = int(cfg["d_in"]) * (4 if cfg["gen"] == "relu_mixture" else 8)
+            ex = exchange_model(world, NQ, max(NQ // world, 1), LIMIT, row_bytes)
+            ex["weak_routed"] = exchange_model(world, NQ * world, NQ, LIMIT, row_bytes)["routed"]
+            line["exchange"] = ex
+            line["exchange_bytes_per_step"] = {"allgather": ex["allgather"]["exchange_bytes_per_step"], "routed_strong": ex["routed"]["exchange_bytes_per_step"],
+                                               "routed_weak": ex["weak_routed"]["exchange_bytes_per_step"], "per": "rank and step (sent)"}
+        if collectives is not None:
+            line["collectives"] = collectives
     if ctx.use_dist:
         import torch.distributed as dist
         with wd.phase("final barrier", 120):

@@ -190,11 +190,36 @@ def test_sampled_scan_at_m16_with_its_saturating_scale(monkeypatch):
     P = B.mixture_centers("relu_mixture", dev)
     n, chunk_n = 1_000_000, 100_000
     s = LOPQSearcherHIP(model)
+    coarse_h, fine_h = [], []
     for c in range(n // chunk_n):
         a, b = model.predict_batch_dev(B.gen_chunk(P, c, chunk_n, dev))
         s.add_codes_dev(a, b, torch.arange(c * chunk_n, (c + 1) * chunk_n, dtype=torch.int64, device=dev), dedup=False)
+        coarse_h.append(a.cpu().numpy().view(np.uint16))
+        fine_h.append(b.cpu().numpy())
     x0 = B.gen_chunk(P, 0, chunk_n, dev)
     try:
+        # The ORACLE at this size (round-5 review: pytest compared C3 at 1M with the float64 kernel only): 1024 rows of the build
+        # through the oracle's encoder, 64 queries of the automatic route (k_adc_scan4) through the oracle's search over the same
+        # 1M codes brought to the host -- codes and ranked ids bit-exact, distances to 1e-9.
+        from oracle import lopq_oracle as O
+        om = O.OracleModel.from_npz(z)
+        coarse_all, fine_all = np.concatenate(coarse_h), np.concatenate(fine_h)
+        rows = np.arange(0, chunk_n, chunk_n // 1024)[:1024]
+        oc, of = O.compute_codes(om, x0[torch.as_tensor(rows, device=dev)].cpu().numpy())
+        np.testing.assert_array_equal(oc, coarse_all[rows])
+        np.testing.assert_array_equal(of, fine_all[rows])
+        oix = O.OracleCSRIndex(om, coarse_all, fine_all)
+        q64 = B.make_queries(x0, 2, 4096, dev)
+        got = _np(s.search_batch_dev(q64, quota=QUOTA, limit=LIMIT))
+        assert s.last_stats()["scan_kernel"] == "k_adc_scan4"
+        qh = q64[:64].cpu().numpy()
+        for qi in range(64):
+            ids, dd, vis = oix.search(qh[qi], quota=QUOTA, limit=LIMIT)
+            k = len(ids)
+            assert int(got["n_found"][qi]) == k and int(got["visited"][qi]) == vis
+            np.testing.assert_array_equal(got["ids"][qi, :k], ids)
+            np.testing.assert_allclose(got["dists"][qi, :k], dd, rtol=1e-9, atol=1e-12)
+        del oix, coarse_all, fine_all
         for b, limit in ((0, LIMIT), (1, 37)):
             q = B.make_queries(x0, b, 4096, dev)
             s.set_scan_mode(mode=1)
@@ -398,10 +423,39 @@ def test_bench_multi_rank_protocol_on_one_gpu(gpus, shards, grid_groups):
     assert a["scaling"] == "strong" and a["config"]["cell_shards"] == gpus and a["config"]["queries_per_step"] == 8192 and a["recall_at_10"] >= 0.9
     assert abs(a["value"] - 8192 * 3 / (a["ms_per_step"] * 3e-3)) <= 1e-6 * a["value"]
     assert abs(compact["allgather"]["value"] - a["value"]) <= 1e-4 * a["value"] and compact["routed"]["equals_allgather_protocol"] is True
+    # the SAME job as N = 1 (8192 queries per step over the job) through both protocols, the bytes they exchange with what those should
+    # cost on xGMI, and the bare collectives of exactly those payloads measured before anything else (round-5 review, item 5)
+    st_ = line["strong"]
+    assert st_["queries_per_step"] == 8192 and abs(st_["allgather"]["value"] - a["value"]) <= 1e-6 * a["value"]
+    assert st_["routed"]["equals_allgather_protocol"] is True and st_["routed"]["fallbacks_in_timed_region"] == 0 and st_["routed"]["value"] > 0
+    assert abs(compact["strong"]["routed"]["value"] - st_["routed"]["value"]) <= 1e-4 * st_["routed"]["value"]
+    eb = line["exchange_bytes_per_step"]
+    assert eb["allgather"] > 0 and eb["routed_weak"] > eb["routed_strong"] > 0 and compact["exchange"]["projected_us"]["allgather"] > 0
+    cs = line["collectives"]["sizes"]
+    assert set(cs) == {"ag_counts", "ag_payload", "a2a_counts", "allreduce_word", "a2a_queries_strong", "a2a_lists_strong", "a2a_queries_weak", "a2a_lists_weak"}
+    assert all(v["median_us_max_over_ranks"] > 0 for v in cs.values()) and set(compact["collectives_us"]) == set(cs)
     g = line["grid"]
     assert "error" not in g, g
     assert g["config"]["query_groups"] == grid_groups and g["config"]["cell_shards"] == gpus // grid_groups and g["recall_at_10"] >= 0.9
     assert abs(g["value"] - grid_groups * g["config"]["queries_per_step"] * 3 / (g["ms_per_step"] * 3e-3)) <= 1e-6 * g["value"]
+
+
+def test_bench_collectives_only_two_ranks():
+    """`bench.py --gpus 2 --collectives-only`: the bare collectives of the protocols' payload sizes, each in its own watchdog phase, one JSON
+    line, nothing else run -- the first command for a new multi-GPU node (gloo on one device here)."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CIS_BENCH_BACKEND="gloo", CIS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29591", os.path.join(repo, "bench.py"), "--gpus", "2", "--collectives-only"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=repo)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-3000:]
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, text[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and len(line["collectives"]["sizes"]) == 8 and line["exchange"]["allgather"]["payload_bytes_per_rank"] > 0
+    assert "k_adc_scan" not in text and "recall" not in line
 
 
 def test_fork_before_first_use():
