@@ -202,7 +202,7 @@ def pmc_source(path, d):
 def scan_binding(cfg_name, scan_name, cand, cand_items, M, scan_s, launches):
     """What binds the scan kernel.  `model`: the share of the launch time that each resource's MINIMUM accounts for (conflict-free
     LDS, the bare gather-and-add loop) -- a lower bound per resource.  `measured`: the SQ counters of the same kernel on the same
-    workload from this round's rocprofv3 --pmc passes (profiles/scan_binding_<config>.json, made by tools/scan_binding.py: VALU
+    workload from this round's rocprofv3 --pmc passes (profiles/scan_binding_<config>.json, made by tools/pmc_scan.py: VALU
     busy, LDS busy incl. bank conflicts) -- PMC counters need their own passes and cannot be read inside a timed run."""
     G = {"k_adc_scan2": 2, "k_adc_scan3": 4, "k_adc_scan4": 4}.get(scan_name, 1)
     K = 256

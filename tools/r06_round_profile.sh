@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/r05_round_profile.sh <tag> -- the round's evidence run
+# usage (GPU box, repo root): tools/r06_round_profile.sh <tag> -- the round's evidence run (every file profiles/README.md lists)
 tag=$1
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -8,7 +8,10 @@ timeout 900 python bench.py --detail-file gpurun_out/${tag}_bench_detail.json > 
 grep '^{' gpurun_out/${tag}_bench_default.log | tail -1 > gpurun_out/${tag}_bench_line.json
 for c in c4 c2 c3; do timeout 900 tools/gpu_config_profile.sh ${tag} $c pmc > gpurun_out/${tag}_${c}_profile.txt 2>&1; done
 timeout 600 tools/c4x_pmc.sh ${tag} > gpurun_out/${tag}_c4x_pmc.txt 2>&1
-timeout 300 tools/profile_c4x.sh ${tag} 200000000 1,2 > gpurun_out/${tag}_c4x_kernels.txt 2>&1
+timeout 300 tools/profile_c4x.sh ${tag} 200000000 1,2,4,8 > gpurun_out/${tag}_c4x_kernels.txt 2>&1
+timeout 300 tools/r06_call_timeline.sh > gpurun_out/${tag}_c4x_call_timeline.txt 2>&1
+timeout 300 tools/r06_single_timeline.sh > gpurun_out/${tag}_single_query_c4.txt 2>&1
+timeout 200 tools/probes/stream_probe 200000000 8 > gpurun_out/${tag}_stream_probe_kept_forms.txt 2>&1
 for c in c4 c2; do tools/batch_gaps.sh $c > gpurun_out/${tag}_batch_timeline_$c.txt 2>&1; done
 for c in c4 c2; do tools/overlap_trace.sh $c 3 > gpurun_out/${tag}_overlap_$c.txt 2>&1; done
 { timeout 200 python tools/bench_dlib.py 256; timeout 200 python tools/bench_dlib.py 1024; timeout 200 python tools/bench_cnn.py; } 2>&1 | grep batch > gpurun_out/${tag}_cnn.txt
