@@ -1020,7 +1020,8 @@ def pcie_leg(st, resident_qps):
     dtp = (time.perf_counter() - tp) / reps
     out = {"pageable_blocking": {"value": NQ / dtp, "unit": "queries/s", "ms_per_step": dtp * 1e3,
                                  "note": "cis_index_search: one blocking call per batch, pageable numpy arrays in and out"}}
-    lanes = [st.searcher] + [st.searcher.view() for _ in range(2)]
+    n_lanes = max(2, int(os.environ.get("CIS_BENCH_PCIE_LANES", 3)))
+    lanes = [st.searcher] + [st.searcher.view() for _ in range(n_lanes - 1)]
     try:
         qpin, outs = [], []
         for i in range(len(lanes)):
@@ -1046,7 +1047,8 @@ def pcie_leg(st, resident_qps):
         dta = (time.perf_counter() - tp) / nb
         out.update({"value": NQ / dta, "unit": "queries/s", "ms_per_step": dta * 1e3, "frac_of_resident": (NQ / dta) / resident_qps if resident_qps else None,
                     "bytes_per_step": int(qh_all.nbytes + NQ * LIMIT * 16 + NQ * 8), "results_equal_blocking_call": same,
-                    "note": "cis_index_search_async / _wait on three handles (index + two views), queries and results in pinned host memory "
+                    "handles": n_lanes,
+                    "note": "cis_index_search_async / _wait on several handles (the index + views), queries and results in pinned host memory "
                             "(cis_host_alloc); all copies on one copy stream (a copy-in beside a copy-out collapses to 11 GB/s on this platform), "
                             "overlapping the other handles' searches"})
     finally:

@@ -875,5 +875,18 @@ int main(int argc, char** argv) {
         run<M, 4, 8, 1, 1, 1, 1, 0, 2, 2, 2>(S, 2, 1, "four: 8w U1 R1 ring1 nt, builtins");
         }
     }
+    if (sel == 14) {   // what the piece boundaries cost: the same run with ONE table for every slot (no restaging after the first piece)
+        for (int rep = 0; rep < 3; ++rep) {
+            build_slots(1, 65536, sl, ro);
+            CHECK(hipMemcpy(S.d_slots, sl.data(), sl.size() * sizeof(PSlot), hipMemcpyHostToDevice));
+            run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 2>(S, 2, 1, "8w U1 R4 ring1 nt: tables per cell");
+            for (auto& p : sl) { p.tab0[0] = 0; p.tab1[0] = 16; }
+            CHECK(hipMemcpy(S.d_slots, sl.data(), sl.size() * sizeof(PSlot), hipMemcpyHostToDevice));
+            run<M, 1, 8, 1, 4, 1, 1, 2, 1, 2, 0>(S, 2, 1, "  one table for all slots: loads + staging only");
+            g_ref_cnt[1] = -1;
+            run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 2>(S, 2, 1, "  one table for all slots (different survivors)");
+            g_ref_cnt[1] = -1;
+        }
+    }
     return 0;
 }
