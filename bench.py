@@ -1224,6 +1224,27 @@ def ingest_leg(ctx, st, net_kind, n_ing=12):
     return out
 
 
+def single_query_leg(st):
+    """What the reference's callers issue: ONE query per search call (searcher_lopqhbase.py:849-857, 964-970).  Median HIP-event time of
+    search_batch_dev on one query of the timed workload (quota 10000, limit 100), 16 different queries in turn, one call at a time."""
+    qs = [st.qbatches[0][i:i + 1].contiguous() for i in range(16)]
+    for q in qs:
+        st.searcher.search_batch_dev(q, quota=QUOTA, limit=LIMIT)
+    torch.cuda.synchronize()
+    ts = []
+    for r in range(48):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        st.searcher.search_batch_dev(qs[r % 16], quota=QUOTA, limit=LIMIT)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    s_ = sorted(ts)
+    return {"ms": {"median": s_[len(s_) // 2], "min": s_[0], "max": s_[-1]}, "calls": len(ts), "quota": QUOTA, "limit": LIMIT,
+            "candidates": st.searcher.last_stats()["candidates"], "route": st.searcher.last_stats()["scan_kernel"] or "all-candidates select"}
+
+
 def release_state(st):
     try:
         for sv, _ in (getattr(st, "lanes", None) or [])[1:]:
@@ -1456,6 +1477,8 @@ def compact_line(line):
         c["encode"] = {"value": e["value"], "unit": e["unit"], "frac": e["roofline"]["frac"]}
     if line.get("pcie_inclusive"):
         c["pcie_inclusive"] = _pick(line["pcie_inclusive"], "value", "ms_per_step", "frac_of_resident")
+    if line.get("single_query_quota_10000"):
+        c["single_query_quota_10000_ms"] = line["single_query_quota_10000"]["ms"]["median"]
     for k in ("cnn", "dlib"):
         x = line.get(k)
         if x:
@@ -1665,6 +1688,12 @@ def main():
             routed_strong = {"error": repr(e)}
             sys.stderr.write("[bench rank %d] routed leg (strong) failed: %r\n" % (rank, e))
     pcie = pcie_leg(st, head["value"]) if solo and not args.no_pcie else None
+    single = None
+    if solo:
+        try:
+            single = single_query_leg(st)
+        except Exception as e:  # a side leg must never cost the headline line
+            sys.stderr.write("[bench] single-query leg failed: %r\n" % (e,))
     cpu = parity = None
     if want_oracle:
         parity, orc = oracle_parity(st, 10.0, 256, 4.0, 1024)
@@ -1765,6 +1794,7 @@ def main():
             "stage_ms_per_step": head["stage_ms_per_step"],
             "encode": head["encode"],
             "pcie_inclusive": pcie,
+            "single_query_quota_10000": single,
             "cnn": cnn,
             "dlib": dlib,
             "cpu_baseline": cpu,

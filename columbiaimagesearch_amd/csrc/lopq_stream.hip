@@ -8,24 +8,27 @@
 //
 // The batch kernels (k_adc_scan2 / 3 / 4) keep a running top-`limit` per work item and hand its survivors to a one-wave-per-query
 // merge: with ~50 000 work items per query that merge took 40 ms of the 42 ms of a single exhaustive query over 200 M codes.
-// Here nothing is ranked inside the stream:
-//   1. k_adc_stream<SAMPLE>: every SS-th row of every chunk; each lane keeps the MINIMUM float32 distance it saw and folds it into
-//      one of B buckets per query (atomicMin).  count(buckets <= v) <= count(samples <= v), so the k-th smallest bucket minimum is
-//      an upper bound of the k-th smallest sample distance;
+// Here nothing is ranked inside the stream (one launch each; k_stream_prep lays the batch out first: candidate offsets, one record per
+// slot, the rows of the slots before each):
+//   1. k_adc_stream<SAMPLE>: every SS-th row of every chunk; a lane folds the MINIMUM float32 distance of a block of its sampled rows
+//      into one of B buckets per query (atomicMin; the bucket is a hash of (slot, row block, thread)).  Any partition of the samples
+//      into buckets gives count(buckets <= v) <= count(samples <= v), so the k-th smallest bucket minimum is an upper bound of the
+//      k-th smallest sample distance;
 //   2. k_stream_tau: per query, tau = the k-th smallest bucket minimum -- about k x SS candidates of the whole query lie below it
-//      (k is chosen so that this is a few thousand, ~20 x limit);
-//   3. k_adc_stream: the stream.  Codes arrive as 16 bytes per lane with several loads in flight, the float32 tables of the slot's
-//      (<= G) queries sit in LDS entry-major with the sub-quantizers rotated over the lanes (RotConsts: 2.1-way bank conflicts
-//      instead of 3.5), a candidate costs M gathers + M adds and ONE compare against tau; the few that pass append their
-//      retrieval index to the query's list (one atomic each);
+//      (k is chosen so that this is a few thousand, ~20 x limit); it resets the buckets it reads;
+//   3. k_adc_stream: the stream.  Codes arrive as 16 bytes per lane, the float32 tables of the slot's (<= G) queries sit in LDS
+//      entry-major, REPLICATED so that a gather meets no bank conflict, with the sub-quantizers rotated over the lanes; a candidate
+//      costs M gathers + M adds and ONE compare against tau; the few that pass append their retrieval index to the query's list (one
+//      atomic each);
 //   4. k_stream_keys: the exact float64 distance of every listed candidate (left-to-right sum of the float64 entries: the bits of
-//      every other route), k_select_topl ranks them by (distance, retrieval index), k_stream_verify PROVES the result:
+//      every other route), k_select_topl ranks them by (distance, retrieval index), k_stream_finish PROVES the result and writes it:
 //          let B = the limit-th smallest exact distance in the list (the list holds >= limit candidates, or every candidate);
 //          |d32 - d64| <= eps d64 (eps = 2 M 2^-24: M rounded entries, M - 1 rounded adds), so a candidate of the true top
 //          `limit` has d64 <= B, hence d32 <= B (1 + eps); if B (1 + 2 eps) <= tau it was listed.  All candidates with d64 <= B are
 //          then in the list, ties included, and ranking the list by (d64, retrieval index) is the reference's stable sort.
-//      A query whose proof fails (sample unlucky), or whose list overflowed (a crowd of equal codes), is flagged in pinned
-//      memory; the host then answers the batch through the generic path.  The result never depends on the sample.
+//      A query whose proof fails (sample unlucky), whose list overflowed (a crowd of equal codes) or whose cut sits in more exact ties
+//      than k_select_topl ranks is flagged in pinned memory; the host then answers the batch through the generic path.  The result
+//      never depends on the sample.
 #include "scan_common.h"
 
 // Geometry of the stream (round 6; every choice below is a measurement of tools/probes/stream_probe.hip on 200 M x 8-byte codes,

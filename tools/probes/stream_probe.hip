@@ -888,5 +888,21 @@ int main(int argc, char** argv) {
             g_ref_cnt[1] = -1;
         }
     }
+    if (sel == 15) {   // fewer waves per CU
+        //            M  G  NW U  R MODE RING BARE STG AUX PK
+        for (int rep = 0; rep < 2; ++rep) {
+            run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 2>(S, 2, 1, "8w x 2 per CU U1 ring1 nt (kept)");
+            run<M, 1, 8, 1, 4, 1, 1, 0, 1, 2, 2>(S, 1, 1, "8w x 1 per CU U1");
+            run<M, 1, 8, 2, 4, 1, 1, 0, 1, 2, 2>(S, 1, 1, "8w x 1 per CU U2");
+            run<M, 1, 8, 4, 4, 1, 1, 0, 1, 2, 2>(S, 1, 1, "8w x 1 per CU U4");
+            run<M, 1, 4, 1, 4, 1, 1, 0, 1, 2, 2>(S, 3, 1, "4w x 3 per CU U1");
+            run<M, 1, 4, 2, 4, 1, 1, 0, 1, 2, 2>(S, 3, 1, "4w x 3 per CU U2");
+            run<M, 1, 4, 2, 4, 1, 1, 0, 1, 2, 2>(S, 2, 1, "4w x 2 per CU U2");
+            run<M, 1, 4, 4, 4, 1, 1, 0, 1, 2, 2>(S, 2, 1, "4w x 2 per CU U4");
+            run<M, 1, 8, 1, 4, 1, 1, 0, 1, 0, 2>(S, 1, 1, "8w x 1 per CU U1 (default policy)");
+            run<M, 1, 8, 2, 4, 1, 1, 0, 1, 0, 2>(S, 1, 1, "8w x 1 per CU U2 (default policy)");
+            run<M, 1, 8, 2, 4, 1, 1, 0, 1, 0, 2>(S, 2, 1, "8w x 2 per CU U2 (default policy)");
+        }
+    }
     return 0;
 }
