@@ -1007,7 +1007,7 @@ struct cis_cnn {
     DevBuf in_buf, out_buf;
     // views (round 5): a handle that shares the weights of its base and owns workspaces, streams and events -- several BATCHES in flight
     // on the caller's streams (consecutive forwards are in different layers at any time and fill each other's workgroup rounds:
-    // dlib 0.47-0.52 -> 0.60, DeepSentibank 0.61 -> 0.68 of the f32 MFMA peak at batch 256, profiles/r05_experiments.txt)
+    // dlib 0.47-0.52 -> 0.60, DeepSentibank 0.61 -> 0.68 of the f32 MFMA peak at batch 256, profiles/archive/r05b/r05_experiments.txt)
     cis_cnn* base = nullptr;
     std::vector<cis_cnn*> views;
     bool orphaned = false;      // a view whose base was destroyed first: every call fails, nothing dangles

@@ -5997,7 +5997,7 @@ extern "C" int cis_index_search_async(cis_index* ix, const void* Q, int q_dtype,
     hipStream_t st = ix->h_stream;
     // Every copy of every handle goes through ONE copy stream per device: a copy-in and a copy-out that run at the same time collapse
     // on this platform (measured with pinned memory: 52-56 GB/s in either direction alone, 11 GB/s combined when both run --
-    // profiles/r05_pcie_probe.txt), so the copies are serialised among themselves and overlap only the searches.
+    // profiles/archive/r05b/r05_pcie_probe.txt), so the copies are serialised among themselves and overlap only the searches.
     hipStream_t cp = nullptr;
     CIS_TRY(cis_copy_stream(ix->m->device, &cp));
     if (ix->h_pending) CIS_TRY(cis_index_search_wait(ix));  // one batch in flight per handle: its buffers are this handle's workspaces
