@@ -4604,7 +4604,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     // (Round 3 cut the long cells of a shard of four or more into chunks of 20480 candidates so that its few work items spread over
     // the chip: partial search 0.343 -> 0.307 ms alone on the device.  With three batches in flight the whole-cell chunks win -- emulated
     // rank 0 of world 8: 0.227 -> 0.163 ms per step, and 0.552 -> 0.479 ms for the routed protocol's full batches
-    // (profiles/r05_shards.txt) -- so the rule is gone; CIS_SEG_MAX=20480 brings it back for A/B runs.)
+    // (profiles/archive/r05b/r05_shards.txt) -- so the rule is gone; CIS_SEG_MAX=20480 brings it back for A/B runs.)
     // The HBM-streaming route (lopq_stream.hip): few queries, very many candidates each -- an exhaustive quota, or any quota on cells
     // of hundreds of thousands of codes.  Decided here from the bound of the candidates per query (the chunk size is part of the
     // plan); the exact count confirms it below.  Chunks of 65536 candidates, longer when the largest cell would need more than the
