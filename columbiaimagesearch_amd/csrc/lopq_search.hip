@@ -1234,7 +1234,9 @@ static void launch_tables(int64_t n_tabs, size_t tab_lds, hipStream_t st, const 
     }
 }
 
-template <int W>
+// TPB tables per block: 64 for batches (the sub-centroid a thread keeps in registers serves 64 tables), 8 when the batch has few
+// tables -- a single exhaustive query has 32: two blocks per (sub-quantizer, split) then walked 16 of them one after the other, 19 us.
+template <int W, int TPB = 64>
 __global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict__ px /* [ntab][h] */,
                                                         TabDesc* __restrict__ tabs, int n_tabs,
                                                         const double* __restrict__ subs, int h, int nf, int K,
@@ -1242,16 +1244,16 @@ __global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict
                                                         float* __restrict__ T32 /* [ntab][nf][K] float32 copy for the scan */,
                                                         const int64_t* __restrict__ d_totals /* null, or the plan totals: n_tabs is a bound */) {
 #ifndef CIS_TABLES_SCALAR_PX  // (scalar loads of the projected residual instead of the LDS copy: measured 0.185 against 0.162 ms on C2)
-    __shared__ double sf[64][W];
+    __shared__ double sf[TPB][W];
 #endif
-    __shared__ int ssplit[64];
+    __shared__ int ssplit[TPB];
     const int j = blockIdx.y, z = blockIdx.z, k = threadIdx.x;
-    const int t0 = blockIdx.x * 64;
+    const int t0 = blockIdx.x * TPB;
     if (d_totals) {
         n_tabs = (int)d_totals[1];
         if (t0 >= n_tabs) return;
     }
-    const int nt = (n_tabs - t0 < 64) ? (n_tabs - t0) : 64;
+    const int nt = (n_tabs - t0 < TPB) ? (n_tabs - t0) : TPB;
 #ifndef CIS_TABLES_SCALAR_PX  // (scalar loads of the projected residual instead of the LDS copy: measured 0.185 against 0.162 ms on C2)
     for (int e = threadIdx.x; e < nt * W; e += 256) {
         const int t = e / W, i = e - t * W;
@@ -4883,13 +4885,18 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     const bool direct = direct_elig;
     if (direct) {
     } else if (split_tables && n_tabs > 0) {
-        dim3 g((unsigned)ceil_div(n_tabs, 64), (unsigned)nf, 2);
+        const bool few = n_tabs <= 1024;   // (d_tot: n_tabs is a bound, the kernel reads the real count)
+        dim3 g((unsigned)ceil_div(n_tabs, few ? 8 : 64), (unsigned)nf, 2);
+#define CIS_TFP(WW)                                                                                                                                      \
+        if (few) hipLaunchKernelGGL((k_tables_from_px<WW, 8>), g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32, d_tot);      \
+        else hipLaunchKernelGGL((k_tables_from_px<WW, 64>), g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32, d_tot)
         switch (m->w) {
-            case 4: hipLaunchKernelGGL(k_tables_from_px<4>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32, d_tot); break;
-            case 8: hipLaunchKernelGGL(k_tables_from_px<8>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32, d_tot); break;
-            case 16: hipLaunchKernelGGL(k_tables_from_px<16>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32, d_tot); break;
-            default: hipLaunchKernelGGL(k_tables_from_px<32>, g, dim3(256), 0, st, px_buf, tabs, (int)n_tabs, m->d_subs, h, nf, K, T, T32, d_tot); break;
+            case 4: CIS_TFP(4); break;
+            case 8: CIS_TFP(8); break;
+            case 16: CIS_TFP(16); break;
+            default: CIS_TFP(32); break;
         }
+#undef CIS_TFP
     } else if (fast && n_tabs > 0) {
         const int64_t ne = n_tabs * nf * K;
         hipLaunchKernelGGL(k_tables_f32, dim3((unsigned)ceil_div(ne, 256)), dim3(256), 0, st, T, ne, nf, K, T32, tabs);
