@@ -891,7 +891,9 @@ static __device__ __forceinline__ int slot_key(const WorkItem& it, int ncells, i
     return (2 * b + (it.rank > 0 ? sz : 0) + (it.cell - b)) * CH + ch;
 }
 
-__global__ void k_item_hist(const WorkItem* __restrict__ items, int64_t n, int* __restrict__ cell_cnt, int ncells, int CH, int seg_max) {
+__global__ void k_item_hist(const WorkItem* __restrict__ items, int64_t n, int* __restrict__ cell_cnt, int ncells, int CH, int seg_max,
+                            const int64_t* __restrict__ d_totals = nullptr /* the plan totals: n is a bound */) {
+    if (d_totals) n = d_totals[0];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) atomicAdd(&cell_cnt[slot_key(items[i], ncells, CH, seg_max)], 1);
 }
@@ -943,7 +945,9 @@ __global__ __launch_bounds__(1024) void k_cell_scan(int* __restrict__ cell_cnt, 
 
 // slots[(slot_off[cell] + r / G) * G + r % G] = item, r = arrival rank of the item inside its cell
 __global__ void k_item_scatter(const WorkItem* __restrict__ items, int64_t n, const int* __restrict__ slot_off,
-                               int* __restrict__ cursor, int G, int* __restrict__ slots, int ncells, int CH, int seg_max) {
+                               int* __restrict__ cursor, int G, int* __restrict__ slots, int ncells, int CH, int seg_max,
+                               const int64_t* __restrict__ d_totals = nullptr /* the plan totals: n is a bound */) {
+    if (d_totals) n = d_totals[0];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int c = slot_key(items[i], ncells, CH, seg_max);
@@ -4764,6 +4768,19 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             n_cand_all = (int64_t)nq * per_q;
             ix->stats_pending_seq = seq;
         }
+        // The streaming route when it is CERTAIN before the plan is known -- every query collects at least min(quota, n_total)
+        // candidates (search.py:128-133 stops at the quota or at the end of the index), and that alone is past the route's threshold
+        // (an exhaustive quota): the same bounds size the workspaces, the kernels read the real totals from device memory, and the
+        // host does not stop in the middle of the batch (round 6: the read-back was a 35 us hole in a 0.5 ms exhaustive query).
+        static const bool no_stream_bounds = getenv("CIS_STREAM_WAIT") != nullptr;   // A/B runs: the read-back as before
+        if (!no_bounds && !no_stream_bounds && stream_hint && split_ok && items_q <= 65536 && (double)nq * (double)items_q < 4.0e6 &&
+            (ix->force_stream || (q_eff < ix->n_total ? q_eff : ix->n_total) >= stream_min) && ix->n_total > 0 && nq <= 64) {
+            d_tot = totals;
+            n_items = (int64_t)nq * items_q;
+            n_tabs = (int64_t)nq * 2 * V;
+            n_cand_all = (int64_t)nq * per_q;
+            ix->stats_pending_seq = seq;
+        }
     }
     if (!d_tot) {
         // the plan totals size the rest of the batch: poll the pinned sequence word (a blocking stream synchronisation
@@ -4799,8 +4816,8 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     // tiny cells on the all-candidates path: entries computed per candidate from px (k_adc_direct), no tables
     const bool direct_elig = !d_tot && use_all_path(ix, M, K, L, nq) && index_has_tiny_cells(ix) && h <= 256 && direct_jp(M, K, m->w) > 0 &&
                              !getenv("CIS_TABLES_UNGROUPED") && !getenv("CIS_NO_DIRECT");
-    const bool stream = stream_hint && !d_tot && n_items > 0 && ((m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) || (scan2_supported(M, K, L) && !ix->force_exact_scan)) &&
-                        (ix->force_stream || n_cand_all / (nq > 0 ? nq : 1) >= stream_min);
+    const bool stream = stream_hint && n_items > 0 && ((m->w == 4 || m->w == 8 || m->w == 16 || m->w == 32) || (scan2_supported(M, K, L) && !ix->force_exact_scan)) &&
+                        (ix->force_stream || d_tot != nullptr || n_cand_all / (nq > 0 ? nq : 1) >= stream_min);   // (d_tot: certain, see above)
     if (!stream)
     {
         // workspace budget: per-item hit lists and the float64 tables.  A batch that would need more (e.g. an
@@ -4929,9 +4946,9 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         if (G > 1) {
             const int64_t ninit = max_slots * G > nkeys ? max_slots * G : nkeys;
             hipLaunchKernelGGL(k_slots_init, dim3((unsigned)ceil_div(ninit < 16 ? 16 : ninit, 256)), dim3(256), 0, st, qctr, cell_cnt, (int)nkeys, slots, max_slots * G);
-            hipLaunchKernelGGL(k_item_hist, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, cell_cnt, (int)ix->ncells, (int)CH, seg_max);
+            hipLaunchKernelGGL(k_item_hist, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, cell_cnt, (int)ix->ncells, (int)CH, seg_max, d_tot);
             hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, cell_cnt, slot_off, (int)nkeys, G, n_slots, qstart, (int)CH);
-            hipLaunchKernelGGL(k_item_scatter, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, slot_off, cell_cnt, G, slots, (int)ix->ncells, (int)CH, seg_max);
+            hipLaunchKernelGGL(k_item_scatter, dim3((unsigned)ceil_div(n_items, 256)), dim3(256), 0, st, items, n_items, slot_off, cell_cnt, G, slots, (int)ix->ncells, (int)CH, seg_max, d_tot);
         } else
             slots = nullptr;   // one query per slot: slot i = work item i (k_stream_prep)
         // workspace: candidate layout, lists, keys, ranked pairs; the sample buckets live in their own buffer (k_stream_tau leaves them
@@ -4962,7 +4979,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
         float* tau = reinterpret_cast<float*>(nsel + (nq + 2));
         int* status = reinterpret_cast<int*>(tau + (nq + 2));
         // candidate layout + slot records + row offsets + resets: one launch of one workgroup
-        launch_stream_prep(st, items, n_items, item_off, nq, n_cand_all, slots, n_slots, G, M, cand_start, seg, qmin, qmax, cnt, status, rowoff, sdesc);
+        launch_stream_prep(st, items, n_items, item_off, nq, n_cand_all, slots, n_slots, G, M, cand_start, seg, qmin, qmax, cnt, status, rowoff, sdesc, d_tot);
         // sample: every SS-th row; the k-th smallest of the bucket minima lets about k * SS candidates of a query through -- aim at
         // ~max(4096, 16 limit) of them, with k >= 8 so that the count is stable (relative spread 1 / sqrt(k))
         const int64_t per_q = n_cand_all / nq;

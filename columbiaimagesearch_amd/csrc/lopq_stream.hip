@@ -101,9 +101,11 @@ __device__ __forceinline__ int64_t prep_block_excl_scan(int64_t x, int64_t* s_w,
 __global__ __launch_bounds__(1024) void k_stream_prep(const WorkItem* __restrict__ items, int64_t n_items, const int64_t* __restrict__ item_off, int nq, int64_t n_cand,
                                                       const int* __restrict__ slots, int* __restrict__ n_slots, int G, int row,
                                                       int64_t* cand_start, int64_t* seg, unsigned long long* __restrict__ qmin, unsigned long long* __restrict__ qmax,
-                                                      int* __restrict__ cnt, int* __restrict__ status, int64_t* __restrict__ rowoff, StreamSlot* __restrict__ desc) {
+                                                      int* __restrict__ cnt, int* __restrict__ status, int64_t* __restrict__ rowoff, StreamSlot* __restrict__ desc,
+                                                      const int64_t* __restrict__ d_totals /* null, or the plan totals (n_items and n_cand are bounds) */) {
     __shared__ int64_t s_w[16];
     const int tid = threadIdx.x;
+    if (d_totals) { n_items = d_totals[0]; n_cand = d_totals[2]; }
     // A. (cand_start and seg are written and read by this workgroup through agent-scope atomics: no stale L1 line, as in k_cand_layout)
     int64_t run = 0;
     for (int64_t i0 = 0; i0 < n_items; i0 += 1024) {
@@ -365,14 +367,15 @@ __global__ __launch_bounds__(64 * CIS_STREAM_NW) void k_adc_stream(const StreamS
 }
 
 // tau[q] = (an upper bound within 2^-16 of the range of) the k-th smallest of the query's B bucket minima; +inf when fewer than k buckets
-// were touched.  One workgroup of 1024 threads per query, B / 1024 values per thread.  Non-negative floats order like their bits: four
-// rounds of FIFTEEN pivots each narrow [min, max] sixteen-fold per round (round 5: sixteen halvings, a barrier pair each: 20 us).
-// hi always has >= k buckets at or below it, so tau = hi admits a few more candidates than the exact k-th smallest would, which only
-// lengthens the list; the proof does not care where tau came from.
+// were touched.  One workgroup of 1024 threads per query, B / 1024 values per thread.  Non-negative floats order like their bits: a
+// two-level radix SELECT on (value - min) -- a 256-bin LDS histogram of the leading eight bits of the range, the bin that holds the
+// k-th value, then the next eight bits inside that bin -- and tau = the upper edge of the final sub-bin (round 5: sixteen halvings, a
+// barrier pair each: 20 us; fifteen pivots per round x four: 17-20 us, all compares; this form: two histogram passes).
+// Every value at or below the k-th smallest lies at or below that edge, so tau admits a few more candidates than the exact k-th
+// smallest would, which only lengthens the list; the proof does not care where tau came from.
 // The buckets are RESET here, by their only reader: the next batch's sample pass finds them clean (the index memsets them when it
 // allocates them; values >= 0x7f800000 are empty).
-// sum over the wave on the VALU (DPP / permlane swaps: a ds_bpermute shuffle costs ~0.2 us of dependent latency per step here)
-static __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
+static __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {   // on the VALU (DPP / permlane swaps)
     v += lane_xor<1>(v);
     v += lane_xor<2>(v);
     v += lane_xor<4>(v);
@@ -381,7 +384,6 @@ static __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
     v += lane_xor<32>(v);
     return v;
 }
-
 static __device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v) {
     uint32_t o;
     o = lane_xor<1>(v); v = o < v ? o : v;
@@ -403,10 +405,37 @@ static __device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v) {
     return v;
 }
 
+// the bin of a 256-bin histogram (four bins per lane of wave 0) where the running count, started at `before`, first reaches k;
+// *below = the count of the bins before it.  Every lane returns the same pair.
+static __device__ __forceinline__ int tau_pick_bin(const int* __restrict__ hist, int before, int k, int* below) {
+    const int lane = threadIdx.x & 63;
+    const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+    int inc = c0 + c1 + c2 + c3;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(inc, d);
+        if (lane >= d) inc += y;
+    }
+    const int ex = before + inc - (c0 + c1 + c2 + c3);   // count of everything before this lane's four bins
+    int bin = -1, bel = 0;
+    if (ex < k && ex + c0 + c1 + c2 + c3 >= k) {          // exactly one lane
+        int run = ex;
+        bin = 4 * lane; bel = run;
+        if (run + c0 < k) { run += c0; bin = 4 * lane + 1; bel = run;
+            if (run + c1 < k) { run += c1; bin = 4 * lane + 2; bel = run;
+                if (run + c2 < k) { run += c2; bin = 4 * lane + 3; bel = run; } } }
+    }
+    const unsigned long long m = __ballot(bin >= 0);
+    const int src = m ? __builtin_ctzll(m) : 0;
+    *below = __shfl(bel, src);
+    return __shfl(bin, src);
+}
+
 template <int PER>
 __global__ __launch_bounds__(1024) void k_stream_tau(uint32_t* __restrict__ bmin, int B, int k, float* __restrict__ tau) {
-    __shared__ int s_tot[5][16];   // [0]: finite buckets; [1 + round]: buckets <= pivot j of the round (summed by one atomic per wave and pivot)
+    __shared__ int s_h1[256], s_h2[256];
     __shared__ uint32_t s_mm[2];
+    __shared__ int s_sel[4];   // finite buckets; bin of the first level; count below it
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     uint32_t v[PER];
     uint32_t lo = 0xffffffffu, hi = 0u;
@@ -419,8 +448,8 @@ __global__ __launch_bounds__(1024) void k_stream_tau(uint32_t* __restrict__ bmin
         if (v[i] < 0x7f800000u) { hi = v[i] > hi ? v[i] : hi; lo = v[i] < lo ? v[i] : lo; ++nfin; }
         else v[i] = 0xffffffffu;
     }
-    if (tid == 0) { s_mm[0] = 0xffffffffu; s_mm[1] = 0u; }
-    if (tid < 80) s_tot[tid >> 4][tid & 15] = 0;
+    if (tid == 0) { s_mm[0] = 0xffffffffu; s_mm[1] = 0u; s_sel[0] = 0; }
+    if (tid < 256) { s_h1[tid] = 0; s_h2[tid] = 0; }
     __syncthreads();
     lo = wave_min_dpp(lo);
     hi = wave_max_dpp(hi);
@@ -428,47 +457,43 @@ __global__ __launch_bounds__(1024) void k_stream_tau(uint32_t* __restrict__ bmin
     if (lane == 0) {
         atomicMin(&s_mm[0], lo);
         atomicMax(&s_mm[1], hi);
-        atomicAdd(&s_tot[0][0], nfin);
+        atomicAdd(&s_sel[0], nfin);
     }
     __syncthreads();
     lo = s_mm[0];
     hi = s_mm[1];
-    if (s_tot[0][0] < k) {   // uniform over the workgroup
+    if (s_sel[0] < k) {   // uniform over the workgroup
         if (tid == 0) tau[q] = __uint_as_float(0x7f800000u);
         return;
     }
-    for (int round = 0; round < 4 && lo < hi; ++round) {  // uniform over the workgroup
-        const uint64_t span = (uint64_t)(hi - lo);
-        int c[15];
+    const uint32_t span = hi - lo;
+    const int bits = span ? 32 - __builtin_clz(span) : 0;   // (v - lo) < 2^bits
+    const int sh1 = bits > 8 ? bits - 8 : 0, sh2 = sh1 > 8 ? sh1 - 8 : 0;
 #pragma unroll
-        for (int j = 0; j < 15; ++j) {
-            const uint32_t pj = lo + (uint32_t)((span * (uint64_t)(j + 1)) >> 4);
-            int cc = 0;
-#pragma unroll
-            for (int i = 0; i < PER; ++i) cc += v[i] <= pj ? 1 : 0;
-            c[j] = cc;
-        }
-        // wave sums: two counts (<= 1024 each) per register
-#pragma unroll
-        for (int j = 0; j < 14; j += 2) c[j] |= c[j + 1] << 16;
-#pragma unroll
-        for (int j = 0; j < 15; j += 2) c[j] = (int)wave_sum_dpp((uint32_t)c[j]);
-        if (lane == 0) {
-#pragma unroll
-            for (int j = 0; j < 14; j += 2) { atomicAdd(&s_tot[1 + round][j], c[j] & 0xffff); atomicAdd(&s_tot[1 + round][j + 1], c[j] >> 16); }
-            atomicAdd(&s_tot[1 + round][14], c[14]);
-        }
-        __syncthreads();
-        int pick = 15;
-#pragma unroll
-        for (int j = 14; j >= 0; --j)
-            if (s_tot[1 + round][j] >= k) pick = j;
-        const uint32_t nlo = pick > 0 ? lo + (uint32_t)((span * (uint64_t)pick) >> 4) + 1u : lo;
-        const uint32_t nhi = pick < 15 ? lo + (uint32_t)((span * (uint64_t)(pick + 1)) >> 4) : hi;
-        lo = nlo < nhi ? nlo : nhi;
-        hi = nhi;
+    for (int i = 0; i < PER; ++i)
+        if (v[i] != 0xffffffffu) atomicAdd(&s_h1[(v[i] - lo) >> sh1], 1);
+    __syncthreads();
+    if (tid < 64) {
+        int below;
+        const int b1 = tau_pick_bin(s_h1, 0, k, &below);
+        if (tid == 0) { s_sel[1] = b1; s_sel[2] = below; }
     }
-    if (tid == 0) tau[q] = __uint_as_float(hi);
+    __syncthreads();
+    const uint32_t b1 = (uint32_t)s_sel[1];
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+        if (v[i] != 0xffffffffu && ((v[i] - lo) >> sh1) == b1) atomicAdd(&s_h2[((v[i] - lo) >> sh2) & ((1u << (sh1 - sh2)) - 1u)], 1);
+    __syncthreads();
+    if (tid < 64) {
+        int below;
+        const int b2 = sh1 > sh2 ? tau_pick_bin(s_h2, s_sel[2], k, &below) : 0;
+        if (tid == 0) {
+            // upper edge of sub-bin (b1, b2): the largest offset whose leading bits are (b1 << (sh1 - sh2)) | b2
+            const uint64_t edge = ((((uint64_t)b1 << (sh1 - sh2)) | (uint64_t)b2) + 1ull) << sh2;
+            const uint64_t t = (uint64_t)lo + edge - 1ull;
+            tau[q] = __uint_as_float(t < (uint64_t)hi ? (uint32_t)t : hi);
+        }
+    }
 }
 
 // exact float64 key of every listed candidate + the key range of the query (for k_select_topl)
@@ -624,9 +649,9 @@ int stream_grid(int M, int G, int K, int64_t max_rows) {
 
 void launch_stream_prep(hipStream_t st, const WorkItem* items, int64_t n_items, const int64_t* item_off, int nq, int64_t n_cand, const int* slots, int* n_slots,
                         int G, int M, int64_t* cand_start, int64_t* seg, unsigned long long* qmin, unsigned long long* qmax, int* cnt, int* status, int64_t* rowoff,
-                        void* desc) {
+                        void* desc, const int64_t* d_totals) {
     hipLaunchKernelGGL(k_stream_prep, dim3(1), dim3(1024), 0, st, items, n_items, item_off, nq, n_cand, slots, n_slots, G, 64 * (16 / M), cand_start, seg, qmin, qmax,
-                       cnt, status, rowoff, static_cast<StreamSlot*>(desc));
+                       cnt, status, rowoff, static_cast<StreamSlot*>(desc), d_totals);
 }
 
 void launch_stream_tau(hipStream_t st, uint32_t* bmin, int B, int k, int nq, float* tau) {

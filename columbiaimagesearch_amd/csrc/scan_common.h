@@ -261,7 +261,7 @@ size_t stream_slot_bytes();  // one record per slot (lopq_stream.hip: StreamSlot
 void launch_stream_prep(hipStream_t st, const WorkItem* items, int64_t n_items, const int64_t* item_off, int nq, int64_t n_cand,
                         const int* slots /* null: slot i = work item i alone */, int* n_slots, int G, int M, int64_t* cand_start, int64_t* seg,
                         unsigned long long* qmin, unsigned long long* qmax, int* cnt, int* status, int64_t* rowoff /* [n_slots + 1]: rows of the slots before each */,
-                        void* desc /* [max_slots] records */);
+                        void* desc /* [max_slots] records */, const int64_t* d_totals /* null, or the plan totals: n_items and n_cand are bounds */);
 void launch_stream_scan(int M, int G, bool sample, int grid, hipStream_t st, const void* desc, const int* n_slots, const int64_t* rowoff,
                         const float* T32, const double* T, const uint8_t* codes, int K, const float* tau,
                         uint32_t* bmin, int B, int sample_stride, int flush /* sampled rows a lane folds into one bucket */, uint32_t* surv, int* cnt, int cap);
