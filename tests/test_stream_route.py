@@ -142,3 +142,35 @@ def test_exhaustive_query_takes_the_streaming_route_by_itself():
     served = a.stream_counters()[0]
     a.search_batch(Q[:1], quota=1000, limit=100)
     assert a.stream_counters()[0] == served and a.last_stats()["scan_kernel"] != "k_adc_stream"
+
+
+def test_tie_crowd_in_a_short_query_is_handed_back(monkeypatch):
+    """Round-5 advice: a query whose EVERY candidate was listed (fewer candidates than the list holds) and whose cut sits in more exact
+    ties than k_select_topl ranks used to return n_found = 0 -- the verification took the every-candidate-listed shortcut before it
+    looked at the ranked count.  A quota of 5000 over 20000 codes (the query meets fewer candidates than the 16384-entry list holds, so
+    the sparse sample gives tau = +inf and everything is listed), 2000 of them identical to the query's own code: the first `limit` ties
+    in retrieval (= insertion) order, through the generic path, and the counter says the batch was handed back."""
+    from test_lopq_hip_parity import hip_model
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    monkeypatch.setenv("CIS_STREAM_SEG", "1024")
+    z, X, Q = load_golden("c2")
+    m = hip_model(z)
+    n, dup, quota = 20000, 2000, 5000
+    coarse, fine = z["coarse"][:n].copy(), z["fine"][:n].copy()
+    qc, qf = m.predict_batch(Q[:1])
+    coarse[500:500 + dup] = qc[0]
+    fine[500:500 + dup] = qf[0]
+    a, b = LOPQSearcherHIP(m), LOPQSearcherHIP(m)
+    a.add_codes_array(coarse, fine)
+    b.add_codes_array(coarse, fine)
+    a.set_scan_mode(mode=6)
+    b.set_scan_mode(mode=1)
+    for nq, limit in ((1, 100), (2, 100), (1, 440)):
+        before = a.stream_counters()
+        r = a.search_batch(Q[:nq], quota=quota, limit=limit)
+        after = a.stream_counters()
+        _same(r, b.search_batch(Q[:nq], quota=quota, limit=limit))
+        assert int(r["n_found"][0]) == limit and (r["ids"][0, :limit] == np.arange(500, 500 + limit)).all()
+        assert after[0] == before[0] + 1 and after[1] == before[1] + 1, "the tie crowd must go to the generic path"
+    a.close()
+    b.close()
