@@ -1276,14 +1276,14 @@ def _roof_c(r):
     if not isinstance(r, dict):
         return None
     out = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "physical_frac", "traffic_frac", "accounting_frac",
-                "binding_frac", "binding_resource", "pipeline_accounting_frac", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch")
+                "binding_frac", "binding_resource", "avg_launch_ms", "algorithmic_bytes_per_launch")
     if isinstance(r.get("pmc_source"), dict):
-        out["pmc_source"] = _pick(r["pmc_source"], "file", "commit", "kernel", "sources_match_this_build")
+        out["pmc_source"] = _pick(r["pmc_source"], "file", "commit", "sources_match_this_build")   # (+ kernel symbol in #detail)
+        if out["pmc_source"].get("commit"):
+            out["pmc_source"]["commit"] = out["pmc_source"]["commit"][:10]
     out.setdefault("traffic", None)
     b = r.get("binding") or {}
     m = b.get("measured") or {}
-    if b.get("binds"):
-        out["binds"] = b["binds"]
     for k in ("valu_busy_frac", "lds_busy_frac", "lds_conflict_ratio"):
         if k in m:
             out[k] = m[k]
@@ -1464,10 +1464,10 @@ def compact_line(line):
     c["vs_baseline"] = line.get("vs_baseline")
     cfg = line.get("config") or {}
     c["config"] = _pick(cfg, "name", "index_vectors", "queries_per_step", "quota", "limit", "parallelism", "batches_in_flight", "candidates_per_query")
-    c["config"]["workload"] = (cfg.get("workload") or "")[:80]
+    c["config"]["workload"] = (cfg.get("workload") or "")[:48]
     c["roofline"] = _roof_c(line.get("roofline"))
     t = line.get("timing") or {}
-    c["timing"] = _pick(t, "repetitions", "timed_s", "wall_over_events", "workspace_allocations_in_timed_region", "suspect")
+    c["timing"] = _pick(t, "repetitions", "wall_over_events", "workspace_allocations_in_timed_region", "suspect")
     if "ms_per_step" in t:
         c["timing"]["min_max_ms"] = [t["ms_per_step"]["min"], t["ms_per_step"]["max"]]
     if line.get("stage_ms_per_step"):
@@ -1490,9 +1490,9 @@ def compact_line(line):
                 c[k]["frac_batch_1024"] = x["batch_1024"]["frac"]
     cb = line.get("cpu_baseline")
     if cb:
-        c["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind", "search_vectorised_1core_qps", "search_vectorised_allcore_qps", "allcore_workers",
-                                  "encode_loop_1core_vps", "encode_vectorised_allcore_vps", "cnn_torch_cpu_batch1_x_cores_ips", "cnn_torch_cpu_batch256_ips")
-        c["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:48]
+        c["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind", "search_vectorised_allcore_qps", "allcore_workers",
+                                  "encode_vectorised_allcore_vps", "cnn_torch_cpu_batch1_x_cores_ips", "cnn_torch_cpu_batch256_ips")
+        c["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:24]
     else:
         c["cpu_baseline"] = None
     if line.get("parity"):
@@ -1536,10 +1536,9 @@ def compact_line(line):
             elif name == "c4x":
                 e1 = x["exhaustive"]["nq1"]
                 cc[name] = {"value": x["value"], "ms_per_step": x["ms_per_step"], "index_vectors": x["config"]["index_vectors"],
-                            "batch_accounting_frac": x["roofline"]["frac"], "batch_kernel": x["roofline"]["kernel"], "batch_launch_ms": x["roofline"]["avg_launch_ms"],
+                            "batch_accounting_frac": x["roofline"]["frac"], "batch_launch_ms": x["roofline"]["avg_launch_ms"],
                             "roofline": _roof_c(e1["roofline"]),
                             "exhaustive_ms": {k: v["ms_per_batch"]["median"] for k, v in x["exhaustive"].items() if "ms_per_batch" in v},
-                            "exhaustive_frac_nq2": x["exhaustive"]["nq2"]["roofline"]["frac"],
                             "exhaustive_queries_per_s": {k: v["queries_per_s"] for k, v in x["exhaustive"].items() if "queries_per_s" in v},
                             "exhaustive_kernel_ms": {k: v["roofline"]["avg_launch_ms"] for k, v in x["exhaustive"].items() if "roofline" in v},
                             "single_query_quota_10000_ms": x["exhaustive"]["single_query_quota_10000"]["ms"]["median"],
@@ -1547,12 +1546,20 @@ def compact_line(line):
             else:
                 r = x["roofline"]
                 cc[name] = {"value": x["value"], "ms_per_step": x["ms_per_step"], "recall_at_10": x["recall_at_10"], "kernel": r["kernel"], "frac": r["frac"],
-                            "physical_frac": r.get("physical_frac"), "launch_ms": r["avg_launch_ms"], "pipeline_frac": r.get("pipeline_accounting_frac"),
-                            "stage_ms": {k[:-3]: v for k, v in x["stage_ms_per_step"].items()}, "encode": x["encode"]["value"], "encode_frac": x["encode"]["roofline"]["frac"],
-                            "parity_green": x.get("parity_green"), "suspect_timing": (x.get("timing") or {}).get("suspect")}
+                            "accounting_frac": r.get("accounting_frac"), "physical_frac": r.get("physical_frac"), "launch_ms": r["avg_launch_ms"],
+                            "stage_ms": {k[:-3]: v for k, v in x["stage_ms_per_step"].items() if k != "scan_kernel_ms"}, "encode": x["encode"]["value"],
+                            "encode_frac": x["encode"]["roofline"]["frac"], "parity_green": x.get("parity_green")}
+                if (x.get("timing") or {}).get("suspect"):
+                    cc[name]["suspect_timing"] = True
         c["configs"] = cc
-    c["detail"] = "full object: the `#detail ` line above"
-    return _r(c)
+    c["detail"] = "#detail line above"
+    # the contract's top-level numbers keep five significant digits, everything nested four (the line must stay under 4 KB)
+    out = {k: (_r(v, 2) if isinstance(v, (dict, list, tuple)) else _r(v, 3)) for k, v in c.items()}
+    for drop in ("ingest", "timing", "stage_ms", "encode", "collectives_us", "grid"):   # never needed so far: the last resort of a line that grew
+        if len(json.dumps(out)) <= 4000:
+            break
+        out.pop(drop, None)
+    return out
 
 
 def emit_lines(line, compact, detail_file=None):

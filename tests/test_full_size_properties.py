@@ -422,13 +422,13 @@ def test_bench_multi_rank_protocol_on_one_gpu(gpus, shards, grid_groups):
     a = line["allgather"]
     assert a["scaling"] == "strong" and a["config"]["cell_shards"] == gpus and a["config"]["queries_per_step"] == 8192 and a["recall_at_10"] >= 0.9
     assert abs(a["value"] - 8192 * 3 / (a["ms_per_step"] * 3e-3)) <= 1e-6 * a["value"]
-    assert abs(compact["allgather"]["value"] - a["value"]) <= 1e-4 * a["value"] and compact["routed"]["equals_allgather_protocol"] is True
+    assert abs(compact["allgather"]["value"] - a["value"]) <= 1e-3 * a["value"] and compact["routed"]["equals_allgather_protocol"] is True
     # the SAME job as N = 1 (8192 queries per step over the job) through both protocols, the bytes they exchange with what those should
     # cost on xGMI, and the bare collectives of exactly those payloads measured before anything else (round-5 review, item 5)
     st_ = line["strong"]
     assert st_["queries_per_step"] == 8192 and abs(st_["allgather"]["value"] - a["value"]) <= 1e-6 * a["value"]
     assert st_["routed"]["equals_allgather_protocol"] is True and st_["routed"]["fallbacks_in_timed_region"] == 0 and st_["routed"]["value"] > 0
-    assert abs(compact["strong"]["routed"]["value"] - st_["routed"]["value"]) <= 1e-4 * st_["routed"]["value"]
+    assert abs(compact["strong"]["routed"]["value"] - st_["routed"]["value"]) <= 1e-3 * st_["routed"]["value"]
     eb = line["exchange_bytes_per_step"]
     assert eb["allgather"] > 0 and eb["routed_weak"] > eb["routed_strong"] > 0 and compact["exchange"]["projected_us"]["allgather"] > 0
     cs = line["collectives"]["sizes"]
