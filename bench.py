@@ -1291,7 +1291,7 @@ def _roof_c(r):
 
 
 XGMI_LINK_GBS = 153.0   # one xGMI link of an MI355X (MI355X_MICROARCH.md / the task statement: 7 links x ~153 GB/s per GPU, point to point)
-COLLECTIVE_LATENCY_US = 15.0   # what a small RCCL collective costs whatever its size (assumed until a node measures it: `collectives.measured`)
+COLLECTIVE_LATENCY_US = 25.0   # what a small RCCL collective costs whatever its size: 21-30 us measured at world 1 on one MI355X (`--collectives-only`, round 6); a node's own figure is in `collectives`
 
 
 def exchange_model(world, nq_total, nq_home, L, row_bytes):
@@ -1664,6 +1664,9 @@ def main():
                     "config": {"workload": "collectives only: the all-gather and all-to-all payload sizes of an %d-query step at limit %d" % (NQ, LIMIT)},
                     "collectives": collectives, "exchange": exchange_model(world, NQ, max(NQ // world, 1), LIMIT, 1024) if world > 1 else None}
             emit_lines(line, line, args.detail_file)
+        if ctx.use_dist:
+            import torch.distributed as dist
+            dist.destroy_process_group()
         return
     ctx.c4x_oracle_exhaustive = bool(args.c4x_oracle)
     solo = rank == 0 and world == 1

@@ -18,7 +18,7 @@ def test_exchange_model_sizes_follow_the_protocols():
     assert rt["query_block_bytes_per_peer"] == route_capacity(1024, 256, 8) * 1024
     assert ag["exchange_bytes_per_step"] > 0 and rt["exchange_bytes_per_step"] > rt["query_bytes_sent_per_rank"]
     # per-peer share / link rate + fixed latencies: tens to hundreds of microseconds at these sizes, and the weak form moves 8 x the rows
-    assert 30.0 < ag["projected_us"] < 200.0 and 60.0 < rt["projected_us"] < 200.0
+    assert 50.0 < ag["projected_us"] < 250.0 and 100.0 < rt["projected_us"] < 250.0
     weak = bench.exchange_model(8, 8 * 8192, 8192, 100, 1024)["routed"]
     assert weak["query_block_bytes_per_peer"] == 8 * rt["query_block_bytes_per_peer"] and weak["projected_us"] > rt["projected_us"]
     one = bench.exchange_model(1, 8192, 8192, 100, 1024)
