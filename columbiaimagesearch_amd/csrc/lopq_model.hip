@@ -1707,9 +1707,63 @@ extern "C" int cis_model_create(cis_model** out, int D_in, int D, int V, int M, 
 
 static inline int grid1(int64_t n, int bs) { return (int)ceil_div(n, bs); }
 
+// apply_PCA of a HANDFUL of rows in one launch (round 6: the reference's callers search one feature per call, and the two launches of the
+// batched form -- a 64-row MFMA tile for one row, then the finish pass -- were 14 us of a 120-170 us call).  One workgroup per row; thread c
+// owns output column c.  Bit-identical to the batched form by construction: the float64 MFMA is, per output element, ONE chain of fused
+// multiply-adds over ascending k from a zero accumulator (tools/probes/mfma_f64_order.hip), which is this loop; the centring follows
+// k_pca_gemm_mfma_pf's stash (float32 - float32 when both are float32), the norm k_pca_finish8's order (numpy's eight interleaved
+// accumulators, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))), the division and the float32 cast are the same expressions.
+template <typename TX, bool SUBF32>
+__global__ __launch_bounds__(128) void k_pca_small(const TX* __restrict__ X, const double* __restrict__ mu, const double* __restrict__ P,
+                                                   float* __restrict__ out, int D_in /* <= 512 */, int D /* <= 128, multiple of 8 */) {
+    __shared__ double s_a[512];
+    __shared__ double s_y[128];
+    __shared__ double s_nrm;
+    const int tid = threadIdx.x;
+    const TX* x = X + (int64_t)blockIdx.x * D_in;
+    for (int k = tid; k < D_in; k += 128) {
+        if constexpr (sizeof(TX) == 4) {
+            if constexpr (SUBF32) s_a[k] = (double)((float)x[k] - (float)mu[k]);
+            else s_a[k] = (double)x[k] - mu[k];
+        } else {
+            s_a[k] = (double)x[k] - mu[k];
+        }
+    }
+    __syncthreads();
+    if (tid < D) {
+        double acc = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < D_in; ++k) acc = fma(s_a[k], P[(int64_t)k * D + tid], acc);
+        s_y[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < 64) {   // (every 8-lane group of the wave computes the same norm; lane 0 publishes it)
+        const int j = tid & 7;
+        double acc = s_y[j] * s_y[j];
+        for (int i = 1; i * 8 < D; ++i) acc = acc + s_y[i * 8 + j] * s_y[i * 8 + j];
+        acc = acc + __shfl_xor(acc, 1);
+        acc = acc + __shfl_xor(acc, 2);
+        acc = acc + __shfl_xor(acc, 4);
+        if (tid == 0) s_nrm = sqrt(acc);
+    }
+    __syncthreads();
+    if (tid < D) out[(int64_t)blockIdx.x * D + tid] = (float)(s_y[tid] / s_nrm);
+}
+
 int cis_dev_apply_pca(cis_model* m, const void* dX, int x_dtype, int64_t n, float* d_out, hipStream_t st, DevBuf* ws_y) {
     CIS_REQUIRE(m->has_pca, "model has no PCA parameters");
     if (n == 0) return CIS_OK;
+    static const bool no_small = getenv("CIS_PCA_NO_SMALL") != nullptr;   // A/B runs and tests: the batched form for every n
+    if (!no_small && n <= 8 && m->renorm && m->D >= 8 && m->D <= 128 && m->D % 8 == 0 && m->D_in <= 512) {
+        if (x_dtype == CIS_F32 && m->pca_mu_f32)
+            hipLaunchKernelGGL((k_pca_small<float, true>), dim3((unsigned)n), dim3(128), 0, st, (const float*)dX, m->d_pmu, m->d_P, d_out, m->D_in, m->D);
+        else if (x_dtype == CIS_F32)
+            hipLaunchKernelGGL((k_pca_small<float, false>), dim3((unsigned)n), dim3(128), 0, st, (const float*)dX, m->d_pmu, m->d_P, d_out, m->D_in, m->D);
+        else
+            hipLaunchKernelGGL((k_pca_small<double, false>), dim3((unsigned)n), dim3(128), 0, st, (const double*)dX, m->d_pmu, m->d_P, d_out, m->D_in, m->D);
+        CIS_CHECK_HIP(hipGetLastError());
+        return CIS_OK;
+    }
     DevBuf* wy = ws_y ? ws_y : &m->ws_y64;
     CIS_TRY(wy->reserve((size_t)n * m->D * sizeof(double)));
     double* Y = wy->as<double>();

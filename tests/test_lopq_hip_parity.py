@@ -142,6 +142,20 @@ def test_encode_pca_forms_agree(monkeypatch, name):
     np.testing.assert_array_equal(fa, fb)
 
 
+@pytest.mark.parametrize("name", PCA_FIXTURES)
+def test_pca_of_a_few_rows_equals_the_batched_form(name):
+    """apply_PCA of one to eight rows runs in one launch (k_pca_small, round 6); its bits are the batched MFMA form's: the same chain of
+    fused multiply-adds over ascending k per output element, the same centring, norm order, division and cast.  Both input types."""
+    z, X, Q = load_golden(name)
+    m = hip_model(z)
+    for Xs in (X[:64], X[:64].astype(np.float64) if X.dtype == np.float32 else X[:64].astype(np.float32)):
+        big = np.asarray(m.apply_PCA(Xs)).view(np.uint32)          # 64 rows: the batched form
+        for a, b in ((0, 1), (5, 6), (10, 13), (20, 28), (63, 64)):  # 1, 1, 3, 8, 1 rows: the small form where the model's shape allows
+            got = np.asarray(m.apply_PCA(Xs[a:b])).view(np.uint32)
+            np.testing.assert_array_equal(got, big[a:b])
+        np.testing.assert_array_equal(np.asarray(m.apply_PCA(Xs[7])).view(np.uint32), big[7])   # a 1-D vector
+
+
 @pytest.mark.parametrize("name", ALL)
 def test_model_pieces(name):
     from oracle import lopq_oracle as O
