@@ -15,7 +15,7 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int GMAX = 4;
+constexpr int GMAX = 8;
 struct PSlot {
     int64_t start;   // first candidate
     int len;         // candidates
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * NW) void k_stream(const PSlot* __restrict__ sl
     constexpr int CPL = 16 / M;
     constexpr int ROW = 64 * CPL;
     constexpr int ROWB = R * M * G * 4;  // bytes of a table row
-    constexpr int ROWSH = ROWB == 256 ? 8 : (ROWB == 128 ? 7 : (ROWB == 64 ? 6 : (ROWB == 32 ? 5 : 4)));
+    constexpr int ROWSH = ROWB == 512 ? 9 : ROWB == 256 ? 8 : (ROWB == 128 ? 7 : (ROWB == 64 ? 6 : (ROWB == 32 ? 5 : 4)));
     static_assert((1 << ROWSH) == ROWB, "row bytes");
     extern __shared__ __align__(16) float s_tab[];  // [K][R][M][G]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -236,10 +236,18 @@ __global__ __launch_bounds__(64 * NW) void k_stream(const PSlot* __restrict__ sl
                                 const f32x2_t e = *reinterpret_cast<const f32x2_t*>(ep);
                                 d[u * CPL + c][0] = t == 0 ? e[0] : d[u * CPL + c][0] + e[0];
                                 d[u * CPL + c][1] = t == 0 ? e[1] : d[u * CPL + c][1] + e[1];
-                            } else {
+                            } else if constexpr (G == 4) {
                                 const f32x4_t e = *reinterpret_cast<const f32x4_t*>(ep);
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) d[u * CPL + c][g] = t == 0 ? e[g] : d[u * CPL + c][g] + e[g];
+                            } else {
+                                const f32x4_t e0 = *reinterpret_cast<const f32x4_t*>(ep);
+                                const f32x4_t e1 = *reinterpret_cast<const f32x4_t*>(ep + 16);
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    d[u * CPL + c][g] = t == 0 ? e0[g] : d[u * CPL + c][g] + e0[g];
+                                    d[u * CPL + c][4 + g] = t == 0 ? e1[g] : d[u * CPL + c][4 + g] + e1[g];
+                                }
                             }
                         }
                     }
@@ -446,7 +454,7 @@ struct Setup {
     int nq;
 };
 
-static long long g_ref_cnt[GMAX + 1] = {-1, -1, -1, -1, -1};
+static long long g_ref_cnt[GMAX + 1] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
 static unsigned long long g_ref_sum[GMAX + 1];
 
 template <int M, int G, int NW, int U, int R, int MODE, int RING, int BARE, int STG = 0, int AUX = 0, int PK = 0>
@@ -902,6 +910,22 @@ int main(int argc, char** argv) {
             run<M, 1, 8, 1, 4, 1, 1, 0, 1, 0, 2>(S, 1, 1, "8w x 1 per CU U1 (default policy)");
             run<M, 1, 8, 2, 4, 1, 1, 0, 1, 0, 2>(S, 1, 1, "8w x 1 per CU U2 (default policy)");
             run<M, 1, 8, 2, 4, 1, 1, 0, 1, 0, 2>(S, 2, 1, "8w x 2 per CU U2 (default policy)");
+        }
+    }
+    if (sel == 16) {   // eight queries per slot
+        //            M  G  NW U  R MODE RING BARE STG AUX PK
+        for (int rep = 0; rep < 2; ++rep) {
+            build_slots(4, 65536, sl, ro);
+            CHECK(hipMemcpy(S.d_slots, sl.data(), sl.size() * sizeof(PSlot), hipMemcpyHostToDevice));
+            run<M, 4, 8, 1, 2, 1, 1, 0, 2, 2, 2>(S, 2, 1, "four: 8w U1 R2 ring1 nt, builtins (the library's form)");
+            build_slots(8, 65536, sl, ro);
+            CHECK(hipMemcpy(S.d_slots, sl.data(), sl.size() * sizeof(PSlot), hipMemcpyHostToDevice));
+            run<M, 8, 8, 1, 1, 1, 1, 0, 2, 2, 2>(S, 2, 1, "eight: 8w U1 R1 ring1 nt, builtins (64 KB)");
+            run<M, 8, 8, 1, 1, 1, 1, 0, 2, 0, 2>(S, 2, 1, "eight: 8w U1 R1 ring1, default policy");
+            run<M, 8, 16, 1, 1, 1, 1, 0, 2, 2, 2>(S, 1, 1, "eight: 16w U1 R1 ring1 nt");
+            run<M, 8, 16, 1, 2, 1, 1, 0, 2, 2, 2>(S, 1, 1, "eight: 16w U1 R2 ring1 nt (128 KB, one workgroup per CU)");
+            run<M, 8, 4, 1, 1, 1, 1, 0, 2, 2, 2>(S, 2, 1, "eight: 4w x 2 U1 R1 ring1 nt");
+            run<M, 8, 4, 2, 1, 1, 1, 0, 2, 2, 2>(S, 2, 1, "eight: 4w x 2 U2 R1 ring1 nt");
         }
     }
     return 0;
