@@ -1284,7 +1284,15 @@ __global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict
         const double v = pw_leaf<double>(elem, 0, W);
         const float v32 = (float)v;
         if (on) {
+            // NON-TEMPORAL: the float64 copy (2/3 of the bytes this kernel writes) is read sparsely, by the merge, much later; written with
+            // the default policy it pushed the float32 copy -- which the scan stages next -- and the codes out of L2 / Infinity Cache.
+            // Round 6, same box, median of two runs each: C4 21.3 -> 21.8 M queries/s (scan 0.233 -> 0.230 ms), C2 19.7 -> 21.1 M
+            // (scan 0.157 -> 0.152, merge 0.115 -> 0.105 ms).  -DCIS_TABLES_NO_NT: the default policy (A/B).
+#ifndef CIS_TABLES_NO_NT
+            __builtin_nontemporal_store(v, &T[((int64_t)(t0 + t) * nf + j) * K + k]);
+#else
             T[((int64_t)(t0 + t) * nf + j) * K + k] = v;
+#endif
             if (T32) T32[((int64_t)(t0 + t) * nf + j) * K + k] = v32;  // (null: the scans convert the float64 entries themselves, see tab_f4)
         }
         // largest float32 entry of the table (entries are >= 0: the bit patterns order like the values), for the

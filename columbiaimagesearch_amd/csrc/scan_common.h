@@ -146,7 +146,7 @@ static __device__ __forceinline__ double adc64_words(const uint32_t (&cw)[(M + 3
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         const uint32_t c = (cw[j >> 2] >> (8 * (j & 3))) & 255u;
-        f[j] = (j < nf) ? t0[j * K + c] : t1[(j - nf) * K + c];
+        f[j] = (j < nf) ? t0[j * K + c] : t1[(j - nf) * K + c];   // (non-temporal loads here: the merge 0.104 -> 0.119 ms on C2, round 6)
     }
     double d = f[0];
 #pragma unroll
@@ -231,7 +231,7 @@ __device__ __forceinline__ CodeWords<M> load_code_buf(__amdgpu_buffer_rsrc_t rs,
 // the batch has one, else converted from the float64 tables (round 5: the copy is a third of the tables kernel's writes -- 402 MB per C2
 // batch -- and (float)T is the value the copy holds, so the scans see the same bits either way).
 static __device__ __forceinline__ float4 tab_f4(const float* __restrict__ T32, const double* __restrict__ T, int64_t tab, int nfK, int e4) {
-    if (T32) return reinterpret_cast<const float4*>(T32 + tab * nfK)[e4];
+    if (T32) return reinterpret_cast<const float4*>(T32 + tab * nfK)[e4];   // (non-temporal loads here: no effect, round 6 same-box A/B)
     const double2* p = reinterpret_cast<const double2*>(T + tab * nfK) + 2 * e4;
     const double2 a = p[0], b = p[1];
     return make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
