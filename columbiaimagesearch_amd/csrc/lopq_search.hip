@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(256) void k_tables_from_px(const double* __restrict
 #else
             T[((int64_t)(t0 + t) * nf + j) * K + k] = v;
 #endif
-            if (T32) T32[((int64_t)(t0 + t) * nf + j) * K + k] = v32;  // (null: the scans convert the float64 entries themselves, see tab_f4)
+            if (T32) T32[((int64_t)(t0 + t) * nf + j) * K + k] = v32;  // (null: the scans convert the float64 entries themselves, see tab_f4; stored non-temporal too: no gain)
         }
         // largest float32 entry of the table (entries are >= 0: the bit patterns order like the values), for the
         // fixed-point scan's scale (lopq_scan3.hip); TabDesc::pad was zeroed when the descriptor was written
