@@ -1604,8 +1604,8 @@ def main():
                     help="N > 1: time the bare RCCL collectives of the protocols' payload sizes (all-gather counts / payload, all-to-all query blocks / "
                          "ranked lists, the small ones), print them and stop -- the first thing to run on a new node")
     ap.add_argument("--no-routed", action="store_true", help="N > 1: skip the routed protocol (the headline is then the all-gather protocol at 8192 queries per step)")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("CIS_BENCH_PIPELINE", 3)),
-                    help="N = 1: query batches in flight at once (each through its own view of the index on its own stream); 1 = one after the other")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("CIS_BENCH_PIPELINE", 0)),
+                    help="N = 1: query batches in flight at once (each through its own view of the index on its own stream; default 4, at N > 1 three partial searches per rank); 1 = one after the other")
     ap.add_argument("--no-configs", action="store_true", help="skip the c2 / c3 / c5 sub-runs of the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cnn", action="store_true")
@@ -1630,7 +1630,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = ctx.device = torch.device("cuda", local_rank)
     wd = ctx.wd = Watchdog(rank)
-    ctx.pipeline = args.pipeline
+    # batches in flight: FOUR on one GPU (round 6, same-box A/B of three runs each: C4 21.8-21.9 -> 22.0-22.4 M queries/s, C2 20.6-20.7 ->
+    # 20.7-21.0 M; five lose), three partial searches in flight per rank at N > 1 (the exchange runs beside them)
+    ctx.pipeline = args.pipeline if args.pipeline > 0 else (4 if world == 1 else 3)
     from columbiaimagesearch_amd import _lib
     _lib.check(_lib.lib().cis_set_device(local_rank))
     # CIS_BENCH_FORCE_DIST=1 runs the sharded code path (process group, all-gather, merge) even with one
