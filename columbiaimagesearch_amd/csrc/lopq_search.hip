@@ -301,13 +301,14 @@ __global__ __launch_bounds__(64) void k_front_small(const CT* __restrict__ X /* 
 //      list holds: the query is flagged and the frontier walk above (k_plan with `only`) handles it.
 // The count pass leaves the visited (i, j) list in global memory for the emit pass.
 #ifdef CIS_PLAN_DBG  // tools/build_variant.sh plandbg -DCIS_PLAN_DBG: probes / bands / cycles per phase of k_plan_par's count pass
-__device__ unsigned long long g_plan_dbg[8];
+__device__ unsigned long long g_plan_dbg[12];
 #define PLAN_DBG(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_plan_dbg[i], (unsigned long long)(v)); } while (0)
 #else
 #define PLAN_DBG(i, v) do { } while (0)
 #endif
 static const int PLAN_PAR_CAP = 2048;   // cells a workgroup enumerates and sorts per band
 static const int PLAN_PAR_STAGE = 4096; // d0 / d1 staged in LDS: the kernel takes V <= 4096
+static const int PLAN_NB_LOG = 10, PLAN_NB = 1 << PLAN_NB_LOG;  // buckets of a band's distribution sort
 
 // all of d0 / d1 is staged in LDS (V <= PLAN_PAR_STAGE); read in place (no generic pointers to the LDS arrays)
 #define PL0(i) s_d0[(i)]
@@ -331,9 +332,12 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
     extern __shared__ __align__(16) unsigned char s_plan_dyn[];  // d0, d1: 2 V values (count pass; two workgroups per CU at V = 2048)
     CT* s_d0 = reinterpret_cast<CT*>(s_plan_dyn);
     CT* s_d1 = s_d0 + V;
+    __shared__ int s_hist[PLAN_NB];  // the band's distribution sort: bucket sizes, then bucket starts
     __shared__ int64_t s_red[8];
     __shared__ int s_i[8];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long dbg_k0 = wall_clock64();
+    (void)dbg_k0;
     const CT* d0 = sorted + ((int64_t)q * 2 + 0) * V;
     const CT* d1 = sorted + ((int64_t)q * 2 + 1) * V;
     const uint16_t* o0 = order + ((int64_t)q * 2 + 0) * V;
@@ -407,27 +411,36 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
         const int ns = V < PLAN_PAR_STAGE ? V : PLAN_PAR_STAGE;
         for (int i = tid; i < ns; i += 256) { s_d0[i] = d0[i]; s_d1[i] = d1[i]; }
         __syncthreads();
-        // prefix length of row i under tau: #{j : fl(d0[i] + d1[j]) <= tau}
-        auto row_prefix = [&](CT a, uint64_t tau) -> int {
-            int lo = 0, hi = V;  // first j with sum > tau
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (f2bits((CT)(a + PL1(mid))) <= tau) lo = mid + 1;
-                else hi = mid;
+        // A thread owns the rows i = tid + 256 k and keeps three prefix lengths of each in registers: under the last band's tau
+        // (`pprev`), under the bisection's lower end (`plo`: a tau below every later probe) and under its upper end (`phi`, exact).
+        // A probe searches [plo, phi] only -- a step or two instead of log2 V -- and the band's enumeration needs no search at all.
+        constexpr int KR = PLAN_PAR_STAGE / 256;
+        int pprev[KR], plo[KR], phi[KR];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) { pprev[k] = 0; plo[k] = 0; phi[k] = 0; }
+        // first j of [lo_, hi_] with fl(a + d1[j]) > tau (hi_ when there is none below it)
+        auto prefix_in = [&](CT a, uint64_t tau, int lo_, int hi_) -> int {
+            while (lo_ < hi_) {
+                const int mid = (lo_ + hi_) >> 1;
+                if (f2bits((CT)(a + PL1(mid))) <= tau) lo_ = mid + 1;
+                else hi_ = mid;
             }
-            return lo;
+            return lo_;
         };
-        auto count_le = [&](uint64_t tau) -> int64_t {
-            int64_t c = 0;
-            for (int i = tid; i < V; i += 256) {
-                const CT a = PL0(i);
-                if (f2bits((CT)(a + PL1(0))) > tau) break;  // rows are ascending too
-                c += row_prefix(a, tau);
+        // rows with a cell under tau: first i with fl(d0[i] + d1[0]) > tau (every thread reads the same words: a uniform value)
+        auto rows_under = [&](uint64_t tau) -> int {
+            int lo_ = 0, hi_ = V;
+            const CT b0 = PL1(0);
+            while (lo_ < hi_) {
+                const int mid = (lo_ + hi_) >> 1;
+                if (f2bits((CT)(PL0(mid) + b0)) <= tau) lo_ = mid + 1;
+                else hi_ = mid;
             }
-            return block_sum(c);
+            return __builtin_amdgcn_readfirstlane(lo_);
         };
         // Bands of increasing tau: band b holds the cells with tau_{b-1} < s <= tau_b (at most PLAN_PAR_CAP of them), is
         // sorted on its own and appended to the visited list; the quota prefix sum carries over.
+        PLAN_DBG(8, wall_clock64() - dbg_k0);
         bool fb = false, done = false;
         int visited = 0;
         int64_t cum = 0, c_prev = 0, target = 256;
@@ -444,80 +457,125 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
         uint64_t tau_prev = 0;
         const int64_t all_cells = (int64_t)V * V;
         const uint64_t s_min = f2bits((CT)(PL0(0) + PL1(0)));
-        const uint64_t s_max = f2bits((CT)(s_d0[V - 1] + s_d1[V - 1]));
         if (quota <= 0) { target = 1; }  // the test follows the first append (search.py:131-132): one cell
         while (!done && !fb) {
             const int64_t left = all_cells - c_prev;
             if (left <= 0) break;  // every cell visited, quota not reached
             const int64_t want = target < left ? target : left;
-            // tau with want <= #{tau_prev < s <= tau} <= 2 * want (or the smallest tau that reaches `want` when values repeat)
-            uint64_t lo = have_prev ? tau_prev + 1 : s_min, hi = s_max;
-            int64_t c_hi = all_cells;
+            // tau with want <= #{tau_prev < s <= tau} <= 2 * want (or the smallest tau that reaches `want` when values repeat).
+            // Upper end to start from: the a x a square of rank pairs lies under fl(d0[a-1] + d1[a-1]) (the sums are monotone in both
+            // ranks), so with a * a >= c_prev + want that tau holds the band; it is ~2 x too large (the region under a tau is closer to
+            // a triangle than a square), so a few probes finish -- and every probe sees few active rows (from s_max the first probes
+            // searched all V rows).
+            const uint64_t lo_key = have_prev ? tau_prev + 1 : s_min;
+            uint64_t lo = lo_key, hi;
+            {
+                const int64_t need = c_prev + want;
+                int64_t a = (int64_t)sqrt((double)need);
+                while (a * a < need) ++a;
+                while (a > 1 && (a - 1) * (a - 1) >= need) --a;
+                if (a > V) a = V;
+                hi = f2bits((CT)(PL0((int)a - 1) + PL1((int)a - 1)));
+            }
             const long long dbg_t0 = wall_clock64();
             (void)dbg_t0;
+            const int R0 = rows_under(hi);
+            int64_t c_hi;
+            {
+                int64_t c = 0;
+#pragma unroll
+                for (int k = 0; k < KR; ++k) {
+                    plo[k] = pprev[k];
+                    phi[k] = pprev[k];
+                    if (k * 256 < R0) {
+                        const int i = k * 256 + tid;
+                        if (i < R0) phi[k] = prefix_in(PL0(i), hi, pprev[k], V);
+                        c += phi[k];
+                    }
+                }
+                c_hi = block_sum(c);
+                PLAN_DBG(0, 1);
+            }
             while (c_hi - c_prev > 2 * want && lo < hi) {
                 const uint64_t mid = lo + ((hi - lo) >> 1);
-                const int64_t c = count_le(mid);
+                int pm[KR];
+                int64_t c = 0;
+#pragma unroll
+                for (int k = 0; k < KR; ++k) {
+                    pm[k] = plo[k];
+                    if (k * 256 < R0) {
+                        const int i = k * 256 + tid;
+                        if (i < R0) pm[k] = prefix_in(PL0(i), mid, plo[k], phi[k]);
+                        c += pm[k];
+                    }
+                }
+                c = block_sum(c);
                 PLAN_DBG(0, 1);
-                if (c - c_prev >= want) { hi = mid; c_hi = c; }
-                else lo = mid + 1;
+                if (c - c_prev >= want) {
+                    hi = mid; c_hi = c;
+#pragma unroll
+                    for (int k = 0; k < KR; ++k) phi[k] = pm[k];
+                } else {
+                    lo = mid + 1;
+#pragma unroll
+                    for (int k = 0; k < KR; ++k) plo[k] = pm[k];
+                }
             }
             PLAN_DBG(1, 1);
             PLAN_DBG(2, wall_clock64() - dbg_t0);
             if (c_hi - c_prev > PLAN_PAR_CAP) { fb = true; break; }
             const int cnt = (int)(c_hi - c_prev);
             if (visited + cnt > vis_cap) { fb = true; break; }
-            // enumerate the band.  (a) per row: cells (p_prev, p_hi]; first slot of every row in s_gc[i] (rows in order)
-            int run = 0, rows = 0;
-            for (int b0 = 0; b0 < V; b0 += 256) {
-                const int i = b0 + tid;
-                int p = 0;
-                bool act = false;
-                if (i < V) {
-                    const CT a = PL0(i);
-                    act = f2bits((CT)(a + PL1(0))) <= hi;
-                    if (act) p = row_prefix(a, hi) - (have_prev ? row_prefix(a, tau_prev) : 0);
-                }
-                int x = p;
+            // enumerate the band.  (a) per row: cells [pprev, phi); s_gc[i] = first slot of the row | pprev << 12 (rows in order)
+            const int rows = rows_under(hi);
+            for (int x = tid; x < PLAN_NB; x += 256) s_hist[x] = 0;
+            int run = 0;
 #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int y = __shfl_up(x, d);
-                    if (lane >= d) x += y;
+            for (int k = 0; k < KR; ++k) {
+                if (k * 256 < rows) {
+                    const int i = k * 256 + tid;
+                    const int p = i < rows ? phi[k] - pprev[k] : 0;
+                    int x = p;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const int y = __shfl_up(x, d);
+                        if (lane >= d) x += y;
+                    }
+                    __syncthreads();
+                    if (lane == 63) s_i[wv] = x;
+                    __syncthreads();
+                    int base = run;
+                    for (int w = 0; w < wv; ++w) base += s_i[w];
+                    if (i < rows) s_gc[i] = (uint32_t)(base + x - p) | ((uint32_t)pprev[k] << 12);
+                    run += s_i[0] + s_i[1] + s_i[2] + s_i[3];
                 }
-                __syncthreads();
-                if (lane == 63) s_i[wv] = x;
-                __syncthreads();
-                int base = run;
-                for (int w = 0; w < wv; ++w) base += s_i[w];
-                if (act) s_gc[i] = (uint32_t)(base + x - p);
-                run += s_i[0] + s_i[1] + s_i[2] + s_i[3];
-                const int nact = (int)block_sum(act ? 1 : 0);
-                rows += nact;
-                if (nact < 256) break;  // the active rows are a prefix (ascending d0): this was the last block of them
             }
+            __syncthreads();
+            PLAN_DBG(5, wall_clock64() - dbg_t0);
             // (b) one thread per cell: row by binary search over the row starts (the LAST row whose start is <= e is the
             // one that holds e: empty rows share their start with the next row), then sum, rank pair and GLOBAL cell size
             constexpr int PER = PLAN_PAR_CAP / 256;
             // (the global reads of the thread's PER cells go out together, level by level -- cluster ids, then sizes: as
             // `if (e < cnt) { ... gcount[o0[i] * V + o1[j]] }` per cell they were 2 x PER round trips in a row, ~25 us per band)
-            uint32_t gsz[PER];
+            uint32_t eij[PER];
+            uint64_t ekey[PER];
             int ei[PER], ej[PER];
 #pragma unroll
             for (int r = 0; r < PER; ++r) {
                 const int e = r * 256 + tid;
-                ei[r] = 0; ej[r] = 0;
+                ei[r] = 0; ej[r] = 0; ekey[r] = 0; eij[r] = 0;
                 if (e < cnt) {
                     int lo_ = 0, hi_ = rows;  // first row whose start is > e
                     while (lo_ < hi_) {
                         const int mid = (lo_ + hi_) >> 1;
-                        if ((int)s_gc[mid] <= e) lo_ = mid + 1;
+                        if ((int)(s_gc[mid] & 0xfffu) <= e) lo_ = mid + 1;
                         else hi_ = mid;
                     }
                     const int i = lo_ - 1;
-                    const CT a = PL0(i);
-                    const int j = e - (int)s_gc[i] + (have_prev ? row_prefix(a, tau_prev) : 0);
-                    s_key[e] = f2bits((CT)(a + PL1(j)));
-                    s_ij[e] = ((uint32_t)i << 16) | (uint32_t)j;
+                    const uint32_t w = s_gc[i];
+                    const int j = e - (int)(w & 0xfffu) + (int)(w >> 12);
+                    ekey[r] = f2bits((CT)(PL0(i) + PL1(j)));
+                    eij[r] = ((uint32_t)i << 16) | (uint32_t)j;
                     ei[r] = i; ej[r] = j;
                 }
             }
@@ -527,38 +585,83 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
             int64_t gg[PER];
 #pragma unroll
             for (int r = 0; r < PER; ++r) gg[r] = gcount[(int64_t)ci[r] * V + cj[r]];
+            // Sort by (s, i, j) as a distribution sort: the keys lie in (tau_prev, tau], a bucket is a slice of that range (the key
+            // minus its lower end, shifted down to PLAN_NB values: monotone), a cell takes the next slot of its bucket (an LDS counter),
+            // the buckets' sizes are scanned, and a cell's rank is its bucket's start + the cells of the bucket that order before it (a
+            // cell or two per bucket; tied sums pile up in one bucket and are ordered by the rank pair there -- quadratic only in the
+            // size of a tie group).  The bitonic network this replaces was 32-47 us of a band's ~80 us.
+            int bk[PER], slot[PER];
+            {
+                const uint64_t range = hi - lo_key;
+                const int nbits = range ? 64 - __builtin_clzll(range) : 0;
+                const int shift = nbits > PLAN_NB_LOG ? nbits - PLAN_NB_LOG : 0;
 #pragma unroll
-            for (int r = 0; r < PER; ++r) {
-                const int e = r * 256 + tid;
-                gsz[r] = e < cnt ? (gg[r] > 0x7fffffffll ? 0x7fffffffu : (uint32_t)gg[r]) : 0u;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < PER; ++r) {
-                const int e = r * 256 + tid;
-                if (e < cnt) s_gc[e] = gsz[r];
-            }
-            int ns2 = 256;
-            while (ns2 < cnt) ns2 <<= 1;
-            for (int x = cnt + tid; x < ns2; x += 256) { s_key[x] = ~0ull; s_ij[x] = ~0u; s_gc[x] = 0u; }
-            __syncthreads();
-            for (int k = 2; k <= ns2; k <<= 1) {
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int t = tid; t < (ns2 >> 1); t += 256) {
-                        const int a_ = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                        const int b_ = a_ + j;
-                        const bool asc = ((a_ & k) == 0);
-                        const uint64_t ka = s_key[a_], kb = s_key[b_];
-                        const uint32_t ia = s_ij[a_], ib = s_ij[b_];
-                        const bool gt = (ka > kb) || (ka == kb && ia > ib);
-                        if (gt == asc) {
-                            s_key[a_] = kb; s_key[b_] = ka; s_ij[a_] = ib; s_ij[b_] = ia;
-                            const uint32_t ga = s_gc[a_]; s_gc[a_] = s_gc[b_]; s_gc[b_] = ga;
-                        }
+                for (int r = 0; r < PER; ++r) {
+                    const int e = r * 256 + tid;
+                    bk[r] = 0; slot[r] = 0;
+                    if (e < cnt) {
+                        bk[r] = (int)((ekey[r] - lo_key) >> shift);
+                        slot[r] = atomicAdd(&s_hist[bk[r]], 1);
                     }
-                    __syncthreads();
                 }
             }
+            __syncthreads();
+            {   // exclusive scan of the bucket sizes, in place (thread t: buckets [t * NBT, (t + 1) * NBT))
+                constexpr int NBT = PLAN_NB / 256;
+                int hb[NBT], sum = 0;
+#pragma unroll
+                for (int u = 0; u < NBT; ++u) { hb[u] = s_hist[tid * NBT + u]; sum += hb[u]; }
+                int x = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int y = __shfl_up(x, d);
+                    if (lane >= d) x += y;
+                }
+                if (lane == 63) s_i[wv] = x;
+                __syncthreads();
+                int base = x - sum;
+                for (int w = 0; w < wv; ++w) base += s_i[w];
+#pragma unroll
+                for (int u = 0; u < NBT; ++u) { s_hist[tid * NBT + u] = base; base += hb[u]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int e = r * 256 + tid;
+                if (e < cnt) {
+                    const int pos = s_hist[bk[r]] + slot[r];
+                    s_key[pos] = ekey[r]; s_ij[pos] = eij[r];
+                }
+            }
+            __syncthreads();
+            int rk[PER];
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int e = r * 256 + tid;
+                rk[r] = 0;
+                if (e < cnt) {
+                    const int bb = s_hist[bk[r]], be = bk[r] + 1 < PLAN_NB ? s_hist[bk[r] + 1] : cnt;
+                    int rank = bb;
+                    for (int p = bb; p < be; ++p) {
+                        const uint64_t k2 = s_key[p];
+                        const uint32_t i2 = s_ij[p];
+                        rank += (k2 < ekey[r] || (k2 == ekey[r] && i2 < eij[r])) ? 1 : 0;
+                    }
+                    rk[r] = rank;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int e = r * 256 + tid;
+                if (e < cnt) {
+                    s_key[rk[r]] = ekey[r]; s_ij[rk[r]] = eij[r];
+                    s_gc[rk[r]] = gg[r] > 0x7fffffffll ? 0x7fffffffu : (uint32_t)gg[r];
+                }
+            }
+            __syncthreads();
+            PLAN_DBG(6, wall_clock64() - dbg_t0);
+            PLAN_DBG(7, wall_clock64() - dbg_t0);
             // quota cut inside this band: first position whose inclusive prefix of the cell sizes reaches the quota
             int64_t run64 = cum;
             int cut = -1;
@@ -596,6 +699,8 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
             c_prev = c_hi;
             tau_prev = hi;
             have_prev = true;
+#pragma unroll
+            for (int k = 0; k < KR; ++k) pprev[k] = phi[k];
             // the next band: the cells the quota still needs at the candidates per cell seen so far, + 25 % (round 4).  Four times the
             // last target made the second band of a V = 2048 query 1024 ... 2048 cells when ~300 more were needed: the band's
             // enumeration and its sort (n log^2 n) were most of the count pass (tools/build_variant.sh plandbg -DCIS_PLAN_DBG).
@@ -611,6 +716,7 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
             }
             __syncthreads();
         }
+        PLAN_DBG(9, wall_clock64() - dbg_k0);
         if (tid == 0) fallback[q] = fb ? 1 : 0;
         if (fb) return;
         if (tid == 0 && hint && quota > 0) {
@@ -646,6 +752,7 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
         __syncthreads();
         max_i = s_i[0]; max_j = s_i[4];
         for (int w = 1; w < 4; ++w) { max_i = s_i[w] > max_i ? s_i[w] : max_i; max_j = s_i[4 + w] > max_j ? s_i[4 + w] : max_j; }
+        PLAN_DBG(10, wall_clock64() - dbg_k0);
         if (tid == 0) {
             PlanOut p;
             p.visited = visited; p.n_items = (int)n_items; p.ntab0 = max_i + 1; p.ntab1 = max_j + 1; p.ncand = ncand;
@@ -655,6 +762,7 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
             const int g = i <= max_i ? (int)o0[i] : V + (int)o1[i - (max_i + 1)];
             atomicAdd(&grp_cnt[g * GRP_SUB + (q % GRP_SUB)], 1);
         }
+        PLAN_DBG(11, wall_clock64() - dbg_k0);
     }
 }
 
@@ -4706,11 +4814,12 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
                                nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap, plan_hint, hint_slot);
 #ifdef CIS_PLAN_DBG
         if (par_plan) {
-            unsigned long long h[8];
+            unsigned long long h[12];
             (void)hipDeviceSynchronize();
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_plan_dbg), sizeof(h));
-            fprintf(stderr, "[cis] k_plan_par: %d queries, probes %.1f / query, bands %.2f / query, bisection %.1f us / query, bisection + enumeration + sort + cut %.1f us / query, cells per band %.0f (100 MHz clock)\n",
-                    nq, (double)h[0] / nq, (double)h[1] / nq, (double)h[2] / nq / 100.0, (double)h[3] / nq / 100.0, h[1] ? (double)h[4] / (double)h[1] : 0.0);
+            fprintf(stderr, "[cis] k_plan_par: %d queries, probes %.1f / query, bands %.2f / query, bisection %.1f us / query, after rows %.1f, after cells %.1f, after sort %.1f, after cut %.1f us / query (cumulative), cells per band %.0f (100 MHz clock)\n",
+                    nq, (double)h[0] / nq, (double)h[1] / nq, (double)h[2] / nq / 100.0, (double)h[5] / nq / 100.0, (double)h[6] / nq / 100.0, (double)h[7] / nq / 100.0, (double)h[3] / nq / 100.0, h[1] ? (double)h[4] / (double)h[1] : 0.0);
+            fprintf(stderr, "[cis] k_plan_par since kernel start: staged %.1f, bands done %.1f, visited pass %.1f, end %.1f us / query\n", (double)h[8] / nq / 100.0, (double)h[9] / nq / 100.0, (double)h[10] / nq / 100.0, (double)h[11] / nq / 100.0);
             memset(h, 0, sizeof(h));
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_plan_dbg), h, sizeof(h));
         }
