@@ -311,11 +311,17 @@ static const int PLAN_PAR_STAGE = 4096; // d0 / d1 staged in LDS: the kernel tak
 static const int PLAN_NB_LOG = 10, PLAN_NB = 1 << PLAN_NB_LOG;  // buckets of a band's distribution sort
 
 // all of d0 / d1 is staged in LDS (V <= PLAN_PAR_STAGE); read in place (no generic pointers to the LDS arrays)
-#define PL0(i) s_d0[(i)]
-#define PL1(i) s_d1[(i)]
+#ifndef CIS_PLAN_WPE
+#define CIS_PLAN_WPE 3
+#endif
+static const int PLAN_SP = 1024;        // ... of which the first PLAN_SP ranks of either list are staged in LDS (the rest is read in place)
+template <typename CT> struct PlanKeyT { typedef uint64_t type; };
+template <> struct PlanKeyT<float> { typedef uint32_t type; };
+#define PL0(i) ((i) < SP ? s_d0[(i)] : d0[(i)])
+#define PL1(i) ((i) < SP ? s_d1[(i)] : d1[(i)])
 
 template <typename CT, bool EMIT>
-__global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted, const uint16_t* __restrict__ order,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIS_PLAN_WPE))) void k_plan_par(const CT* __restrict__ sorted, const uint16_t* __restrict__ order,
                                                   const int64_t* __restrict__ gcount, const int64_t* __restrict__ loff,
                                                   int nq, int V, int64_t quota, int seg_max, PlanOut* __restrict__ plan,
                                                   const int64_t* __restrict__ item_off, const int64_t* __restrict__ tab_off,
@@ -326,12 +332,16 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
                                                   int* __restrict__ fallback /* [nq] */, int vis_cap,
                                                   unsigned long long* __restrict__ hint /* null, or [2][2]: (cells visited, quota) summed over the
                                                   queries of the launches of either parity (count pass) */, int hint_slot) {
-    __shared__ uint64_t s_key[PLAN_PAR_CAP];
+    __shared__ typename PlanKeyT<CT>::type s_key[PLAN_PAR_CAP];
     __shared__ uint32_t s_ij[PLAN_PAR_CAP];
     __shared__ uint32_t s_gc[PLAN_PAR_STAGE];  // row starts of the band (one per active row, <= V), then the cells' sizes (<= PLAN_PAR_CAP)
-    extern __shared__ __align__(16) unsigned char s_plan_dyn[];  // d0, d1: 2 V values (count pass; two workgroups per CU at V = 2048)
+    // d0, d1: the first SP ranks of either (count pass).  A query of the release operating points touches a few hundred ranks; staging
+    // all 2 x 4096 took 32 KB and held the kernel at two workgroups per CU -- it is bound by latency (barriers, dependent LDS and
+    // global reads), three hide more of it.
+    extern __shared__ __align__(16) unsigned char s_plan_dyn[];
+    const int SP = V < PLAN_SP ? V : PLAN_SP;
     CT* s_d0 = reinterpret_cast<CT*>(s_plan_dyn);
-    CT* s_d1 = s_d0 + V;
+    CT* s_d1 = s_d0 + SP;
     __shared__ int s_hist[PLAN_NB];  // the band's distribution sort: bucket sizes, then bucket starts
     __shared__ int64_t s_red[8];
     __shared__ int s_i[8];
@@ -408,16 +418,16 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
         }
         return;
     } else {
-        const int ns = V < PLAN_PAR_STAGE ? V : PLAN_PAR_STAGE;
-        for (int i = tid; i < ns; i += 256) { s_d0[i] = d0[i]; s_d1[i] = d1[i]; }
+        for (int i = tid; i < SP; i += 256) { s_d0[i] = d0[i]; s_d1[i] = d1[i]; }
         __syncthreads();
         // A thread owns the rows i = tid + 256 k and keeps three prefix lengths of each in registers: under the last band's tau
         // (`pprev`), under the bisection's lower end (`plo`: a tau below every later probe) and under its upper end (`phi`, exact).
         // A probe searches [plo, phi] only -- a step or two instead of log2 V -- and the band's enumeration needs no search at all.
         constexpr int KR = PLAN_PAR_STAGE / 256;
-        int pprev[KR], plo[KR], phi[KR];
+        int pprev[KR];
+        uint32_t pbr[KR];  // plo | phi << 16 (prefix lengths <= 4096)
 #pragma unroll
-        for (int k = 0; k < KR; ++k) { pprev[k] = 0; plo[k] = 0; phi[k] = 0; }
+        for (int k = 0; k < KR; ++k) { pprev[k] = 0; pbr[k] = 0; }
         // first j of [lo_, hi_] with fl(a + d1[j]) > tau (hi_ when there is none below it)
         auto prefix_in = [&](CT a, uint64_t tau, int lo_, int hi_) -> int {
             while (lo_ < hi_) {
@@ -427,10 +437,22 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
             }
             return lo_;
         };
+        // the same over [lo_, V]: the staged part first
+        auto prefix_from = [&](CT a, uint64_t tau, int lo_) -> int {
+            if (SP < V && lo_ < SP) {
+                if (f2bits((CT)(a + s_d1[SP - 1])) > tau) return prefix_in(a, tau, lo_, SP - 1);
+                lo_ = SP;
+            }
+            return prefix_in(a, tau, lo_, V);
+        };
         // rows with a cell under tau: first i with fl(d0[i] + d1[0]) > tau (every thread reads the same words: a uniform value)
         auto rows_under = [&](uint64_t tau) -> int {
             int lo_ = 0, hi_ = V;
-            const CT b0 = PL1(0);
+            const CT b0 = s_d1[0];
+            if (SP < V) {
+                if (f2bits((CT)(s_d0[SP - 1] + b0)) > tau) hi_ = SP - 1;
+                else lo_ = SP;
+            }
             while (lo_ < hi_) {
                 const int mid = (lo_ + hi_) >> 1;
                 if (f2bits((CT)(PL0(mid) + b0)) <= tau) lo_ = mid + 1;
@@ -485,27 +507,27 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
                 int64_t c = 0;
 #pragma unroll
                 for (int k = 0; k < KR; ++k) {
-                    plo[k] = pprev[k];
-                    phi[k] = pprev[k];
+                    int ph = pprev[k];
                     if (k * 256 < R0) {
                         const int i = k * 256 + tid;
-                        if (i < R0) phi[k] = prefix_in(PL0(i), hi, pprev[k], V);
-                        c += phi[k];
+                        if (i < R0) ph = prefix_from(PL0(i), hi, pprev[k]);
+                        c += ph;
                     }
+                    pbr[k] = (uint32_t)pprev[k] | ((uint32_t)ph << 16);
                 }
                 c_hi = block_sum(c);
                 PLAN_DBG(0, 1);
             }
             while (c_hi - c_prev > 2 * want && lo < hi) {
                 const uint64_t mid = lo + ((hi - lo) >> 1);
-                int pm[KR];
+                uint16_t pm[KR];
                 int64_t c = 0;
 #pragma unroll
                 for (int k = 0; k < KR; ++k) {
-                    pm[k] = plo[k];
+                    pm[k] = (uint16_t)(pbr[k] & 0xffffu);
                     if (k * 256 < R0) {
                         const int i = k * 256 + tid;
-                        if (i < R0) pm[k] = prefix_in(PL0(i), mid, plo[k], phi[k]);
+                        if (i < R0) pm[k] = (uint16_t)prefix_in(PL0(i), mid, (int)(pbr[k] & 0xffffu), (int)(pbr[k] >> 16));
                         c += pm[k];
                     }
                 }
@@ -514,11 +536,11 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
                 if (c - c_prev >= want) {
                     hi = mid; c_hi = c;
 #pragma unroll
-                    for (int k = 0; k < KR; ++k) phi[k] = pm[k];
+                    for (int k = 0; k < KR; ++k) pbr[k] = (pbr[k] & 0xffffu) | ((uint32_t)pm[k] << 16);
                 } else {
                     lo = mid + 1;
 #pragma unroll
-                    for (int k = 0; k < KR; ++k) plo[k] = pm[k];
+                    for (int k = 0; k < KR; ++k) pbr[k] = (pbr[k] & 0xffff0000u) | (uint32_t)pm[k];
                 }
             }
             PLAN_DBG(1, 1);
@@ -534,7 +556,7 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
             for (int k = 0; k < KR; ++k) {
                 if (k * 256 < rows) {
                     const int i = k * 256 + tid;
-                    const int p = i < rows ? phi[k] - pprev[k] : 0;
+                    const int p = i < rows ? (int)(pbr[k] >> 16) - pprev[k] : 0;
                     int x = p;
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) {
@@ -630,7 +652,7 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
                 const int e = r * 256 + tid;
                 if (e < cnt) {
                     const int pos = s_hist[bk[r]] + slot[r];
-                    s_key[pos] = ekey[r]; s_ij[pos] = eij[r];
+                    s_key[pos] = (typename PlanKeyT<CT>::type)ekey[r]; s_ij[pos] = eij[r];
                 }
             }
             __syncthreads();
@@ -643,7 +665,7 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
                     const int bb = s_hist[bk[r]], be = bk[r] + 1 < PLAN_NB ? s_hist[bk[r] + 1] : cnt;
                     int rank = bb;
                     for (int p = bb; p < be; ++p) {
-                        const uint64_t k2 = s_key[p];
+                        const uint64_t k2 = (uint64_t)s_key[p];
                         const uint32_t i2 = s_ij[p];
                         rank += (k2 < ekey[r] || (k2 == ekey[r] && i2 < eij[r])) ? 1 : 0;
                     }
@@ -655,7 +677,7 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
             for (int r = 0; r < PER; ++r) {
                 const int e = r * 256 + tid;
                 if (e < cnt) {
-                    s_key[rk[r]] = ekey[r]; s_ij[rk[r]] = eij[r];
+                    s_key[rk[r]] = (typename PlanKeyT<CT>::type)ekey[r]; s_ij[rk[r]] = eij[r];
                     s_gc[rk[r]] = gg[r] > 0x7fffffffll ? 0x7fffffffu : (uint32_t)gg[r];
                 }
             }
@@ -700,7 +722,7 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
             tau_prev = hi;
             have_prev = true;
 #pragma unroll
-            for (int k = 0; k < KR; ++k) pprev[k] = phi[k];
+            for (int k = 0; k < KR; ++k) pprev[k] = (int)(pbr[k] >> 16);
             // the next band: the cells the quota still needs at the candidates per cell seen so far, + 25 % (round 4).  Four times the
             // last target made the second band of a V = 2048 query 1024 ... 2048 cells when ~300 more were needed: the band's
             // enumeration and its sort (n log^2 n) were most of the count pass (tools/build_variant.sh plandbg -DCIS_PLAN_DBG).
@@ -727,16 +749,29 @@ __global__ __launch_bounds__(256) void k_plan_par(const CT* __restrict__ sorted,
         __syncthreads();
         int64_t n_items = 0, ncand = 0;
         int max_i = -1, max_j = -1;
-        for (int idx = tid; idx < visited; idx += 256) {
-            const uint32_t ij = vl[idx];
-            const int bi = (int)(ij >> 16), bj = (int)(ij & 0xffff);
-            const int64_t cell = (int64_t)o0[bi] * V + o1[bj];
-            const int64_t ll = loff[(int64_t)V * V + 1 + cell] - loff[cell];
-            if (ll > 0) {
-                n_items += (ll + seg_max - 1) / seg_max;
-                ncand += ll;
-                max_i = bi > max_i ? bi : max_i;
-                max_j = bj > max_j ? bj : max_j;
+        for (int b0 = 0; b0 < visited; b0 += 4 * 256) {  // four cells per thread: their reads go out together, level by level
+            uint32_t vij[4];
+            int64_t vc[4], l0[4], l1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = b0 + u * 256 + tid;
+                vij[u] = vl[idx < visited ? idx : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) vc[u] = (int64_t)o0[vij[u] >> 16] * V + o1[vij[u] & 0xffff];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { l0[u] = loff[vc[u]]; l1[u] = loff[(int64_t)V * V + 1 + vc[u]]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = b0 + u * 256 + tid;
+                const int64_t ll = l1[u] - l0[u];
+                if (idx < visited && ll > 0) {
+                    const int bi = (int)(vij[u] >> 16), bj = (int)(vij[u] & 0xffff);
+                    n_items += (ll + seg_max - 1) / seg_max;
+                    ncand += ll;
+                    max_i = bi > max_i ? bi : max_i;
+                    max_j = bj > max_j ? bj : max_j;
+                }
             }
         }
         n_items = block_sum(n_items);
@@ -4809,7 +4844,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             hipLaunchKernelGGL(k_rank<float>, dim3(nq, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, st, ix->w_cd.as<float>(), nq, V,
                                ix->w_order.as<uint16_t>(), ix->w_sorted.as<float>(), grp_cnt);
         if (par_plan)
-            hipLaunchKernelGGL((k_plan_par<float, false>), dim3(nq), dim3(256), (size_t)2 * V * sizeof(float), st, ix->w_sorted.as<float>(), ix->w_order.as<uint16_t>(),
+            hipLaunchKernelGGL((k_plan_par<float, false>), dim3(nq), dim3(256), (size_t)2 * (V < PLAN_SP ? V : PLAN_SP) * sizeof(float), st, ix->w_sorted.as<float>(), ix->w_order.as<uint16_t>(),
                                ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
                                nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap, plan_hint, hint_slot);
 #ifdef CIS_PLAN_DBG
@@ -4835,7 +4870,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
             hipLaunchKernelGGL(k_rank<double>, dim3(nq, 2), dim3(V <= 64 ? 64 : 256), (size_t)V * 8, st, ix->w_cd.as<double>(), nq,
                                V, ix->w_order.as<uint16_t>(), ix->w_sorted.as<double>(), grp_cnt);
         if (par_plan)
-            hipLaunchKernelGGL((k_plan_par<double, false>), dim3(nq), dim3(256), (size_t)2 * V * sizeof(double), st, ix->w_sorted.as<double>(), ix->w_order.as<uint16_t>(),
+            hipLaunchKernelGGL((k_plan_par<double, false>), dim3(nq), dim3(256), (size_t)2 * (V < PLAN_SP ? V : PLAN_SP) * sizeof(double), st, ix->w_sorted.as<double>(), ix->w_order.as<uint16_t>(),
                                ix->gcount_ptr(), ix->loff_ptr(), nq, V, quota, seg_max, plan, nullptr, nullptr, nullptr,
                                nullptr, grp_cnt, nullptr, nullptr, nullptr, vis_list, plan_fb, vis_cap, plan_hint, hint_slot);
         hipLaunchKernelGGL((k_plan<double, false>), dim3(nq), dim3(64), plan_lds, st, ix->w_sorted.as<double>(),
