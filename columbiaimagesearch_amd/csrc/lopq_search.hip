@@ -37,6 +37,9 @@ static __device__ __forceinline__ uint64_t f2bits(float f) { return (uint64_t)__
 // bit patterns order like the values (NaN sorts last, as np.argsort does).  Ties -> lower index.
 // counters of the table groups are split GRP_SUB ways by query index: 16 k atomics on 32 addresses would serialise
 static const int GRP_SUB = 32;
+// words of the counters, cursors and bases of the table groups (+ 2, to an even count), then one 64-bit word per tile of k_group_bases
+#define GRP_WORDS(V) (6 * (V) * GRP_SUB + 2)
+#define GRP_TILES(V) ((2 * (V) * GRP_SUB + 1023) / 1024)
 
 template <typename CT>
 __global__ void k_rank(const CT* __restrict__ dist /* [2][nq][V] */, int nq, int V,
@@ -846,46 +849,51 @@ __global__ __launch_bounds__(64) void k_multiseq_list(const CT* __restrict__ sor
     }
 }
 
-// The table-group part of k_plan_scan for wide vocabularies (round 4): 2 V x 32 counters are 131072 words at V = 2048, and one wave
-// scanning them 1024 at a time held the whole plan scan for 0.29 ms (0.58 at V = 4096).  Here the workgroup's 16 waves take 16384 per round.
-__global__ __launch_bounds__(1024) void k_group_bases(int* __restrict__ grp_cnt, int* __restrict__ grp_base, int n_groups) {
-    __shared__ int s_w[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int run = 0;
-    for (int g0 = 0; g0 < n_groups; g0 += 16384) {
-        int c[16];
+// The table-group part of k_plan_scan for wide vocabularies: 2 V x 32 counters are 262144 words at V = 4096.  One tile of 1024 counters per
+// workgroup (16-byte loads); a tile publishes its sum tagged with the batch's sequence number and takes as its base the sum of the tiles
+// before it, each waited for by one thread -- every tile publishes before it waits, and tiles are dispatched in order, so nothing can wait
+// for a tile that has not started.  (Round 4: one workgroup, 16384 counters per round, 0.46 ms at V = 4096 on the batch's critical path.)
+static const int GROUP_TILE = 1024;
+__global__ __launch_bounds__(256) void k_group_bases(int* __restrict__ grp_cnt, int* __restrict__ grp_base, int n_groups,
+                                                     unsigned long long* __restrict__ agg /* [tiles] tag << 32 | sum */, uint32_t tag) {
+    __shared__ int s_w[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, t = blockIdx.x;
+    const int g = t * GROUP_TILE + tid * 4;
+    int c[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int g = g0 + tid * 16 + i;
-            c[i] = g < n_groups ? grp_cnt[g] : 0;
+    for (int i = 0; i < 4; ++i) c[i] = g + i < n_groups ? grp_cnt[g + i] : 0;
+    const int tot = c[0] + c[1] + c[2] + c[3];
+    int x = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_w[wv] = x;
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_store(&agg[t], ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)(s_w[0] + s_w[1] + s_w[2] + s_w[3]),
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    int pre = 0;
+    for (int p = tid; p < t; p += 256) {
+        unsigned long long v;
+        do { v = __hip_atomic_load(&agg[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(v >> 32) != tag);
+        pre += (int)(uint32_t)v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
+    if (lane == 0) s_w[4 + wv] = pre;
+    __syncthreads();
+    int r = s_w[4] + s_w[5] + s_w[6] + s_w[7] + x - tot;
+    for (int w = 0; w < wv; ++w) r += s_w[w];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (g + i < n_groups) {
+            grp_base[g + i] = r;
+            grp_cnt[g + i] = 0;              // as k_plan_scan: clean counters for the next batch, clean cursors for this batch's emit pass
+            grp_cnt[n_groups + g + i] = 0;
         }
-        int tot = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) tot += c[i];
-        int x = tot;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int y = __shfl_up(x, d);
-            if (lane >= d) x += y;
-        }
-        __syncthreads();  // the previous round's wave totals have been read
-        if (lane == 63) s_w[wv] = x;
-        __syncthreads();
-        int base = run, all = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { base += w < wv ? s_w[w] : 0; all += s_w[w]; }
-        int r = base + x - tot;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int g = g0 + tid * 16 + i;
-            if (g < n_groups) {
-                grp_base[g] = r;
-                grp_cnt[g] = 0;              // as k_plan_scan: clean counters for the next batch, clean cursors for this batch's emit pass
-                grp_cnt[n_groups + g] = 0;
-            }
-            r += c[i];
-        }
-        run += all;
+        r += c[i];
     }
 }
 
@@ -4725,7 +4733,7 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     PlanOut* plan = ix->w_plan.as<PlanOut>();
     {
         const void* grp_before = ix->w_grp.p;
-        CIS_TRY(ix->w_grp.reserve((size_t)(6 * V * GRP_SUB + 2) * sizeof(int)));
+        CIS_TRY(ix->w_grp.reserve((size_t)(GRP_WORDS(V) + 2 * GRP_TILES(V)) * sizeof(int)));
         if (ix->w_grp.p != grp_before)  // fresh memory: the counters start clean (afterwards every k_plan_scan leaves them clean)
             CIS_CHECK_HIP(hipMemsetAsync(ix->w_grp.p, 0, ix->w_grp.cap, st));
     }
@@ -4896,7 +4904,9 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     const int64_t seq = ++ix->plan_seq;
     const int n_groups = 2 * V * GRP_SUB;
     const bool groups_apart = n_groups > 8192;  // wide vocabularies: the group bases by their own launch (all 16 waves)
-    if (groups_apart) hipLaunchKernelGGL(k_group_bases, dim3(1), dim3(1024), 0, st, grp_cnt, grp_base, n_groups);
+    if (groups_apart)
+        hipLaunchKernelGGL(k_group_bases, dim3((n_groups + GROUP_TILE - 1) / GROUP_TILE), dim3(256), 0, st, grp_cnt, grp_base, n_groups,
+                           reinterpret_cast<unsigned long long*>(grp_cnt + GRP_WORDS(V)), (uint32_t)(seq & 0x7fffffff) | 0x80000000u);
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, plan, nq, item_off, tab_off, totals, qbound, ix->d_h_totals, seq, grp_cnt, grp_base, groups_apart ? 0 : n_groups,
                        plan_hint ? plan_hint + (hint_slot ^ 1) * 2 : nullptr);
     volatile int64_t* h_tot = ix->h_totals;
@@ -5594,7 +5604,7 @@ extern "C" int cis_index_query_owners_dev(cis_index* ix, const void* dQ, int q_d
     CIS_TRY(ix->w_order.reserve((size_t)2 * nq * V * sizeof(uint16_t)));
     {
         const void* grp_before = ix->w_grp.p;
-        CIS_TRY(ix->w_grp.reserve((size_t)(6 * V * GRP_SUB + 2) * sizeof(int)));
+        CIS_TRY(ix->w_grp.reserve((size_t)(GRP_WORDS(V) + 2 * GRP_TILES(V)) * sizeof(int)));
         if (ix->w_grp.p != grp_before) CIS_CHECK_HIP(hipMemsetAsync(ix->w_grp.p, 0, ix->w_grp.cap, st));
     }
     int* grp_cnt = ix->w_grp.as<int>();  // the rank kernels leave the table-group counters zeroed, as every search expects to find them
