@@ -13,6 +13,7 @@
 // axis of the gather and the across-channel LRN window are contiguous.  Bias + ReLU are fused into the
 // GEMM epilogue; pooling uses caffe's ceil-mode output size with windows clipped to the input.
 #include <algorithm>
+#include <cstring>
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -994,6 +995,20 @@ struct CnnWs {
 };
 static const int kMaxParts = 4;
 
+// A captured forward (hipGraph) of the dlib network (CIS_CNN_GRAPH=1; see cis_cnn_forward_dev for why it is not the default): ~50 launches
+// per chain, two chains per batch of 256 -- on a slow host the enqueue is longer than the kernels.  Keyed by what the launches bake in:
+// input, batch size, output, parts, the CIS_CNN_* switches; valid while the workspaces it was captured on are the handle's.
+static const int kCnnGraphs = 4;
+struct CnnGraph {
+    const float* in = nullptr;
+    float* out = nullptr;
+    int n = 0, parts = 0;
+    uint64_t env = 0, used = 0;
+    void* wsp[kMaxParts][5] = {};
+    hipGraphExec_t exec = nullptr;
+    bool seen = false;
+};
+
 struct cis_cnn {
     int arch = 0, device = 0;
     LayerW conv[5], fc[2];        // DeepSentibank
@@ -1012,6 +1027,10 @@ struct cis_cnn {
     std::vector<cis_cnn*> views;
     bool orphaned = false;      // a view whose base was destroyed first: every call fails, nothing dangles
     int parts_override = 0;     // > 0: parts of a batch that run concurrently (views and their base: 1 -- whole batches overlap instead)
+    CnnGraph graphs[kCnnGraphs];
+    uint64_t graph_clock = 0;
+    hipStream_t gs = nullptr;   // capture stream
+    bool graph_off = false;     // a capture failed on this handle: launches from here on
 };
 
 // dlib anet_type block plan: (in channels, out channels, down-sampling block)
@@ -1049,6 +1068,8 @@ extern "C" void cis_cnn_destroy(cis_cnn* c) {
     for (auto& l : c->conv) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_w2) (void)hipFree(l.d_w2); }
     for (auto& l : c->fc) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
     for (auto& l : c->dl) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_w2) (void)hipFree(l.d_w2); }
+    for (auto& g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (c->gs) (void)hipStreamDestroy(c->gs);
     for (auto& w : c->ws) w.release();
     for (auto& s : c->ps) if (s) (void)hipStreamDestroy(s);
     for (auto& e : c->ev_done) if (e) (void)hipEventDestroy(e);
@@ -1487,6 +1508,94 @@ static int cnn_forward_dlib(cis_cnn* c, CnnWs* ws, const float* d_in, int n, flo
 
 static int cnn_forward_sentibank(cis_cnn* c, CnnWs* ws, const float* d_nchw, int n, float* d_feats, hipStream_t st);
 
+extern char** environ;
+// the CIS_CNN_* switches of the environment as one word (they are read per call, so that one process can compare routes: a captured
+// forward belongs to the switches it was captured under)
+static uint64_t cnn_env_signature() {
+    uint64_t h = 1469598103934665603ull;
+    for (char** e = environ; e && *e; ++e) {
+        if (strncmp(*e, "CIS_CNN_", 8) != 0) continue;
+        for (const char* p = *e; *p; ++p) h = (h ^ (unsigned char)*p) * 1099511628211ull;
+        h = (h ^ 0xffu) * 1099511628211ull;
+    }
+    return h;
+}
+
+// The forward of (input, n, output, parts) as a graph launch on the caller's stream.  First sight of a key: nothing (the caller enqueues
+// the launches, which also sizes the workspaces); second sight: the same enqueue is captured on the handle's own streams -- the parts fork
+// from and join the capture stream through the events the launch path uses -- and instantiated; from then on one hipGraphLaunch.
+// *handled = false: the caller goes on with the launches (not captured yet, or the capture failed: the handle stops trying).
+static int cnn_forward_graph(cis_cnn* c, const float* d_in, int n, float* d_feats, int parts, size_t in_item, size_t out_item, hipStream_t st,
+                             bool* handled) {
+    *handled = false;
+    const uint64_t env = cnn_env_signature();
+    CnnGraph* g = nullptr;
+    CnnGraph* lru = &c->graphs[0];
+    for (auto& e : c->graphs) {
+        if (e.seen && e.in == d_in && e.out == d_feats && e.n == n && e.parts == parts && e.env == env) { g = &e; break; }
+        if (e.used < lru->used) lru = &e;
+    }
+    if (!g) {  // first sight: remember the key in the least recently used slot
+        if (lru->exec) { (void)hipGraphExecDestroy(lru->exec); lru->exec = nullptr; }
+        lru->in = d_in; lru->out = d_feats; lru->n = n; lru->parts = parts; lru->env = env; lru->seen = true;
+        lru->used = ++c->graph_clock;
+        return CIS_OK;
+    }
+    g->used = ++c->graph_clock;
+    auto same_ws = [&]() {
+        for (int p = 0; p < parts; ++p) {
+            const void* now[5] = {c->ws[p].act0.p, c->ws[p].act1.p, c->ws[p].act2.p, c->ws[p].act3.p, c->ws[p].part.p};
+            for (int i = 0; i < 5; ++i) if (g->wsp[p][i] != now[i]) return false;
+        }
+        return true;
+    };
+    if (g->exec && !same_ws()) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }  // a larger batch grew a workspace since
+    if (!g->exec) {
+        if (!c->gs && hipStreamCreateWithFlags(&c->gs, hipStreamNonBlocking) != hipSuccess) { c->graph_off = true; return CIS_OK; }
+        bool ok = true;
+        if (parts > 1) {
+            if (!c->ev_in) ok = ok && hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) == hipSuccess;
+            for (int p = 0; p < parts && ok; ++p) {
+                if (!c->ps[p]) ok = ok && hipStreamCreateWithFlags(&c->ps[p], hipStreamNonBlocking) == hipSuccess;
+                if (!c->ev_done[p]) ok = ok && hipEventCreateWithFlags(&c->ev_done[p], hipEventDisableTiming) == hipSuccess;
+            }
+        }
+        if (!ok || hipStreamBeginCapture(c->gs, hipStreamCaptureModeRelaxed) != hipSuccess) { c->graph_off = true; (void)hipGetLastError(); return CIS_OK; }
+        int rc = CIS_OK;
+        if (parts <= 1) {
+            rc = cnn_forward_dlib(c, &c->ws[0], d_in, n, d_feats, c->gs);
+        } else {
+            ok = hipEventRecord(c->ev_in, c->gs) == hipSuccess;
+            for (int p = 0; p < parts && ok && rc == CIS_OK; ++p) {
+                const int lo = (int)((int64_t)n * p / parts), hi = (int)((int64_t)n * (p + 1) / parts);
+                ok = hipStreamWaitEvent(c->ps[p], c->ev_in, 0) == hipSuccess;
+                if (!ok) break;
+                rc = cnn_forward_dlib(c, &c->ws[p], d_in + lo * in_item, hi - lo, d_feats + lo * out_item, c->ps[p]);
+                ok = hipEventRecord(c->ev_done[p], c->ps[p]) == hipSuccess && hipStreamWaitEvent(c->gs, c->ev_done[p], 0) == hipSuccess;
+            }
+        }
+        hipGraph_t graph = nullptr;
+        const hipError_t ee = hipStreamEndCapture(c->gs, &graph);
+        if (!ok || rc != CIS_OK || ee != hipSuccess || !graph ||
+            hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            g->exec = nullptr;
+            c->graph_off = true;
+            (void)hipGetLastError();
+            return CIS_OK;  // (the launches: they report what is wrong, if anything is)
+        }
+        (void)hipGraphDestroy(graph);
+        for (int p = 0; p < kMaxParts; ++p) {
+            const void* now[5] = {c->ws[p].act0.p, c->ws[p].act1.p, c->ws[p].act2.p, c->ws[p].act3.p, c->ws[p].part.p};
+            for (int i = 0; i < 5; ++i) g->wsp[p][i] = const_cast<void*>(now[i]);
+        }
+    }
+    CIS_CHECK_HIP(hipGraphLaunch(g->exec, st));
+    *handled = true;
+    return CIS_OK;
+}
+
+
 extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float* d_feats, void* stream) {
     CIS_REQUIRE(c != nullptr, "cnn is NULL");
     CIS_REQUIRE(n >= 0, "n must be >= 0");
@@ -1503,6 +1612,16 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
     if (parts > kMaxParts) parts = kMaxParts;
     if (parts > n) parts = n;
     const size_t in_item = c->arch == 2 ? (size_t)150 * 150 * 3 : (size_t)3 * 227 * 227, out_item = c->arch == 2 ? 128 : 4096;
+    static const bool threaded = getenv("CIS_CNN_THREADS") && atoi(getenv("CIS_CNN_THREADS")) != 0;
+    // CIS_CNN_GRAPH=1: the dlib forward as a captured graph.  Off by default -- measured on ROCm 7.2 (profiles/r06_cnn_graph_ab.txt): the two
+    // half-batch chains of a graph do not overlap (2.15 ms against 1.71 ms as launches), three views in flight 1.58 against 1.44 ms.
+    const char* ge = getenv("CIS_CNN_GRAPH");
+    const bool graphs_on = ge && atoi(ge) != 0;
+    if (graphs_on && c->arch == 2 && !c->graph_off && !threaded && parts >= 1) {
+        bool handled = false;
+        const int rc = cnn_forward_graph(c, d_nchw, n, d_feats, parts, in_item, out_item, st, &handled);
+        if (handled) return rc;
+    }
     if (parts <= 1)
         return c->arch == 2 ? cnn_forward_dlib(c, &c->ws[0], d_nchw, n, d_feats, st) : cnn_forward_sentibank(c, &c->ws[0], d_nchw, n, d_feats, st);
     // (streams are made for the parts in use only: HIP maps a process's streams onto four hardware queues by default, and streams that
@@ -1519,7 +1638,6 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
     hipError_t herr = hipSuccess;
     // CIS_CNN_THREADS=1: every part is enqueued from its own host thread (a part is ~50 launches: enqueued one part after the other,
     // the last part starts late); default off, measured in profiles/r03y_cnn_parts.txt
-    static const bool threaded = getenv("CIS_CNN_THREADS") && atoi(getenv("CIS_CNN_THREADS")) != 0;
     if (threaded) {
         int rcs[kMaxParts] = {0, 0, 0, 0};
         for (int p = 0; p < parts && herr == hipSuccess; ++p) herr = hipStreamWaitEvent(c->ps[p], c->ev_in, 0);

@@ -263,6 +263,56 @@ def test_dlib_fused_tail_agrees_with_the_six_launches_it_replaces(monkeypatch):
     net.close()
 
 
+def test_dlib_forward_as_a_captured_graph_equals_the_launches(monkeypatch):
+    """CIS_CNN_GRAPH=1: the forward of (input, n, output) is captured on its second call and replayed as one hipGraphLaunch from the
+    third on -- the descriptors of every call equal the launches', bit for bit; new contents at the same addresses are seen (a graph
+    bakes in addresses, not data); a switch flipped between calls (CIS_CNN_NO_TAIL) takes the launches of THAT route, not the cached
+    graph; a view captures its own single chain."""
+    import torch
+    from oracle import dlib_oracle as D
+    from columbiaimagesearch_amd.featurizer import DLibFaceNet
+    net = DLibFaceNet(D.synthetic_weights(2))
+    x = torch.as_tensor(D.synthetic_chips(160, seed=3)).cuda().float().contiguous()
+    out = torch.empty((160, 128), device="cuda")
+    monkeypatch.delenv("CIS_CNN_GRAPH", raising=False)
+    want = net.forward_dev(x).cpu().numpy()
+    monkeypatch.setenv("CIS_CNN_GRAPH", "1")
+    for _ in range(4):  # launches, capture + launch, graph, graph
+        out.fill_(-1.0)
+        net.forward_dev(x, out)
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+    x2 = torch.as_tensor(D.synthetic_chips(160, seed=4)).cuda().float().contiguous()
+    monkeypatch.delenv("CIS_CNN_GRAPH")
+    want2 = net.forward_dev(x2).cpu().numpy()
+    monkeypatch.setenv("CIS_CNN_GRAPH", "1")
+    x.copy_(x2)
+    net.forward_dev(x, out)
+    np.testing.assert_array_equal(out.cpu().numpy(), want2)
+    monkeypatch.setenv("CIS_CNN_NO_TAIL", "1")
+    net.forward_dev(x, out)
+    no_tail = out.cpu().numpy().copy()
+    monkeypatch.delenv("CIS_CNN_GRAPH")
+    net.forward_dev(x, out)
+    np.testing.assert_array_equal(out.cpu().numpy(), no_tail)
+    monkeypatch.delenv("CIS_CNN_NO_TAIL")
+    monkeypatch.setenv("CIS_CNN_GRAPH", "1")
+    v = net.view()
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            out.fill_(-1.0)
+            v.forward_dev(x, out)
+        side.synchronize()
+        got = out.cpu().numpy()
+    monkeypatch.delenv("CIS_CNN_GRAPH")
+    with torch.cuda.stream(side):
+        v.forward_dev(x, out)
+    side.synchronize()
+    np.testing.assert_array_equal(got, out.cpu().numpy())
+    v.close()
+    net.close()
+
+
 @pytest.mark.parametrize("n", [128, 257, 512])
 def test_dlib_batch_in_concurrent_parts_equals_the_single_chain(monkeypatch, n):
     """A batch of 128-512 chips runs as two parts on the handle's own streams (own workspaces, event fences on the caller's
