@@ -331,8 +331,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIS_PLAN_WP
                                                   WorkItem* __restrict__ items, TabDesc* __restrict__ tabs,
                                                   int* __restrict__ grp_cnt, const int* __restrict__ grp_base,
                                                   int* __restrict__ grp_cur, int* __restrict__ tab_order,
-                                                  uint32_t* __restrict__ vis_list /* [nq][vis_cap] (i << 16 | j) in visit order */,
-                                                  int* __restrict__ fallback /* [nq] */, int vis_cap,
+                                                  uint64_t* __restrict__ ent_list /* [nq][ent_cap][2]: the visited cells that hold anything, in visit
+                                                  order: start (40 bits) | (i << 12 | j) << 40, then length | visit rank << 32 */,
+                                                  int* __restrict__ fallback /* [nq] flags, then [nq] entries per query */, int ent_cap,
                                                   unsigned long long* __restrict__ hint /* null, or [2][2]: (cells visited, quota) summed over the
                                                   queries of the launches of either parity (count pass) */, int hint_slot) {
     __shared__ typename PlanKeyT<CT>::type s_key[PLAN_PAR_CAP];
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIS_PLAN_WP
     const CT* d1 = sorted + ((int64_t)q * 2 + 1) * V;
     const uint16_t* o0 = order + ((int64_t)q * 2 + 0) * V;
     const uint16_t* o1 = order + ((int64_t)q * 2 + 1) * V;
-    uint32_t* vl = vis_list + (int64_t)q * vis_cap;
+    uint64_t* ent = ent_list + (int64_t)q * ent_cap * 2;
     auto block_sum = [&](int64_t v) -> int64_t {  // every thread gets the sum
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -368,20 +369,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIS_PLAN_WP
     };
     if constexpr (EMIT) {
         if (fallback[q]) return;  // the frontier walk emits this query
+        const int n_ent = fallback[nq + q];
         const PlanOut pl = plan[q];
         const int64_t ibase = item_off[q], tbase = tab_off[q];
-        // items: exclusive scan of the chunk counts of the visited cells, in visit order
+        // the ranks of either list that have a cell with candidates, as bits; a half table per set bit, numbered densely in rank order
+        // (the count pass counted the same bits into ntab0 / ntab1)
+        __shared__ uint32_t s_used[2 * PLAN_PAR_STAGE / 32];
+        __shared__ uint16_t s_pre[2 * PLAN_PAR_STAGE / 32];
+        constexpr int UW = PLAN_PAR_STAGE / 32;  // words per split
+        s_used[tid] = 0u;
+        __syncthreads();
+        for (int idx = tid; idx < n_ent; idx += 256) {
+            const uint64_t e0 = ent[2 * idx], e1 = ent[2 * idx + 1];
+            if ((uint32_t)e1 > 0u) {
+                const int bi = (int)(e0 >> 52), bj = (int)((e0 >> 40) & 0xfffu);
+                atomicOr(&s_used[bi >> 5], 1u << (bi & 31));
+                atomicOr(&s_used[UW + (bj >> 5)], 1u << (bj & 31));
+            }
+        }
+        __syncthreads();
+        {
+            const int pc = __popc(s_used[tid]);
+            int x = pc;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(x, d);
+                if (lane >= d) x += y;
+            }
+            if (lane == 63) s_i[wv] = x;
+            __syncthreads();
+            s_pre[tid] = (uint16_t)(((wv & 1) ? s_i[wv - 1] : 0) + x - pc);  // waves 0, 1: split 0; waves 2, 3: split 1
+        }
+        __syncthreads();
+        auto dense = [&](int split, int r) -> int {
+            const int w = split * UW + (r >> 5);
+            return (int)s_pre[w] + __popc(s_used[w] & ((1u << (r & 31)) - 1u));
+        };
+        // items: exclusive scan of the chunk counts of the listed cells, in visit order
         int run = 0;
-        for (int b0 = 0; b0 < pl.visited; b0 += 256) {
+        for (int b0 = 0; b0 < n_ent; b0 += 256) {
             const int idx = b0 + tid;
-            int nch = 0, bi = 0, bj = 0;
-            int64_t ls = 0, ll = 0, cell = 0;
-            if (idx < pl.visited) {
-                const uint32_t ij = vl[idx];
-                bi = (int)(ij >> 16); bj = (int)(ij & 0xffff);
-                cell = (int64_t)o0[bi] * V + o1[bj];
-                ls = loff[cell];
-                ll = loff[(int64_t)V * V + 1 + cell] - ls;
+            int nch = 0, bi = 0, bj = 0, rank = 0;
+            int64_t ls = 0, ll = 0;
+            if (idx < n_ent) {
+                const uint64_t e0 = ent[2 * idx], e1 = ent[2 * idx + 1];
+                bi = (int)(e0 >> 52); bj = (int)((e0 >> 40) & 0xfffu);
+                ls = (int64_t)(e0 & ((1ull << 40) - 1));
+                ll = (int64_t)(uint32_t)e1;
+                rank = (int)(e1 >> 32);
                 nch = ll > 0 ? (int)((ll + seg_max - 1) / seg_max) : 0;
             }
             int x = nch;
@@ -396,28 +431,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIS_PLAN_WP
             int base = run;
             for (int w = 0; w < wv; ++w) base += s_i[w];
             const int pos = base + x - nch;
-            for (int ch = 0; ch < nch; ++ch) {
-                WorkItem it;
-                it.q = q; it.rank = idx;
-                it.tab0 = (int)(tbase + bi);
-                it.tab1 = (int)(tbase + pl.ntab0 + bj);
-                it.pos0 = ch * seg_max;
-                it.cell = (int)cell; it.pad = 0;
-                it.start = ls + (int64_t)ch * seg_max;
-                const int64_t rem = ll - (int64_t)ch * seg_max;
-                it.len = (int)(rem < seg_max ? rem : seg_max);
-                items[ibase + pos + ch] = it;
+            if (nch > 0) {
+                const int64_t cell = (int64_t)o0[bi] * V + o1[bj];
+                const int t0 = (int)tbase + dense(0, bi), t1 = (int)tbase + pl.ntab0 + dense(1, bj);
+                for (int ch = 0; ch < nch; ++ch) {
+                    WorkItem it;
+                    it.q = q; it.rank = rank;
+                    it.tab0 = t0;
+                    it.tab1 = t1;
+                    it.pos0 = ch * seg_max;
+                    it.cell = (int)cell; it.pad = 0;
+                    it.start = ls + (int64_t)ch * seg_max;
+                    const int64_t rem = ll - (int64_t)ch * seg_max;
+                    it.len = (int)(rem < seg_max ? rem : seg_max);
+                    items[ibase + pos + ch] = it;
+                }
             }
             run += s_i[0] + s_i[1] + s_i[2] + s_i[3];
         }
-        for (int i = tid; i < pl.ntab0 + pl.ntab1; i += 256) {
-            TabDesc td;
-            td.q = q; td.pad = 0;
-            if (i < pl.ntab0) { td.split = 0; td.cluster = o0[i]; }
-            else { td.split = 1; td.cluster = o1[i - pl.ntab0]; }
-            tabs[tbase + i] = td;
-            const int g = (td.split * V + td.cluster) * GRP_SUB + (q % GRP_SUB);
-            tab_order[grp_base[g] + atomicAdd(&grp_cur[g], 1)] = (int)(tbase + i);
+        {   // tables: thread t walks the set bits of word t
+            const int split = tid >= UW ? 1 : 0;
+            uint32_t bits = s_used[tid];
+            int dn = (int)s_pre[tid];
+            while (bits) {
+                const int b = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                const int r = (tid - split * UW) * 32 + b;
+                TabDesc td;
+                td.q = q; td.pad = 0; td.split = split;
+                td.cluster = split ? o1[r] : o0[r];
+                const int ti = (int)tbase + (split ? pl.ntab0 : 0) + dn++;
+                tabs[ti] = td;
+                const int g = (td.split * V + td.cluster) * GRP_SUB + (q % GRP_SUB);
+                tab_order[grp_base[g] + atomicAdd(&grp_cur[g], 1)] = ti;
+            }
         }
         return;
     } else {
@@ -467,7 +514,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIS_PLAN_WP
         // sorted on its own and appended to the visited list; the quota prefix sum carries over.
         PLAN_DBG(8, wall_clock64() - dbg_k0);
         bool fb = false, done = false;
-        int visited = 0;
+        int visited = 0, ne_total = 0;
         int64_t cum = 0, c_prev = 0, target = 256;
         // first band: 0.6 x the cells a query of this quota visited in the previous launch (so that [target, 2 target] holds what most
         // queries need and ONE band is enumerated and sorted); 256 without a hint.  The hint only sizes the bands.
@@ -550,7 +597,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIS_PLAN_WP
             PLAN_DBG(2, wall_clock64() - dbg_t0);
             if (c_hi - c_prev > PLAN_PAR_CAP) { fb = true; break; }
             const int cnt = (int)(c_hi - c_prev);
-            if (visited + cnt > vis_cap) { fb = true; break; }
             // enumerate the band.  (a) per row: cells [pprev, phi); s_gc[i] = first slot of the row | pprev << 12 (rows in order)
             const int rows = rows_under(hi);
             for (int x = tid; x < PLAN_NB; x += 256) s_hist[x] = 0;
@@ -717,7 +763,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIS_PLAN_WP
             PLAN_DBG(4, cnt);
             if (quota <= 0) cut = 0;
             const int take = cut >= 0 ? cut + 1 : cnt;
-            for (int idx = tid; idx < take; idx += 256) vl[visited + idx] = s_ij[idx];
+            if (ne_total + take > ent_cap) { fb = true; break; }
+            // the cells of the band that hold anything (size over all shards > 0: the visited list is mostly empty cells at thousands
+            // of coarse clusters) are appended to the query's list with their visit rank
+            for (int b0 = 0; b0 < take; b0 += 256) {
+                const int idx = b0 + tid;
+                const int f = (idx < take && s_gc[idx] > 0u) ? 1 : 0;
+                int x = f;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int y = __shfl_up(x, d);
+                    if (lane >= d) x += y;
+                }
+                __syncthreads();
+                if (lane == 63) s_i[wv] = x;
+                __syncthreads();
+                int base = ne_total;
+                for (int w = 0; w < wv; ++w) base += s_i[w];
+                if (f) {
+                    const uint32_t ij = s_ij[idx];
+                    const int64_t ep = (int64_t)(base + x - 1) * 2;
+                    ent[ep] = (uint64_t)(((ij >> 16) << 12) | (ij & 0xfffu)) << 40;
+                    ent[ep + 1] = (uint64_t)(uint32_t)(visited + idx) << 32;
+                }
+                ne_total += s_i[0] + s_i[1] + s_i[2] + s_i[3];
+            }
             visited += take;
             if (cut >= 0) { done = true; break; }
             cum = run64;
@@ -750,55 +820,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIS_PLAN_WP
         }
         __threadfence_block();
         __syncthreads();
+        // the listed cells' own starts and lengths (this shard's), written back into the list: the emit pass reads nothing else.  The ranks
+        // of either list that have a cell with candidates are bits (they alias the sort's bucket counters): a half table per set bit.
+        constexpr int UW = PLAN_PAR_STAGE / 32;
+        uint32_t* s_used = reinterpret_cast<uint32_t*>(s_hist);
+        s_used[tid] = 0u;
+        __syncthreads();
         int64_t n_items = 0, ncand = 0;
-        int max_i = -1, max_j = -1;
-        for (int b0 = 0; b0 < visited; b0 += 4 * 256) {  // four cells per thread: their reads go out together, level by level
-            uint32_t vij[4];
+        for (int b0 = 0; b0 < ne_total; b0 += 4 * 256) {  // four cells per thread: their reads go out together, level by level
+            uint64_t e0[4], e1[4];
             int64_t vc[4], l0[4], l1[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = b0 + u * 256 + tid;
-                vij[u] = vl[idx < visited ? idx : 0];
+                const int64_t ep = (int64_t)(idx < ne_total ? idx : 0) * 2;
+                e0[u] = ent[ep]; e1[u] = ent[ep + 1];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) vc[u] = (int64_t)o0[vij[u] >> 16] * V + o1[vij[u] & 0xffff];
+            for (int u = 0; u < 4; ++u) vc[u] = (int64_t)o0[(int)(e0[u] >> 52)] * V + o1[(int)((e0[u] >> 40) & 0xfffu)];
 #pragma unroll
             for (int u = 0; u < 4; ++u) { l0[u] = loff[vc[u]]; l1[u] = loff[(int64_t)V * V + 1 + vc[u]]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = b0 + u * 256 + tid;
-                const int64_t ll = l1[u] - l0[u];
-                if (idx < visited && ll > 0) {
-                    const int bi = (int)(vij[u] >> 16), bj = (int)(vij[u] & 0xffff);
-                    n_items += (ll + seg_max - 1) / seg_max;
-                    ncand += ll;
-                    max_i = bi > max_i ? bi : max_i;
-                    max_j = bj > max_j ? bj : max_j;
+                if (idx < ne_total) {
+                    const int64_t ll = l1[u] - l0[u];
+                    ent[(int64_t)idx * 2] = e0[u] | (uint64_t)l0[u];
+                    ent[(int64_t)idx * 2 + 1] = e1[u] | (uint64_t)(uint32_t)(ll > 0 ? ll : 0);
+                    if (ll > 0) {
+                        const int bi = (int)(e0[u] >> 52), bj = (int)((e0[u] >> 40) & 0xfffu);
+                        n_items += (ll + seg_max - 1) / seg_max;
+                        ncand += ll;
+                        atomicOr(&s_used[bi >> 5], 1u << (bi & 31));
+                        atomicOr(&s_used[UW + (bj >> 5)], 1u << (bj & 31));
+                    }
                 }
             }
         }
         n_items = block_sum(n_items);
         ncand = block_sum(ncand);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const int a = __shfl_xor(max_i, o), b = __shfl_xor(max_j, o);
-            max_i = a > max_i ? a : max_i;
-            max_j = b > max_j ? b : max_j;
-        }
-        __syncthreads();
-        if (lane == 0) { s_i[wv] = max_i; s_i[4 + wv] = max_j; }
-        __syncthreads();
-        max_i = s_i[0]; max_j = s_i[4];
-        for (int w = 1; w < 4; ++w) { max_i = s_i[w] > max_i ? s_i[w] : max_i; max_j = s_i[4 + w] > max_j ? s_i[4 + w] : max_j; }
+        const uint32_t ubits = s_used[tid];
+        const int64_t ntabs = block_sum(tid < UW ? (int64_t)__popc(ubits) : ((int64_t)__popc(ubits) << 32));
         PLAN_DBG(10, wall_clock64() - dbg_k0);
         if (tid == 0) {
             PlanOut p;
-            p.visited = visited; p.n_items = (int)n_items; p.ntab0 = max_i + 1; p.ntab1 = max_j + 1; p.ncand = ncand;
+            p.visited = visited; p.n_items = (int)n_items; p.ntab0 = (int)(uint32_t)ntabs; p.ntab1 = (int)(ntabs >> 32); p.ncand = ncand;
             plan[q] = p;
+            fallback[nq + q] = ne_total;
         }
-        for (int i = tid; i < max_i + 1 + max_j + 1; i += 256) {
-            const int g = i <= max_i ? (int)o0[i] : V + (int)o1[i - (max_i + 1)];
-            atomicAdd(&grp_cnt[g * GRP_SUB + (q % GRP_SUB)], 1);
+        {
+            const int split = tid >= UW ? 1 : 0;
+            uint32_t bits = ubits;
+            while (bits) {
+                const int b = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                const int r = (tid - split * UW) * 32 + b;
+                const int g = split ? V + (int)o1[r] : (int)o0[r];
+                atomicAdd(&grp_cnt[g * GRP_SUB + (q % GRP_SUB)], 1);
+            }
         }
         PLAN_DBG(11, wall_clock64() - dbg_k0);
     }
@@ -4807,19 +4886,20 @@ static int search_batch(cis_index* ix, const void* dQ, int q_dtype, int nq, int6
     unsigned long long* plan_hint = (par_plan && !getenv("CIS_NO_PLAN_HINT")) ? ix->plan_hint_ptr() : nullptr;
     const int hint_slot = (int)((ix->plan_seq + 1) & 1);  // this batch's launches add into this parity and read the other
     int* plan_fb = nullptr;
-    uint32_t* vis_list = nullptr;
-    // visited cells per query the fast plan records: 2 GB of visit lists per batch (an outlier query far from the data walks
-    // tens of thousands of empty cells at V = 4096; past the cap the query goes to the serial frontier walk, ~3 us per cell)
-    int64_t vis_cap64 = ((int64_t)1 << 31) / ((int64_t)(nq > 0 ? nq : 1) * 4);
-    if (vis_cap64 < 16384) vis_cap64 = 16384;
+    uint64_t* vis_list = nullptr;
+    // cells WITH candidates per query the fast plan lists (16 bytes each; the empty cells it walks -- most of them at thousands of coarse
+    // clusters, tens of thousands for an outlier query -- are not listed): 2 GB of lists per batch at most; past the cap the query goes
+    // to the serial frontier walk, ~3 us per cell
+    int64_t vis_cap64 = ((int64_t)1 << 31) / ((int64_t)(nq > 0 ? nq : 1) * 16);
+    if (vis_cap64 < 4096) vis_cap64 = 4096;
     if (vis_cap64 > (1 << 20)) vis_cap64 = 1 << 20;
     if (vis_cap64 > (int64_t)V * V) vis_cap64 = (int64_t)V * V;
     const int vis_cap = (int)vis_cap64;
     if (par_plan) {
-        CIS_TRY(ix->w_planfb.reserve((size_t)nq * sizeof(int)));
-        CIS_TRY(ix->w_vis.reserve((size_t)nq * vis_cap * sizeof(uint32_t)));
+        CIS_TRY(ix->w_planfb.reserve((size_t)2 * nq * sizeof(int)));
+        CIS_TRY(ix->w_vis.reserve((size_t)nq * vis_cap * 2 * sizeof(uint64_t)));
         plan_fb = ix->w_planfb.as<int>();
-        vis_list = ix->w_vis.as<uint32_t>();
+        vis_list = ix->w_vis.as<uint64_t>();
     }
     const size_t plan_lds = (size_t)V * sizeof(int);
     int Vp2 = 64;
