@@ -1013,6 +1013,64 @@ def test_multisequence_plan_with_thousands_of_cells_and_tied_sums():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("swap", [False, True])
+def test_multisequence_plan_past_the_staged_ranks(swap, monkeypatch):
+    """k_plan_par keeps the first 1024 ranks of either sorted list in LDS and reads deeper ranks in place; it lists only the visited cells
+    that hold anything and gives half tables to the ranks that have one.  A lattice model with V = 1500 whose one half is 40 times coarser
+    than the other (the region under a threshold is a thin ellipse: ~1400 ranks deep on one list after ~20 k cells), few points per cell,
+    most cells empty: visited count, ids and distances against the oracle's frontier walk, and -- for a longer walk than the oracle
+    finishes in seconds -- against the serial frontier walk of the library (CIS_NO_PAR_PLAN)."""
+    from oracle import lopq_oracle as O
+    from columbiaimagesearch_amd.lopq import LOPQModel, LOPQSearcherHIP
+    V = 1500
+    c = np.arange(1, V + 1, dtype=np.float32).reshape(V, 1)
+    scale = np.array([40.0, 1.0] if swap else [1.0, 40.0], dtype=np.float32)
+    Cs = ((c * scale[0]).copy(), (c * scale[1]).copy())
+    Rs = tuple(np.ones((V, 1, 1)) for _ in range(2))
+    mus = tuple(np.zeros((V, 1)) for _ in range(2))
+    subs = tuple([np.array([[-0.3], [-0.1], [0.1], [0.3]])] for _ in range(2))
+    m = LOPQModel(parameters=(Cs, Rs, mus, subs))
+    om = O.OracleModel(list(Cs), list(Rs), list(mus), [list(subs[0]), list(subs[1])])
+    rs = np.random.RandomState(5)
+    n = 20000
+    cells = rs.randint(1, V + 1, size=(n, 2))
+    X = (cells * scale + rs.uniform(-0.4, 0.4, size=(n, 2))).astype(np.float32)
+    coarse, fine = m.predict_batch(X)
+    np.testing.assert_array_equal(coarse, cells - 1)
+    s = LOPQSearcherHIP(m)
+    s.add_codes_array(coarse, fine)
+    oi = O.OracleCSRIndex(om, coarse, fine)
+    Q = (np.array([[700.3, 30.6], [-200.0, 3.2], [1480.2, 1499.7]], dtype=np.float32) * scale).astype(np.float32)
+    if swap:
+        Q = Q[:, ::-1].copy() / scale[::-1] * scale
+    r = s.search_batch(Q, quota=200, limit=40)
+    deep = 0
+    for qi in range(len(Q)):
+        ids, dists, visited = oi.search(Q[qi], quota=200, limit=40)
+        k = len(ids)
+        assert int(r["visited"][qi]) == visited and int(r["n_found"][qi]) == k, (qi, int(r["visited"][qi]), visited)
+        np.testing.assert_array_equal(r["ids"][qi, :k], ids)
+        np.testing.assert_allclose(r["dists"][qi, :k], dists, rtol=1e-9, atol=1e-12)
+        deep = max(deep, visited)
+    assert deep > 15000
+    # a walk of hundreds of thousands of cells: the banded plan against the frontier walk, cell by cell
+    want = None
+    for no_par in ("1", None):
+        if no_par:
+            monkeypatch.setenv("CIS_NO_PAR_PLAN", no_par)
+        else:
+            monkeypatch.delenv("CIS_NO_PAR_PLAN")
+        got = s.search_batch(Q, quota=2500, limit=30)
+        if want is None:
+            want = got
+    for k in ("ids", "visited", "n_found"):
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    np.testing.assert_array_equal(got["dists"].view(np.uint64), want["dists"].view(np.uint64))
+    assert int(got["visited"].max()) > 200000
+    s.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("V,M,D,dup", [(96, 8, 128, 0), (96, 4, 128, 0), (96, 16, 128, 0), (64, 8, 64, 0), (64, 16, 64, 0), (64, 4, 64, 0), (96, 16, 256, 0), (96, 8, 256, 0), (96, 8, 128, 5000)])
 def test_tiny_cells_prefilter_equals_exact_kernels(V, M, D, dup, monkeypatch):
     """k_tiny_select (byte-table prefilter + exact keys of the survivors, one workgroup per query) against the exact kernels it
