@@ -969,7 +969,8 @@ def test_training_accumulations_on_gpu_match_host():
 
 
 @pytest.mark.gpu
-def test_multisequence_plan_with_thousands_of_cells_and_tied_sums():
+@pytest.mark.parametrize("cdtype", [np.float32, np.float64])
+def test_multisequence_plan_with_thousands_of_cells_and_tied_sums(cdtype):
     """The plan of indexes with many coarse clusters (k_plan_par: banded selection + sort instead of one frontier step per
     cell) against the oracle's frontier walk, on a lattice model built to make the rank-pair sums d0[i] + d1[j] TIE by
     the hundreds (integer squares: 1 + 49 == 25 + 25): the heap's order is the (sum, i, j) order, ties included.
@@ -977,7 +978,7 @@ def test_multisequence_plan_with_thousands_of_cells_and_tied_sums():
     from oracle import lopq_oracle as O
     from columbiaimagesearch_amd.lopq import LOPQModel, LOPQSearcherHIP
     V, K = 128, 4
-    c = np.arange(1, V + 1, dtype=np.float32).reshape(V, 1)
+    c = np.arange(1, V + 1, dtype=cdtype).reshape(V, 1)   # (float64 coarse centroids: 64-bit sums and sort keys in k_plan_par)
     Cs = (c.copy(), c.copy())
     Rs = tuple(np.ones((V, 1, 1)) for _ in range(2))
     mus = tuple(np.zeros((V, 1)) for _ in range(2))
