@@ -449,18 +449,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIS_PLAN_WP
             }
             run += s_i[0] + s_i[1] + s_i[2] + s_i[3];
         }
-        {   // tables: thread t walks the set bits of word t
-            const int split = tid >= UW ? 1 : 0;
-            uint32_t bits = s_used[tid];
-            int dn = (int)s_pre[tid];
-            while (bits) {
-                const int b = __ffs((int)bits) - 1;
-                bits &= bits - 1;
-                const int r = (tid - split * UW) * 32 + b;
+        // tables: a thread per rank of either list (a thread per word walking its bits ran the 16 tables of a V = 16 query one after the
+        // other, each behind a load and an atomic's return)
+        for (int x = tid; x < 2 * V; x += 256) {
+            const int split = x >= V ? 1 : 0, r = x - split * V;
+            if ((s_used[split * UW + (r >> 5)] >> (r & 31)) & 1u) {
                 TabDesc td;
                 td.q = q; td.pad = 0; td.split = split;
                 td.cluster = split ? o1[r] : o0[r];
-                const int ti = (int)tbase + (split ? pl.ntab0 : 0) + dn++;
+                const int ti = (int)tbase + (split ? pl.ntab0 : 0) + dense(split, r);
                 tabs[ti] = td;
                 const int g = (td.split * V + td.cluster) * GRP_SUB + (q % GRP_SUB);
                 tab_order[grp_base[g] + atomicAdd(&grp_cur[g], 1)] = ti;
@@ -868,13 +865,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIS_PLAN_WP
             plan[q] = p;
             fallback[nq + q] = ne_total;
         }
-        {
-            const int split = tid >= UW ? 1 : 0;
-            uint32_t bits = ubits;
-            while (bits) {
-                const int b = __ffs((int)bits) - 1;
-                bits &= bits - 1;
-                const int r = (tid - split * UW) * 32 + b;
+        for (int x = tid; x < 2 * V; x += 256) {  // (a thread per rank: see the emit pass)
+            const int split = x >= V ? 1 : 0, r = x - split * V;
+            if ((s_used[split * UW + (r >> 5)] >> (r & 31)) & 1u) {
                 const int g = split ? V + (int)o1[r] : (int)o0[r];
                 atomicAdd(&grp_cnt[g * GRP_SUB + (q % GRP_SUB)], 1);
             }

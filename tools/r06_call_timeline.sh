@@ -9,7 +9,7 @@ import csv, re
 rows = list(csv.DictReader(open("/tmp/kt/r_kernel_trace.csv")))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-starts = [i for i, n in enumerate(names) if "k_pca_gemm" in n]
+starts = [i for i, n in enumerate(names) if "k_pca_gemm" in n or "k_pca_small" in n]
 def show(a, b, title):
     print("==", title)
     t0 = int(rows[a]["Start_Timestamp"]); prev_end = t0; tot = 0; gaps = 0
