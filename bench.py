@@ -43,7 +43,7 @@ import contextlib
 import json
 import os
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime initialises: see columbiaimagesearch_amd/_lib.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime initialises: see columbiaimagesearch_amd/_lib.py
 import sys
 import threading
 import time

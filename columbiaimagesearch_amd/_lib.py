@@ -16,10 +16,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CIS_LIB_PATH") or os.path.join(_HERE, "lib", "libcis_hip.so")  # override: kernel A/B experiments
 
 # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue do not overlap.  This
-# package runs batches in flight on several streams (index views, CNN views, copy streams, RCCL): ask for 8 queues unless the caller
-# decided otherwise.  Read by the HIP runtime when it initialises, i.e. effective when this module is imported before the first
+# package runs batches in flight on several streams (index views, CNN views, copy streams, RCCL): ask for 16 queues unless the caller
+# decided otherwise (8 were one too few from four search batches in flight on: the two part streams of a dlib forward landed on one
+# queue -- one batch at a time 1.72 -> 2.47 ms, three views in flight 0.61 -> 0.55 of the MFMA peak; 12 and 16 measure alike).  Read by the HIP runtime when it initialises, i.e. effective when this module is imported before the first
 # torch.cuda / HIP call of the process (bench.py sets it first thing; a caller that initialises HIP earlier sets it itself).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
 class cis_hit(ctypes.Structure):
