@@ -1555,7 +1555,7 @@ static int cnn_forward_graph(cis_cnn* c, const float* d_in, int n, float* d_feat
         bool ok = true;
         if (parts > 1) {
             if (!c->ev_in) ok = ok && hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) == hipSuccess;
-            for (int p = 0; p < parts && ok; ++p) {
+            for (int p = 1; p < parts && ok; ++p) {
                 if (!c->ps[p]) ok = ok && hipStreamCreateWithFlags(&c->ps[p], hipStreamNonBlocking) == hipSuccess;
                 if (!c->ev_done[p]) ok = ok && hipEventCreateWithFlags(&c->ev_done[p], hipEventDisableTiming) == hipSuccess;
             }
@@ -1566,13 +1566,14 @@ static int cnn_forward_graph(cis_cnn* c, const float* d_in, int n, float* d_feat
             rc = cnn_forward_dlib(c, &c->ws[0], d_in, n, d_feats, c->gs);
         } else {
             ok = hipEventRecord(c->ev_in, c->gs) == hipSuccess;
-            for (int p = 0; p < parts && ok && rc == CIS_OK; ++p) {
+            for (int p = 1; p < parts && ok && rc == CIS_OK; ++p) {
                 const int lo = (int)((int64_t)n * p / parts), hi = (int)((int64_t)n * (p + 1) / parts);
                 ok = hipStreamWaitEvent(c->ps[p], c->ev_in, 0) == hipSuccess;
                 if (!ok) break;
                 rc = cnn_forward_dlib(c, &c->ws[p], d_in + lo * in_item, hi - lo, d_feats + lo * out_item, c->ps[p]);
                 ok = hipEventRecord(c->ev_done[p], c->ps[p]) == hipSuccess && hipStreamWaitEvent(c->gs, c->ev_done[p], 0) == hipSuccess;
             }
+            if (ok && rc == CIS_OK) rc = cnn_forward_dlib(c, &c->ws[0], d_in, (int)((int64_t)n / parts), d_feats, c->gs);
         }
         hipGraph_t graph = nullptr;
         const hipError_t ee = hipStreamEndCapture(c->gs, &graph);
@@ -1624,10 +1625,13 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
     }
     if (parts <= 1)
         return c->arch == 2 ? cnn_forward_dlib(c, &c->ws[0], d_nchw, n, d_feats, st) : cnn_forward_sentibank(c, &c->ws[0], d_nchw, n, d_feats, st);
-    // (streams are made for the parts in use only: HIP maps a process's streams onto four hardware queues by default, and streams that
-    // share a queue do not overlap -- four idle part streams of a handle were enough to serialise two of three lanes of views)
+    // Part 0 runs on the caller's stream, parts 1.. on the handle's own (made for the parts in use only).  The GPU dispatches from four
+    // hardware pipes and a process's streams are dealt onto them in the order they first submit work (tools/r06_queue_probe.py): two
+    // streams on one pipe do not overlap, and a stream that holds a wait blocks its pipe for the others on it.  With every part on a
+    // stream of the handle and the caller's stream holding the joins, a part that shared the caller's pipe ran after the other part
+    // (2.5 instead of 1.7 ms for 256 dlib chips); now one stream instead of two can collide, and a collision costs the overlap only.
     if (!c->ev_in) CIS_CHECK_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-    for (int p = 0; p < parts; ++p) {
+    for (int p = 1; p < parts; ++p) {
         if (!c->ps[p]) CIS_CHECK_HIP(hipStreamCreateWithFlags(&c->ps[p], hipStreamNonBlocking));
         if (!c->ev_done[p]) CIS_CHECK_HIP(hipEventCreateWithFlags(&c->ev_done[p], hipEventDisableTiming));
     }
@@ -1639,6 +1643,8 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
     // CIS_CNN_THREADS=1: every part is enqueued from its own host thread (a part is ~50 launches: enqueued one part after the other,
     // the last part starts late); default off, measured in profiles/r03y_cnn_parts.txt
     if (threaded) {
+        if (!c->ps[0]) CIS_CHECK_HIP(hipStreamCreateWithFlags(&c->ps[0], hipStreamNonBlocking));
+        if (!c->ev_done[0]) CIS_CHECK_HIP(hipEventCreateWithFlags(&c->ev_done[0], hipEventDisableTiming));
         int rcs[kMaxParts] = {0, 0, 0, 0};
         for (int p = 0; p < parts && herr == hipSuccess; ++p) herr = hipStreamWaitEvent(c->ps[p], c->ev_in, 0);
         if (herr == hipSuccess) {
@@ -1663,17 +1669,25 @@ extern "C" int cis_cnn_forward_dev(cis_cnn* c, const float* d_nchw, int n, float
         CIS_CHECK_HIP(herr);
         return CIS_OK;
     }
-    for (int p = 0; p < parts && rc == CIS_OK && herr == hipSuccess; ++p) {
+    int started = 1;  // parts 1 .. started - 1 were enqueued
+    for (int p = 1; p < parts && rc == CIS_OK && herr == hipSuccess; ++p) {
         const int lo = (int)((int64_t)n * p / parts), hi = (int)((int64_t)n * (p + 1) / parts);
         herr = hipStreamWaitEvent(c->ps[p], c->ev_in, 0);
         if (herr != hipSuccess) break;  // nothing of this part was enqueued
         rc = c->arch == 2 ? cnn_forward_dlib(c, &c->ws[p], d_nchw + lo * in_item, hi - lo, d_feats + lo * out_item, c->ps[p])
                           : cnn_forward_sentibank(c, &c->ws[p], d_nchw + lo * in_item, hi - lo, d_feats + lo * out_item, c->ps[p]);
+        started = p + 1;
+    }
+    if (rc == CIS_OK && herr == hipSuccess) {
+        const int hi = (int)((int64_t)n / parts);
+        rc = c->arch == 2 ? cnn_forward_dlib(c, &c->ws[0], d_nchw, hi, d_feats, st) : cnn_forward_sentibank(c, &c->ws[0], d_nchw, hi, d_feats, st);
+    }
+    for (int p = 1; p < started; ++p) {  // ... and the caller's later work waits for every part
         hipError_t e = hipEventRecord(c->ev_done[p], c->ps[p]);
-        if (e == hipSuccess) e = hipStreamWaitEvent(st, c->ev_done[p], 0);  // ... and the caller's later work waits for every part
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, c->ev_done[p], 0);
         if (e != hipSuccess) {
             (void)hipStreamSynchronize(c->ps[p]);  // the fence could not be placed: drain the part before reporting
-            herr = e;
+            if (herr == hipSuccess) herr = e;
         }
     }
     if (rc != CIS_OK) return rc;
