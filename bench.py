@@ -177,22 +177,16 @@ class Ctx(object):
     pass
 
 
-_LANE_STREAMS = {}
-
-
 def pipe_streams(device, n):
-    """The process's lane streams: made back to back at the first call, each with a first submission right away.  The GPU dispatches from
-    four hardware pipes and HIP deals a process's streams onto them in the order they first submit work (queue number modulo 4:
-    tools/r06_queue_probe.py) -- two streams on one pipe do not overlap.  Streams made one after the other sit on different pipes; streams
-    made leg by leg, after a varying number of others, may not (round 6: four search lanes moved the CNN lanes of a later leg onto
-    shared pipes, dlib three in flight 0.61 -> 0.55 of the MFMA peak).  Every leg with batches in flight takes its streams from here."""
-    pool = _LANE_STREAMS.setdefault(str(device), [])
-    while len(pool) < max(n, 4):
-        s = torch.cuda.Stream(device=device)
-        with torch.cuda.stream(s):
-            torch.zeros(1, device=device)
-        pool.append(s)
-    return pool[:n]
+    """The process's lane streams (columbiaimagesearch_amd/streams.py): made back to back at the first call, each with a first submission
+    right away.  The GPU dispatches from four hardware pipes and HIP deals a process's streams onto them in the order they first submit
+    work (queue number modulo 4: tools/r06_queue_probe.py) -- two streams on one pipe do not overlap.  Streams made one after the other sit
+    on different pipes; streams made leg by leg, after a varying number of others, may not (round 6: four search lanes moved the CNN
+    lanes of a later leg onto shared pipes, dlib three in flight 0.61 -> 0.55 of the MFMA peak).  Every leg with batches in flight takes
+    its streams from here."""
+    from columbiaimagesearch_amd.streams import lane_streams
+    lane_streams(4, device)
+    return lane_streams(n, device)
 
 
 def pmc_source(path, d):

@@ -263,6 +263,29 @@ def test_dlib_fused_tail_agrees_with_the_six_launches_it_replaces(monkeypatch):
     net.close()
 
 
+def test_lane_streams_are_made_once_and_reused():
+    """columbiaimagesearch_amd.streams.lane_streams: the same stream objects on every call (the pool grows, it is never remade), distinct
+    streams, none of them the default stream; a forward on each of them gives the descriptors of the default stream."""
+    import torch
+    from oracle import dlib_oracle as D
+    from columbiaimagesearch_amd.featurizer import DLibFaceNet
+    from columbiaimagesearch_amd.streams import lane_streams
+    a = lane_streams(3)
+    b = lane_streams(5)
+    assert [x.cuda_stream for x in a] == [x.cuda_stream for x in b[:3]]
+    assert len({x.cuda_stream for x in b}) == 5 and torch.cuda.default_stream().cuda_stream not in {x.cuda_stream for x in b}
+    net = DLibFaceNet(D.synthetic_weights(2))
+    x = torch.as_tensor(D.synthetic_chips(160, seed=3)).cuda().float().contiguous()
+    want = net.forward_dev(x).cpu().numpy()
+    torch.cuda.synchronize()
+    for s in lane_streams(4):
+        with torch.cuda.stream(s):
+            got = net.forward_dev(x)
+        s.synchronize()
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    net.close()
+
+
 def test_dlib_forward_as_a_captured_graph_equals_the_launches(monkeypatch):
     """CIS_CNN_GRAPH=1: the forward of (input, n, output) is captured on its second call and replayed as one hipGraphLaunch from the
     third on -- the descriptors of every call equal the launches', bit for bit; new contents at the same addresses are seen (a graph
