@@ -104,7 +104,9 @@ class BatchIngest(object):
         if getattr(self, "_lanes", None) is None or len(self._lanes) != lanes:
             for h, _ in (getattr(self, "_lanes", None) or [])[1:]:
                 h.close()
-            self._lanes = [(self.net, torch.cuda.Stream())] + [(self.net.view(), torch.cuda.Stream()) for _ in range(lanes - 1)]
+            from .streams import lane_streams   # streams on different hardware pipes, made once per process (streams.py)
+            ls = lane_streams(lanes)
+            self._lanes = [(self.net, ls[0])] + [(self.net.view(), ls[i]) for i in range(1, lanes)]
         ids_it = iter(ids) if ids is not None else None
         out, queue = [], deque()
 
