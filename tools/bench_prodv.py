@@ -70,19 +70,21 @@ for quota, limit in (((10000, 100),) if FAST else ((1000, 100), (10000, 100))):
     s.set_profiling(False)
     # three batches in flight through views of the index (what bench.py does at V = 16): the serial front end of one batch under
     # the ranking kernels of another
-    lanes = [(s, torch.cuda.current_stream())] + [(s.view(), torch.cuda.Stream()) for _ in range(2)]
+    from columbiaimagesearch_amd.streams import lane_streams
+    NL = int(os.environ.get("PRODV_LANES", "3"))
+    lanes = [(s, torch.cuda.current_stream())] + [(s.view(), ls) for ls in lane_streams(NL - 1)]
     for sv, stq in lanes:
         with torch.cuda.stream(stq):
             sv.search_batch_dev(q, quota=quota, limit=limit)
     torch.cuda.synchronize()
-    t = time.perf_counter(); reps = 9
+    t = time.perf_counter(); reps = 3 * NL
     for i in range(reps):
-        sv, stq = lanes[i % 3]
+        sv, stq = lanes[i % NL]
         with torch.cuda.stream(stq):
             sv.search_batch_dev(q, quota=quota, limit=limit)
     torch.cuda.synchronize()
     dtp = (time.perf_counter() - t) / reps
-    print("    three batches in flight: %.2f ms per %d queries = %.0f queries/s" % (dtp * 1e3, NQ, NQ / dtp))
+    print("    %s batches in flight: %.2f ms per %d queries = %.0f queries/s" % ({2: "two", 3: "three", 4: "four"}.get(NL, str(NL)), dtp * 1e3, NQ, NQ / dtp))
     for sv, _ in lanes[1:]:
         sv.close()
 if FAST:
