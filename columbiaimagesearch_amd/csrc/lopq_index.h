@@ -89,6 +89,7 @@ struct cis_index {
     hipStream_t h_stream = nullptr; // the host-pointer entry points' own stream (cis_index_search[_async])
     hipEvent_t h_ev_in = nullptr, h_ev_out = nullptr, h_ev_done = nullptr;  // copy-in landed / search done / copy-out landed
     bool h_pending = false;         // a batch of cis_index_search_async is in flight on it
+    bool h_out_enqueued = false;    // ... and its copy-out is on the copy stream already (cis_host_pump_locked: lopq_search.hip)
     struct HostOut { int64_t* ids; double* dists; int32_t* n_found; int32_t* visited; int32_t* cells; uint32_t* pos; int nq, L; };
     HostOut h_out = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};  // where its results go (copied out by cis_index_search_wait)
     bool force_scan5 = false;       // scan mode 7 (tests): k_adc_scan5 (one threshold per query, eight queries per slot) whatever the batch size
@@ -117,3 +118,6 @@ struct cis_index {
 
 // Makes the device arrays exist (empty index: offsets all zero) -- called at the head of every search.
 int cis_index_ready(cis_index* ix);
+
+// lopq_search.hip: a handle that is being destroyed leaves the list of handles whose copy-out is still to be enqueued
+void cis_host_forget(cis_index* ix);

@@ -777,6 +777,7 @@ extern "C" void cis_index_destroy(cis_index* ix) {
     // later search through them is refused (no dangling pointer is ever followed)
     for (cis_index* v : ix->views) { v->base = nullptr; v->orphaned = true; }
     ix->views.clear();
+    cis_host_forget(ix);
     if (ix->h_stream) {
         if (ix->h_pending && ix->h_ev_done) (void)hipEventSynchronize(ix->h_ev_done);
         (void)hipStreamSynchronize(ix->h_stream);

@@ -6217,6 +6217,51 @@ static int cis_copy_stream(int device, hipStream_t* out) {
     return CIS_OK;
 }
 
+// Copy-outs ahead of their wait (round 6).  cis_index_search_wait used to enqueue its handle's copy-out and block for it: 13 MB of
+// results of a C4 batch are 0.25 ms during which the calling thread launched nothing -- with the plan read-back of the next launch that
+// made the host the bottleneck of the host-facing path (0.57 ms per step against 0.375 ms resident).  Now every call that holds the copy
+// stream's lock looks at the OTHER handles with a search in flight: where the search has finished (hipEventQuery) the copy-out goes onto
+// the copy stream there and then, and runs while the caller launches its own batch; the owner's wait finds it under way or landed.
+static std::vector<cis_index*> g_host_pending;  // guarded by g_copy_mu: search enqueued, copy-out not yet
+
+static hipError_t host_copy_out_locked(cis_index* ix, hipStream_t cp) {
+    const cis_index::HostOut& o = ix->h_out;
+    const int nq = o.nq, L = o.L;
+    hipError_t e = hipSuccess;
+    auto cpy = [&](void* dst, const void* src, size_t bytes) { if (e == hipSuccess && dst) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cp); };
+    if (nq > 0) {
+        if (L > 0) {
+            cpy(o.ids, ix->w_oids.p, (size_t)nq * L * sizeof(int64_t));
+            cpy(o.dists, ix->w_odists.p, (size_t)nq * L * sizeof(double));
+            cpy(o.cells, ix->w_ocell.p, (size_t)nq * L * sizeof(int32_t));
+            cpy(o.pos, ix->w_opos.p, (size_t)nq * L * sizeof(uint32_t));
+        }
+        cpy(o.n_found, ix->w_onf.p, (size_t)nq * sizeof(int32_t));
+        cpy(o.visited, ix->w_ovis.p, (size_t)nq * sizeof(int32_t));
+    }
+    if (e == hipSuccess) e = hipEventRecord(ix->h_ev_done, cp);
+    if (e == hipSuccess) ix->h_out_enqueued = true;
+    return e;
+}
+
+static void host_pump_locked(int device, hipStream_t cp, const cis_index* self) {
+    for (size_t i = 0; i < g_host_pending.size();) {
+        cis_index* o = g_host_pending[i];
+        if (o != self && o->m->device == device && hipEventQuery(o->h_ev_out) == hipSuccess && host_copy_out_locked(o, cp) == hipSuccess) {
+            g_host_pending[i] = g_host_pending.back();
+            g_host_pending.pop_back();
+        } else {
+            ++i;
+        }
+    }
+    (void)hipGetLastError();  // (hipEventQuery's hipErrorNotReady is not an error of this call)
+}
+
+void cis_host_forget(cis_index* ix) {
+    std::lock_guard<std::mutex> lk(g_copy_mu);
+    g_host_pending.erase(std::remove(g_host_pending.begin(), g_host_pending.end(), ix), g_host_pending.end());
+}
+
 extern "C" int cis_host_alloc(void** out, size_t bytes) {
     CIS_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
@@ -6247,6 +6292,11 @@ extern "C" int cis_index_search_async(cis_index* ix, const void* Q, int q_dtype,
     CIS_REQUIRE(Q && n_found && visited && (L == 0 || (ids && dists)), "NULL buffer");
     CIS_TRY(cis_lazy_init());
     CIS_CHECK_HIP(hipSetDevice(ix->m->device));
+    // (the copy stream is made before the first handle's stream: the GPU dispatches from four hardware pipes, streams are dealt onto them
+    // in the order they first submit work, and two compute streams on one pipe do not overlap -- with the copy stream first, the fourth
+    // handle's stream shares a pipe with it and not with the first handle's: tools/r06_queue_probe.py)
+    hipStream_t cp = nullptr;
+    CIS_TRY(cis_copy_stream(ix->m->device, &cp));
     if (!ix->h_stream) {
         CIS_CHECK_HIP(hipStreamCreateWithFlags(&ix->h_stream, hipStreamNonBlocking));
         CIS_CHECK_HIP(hipEventCreateWithFlags(&ix->h_ev_in, hipEventDisableTiming));
@@ -6257,8 +6307,6 @@ extern "C" int cis_index_search_async(cis_index* ix, const void* Q, int q_dtype,
     // Every copy of every handle goes through ONE copy stream per device: a copy-in and a copy-out that run at the same time collapse
     // on this platform (measured with pinned memory: 52-56 GB/s in either direction alone, 11 GB/s combined when both run --
     // profiles/archive/r05b/r05_pcie_probe.txt), so the copies are serialised among themselves and overlap only the searches.
-    hipStream_t cp = nullptr;
-    CIS_TRY(cis_copy_stream(ix->m->device, &cp));
     if (ix->h_pending) CIS_TRY(cis_index_search_wait(ix));  // one batch in flight per handle: its buffers are this handle's workspaces
     const size_t qbytes = (size_t)nq * ix->m->D_in * q_dtype;
     const int Lk = L > 0 ? L : 1;
@@ -6273,6 +6321,9 @@ extern "C" int cis_index_search_async(cis_index* ix, const void* Q, int q_dtype,
         std::lock_guard<std::mutex> lk(g_copy_mu);  // (enqueue order on the shared stream: a handle's copy and its event stay adjacent)
         CIS_CHECK_HIP(hipMemcpyAsync(ix->w_q.p, Q, qbytes, hipMemcpyHostToDevice, cp));
         CIS_CHECK_HIP(hipEventRecord(ix->h_ev_in, cp));
+        // finished searches of the other handles: their results leave BEHIND this copy-in (4 MB against 13 MB: the launch below blocks
+        // on this batch's plan read-back, which waits for the copy-in)
+        host_pump_locked(ix->m->device, cp, ix);
     }
     // h_pending is set LAST, with this batch's h_out in place: an error exit in between must not leave the flag set over the previous
     // call's h_out (whose host buffers may be gone) -- cis_index_search_wait / cis_index_destroy would copy results into them.  Every
@@ -6290,8 +6341,15 @@ extern "C" int cis_index_search_async(cis_index* ix, const void* Q, int q_dtype,
     // the copy-out is enqueued by cis_index_search_wait, once the search has finished: enqueued here it would sit at the head of the
     // shared copy stream, waiting for the search, with every later copy-in of the other handles stuck behind it
     ix->h_out = {ids, dists, n_found, visited, cells, pos, nq, L};
+    ix->h_out_enqueued = false;
     ix->h_pending = true;
     guard.armed = false;
+    {
+        // (no copy-outs from here: one enqueued now would be in the next call's copy-in's way -- that call's launch blocks on its plan
+        // read-back, the read-back waits for the copy-in, and the copy stream is first in, first out)
+        std::lock_guard<std::mutex> lk(g_copy_mu);
+        g_host_pending.push_back(ix);
+    }
     return CIS_OK;
 }
 
@@ -6300,26 +6358,23 @@ extern "C" int cis_index_search_wait(cis_index* ix) {
     if (ix->h_stream && ix->h_pending) {
         CIS_CHECK_HIP(hipSetDevice(ix->m->device));
         ix->h_pending = false;
-        CIS_CHECK_HIP(hipEventSynchronize(ix->h_ev_out));
-        const cis_index::HostOut& o = ix->h_out;
-        if (o.nq > 0) {
-            hipStream_t cp = nullptr;
-            CIS_TRY(cis_copy_stream(ix->m->device, &cp));
-            {
-                std::lock_guard<std::mutex> lk(g_copy_mu);
-                const int nq = o.nq, L = o.L;
-                if (L > 0) {
-                    CIS_CHECK_HIP(hipMemcpyAsync(o.ids, ix->w_oids.p, (size_t)nq * L * sizeof(int64_t), hipMemcpyDeviceToHost, cp));
-                    CIS_CHECK_HIP(hipMemcpyAsync(o.dists, ix->w_odists.p, (size_t)nq * L * sizeof(double), hipMemcpyDeviceToHost, cp));
-                    if (o.cells) CIS_CHECK_HIP(hipMemcpyAsync(o.cells, ix->w_ocell.p, (size_t)nq * L * sizeof(int32_t), hipMemcpyDeviceToHost, cp));
-                    if (o.pos) CIS_CHECK_HIP(hipMemcpyAsync(o.pos, ix->w_opos.p, (size_t)nq * L * sizeof(uint32_t), hipMemcpyDeviceToHost, cp));
-                }
-                CIS_CHECK_HIP(hipMemcpyAsync(o.n_found, ix->w_onf.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, cp));
-                CIS_CHECK_HIP(hipMemcpyAsync(o.visited, ix->w_ovis.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, cp));
-                CIS_CHECK_HIP(hipEventRecord(ix->h_ev_done, cp));
-            }
-            CIS_CHECK_HIP(hipEventSynchronize(ix->h_ev_done));
+        hipStream_t cp = nullptr;
+        CIS_TRY(cis_copy_stream(ix->m->device, &cp));
+        bool enq;
+        {
+            std::lock_guard<std::mutex> lk(g_copy_mu);
+            enq = ix->h_out_enqueued;   // another handle's call may have put this handle's copy-out on the copy stream already
         }
+        if (!enq) {
+            CIS_CHECK_HIP(hipEventSynchronize(ix->h_ev_out));
+            std::lock_guard<std::mutex> lk(g_copy_mu);
+            if (!ix->h_out_enqueued) {
+                g_host_pending.erase(std::remove(g_host_pending.begin(), g_host_pending.end(), ix), g_host_pending.end());
+                CIS_CHECK_HIP(host_copy_out_locked(ix, cp));
+            }
+            host_pump_locked(ix->m->device, cp, ix);
+        }
+        CIS_CHECK_HIP(hipEventSynchronize(ix->h_ev_done));
     }
     return CIS_OK;
 }

@@ -58,6 +58,55 @@ def test_async_search_on_pinned_buffers_equals_the_blocking_call():
     gc.collect()
 
 
+def test_copy_outs_started_by_other_handles_calls_land_in_the_right_buffers():
+    """cis_index_search_async of one handle puts the finished searches' results of the OTHER handles on the copy stream (round 6: the
+    copy-out no longer waits for its owner's cis_index_search_wait).  Three handles in rotation, wait-then-launch as bench.py's host
+    leg does, different queries and quotas per step, a pause that lets every search finish before the next launch (so that launch does
+    start the others' copy-outs): every result equals the blocking call's; a view closed with a batch in flight and never waited for
+    leaves the others working."""
+    import time
+    from test_lopq_hip_parity import hip_model
+    from columbiaimagesearch_amd import _lib
+    from columbiaimagesearch_amd.lopq import LOPQSearcherHIP
+    z, X, Q = load_golden("c2")
+    m = hip_model(z)
+    s = LOPQSearcherHIP(m)
+    s.add_codes_array(z["coarse"], z["fine"])
+    nq = 16
+    lanes = [s, s.view(), s.view()]
+    steps = [(b, (b * 7) % (len(Q) - nq), (500, 1000, 3000)[b % 3]) for b in range(12)]
+    want = {b: s.search_batch(Q[o:o + nq], quota=quota, limit=40) for b, o, quota in steps}
+    qpin = [_lib.pinned_empty((nq, Q.shape[1]), Q.dtype) for _ in lanes]
+    flying = [None] * len(lanes)
+
+    def check(lane):
+        r = lanes[lane].search_wait()
+        b = flying[lane]
+        if b is None:
+            assert r is None
+            return
+        for k in ("ids", "n_found", "visited"):
+            assert (r[k] == want[b][k]).all(), (b, k)
+        assert np.array_equal(np.nan_to_num(r["dists"]), np.nan_to_num(want[b]["dists"]))
+        flying[lane] = None
+
+    for b, o, quota in steps:
+        lane = b % len(lanes)
+        check(lane)
+        if b % 4 == 3:
+            time.sleep(0.05)   # every search in flight has finished: the next launch starts their copy-outs
+        qpin[lane][...] = Q[o:o + nq]
+        lanes[lane].search_batch_async(qpin[lane], quota=quota, limit=40)
+        flying[lane] = b
+    check(1)
+    lanes[2].close()       # a batch in flight, never waited for
+    check(0)
+    r = s.search_batch(Q[:nq], quota=1000, limit=40)
+    assert (r["ids"] == s.search_batch(Q[:nq], quota=1000, limit=40)["ids"]).all()
+    lanes[1].close()
+    s.close()
+
+
 def test_limit_equals_quota_ranks_through_the_own_segmented_sort():
     """limit = None => limit = quota (lopq/lopq/search.py:213-214): with quota = 10000 every one of ~10 k retrieved candidates is returned,
     ranked by the stable sort of :210.  Above 3072 results per query the ranking is the library's own segmented merge sort
