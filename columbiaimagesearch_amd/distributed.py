@@ -332,9 +332,11 @@ class ShardedSearcher(object):
         on its own stream, so that the small kernels of one batch's front end overlap another batch's scan."""
         import torch
         if getattr(self, "_lanes", None) is None:
+            from .streams import lane_streams   # (streams on different hardware pipes, made once per process: streams.py)
+            depth = max(1, int(self.pipeline_depth))
             self._lanes = [(self.local, None)]
-            for _ in range(max(1, int(self.pipeline_depth)) - 1):
-                self._lanes.append((self.local.view(), torch.cuda.Stream()))
+            for ls in lane_streams(depth - 1):
+                self._lanes.append((self.local.view(), ls))
             self._turn = 0
         return self._lanes
 
@@ -370,7 +372,8 @@ class ShardedSearcher(object):
         read at all -- the caller verifies `overflowed(outs)` once after its loop."""
         import torch
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            from .streams import lane_streams   # the lane after the search lanes': another pipe than theirs while there are four or fewer
+            self._side = lane_streams(max(1, int(self.pipeline_depth)))[-1]
         cur = torch.cuda.current_stream()
         p = h["p"]
         with torch.cuda.stream(self._side):
