@@ -1129,7 +1129,7 @@ def cnn_legs(ctx):
                 "frac": flop / dt / (F32_MFMA_PEAK_TFLOPS * 1e12), "flop_per_image": 2 * mac}
 
     with ctx.wd.phase("CNN legs (replicas, barrier + all-reduce of the time)", 600):
-        LANES = 3  # batches in flight (like the search legs): consecutive forwards are in different layers and fill each other's rounds
+        LANES = 4  # batches in flight, one per hardware pipe (like the search legs): consecutive forwards are in different layers and fill each other's rounds (three: dlib 0.608, four: 0.620)
         net = SentiBankNet(sentibank_weights(0))
         xb = (torch.randn((B, 3, 227, 227), generator=gcn, device=device) * 50.0).contiguous()
         dt1, _ = time_net(net, xb, torch.empty((B, 4096), device=device))
